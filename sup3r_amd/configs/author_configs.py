@@ -1,0 +1,118 @@
+"""Authors the sup3r-spec JSON files shipped in this directory.
+
+These are written in the reference's own ``hidden_layers`` spec language
+(sup3r/configs/**) so they parse with phygnn unchanged; they are generated
+here, not copied:
+
+* ``gen_5x_12x_2f.json`` — BASELINE.json config C2.  The reference ships no
+  5x/12x generator; this follows the topology of
+  ``spatiotemporal/gen_2x_12x_14f.json`` (temporal head 2*2*3, 16 residual
+  blocks x 64 ch) with the expansion conv at 8*5^2 = 200 filters,
+  ``spatial_mult`` 5 and 2 output features.
+* ``disc_st.json`` / ``disc_s.json`` — the 8-conv + dense patch discriminator
+  topology (valid padding, production) and ``*_same`` variants (the padding the
+  reference's own tests use so that tiny samples survive 4 stride-2 convs).
+* ``test_*.json`` — small-channel nets of the same archetypes for fast parity.
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def pcc(nd, filters, act=True, pad=3, crop=2, conv=None, **kw):
+    """REFLECT pad -> conv(k=3, valid) -> crop [-> LeakyReLU 0.2]."""
+    cls = conv or f'Conv{nd}D'
+    pads = [[0, 0]] + [[pad, pad]] * nd + [[0, 0]]
+    conv_spec = {'class': cls, 'filters': filters, 'kernel_size': 3,
+                 'strides': 1}
+    conv_spec.update(kw)
+    out = [{'class': 'FlexiblePadding', 'paddings': pads, 'mode': 'REFLECT'},
+           conv_spec, {'class': f'Cropping{nd}D', 'cropping': crop}]
+    if act:
+        out.append({'alpha': 0.2, 'class': 'LeakyReLU'})
+    return out
+
+
+def st_gen(s, tmults, nf_out, body=16, ch=64, exo=None):
+    hl = []
+    if len(tmults) > 1:
+        assert len(set(tmults[:-1])) == 1
+        hl.append({'n': len(tmults) - 1, 'repeat': pcc(3, ch) + [
+            {'class': 'SpatioTemporalExpansion', 'temporal_mult': tmults[0],
+             'temporal_method': 'nearest'}]})
+    hl += pcc(3, ch) + [{'class': 'SpatioTemporalExpansion',
+                         'temporal_mult': tmults[-1],
+                         'temporal_method': 'nearest'}]
+    hl.append({'class': 'SkipConnection', 'name': 'a'})
+    hl.append({'n': body, 'repeat': (
+        [{'class': 'SkipConnection', 'name': 'b'}] + pcc(3, ch)
+        + pcc(3, ch, act=False) + [{'class': 'SkipConnection', 'name': 'b'}])})
+    hl += pcc(3, ch, act=False) + [{'class': 'SkipConnection', 'name': 'a'}]
+    hl += pcc(3, 8 * s * s, act=False) + [
+        {'class': 'SpatioTemporalExpansion', 'spatial_mult': s},
+        {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    if exo:
+        hl.append({'class': exo[0], 'name': exo[1]})
+    hl += pcc(3, nf_out, act=False)
+    return {'hidden_layers': hl}
+
+
+def s_gen(s, nf_out, body=16, ch=64):
+    """Spatial generator of the Conv2DTranspose archetype (pad 3 / crop 4)."""
+    def blk(f, act):
+        return pcc(2, f, act=False, crop=4, conv='Conv2DTranspose',
+                   activation=act)
+    hl = blk(ch, 'relu') + [{'class': 'SkipConnection', 'name': 'a'}]
+    hl.append({'n': body, 'repeat': (
+        [{'class': 'SkipConnection', 'name': 'b'}] + blk(ch, 'relu')
+        + blk(ch, None) + [{'class': 'SkipConnection', 'name': 'b'}])})
+    hl += blk(ch, None) + [{'class': 'SkipConnection', 'name': 'a'}]
+    hl += blk(ch * s * s, None) + [
+        {'class': 'SpatialExpansion', 'spatial_mult': s},
+        {'class': 'Activation', 'activation': 'relu'}]
+    hl += blk(nf_out, None)
+    return {'hidden_layers': hl}
+
+
+def disc(nd, padding, dense=(2048, 1024), widths=(32, 64, 128, 256)):
+    hl = []
+    for w in widths:
+        for stride in (1, 2):
+            hl += [{'class': f'Conv{nd}D', 'filters': w, 'kernel_size': 3,
+                    'padding': padding, 'strides': stride},
+                   {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    hl.append({'class': 'Flatten'})
+    for u in dense:
+        hl += [{'class': 'Dense', 'units': u},
+               {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    hl.append({'class': 'Dense', 'units': 1})
+    return {'hidden_layers': hl}
+
+
+def main():
+    files = {
+        'gen_5x_12x_2f.json': st_gen(5, [2, 2, 3], 2),
+        'disc_st.json': disc(3, 'valid'),
+        'disc_s.json': disc(2, 'valid', dense=(1024,)),
+        'disc_st_same.json': disc(3, 'same'),
+        'disc_s_same.json': disc(2, 'same', dense=(1024,)),
+        'test_gen_st_2x_4x_2f.json': st_gen(2, [2, 2], 2, body=2, ch=16),
+        'test_gen_st_3x_4x_2f_topo.json': st_gen(
+            3, [2, 2], 2, body=1, ch=8, exo=('Sup3rConcat', 'topography')),
+        'test_gen_st_64ch.json': st_gen(2, [2], 2, body=1, ch=64),
+        'test_gen_s_2x_2f.json': s_gen(2, 2, body=2, ch=16),
+        'test_disc_st_same.json': disc(3, 'same', dense=(64, 32),
+                                       widths=(8, 8, 16, 16)),
+        'test_disc_s_same.json': disc(2, 'same', dense=(32,),
+                                      widths=(8, 8, 16, 16)),
+        'test_disc_st_valid.json': disc(3, 'valid', dense=(32,),
+                                        widths=(8, 16)),
+    }
+    for name, spec in files.items():
+        with open(os.path.join(HERE, name), 'w') as f:
+            json.dump(spec, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
