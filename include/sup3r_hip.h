@@ -1,0 +1,192 @@
+/* sup3r_hip.h — C-ABI of libsup3r_hip.so, the MI355X (gfx950) compute core
+ * for NREL/sup3r's Sup3rGan hot path.
+ *
+ * The reference has NO native/FFI seam: its hot path is a Python loop over
+ * keras layer objects inside TensorFlow.  This header defines the boundary a
+ * sup3r maintainer binds with ctypes.  Each entry point names
+ * the reference interface it replaces (paths relative to the sup3r repo).
+ *
+ * Conventions
+ *  - plain C: opaque handles, raw device/host pointers, sizes; no torch types.
+ *  - every call returns 0 on success or a negative S3_E* code; the message is
+ *    retrievable with s3_last_error().  No exceptions cross the ABI.
+ *  - tensors are channels-last fp32, always described 5-D (N, s1, s2, t, C);
+ *    4-D (spatial) nets use t = 1.  Device pointers are caller-owned unless
+ *    stated otherwise; all work is enqueued on the context's HIP stream.
+ *  - a context is used by one host thread at a time (one process per GPU).
+ */
+#ifndef SUP3R_HIP_H
+#define SUP3R_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3_OK 0
+#define S3_EINVAL (-1)   /* bad argument / unsupported op description */
+#define S3_EHIP (-2)     /* HIP runtime error */
+#define S3_ENOMEM (-3)
+#define S3_ERCCL (-4)
+#define S3_ESTATE (-5)   /* call sequence error (e.g. backward w/o forward) */
+
+/* op kinds of the fused plan (sup3r_amd/spec.py lowers the reference's
+ * hidden_layers JSON — sup3r/configs/<family>/<model>.json — to these) */
+enum {
+  S3_OP_CONV = 1,     /* [virtual pad] + conv + bias + act + residual + d2s  */
+  S3_OP_REPEAT_T = 2, /* SpatioTemporalExpansion temporal nearest            */
+  S3_OP_D2S = 3,      /* depth_to_space (DCR) on (s1, s2)                    */
+  S3_OP_ACT = 4,
+  S3_OP_ADD = 5,      /* SkipConnection end / Sup3rAdder                     */
+  S3_OP_CONCAT = 6,   /* Sup3rConcat                                         */
+  S3_OP_DENSE = 7,
+  S3_OP_PAD = 8,      /* FlexiblePadding not consumed by a conv              */
+  S3_OP_CROP = 9,
+  S3_OP_VIEW = 10,    /* Flatten / depth_to_time reshape (alias, no copy)    */
+  S3_OP_ROLL_T = 11   /* tf.roll along t (depth_to_time t_roll)              */
+};
+enum { S3_ACT_NONE = 0, S3_ACT_RELU = 1, S3_ACT_LEAKY = 2 };
+enum { S3_PAD_ZERO = 0, S3_PAD_REFLECT = 1 };
+/* arithmetic mode of the MFMA convolution kernels */
+enum {
+  S3_PREC_F32 = 0,   /* v_mfma_f32_16x16x4_f32: exact fp32 (parity mode)     */
+  S3_PREC_BF16 = 1,  /* v_mfma_f32_16x16x32_bf16, fp32 accumulate            */
+  S3_PREC_BF16X3 = 2 /* 3-term bf16 split (hi*hi + hi*lo + lo*hi), ~fp32     */
+};
+enum { S3_LOSS_MAE = 0, S3_LOSS_MSE = 1 };
+enum { S3_BUF_W = 0, S3_BUF_G = 1, S3_BUF_M = 2, S3_BUF_V = 3 };
+
+typedef struct s3_ctx s3_ctx;
+typedef struct s3_params s3_params;
+typedef struct s3_plan s3_plan;
+
+typedef struct {
+  int64_t dims[5]; /* N, s1, s2, t, C */
+} s3_tensor_desc;
+
+typedef struct {
+  int32_t kind;
+  int32_t in0, in1, res, out; /* tensor ids, -1 = none                      */
+  int32_t w, b;               /* parameter ids, -1 = none                   */
+  int32_t k[3], stride[3], lo[3], hi[3]; /* conv / pad / crop geometry      */
+  int32_t pad_mode;
+  int32_t act;
+  float alpha;
+  int32_t d2s; /* depth-to-space block fused at the conv store (1 = none)  */
+  int32_t rep; /* REPEAT_T factor / ROLL_T shift                           */
+  int32_t bcast_c; /* ADD: in1 has one channel, broadcast over C           */
+  int32_t reserved[4];
+} s3_op_desc;
+
+/* ---- context ----------------------------------------------------------
+ * replaces: tf.device(default_device) placement in
+ * sup3r/models/abstract.py:41-42,1230 and base.py:104-106.
+ * stream: a hipStream_t the caller already owns (e.g.
+ * torch.cuda.current_stream().cuda_stream) or NULL to create one. */
+int s3_ctx_create(int device_id, void* stream, s3_ctx** out);
+void s3_ctx_destroy(s3_ctx* ctx);
+const char* s3_last_error(const s3_ctx* ctx);
+int s3_ctx_sync(s3_ctx* ctx);
+void* s3_ctx_stream(s3_ctx* ctx);
+
+/* ---- parameter store ---------------------------------------------------
+ * replaces: phygnn.CustomNetwork.weights (list of tf.Variable: kernel, bias
+ * per layer in layer order — sup3r/models/abstract.py:312-319,
+ * base.py:226-235,388-392), the gradient list of tape.gradient
+ * (abstract.py:1237) and the keras Adam slot variables
+ * (abstract.py:566-587).  One store per network; four flat fp32 device
+ * buffers (weights, grads, Adam m, Adam v) so that the optimizer step and the
+ * gradient all-reduce are ONE launch / ONE collective.
+ * Kernels are stored in canonical [taps..., C_in, C_out] layout (== keras
+ * Conv layout; Conv2DTranspose is flipped/transposed by the host shim). */
+int s3_params_create(s3_ctx* ctx, int n, const int64_t* sizes, s3_params** out);
+void s3_params_destroy(s3_params* p);
+int64_t s3_params_total(const s3_params* p);
+int s3_params_set(s3_params* p, int which, int idx, const float* host);
+int s3_params_get(s3_params* p, int which, int idx, float* host);
+void* s3_params_dptr(s3_params* p, int which, int idx);
+int s3_params_zero_grad(s3_params* p);
+/* mean(|x|) of one Adam slot / weight tensor (history columns
+ * OptmGen/Adam/m/..., abstract.py:582-586) */
+int s3_params_mean_abs(s3_params* p, int which, int idx, float* host_out);
+
+/* keras-2.15 Adam.update_step on the whole store (abstract.py:899,912):
+ * alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)(1-b1); v += (g*g-v)(1-b2);
+ * w -= m*alpha/(sqrt(v)+eps).  t is the 1-based step count. */
+int s3_adam_step(s3_params* p, float lr, float beta1, float beta2, float eps,
+                 int64_t t);
+
+/* ---- plan (shape-specialised executor) ---------------------------------
+ * replaces: the eager/graph layer loops AbstractSingleModel._tf_generate
+ * (abstract.py:1131-1173) and Sup3rGan._tf_discriminate (base.py:283-313).
+ * inputs[]: tensor ids fed by the caller at forward time (low_res first, then
+ * hi-res exo tensors in Sup3rConcat/Sup3rAdder layer order).
+ * training != 0 keeps every activation for s3_plan_backward. */
+int s3_plan_create(s3_ctx* ctx, s3_params* params, const s3_tensor_desc* tensors,
+                   int n_tensors, const s3_op_desc* ops, int n_ops,
+                   const int32_t* inputs, int n_inputs, int32_t output,
+                   int precision, int training, s3_plan** out);
+void s3_plan_destroy(s3_plan* plan);
+/* inputs: device pointers (fp32, NDHWC) in the order given at creation;
+ * output: device pointer receiving the result, or NULL to leave it in the
+ * plan's own buffer (s3_plan_tensor). */
+int s3_plan_forward(s3_plan* plan, const void* const* inputs, void* output);
+/* reverse-mode pass of the last forward (tf.GradientTape().gradient,
+ * abstract.py:1230-1237).  d_output: dL/d(output); d_input: nullable, receives
+ * dL/d(inputs[0]).  accumulate_wgrad != 0 adds into the grad buffer (the
+ * discriminator sees true and generated batches).  need_wgrad == 0 skips
+ * weight gradients (generator step: only dgrad flows through the disc). */
+int s3_plan_backward(s3_plan* plan, const void* d_output, void* d_input,
+                     int need_wgrad, int accumulate_wgrad);
+void* s3_plan_tensor(s3_plan* plan, int32_t tensor_id);
+int64_t s3_plan_workspace_bytes(const s3_plan* plan);
+/* per-op timing of the last forward, ms (HIP events on the ctx stream); used by
+ * bench.py for the roofline object.  Returns number of ops written. */
+int s3_plan_profile_forward(s3_plan* plan, const void* const* inputs,
+                            float* ms_per_op, int cap);
+
+/* ---- losses ------------------------------------------------------------
+ * content loss: keras MeanAbsoluteError / MeanSquaredError as used by
+ * Sup3rGan.calc_loss_gen_content (base.py:478-503): mean over the first
+ * c_used channels of a (c_a channels, generated) vs b (c_b channels, truth
+ * incl. trailing exo channels).  loss_out: device float (accumulated with
+ * weight); d_a (nullable): d(weight*loss)/da written (accumulate != 0: added). */
+int s3_loss_content(s3_ctx* ctx, int kind, const float* a, int c_a,
+                    const float* b, int c_b, int c_used, int64_t n_pos,
+                    float weight, float* loss_out, float* d_a, int accumulate);
+/* relativistic BCE of Sup3rGan.calc_loss_disc (base.py:505-549).
+ * loss_out: device float; d_true / d_gen nullable (n floats each), scaled by
+ * `scale` (weight_gen_advers for the adversarial term). */
+int s3_loss_rel_bce(s3_ctx* ctx, const float* disc_true, const float* disc_gen,
+                    int n, float scale, float* loss_out, float* d_true,
+                    float* d_gen);
+
+/* ---- small tensor utilities on the ctx stream --------------------------
+ * channel slice/concat used by _combine_loss_input / get_hr_exo_input
+ * (abstract.py:415-459) and per-feature affine of norm_input /
+ * un_norm_output (abstract.py:197-275). */
+int s3_copy_channels(s3_ctx* ctx, const float* src, int c_src, int c0_src,
+                     float* dst, int c_dst, int c0_dst, int nc, int64_t n_pos,
+                     int accumulate);
+int s3_affine_channels(s3_ctx* ctx, const float* src, float* dst, int c,
+                       int64_t n_pos, const float* scale_host,
+                       const float* shift_host);
+int s3_fill(s3_ctx* ctx, float* dst, int64_t n, float value);
+
+/* ---- data-parallel gradient sync (RCCL over xGMI) -----------------------
+ * replaces: the host-side python sum of per-GPU gradient lists,
+ * AbstractSingleModel._sum_parallel_grad (abstract.py:785-805): elementwise
+ * SUM over ranks of the flat gradient buffer, one ncclAllReduce. */
+int s3_comm_unique_id(void* out128); /* rank 0; 128 bytes                  */
+int s3_comm_init(s3_ctx* ctx, int rank, int nranks, const void* unique_id128);
+int s3_params_allreduce_grads(s3_params* p);
+int s3_allreduce_sum(s3_ctx* ctx, float* buf, int64_t n);
+
+/* library / build information */
+const char* s3_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUP3R_HIP_H */

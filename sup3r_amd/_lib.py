@@ -1,0 +1,120 @@
+"""ctypes binding of ``libsup3r_hip.so`` (include/sup3r_hip.h).
+
+This is the only compute back-end of the package: there is no CPU fallback.
+If the shared library is missing or a call fails, a ``RuntimeError`` naming the
+problem is raised — nothing is silently routed elsewhere.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libsup3r_hip.so')
+
+# enums (include/sup3r_hip.h)
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+LOSS_MAE, LOSS_MSE = 0, 1
+BUF_W, BUF_G, BUF_M, BUF_V = 0, 1, 2, 3
+PRECISIONS = {'f32': PREC_F32, 'bf16': PREC_BF16}
+
+EXPORTS = [
+    's3_ctx_create', 's3_ctx_destroy', 's3_last_error', 's3_ctx_sync',
+    's3_ctx_stream', 's3_params_create', 's3_params_destroy',
+    's3_params_total', 's3_params_set', 's3_params_get', 's3_params_dptr',
+    's3_params_zero_grad', 's3_params_mean_abs', 's3_adam_step',
+    's3_plan_create', 's3_plan_destroy', 's3_plan_forward',
+    's3_plan_backward', 's3_plan_tensor', 's3_plan_workspace_bytes',
+    's3_plan_profile_forward', 's3_loss_content', 's3_loss_rel_bce',
+    's3_copy_channels', 's3_affine_channels', 's3_fill',
+    's3_comm_unique_id', 's3_comm_init', 's3_params_allreduce_grads',
+    's3_allreduce_sum', 's3_version',
+]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [('dims', C.c_int64 * 5)]
+
+
+class OpDesc(C.Structure):
+    _fields_ = [
+        ('kind', C.c_int32), ('in0', C.c_int32), ('in1', C.c_int32),
+        ('res', C.c_int32), ('out', C.c_int32), ('w', C.c_int32),
+        ('b', C.c_int32), ('k', C.c_int32 * 3), ('stride', C.c_int32 * 3),
+        ('lo', C.c_int32 * 3), ('hi', C.c_int32 * 3), ('pad_mode', C.c_int32),
+        ('act', C.c_int32), ('alpha', C.c_float), ('d2s', C.c_int32),
+        ('rep', C.c_int32), ('bcast_c', C.c_int32),
+        ('reserved', C.c_int32 * 4),
+    ]
+
+
+_lib = None
+
+
+def build_hint():
+    return ('build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` or `make -C sup3r_amd/csrc` (needs hipcc)')
+
+
+def lib():
+    """Load (once) and return the ctypes handle of libsup3r_hip.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'sup3r_amd: HIP library {LIB_PATH} not found; {build_hint()}. '
+            'There is no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    pf = C.POINTER(C.c_float)
+    sig = {
+        's3_ctx_create': (i32, [i32, vp, C.POINTER(vp)]),
+        's3_ctx_destroy': (None, [vp]),
+        's3_last_error': (C.c_char_p, [vp]),
+        's3_ctx_sync': (i32, [vp]),
+        's3_ctx_stream': (vp, [vp]),
+        's3_params_create': (i32, [vp, i32, C.POINTER(i64), C.POINTER(vp)]),
+        's3_params_destroy': (None, [vp]),
+        's3_params_total': (i64, [vp]),
+        's3_params_set': (i32, [vp, i32, i32, pf]),
+        's3_params_get': (i32, [vp, i32, i32, pf]),
+        's3_params_dptr': (vp, [vp, i32, i32]),
+        's3_params_zero_grad': (i32, [vp]),
+        's3_params_mean_abs': (i32, [vp, i32, i32, pf]),
+        's3_adam_step': (i32, [vp, f32, f32, f32, f32, i64]),
+        's3_plan_create': (i32, [vp, vp, C.POINTER(TensorDesc), i32,
+                                 C.POINTER(OpDesc), i32, C.POINTER(i32), i32,
+                                 i32, i32, i32, C.POINTER(vp)]),
+        's3_plan_destroy': (None, [vp]),
+        's3_plan_forward': (i32, [vp, C.POINTER(vp), vp]),
+        's3_plan_backward': (i32, [vp, vp, vp, i32, i32]),
+        's3_plan_tensor': (vp, [vp, i32]),
+        's3_plan_workspace_bytes': (i64, [vp]),
+        's3_plan_profile_forward': (i32, [vp, C.POINTER(vp), pf, i32]),
+        's3_loss_content': (i32, [vp, i32, vp, i32, vp, i32, i32, i64, f32,
+                                  vp, vp, i32]),
+        's3_loss_rel_bce': (i32, [vp, vp, vp, i32, f32, vp, vp, vp]),
+        's3_copy_channels': (i32, [vp, vp, i32, i32, vp, i32, i32, i32, i64,
+                                   i32]),
+        's3_affine_channels': (i32, [vp, vp, vp, i32, i64, pf, pf]),
+        's3_fill': (i32, [vp, vp, i64, f32]),
+        's3_comm_unique_id': (i32, [vp]),
+        's3_comm_init': (i32, [vp, i32, i32, vp]),
+        's3_params_allreduce_grads': (i32, [vp]),
+        's3_allreduce_sum': (i32, [vp, vp, i64]),
+        's3_version': (C.c_char_p, []),
+    }
+    for name in EXPORTS:
+        fn = getattr(L, name)   # AttributeError if the .so lacks a symbol
+        fn.restype, fn.argtypes = sig[name]
+    _lib = L
+    return L
+
+
+def check(rc, ctx=None, what=''):
+    if rc == 0:
+        return
+    msg = ''
+    if ctx:
+        raw = lib().s3_last_error(ctx)
+        msg = raw.decode() if raw else ''
+    raise RuntimeError(f'sup3r_amd HIP call failed ({what}, code {rc}): {msg}')

@@ -1,0 +1,118 @@
+// Internal declarations shared by the translation units of libsup3r_hip.so.
+// gfx950 (MI355X, CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sup3r_hip.h"
+
+struct s3_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  void* comm = nullptr;  // ncclComm_t
+  int rank = 0, nranks = 1;
+  float* scratch = nullptr;  // small device scratch (reductions)
+  size_t scratch_bytes = 0;
+  int num_cu = 256;
+};
+
+#define S3_HIP(ctx, call)                                                    \
+  do {                                                                       \
+    hipError_t e_ = (call);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);        \
+      return S3_EHIP;                                                        \
+    }                                                                        \
+  } while (0)
+
+#define S3_FAIL(ctx, code, msg) \
+  do {                          \
+    (ctx)->err = (msg);         \
+    return (code);              \
+  } while (0)
+
+// geometry of one fused convolution, passed by value to kernels
+struct ConvGeom {
+  int N;
+  int D[3];   // input spatial dims (s1, s2, t)
+  int O[3];   // conv output dims BEFORE the depth-to-space store
+  int Cin, Cout;
+  int k[3], s[3], lo[3];
+  int pad_mode;
+  int act;
+  float alpha;
+  int d2s;    // block size (1 = none)
+};
+
+// generic gather op (pad / crop / repeat / roll / d2s / concat): out <- in
+struct GatherGeom {
+  int kind;
+  int N;
+  int Di[3], Ci;  // input dims
+  int Do[3], Co;  // output dims
+  int lo[3];
+  int pad_mode;
+  int rep;
+  int d2s;
+  int c_off;      // concat: channel offset of in within out
+};
+
+__host__ __device__ inline int s3_reflect(int i, int n) {
+  if (i < 0) i = -i;
+  if (i > n - 1) i = 2 * (n - 1) - i;
+  return i;
+}
+
+// ---- launchers (defined in the .hip files) ------------------------------
+int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x,
+                            const float* w, const float* bias,
+                            const float* res, float* y);
+int launch_conv_generic_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,
+                              const float* w, float* dx);
+int launch_conv_generic_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,
+                              const float* dy, float* dw, float* partial,
+                              size_t partial_bytes, int accumulate);
+size_t conv_generic_wgrad_partial_bytes(const ConvGeom& g);
+
+// MFMA halo-tile conv (3x3x3 / 3x3x1, stride 1, C_in == 64)
+bool conv_mfma_supported(const ConvGeom& g, int precision);
+size_t conv_mfma_packed_bytes(const ConvGeom& g, int precision);
+int launch_conv_mfma_pack(s3_ctx* ctx, const ConvGeom& g, int precision,
+                          const float* w, void* packed);
+int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
+                         const float* x, const void* packed, const float* bias,
+                         const float* res, float* y);
+
+int launch_gather(s3_ctx* ctx, const GatherGeom& g, const float* in, float* out);
+int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
+                      float* din);
+int launch_act(s3_ctx* ctx, const float* x, float* y, int64_t n, int act,
+               float alpha);
+// dx = dy * act'(y)  (y is the activation OUTPUT; sign-preserving acts only)
+int launch_act_bwd(s3_ctx* ctx, const float* y, const float* dy, float* dx,
+                   int64_t n, int act, float alpha);
+// dpre[pos][c] = dy[d2s-permuted] * act'(y[d2s-permuted]) (conv epilogue adj.)
+int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
+                             const float* dy, float* dpre);
+int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
+               int c, int bcast_c);
+int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n);  // y += x
+int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
+                     float* db, int accumulate);
+int launch_dense_fwd(s3_ctx* ctx, const float* x, const float* w,
+                     const float* bias, float* y, int n, int cin, int cout,
+                     int act, float alpha);
+int launch_dense_dgrad(s3_ctx* ctx, const float* dy, const float* w, float* dx,
+                       int n, int cin, int cout);
+int launch_dense_wgrad(s3_ctx* ctx, const float* x, const float* dy, float* dw,
+                       int n, int cin, int cout, int accumulate);
+int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
+                int64_t n, float alpha, float b1, float b2, float eps);
+int launch_fill(s3_ctx* ctx, float* p, int64_t n, float v);
+int launch_mean_abs(s3_ctx* ctx, const float* p, int64_t n, float* out_dev);
+int ensure_scratch(s3_ctx* ctx, size_t bytes);

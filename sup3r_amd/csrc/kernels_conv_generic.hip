@@ -1,0 +1,372 @@
+// Generic direct convolution (fp32 VALU) for the HBM-/latency-bound layers of
+// the Sup3rGan path: low-channel convs (C_in <= 8 or C_out <= 2: generator head
+// / tail, discriminator entry), strided discriminator convs, SAME/VALID
+// padding, 2-D nets (t = 1).  NDHWC, reflect / zero padding evaluated as index
+// math at load time (never materialised), bias + activation + residual +
+// depth-to-space fused into the store.
+//
+// Mapping (wave64): one wave = 64 consecutive output positions x CO_T output
+// channels.  The filter block w[tap][ci][co0 .. co0+CO_T) is identical for
+// every lane of the wave -> address is wave-uniform (readfirstlane) so the
+// compiler emits scalar (SMEM) loads; x is read per lane, vectorised over
+// C_in when C_in % 4 == 0.  No MFMA here on purpose: these layers have
+// arithmetic intensity <= ~20 FLOP/B and are bound by HBM / L2, not math.
+#include "common.h"
+
+namespace {
+
+__device__ inline float act_f(float v, int act, float alpha) {
+  if (act == S3_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == S3_ACT_LEAKY) return v > 0.f ? v : alpha * v;
+  return v;
+}
+
+__device__ inline int src_index(int o, int t, int stride, int lo, int n,
+                                int pad_mode, bool& valid) {
+  int i = o * stride + t - lo;
+  if (pad_mode == S3_PAD_REFLECT) {
+    i = s3_reflect(i, n);
+    // ragged tiles never index outside: clamp is a no-op for legal plans
+    i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+  } else if (i < 0 || i >= n) {
+    valid = false;
+    i = 0;
+  }
+  return i;
+}
+
+template <int CO_T, int CI_V>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ res,
+    float* __restrict__ y, ConvGeom g, int n_cgroups) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  const int64_t wave_task = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t chunk = wave_task / n_cgroups;
+  const int cg = (int)(wave_task % n_cgroups);
+  const int co0 = cg * CO_T;
+  const int64_t pos = chunk * 64 + lane;
+  if (chunk * 64 >= P) return;
+  const bool live = pos < P;
+  int64_t r = live ? pos : P - 1;
+  const int o2 = (int)(r % g.O[2]); r /= g.O[2];
+  const int o1 = (int)(r % g.O[1]); r /= g.O[1];
+  const int o0 = (int)(r % g.O[0]); r /= g.O[0];
+  const int n = (int)r;
+
+  float acc[CO_T];
+#pragma unroll
+  for (int j = 0; j < CO_T; ++j) acc[j] = 0.f;
+
+  const int Cin = g.Cin, Cout = g.Cout;
+  for (int a = 0; a < g.k[0]; ++a) {
+    bool v0 = true;
+    const int i0 = src_index(o0, a, g.s[0], g.lo[0], g.D[0], g.pad_mode, v0);
+    for (int b = 0; b < g.k[1]; ++b) {
+      bool v1 = v0;
+      const int i1 = src_index(o1, b, g.s[1], g.lo[1], g.D[1], g.pad_mode, v1);
+      for (int c = 0; c < g.k[2]; ++c) {
+        bool v2 = v1;
+        const int i2 = src_index(o2, c, g.s[2], g.lo[2], g.D[2], g.pad_mode, v2);
+        const float* xp = x + ((((int64_t)n * g.D[0] + i0) * g.D[1] + i1) *
+                                   g.D[2] + i2) * Cin;
+        const float* wp = w + (int64_t)((a * g.k[1] + b) * g.k[2] + c) * Cin * Cout + co0;
+        const float m = v2 ? 1.f : 0.f;
+        for (int ci = 0; ci < Cin; ci += CI_V) {
+          float xv[CI_V];
+          if (CI_V == 4) {
+            float4 t = *reinterpret_cast<const float4*>(xp + ci);
+            xv[0] = t.x * m; xv[1] = t.y * m; xv[2] = t.z * m; xv[3] = t.w * m;
+          } else if (CI_V == 2) {
+            float2 t = *reinterpret_cast<const float2*>(xp + ci);
+            xv[0] = t.x * m; xv[1] = t.y * m;
+          } else {
+            xv[0] = xp[ci] * m;
+          }
+#pragma unroll
+          for (int q = 0; q < CI_V; ++q) {
+            const float* wr = wp + (int64_t)(ci + q) * Cout;
+#pragma unroll
+            for (int j = 0; j < CO_T; ++j) {
+              float wv = (co0 + j < Cout) ? wr[j] : 0.f;
+              acc[j] = fmaf(xv[q], wv, acc[j]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!live) return;
+  // epilogue: bias, [d2s permutation], act, residual
+  const int b = g.d2s;
+  const int cpo = Cout / (b * b);  // channels after depth-to-space
+#pragma unroll
+  for (int j = 0; j < CO_T; ++j) {
+    const int co = co0 + j;
+    if (co >= Cout) break;
+    float v = acc[j] + (bias ? bias[co] : 0.f);
+    int64_t dst;
+    if (b == 1) {
+      dst = pos * Cout + co;
+    } else {
+      const int blk = co / cpo, cc = co % cpo;
+      dst = ((((int64_t)n * g.O[0] * b + o0 * b + blk / b) * (g.O[1] * b) +
+              o1 * b + blk % b) * g.O[2] + o2) * cpo + cc;
+    }
+    v = act_f(v, g.act, g.alpha);
+    if (res) v += res[dst];
+    y[dst] = v;
+  }
+}
+
+// ---- dgrad: dX[n,i,ci] = sum over pre-images q of i under the (virtual)
+// padding, taps k, co:  dY[n,(q+lo-k)/s,co] * W[k][ci][co]
+template <int CI_T>
+__global__ __launch_bounds__(256) void conv_dgrad_kernel(
+    const float* __restrict__ dy, const float* __restrict__ w,
+    float* __restrict__ dx, ConvGeom g, int n_cgroups) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t P = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
+  const int64_t wave_task = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t chunk = wave_task / n_cgroups;
+  const int cg = (int)(wave_task % n_cgroups);
+  const int ci0 = cg * CI_T;
+  const int64_t pos = chunk * 64 + lane;
+  if (chunk * 64 >= P) return;
+  const bool live = pos < P;
+  int64_t r = live ? pos : P - 1;
+  int ii[3];
+  ii[2] = (int)(r % g.D[2]); r /= g.D[2];
+  ii[1] = (int)(r % g.D[1]); r /= g.D[1];
+  ii[0] = (int)(r % g.D[0]); r /= g.D[0];
+  const int n = (int)r;
+  const int Cin = g.Cin, Cout = g.Cout;
+
+  // candidate virtual (padded-frame) coordinates q with source(q) == i
+  int cand[3][3], cnt[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    cnt[d] = 0;
+    cand[d][cnt[d]++] = ii[d];
+    if (g.pad_mode == S3_PAD_REFLECT) {
+      const int nI = g.D[d];
+      const int vmax = (g.O[d] - 1) * g.s[d] + g.k[d] - 1 - g.lo[d];
+      if (ii[d] >= 1 && -ii[d] >= -g.lo[d]) cand[d][cnt[d]++] = -ii[d];
+      const int mq = 2 * (nI - 1) - ii[d];
+      if (ii[d] <= nI - 2 && mq <= vmax && mq >= nI) cand[d][cnt[d]++] = mq;
+    }
+  }
+  float acc[CI_T];
+#pragma unroll
+  for (int j = 0; j < CI_T; ++j) acc[j] = 0.f;
+
+  for (int e0 = 0; e0 < cnt[0]; ++e0)
+    for (int a = 0; a < g.k[0]; ++a) {
+      int t0 = cand[0][e0] + g.lo[0] - a;
+      if (t0 < 0 || t0 % g.s[0] != 0) continue;
+      t0 /= g.s[0];
+      if (t0 >= g.O[0]) continue;
+      for (int e1 = 0; e1 < cnt[1]; ++e1)
+        for (int b = 0; b < g.k[1]; ++b) {
+          int t1 = cand[1][e1] + g.lo[1] - b;
+          if (t1 < 0 || t1 % g.s[1] != 0) continue;
+          t1 /= g.s[1];
+          if (t1 >= g.O[1]) continue;
+          for (int e2 = 0; e2 < cnt[2]; ++e2)
+            for (int c = 0; c < g.k[2]; ++c) {
+              int t2 = cand[2][e2] + g.lo[2] - c;
+              if (t2 < 0 || t2 % g.s[2] != 0) continue;
+              t2 /= g.s[2];
+              if (t2 >= g.O[2]) continue;
+              const float* dyp = dy + ((((int64_t)n * g.O[0] + t0) * g.O[1] + t1) *
+                                           g.O[2] + t2) * Cout;
+              const float* wp = w + ((int64_t)((a * g.k[1] + b) * g.k[2] + c) * Cin + ci0) * Cout;
+              for (int co = 0; co < Cout; ++co) {
+                const float d = dyp[co];
+#pragma unroll
+                for (int j = 0; j < CI_T; ++j) {
+                  float wv = (ci0 + j < Cin) ? wp[(int64_t)j * Cout + co] : 0.f;
+                  acc[j] = fmaf(d, wv, acc[j]);
+                }
+              }
+            }
+        }
+    }
+  if (!live) return;
+#pragma unroll
+  for (int j = 0; j < CI_T; ++j)
+    if (ci0 + j < Cin) dx[pos * Cin + ci0 + j] = acc[j];
+}
+
+// ---- wgrad: dW[tap][ci][co] = sum_{n,o} Xp[n, o*s + k - lo][ci] * dY[n,o][co]
+// block = (position slab, tap, 64x64 (ci,co) tile); x / dy slabs of 32
+// positions staged through LDS; each thread owns a 4x4 (ci,co) register block.
+// Partials per slab go to scratch and are summed in fixed order (deterministic,
+// identical on every rank).
+constexpr int WG_TILE = 64;
+constexpr int WG_POS = 32;
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy,
+    float* __restrict__ partial, ConvGeom g, int n_slabs, int tiles_ci,
+    int tiles_co) {
+  __shared__ float xs[WG_POS][WG_TILE + 4];
+  __shared__ float ds[WG_POS][WG_TILE + 4];
+  const int slab = blockIdx.x;
+  const int tap = blockIdx.y;
+  const int tile = blockIdx.z;
+  const int tci = (tile / tiles_co) * WG_TILE, tco = (tile % tiles_co) * WG_TILE;
+  const int a = tap / (g.k[1] * g.k[2]), b = (tap / g.k[2]) % g.k[1], c = tap % g.k[2];
+  const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  const int64_t per = (P + n_slabs - 1) / n_slabs;
+  const int64_t p_begin = (int64_t)slab * per;
+  const int64_t p_end = p_begin + per < P ? p_begin + per : P;
+  const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;  // 16x16 threads
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_POS) {
+    // stage: 32 positions x 64 channels each for x (tap-shifted) and dy
+    for (int e = threadIdx.x; e < WG_POS * WG_TILE; e += 256) {
+      const int pr = e / WG_TILE, ch = e % WG_TILE;
+      const int64_t pos = p0 + pr;
+      float xv = 0.f, dv = 0.f;
+      if (pos < p_end) {
+        int64_t r = pos;
+        const int o2 = (int)(r % g.O[2]); r /= g.O[2];
+        const int o1 = (int)(r % g.O[1]); r /= g.O[1];
+        const int o0 = (int)(r % g.O[0]); r /= g.O[0];
+        const int n = (int)r;
+        bool v = true;
+        const int i0 = src_index(o0, a, g.s[0], g.lo[0], g.D[0], g.pad_mode, v);
+        const int i1 = src_index(o1, b, g.s[1], g.lo[1], g.D[1], g.pad_mode, v);
+        const int i2 = src_index(o2, c, g.s[2], g.lo[2], g.D[2], g.pad_mode, v);
+        if (v && tci + ch < g.Cin)
+          xv = x[((((int64_t)n * g.D[0] + i0) * g.D[1] + i1) * g.D[2] + i2) * g.Cin + tci + ch];
+        if (tco + ch < g.Cout) dv = dy[pos * g.Cout + tco + ch];
+      }
+      xs[pr][ch] = xv;
+      ds[pr][ch] = dv;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int pr = 0; pr < WG_POS; ++pr) {
+      float4 xv = *reinterpret_cast<const float4*>(&xs[pr][ty * 4]);
+      float4 dv = *reinterpret_cast<const float4*>(&ds[pr][tx * 4]);
+      const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+      const float da[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(xa[i], da[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  // partial[slab][tap][ci][co]
+  float* out = partial + ((int64_t)slab * (g.k[0] * g.k[1] * g.k[2]) + tap) * g.Cin * g.Cout;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ci = tci + ty * 4 + i;
+    if (ci >= g.Cin) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = tco + tx * 4 + j;
+      if (co < g.Cout) out[(int64_t)ci * g.Cout + co] = acc[i][j];
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                    int n_slabs, int64_t wsize,
+                                    float* __restrict__ dw, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < wsize;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int s = 0; s < n_slabs; ++s) t += partial[(int64_t)s * wsize + i];
+    dw[i] = accumulate ? dw[i] + t : t;
+  }
+}
+
+int wgrad_slabs(const ConvGeom& g) {
+  const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  int64_t s = (P + 2047) / 2048;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+}  // namespace
+
+int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x,
+                            const float* w, const float* bias,
+                            const float* res, float* y) {
+  const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  int co_t = g.Cout >= 16 ? 16 : (g.Cout >= 8 ? 8 : (g.Cout >= 4 ? 4 : (g.Cout >= 2 ? 2 : 1)));
+  int n_cg = (g.Cout + co_t - 1) / co_t;
+  int64_t tasks = ((P + 63) / 64) * n_cg;
+  dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
+  int civ = (g.Cin % 4 == 0) ? 4 : ((g.Cin % 2 == 0) ? 2 : 1);
+#define S3_LAUNCH_FWD(CO, CI)                                                 \
+  hipLaunchKernelGGL((conv_fwd_kernel<CO, CI>), grid, block, 0, ctx->stream, \
+                     x, w, bias, res, y, g, n_cg)
+#define S3_FWD_CI(CO)                                  \
+  if (civ == 4) S3_LAUNCH_FWD(CO, 4);                  \
+  else if (civ == 2) S3_LAUNCH_FWD(CO, 2);             \
+  else S3_LAUNCH_FWD(CO, 1)
+  switch (co_t) {
+    case 16: S3_FWD_CI(16); break;
+    case 8: S3_FWD_CI(8); break;
+    case 4: S3_FWD_CI(4); break;
+    case 2: S3_FWD_CI(2); break;
+    default: S3_FWD_CI(1); break;
+  }
+#undef S3_FWD_CI
+#undef S3_LAUNCH_FWD
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_conv_generic_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,
+                              const float* w, float* dx) {
+  const int64_t P = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
+  int ci_t = g.Cin >= 8 ? 8 : (g.Cin >= 4 ? 4 : (g.Cin >= 2 ? 2 : 1));
+  int n_cg = (g.Cin + ci_t - 1) / ci_t;
+  int64_t tasks = ((P + 63) / 64) * n_cg;
+  dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
+  switch (ci_t) {
+    case 8: hipLaunchKernelGGL(conv_dgrad_kernel<8>, grid, block, 0, ctx->stream, dy, w, dx, g, n_cg); break;
+    case 4: hipLaunchKernelGGL(conv_dgrad_kernel<4>, grid, block, 0, ctx->stream, dy, w, dx, g, n_cg); break;
+    case 2: hipLaunchKernelGGL(conv_dgrad_kernel<2>, grid, block, 0, ctx->stream, dy, w, dx, g, n_cg); break;
+    default: hipLaunchKernelGGL(conv_dgrad_kernel<1>, grid, block, 0, ctx->stream, dy, w, dx, g, n_cg); break;
+  }
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+size_t conv_generic_wgrad_partial_bytes(const ConvGeom& g) {
+  return (size_t)wgrad_slabs(g) * g.k[0] * g.k[1] * g.k[2] * g.Cin * g.Cout * sizeof(float);
+}
+
+int launch_conv_generic_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,
+                              const float* dy, float* dw, float* partial,
+                              size_t partial_bytes, int accumulate) {
+  const int n_slabs = wgrad_slabs(g);
+  if (partial_bytes < conv_generic_wgrad_partial_bytes(g))
+    S3_FAIL(ctx, S3_EINVAL, "wgrad: partial buffer too small");
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int tci = (g.Cin + WG_TILE - 1) / WG_TILE, tco = (g.Cout + WG_TILE - 1) / WG_TILE;
+  dim3 grid(n_slabs, taps, tci * tco), block(256);
+  hipLaunchKernelGGL(conv_wgrad_kernel, grid, block, 0, ctx->stream, x, dy, partial, g, n_slabs, tci, tco);
+  const int64_t wsize = (int64_t)taps * g.Cin * g.Cout;
+  int rg = (int)((wsize + 255) / 256);
+  if (rg > 2048) rg = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, ctx->stream, partial, n_slabs, wsize, dw, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}

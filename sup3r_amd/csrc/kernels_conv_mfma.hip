@@ -1,0 +1,365 @@
+// Halo-tile implicit-GEMM Conv3D for the generator body of Sup3rGan
+// (K2: 33 x [REFLECT pad 3 -> Conv3D 64->64 k3 -> crop 2] + the 64->200
+// expansion conv = 99.7 % of the generator FLOPs), written for gfx950.
+//
+//   y[n, p, co] = act(b[co] + sum_{tap, ci} x[n, reflect(p + tap - 1), ci] *
+//                 w[tap][ci][co]) (+ residual) (store optionally permuted by
+//                 depth-to-space)
+//
+// im2col-free: a workgroup owns TS0 x TS1 x 16 output positions (16 = run along
+// t, the innermost spatial axis) and all 64 output channels of one cout tile.
+// The (TS0+2)(TS1+2)(18) x 64-channel input halo is staged ONCE in LDS with the
+// reflect/zero boundary evaluated as index math in the load; every one of the
+// 27 taps then reads its shifted window straight out of LDS as MFMA A
+// fragments.  The 64x64 filter slab of tap+1 is prefetched into registers while
+// tap is on the matrix cores and lands in the other half of a 2-slab LDS ring
+// (one barrier per tap).  K = 27 * 64 = 1728 is contracted on MFMA:
+//
+//   S3_PREC_BF16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Halo and filter
+//                  rows are 128 B (64 x bf16); 16-B chunks are XOR-swizzled by
+//                  ((row >> 1) & 7) so that the 16-lane groups of ds_read_b128
+//                  hit 16 distinct 16-B slots of the 256-B bank row.
+//   S3_PREC_F32  : v_mfma_f32_16x16x4_f32 (exact fp32, == fmaf chain): parity
+//                  mode.  Halo rows padded to 66 dwords, filter rows to 80, so
+//                  the per-lane ds_read_b32 of the (row, k) fragments are
+//                  conflict-free.
+//
+// Fragment maps (guide §3): A lane l: row l&15, k-group l>>4; B lane l: col
+// l&15, k-group l>>4; C/D lane l reg r: col l&15, row (l>>4)*4 + r.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TS2 = 16;
+constexpr int H2 = TS2 + 2;
+constexpr int CIN = 64;
+constexpr int CT = 64;          // cout tile
+constexpr int F32_ROW = 66;     // halo row stride (dwords), f32 mode
+constexpr int F32_BROW = 80;    // filter row stride (dwords), f32 mode
+
+__device__ inline unsigned short f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);   // round to nearest even
+  return (unsigned short)(u >> 16);
+}
+
+__device__ inline float act_f(float v, int act, float alpha) {
+  if (act == S3_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == S3_ACT_LEAKY) return v > 0.f ? v : alpha * v;
+  return v;
+}
+
+template <int TS0, int TS1>
+struct Tile {
+  static constexpr int H0 = TS0 + 2, H1 = TS1 + 2;
+  static constexpr int HP = H0 * H1 * H2;        // halo positions
+  static constexpr int MFW = TS0 * TS1 / 4;      // M fragments per wave
+  static constexpr int NPOS = TS0 * TS1 * TS2;
+  static constexpr size_t lds_bf16 = (size_t)HP * 128 + 2 * 8192;
+  static constexpr size_t lds_f32 = (size_t)HP * F32_ROW * 4 + 2 * CIN * F32_BROW * 4;
+};
+
+// pack canonical fp32 w[tap][ci][co] -> bf16 slabs [ct][tap][co 64][ci 64],
+// 16-B chunks pre-swizzled (the slab is the LDS image)
+__global__ void pack_bf16_kernel(const float* __restrict__ w,
+                                 unsigned short* __restrict__ out, int taps,
+                                 int cout, int n_ct) {
+  const int64_t total = (int64_t)n_ct * taps * CT * CIN;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx;
+    const int ci = (int)(r % CIN); r /= CIN;
+    const int row = (int)(r % CT); r /= CT;
+    const int tap = (int)(r % taps); r /= taps;
+    const int ct = (int)r;
+    const int co = ct * CT + row;
+    const float v = co < cout ? w[((int64_t)tap * CIN + ci) * cout + co] : 0.f;
+    const int chunk = ci >> 3, e = ci & 7;
+    const int slot = chunk ^ ((row >> 1) & 7);
+    out[(((int64_t)ct * taps + tap) * CT + row) * CIN + slot * 8 + e] = f2bf(v);
+  }
+}
+
+template <int PREC, int TS0, int TS1>
+__global__ __launch_bounds__(256) void conv3_mfma_kernel(
+    const float* __restrict__ x, const void* __restrict__ wpk,
+    const float* __restrict__ bias, const float* __restrict__ res,
+    float* __restrict__ y, ConvGeom g, int tiles0, int tiles1, int tiles2) {
+  using T = Tile<TS0, TS1>;
+  constexpr int H1 = T::H1, HP = T::HP, MFW = T::MFW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // XCD-aware tile order: dispatcher places block b on XCD b % 8; hand each
+  // XCD a contiguous run of tiles so neighbouring halos share its private L2.
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int ct = blockIdx.y;
+  int tr = bid;
+  const int t2i = tr % tiles2; tr /= tiles2;
+  const int t1i = tr % tiles1; tr /= tiles1;
+  const int t0i = tr % tiles0; tr /= tiles0;
+  const int n = tr;
+  const int org0 = t0i * TS0, org1 = t1i * TS1, org2 = t2i * TS2;
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int KK1 = g.k[1], KK2 = g.k[2];
+
+  char* halo = smem;
+  char* bslab = smem + (PREC == S3_PREC_BF16 ? (size_t)HP * 128
+                                             : (size_t)HP * F32_ROW * 4);
+  constexpr int BSLAB_BYTES = PREC == S3_PREC_BF16 ? 8192 : CIN * F32_BROW * 4;
+
+  // ---- B slab register prefetch helpers
+  uint4 breg[PREC == S3_PREC_BF16 ? 2 : 4];
+  auto b_issue = [&](int tap) {
+    if (PREC == S3_PREC_BF16) {
+      const uint4* src = reinterpret_cast<const uint4*>(
+          (const char*)wpk + ((size_t)ct * taps + tap) * 8192);
+      breg[0] = src[tid];
+      breg[1] = src[256 + tid];
+    } else {
+      const float* w = (const float*)wpk + (size_t)tap * CIN * g.Cout + ct * CT;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ci = (tid >> 4) + 16 * q, co4 = (tid & 15) * 4;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ct * CT + co4 < g.Cout)
+          v = *reinterpret_cast<const uint4*>(w + (size_t)ci * g.Cout + co4);
+        breg[q] = v;
+      }
+    }
+  };
+  auto b_commit = [&](int buf) {
+    char* dst = bslab + buf * BSLAB_BYTES;
+    if (PREC == S3_PREC_BF16) {
+      reinterpret_cast<uint4*>(dst)[tid] = breg[0];
+      reinterpret_cast<uint4*>(dst)[256 + tid] = breg[1];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ci = (tid >> 4) + 16 * q, co4 = (tid & 15) * 4;
+        *reinterpret_cast<uint4*>(dst + ((size_t)ci * F32_BROW + co4) * 4) = breg[q];
+      }
+    }
+  };
+
+  b_issue(0);
+
+  // ---- stage the input halo (boundary handled here, once per element)
+  {
+    constexpr int CHUNKS = PREC == S3_PREC_BF16 ? 8 : 16;  // per position
+    for (int item = tid; item < HP * CHUNKS; item += 256) {
+      const int hp = item / CHUNKS, ch = item % CHUNKS;
+      int h = hp;
+      const int c2 = h % H2; h /= H2;
+      const int c1 = h % H1; h /= H1;
+      const int c0 = h;
+      int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
+      bool valid = true;
+      if (g.pad_mode == S3_PAD_REFLECT) {
+        i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
+      } else {
+        valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
+      }
+      // ragged tiles: keep addresses legal (results are masked at the store)
+      i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
+      i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
+      i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
+      const float* src = x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * CIN;
+      if (PREC == S3_PREC_BF16) {
+        float4 a = make_float4(0, 0, 0, 0), b = a;
+        if (valid) {
+          a = *reinterpret_cast<const float4*>(src + ch * 8);
+          b = *reinterpret_cast<const float4*>(src + ch * 8 + 4);
+        }
+        uint4 o;
+        o.x = f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
+        o.y = f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
+        o.z = f2bf(b.x) | ((unsigned)f2bf(b.y) << 16);
+        o.w = f2bf(b.z) | ((unsigned)f2bf(b.w) << 16);
+        const int slot = ch ^ ((hp >> 1) & 7);
+        *reinterpret_cast<uint4*>(halo + (size_t)hp * 128 + slot * 16) = o;
+      } else {
+        float4 a = make_float4(0, 0, 0, 0);
+        if (valid) a = *reinterpret_cast<const float4*>(src + ch * 4);
+        float2* d = reinterpret_cast<float2*>(halo + ((size_t)hp * F32_ROW + ch * 4) * 4);
+        d[0] = make_float2(a.x, a.y);
+        d[1] = make_float2(a.z, a.w);
+      }
+    }
+  }
+  b_commit(0);
+  __syncthreads();
+
+  // ---- per-wave fragment coordinates
+  const int frow = lane & 15, kq = lane >> 4;
+  int hp_base[MFW];
+#pragma unroll
+  for (int m = 0; m < MFW; ++m) {
+    const int mf = wave * MFW + m;       // (s1, s2) pair inside the tile
+    const int s1 = mf / TS1, s2 = mf % TS1;
+    hp_base[m] = (s1 * H1 + s2) * H2 + frow;
+  }
+  f32x4 acc[MFW][4];
+#pragma unroll
+  for (int m = 0; m < MFW; ++m)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) acc[m][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tap = 0; tap < taps; ++tap) {
+    if (tap + 1 < taps) b_issue(tap + 1);
+    const int ta = tap / (KK1 * KK2), tb = (tap / KK2) % KK1, tc = tap % KK2;
+    const int tap_off = (ta * H1 + tb) * H2 + tc;
+    const char* bs = bslab + (tap & 1) * BSLAB_BYTES;
+    if (PREC == S3_PREC_BF16) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 bfr[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          const int row = nf * 16 + frow;
+          const int slot = (ks * 4 + kq) ^ ((row >> 1) & 7);
+          bfr[nf] = *reinterpret_cast<const bf16x8*>(bs + row * 128 + slot * 16);
+        }
+#pragma unroll
+        for (int m = 0; m < MFW; ++m) {
+          const int hp = hp_base[m] + tap_off;
+          const int slot = (ks * 4 + kq) ^ ((hp >> 1) & 7);
+          const bf16x8 afr = *reinterpret_cast<const bf16x8*>(halo + (size_t)hp * 128 + slot * 16);
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+            acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nf], acc[m][nf], 0, 0, 0);
+        }
+      }
+    } else {
+      const float* hf = reinterpret_cast<const float*>(halo);
+      const float* bf = reinterpret_cast<const float*>(bs);
+#pragma unroll 4
+      for (int ks = 0; ks < CIN / 4; ++ks) {
+        float bv[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+          bv[nf] = bf[(ks * 4 + kq) * F32_BROW + nf * 16 + frow];
+#pragma unroll
+        for (int m = 0; m < MFW; ++m) {
+          const float av = hf[(size_t)(hp_base[m] + tap_off) * F32_ROW + ks * 4 + kq];
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+            acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nf], acc[m][nf], 0, 0, 0);
+        }
+      }
+    }
+    if (tap + 1 < taps) b_commit((tap + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, [depth-to-space], activation, residual, store
+  const int b = g.d2s;
+  const int cpo = g.Cout / (b * b);
+#pragma unroll
+  for (int m = 0; m < MFW; ++m) {
+    const int mf = wave * MFW + m;
+    const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1;
+    if (o0 >= g.O[0] || o1 >= g.O[1]) continue;
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int co = ct * CT + nf * 16 + frow;
+      if (co >= g.Cout) continue;
+      const float bsv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o2 = org2 + kq * 4 + r;
+        if (o2 >= g.O[2]) continue;
+        float v = acc[m][nf][r] + bsv;
+        size_t dst;
+        if (b == 1) {
+          dst = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co;
+        } else {
+          const int blk = co / cpo, cc = co % cpo;
+          dst = ((((size_t)n * g.O[0] * b + o0 * b + blk / b) * (g.O[1] * b) +
+                  o1 * b + blk % b) * g.O[2] + o2) * cpo + cc;
+        }
+        v = act_f(v, g.act, g.alpha);
+        if (res) v += res[dst];
+        y[dst] = v;
+      }
+    }
+  }
+}
+
+template <int PREC, int TS0, int TS1>
+int launch_cfg(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* wpk,
+               const float* bias, const float* res, float* y) {
+  using T = Tile<TS0, TS1>;
+  const size_t lds = PREC == S3_PREC_BF16 ? T::lds_bf16 : T::lds_f32;
+  auto kern = conv3_mfma_kernel<PREC, TS0, TS1>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int tiles0 = (g.O[0] + TS0 - 1) / TS0, tiles1 = (g.O[1] + TS1 - 1) / TS1,
+            tiles2 = (g.O[2] + TS2 - 1) / TS2;
+  dim3 grid((unsigned)(g.N * tiles0 * tiles1 * tiles2), (unsigned)((g.Cout + CT - 1) / CT));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, x, wpk, bias, res, y, g, tiles0, tiles1, tiles2);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+}  // namespace
+
+bool conv_mfma_supported(const ConvGeom& g, int precision) {
+  if (precision != S3_PREC_F32 && precision != S3_PREC_BF16) return false;
+  if (g.Cin != CIN) return false;
+  if (g.Cout % 4 != 0 || g.Cout < 16) return false;
+  if (g.k[0] != 3 || g.k[1] != 3 || (g.k[2] != 3 && g.k[2] != 1)) return false;
+  for (int d = 0; d < 3; ++d) {
+    if (g.s[d] != 1) return false;
+    const int lo = g.k[d] == 3 ? 1 : 0;
+    if (g.lo[d] != lo || g.O[d] != g.D[d]) return false;
+  }
+  if (g.k[2] == 1) return false;   // 2-D nets stay on the direct kernel for now
+  if (g.D[2] < 8) return false;    // 16-long t runs would be mostly masked
+  return true;
+}
+
+size_t conv_mfma_packed_bytes(const ConvGeom& g, int precision) {
+  if (precision == S3_PREC_BF16) {
+    const int n_ct = (g.Cout + CT - 1) / CT;
+    return (size_t)n_ct * g.k[0] * g.k[1] * g.k[2] * CT * CIN * 2;
+  }
+  return 16;  // f32 mode reads the canonical weights directly
+}
+
+int launch_conv_mfma_pack(s3_ctx* ctx, const ConvGeom& g, int precision,
+                          const float* w, void* packed) {
+  if (precision != S3_PREC_BF16) return S3_OK;
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int n_ct = (g.Cout + CT - 1) / CT;
+  const int64_t total = (int64_t)n_ct * taps * CT * CIN;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, (unsigned short*)packed, taps, g.Cout, n_ct);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
+                         const float* x, const void* packed, const float* bias,
+                         const float* res, float* y) {
+  if (precision == S3_PREC_BF16)
+    return launch_cfg<S3_PREC_BF16, 4, 4>(ctx, g, x, packed, bias, res, y);
+  // f32: the filters are read in canonical layout; `packed` is unused
+  return launch_cfg<S3_PREC_F32, 2, 4>(ctx, g, x, packed, bias, res, y);
+}

@@ -1,0 +1,611 @@
+// HBM-bound helper kernels of the Sup3rGan path: index-permutation ops
+// (temporal nearest repeat, depth-to-space, pad, crop, roll, concat),
+// activations, residual adds, bias gradients, losses, Adam, reductions.
+// All are one-pass streaming kernels: coalesced 16-B accesses where the
+// channel count allows, grid-stride loops capped at ~8 blocks per CU.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(int64_t n_threads, int num_cu) {
+  int64_t b = (n_threads + kBlock - 1) / kBlock;
+  int64_t cap = (int64_t)num_cu * 8;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------ gather
+// out[n, o0, o1, o2, c] = in[map(...)]; V = channels per thread (1 or 4)
+template <int V>
+__global__ void gather_kernel(const float* __restrict__ in,
+                              float* __restrict__ out, GatherGeom g) {
+  const int cg_out = g.Co / V;
+  const int64_t total = (int64_t)g.N * g.Do[0] * g.Do[1] * g.Do[2] * cg_out;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx;
+    int cg = (int)(r % cg_out); r /= cg_out;
+    int o2 = (int)(r % g.Do[2]); r /= g.Do[2];
+    int o1 = (int)(r % g.Do[1]); r /= g.Do[1];
+    int o0 = (int)(r % g.Do[0]); r /= g.Do[0];
+    int n = (int)r;
+    int c = cg * V;
+    int i0 = o0, i1 = o1, i2 = o2, ci = c;
+    bool zero = false;
+    int64_t out_c = c;
+    switch (g.kind) {
+      case S3_OP_REPEAT_T: i2 = o2 / g.rep; break;
+      case S3_OP_ROLL_T: {
+        int s = g.rep % g.Do[2];
+        i2 = o2 - s; if (i2 < 0) i2 += g.Do[2];
+      } break;
+      case S3_OP_D2S: {
+        int b = g.d2s;
+        i0 = o0 / b; i1 = o1 / b;
+        ci = ((o0 % b) * b + (o1 % b)) * g.Co + c;
+      } break;
+      case S3_OP_CROP: i0 = o0 + g.lo[0]; i1 = o1 + g.lo[1]; i2 = o2 + g.lo[2]; break;
+      case S3_OP_PAD: {
+        i0 = o0 - g.lo[0]; i1 = o1 - g.lo[1]; i2 = o2 - g.lo[2];
+        if (g.pad_mode == S3_PAD_REFLECT) {
+          i0 = s3_reflect(i0, g.Di[0]); i1 = s3_reflect(i1, g.Di[1]);
+          i2 = s3_reflect(i2, g.Di[2]);
+        } else {
+          zero = i0 < 0 || i0 >= g.Di[0] || i1 < 0 || i1 >= g.Di[1] ||
+                 i2 < 0 || i2 >= g.Di[2];
+        }
+      } break;
+      case S3_OP_CONCAT: {
+        // thread indexes the INPUT channel range; output channel is offset
+        // (Do == Di, Co here is the number of channels copied)
+        out_c = c + g.c_off;
+      } break;
+      default: break;
+    }
+    int64_t src = ((((int64_t)n * g.Di[0] + i0) * g.Di[1] + i1) * g.Di[2] + i2) *
+                      g.Ci + ci;
+    int co_total = (g.kind == S3_OP_CONCAT) ? g.rep : g.Co;  // rep = C of out
+    int64_t dst = ((((int64_t)n * g.Do[0] + o0) * g.Do[1] + o1) * g.Do[2] + o2) *
+                      co_total + out_c;
+    if (V == 4) {
+      float4 v = zero ? make_float4(0, 0, 0, 0)
+                      : *reinterpret_cast<const float4*>(in + src);
+      *reinterpret_cast<float4*>(out + dst) = v;
+    } else {
+      out[dst] = zero ? 0.f : in[src];
+    }
+  }
+}
+
+// backward of the gather ops: one thread per din element (gathers its
+// pre-images from dout; no atomics, deterministic)
+__global__ void gather_bwd_kernel(const float* __restrict__ dout,
+                                  float* __restrict__ din, GatherGeom g) {
+  const int64_t total = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx;
+    int c = (int)(r % g.Ci); r /= g.Ci;
+    int i2 = (int)(r % g.Di[2]); r /= g.Di[2];
+    int i1 = (int)(r % g.Di[1]); r /= g.Di[1];
+    int i0 = (int)(r % g.Di[0]); r /= g.Di[0];
+    int n = (int)r;
+    auto at = [&](int o0, int o1, int o2, int co, int ctot) -> float {
+      return dout[((((int64_t)n * g.Do[0] + o0) * g.Do[1] + o1) * g.Do[2] + o2) *
+                      ctot + co];
+    };
+    float acc = 0.f;
+    switch (g.kind) {
+      case S3_OP_REPEAT_T:
+        for (int j = 0; j < g.rep; ++j) acc += at(i0, i1, i2 * g.rep + j, c, g.Co);
+        break;
+      case S3_OP_ROLL_T: {
+        int s = g.rep % g.Do[2];
+        int o2 = i2 + s; if (o2 >= g.Do[2]) o2 -= g.Do[2];
+        acc = at(i0, i1, o2, c, g.Co);
+      } break;
+      case S3_OP_D2S: {
+        int b = g.d2s;
+        int blk = c / g.Co, co = c % g.Co;
+        acc = at(i0 * b + blk / b, i1 * b + blk % b, i2, co, g.Co);
+      } break;
+      case S3_OP_CROP: {
+        int o0 = i0 - g.lo[0], o1 = i1 - g.lo[1], o2 = i2 - g.lo[2];
+        if (o0 >= 0 && o0 < g.Do[0] && o1 >= 0 && o1 < g.Do[1] && o2 >= 0 &&
+            o2 < g.Do[2])
+          acc = at(o0, o1, o2, c, g.Co);
+      } break;
+      case S3_OP_PAD: {
+        // pre-images of i under reflect: i+lo, lo-i (1<=i<=lo), and the
+        // mirror about the far edge
+        int cand[3][3], cnt[3];
+        const int ii[3] = {i0, i1, i2};
+        for (int d = 0; d < 3; ++d) {
+          int nI = g.Di[d], lo = g.lo[d], nO = g.Do[d];
+          cnt[d] = 0;
+          cand[d][cnt[d]++] = ii[d] + lo;
+          if (g.pad_mode == S3_PAD_REFLECT) {
+            if (ii[d] >= 1 && ii[d] <= lo) cand[d][cnt[d]++] = lo - ii[d];
+            int m = 2 * (nI - 1) - ii[d] + lo;  // mirrored padded index
+            if (ii[d] <= nI - 2 && m < nO && m >= nI + lo) cand[d][cnt[d]++] = m;
+          }
+        }
+        for (int a = 0; a < cnt[0]; ++a)
+          for (int b = 0; b < cnt[1]; ++b)
+            for (int e = 0; e < cnt[2]; ++e)
+              acc += at(cand[0][a], cand[1][b], cand[2][e], c, g.Co);
+      } break;
+      case S3_OP_CONCAT:
+        acc = at(i0, i1, i2, c + g.c_off, g.rep);
+        break;
+      default: break;
+    }
+    din[idx] = acc;
+  }
+}
+
+// ------------------------------------------------------------- elementwise
+__device__ inline float act_f(float v, int act, float alpha) {
+  if (act == S3_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == S3_ACT_LEAKY) return v > 0.f ? v : alpha * v;
+  return v;
+}
+__device__ inline float act_d(float y, int act, float alpha) {
+  if (act == S3_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == S3_ACT_LEAKY) return y > 0.f ? 1.f : alpha;
+  return 1.f;
+}
+
+__global__ void act_kernel(const float* __restrict__ x, float* __restrict__ y,
+                           int64_t n, int act, float alpha) {
+  int64_t n4 = n / 4;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x = act_f(v.x, act, alpha); v.y = act_f(v.y, act, alpha);
+    v.z = act_f(v.z, act, alpha); v.w = act_f(v.w, act, alpha);
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       i < n; i += stride)
+    y[i] = act_f(x[i], act, alpha);
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ y,
+                               const float* __restrict__ dy,
+                               float* __restrict__ dx, int64_t n, int act,
+                               float alpha) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride)
+    dx[i] = dy[i] * act_d(y[i], act, alpha);
+}
+
+// dpre[n,o0,o1,o2,c] = dy[perm] * act'(y[perm]) with the d2s store permutation
+__global__ void conv_epilogue_bwd_kernel(const float* __restrict__ y,
+                                         const float* __restrict__ dy,
+                                         float* __restrict__ dpre, ConvGeom g) {
+  const int64_t total = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout;
+  const int b = g.d2s;
+  const int co = g.Cout / (b * b);
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t src = idx;
+    if (b > 1) {
+      int64_t r = idx;
+      int c = (int)(r % g.Cout); r /= g.Cout;
+      int o2 = (int)(r % g.O[2]); r /= g.O[2];
+      int o1 = (int)(r % g.O[1]); r /= g.O[1];
+      int o0 = (int)(r % g.O[0]); r /= g.O[0];
+      int n = (int)r;
+      int blk = c / co, cc = c % co;
+      src = ((((int64_t)n * g.O[0] * b + o0 * b + blk / b) * (g.O[1] * b) +
+              o1 * b + blk % b) * g.O[2] + o2) * co + cc;
+    }
+    dpre[idx] = dy[src] * act_d(y[src], g.act, g.alpha);
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a,
+                           const float* __restrict__ b, float* __restrict__ y,
+                           int64_t n, int c, int bcast_c) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride)
+    y[i] = a[i] + (bcast_c ? b[i / c] : b[i]);
+}
+
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y,
+                            int64_t n) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride)
+    y[i] += x[i];
+}
+
+__global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride)
+    p[i] = v;
+}
+
+// ------------------------------------------------------------- reductions
+__device__ inline float wave_sum(float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ inline float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+  }
+  return t;  // valid on thread 0
+}
+
+// bias gradient: db[c] = sum over positions of dy[pos][c].  Two stages:
+// stage 1: grid of blocks, each reduces a slab of positions to partial[blk][c]
+// stage 2: one block sums the partials in fixed order (deterministic)
+__global__ void bias_grad_stage1(const float* __restrict__ dy, int64_t n_pos,
+                                 int c, float* __restrict__ partial) {
+  // thread t handles channel (t % c_pad) for positions strided by rows
+  extern __shared__ float sm[];
+  const int rows = blockDim.x / c;           // positions handled per sweep
+  const int my_c = threadIdx.x % c, my_r = threadIdx.x / c;
+  float acc = 0.f;
+  if (my_r < rows) {
+    for (int64_t p = (int64_t)blockIdx.x * rows + my_r; p < n_pos;
+         p += (int64_t)gridDim.x * rows)
+      acc += dy[p * c + my_c];
+  }
+  sm[threadIdx.x] = (my_r < rows) ? acc : 0.f;
+  __syncthreads();
+  if (threadIdx.x < c) {
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += sm[r * c + threadIdx.x];
+    partial[(int64_t)blockIdx.x * c + threadIdx.x] = t;
+  }
+}
+
+__global__ void bias_grad_stage2(const float* __restrict__ partial, int nblk,
+                                 int c, float* __restrict__ db, int accumulate) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * c + ch];
+  db[ch] = accumulate ? db[ch] + t : t;
+}
+
+__global__ void mean_abs_stage1(const float* __restrict__ p, int64_t n,
+                                float* __restrict__ partial) {
+  __shared__ float sm[8];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    acc += fabsf(p[i]);
+  float t = block_sum(acc, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ void sum_stage2(const float* __restrict__ partial, int nblk,
+                           float scale, float* __restrict__ out,
+                           int accumulate) {
+  __shared__ float sm[8];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) acc += partial[i];
+  float t = block_sum(acc, sm);
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + t * scale : t * scale;
+}
+
+// ------------------------------------------------------------------ losses
+// content loss over the first c_used channels; grad wrt a (c_a channels)
+__global__ void loss_content_kernel(int kind, const float* __restrict__ a,
+                                    int c_a, const float* __restrict__ b,
+                                    int c_b, int c_used, int64_t n_pos,
+                                    float gscale, float* __restrict__ partial,
+                                    float* __restrict__ d_a, int accumulate) {
+  __shared__ float sm[8];
+  const int64_t total = n_pos * c_used;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t p = i / c_used;
+    int c = (int)(i % c_used);
+    float d = a[p * c_a + c] - b[p * c_b + c];
+    float g;
+    if (kind == S3_LOSS_MAE) {
+      acc += fabsf(d);
+      g = (d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f);
+    } else {
+      acc += d * d;
+      g = 2.f * d;
+    }
+    if (d_a) {
+      float v = g * gscale;
+      d_a[p * c_a + c] = accumulate ? d_a[p * c_a + c] + v : v;
+    }
+  }
+  float t = block_sum(acc, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// relativistic BCE (single block; n is the batch size, small)
+__global__ void rel_bce_kernel(const float* __restrict__ dt,
+                               const float* __restrict__ dg, int n, float scale,
+                               float* __restrict__ loss_out,
+                               float* __restrict__ d_true,
+                               float* __restrict__ d_gen) {
+  __shared__ float sm[8];
+  __shared__ float s_mt, s_mg, s_gt, s_gf;
+  float at = 0.f, ag = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { at += dt[i]; ag += dg[i]; }
+  float t = block_sum(at, sm);
+  if (threadIdx.x == 0) s_mt = t / n;
+  t = block_sum(ag, sm);
+  if (threadIdx.x == 0) s_mg = t / n;
+  __syncthreads();
+  const float mt = s_mt, mg = s_mg;
+  float loss = 0.f, sgt = 0.f, sgf = 0.f;
+  const float inv = 1.f / (2.f * n);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float xt = dt[i] - mg;  // label 1
+    float xf = dg[i] - mt;  // label 0
+    float et = expf(-fabsf(xt)), ef = expf(-fabsf(xf));
+    loss += fmaxf(xt, 0.f) - xt + log1pf(et);
+    loss += fmaxf(xf, 0.f) + log1pf(ef);
+    float st = xt >= 0.f ? 1.f / (1.f + et) : et / (1.f + et);
+    float sf = xf >= 0.f ? 1.f / (1.f + ef) : ef / (1.f + ef);
+    sgt += (st - 1.f) * inv;
+    sgf += sf * inv;
+  }
+  t = block_sum(loss, sm);
+  if (threadIdx.x == 0) loss_out[0] = t * inv;
+  t = block_sum(sgt, sm);
+  if (threadIdx.x == 0) s_gt = t;
+  t = block_sum(sgf, sm);
+  if (threadIdx.x == 0) s_gf = t;
+  __syncthreads();
+  if (d_true || d_gen) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      float xt = dt[i] - mg, xf = dg[i] - mt;
+      float et = expf(-fabsf(xt)), ef = expf(-fabsf(xf));
+      float st = xt >= 0.f ? 1.f / (1.f + et) : et / (1.f + et);
+      float sf = xf >= 0.f ? 1.f / (1.f + ef) : ef / (1.f + ef);
+      float gt = (st - 1.f) * inv, gf = sf * inv;
+      if (d_true) d_true[i] = scale * (gt - s_gf / n);
+      if (d_gen) d_gen[i] = scale * (gf - s_gt / n);
+    }
+  }
+}
+
+// -------------------------------------------------------------------- Adam
+__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, float alpha, float omb1, float omb2,
+                            float eps) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += stride) {
+    float4 gw = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float4 ww = reinterpret_cast<float4*>(w)[i];
+#define S3_ADAM1(q)                                   \
+    mm.q += (gw.q - mm.q) * omb1;                     \
+    vv.q += (gw.q * gw.q - vv.q) * omb2;              \
+    ww.q -= (mm.q * alpha) / (sqrtf(vv.q) + eps);
+    S3_ADAM1(x) S3_ADAM1(y) S3_ADAM1(z) S3_ADAM1(w)
+#undef S3_ADAM1
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    reinterpret_cast<float4*>(w)[i] = ww;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       i < n; i += stride) {
+    float gi = g[i];
+    float mi = m[i] + (gi - m[i]) * omb1;
+    float vi = v[i] + (gi * gi - v[i]) * omb2;
+    m[i] = mi; v[i] = vi;
+    w[i] -= (mi * alpha) / (sqrtf(vi) + eps);
+  }
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ src, int c_src,
+                                     int c0_src, float* __restrict__ dst,
+                                     int c_dst, int c0_dst, int nc,
+                                     int64_t n_pos, int accumulate) {
+  const int64_t total = n_pos * nc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t p = i / nc;
+    int c = (int)(i % nc);
+    float v = src[p * c_src + c0_src + c];
+    float* d = dst + p * c_dst + c0_dst + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+struct Affine8 { float scale[16]; float shift[16]; };
+__global__ void affine_channels_kernel(const float* __restrict__ src,
+                                       float* __restrict__ dst, int c,
+                                       int64_t n, Affine8 a) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int ch = (int)(i % c);
+    dst[i] = src[i] * a.scale[ch] + a.shift[ch];
+  }
+}
+
+}  // namespace
+
+// ================================================================ launchers
+int ensure_scratch(s3_ctx* ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return S3_OK;
+  if (ctx->scratch) {
+    S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    S3_HIP(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+  }
+  size_t want = bytes < (size_t)(1 << 20) ? (size_t)(1 << 20) : bytes;
+  S3_HIP(ctx, hipMalloc((void**)&ctx->scratch, want));
+  ctx->scratch_bytes = want;
+  return S3_OK;
+}
+
+int launch_gather(s3_ctx* ctx, const GatherGeom& g, const float* in, float* out) {
+  bool vec = (g.Co % 4 == 0) && (g.Ci % 4 == 0) &&
+             (g.kind != S3_OP_CONCAT || (g.c_off % 4 == 0 && g.rep % 4 == 0));
+  int64_t n = (int64_t)g.N * g.Do[0] * g.Do[1] * g.Do[2] * (g.Co / (vec ? 4 : 1));
+  int grid = grid_for(n, ctx->num_cu);
+  if (vec) hipLaunchKernelGGL(gather_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, in, out, g);
+  else hipLaunchKernelGGL(gather_kernel<1>, dim3(grid), dim3(kBlock), 0, ctx->stream, in, out, g);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
+                      float* din) {
+  int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, dout, din, g);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_act(s3_ctx* ctx, const float* x, float* y, int64_t n, int act,
+               float alpha) {
+  hipLaunchKernelGGL(act_kernel, dim3(grid_for(n / 4 + 1, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, x, y, n, act, alpha);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_act_bwd(s3_ctx* ctx, const float* y, const float* dy, float* dx,
+                   int64_t n, int act, float alpha) {
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, y, dy, dx, n, act, alpha);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
+                             const float* dy, float* dpre) {
+  int64_t n = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout;
+  hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, y, dy, dpre, g);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
+               int c, int bcast_c) {
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, a, b, y, n, c, bcast_c);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, x, y, n);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_fill(s3_ctx* ctx, float* p, int64_t n, float v) {
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, p, n, v);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
+                     float* db, int accumulate) {
+  if (c > 1024) S3_FAIL(ctx, S3_EINVAL, "bias_grad: more than 1024 channels");
+  int block = c <= 256 ? 256 : 1024;
+  int rows = block / c;
+  int64_t want = (n_pos + rows - 1) / rows;
+  int nblk = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
+  int rc = ensure_scratch(ctx, (size_t)nblk * c * sizeof(float));
+  if (rc) return rc;
+  hipLaunchKernelGGL(bias_grad_stage1, dim3(nblk), dim3(block), block * sizeof(float), ctx->stream, dy, n_pos, c, ctx->scratch);
+  hipLaunchKernelGGL(bias_grad_stage2, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, ctx->scratch, nblk, c, db, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_mean_abs(s3_ctx* ctx, const float* p, int64_t n, float* out_dev) {
+  int nblk = grid_for(n, ctx->num_cu);
+  if (nblk > 1024) nblk = 1024;
+  int rc = ensure_scratch(ctx, (size_t)(nblk + 4) * sizeof(float));
+  if (rc) return rc;
+  hipLaunchKernelGGL(mean_abs_stage1, dim3(nblk), dim3(kBlock), 0, ctx->stream, p, n, ctx->scratch);
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->scratch, nblk, 1.f / (float)n, out_dev, 0);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
+                int64_t n, float alpha, float b1, float b2, float eps) {
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, w, g, m, v, n, alpha, 1.f - b1, 1.f - b2, eps);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_loss_content(s3_ctx* ctx, int kind, const float* a, int c_a,
+                               const float* b, int c_b, int c_used,
+                               int64_t n_pos, float weight, float* loss_out,
+                               float* d_a, int accumulate) {
+  if (!ctx) return S3_EINVAL;
+  if (c_used > c_a || c_used > c_b) S3_FAIL(ctx, S3_EINVAL, "loss_content: c_used exceeds channel counts");
+  int64_t total = n_pos * c_used;
+  int nblk = grid_for(total, ctx->num_cu);
+  if (nblk > 1024) nblk = 1024;
+  int rc = ensure_scratch(ctx, (size_t)(nblk + 4) * sizeof(float));
+  if (rc) return rc;
+  float gscale = weight / (float)total;
+  hipLaunchKernelGGL(loss_content_kernel, dim3(nblk), dim3(kBlock), 0, ctx->stream, kind, a, c_a, b, c_b, c_used, n_pos, gscale, ctx->scratch, d_a, accumulate);
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->scratch, nblk, 1.f / (float)total, loss_out, 0);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_loss_rel_bce(s3_ctx* ctx, const float* disc_true,
+                               const float* disc_gen, int n, float scale,
+                               float* loss_out, float* d_true, float* d_gen) {
+  if (!ctx) return S3_EINVAL;
+  hipLaunchKernelGGL(rel_bce_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, disc_true, disc_gen, n, scale, loss_out, d_true, d_gen);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_copy_channels(s3_ctx* ctx, const float* src, int c_src,
+                                int c0_src, float* dst, int c_dst, int c0_dst,
+                                int nc, int64_t n_pos, int accumulate) {
+  if (!ctx) return S3_EINVAL;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(n_pos * nc, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, src, c_src, c0_src, dst, c_dst, c0_dst, nc, n_pos, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_affine_channels(s3_ctx* ctx, const float* src, float* dst,
+                                  int c, int64_t n_pos, const float* scale_host,
+                                  const float* shift_host) {
+  if (!ctx) return S3_EINVAL;
+  if (c > 16) S3_FAIL(ctx, S3_EINVAL, "affine_channels supports at most 16 channels");
+  Affine8 a;
+  for (int i = 0; i < c; ++i) { a.scale[i] = scale_host[i]; a.shift[i] = shift_host[i]; }
+  int64_t n = n_pos * c;
+  hipLaunchKernelGGL(affine_channels_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, src, dst, c, n, a);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_fill(s3_ctx* ctx, float* dst, int64_t n, float value) {
+  if (!ctx) return S3_EINVAL;
+  return launch_fill(ctx, dst, n, value);
+}

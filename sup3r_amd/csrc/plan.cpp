@@ -1,0 +1,680 @@
+// Context, parameter store and the shape-specialised plan executor of
+// libsup3r_hip.so (host side, C++).  The executor replaces the eager keras
+// layer loops of sup3r (abstract.py:1131-1173, base.py:283-313) and
+// tf.GradientTape (abstract.py:1230-1237): a fused op list runs on one HIP
+// stream out of a statically planned activation arena; the backward pass walks
+// the same list in reverse.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+#include "common.h"
+
+struct Param {
+  int64_t offset, size;
+};
+
+struct s3_params {
+  s3_ctx* ctx = nullptr;
+  std::vector<Param> p;
+  int64_t total = 0;
+  float* buf[4] = {nullptr, nullptr, nullptr, nullptr};  // W, G, M, V
+  uint64_t version = 1;  // bumped whenever W changes (re-pack trigger)
+};
+
+struct TensorRec {
+  int64_t dims[5];
+  int64_t numel = 0;
+  int buffer = -1;      // arena buffer id (-1: external input)
+  int alias_root = -1;  // tensor id this one aliases (VIEW)
+  float* ptr = nullptr;
+  float* gptr = nullptr;  // gradient buffer (training plans)
+  bool is_input = false;
+};
+
+struct OpRec {
+  s3_op_desc d;
+  ConvGeom cg;
+  GatherGeom gg;
+  bool mfma = false;
+  void* packed = nullptr;
+  uint64_t packed_version = 0;
+};
+
+struct s3_plan {
+  s3_ctx* ctx = nullptr;
+  s3_params* params = nullptr;
+  std::vector<TensorRec> t;
+  std::vector<OpRec> ops;
+  std::vector<int32_t> inputs;
+  int32_t output = -1;
+  int precision = S3_PREC_F32;
+  int training = 0;
+  std::vector<float*> buffers;
+  std::vector<size_t> buffer_bytes;
+  std::vector<void*> owned;  // every hipMalloc of this plan
+  float* dpre = nullptr;      // conv/dense epilogue-adjoint workspace
+  float* gtmp = nullptr;      // gradient staging when a tensor has >1 consumer
+  float* wg_partial = nullptr;
+  size_t wg_partial_bytes = 0;
+  size_t total_bytes = 0;
+  bool forward_done = false;
+  std::vector<char> gwritten;
+};
+
+static int plan_alloc(s3_plan* pl, void** out, size_t bytes) {
+  s3_ctx* ctx = pl->ctx;
+  if (bytes == 0) bytes = 16;
+  S3_HIP(ctx, hipMalloc(out, bytes));
+  pl->owned.push_back(*out);
+  pl->total_bytes += bytes;
+  return S3_OK;
+}
+
+// ------------------------------------------------------------------ context
+extern "C" int s3_ctx_create(int device_id, void* stream, s3_ctx** out) {
+  if (!out) return S3_EINVAL;
+  s3_ctx* ctx = new s3_ctx();
+  ctx->device = device_id;
+  hipError_t e = hipSetDevice(device_id);
+  if (e != hipSuccess) {
+    // keep the object so the caller can read the message
+    ctx->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    *out = ctx;
+    return S3_EHIP;
+  }
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      ctx->err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+      *out = ctx;
+      return S3_EHIP;
+    }
+    ctx->own_stream = true;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess)
+    ctx->num_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return S3_OK;
+}
+
+extern "C" void s3_ctx_destroy(s3_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* s3_last_error(const s3_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : "null context";
+}
+
+extern "C" int s3_ctx_sync(s3_ctx* ctx) {
+  if (!ctx) return S3_EINVAL;
+  S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return S3_OK;
+}
+
+extern "C" void* s3_ctx_stream(s3_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" const char* s3_version(void) { return "sup3r_hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------- params
+extern "C" int s3_params_create(s3_ctx* ctx, int n, const int64_t* sizes,
+                                s3_params** out) {
+  if (!ctx || !out || n < 0) return S3_EINVAL;
+  s3_params* p = new s3_params();
+  p->ctx = ctx;
+  int64_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    if (sizes[i] <= 0) { delete p; S3_FAIL(ctx, S3_EINVAL, "params_create: non-positive size"); }
+    p->p.push_back({off, sizes[i]});
+    off += (sizes[i] + 3) / 4 * 4;  // keep every tensor 16-B aligned
+  }
+  p->total = off;
+  size_t bytes = (size_t)(off > 0 ? off : 4) * sizeof(float);
+  for (int k = 0; k < 4; ++k) {
+    hipError_t e = hipMalloc((void**)&p->buf[k], bytes);
+    if (e != hipSuccess) {
+      ctx->err = std::string("params hipMalloc: ") + hipGetErrorString(e);
+      for (int q = 0; q < k; ++q) (void)hipFree(p->buf[q]);
+      delete p;
+      return S3_ENOMEM;
+    }
+    S3_HIP(ctx, hipMemsetAsync(p->buf[k], 0, bytes, ctx->stream));
+  }
+  *out = p;
+  return S3_OK;
+}
+
+extern "C" void s3_params_destroy(s3_params* p) {
+  if (!p) return;
+  (void)hipStreamSynchronize(p->ctx->stream);
+  for (int k = 0; k < 4; ++k)
+    if (p->buf[k]) (void)hipFree(p->buf[k]);
+  delete p;
+}
+
+extern "C" int64_t s3_params_total(const s3_params* p) { return p ? p->total : 0; }
+
+static int params_check(s3_params* p, int which, int idx) {
+  if (!p) return S3_EINVAL;
+  if (which < 0 || which > 3 || idx < 0 || idx >= (int)p->p.size())
+    S3_FAIL(p->ctx, S3_EINVAL, "params: bad buffer / index");
+  return S3_OK;
+}
+
+extern "C" int s3_params_set(s3_params* p, int which, int idx, const float* host) {
+  int rc = params_check(p, which, idx);
+  if (rc) return rc;
+  s3_ctx* ctx = p->ctx;
+  S3_HIP(ctx, hipMemcpyAsync(p->buf[which] + p->p[idx].offset, host,
+                             p->p[idx].size * sizeof(float),
+                             hipMemcpyHostToDevice, ctx->stream));
+  S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (which == S3_BUF_W) p->version++;
+  return S3_OK;
+}
+
+extern "C" int s3_params_get(s3_params* p, int which, int idx, float* host) {
+  int rc = params_check(p, which, idx);
+  if (rc) return rc;
+  s3_ctx* ctx = p->ctx;
+  S3_HIP(ctx, hipMemcpyAsync(host, p->buf[which] + p->p[idx].offset,
+                             p->p[idx].size * sizeof(float),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return S3_OK;
+}
+
+extern "C" void* s3_params_dptr(s3_params* p, int which, int idx) {
+  if (!p || which < 0 || which > 3) return nullptr;
+  if (idx < 0) return p->buf[which];
+  if (idx >= (int)p->p.size()) return nullptr;
+  return p->buf[which] + p->p[idx].offset;
+}
+
+extern "C" int s3_params_zero_grad(s3_params* p) {
+  if (!p) return S3_EINVAL;
+  s3_ctx* ctx = p->ctx;
+  S3_HIP(ctx, hipMemsetAsync(p->buf[S3_BUF_G], 0, (size_t)p->total * sizeof(float), ctx->stream));
+  return S3_OK;
+}
+
+extern "C" int s3_params_mean_abs(s3_params* p, int which, int idx, float* host_out) {
+  int rc = params_check(p, which, idx);
+  if (rc) return rc;
+  s3_ctx* ctx = p->ctx;
+  rc = ensure_scratch(ctx, 1 << 20);
+  if (rc) return rc;
+  // result lands in the last float of the 1 MiB minimum scratch
+  float* out_dev = ctx->scratch + (ctx->scratch_bytes / sizeof(float)) - 1;
+  rc = launch_mean_abs(ctx, p->buf[which] + p->p[idx].offset, p->p[idx].size, out_dev);
+  if (rc) return rc;
+  S3_HIP(ctx, hipMemcpyAsync(host_out, out_dev, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return S3_OK;
+}
+
+extern "C" int s3_adam_step(s3_params* p, float lr, float beta1, float beta2,
+                            float eps, int64_t t) {
+  if (!p || t < 1) return S3_EINVAL;
+  // keras-2.15 Adam.update_step, evaluated in fp32 like the reference
+  float b1p = powf(beta1, (float)t), b2p = powf(beta2, (float)t);
+  float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+  int rc = launch_adam(p->ctx, p->buf[S3_BUF_W], p->buf[S3_BUF_G], p->buf[S3_BUF_M],
+                       p->buf[S3_BUF_V], p->total, alpha, beta1, beta2, eps);
+  if (rc) return rc;
+  p->version++;
+  return S3_OK;
+}
+
+// --------------------------------------------------------------------- plan
+static int64_t numel5(const int64_t* d) { return d[0] * d[1] * d[2] * d[3] * d[4]; }
+
+static int root_of(const s3_plan* pl, int t) {
+  while (pl->t[t].alias_root >= 0) t = pl->t[t].alias_root;
+  return t;
+}
+
+static void fill_conv_geom(const s3_plan* pl, const s3_op_desc& d, ConvGeom& g) {
+  const TensorRec& in = pl->t[d.in0];
+  const TensorRec& out = pl->t[d.out];
+  g.N = (int)in.dims[0];
+  for (int i = 0; i < 3; ++i) {
+    g.D[i] = (int)in.dims[1 + i];
+    g.k[i] = d.k[i]; g.s[i] = d.stride[i]; g.lo[i] = d.lo[i];
+  }
+  const int b = d.d2s < 1 ? 1 : d.d2s;
+  g.O[0] = (int)out.dims[1] / b; g.O[1] = (int)out.dims[2] / b; g.O[2] = (int)out.dims[3];
+  g.Cin = (int)in.dims[4];
+  g.Cout = (int)out.dims[4] * b * b;
+  g.pad_mode = d.pad_mode; g.act = d.act; g.alpha = d.alpha; g.d2s = b;
+}
+
+static void fill_gather_geom(const s3_plan* pl, const s3_op_desc& d, GatherGeom& g) {
+  const TensorRec& in = pl->t[d.in0];
+  const TensorRec& out = pl->t[d.out];
+  g.kind = d.kind; g.N = (int)in.dims[0];
+  for (int i = 0; i < 3; ++i) {
+    g.Di[i] = (int)in.dims[1 + i]; g.Do[i] = (int)out.dims[1 + i]; g.lo[i] = d.lo[i];
+  }
+  g.Ci = (int)in.dims[4]; g.Co = (int)out.dims[4];
+  g.pad_mode = d.pad_mode; g.rep = d.rep; g.d2s = d.d2s; g.c_off = 0;
+}
+
+extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
+                              const s3_tensor_desc* tensors, int n_tensors,
+                              const s3_op_desc* ops, int n_ops,
+                              const int32_t* inputs, int n_inputs,
+                              int32_t output, int precision, int training,
+                              s3_plan** out) {
+  if (!ctx || !params || !tensors || !ops || !out) return S3_EINVAL;
+  if (output < 0 || output >= n_tensors) S3_FAIL(ctx, S3_EINVAL, "plan: bad output id");
+  s3_plan* pl = new s3_plan();
+  pl->ctx = ctx; pl->params = params; pl->precision = precision;
+  pl->training = training; pl->output = output;
+  pl->t.resize(n_tensors);
+  for (int i = 0; i < n_tensors; ++i) {
+    memcpy(pl->t[i].dims, tensors[i].dims, sizeof(int64_t) * 5);
+    pl->t[i].numel = numel5(tensors[i].dims);
+    if (pl->t[i].numel <= 0) { delete pl; S3_FAIL(ctx, S3_EINVAL, "plan: empty tensor"); }
+  }
+  for (int i = 0; i < n_inputs; ++i) {
+    if (inputs[i] < 0 || inputs[i] >= n_tensors) { delete pl; S3_FAIL(ctx, S3_EINVAL, "plan: bad input id"); }
+    pl->inputs.push_back(inputs[i]);
+    pl->t[inputs[i]].is_input = true;
+  }
+  auto bad = [&](const char* m) { ctx->err = m; delete pl; return S3_EINVAL; };
+  const int np = (int)params->p.size();
+  pl->ops.resize(n_ops);
+  size_t max_dpre = 0, max_partial = 0, max_t = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    OpRec& o = pl->ops[i];
+    o.d = ops[i];
+    const s3_op_desc& d = o.d;
+    auto tid_ok = [&](int id, bool opt) { return (opt && id < 0) || (id >= 0 && id < n_tensors); };
+    if (!tid_ok(d.in0, false) || !tid_ok(d.out, false) || !tid_ok(d.in1, true) || !tid_ok(d.res, true))
+      return bad("plan: op references a bad tensor id");
+    if (d.w >= np || d.b >= np) return bad("plan: op references a bad parameter id");
+    switch (d.kind) {
+      case S3_OP_CONV: {
+        if (d.w < 0) return bad("plan: conv without weights");
+        fill_conv_geom(pl, d, o.cg);
+        const ConvGeom& g = o.cg;
+        int64_t wsz = (int64_t)g.k[0] * g.k[1] * g.k[2] * g.Cin * g.Cout;
+        if (params->p[d.w].size != wsz) return bad("plan: conv weight size mismatch");
+        if (d.b >= 0 && params->p[d.b].size != g.Cout) return bad("plan: conv bias size mismatch");
+        const TensorRec& ot = pl->t[d.out];
+        if (ot.dims[0] != g.N || ot.dims[4] * g.d2s * g.d2s != g.Cout)
+          return bad("plan: conv output shape mismatch");
+        for (int q = 0; q < 3; ++q) {
+          if (g.s[q] < 1 || g.k[q] < 1) return bad("plan: bad conv geometry");
+          int mx = (g.O[q] - 1) * g.s[q] + g.k[q] - 1 - g.lo[q];
+          if (g.pad_mode == S3_PAD_REFLECT &&
+              (g.lo[q] > g.D[q] - 1 || mx > 2 * (g.D[q] - 1)))
+            return bad("plan: reflect padding exceeds the tensor extent");
+        }
+        if (d.res >= 0 && pl->t[d.res].numel != ot.numel) return bad("plan: residual shape mismatch");
+        o.mfma = conv_mfma_supported(g, precision);
+        size_t ysz = (size_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout * sizeof(float);
+        max_dpre = std::max(max_dpre, ysz);
+        max_partial = std::max(max_partial, conv_generic_wgrad_partial_bytes(g));
+      } break;
+      case S3_OP_DENSE: {
+        if (d.w < 0) return bad("plan: dense without weights");
+        const TensorRec& it = pl->t[d.in0];
+        const TensorRec& ot = pl->t[d.out];
+        if (params->p[d.w].size != it.dims[4] * ot.dims[4]) return bad("plan: dense weight size mismatch");
+        max_dpre = std::max(max_dpre, (size_t)ot.numel * sizeof(float));
+      } break;
+      case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
+      case S3_OP_ROLL_T:
+        fill_gather_geom(pl, d, o.gg);
+        break;
+      case S3_OP_CONCAT:
+        if (d.in1 < 0) return bad("plan: concat without second input");
+        break;
+      case S3_OP_ADD:
+        if (d.in1 < 0) return bad("plan: add without second input");
+        break;
+      case S3_OP_ACT: break;
+      case S3_OP_VIEW:
+        if (pl->t[d.in0].numel != pl->t[d.out].numel) return bad("plan: view changes element count");
+        pl->t[d.out].alias_root = d.in0;
+        break;
+      default:
+        return bad("plan: unknown op kind");
+    }
+  }
+  // ---- static arena planning.  Training keeps every tensor; inference
+  // reuses buffers by liveness (greedy best-fit).
+  std::vector<int> last_use(n_tensors, -1);
+  for (int i = 0; i < n_ops; ++i) {
+    const s3_op_desc& d = pl->ops[i].d;
+    int ids[4] = {d.in0, d.in1, d.res, d.out};
+    for (int q = 0; q < 4; ++q)
+      if (ids[q] >= 0) last_use[root_of(pl, ids[q])] = i;
+  }
+  last_use[root_of(pl, output)] = n_ops + 1;
+  std::vector<size_t> bsize;
+  std::vector<int> bfree_at;  // op index after which the buffer is free
+  for (int i = 0; i < n_ops; ++i) {
+    const s3_op_desc& d = pl->ops[i].d;
+    if (d.kind == S3_OP_VIEW) continue;
+    TensorRec& ot = pl->t[d.out];
+    size_t need = (size_t)ot.numel * sizeof(float);
+    int pick = -1;
+    if (!training) {
+      for (int b = 0; b < (int)bsize.size(); ++b)
+        if (bfree_at[b] < i && bsize[b] >= need &&
+            (pick < 0 || bsize[b] < bsize[pick]))
+          pick = b;
+    }
+    if (pick < 0) { bsize.push_back(need); bfree_at.push_back(0); pick = (int)bsize.size() - 1; }
+    ot.buffer = pick;
+    bfree_at[pick] = last_use[d.out];
+    max_t = std::max(max_t, need);
+  }
+  for (int i = 0; i < n_tensors; ++i) max_t = std::max(max_t, (size_t)pl->t[i].numel * sizeof(float));
+  pl->buffers.resize(bsize.size());
+  pl->buffer_bytes = bsize;
+  for (size_t b = 0; b < bsize.size(); ++b) {
+    int rc = plan_alloc(pl, (void**)&pl->buffers[b], bsize[b]);
+    if (rc) { s3_plan_destroy(pl); return rc; }
+  }
+  for (int i = 0; i < n_tensors; ++i)
+    if (pl->t[i].buffer >= 0) pl->t[i].ptr = pl->buffers[pl->t[i].buffer];
+  if (training) {
+    for (int i = 0; i < n_tensors; ++i) {
+      if (pl->t[i].alias_root >= 0) continue;
+      int rc = plan_alloc(pl, (void**)&pl->t[i].gptr, (size_t)pl->t[i].numel * sizeof(float));
+      if (rc) { s3_plan_destroy(pl); return rc; }
+    }
+    int rc = plan_alloc(pl, (void**)&pl->dpre, max_dpre);
+    if (!rc) rc = plan_alloc(pl, (void**)&pl->gtmp, max_t);
+    if (!rc && max_partial) {
+      rc = plan_alloc(pl, (void**)&pl->wg_partial, max_partial);
+      pl->wg_partial_bytes = max_partial;
+    }
+    if (rc) { s3_plan_destroy(pl); return rc; }
+  }
+  // packed weights of the MFMA convs
+  for (auto& o : pl->ops) {
+    if (o.d.kind == S3_OP_CONV && o.mfma) {
+      int rc = plan_alloc(pl, &o.packed, conv_mfma_packed_bytes(o.cg, precision));
+      if (rc) { s3_plan_destroy(pl); return rc; }
+    }
+  }
+  pl->gwritten.assign(n_tensors, 0);
+  *out = pl;
+  return S3_OK;
+}
+
+extern "C" void s3_plan_destroy(s3_plan* pl) {
+  if (!pl) return;
+  (void)hipStreamSynchronize(pl->ctx->stream);
+  for (void* p : pl->owned) (void)hipFree(p);
+  delete pl;
+}
+
+extern "C" void* s3_plan_tensor(s3_plan* pl, int32_t id) {
+  if (!pl || id < 0 || id >= (int)pl->t.size()) return nullptr;
+  return pl->t[root_of(pl, id)].ptr;
+}
+
+extern "C" int64_t s3_plan_workspace_bytes(const s3_plan* pl) {
+  return pl ? (int64_t)pl->total_bytes : 0;
+}
+
+static float* tptr(s3_plan* pl, int id) { return pl->t[root_of(pl, id)].ptr; }
+static float* gptr(s3_plan* pl, int id) { return pl->t[root_of(pl, id)].gptr; }
+
+static int run_op_forward(s3_plan* pl, OpRec& o) {
+  s3_ctx* ctx = pl->ctx;
+  s3_params* P = pl->params;
+  const s3_op_desc& d = o.d;
+  float* W = P->buf[S3_BUF_W];
+  const TensorRec& ot = pl->t[d.out];
+  switch (d.kind) {
+    case S3_OP_CONV: {
+      const float* w = W + P->p[d.w].offset;
+      const float* b = d.b >= 0 ? W + P->p[d.b].offset : nullptr;
+      const float* res = d.res >= 0 ? tptr(pl, d.res) : nullptr;
+      if (o.mfma) {
+        if (o.packed_version != P->version) {
+          int rc = launch_conv_mfma_pack(ctx, o.cg, pl->precision, w, o.packed);
+          if (rc) return rc;
+          o.packed_version = P->version;
+        }
+        const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.packed : (const void*)w;
+        return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out));
+      }
+      return launch_conv_generic_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out));
+    }
+    case S3_OP_DENSE: {
+      const TensorRec& it = pl->t[d.in0];
+      const float* w = W + P->p[d.w].offset;
+      const float* b = d.b >= 0 ? W + P->p[d.b].offset : nullptr;
+      int rows = (int)(it.numel / it.dims[4]);
+      return launch_dense_fwd(ctx, tptr(pl, d.in0), w, b, tptr(pl, d.out), rows, (int)it.dims[4], (int)ot.dims[4], d.act, d.alpha);
+    }
+    case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
+    case S3_OP_ROLL_T:
+      return launch_gather(ctx, o.gg, tptr(pl, d.in0), tptr(pl, d.out));
+    case S3_OP_CONCAT: {
+      // two channel-range copies: x -> out[..., :Cx], exo -> out[..., Cx:]
+      const TensorRec& a = pl->t[d.in0];
+      const TensorRec& b = pl->t[d.in1];
+      int64_t npos = ot.numel / ot.dims[4];
+      int rc = s3_copy_channels(ctx, tptr(pl, d.in0), (int)a.dims[4], 0, tptr(pl, d.out), (int)ot.dims[4], 0, (int)a.dims[4], npos, 0);
+      if (rc) return rc;
+      return s3_copy_channels(ctx, tptr(pl, d.in1), (int)b.dims[4], 0, tptr(pl, d.out), (int)ot.dims[4], (int)a.dims[4], (int)b.dims[4], npos, 0);
+    }
+    case S3_OP_ADD:
+      return launch_add(ctx, tptr(pl, d.in0), tptr(pl, d.in1), tptr(pl, d.out), ot.numel, (int)ot.dims[4], d.bcast_c);
+    case S3_OP_ACT:
+      return launch_act(ctx, tptr(pl, d.in0), tptr(pl, d.out), ot.numel, d.act, d.alpha);
+    case S3_OP_VIEW:
+      return S3_OK;
+  }
+  S3_FAIL(ctx, S3_EINVAL, "forward: unknown op");
+}
+
+static int bind_inputs(s3_plan* pl, const void* const* inputs) {
+  for (size_t i = 0; i < pl->inputs.size(); ++i) {
+    if (!inputs || !inputs[i]) S3_FAIL(pl->ctx, S3_EINVAL, "forward: null input pointer");
+    pl->t[pl->inputs[i]].ptr = (float*)inputs[i];
+  }
+  return S3_OK;
+}
+
+extern "C" int s3_plan_forward(s3_plan* pl, const void* const* inputs, void* output) {
+  if (!pl) return S3_EINVAL;
+  s3_ctx* ctx = pl->ctx;
+  int rc = bind_inputs(pl, inputs);
+  if (rc) return rc;
+  for (auto& o : pl->ops) {
+    rc = run_op_forward(pl, o);
+    if (rc) return rc;
+  }
+  if (output) {
+    S3_HIP(ctx, hipMemcpyAsync(output, tptr(pl, pl->output),
+                               (size_t)pl->t[pl->output].numel * sizeof(float),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  pl->forward_done = true;
+  return S3_OK;
+}
+
+extern "C" int s3_plan_profile_forward(s3_plan* pl, const void* const* inputs,
+                                       float* ms_per_op, int cap) {
+  if (!pl || !ms_per_op) return S3_EINVAL;
+  s3_ctx* ctx = pl->ctx;
+  int rc = bind_inputs(pl, inputs);
+  if (rc) return rc;
+  const int n = (int)pl->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) S3_HIP(ctx, hipEventCreate(&e));
+  S3_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+  for (int i = 0; i < n; ++i) {
+    rc = run_op_forward(pl, pl->ops[i]);
+    if (rc) return rc;
+    S3_HIP(ctx, hipEventRecord(ev[i + 1], ctx->stream));
+  }
+  S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n && i < cap; ++i)
+    S3_HIP(ctx, hipEventElapsedTime(&ms_per_op[i], ev[i], ev[i + 1]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  pl->forward_done = true;
+  return n < cap ? n : cap;
+}
+
+// deliver a gradient contribution `src` (numel floats) to tensor `id`
+static int grad_deliver(s3_plan* pl, int id, const float* src) {
+  int r = root_of(pl, id);
+  TensorRec& t = pl->t[r];
+  s3_ctx* ctx = pl->ctx;
+  if (!pl->gwritten[r]) {
+    if (src != t.gptr)
+      S3_HIP(ctx, hipMemcpyAsync(t.gptr, src, (size_t)t.numel * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    pl->gwritten[r] = 1;
+    return S3_OK;
+  }
+  return launch_axpy(ctx, src, t.gptr, t.numel);
+}
+
+// destination a backward kernel should write dL/d(tensor id) into
+static float* grad_dest(s3_plan* pl, int id) {
+  int r = root_of(pl, id);
+  return pl->gwritten[r] ? pl->gtmp : pl->t[r].gptr;
+}
+
+extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input,
+                                int need_wgrad, int accumulate_wgrad) {
+  if (!pl || !d_output) return S3_EINVAL;
+  s3_ctx* ctx = pl->ctx;
+  if (!pl->training) S3_FAIL(ctx, S3_ESTATE, "backward on an inference plan");
+  if (!pl->forward_done) S3_FAIL(ctx, S3_ESTATE, "backward before forward");
+  s3_params* P = pl->params;
+  float* W = P->buf[S3_BUF_W];
+  float* G = P->buf[S3_BUF_G];
+  std::fill(pl->gwritten.begin(), pl->gwritten.end(), 0);
+  {
+    int r = root_of(pl, pl->output);
+    S3_HIP(ctx, hipMemcpyAsync(pl->t[r].gptr, d_output, (size_t)pl->t[r].numel * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    pl->gwritten[r] = 1;
+  }
+  const int x_id = pl->inputs.empty() ? -1 : root_of(pl, pl->inputs[0]);
+  auto wants_grad = [&](int id) {
+    int r = root_of(pl, id);
+    if (!pl->t[r].is_input) return true;
+    return r == x_id && d_input != nullptr;
+  };
+  for (int i = (int)pl->ops.size() - 1; i >= 0; --i) {
+    OpRec& o = pl->ops[i];
+    const s3_op_desc& d = o.d;
+    if (d.kind == S3_OP_VIEW) continue;
+    const int ro = root_of(pl, d.out);
+    if (!pl->gwritten[ro]) continue;  // nothing flows through this op
+    const float* dy = pl->t[ro].gptr;
+    const TensorRec& ot = pl->t[d.out];
+    int rc = S3_OK;
+    switch (d.kind) {
+      case S3_OP_CONV: {
+        const ConvGeom& g = o.cg;
+        if (d.res >= 0 && wants_grad(d.res)) {
+          rc = grad_deliver(pl, d.res, dy);
+          if (rc) return rc;
+        }
+        const float* dpre = dy;
+        if (g.act != S3_ACT_NONE || g.d2s > 1) {
+          rc = launch_conv_epilogue_bwd(ctx, g, tptr(pl, d.out), dy, pl->dpre);
+          if (rc) return rc;
+          dpre = pl->dpre;
+        }
+        const int64_t npos = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+        if (need_wgrad) {
+          if (d.b >= 0) {
+            rc = launch_bias_grad(ctx, dpre, npos, g.Cout, G + P->p[d.b].offset, accumulate_wgrad);
+            if (rc) return rc;
+          }
+          rc = launch_conv_generic_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+          if (rc) return rc;
+        }
+        if (wants_grad(d.in0)) {
+          float* dst = grad_dest(pl, d.in0);
+          rc = launch_conv_generic_dgrad(ctx, g, dpre, W + P->p[d.w].offset, dst);
+          if (rc) return rc;
+          rc = grad_deliver(pl, d.in0, dst);
+        }
+      } break;
+      case S3_OP_DENSE: {
+        const TensorRec& it = pl->t[d.in0];
+        const int rows = (int)(it.numel / it.dims[4]);
+        const int cin = (int)it.dims[4], cout = (int)ot.dims[4];
+        const float* dpre = dy;
+        if (d.act != S3_ACT_NONE) {
+          rc = launch_act_bwd(ctx, tptr(pl, d.out), dy, pl->dpre, ot.numel, d.act, d.alpha);
+          if (rc) return rc;
+          dpre = pl->dpre;
+        }
+        if (need_wgrad) {
+          if (d.b >= 0) {
+            rc = launch_bias_grad(ctx, dpre, rows, cout, G + P->p[d.b].offset, accumulate_wgrad);
+            if (rc) return rc;
+          }
+          rc = launch_dense_wgrad(ctx, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, rows, cin, cout, accumulate_wgrad);
+          if (rc) return rc;
+        }
+        if (wants_grad(d.in0)) {
+          float* dst = grad_dest(pl, d.in0);
+          rc = launch_dense_dgrad(ctx, dpre, W + P->p[d.w].offset, dst, rows, cin, cout);
+          if (rc) return rc;
+          rc = grad_deliver(pl, d.in0, dst);
+        }
+      } break;
+      case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
+      case S3_OP_ROLL_T:
+        if (wants_grad(d.in0)) {
+          float* dst = grad_dest(pl, d.in0);
+          rc = launch_gather_bwd(ctx, o.gg, dy, dst);
+          if (rc) return rc;
+          rc = grad_deliver(pl, d.in0, dst);
+        }
+        break;
+      case S3_OP_CONCAT:
+        if (wants_grad(d.in0)) {
+          const TensorRec& a = pl->t[d.in0];
+          float* dst = grad_dest(pl, d.in0);
+          rc = s3_copy_channels(ctx, dy, (int)ot.dims[4], 0, dst, (int)a.dims[4], 0, (int)a.dims[4], a.numel / a.dims[4], 0);
+          if (rc) return rc;
+          rc = grad_deliver(pl, d.in0, dst);
+        }
+        break;
+      case S3_OP_ADD:
+        if (wants_grad(d.in0)) rc = grad_deliver(pl, d.in0, dy);
+        if (!rc && !d.bcast_c && wants_grad(d.in1)) rc = grad_deliver(pl, d.in1, dy);
+        break;
+      case S3_OP_ACT:
+        if (wants_grad(d.in0)) {
+          float* dst = grad_dest(pl, d.in0);
+          rc = launch_act_bwd(ctx, tptr(pl, d.out), dy, dst, ot.numel, d.act, d.alpha);
+          if (rc) return rc;
+          rc = grad_deliver(pl, d.in0, dst);
+        }
+        break;
+      default: break;
+    }
+    if (rc) return rc;
+  }
+  if (d_input) {
+    if (x_id < 0 || !pl->gwritten[x_id]) S3_FAIL(ctx, S3_ESTATE, "backward: no gradient reached the input");
+    S3_HIP(ctx, hipMemcpyAsync(d_input, pl->t[x_id].gptr, (size_t)pl->t[x_id].numel * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return S3_OK;
+}

@@ -1,0 +1,364 @@
+"""Host-side engine: device context, the ``CustomNetwork`` counterpart
+(``Network``) and shape-specialised plans, all thin shims over the C-ABI of
+``libsup3r_hip.so``.  torch is used ONLY as the device-memory container /
+stream owner (``torch.Tensor.data_ptr()`` pointers cross the ABI); no torch op
+computes anything on the hot path.
+
+Mirrors, for the hot path, what sup3r gets from ``phygnn.CustomNetwork``
+(``.layers``, ``.weights``, ``.save`` / ``.load`` — sup3r/models/abstract.py:
+57-111,312-319; base.py:133-214).
+"""
+import ctypes as C
+import os
+import pickle
+
+import numpy as np
+
+from . import _lib
+from . import spec as S
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Device:
+    """One HIP context per (process, GPU): owns the s3_ctx bound to torch's
+    current stream on that device."""
+
+    _cache = {}
+
+    def __init__(self, index=0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                'sup3r_amd needs an AMD GPU (torch.cuda.is_available() is '
+                'False); there is no CPU fallback')
+        self.index = index
+        self.torch_device = torch.device('cuda', index)
+        L = _lib.lib()
+        with torch.cuda.device(index):
+            stream = torch.cuda.current_stream().cuda_stream
+        h = C.c_void_p()
+        rc = L.s3_ctx_create(index, C.c_void_p(stream), C.byref(h))
+        _lib.check(rc, h, 's3_ctx_create')
+        self.ctx = h
+        self.rank, self.nranks = 0, 1
+
+    @classmethod
+    def get(cls, index=None):
+        if index is None:
+            index = int(os.environ.get('LOCAL_RANK', 0))
+        if index not in cls._cache:
+            cls._cache[index] = cls(index)
+        return cls._cache[index]
+
+    def sync(self):
+        _lib.check(_lib.lib().s3_ctx_sync(self.ctx), self.ctx, 'sync')
+
+    def empty(self, shape):
+        torch = _torch()
+        return torch.empty(tuple(int(v) for v in shape), dtype=torch.float32,
+                           device=self.torch_device)
+
+    def to_device(self, arr):
+        """numpy / torch / anything with .numpy() -> contiguous fp32 device
+        tensor (batch payloads are duck-typed like the reference does,
+        preprocessing/utilities.py:255-257)."""
+        torch = _torch()
+        if isinstance(arr, torch.Tensor):
+            return arr.to(device=self.torch_device,
+                          dtype=torch.float32).contiguous()
+        if hasattr(arr, 'numpy') and not isinstance(arr, np.ndarray):
+            arr = arr.numpy()
+        arr = np.ascontiguousarray(np.asarray(arr, dtype=np.float32))
+        return torch.from_numpy(arr).to(self.torch_device)
+
+    def init_comm(self, rank, nranks, unique_id):
+        rc = _lib.lib().s3_comm_init(self.ctx, rank, nranks, unique_id)
+        _lib.check(rc, self.ctx, 's3_comm_init')
+        self.rank, self.nranks = rank, nranks
+
+
+def precision_code(precision=None):
+    precision = precision or os.environ.get('SUP3R_AMD_PRECISION', 'f32')
+    if precision not in _lib.PRECISIONS:
+        raise KeyError(f'precision must be one of {list(_lib.PRECISIONS)}')
+    return _lib.PRECISIONS[precision]
+
+
+class PlanHandle:
+    """One s3_plan (fixed input shape, precision, training flag)."""
+
+    def __init__(self, net, plan, precision, training):
+        L = _lib.lib()
+        self.net, self.plan = net, plan
+        self.dev = net.dev
+        nt, nops = len(plan.tensors), len(plan.ops)
+        tens = (_lib.TensorDesc * nt)()
+        for i, sh in enumerate(plan.tensors):
+            for j in range(5):
+                tens[i].dims[j] = sh[j]
+        ops = (_lib.OpDesc * nops)()
+        for i, op in enumerate(plan.ops):
+            d = ops[i]
+            d.kind = op['kind']
+            d.in0, d.in1 = op.get('in0', -1), op.get('in1', -1)
+            d.res, d.out = op.get('res', -1), op['out']
+            d.w, d.b = op.get('w', -1), op.get('b', -1)
+            for j in range(3):
+                d.k[j] = op.get('k', [1, 1, 1])[j]
+                d.stride[j] = op.get('stride', [1, 1, 1])[j]
+                d.lo[j] = op.get('lo', [0, 0, 0])[j]
+                d.hi[j] = op.get('hi', [0, 0, 0])[j]
+            d.pad_mode = op.get('pad_mode', 0)
+            d.act = op.get('act', 0)
+            d.alpha = op.get('alpha', 0.0)
+            d.d2s = op.get('d2s', 1)
+            d.rep = op.get('rep', 1)
+            d.bcast_c = op.get('bcast_c', 0)
+        self.input_names = list(plan.inputs)
+        inp = (C.c_int32 * len(self.input_names))(
+            *[plan.inputs[k] for k in self.input_names])
+        h = C.c_void_p()
+        rc = L.s3_plan_create(self.dev.ctx, net.params, tens, nt, ops, nops,
+                              inp, len(self.input_names), plan.output,
+                              precision, int(training), C.byref(h))
+        _lib.check(rc, self.dev.ctx, 's3_plan_create')
+        self.h = h
+        self.out_shape = plan.out_shape
+        self.in_shapes = {k: plan.tensors[v] for k, v in plan.inputs.items()}
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                _lib.lib().s3_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _input_ptrs(self, x, exo):
+        ptrs = (C.c_void_p * len(self.input_names))()
+        keep = []
+        for i, name in enumerate(self.input_names):
+            t = x if name == 'x' else exo[name]
+            want = int(np.prod(self.in_shapes[name]))
+            if t.numel() != want:
+                raise RuntimeError(
+                    f'input "{name}" has {tuple(t.shape)} but the plan '
+                    f'expects {self.in_shapes[name]}')
+            keep.append(t)
+            ptrs[i] = t.data_ptr()
+        return ptrs, keep
+
+    def forward(self, x, exo=None, out=None):
+        """x / exo: contiguous fp32 device tensors.  Returns a device tensor of
+        the keras-view output shape."""
+        ptrs, keep = self._input_ptrs(x, exo or {})
+        if out is None:
+            out = self.dev.empty(self.out_shape)
+        rc = _lib.lib().s3_plan_forward(self.h, ptrs, C.c_void_p(out.data_ptr()))
+        _lib.check(rc, self.dev.ctx, 's3_plan_forward')
+        self._keep = keep
+        return out
+
+    def backward(self, d_out, need_dx=False, need_wgrad=True,
+                 accumulate_wgrad=False):
+        dx = None
+        if need_dx:
+            dx = self.dev.empty(self.in_shapes['x'])
+        rc = _lib.lib().s3_plan_backward(
+            self.h, C.c_void_p(d_out.data_ptr()),
+            C.c_void_p(dx.data_ptr()) if dx is not None else None,
+            int(need_wgrad), int(accumulate_wgrad))
+        _lib.check(rc, self.dev.ctx, 's3_plan_backward')
+        return dx
+
+    def profile_forward(self, x, exo=None):
+        """Per-op forward time in ms (HIP events on the ctx stream)."""
+        ptrs, keep = self._input_ptrs(x, exo or {})
+        n = len(self.plan.ops)
+        ms = (C.c_float * n)()
+        rc = _lib.lib().s3_plan_profile_forward(self.h, ptrs, ms, n)
+        if rc < 0:
+            _lib.check(rc, self.dev.ctx, 's3_plan_profile_forward')
+        return [ms[i] for i in range(n)]
+
+    @property
+    def workspace_bytes(self):
+        return int(_lib.lib().s3_plan_workspace_bytes(self.h))
+
+
+class Network:
+    """Counterpart of ``phygnn.CustomNetwork`` for the hot path: ordered layer
+    specs + one device parameter store + cached plans."""
+
+    def __init__(self, hidden_layers, name=None, device=None, precision=None):
+        self.name = name
+        self.layers = S.parse_layers(hidden_layers)
+        self._dev = device
+        self.precision = precision
+        self.params = None
+        self.param_table = None
+        self._plans = {}
+        self._pending = None   # keras-layout weights set before build
+        self._seed = None
+
+    # -- iteration over layers like ``for layer in model.generator``
+    def __iter__(self):
+        return iter(self.layers)
+
+    def __len__(self):
+        return len(self.layers)
+
+    @property
+    def dev(self):
+        if self._dev is None:
+            self._dev = Device.get()
+        return self._dev
+
+    @property
+    def built(self):
+        return self.params is not None
+
+    def build(self, in_shape, seed=None):
+        """Create the parameter store for ``in_shape`` (keras lazy build:
+        glorot_uniform kernels, zero biases — base.py:394-437)."""
+        if self.built:
+            return
+        plan = S.build_plan(self.layers, in_shape)
+        self.param_table = plan.params
+        L = _lib.lib()
+        n = len(plan.params)
+        sizes = (C.c_int64 * max(n, 1))(
+            *[int(np.prod(p['shape'])) for p in plan.params])
+        h = C.c_void_p()
+        rc = L.s3_params_create(self.dev.ctx, n, sizes, C.byref(h))
+        _lib.check(rc, self.dev.ctx, 's3_params_create')
+        self.params = h
+        if self._pending is not None:
+            self.set_weights(self._pending)
+            self._pending = None
+        else:
+            rng = np.random.default_rng(self._seed if seed is None else seed)
+            ws = []
+            for p in plan.params:
+                if p['kind'] == 'kernel':
+                    ws.append(S.glorot_uniform(p['shape'], rng))
+                else:
+                    ws.append(np.zeros(p['shape'], np.float32))
+            self.set_weights(ws)
+
+    def plan(self, in_shape, training=False, precision=None, slot=0):
+        in_shape = tuple(int(v) for v in in_shape)
+        prec = precision_code(precision or self.precision)
+        key = (in_shape, bool(training), prec, slot)
+        if key not in self._plans:
+            self.build(in_shape)
+            plan = S.build_plan(self.layers, in_shape,
+                                param_table=self.param_table)
+            self._plans[key] = PlanHandle(self, plan, prec, training)
+        return self._plans[key]
+
+    def clear_plans(self):
+        self._plans = {}
+
+    # -- weights, keras layout / keras order
+    def _get(self, which):
+        L = _lib.lib()
+        out = []
+        for i, p in enumerate(self.param_table):
+            cshape = S.canonical_shape(p['shape'], p['layout'])
+            buf = np.empty(cshape, np.float32)
+            rc = L.s3_params_get(self.params, which, i,
+                                 buf.ctypes.data_as(C.POINTER(C.c_float)))
+            _lib.check(rc, self.dev.ctx, 's3_params_get')
+            out.append(S.canonical_to_keras(buf, p['layout']))
+        return out
+
+    @property
+    def weights(self):
+        if not self.built:
+            return []
+        return self._get(_lib.BUF_W)
+
+    @property
+    def grads(self):
+        return self._get(_lib.BUF_G)
+
+    def slots(self, which):
+        return self._get({'m': _lib.BUF_M, 'v': _lib.BUF_V}[which])
+
+    def set_weights(self, arrays, which=_lib.BUF_W):
+        if not self.built:
+            self._pending = [np.asarray(a, np.float32) for a in arrays]
+            return
+        arrays = list(arrays)
+        if len(arrays) != len(self.param_table):
+            raise RuntimeError(
+                f'expected {len(self.param_table)} weight arrays, got '
+                f'{len(arrays)}')
+        L = _lib.lib()
+        for i, (a, p) in enumerate(zip(arrays, self.param_table)):
+            a = np.asarray(a, np.float32)
+            if tuple(a.shape) != tuple(p['shape']):
+                raise RuntimeError(
+                    f'weight #{i} has shape {a.shape}, expected {p["shape"]}')
+            c = S.keras_to_canonical(a, p['layout'])
+            rc = L.s3_params_set(self.params, which, i,
+                                 c.ctypes.data_as(C.POINTER(C.c_float)))
+            _lib.check(rc, self.dev.ctx, 's3_params_set')
+
+    def mean_abs(self, which, idx):
+        v = C.c_float()
+        rc = _lib.lib().s3_params_mean_abs(self.params, which, idx,
+                                           C.byref(v))
+        _lib.check(rc, self.dev.ctx, 's3_params_mean_abs')
+        return float(v.value)
+
+    def zero_grad(self):
+        _lib.check(_lib.lib().s3_params_zero_grad(self.params), self.dev.ctx,
+                   'zero_grad')
+
+    def adam_step(self, lr, beta_1, beta_2, epsilon, t):
+        rc = _lib.lib().s3_adam_step(self.params, lr, beta_1, beta_2, epsilon,
+                                     int(t))
+        _lib.check(rc, self.dev.ctx, 's3_adam_step')
+
+    def allreduce_grads(self):
+        rc = _lib.lib().s3_params_allreduce_grads(self.params)
+        _lib.check(rc, self.dev.ctx, 's3_params_allreduce_grads')
+
+    # -- convenience: numpy in / numpy out
+    def __call__(self, x, exo=None, training=False, precision=None):
+        dev = self.dev
+        xd = dev.to_device(x)
+        exod = {k: dev.to_device(v) for k, v in (exo or {}).items()}
+        ph = self.plan(tuple(xd.shape), training=training,
+                       precision=precision)
+        return ph.forward(xd, exod)
+
+    # -- persistence (replaces CustomNetwork.save / .load of the phygnn pkl:
+    # same role, own schema — phygnn's pickle format is not available here)
+    def save(self, fp):
+        with open(fp, 'wb') as f:
+            pickle.dump({'format': 'sup3r_amd.network.v1', 'name': self.name,
+                         'hidden_layers': [dict(L.kwargs, **{'class': L.cls})
+                                           for L in self.layers],
+                         'weights': self.weights}, f)
+
+    @classmethod
+    def load(cls, fp, device=None, precision=None):
+        with open(fp, 'rb') as f:
+            d = pickle.load(f)
+        if not isinstance(d, dict) or d.get('format') != \
+                'sup3r_amd.network.v1':
+            raise TypeError(
+                f'{fp} is not a sup3r_amd network file (phygnn .pkl files '
+                'need phygnn to be converted)')
+        net = cls(d['hidden_layers'], name=d['name'], device=device,
+                  precision=precision)
+        if d['weights']:
+            net._pending = d['weights']
+        return net

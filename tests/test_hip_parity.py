@@ -1,0 +1,211 @@
+"""GPU parity tests (``-m gpu``): the HIP path, called through the C-ABI of
+libsup3r_hip.so, against the numpy oracle on identical seeded inputs.
+
+Tolerances (stated here, fp32 parity mode): forward L-inf < 1e-4 on O(1)
+outputs (north_star asks < 1e-3); gradients relative L-inf < 1e-3.  bf16
+throughput mode is checked separately with its own, looser bound.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CFG = os.path.join(os.path.dirname(__file__), '..', 'sup3r_amd', 'configs')
+
+
+def _load(name):
+    with open(os.path.join(CFG, name)) as f:
+        return json.load(f)
+
+
+def _oracle_net(spec, x, exo, seed=3):
+    from oracle.network import Network
+    net = Network(spec)
+    net.init_weights(x, exo, seed=seed, bias_scale=0.1)
+    return net
+
+
+def _hip_net(spec, weights, precision='f32'):
+    from sup3r_amd.engine import Network
+    net = Network(spec, precision=precision)
+    net.set_weights(weights)
+    return net
+
+
+CASES = [
+    ('test_gen_st_2x_4x_2f.json', (2, 5, 6, 4, 3), None, (2, 10, 12, 16, 2)),
+    ('test_gen_st_3x_4x_2f_topo.json', (1, 4, 5, 4, 2), 'topography',
+     (1, 12, 15, 16, 2)),
+    ('test_gen_s_2x_2f.json', (3, 7, 6, 2), None, (3, 14, 12, 2)),
+    ('test_disc_st_same.json', (2, 12, 12, 16, 2), None, (2, 1)),
+    ('test_disc_s_same.json', (2, 20, 20, 2), None, (2, 1)),
+    ('test_disc_st_valid.json', (2, 14, 13, 15, 2), None, (2, 1)),
+    ('test_gen_st_64ch.json', (1, 6, 5, 12, 3), None, (1, 12, 10, 24, 2)),
+]
+
+
+@pytest.mark.parametrize('cfg,shape,exo_name,out_shape', CASES)
+def test_forward_backward_fp32(cfg, shape, exo_name, out_shape):
+    rng = np.random.default_rng(11)
+    spec = _load(cfg)
+    x = rng.standard_normal(shape).astype(np.float32)
+    exo = None
+    if exo_name:
+        exo = {exo_name: rng.standard_normal(
+            out_shape[:-1] + (1,)).astype(np.float32)}
+    ref = _oracle_net(spec, x, exo)
+    y_ref = ref.forward(x, exo)
+    net = _hip_net(spec, ref.weights)
+    dev = net.dev
+    xd = dev.to_device(x)
+    exod = {k: dev.to_device(v) for k, v in (exo or {}).items()}
+    ph = net.plan(shape, training=True)
+    y = ph.forward(xd, exod).cpu().numpy()
+    assert y.shape == tuple(out_shape)
+    scale = max(1.0, float(np.abs(y_ref).max()))
+    assert np.abs(y - y_ref).max() < 1e-4 * scale
+
+    # weights round-trip bit-exactly through the canonical device layout
+    for a, b in zip(net.weights, ref.weights):
+        np.testing.assert_array_equal(a, b)
+
+    dy = rng.standard_normal(out_shape).astype(np.float32)
+    dx_ref = ref.backward(dy)
+    dx = ph.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
+    dx = dx.reshape(dx_ref.shape)
+    assert np.abs(dx - dx_ref).max() < 1e-3 * max(1e-6, np.abs(dx_ref).max())
+    for g, g_ref in zip(net.grads, ref.grads):
+        assert g.shape == g_ref.shape
+        assert np.abs(g - g_ref).max() < 1e-3 * max(1e-6, np.abs(g_ref).max())
+
+
+def test_mfma_conv_edge_shapes():
+    """Ragged tiles (dims not multiples of the 2x4x16 / 4x4x16 tile), C_out
+    = 200 with depth-to-space 5, residual epilogue: MFMA fp32 vs oracle."""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(5)
+    spec = pcc(3, 64) + [{'class': 'SkipConnection', 'name': 'a'}] + \
+        pcc(3, 64) + pcc(3, 64, act=False) + \
+        [{'class': 'SkipConnection', 'name': 'a'}] + \
+        pcc(3, 200, act=False) + \
+        [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
+         {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    shape = (2, 5, 7, 19, 4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    for prec, tol in (('f32', 1e-4), ('bf16', 4e-2)):
+        net = _hip_net(spec, ref.weights, precision=prec)
+        y = net(x).cpu().numpy()
+        assert y.shape == (2, 25, 35, 19, 8)
+        err = np.abs(y - y_ref).max() / max(1.0, np.abs(y_ref).max())
+        assert err < tol, (prec, err)
+
+
+def test_bf16_mode_tolerance_c2_topology():
+    """bf16 MFMA throughput mode on the 64-channel residual topology; states
+    its own tolerance (bf16 inputs, fp32 accumulate, 10 stacked convs)."""
+    rng = np.random.default_rng(2)
+    spec = _load('test_gen_st_64ch.json')
+    shape = (1, 6, 5, 12, 3)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    net = _hip_net(spec, ref.weights, precision='bf16')
+    y = net(x).cpu().numpy()
+    err = np.abs(y - y_ref).max() / max(1.0, np.abs(y_ref).max())
+    assert err < 3e-2, err
+
+
+def test_c2_generator_forward_vs_oracle():
+    """BASELINE config C2 at its full size: (1,16,16,24,4) ->
+    (1,80,80,288,2), fp32 parity mode, L-inf < 1e-3 (north_star)."""
+    rng = np.random.default_rng(42)
+    spec = _load('gen_5x_12x_2f.json')
+    shape = (1, 16, 16, 24, 4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None, seed=0)
+    y_ref = ref.forward(x)
+    net = _hip_net(spec, ref.weights)
+    y = net(x).cpu().numpy()
+    assert y.shape == (1, 80, 80, 288, 2)
+    assert np.isfinite(y).all()
+    assert np.abs(y - y_ref).max() < 1e-3
+    # size-independent property: translation of the batch axis (samples are
+    # independent) and determinism
+    y2 = net(np.concatenate([x, x[:, ::-1]], 0)).cpu().numpy()
+    np.testing.assert_array_equal(y2[0], y[0])
+
+
+def test_losses_adam_utils():
+    import torch
+    from oracle import gan as G
+    from sup3r_amd import _lib
+    from sup3r_amd.engine import Device
+    import ctypes as C
+    L = _lib.lib()
+    dev = Device.get()
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((3, 4, 5, 6, 2)).astype(np.float32)
+    b = rng.standard_normal((3, 4, 5, 6, 3)).astype(np.float32)
+    ad, bd = dev.to_device(a), dev.to_device(b)
+    for kind, fn in ((_lib.LOSS_MAE, G.mae), (_lib.LOSS_MSE, G.mse)):
+        loss = dev.empty((1,))
+        da = dev.empty(a.shape)
+        rc = L.s3_loss_content(dev.ctx, kind, ad.data_ptr(), 2, bd.data_ptr(),
+                               3, 2, a.size // 2, 0.5, loss.data_ptr(),
+                               da.data_ptr(), 0)
+        assert rc == 0
+        ref_l, ref_g, _ = fn(a.astype(np.float64), b[..., :2].astype(np.float64))
+        assert abs(loss.item() - ref_l) < 1e-5
+        np.testing.assert_allclose(da.cpu().numpy(), 0.5 * ref_g, atol=1e-7)
+    dt = (rng.standard_normal((15, 1)) * 3).astype(np.float32)
+    dg = (rng.standard_normal((15, 1)) * 3).astype(np.float32)
+    loss = dev.empty((1,))
+    g_t, g_g = dev.empty((15,)), dev.empty((15,))
+    rc = L.s3_loss_rel_bce(dev.ctx, dev.to_device(dt).data_ptr(),
+                           dev.to_device(dg).data_ptr(), 15, 2.0,
+                           loss.data_ptr(), g_t.data_ptr(), g_g.data_ptr())
+    assert rc == 0
+    rl, rt, rg = G.rel_bce(dt.astype(np.float64), dg.astype(np.float64))
+    assert abs(loss.item() - rl) < 1e-5
+    np.testing.assert_allclose(g_t.cpu().numpy(), 2 * rt[:, 0], atol=1e-6)
+    np.testing.assert_allclose(g_g.cpu().numpy(), 2 * rg[:, 0], atol=1e-6)
+    # Adam: 3 steps vs the keras-form oracle
+    from sup3r_amd.engine import Network
+    spec = [{'class': 'Conv2D', 'filters': 5, 'kernel_size': 3},
+            {'class': 'Flatten'}, {'class': 'Dense', 'units': 3}]
+    net = Network(spec)
+    net.build((2, 6, 6, 2), seed=1)
+    w = [x.copy() for x in net.weights]
+    opt = G.Adam(learning_rate=1e-2)
+    for t in range(1, 4):
+        gs = [rng.standard_normal(x.shape).astype(np.float32) for x in w]
+        net.set_weights(gs, which=_lib.BUF_G)
+        net.adam_step(1e-2, 0.9, 0.999, 1e-7, t)
+        opt.apply_gradients(gs, w)
+        for x, y in zip(net.weights, w):
+            np.testing.assert_allclose(x, y, rtol=2e-5, atol=1e-7)
+    for i, m in enumerate(net.slots('m')):
+        np.testing.assert_allclose(m, opt.m[i], rtol=1e-5, atol=1e-8)
+        assert abs(net.mean_abs(_lib.BUF_M, i) - np.abs(opt.m[i]).mean()) < 1e-6
+    # channel utilities
+    out = dev.empty((3, 4, 5, 6, 3))
+    L.s3_fill(dev.ctx, out.data_ptr(), out.numel(), 7.0)
+    L.s3_copy_channels(dev.ctx, ad.data_ptr(), 2, 0, out.data_ptr(), 3, 1, 2,
+                       a.size // 2, 0)
+    o = out.cpu().numpy()
+    np.testing.assert_array_equal(o[..., 1:], a)
+    assert (o[..., 0] == 7.0).all()
+    sc = (C.c_float * 2)(2.0, 3.0)
+    sh = (C.c_float * 2)(-1.0, 0.5)
+    o2 = dev.empty(a.shape)
+    L.s3_affine_channels(dev.ctx, ad.data_ptr(), o2.data_ptr(), 2,
+                         a.size // 2, sc, sh)
+    np.testing.assert_allclose(
+        o2.cpu().numpy(), a * np.array([2, 3], np.float32)
+        + np.array([-1, .5], np.float32), rtol=1e-6)
+    torch.cuda.synchronize()
