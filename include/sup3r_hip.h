@@ -82,9 +82,11 @@ typedef struct {
 /* ---- context ----------------------------------------------------------
  * replaces: tf.device(default_device) placement in
  * sup3r/models/abstract.py:41-42,1230 and base.py:104-106.
- * stream: a hipStream_t the caller already owns (e.g.
- * torch.cuda.current_stream().cuda_stream) or NULL to create one. */
-int s3_ctx_create(int device_id, void* stream, s3_ctx** out);
+ * stream: the hipStream_t all work is enqueued on — one the caller already
+ * owns (e.g. torch.cuda.current_stream().cuda_stream; NULL is the device's
+ * default stream).  create_stream != 0 ignores `stream` and creates a private
+ * non-blocking stream instead. */
+int s3_ctx_create(int device_id, void* stream, int create_stream, s3_ctx** out);
 void s3_ctx_destroy(s3_ctx* ctx);
 const char* s3_last_error(const s3_ctx* ctx);
 int s3_ctx_sync(s3_ctx* ctx);

@@ -67,7 +67,7 @@ def lib():
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     pf = C.POINTER(C.c_float)
     sig = {
-        's3_ctx_create': (i32, [i32, vp, C.POINTER(vp)]),
+        's3_ctx_create': (i32, [i32, vp, i32, C.POINTER(vp)]),
         's3_ctx_destroy': (None, [vp]),
         's3_last_error': (C.c_char_p, [vp]),
         's3_ctx_sync': (i32, [vp]),

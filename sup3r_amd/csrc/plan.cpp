@@ -73,7 +73,8 @@ static int plan_alloc(s3_plan* pl, void** out, size_t bytes) {
 }
 
 // ------------------------------------------------------------------ context
-extern "C" int s3_ctx_create(int device_id, void* stream, s3_ctx** out) {
+extern "C" int s3_ctx_create(int device_id, void* stream, int create_stream,
+                             s3_ctx** out) {
   if (!out) return S3_EINVAL;
   s3_ctx* ctx = new s3_ctx();
   ctx->device = device_id;
@@ -84,7 +85,7 @@ extern "C" int s3_ctx_create(int device_id, void* stream, s3_ctx** out) {
     *out = ctx;
     return S3_EHIP;
   }
-  if (stream) {
+  if (!create_stream) {
     ctx->stream = (hipStream_t)stream;
   } else {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);

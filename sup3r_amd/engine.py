@@ -41,7 +41,7 @@ class Device:
         with torch.cuda.device(index):
             stream = torch.cuda.current_stream().cuda_stream
         h = C.c_void_p()
-        rc = L.s3_ctx_create(index, C.c_void_p(stream), C.byref(h))
+        rc = L.s3_ctx_create(index, C.c_void_p(stream), 0, C.byref(h))
         _lib.check(rc, h, 's3_ctx_create')
         self.ctx = h
         self.rank, self.nranks = 0, 1

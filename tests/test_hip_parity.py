@@ -166,8 +166,8 @@ def test_losses_adam_utils():
     dg = (rng.standard_normal((15, 1)) * 3).astype(np.float32)
     loss = dev.empty((1,))
     g_t, g_g = dev.empty((15,)), dev.empty((15,))
-    rc = L.s3_loss_rel_bce(dev.ctx, dev.to_device(dt).data_ptr(),
-                           dev.to_device(dg).data_ptr(), 15, 2.0,
+    dtd, dgd = dev.to_device(dt), dev.to_device(dg)   # keep both alive
+    rc = L.s3_loss_rel_bce(dev.ctx, dtd.data_ptr(), dgd.data_ptr(), 15, 2.0,
                            loss.data_ptr(), g_t.data_ptr(), g_g.data_ptr())
     assert rc == 0
     rl, rt, rg = G.rel_bce(dt.astype(np.float64), dg.astype(np.float64))
