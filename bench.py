@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Headline benchmark: BASELINE.json config C2 — SpatioTemporal 5x/12x Sup3rGan
+generator forward, lo-res chunks (B,16,16,24,4) -> hi-res (B,80,80,288,2), on
+N MI355X (one process per GPU, chunks sharded data-parallel, no data-path
+collective: ``scaling = weak``).
+
+A "step" is one pass of the hot path (``Sup3rGan._tf_generate``'s layer loop,
+sup3r/models/abstract.py:1131-1173, here one s3_plan_forward) over one batch
+of synthetic chunks already resident in HBM.  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CFG = os.path.join(ROOT, 'sup3r_amd', 'configs', 'gen_5x_12x_2f.json')
+LR_SHAPE = (16, 16, 24, 4)
+HR_SHAPE = (80, 80, 288, 2)
+# algorithmic work, SURVEY.md §8(d) / DESIGN.md: generator forward per sample
+GEN_FLOP_PER_SAMPLE = 598.9e9
+# dominant kernel: Conv3D 64->64 3x3x3 on (16,16,288): 2*73728*64*1728 FLOP
+BODY_CONV_FLOP_PER_SAMPLE = 2.0 * 16 * 16 * 288 * 64 * 27 * 64
+# ... and its algorithmic HBM bytes (read un-padded input once, write output
+# once, fp32 activations) per sample
+BODY_CONV_BYTES_PER_SAMPLE = 2.0 * 16 * 16 * 288 * 64 * 4
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}   # MI355X_MICROARCH.md (dense)
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(spec, seconds_budget=30.0):
+    """Oracle (numpy, as-TF-executes: un-fused pad-3 / valid conv / crop-2,
+    NDHWC fp32, BLAS GEMM per tap) timed on the host cores: one C2 sample."""
+    from oracle.network import Network as OracleNet
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1,) + LR_SHAPE).astype(np.float32)
+    net = OracleNet(spec)
+    t0 = time.time()
+    net.init_weights(x, seed=0)       # includes one forward (lazy build)
+    t_first = time.time() - t0
+    n = 0
+    t0 = time.time()
+    while True:
+        net.forward(x)
+        n += 1
+        el = time.time() - t0
+        if el + el / n > seconds_budget - t_first or n >= 3:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()]
+                      or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {'value': n / el, 'unit': 'samples/s', 'cores': int(threads),
+            'kind': 'port',
+            'sample': f'{n} x one C2 chunk (1,16,16,24,4)->(1,80,80,288,2), '
+                      'numpy oracle as-TF-executes (474 GMAC/sample), '
+                      f'{el / n:.2f} s/sample'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8,
+                    help='lo-res chunks per GPU per step')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda',
+                                                               local_rank))
+
+    from sup3r_amd.engine import Device, Network
+    with open(CFG) as f:
+        spec = json.load(f)
+    dev = Device.get(local_rank)
+    net = Network(spec, name='generator', device=dev,
+                  precision=args.precision)
+    B = args.batch
+    shape = (B,) + LR_SHAPE
+    net.build(shape, seed=0)                    # glorot-uniform, zero bias
+    ph = net.plan(shape, training=False)
+    rng = np.random.default_rng(42 + rank)
+    x = dev.to_device(rng.standard_normal(shape).astype(np.float32))
+    out = dev.empty((B,) + HR_SHAPE)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ph.forward(x, out=out)
+    barrier()
+    ph.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ph.forward(x, out=out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_prof, ms = ph.profile_end()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev.torch_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all().item()
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    samples_per_s = world * B * args.steps / elapsed
+    # dominant kernel = the 64->64 body convs on the full (16,16,288) grid
+    body = [i for i, op in enumerate(ph.plan.ops)
+            if ph.op_is_mfma(i) and op['cout'] == 64
+            and ph.plan.tensors[op['out']][1:4] == [16, 16, 288]]
+    body_ms = float(np.mean([ms[i] for i in body])) if body else float('nan')
+    flop = BODY_CONV_FLOP_PER_SAMPLE * B
+    achieved = flop / (body_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.precision]
+    conv_ms = sum(ms[i] for i, op in enumerate(ph.plan.ops) if 'cout' in op)
+    result = {
+        'metric': 'samples/sec (lo-res chunks), generator forward, '
+                  '5x/12x ST-GAN',
+        'value': samples_per_s, 'unit': 'samples/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.precision, 'data': 'synthetic',
+        'px_per_sec': samples_per_s * float(np.prod(HR_SHAPE[:3])),
+        'gflop_per_sample': GEN_FLOP_PER_SAMPLE / 1e9,
+        'whole_path_tflops': samples_per_s / world * GEN_FLOP_PER_SAMPLE / 1e12,
+        'config': {
+            'workload': 'C2: gen_5x_12x_2f generator forward, lo-res '
+                        f'({B},16,16,24,4) -> hi-res ({B},80,80,288,2) per GPU '
+                        'per step, inputs resident in HBM, random-init weights',
+            'batch_per_gpu': B, 'precision': args.precision,
+            'activations': 'fp32 NDHWC',
+            'parallelism': f'chunk-sharded x{world}, no collective'},
+        'roofline': {
+            'kernel': 'conv3_mfma_kernel (Conv3D 64->64 k3, reflect-pad fused)',
+            'bound': 'mfma', 'achieved': achieved, 'peak': peak,
+            'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+            'launches_per_step': len(body), 'avg_launch_ms': body_ms,
+            'hbm_algorithmic_GBps': BODY_CONV_BYTES_PER_SAMPLE * B
+            / (body_ms * 1e-3) / 1e9,
+            'hbm_frac': BODY_CONV_BYTES_PER_SAMPLE * B / (body_ms * 1e-3)
+            / 1e9 / PEAK_HBM_GBS,
+            'conv_ms_per_step': conv_ms, 'all_ops_ms_per_step': sum(ms),
+            'forwards_profiled': n_prof},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(spec)
+        result['speedup_vs_cpu_baseline'] = \
+            samples_per_s / result['cpu_baseline']['value']
+    print(json.dumps(result))
+
+
+if __name__ == '__main__':
+    main()

@@ -143,10 +143,16 @@ int s3_plan_backward(s3_plan* plan, const void* d_output, void* d_input,
                      int need_wgrad, int accumulate_wgrad);
 void* s3_plan_tensor(s3_plan* plan, int32_t tensor_id);
 int64_t s3_plan_workspace_bytes(const s3_plan* plan);
-/* per-op timing of the last forward, ms (HIP events on the ctx stream); used by
- * bench.py for the roofline object.  Returns number of ops written. */
-int s3_plan_profile_forward(s3_plan* plan, const void* const* inputs,
-                            float* ms_per_op, int cap);
+/* per-op kernel timing with HIP events on the ctx stream (bench.py roofline
+ * object).  After s3_plan_profile_begin(plan, max_forwards) every
+ * s3_plan_forward records one event between consecutive ops (up to
+ * max_forwards forwards); s3_plan_profile_end synchronises, writes the MEAN
+ * duration in ms of each op over the recorded forwards into ms_per_op[0..cap)
+ * and returns the number of forwards averaged (or a negative error). */
+int s3_plan_profile_begin(s3_plan* plan, int max_forwards);
+int s3_plan_profile_end(s3_plan* plan, float* ms_per_op, int cap);
+/* 1 if op i of the plan runs on the MFMA halo-tile kernel, else 0 */
+int s3_plan_op_is_mfma(const s3_plan* plan, int op_index);
 
 /* ---- losses ------------------------------------------------------------
  * content loss: keras MeanAbsoluteError / MeanSquaredError as used by

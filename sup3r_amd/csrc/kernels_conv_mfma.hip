@@ -26,6 +26,8 @@
 //
 // Fragment maps (guide §3): A lane l: row l&15, k-group l>>4; B lane l: col
 // l&15, k-group l>>4; C/D lane l reg r: col l&15, row (l>>4)*4 + r.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -155,46 +157,69 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(
 
   b_issue(0);
 
-  // ---- stage the input halo (boundary handled here, once per element)
+  // ---- stage the input halo (boundary handled here, once per element).
+  // 4 items per thread per trip: all global loads of a trip are issued before
+  // the first convert/ds_write so >= 8 x 16-B loads per lane are in flight.
   {
     constexpr int CHUNKS = PREC == S3_PREC_BF16 ? 8 : 16;  // per position
-    for (int item = tid; item < HP * CHUNKS; item += 256) {
-      const int hp = item / CHUNKS, ch = item % CHUNKS;
-      int h = hp;
-      const int c2 = h % H2; h /= H2;
-      const int c1 = h % H1; h /= H1;
-      const int c0 = h;
-      int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
-      bool valid = true;
-      if (g.pad_mode == S3_PAD_REFLECT) {
-        i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
-      } else {
-        valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
-      }
-      // ragged tiles: keep addresses legal (results are masked at the store)
-      i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
-      i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
-      i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
-      const float* src = x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * CIN;
-      if (PREC == S3_PREC_BF16) {
-        float4 a = make_float4(0, 0, 0, 0), b = a;
-        if (valid) {
-          a = *reinterpret_cast<const float4*>(src + ch * 8);
-          b = *reinterpret_cast<const float4*>(src + ch * 8 + 4);
+    constexpr int ITEMS = HP * CHUNKS;
+    constexpr int UN = 4;
+    for (int base = tid; base < ITEMS; base += 256 * UN) {
+      float4 va[UN], vb[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int item = base + u * 256;
+        va[u] = make_float4(0, 0, 0, 0);
+        vb[u] = va[u];
+        if (item < ITEMS) {
+          const int hp = item / CHUNKS, ch = item % CHUNKS;
+          int h = hp;
+          const int c2 = h % H2; h /= H2;
+          const int c1 = h % H1; h /= H1;
+          const int c0 = h;
+          int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
+          bool valid = true;
+          if (g.pad_mode == S3_PAD_REFLECT) {
+            i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
+          } else {
+            valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
+          }
+          // ragged tiles: keep addresses legal (results are masked at the store)
+          i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
+          i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
+          i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
+          const float* src = x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * CIN;
+          if (valid) {
+            if (PREC == S3_PREC_BF16) {
+              va[u] = *reinterpret_cast<const float4*>(src + ch * 8);
+              vb[u] = *reinterpret_cast<const float4*>(src + ch * 8 + 4);
+            } else {
+              va[u] = *reinterpret_cast<const float4*>(src + ch * 4);
+            }
+          }
         }
-        uint4 o;
-        o.x = f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
-        o.y = f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
-        o.z = f2bf(b.x) | ((unsigned)f2bf(b.y) << 16);
-        o.w = f2bf(b.z) | ((unsigned)f2bf(b.w) << 16);
-        const int slot = ch ^ ((hp >> 1) & 7);
-        *reinterpret_cast<uint4*>(halo + (size_t)hp * 128 + slot * 16) = o;
-      } else {
-        float4 a = make_float4(0, 0, 0, 0);
-        if (valid) a = *reinterpret_cast<const float4*>(src + ch * 4);
-        float2* d = reinterpret_cast<float2*>(halo + ((size_t)hp * F32_ROW + ch * 4) * 4);
-        d[0] = make_float2(a.x, a.y);
-        d[1] = make_float2(a.z, a.w);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int item = base + u * 256;
+        if (item < ITEMS) {
+          const int hp = item / CHUNKS, ch = item % CHUNKS;
+          if (PREC == S3_PREC_BF16) {
+            const float4 a = va[u], b = vb[u];
+            uint4 o;
+            o.x = f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
+            o.y = f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
+            o.z = f2bf(b.x) | ((unsigned)f2bf(b.y) << 16);
+            o.w = f2bf(b.z) | ((unsigned)f2bf(b.w) << 16);
+            const int slot = ch ^ ((hp >> 1) & 7);
+            *reinterpret_cast<uint4*>(halo + (size_t)hp * 128 + slot * 16) = o;
+          } else {
+            const float4 a = va[u];
+            float2* d = reinterpret_cast<float2*>(halo + ((size_t)hp * F32_ROW + ch * 4) * 4);
+            d[0] = make_float2(a.x, a.y);
+            d[1] = make_float2(a.z, a.w);
+          }
+        }
       }
     }
   }
@@ -263,36 +288,55 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(
     __syncthreads();
   }
 
-  // ---- epilogue: bias, [depth-to-space], activation, residual, store
-  const int b = g.d2s;
-  const int cpo = g.Cout / (b * b);
+  // ---- epilogue.  The accumulators go through LDS (the halo is dead after
+  // the last barrier) so that every thread handles 4 consecutive output
+  // channels of one position: 16-B coalesced residual loads / stores, all
+  // independent, instead of 64 scalar 4-B accesses per lane.
+  constexpr int SROW = CT + 4;   // 68: keeps float4 alignment, conflict-free
+  float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int m = 0; m < MFW; ++m) {
     const int mf = wave * MFW + m;
-    const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1;
-    if (o0 >= g.O[0] || o1 >= g.O[1]) continue;
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-      const int co = ct * CT + nf * 16 + frow;
-      if (co >= g.Cout) continue;
-      const float bsv = bias ? bias[co] : 0.f;
+    for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o2 = org2 + kq * 4 + r;
-        if (o2 >= g.O[2]) continue;
-        float v = acc[m][nf][r] + bsv;
-        size_t dst;
-        if (b == 1) {
-          dst = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co;
-        } else {
-          const int blk = co / cpo, cc = co % cpo;
-          dst = ((((size_t)n * g.O[0] * b + o0 * b + blk / b) * (g.O[1] * b) +
-                  o1 * b + blk % b) * g.O[2] + o2) * cpo + cc;
-        }
-        v = act_f(v, g.act, g.alpha);
-        if (res) v += res[dst];
-        y[dst] = v;
+      for (int r = 0; r < 4; ++r)
+        stage[(mf * TS2 + kq * 4 + r) * SROW + nf * 16 + frow] = acc[m][nf][r];
+  }
+  __syncthreads();
+  {
+    const int c4 = (tid & 15) * 4;
+    const int co = ct * CT + c4;
+    const bool co_ok = co < g.Cout;   // C_out % 4 == 0 (checked at dispatch)
+    float4 bv = make_float4(0, 0, 0, 0);
+    if (bias && co_ok) bv = *reinterpret_cast<const float4*>(bias + co);
+    const int b = g.d2s;
+    const int cpo = g.Cout / (b * b);
+    const int blk = co / cpo, cc = co % cpo;
+    const int act = g.act;
+    const float alpha = g.alpha;
+    constexpr int NIT = T::NPOS / 16;
+#pragma unroll 4
+    for (int j = 0; j < NIT; ++j) {
+      const int pl = (tid >> 4) + 16 * j;      // local position
+      const int mf = pl / TS2, o2 = org2 + pl % TS2;
+      const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1;
+      if (!co_ok || o0 >= g.O[0] || o1 >= g.O[1] || o2 >= g.O[2]) continue;
+      float4 v = *reinterpret_cast<const float4*>(stage + pl * SROW + c4);
+      size_t dst;
+      if (b == 1) {
+        dst = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co;
+      } else {
+        dst = ((((size_t)n * g.O[0] * b + o0 * b + blk / b) * (g.O[1] * b) +
+                o1 * b + blk % b) * g.O[2] + o2) * cpo + cc;
       }
+      v.x = act_f(v.x + bv.x, act, alpha); v.y = act_f(v.y + bv.y, act, alpha);
+      v.z = act_f(v.z + bv.z, act, alpha); v.w = act_f(v.w + bv.w, act, alpha);
+      if (res) {
+        const float4 rv = *reinterpret_cast<const float4*>(res + dst);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+      *reinterpret_cast<float4*>(y + dst) = v;
     }
   }
 }
@@ -329,6 +373,7 @@ bool conv_mfma_supported(const ConvGeom& g, int precision) {
     const int lo = g.k[d] == 3 ? 1 : 0;
     if (g.lo[d] != lo || g.O[d] != g.D[d]) return false;
   }
+  if (g.d2s > 1 && (g.Cout / (g.d2s * g.d2s)) % 4 != 0) return false;
   if (g.k[2] == 1) return false;   // 2-D nets stay on the direct kernel for now
   if (g.D[2] < 8) return false;    // 16-long t runs would be mostly masked
   return true;
@@ -358,8 +403,11 @@ int launch_conv_mfma_pack(s3_ctx* ctx, const ConvGeom& g, int precision,
 int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
                          const float* x, const void* packed, const float* bias,
                          const float* res, float* y) {
-  if (precision == S3_PREC_BF16)
+  if (precision == S3_PREC_BF16) {
+    static const int tile = getenv("SUP3R_AMD_MFMA_TILE") ? atoi(getenv("SUP3R_AMD_MFMA_TILE")) : 0;
+    if (tile == 1) return launch_cfg<S3_PREC_BF16, 2, 4>(ctx, g, x, packed, bias, res, y);
     return launch_cfg<S3_PREC_BF16, 4, 4>(ctx, g, x, packed, bias, res, y);
+  }
   // f32: the filters are read in canonical layout; `packed` is unused
   return launch_cfg<S3_PREC_F32, 2, 4>(ctx, g, x, packed, bias, res, y);
 }

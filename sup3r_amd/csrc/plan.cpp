@@ -60,6 +60,8 @@ struct s3_plan {
   size_t wg_partial_bytes = 0;
   size_t total_bytes = 0;
   bool forward_done = false;
+  std::vector<hipEvent_t> prof_ev;  // prof_cap * (n_ops + 1)
+  int prof_cap = 0, prof_n = 0;
   std::vector<char> gwritten;
 };
 
@@ -419,6 +421,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
 extern "C" void s3_plan_destroy(s3_plan* pl) {
   if (!pl) return;
   (void)hipStreamSynchronize(pl->ctx->stream);
+  for (auto& e : pl->prof_ev) (void)hipEventDestroy(e);
   for (void* p : pl->owned) (void)hipFree(p);
   delete pl;
 }
@@ -499,10 +502,17 @@ extern "C" int s3_plan_forward(s3_plan* pl, const void* const* inputs, void* out
   s3_ctx* ctx = pl->ctx;
   int rc = bind_inputs(pl, inputs);
   if (rc) return rc;
-  for (auto& o : pl->ops) {
-    rc = run_op_forward(pl, o);
+  const int n_ops = (int)pl->ops.size();
+  hipEvent_t* ev = nullptr;
+  if (pl->prof_cap > 0 && pl->prof_n < pl->prof_cap)
+    ev = pl->prof_ev.data() + (size_t)pl->prof_n * (n_ops + 1);
+  if (ev) S3_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+  for (int i = 0; i < n_ops; ++i) {
+    rc = run_op_forward(pl, pl->ops[i]);
     if (rc) return rc;
+    if (ev) S3_HIP(ctx, hipEventRecord(ev[i + 1], ctx->stream));
   }
+  if (ev) pl->prof_n++;
   if (output) {
     S3_HIP(ctx, hipMemcpyAsync(output, tptr(pl, pl->output),
                                (size_t)pl->t[pl->output].numel * sizeof(float),
@@ -512,27 +522,47 @@ extern "C" int s3_plan_forward(s3_plan* pl, const void* const* inputs, void* out
   return S3_OK;
 }
 
-extern "C" int s3_plan_profile_forward(s3_plan* pl, const void* const* inputs,
-                                       float* ms_per_op, int cap) {
+static void prof_free(s3_plan* pl) {
+  for (auto& e : pl->prof_ev) (void)hipEventDestroy(e);
+  pl->prof_ev.clear();
+  pl->prof_cap = 0;
+  pl->prof_n = 0;
+}
+
+extern "C" int s3_plan_profile_begin(s3_plan* pl, int max_forwards) {
+  if (!pl || max_forwards < 1) return S3_EINVAL;
+  s3_ctx* ctx = pl->ctx;
+  prof_free(pl);
+  const size_t n = (size_t)max_forwards * (pl->ops.size() + 1);
+  pl->prof_ev.resize(n);
+  for (auto& e : pl->prof_ev) S3_HIP(ctx, hipEventCreate(&e));
+  pl->prof_cap = max_forwards;
+  return S3_OK;
+}
+
+extern "C" int s3_plan_profile_end(s3_plan* pl, float* ms_per_op, int cap) {
   if (!pl || !ms_per_op) return S3_EINVAL;
   s3_ctx* ctx = pl->ctx;
-  int rc = bind_inputs(pl, inputs);
-  if (rc) return rc;
-  const int n = (int)pl->ops.size();
-  std::vector<hipEvent_t> ev(n + 1);
-  for (auto& e : ev) S3_HIP(ctx, hipEventCreate(&e));
-  S3_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
-  for (int i = 0; i < n; ++i) {
-    rc = run_op_forward(pl, pl->ops[i]);
-    if (rc) return rc;
-    S3_HIP(ctx, hipEventRecord(ev[i + 1], ctx->stream));
-  }
   S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < n && i < cap; ++i)
-    S3_HIP(ctx, hipEventElapsedTime(&ms_per_op[i], ev[i], ev[i + 1]));
-  for (auto& e : ev) (void)hipEventDestroy(e);
-  pl->forward_done = true;
-  return n < cap ? n : cap;
+  const int n_ops = (int)pl->ops.size();
+  const int nf = pl->prof_n;
+  for (int i = 0; i < n_ops && i < cap; ++i) {
+    double acc = 0.0;
+    for (int f = 0; f < nf; ++f) {
+      hipEvent_t* ev = pl->prof_ev.data() + (size_t)f * (n_ops + 1);
+      float ms = 0.f;
+      S3_HIP(ctx, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      acc += ms;
+    }
+    ms_per_op[i] = nf ? (float)(acc / nf) : 0.f;
+  }
+  prof_free(pl);
+  return nf;
+}
+
+extern "C" int s3_plan_op_is_mfma(const s3_plan* pl, int i) {
+  if (!pl || i < 0 || i >= (int)pl->ops.size()) return 0;
+  return pl->ops[i].d.kind == S3_OP_CONV && pl->ops[i].mfma ? 1 : 0;
 }
 
 // deliver a gradient contribution `src` (numel floats) to tensor `id`

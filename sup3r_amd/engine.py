@@ -175,15 +175,22 @@ class PlanHandle:
         _lib.check(rc, self.dev.ctx, 's3_plan_backward')
         return dx
 
-    def profile_forward(self, x, exo=None):
-        """Per-op forward time in ms (HIP events on the ctx stream)."""
-        ptrs, keep = self._input_ptrs(x, exo or {})
+    def profile_begin(self, max_forwards):
+        """Record HIP events between ops for the next forwards."""
+        rc = _lib.lib().s3_plan_profile_begin(self.h, int(max_forwards))
+        _lib.check(rc, self.dev.ctx, 's3_plan_profile_begin')
+
+    def profile_end(self):
+        """-> (n_forwards_averaged, [mean ms per op])."""
         n = len(self.plan.ops)
         ms = (C.c_float * n)()
-        rc = _lib.lib().s3_plan_profile_forward(self.h, ptrs, ms, n)
+        rc = _lib.lib().s3_plan_profile_end(self.h, ms, n)
         if rc < 0:
-            _lib.check(rc, self.dev.ctx, 's3_plan_profile_forward')
-        return [ms[i] for i in range(n)]
+            _lib.check(rc, self.dev.ctx, 's3_plan_profile_end')
+        return rc, [ms[i] for i in range(n)]
+
+    def op_is_mfma(self, i):
+        return bool(_lib.lib().s3_plan_op_is_mfma(self.h, i))
 
     @property
     def workspace_bytes(self):

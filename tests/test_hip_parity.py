@@ -188,7 +188,7 @@ def test_losses_adam_utils():
         net.adam_step(1e-2, 0.9, 0.999, 1e-7, t)
         opt.apply_gradients(gs, w)
         for x, y in zip(net.weights, w):
-            np.testing.assert_allclose(x, y, rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(x, y, rtol=2e-5, atol=1e-6)
     for i, m in enumerate(net.slots('m')):
         np.testing.assert_allclose(m, opt.m[i], rtol=1e-5, atol=1e-8)
         assert abs(net.mean_abs(_lib.BUF_M, i) - np.abs(opt.m[i]).mean()) < 1e-6
