@@ -1,0 +1,15 @@
+"""sup3r_amd — MI355X-native compute core for NREL/sup3r's Sup3rGan hot path.
+
+Public surface (mirrors ``sup3r.models`` / ``sup3r.pipeline`` names for the
+path this package replaces):
+
+    from sup3r_amd import Sup3rGan, ForwardPass, ForwardPassStrategy
+
+All arithmetic runs in ``sup3r_amd/lib/libsup3r_hip.so`` (hand-written HIP
+kernels for gfx950, C-ABI in include/sup3r_hip.h).  There is no CPU fallback.
+"""
+__version__ = '0.1.0'
+
+from .gan import Sup3rGan  # noqa: E402,F401
+
+__all__ = ['Sup3rGan', '__version__']

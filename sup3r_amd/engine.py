@@ -201,6 +201,8 @@ class Network:
     """Counterpart of ``phygnn.CustomNetwork`` for the hot path: ordered layer
     specs + one device parameter store + cached plans."""
 
+    _global_seed = None   # set by Sup3rGan.seed()
+
     def __init__(self, hidden_layers, name=None, device=None, precision=None):
         self.name = name
         self.layers = S.parse_layers(hidden_layers)
@@ -248,7 +250,10 @@ class Network:
             self.set_weights(self._pending)
             self._pending = None
         else:
-            rng = np.random.default_rng(self._seed if seed is None else seed)
+            if seed is None:
+                seed = self._seed if self._seed is not None else \
+                    type(self)._global_seed
+            rng = np.random.default_rng(seed)
             ws = []
             for p in plan.params:
                 if p['kind'] == 'kernel':
