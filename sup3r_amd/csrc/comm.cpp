@@ -78,7 +78,7 @@ extern "C" int s3_comm_init(s3_ctx* ctx, int rank, int nranks, const void* uniqu
 
 extern "C" int s3_allreduce_sum(s3_ctx* ctx, float* buf, int64_t n) {
   if (!ctx || !buf || n < 0) return S3_EINVAL;
-  if (ctx->nranks <= 1) return S3_OK;
+  if (ctx->nranks <= 1 && !ctx->comm) return S3_OK;  // single rank, no comm
   if (!ctx->comm) S3_FAIL(ctx, S3_ESTATE, "allreduce before s3_comm_init");
   int rc = g_rccl.allreduce(buf, buf, (size_t)n, kNcclFloat32, kNcclSum, ctx->comm, ctx->stream);
   if (rc != 0) {

@@ -1,0 +1,262 @@
+"""Per-chunk forward-pass executor on MI355X.
+
+Counterpart of the hot-path half of ``sup3r.pipeline.forward_pass.ForwardPass``
+(``run_generator`` :188-272, ``_reshape_data_chunk`` :274-337,
+``pad_source_data`` :122-186, ``_output_check`` :384-425, ``run_chunk``
+:582-673) and of the slice algebra of ``sup3r.pipeline.slicer``
+(padded / unpadded lo-res slices, hi-res windows, crop slices, domain-edge
+reflect padding).  File IO, bias correction, exo rasterisation and the job
+launcher stay in sup3r (boundary / out of scope); here a chunk is
+an in-memory array.
+
+MI355X design points:
+  * the model is loaded ONCE per process / GPU and its shape-specialised plan
+    is reused for every chunk (the reference re-loads the model per chunk,
+    forward_pass.py:638);
+  * chunks are the data-parallel unit: rank r of N takes chunks r, r+N, ...
+    (or a contiguous block) — embarrassingly parallel, no collective;
+  * every chunk is padded to the SAME padded shape (interior overlap +
+    reflect at domain edges) so one plan serves the whole domain.
+"""
+import logging
+from dataclasses import dataclass, field
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+
+def chunk_slices(size, chunk):
+    """[slice(0, chunk), slice(chunk, 2*chunk), ...] covering ``size``
+    (sup3r.pipeline.utilities.get_chunk_slices semantics, step 1)."""
+    out, start = [], 0
+    while start < size:
+        stop = min(start + chunk, size)
+        out.append(slice(start, stop))
+        start = stop
+    return out
+
+
+@dataclass
+class ChunkSlicer:
+    """Index algebra for tiling a lo-res domain (s1, s2, t) into generator
+    chunks with overlap, and placing the cropped hi-res output.
+
+    For chunk ``i``: ``lr_pad_slice`` is the in-domain padded window read from
+    the source, ``pad_width`` the extra reflect padding applied at domain edges
+    so every chunk sees ``spatial_pad`` / ``temporal_pad`` cells of context on
+    all sides, ``hr_crop`` removes the enhanced padding from the generator
+    output and ``hr_slice`` is where the result lands in the hi-res domain."""
+
+    coarse_shape: tuple
+    time_steps: int
+    s_enhance: int
+    t_enhance: int
+    chunk_shape: tuple
+    spatial_pad: int = 0
+    temporal_pad: int = 0
+    chunks: list = field(default_factory=list, init=False)
+
+    def __post_init__(self):
+        s1 = chunk_slices(self.coarse_shape[0], self.chunk_shape[0])
+        s2 = chunk_slices(self.coarse_shape[1], self.chunk_shape[1])
+        tt = chunk_slices(self.time_steps, self.chunk_shape[2])
+        self.n_spatial_chunks = len(s1) * len(s2)
+        self.n_time_chunks = len(tt)
+        dims = (self.coarse_shape[0], self.coarse_shape[1], self.time_steps)
+        pads = (self.spatial_pad, self.spatial_pad, self.temporal_pad)
+        enh = (self.s_enhance, self.s_enhance, self.t_enhance)
+        # chunk index = t_idx * n_spatial + (s1_idx * n_s2 + s2_idx), the
+        # ordering of ForwardPassSlicer.chunk_lookup (slicer.py:473-483)
+        for t_sl in tt:
+            for a in s1:
+                for b in s2:
+                    lr = (a, b, t_sl)
+                    lr_pad, pad_width, hr_crop, hr_slice = [], [], [], []
+                    for sl, n, p, e in zip(lr, dims, pads, enh):
+                        start, stop = max(0, sl.start - p), min(n, sl.stop + p)
+                        lr_pad.append(slice(start, stop))
+                        lo = max(0, p - sl.start)
+                        hi = max(0, sl.stop + p - n)
+                        pad_width.append((lo, hi))
+                        hr_crop.append(slice(
+                            p * e, p * e + (sl.stop - sl.start) * e))
+                        hr_slice.append(slice(sl.start * e, sl.stop * e))
+                    self.chunks.append(dict(
+                        lr_slice=lr, lr_pad_slice=tuple(lr_pad),
+                        pad_width=tuple(pad_width), hr_crop=tuple(hr_crop),
+                        hr_slice=tuple(hr_slice)))
+
+    @property
+    def n_chunks(self):
+        return len(self.chunks)
+
+    @property
+    def hr_shape(self):
+        return (self.coarse_shape[0] * self.s_enhance,
+                self.coarse_shape[1] * self.s_enhance,
+                self.time_steps * self.t_enhance)
+
+    def get_chunk_indices(self, chunk_index):
+        return (chunk_index % self.n_spatial_chunks,
+                chunk_index // self.n_spatial_chunks)
+
+    def rank_chunks(self, rank, nranks, mode='interleave'):
+        """Chunk ids of one rank.  'interleave' balances ragged edge chunks;
+        'block' mirrors ForwardPassStrategy.node_chunks (np.array_split,
+        strategy.py:363-372)."""
+        ids = np.arange(self.n_chunks)
+        if mode == 'block':
+            return list(np.array_split(ids, nranks)[rank])
+        return list(ids[rank::nranks])
+
+
+class ForwardPass:
+    """Run a generator over the chunks of an in-memory lo-res domain."""
+
+    def __init__(self, model, slicer, rank=0, nranks=1, shard='interleave',
+                 output_check=True):
+        self.model = model
+        self.slicer = slicer
+        self.rank, self.nranks = rank, nranks
+        self.shard = shard
+        self.output_check = output_check
+        if model.s_enhance != slicer.s_enhance or \
+                model.t_enhance != slicer.t_enhance:
+            raise RuntimeError(
+                'model enhancement ({}, {}) does not match the slicer ({}, {})'
+                .format(model.s_enhance, model.t_enhance, slicer.s_enhance,
+                        slicer.t_enhance))
+
+    # -- reference-compatible helpers ------------------------------------
+    @staticmethod
+    def pad_source_data(input_data, pad_width, exo_data=None, mode='reflect',
+                        enhancements=None):
+        """forward_pass.py:122-186: reflect-pad the chunk (and its exo data by
+        the enhanced widths)."""
+        out = np.pad(input_data, (*pad_width, (0, 0)), mode=mode)
+        if exo_data is not None:
+            for feature in exo_data:
+                for i, step in enumerate(exo_data[feature]['steps']):
+                    s_en, t_en = enhancements[feature][i] if enhancements \
+                        else (step.get('s_enhance', 1),
+                              step.get('t_enhance', 1))
+                    ew = tuple((en * pw[0], en * pw[1]) for en, pw in
+                               zip((s_en, s_en, t_en), pad_width)) + ((0, 0),)
+                    new = step['data']
+                    if new.ndim == 3:
+                        new = np.repeat(np.expand_dims(new, 2),
+                                        t_en * input_data.shape[2], axis=2)
+                    exo_data[feature]['steps'][i]['data'] = np.pad(
+                        new, ew, mode=mode)
+        return out, exo_data
+
+    @staticmethod
+    def _reshape_data_chunk(model, data_chunk, exo_data):
+        """forward_pass.py:274-337."""
+        if exo_data is not None:
+            for feature in exo_data:
+                for i, entry in enumerate(exo_data[feature]['steps']):
+                    if model.is_4d:
+                        out = np.transpose(entry['data'], axes=(2, 0, 1, 3))
+                    else:
+                        out = np.expand_dims(entry['data'], axis=0)
+                    exo_data[feature]['steps'][i]['data'] = np.asarray(out)
+        if model.is_4d:
+            return (np.asarray(np.transpose(data_chunk, axes=(2, 0, 1, 3))),
+                    exo_data, 0, 1)
+        return np.asarray(np.expand_dims(data_chunk, axis=0)), exo_data, 3, 1
+
+    @classmethod
+    def run_generator(cls, data_chunk, hr_crop_slices, model, s_enhance=None,
+                      t_enhance=None, exo_data=None):
+        """forward_pass.py:188-272."""
+        data_chunk, exo_data, i_lr_t, i_lr_s = cls._reshape_data_chunk(
+            model, data_chunk, exo_data)
+        try:
+            hi_res = model.generate(data_chunk, exogenous_data=exo_data)
+        except Exception as e:
+            msg = 'Forward pass failed on chunk with shape {}.'.format(
+                data_chunk.shape)
+            logger.exception(msg)
+            raise RuntimeError(msg) from e
+        if hi_res.ndim == 4:
+            hi_res = np.expand_dims(np.transpose(hi_res, (1, 2, 0, 3)), axis=0)
+        if s_enhance is not None and \
+                hi_res.shape[1] != s_enhance * data_chunk.shape[i_lr_s]:
+            msg = ('The stated spatial enhancement of {}x did not match the '
+                   'low res / high res shapes of {} -> {}'.format(
+                       s_enhance, data_chunk.shape, hi_res.shape))
+            logger.error(msg)
+            raise RuntimeError(msg)
+        if t_enhance is not None and \
+                hi_res.shape[3] != t_enhance * data_chunk.shape[i_lr_t]:
+            msg = ('The stated temporal enhancement of {}x did not match the '
+                   'low res / high res shapes of {} -> {}'.format(
+                       t_enhance, data_chunk.shape, hi_res.shape))
+            logger.error(msg)
+            raise RuntimeError(msg)
+        return hi_res[0][tuple(hr_crop_slices)]
+
+    @staticmethod
+    def _output_check(out_data, features=None, chunk_index=None):
+        """forward_pass.py:384-425: NaNs or a constant output channel mean the
+        chunk failed."""
+        failed = bool(np.isnan(out_data).any())
+        if not failed:
+            for idf in range(out_data.shape[-1]):
+                ch = out_data[..., idf]
+                if ch.size > 1 and np.all(ch == ch.flat[0]):
+                    failed = True
+                    name = features[idf] if features else idf
+                    logger.error('Forward pass output for "%s" is constant on '
+                                 'chunk %s', name, chunk_index)
+        return failed
+
+    # -- execution ---------------------------------------------------------
+    def chunk_input(self, domain, chunk_index):
+        """Padded lo-res input of one chunk from the (s1, s2, t, f) domain."""
+        c = self.slicer.chunks[chunk_index]
+        data = domain[c['lr_pad_slice']]
+        if any(p != (0, 0) for p in c['pad_width']):
+            data, _ = self.pad_source_data(data, c['pad_width'])
+        return data
+
+    def run_chunk(self, domain, chunk_index):
+        """One chunk: pad -> NaN check -> generate -> enhancement check ->
+        crop (-> output check)."""
+        c = self.slicer.chunks[chunk_index]
+        data = self.chunk_input(domain, chunk_index)
+        if np.isnan(data).any():
+            raise ValueError(
+                f'Forward pass chunk {chunk_index} input data has NaN values')
+        out = self.run_generator(data, c['hr_crop'], self.model,
+                                 s_enhance=self.slicer.s_enhance,
+                                 t_enhance=self.slicer.t_enhance)
+        if self.output_check and self._output_check(
+                out, self.model.hr_out_features, chunk_index):
+            raise MemoryError(
+                f'Forward pass output check failed on chunk {chunk_index}')
+        return out
+
+    def my_chunks(self):
+        return self.slicer.rank_chunks(self.rank, self.nranks, self.shard)
+
+    def run(self, domain, out=None, writer=None):
+        """Process this rank's chunks of ``domain`` (s1, s2, t, features).
+
+        ``out``: optional pre-allocated hi-res array (s1*s, s2*s, t*te, f_out)
+        each cropped chunk is placed into (ranks write disjoint windows).
+        ``writer(chunk_index, hr_slice, data)`` is called per chunk instead when
+        given (file output lives in sup3r's writers).  Returns the number of
+        chunks run."""
+        done = 0
+        for idx in self.my_chunks():
+            hr = self.run_chunk(domain, idx)
+            sl = self.slicer.chunks[idx]['hr_slice']
+            if writer is not None:
+                writer(idx, sl, hr)
+            elif out is not None:
+                out[sl] = hr
+            done += 1
+        return done

@@ -1,0 +1,158 @@
+"""CPU tests of the chunk executor's host logic (slice algebra, padding,
+placement, rank sharding) with a stand-in model whose ``generate`` is a pure
+numpy local operator — the reference's own self-consistency checks
+(tests/forward_pass/test_forward_pass.py:411-558: chunked == un-chunked)
+re-expressed without files.  Includes the world_size-2 gloo run of the
+chunk-sharded path."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from sup3r_amd.forward_pass import ChunkSlicer, ForwardPass, chunk_slices
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class LocalModel:
+    """generate = nearest-neighbour enhancement of a 3x3x3 box mean, i.e. a
+    local operator with receptive radius 1 (so overlap >= 1 makes chunking
+    exact away from domain edges, and reflect padding makes it exact AT them
+    only if the un-chunked run pads the same way)."""
+
+    s_enhance, t_enhance = 2, 3
+    is_4d, is_5d = False, True
+    hr_out_features = ['a', 'b']
+
+    def generate(self, x, exogenous_data=None):
+        x = np.asarray(x, np.float64)
+        xp = np.pad(x, [(0, 0), (1, 1), (1, 1), (1, 1), (0, 0)],
+                    mode='reflect')
+        acc = 0
+        for a in range(3):
+            for b in range(3):
+                for c in range(3):
+                    acc = acc + xp[:, a:a + x.shape[1], b:b + x.shape[2],
+                                   c:c + x.shape[3]]
+        y = acc / 27.0
+        y = np.repeat(np.repeat(np.repeat(y, 2, 1), 2, 2), 3, 3)
+        return y
+
+
+def test_chunk_slices():
+    assert chunk_slices(10, 4) == [slice(0, 4), slice(4, 8), slice(8, 10)]
+    assert chunk_slices(4, 4) == [slice(0, 4)]
+
+
+def test_slicer_covers_domain_once():
+    s = ChunkSlicer((20, 17), 50, 2, 3, (8, 8, 16), spatial_pad=2,
+                    temporal_pad=3)
+    assert s.n_chunks == 3 * 3 * 4
+    cover = np.zeros(s.hr_shape, np.int32)
+    for c in s.chunks:
+        cover[c['hr_slice']] += 1
+        # padded shape is chunk + 2*pad on every side after edge padding
+        for d in range(3):
+            n = c['lr_pad_slice'][d].stop - c['lr_pad_slice'][d].start
+            n += sum(c['pad_width'][d])
+            core = c['lr_slice'][d].stop - c['lr_slice'][d].start
+            assert n == core + 2 * (2 if d < 2 else 3)
+    assert (cover == 1).all()
+    # chunk index ordering: spatial fastest, then time (slicer.py:668-673)
+    assert s.get_chunk_indices(10) == (1, 1)
+    all_ids = sorted(sum((s.rank_chunks(r, 4) for r in range(4)), []))
+    assert all_ids == list(range(s.n_chunks))
+    blk = [s.rank_chunks(r, 4, 'block') for r in range(4)]
+    assert sorted(sum(blk, [])) == list(range(s.n_chunks))
+
+
+def test_chunked_equals_unchunked():
+    rng = np.random.default_rng(0)
+    domain = rng.standard_normal((20, 17, 25, 2))
+    model = LocalModel()
+    full = model.generate(domain[None])[0]
+    s = ChunkSlicer((20, 17), 25, 2, 3, (8, 8, 10), spatial_pad=1,
+                    temporal_pad=1)
+    out = np.zeros(s.hr_shape + (2,))
+    n = ForwardPass(model, s).run(domain, out=out)
+    assert n == s.n_chunks
+    np.testing.assert_allclose(out, full, atol=1e-12)
+    # single chunk == direct generate (test_fwp_nochunking)
+    s1 = ChunkSlicer((20, 17), 25, 2, 3, (20, 17, 25))
+    out1 = np.zeros(s1.hr_shape + (2,))
+    ForwardPass(model, s1).run(domain, out=out1)
+    np.testing.assert_array_equal(out1, full)
+
+
+def test_output_check_and_errors():
+    assert ForwardPass._output_check(np.full((4, 4, 4, 1), np.nan))
+    assert ForwardPass._output_check(np.ones((4, 4, 4, 2)))
+    assert not ForwardPass._output_check(
+        np.random.default_rng(0).standard_normal((4, 4, 4, 2)))
+    model = LocalModel()
+    s = ChunkSlicer((8, 8), 8, 2, 3, (4, 4, 4))
+    fp = ForwardPass(model, s)
+    bad = np.zeros((8, 8, 8, 2))
+    bad[0, 0, 0, 0] = np.nan
+    with pytest.raises(ValueError):
+        fp.run_chunk(bad, 0)
+    with pytest.raises(MemoryError):
+        fp.run_chunk(np.ones((8, 8, 8, 2)), 0)
+    s_bad = ChunkSlicer((8, 8), 8, 3, 3, (4, 4, 4))
+    with pytest.raises(RuntimeError):
+        ForwardPass(model, s_bad)
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["S3_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from sup3r_amd.forward_pass import ChunkSlicer, ForwardPass
+from sup3r_amd.distributed import env_rank, shard_batch, sum_over_ranks_host
+from tests.test_forward_pass_cpu import LocalModel
+dist.init_process_group("gloo")
+rank, _, world = env_rank()
+rng = np.random.default_rng(0)
+domain = rng.standard_normal((12, 10, 14, 2))
+model = LocalModel()
+s = ChunkSlicer((12, 10), 14, 2, 3, (5, 5, 6), spatial_pad=1, temporal_pad=1)
+out = np.zeros(s.hr_shape + (2,))
+fp = ForwardPass(model, s, rank=rank, nranks=world)
+n = fp.run(domain, out=out)
+# ranks wrote disjoint windows: SUM over ranks assembles the domain
+total = sum_over_ranks_host([out])[0]
+full = model.generate(domain[None])[0]
+assert np.allclose(total, full, atol=1e-12), "sharded != unsharded"
+cnt = sum_over_ranks_host([np.array([float(n)])])[0]
+assert cnt[0] == s.n_chunks
+# training-side semantics: equal batch shards, gradients SUMMED over ranks
+batch = np.arange(8 * 3, dtype=np.float64).reshape(8, 3)
+mine = shard_batch(batch, rank, world)
+g = sum_over_ranks_host([mine.sum(axis=0)])[0]
+assert np.allclose(g, batch.sum(axis=0))
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def test_world_size_2_gloo(tmp_path):
+    import subprocess
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, S3_ROOT=ROOT)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    # both workers ran every assertion (their stdout lines may interleave)
+    assert res.stdout.count('ok') >= 2, res.stdout
