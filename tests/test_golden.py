@@ -1,0 +1,158 @@
+"""Golden-vector tests.  CPU: the oracle reproduces the committed vectors
+(freezes the checker).  GPU (-m gpu): the HIP path reproduces them through the
+C-ABI (box-independent expected values)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, 'golden')
+CFG = os.path.join(HERE, '..', 'sup3r_amd', 'configs')
+
+NETS = [('gen_st_2x_4x_2f.npz', 'test_gen_st_2x_4x_2f.json'),
+        ('gen_st_3x_4x_2f_topo.npz', 'test_gen_st_3x_4x_2f_topo.json'),
+        ('gen_s_2x_2f.npz', 'test_gen_s_2x_2f.json'),
+        ('disc_st_same.npz', 'test_disc_st_same.json'),
+        ('disc_st_valid.npz', 'test_disc_st_valid.json')]
+
+
+def _load_cfg(name):
+    with open(os.path.join(CFG, name)) as f:
+        return json.load(f)
+
+
+def _weights(d):
+    n = sum(1 for k in d.files if k.startswith('w') and k[1:].isdigit())
+    return [d[f'w{i}'] for i in range(n)], [d[f'g{i}'] for i in range(n)]
+
+
+@pytest.mark.parametrize('gold,cfg', NETS)
+def test_oracle_reproduces_golden(gold, cfg):
+    from oracle.network import Network
+    d = np.load(os.path.join(GOLD, gold))
+    ws, gs = _weights(d)
+    exo = {'topography': d['exo']} if 'exo' in d.files else None
+    net = Network(_load_cfg(cfg))
+    net.forward(d['x'], exo)
+    net.set_weights(ws)
+    y = net.forward(d['x'], exo)
+    np.testing.assert_allclose(y, d['y'], rtol=0, atol=1e-5)
+    dx = net.backward(d['dy'])
+    np.testing.assert_allclose(dx, d['dx'], rtol=0,
+                               atol=1e-4 * np.abs(d['dx']).max())
+    for g, gr in zip(net.grads, gs):
+        np.testing.assert_allclose(g, gr, rtol=0,
+                                   atol=1e-4 * max(1e-6, np.abs(gr).max()))
+
+
+def test_permutation_goldens_exact():
+    from oracle import layers as L
+    d = np.load(os.path.join(GOLD, 'permutation_ops.npz'))
+    for b in (2, 3, 5):
+        np.testing.assert_array_equal(
+            L.depth_to_space(d[f'd2s_x_b{b}'], b), d[f'd2s_y_b{b}'])
+    for m in (2, 3):
+        y = L.SpatioTemporalExpansion(temporal_mult=m).forward(
+            d[f'trepeat_x_m{m}'])
+        np.testing.assert_array_equal(y, d[f'trepeat_y_m{m}'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('gold,cfg', NETS)
+def test_hip_reproduces_golden(gold, cfg):
+    from sup3r_amd.engine import Network
+    d = np.load(os.path.join(GOLD, gold))
+    ws, gs = _weights(d)
+    net = Network(_load_cfg(cfg), precision='f32')
+    net.set_weights(ws)
+    dev = net.dev
+    exo = {'topography': dev.to_device(d['exo'])} if 'exo' in d.files else {}
+    ph = net.plan(d['x'].shape, training=True)
+    y = ph.forward(dev.to_device(d['x']), exo).cpu().numpy()
+    assert np.abs(y - d['y']).max() < 1e-4 * max(1.0, np.abs(d['y']).max())
+    dx = ph.backward(dev.to_device(d['dy']), need_dx=True).cpu().numpy()
+    assert np.abs(dx.reshape(d['dx'].shape) - d['dx']).max() < \
+        1e-3 * np.abs(d['dx']).max()
+    gmax = max(float(np.abs(g).max()) for g in gs)
+    for g, gr in zip(net.grads, gs):
+        assert np.abs(g - gr).max() < 2e-3 * np.abs(gr).max() + 2e-5 * gmax
+
+
+@pytest.mark.gpu
+def test_hip_permutation_ops_exact():
+    """depth-to-space (DCR) and temporal nearest repeat are pure index
+    permutations: bit-exact against the integer goldens."""
+    from sup3r_amd.engine import Network
+    d = np.load(os.path.join(GOLD, 'permutation_ops.npz'))
+    for b in (2, 3, 5):
+        net = Network([{'class': 'SpatialExpansion', 'spatial_mult': b}])
+        # no weights: an empty parameter store
+        y = net(d[f'd2s_x_b{b}']).cpu().numpy()
+        np.testing.assert_array_equal(y, d[f'd2s_y_b{b}'])
+    for m in (2, 3):
+        net = Network([{'class': 'SpatioTemporalExpansion',
+                        'temporal_mult': m, 'temporal_method': 'nearest'}])
+        y = net(d[f'trepeat_x_m{m}']).cpu().numpy()
+        np.testing.assert_array_equal(y, d[f'trepeat_y_m{m}'])
+
+
+@pytest.mark.gpu
+def test_forward_pass_executor_on_gpu():
+    """Chunk executor with the HIP generator: single chunk == direct generate
+    (test_fwp_nochunking), 2-rank sharding == 1 rank bit-exactly, chunked with
+    overlap >= receptive radius == un-chunked in the interior."""
+    from sup3r_amd import Sup3rGan
+    from sup3r_amd.forward_pass import ChunkSlicer, ForwardPass
+    Sup3rGan.seed(3)
+    model = Sup3rGan(os.path.join(CFG, 'test_gen_st_2x_4x_2f.json'),
+                     os.path.join(CFG, 'test_disc_st_same.json'))
+    model.meta.update(lr_features=['u', 'v'], hr_out_features=['u', 'v'])
+    model.set_norm_stats({'u': 0.3, 'v': -0.2}, {'u': 1.5, 'v': 0.7})
+    rng = np.random.default_rng(1)
+    domain = rng.standard_normal((12, 12, 8, 2)).astype(np.float32)
+    full = model.generate(domain[None])[0]
+    assert full.shape == (24, 24, 32, 2)
+    s1 = ChunkSlicer((12, 12), 8, 2, 4, (12, 12, 8))
+    out1 = np.zeros(s1.hr_shape + (2,), np.float32)
+    ForwardPass(model, s1).run(domain, out=out1)
+    np.testing.assert_array_equal(out1, full)
+    s = ChunkSlicer((12, 12), 8, 2, 4, (6, 6, 4), spatial_pad=3,
+                    temporal_pad=2)
+    a = np.zeros(s.hr_shape + (2,), np.float32)
+    ForwardPass(model, s).run(domain, out=a)
+    b = np.zeros_like(a)
+    n0 = ForwardPass(model, s, rank=0, nranks=2).run(domain, out=b)
+    n1 = ForwardPass(model, s, rank=1, nranks=2).run(domain, out=b)
+    assert n0 + n1 == s.n_chunks
+    np.testing.assert_array_equal(a, b)
+    # overlap reduces the chunk-edge error (the generator's receptive field,
+    # ~10 lo-res cells, exceeds any overlap this tiny domain allows)
+    s0 = ChunkSlicer((12, 12), 8, 2, 4, (6, 6, 4))
+    c = np.zeros_like(a)
+    ForwardPass(model, s0).run(domain, out=c)
+    assert np.abs(a - full).mean() < np.abs(c - full).mean()
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_allreduce():
+    """The RCCL entry points resolve and run (1-rank communicator): SUM
+    all-reduce over the flat gradient buffer is the identity."""
+    import ctypes as C
+    from sup3r_amd import _lib
+    from sup3r_amd.engine import Device, Network
+    L = _lib.lib()
+    dev = Device.get()
+    uid = (C.c_char * 128)()
+    assert L.s3_comm_unique_id(uid) == 0
+    dev.init_comm(0, 1, uid)
+    net = Network([{'class': 'Conv2D', 'filters': 4, 'kernel_size': 3}])
+    net.build((1, 6, 6, 2), seed=0)
+    gs = [np.random.default_rng(0).standard_normal(w.shape).astype(np.float32)
+          for w in net.weights]
+    net.set_weights(gs, which=_lib.BUF_G)
+    net.allreduce_grads()
+    dev.sync()
+    for a, b in zip(net.grads, gs):
+        np.testing.assert_array_equal(a, b)
