@@ -42,6 +42,14 @@ constexpr int CT = 64;          // cout tile
 constexpr int F32_ROW = 66;     // halo row stride (dwords), f32 mode
 constexpr int F32_BROW = 80;    // filter row stride (dwords), f32 mode
 
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16x2 (v_cvt_pk_bf16_f32, round-to-nearest-even)
+__device__ inline unsigned pack_bf16(float a, float b) {
+  hf32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
+}
+
 __device__ inline unsigned short f2bf(float f) {
   unsigned u = __float_as_uint(f);
   u += 0x7FFFu + ((u >> 16) & 1u);   // round to nearest even
@@ -54,11 +62,12 @@ __device__ inline float act_f(float v, int act, float alpha) {
   return v;
 }
 
-template <int TS0, int TS1>
+template <int TS0, int TS1, int NW = 4>
 struct Tile {
   static constexpr int H0 = TS0 + 2, H1 = TS1 + 2;
   static constexpr int HP = H0 * H1 * H2;        // halo positions
-  static constexpr int MFW = TS0 * TS1 / 4;      // M fragments per wave
+  static constexpr int MFW = TS0 * TS1 / NW;     // M fragments per wave
+  static constexpr int NT = NW * 64;             // threads per workgroup
   static constexpr int NPOS = TS0 * TS1 * TS2;
   static constexpr size_t lds_bf16 = (size_t)HP * 128 + 2 * 8192;
   static constexpr size_t lds_f32 = (size_t)HP * F32_ROW * 4 + 2 * CIN * F32_BROW * 4;
@@ -85,13 +94,14 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w,
   }
 }
 
-template <int PREC, int TS0, int TS1>
-__global__ __launch_bounds__(256) void conv3_mfma_kernel(
+template <int PREC, int TS0, int TS1, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
     const float* __restrict__ x, const void* __restrict__ wpk,
     const float* __restrict__ bias, const float* __restrict__ res,
     float* __restrict__ y, ConvGeom g, int tiles0, int tiles1, int tiles2) {
-  using T = Tile<TS0, TS1>;
-  constexpr int H1 = T::H1, HP = T::HP, MFW = T::MFW;
+  using T = Tile<TS0, TS1, NW>;
+  constexpr int H1 = T::H1, HP = T::HP, MFW = T::MFW, NT = T::NT;
+  static_assert(MFW >= 1 && MFW * NW == TS0 * TS1, "tile / wave split");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,19 +131,24 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(
                                              : (size_t)HP * F32_ROW * 4);
   constexpr int BSLAB_BYTES = PREC == S3_PREC_BF16 ? 8192 : CIN * F32_BROW * 4;
 
-  // ---- B slab register prefetch helpers
-  uint4 breg[PREC == S3_PREC_BF16 ? 2 : 4];
+  // ---- B slab register prefetch helpers (one slab = 512 x 16 B in bf16,
+  // 1024 x 16 B in f32; NT threads share it)
+  constexpr int SLAB16 = PREC == S3_PREC_BF16 ? 512 : 1024;  // 16-B units
+  constexpr int NBQ = SLAB16 >= NT ? SLAB16 / NT : 1;
+  uint4 breg[NBQ];
   auto b_issue = [&](int tap) {
     if (PREC == S3_PREC_BF16) {
       const uint4* src = reinterpret_cast<const uint4*>(
           (const char*)wpk + ((size_t)ct * taps + tap) * 8192);
-      breg[0] = src[tid];
-      breg[1] = src[256 + tid];
+#pragma unroll
+      for (int q = 0; q < NBQ; ++q)
+        if (tid + q * NT < SLAB16) breg[q] = src[tid + q * NT];
     } else {
       const float* w = (const float*)wpk + (size_t)tap * CIN * g.Cout + ct * CT;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ci = (tid >> 4) + 16 * q, co4 = (tid & 15) * 4;
+      for (int q = 0; q < NBQ; ++q) {
+        const int idx = tid + q * NT;
+        const int ci = idx >> 4, co4 = (idx & 15) * 4;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (ct * CT + co4 < g.Cout)
           v = *reinterpret_cast<const uint4*>(w + (size_t)ci * g.Cout + co4);
@@ -144,12 +159,14 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(
   auto b_commit = [&](int buf) {
     char* dst = bslab + buf * BSLAB_BYTES;
     if (PREC == S3_PREC_BF16) {
-      reinterpret_cast<uint4*>(dst)[tid] = breg[0];
-      reinterpret_cast<uint4*>(dst)[256 + tid] = breg[1];
+#pragma unroll
+      for (int q = 0; q < NBQ; ++q)
+        if (tid + q * NT < SLAB16) reinterpret_cast<uint4*>(dst)[tid + q * NT] = breg[q];
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ci = (tid >> 4) + 16 * q, co4 = (tid & 15) * 4;
+      for (int q = 0; q < NBQ; ++q) {
+        const int idx = tid + q * NT;
+        const int ci = idx >> 4, co4 = (idx & 15) * 4;
         *reinterpret_cast<uint4*>(dst + ((size_t)ci * F32_BROW + co4) * 4) = breg[q];
       }
     }
@@ -164,11 +181,11 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(
     constexpr int CHUNKS = PREC == S3_PREC_BF16 ? 8 : 16;  // per position
     constexpr int ITEMS = HP * CHUNKS;
     constexpr int UN = 4;
-    for (int base = tid; base < ITEMS; base += 256 * UN) {
+    for (int base = tid; base < ITEMS; base += NT * UN) {
       float4 va[UN], vb[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        const int item = base + u * 256;
+        const int item = base + u * NT;
         va[u] = make_float4(0, 0, 0, 0);
         vb[u] = va[u];
         if (item < ITEMS) {
@@ -201,17 +218,19 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        const int item = base + u * 256;
+        const int item = base + u * NT;
         if (item < ITEMS) {
           const int hp = item / CHUNKS, ch = item % CHUNKS;
           if (PREC == S3_PREC_BF16) {
             const float4 a = va[u], b = vb[u];
             uint4 o;
-            o.x = f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
-            o.y = f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
-            o.z = f2bf(b.x) | ((unsigned)f2bf(b.y) << 16);
-            o.w = f2bf(b.z) | ((unsigned)f2bf(b.w) << 16);
-            const int slot = ch ^ ((hp >> 1) & 7);
+            o.x = pack_bf16(a.x, a.y);
+            o.y = pack_bf16(a.z, a.w);
+            o.z = pack_bf16(b.x, b.y);
+            o.w = pack_bf16(b.z, b.w);
+            // swizzle keyed on the t coordinate of the halo cell so that the
+            // read-side key depends on the tap's t-shift only (3 variants)
+            const int slot = ch ^ (((hp % H2) >> 1) & 7);
             *reinterpret_cast<uint4*>(halo + (size_t)hp * 128 + slot * 16) = o;
           } else {
             const float4 a = va[u];
@@ -241,32 +260,65 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) acc[m][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int tap = 0; tap < taps; ++tap) {
-    if (tap + 1 < taps) b_issue(tap + 1);
-    const int ta = tap / (KK1 * KK2), tb = (tap / KK2) % KK1, tc = tap % KK2;
-    const int tap_off = (ta * H1 + tb) * H2 + tc;
-    const char* bs = bslab + (tap & 1) * BSLAB_BYTES;
-    if (PREC == S3_PREC_BF16) {
+  if constexpr (PREC == S3_PREC_BF16) {
+    // All LDS read addresses are (per-lane register) + (compile-time
+    // immediate): the 27-tap loop below is nothing but ds_read_b128 + MFMA
+    // (+ the filter prefetch).  a_addr[c][ks]: byte offset of this lane's
+    // 16-B A chunk in the halo row of M-fragment 0, tap t-shift c, k-step ks;
+    // b_addr[nf][ks]: the same for the B fragment rows of the filter slab.
+    static_assert(MFW <= TS1 ? (TS1 % MFW == 0) : (MFW % TS1 == 0), "tile/wave split");
+    const int mf0 = wave * MFW;
+    const int row0 = (mf0 / TS1) * H1 + (mf0 % TS1);
+    unsigned a_addr[3][2], b_addr[4][2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 bfr[4];
+    for (int c = 0; c < 3; ++c) {
+      const int sw = ((frow + c) >> 1) & 7;
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-          const int row = nf * 16 + frow;
-          const int slot = (ks * 4 + kq) ^ ((row >> 1) & 7);
-          bfr[nf] = *reinterpret_cast<const bf16x8*>(bs + row * 128 + slot * 16);
-        }
+      for (int ks = 0; ks < 2; ++ks)
+        a_addr[c][ks] = (unsigned)((row0 * H2 + frow + c) * 128 + (((ks * 4 + kq) ^ sw) << 4));
+    }
 #pragma unroll
-        for (int m = 0; m < MFW; ++m) {
-          const int hp = hp_base[m] + tap_off;
-          const int slot = (ks * 4 + kq) ^ ((hp >> 1) & 7);
-          const bf16x8 afr = *reinterpret_cast<const bf16x8*>(halo + (size_t)hp * 128 + slot * 16);
+    for (int nf = 0; nf < 4; ++nf) {
+      const int row = nf * 16 + frow;
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf)
-            acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nf], acc[m][nf], 0, 0, 0);
+      for (int ks = 0; ks < 2; ++ks)
+        b_addr[nf][ks] = (unsigned)(HP * 128 + row * 128 + (((ks * 4 + kq) ^ ((row >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int ta = 0; ta < 3; ++ta) {
+#pragma unroll
+      for (int tb = 0; tb < 3; ++tb) {
+#pragma unroll
+        for (int tc = 0; tc < 3; ++tc) {
+          constexpr int dummy = 0; (void)dummy;
+          const int tap = (ta * 3 + tb) * 3 + tc;
+          if (tap + 1 < 27) b_issue(tap + 1);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bfr[4];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+              bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][ks] + (tap & 1) * 8192);
+#pragma unroll
+            for (int m = 0; m < MFW; ++m) {
+              const int roff = ((m / TS1) * H1 + (m % TS1) + ta * H1 + tb) * H2 * 128;
+              const bf16x8 afr = *reinterpret_cast<const bf16x8*>(smem + a_addr[tc][ks] + roff);
+#pragma unroll
+              for (int nf = 0; nf < 4; ++nf)
+                acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nf], acc[m][nf], 0, 0, 0);
+            }
+          }
+          if (tap + 1 < 27) b_commit((tap + 1) & 1);
+          __syncthreads();
         }
       }
-    } else {
+    }
+  } else {
+    for (int tap = 0; tap < taps; ++tap) {
+      if (tap + 1 < taps) b_issue(tap + 1);
+      const int ta = tap / (KK1 * KK2), tb = (tap / KK2) % KK1, tc = tap % KK2;
+      const int tap_off = (ta * H1 + tb) * H2 + tc;
+      const char* bs = bslab + (tap & 1) * BSLAB_BYTES;
       const float* hf = reinterpret_cast<const float*>(halo);
       const float* bf = reinterpret_cast<const float*>(bs);
 #pragma unroll 4
@@ -283,9 +335,9 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(
             acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nf], acc[m][nf], 0, 0, 0);
         }
       }
+      if (tap + 1 < taps) b_commit((tap + 1) & 1);
+      __syncthreads();
     }
-    if (tap + 1 < taps) b_commit((tap + 1) & 1);
-    __syncthreads();
   }
 
   // ---- epilogue.  The accumulators go through LDS (the halo is dead after
@@ -315,10 +367,11 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(
     const int blk = co / cpo, cc = co % cpo;
     const int act = g.act;
     const float alpha = g.alpha;
-    constexpr int NIT = T::NPOS / 16;
+    constexpr int PPP = NT / 16;          // positions per pass
+    constexpr int NIT = T::NPOS / PPP;
 #pragma unroll 4
     for (int j = 0; j < NIT; ++j) {
-      const int pl = (tid >> 4) + 16 * j;      // local position
+      const int pl = (tid >> 4) + PPP * j;     // local position
       const int mf = pl / TS2, o2 = org2 + pl % TS2;
       const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1;
       if (!co_ok || o0 >= g.O[0] || o1 >= g.O[1] || o2 >= g.O[2]) continue;
@@ -341,12 +394,12 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(
   }
 }
 
-template <int PREC, int TS0, int TS1>
+template <int PREC, int TS0, int TS1, int NW = 4>
 int launch_cfg(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* wpk,
                const float* bias, const float* res, float* y) {
-  using T = Tile<TS0, TS1>;
+  using T = Tile<TS0, TS1, NW>;
   const size_t lds = PREC == S3_PREC_BF16 ? T::lds_bf16 : T::lds_f32;
-  auto kern = conv3_mfma_kernel<PREC, TS0, TS1>;
+  auto kern = conv3_mfma_kernel<PREC, TS0, TS1, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -356,7 +409,7 @@ int launch_cfg(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* wpk,
   const int tiles0 = (g.O[0] + TS0 - 1) / TS0, tiles1 = (g.O[1] + TS1 - 1) / TS1,
             tiles2 = (g.O[2] + TS2 - 1) / TS2;
   dim3 grid((unsigned)(g.N * tiles0 * tiles1 * tiles2), (unsigned)((g.Cout + CT - 1) / CT));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, x, wpk, bias, res, y, g, tiles0, tiles1, tiles2);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, ctx->stream, x, wpk, bias, res, y, g, tiles0, tiles1, tiles2);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -406,6 +459,11 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
   if (precision == S3_PREC_BF16) {
     static const int tile = getenv("SUP3R_AMD_MFMA_TILE") ? atoi(getenv("SUP3R_AMD_MFMA_TILE")) : 0;
     if (tile == 1) return launch_cfg<S3_PREC_BF16, 2, 4>(ctx, g, x, packed, bias, res, y);
+    if (tile == 2) return launch_cfg<S3_PREC_BF16, 4, 4, 8>(ctx, g, x, packed, bias, res, y);
+    if (tile == 3) return launch_cfg<S3_PREC_BF16, 2, 4, 8>(ctx, g, x, packed, bias, res, y);
+    if (tile == 4) return launch_cfg<S3_PREC_BF16, 4, 8, 16>(ctx, g, x, packed, bias, res, y);
+    if (tile == 5) return launch_cfg<S3_PREC_BF16, 4, 4, 16>(ctx, g, x, packed, bias, res, y);
+    if (tile == 6) return launch_cfg<S3_PREC_BF16, 4, 8, 8>(ctx, g, x, packed, bias, res, y);
     return launch_cfg<S3_PREC_BF16, 4, 4>(ctx, g, x, packed, bias, res, y);
   }
   // f32: the filters are read in canonical layout; `packed` is unused

@@ -39,14 +39,15 @@ def main():
     for _ in range(3):
         ph.forward(x, out=out)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    ph.profile_begin(args.iters)
     for _ in range(args.iters):
         ph.forward(x, out=out)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.iters
+    n, ms = ph.profile_end()
+    dt = ms[0] * 1e-3          # HIP-event time of the conv op alone
     flop = 2.0 * args.batch * d[0] * d[1] * d[2] * 64 * 27 * args.cout
-    print(f'{args.precision} cout={args.cout} batch={args.batch}: '
-          f'{dt * 1e3:.4f} ms/launch (incl. D2D copy of the output), '
+    print(f'{args.precision} cout={args.cout} batch={args.batch} '
+          f'tile={os.environ.get("SUP3R_AMD_MFMA_TILE", "0")}: '
+          f'{dt * 1e3:.4f} ms/launch (HIP events, {n} launches), '
           f'{flop / dt / 1e12:.1f} TFLOP/s')
 
 
