@@ -78,6 +78,8 @@ def main():
                     help='lo-res chunks per GPU per step')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dump-ops', default=None,
+                    help='write per-op mean ms of the timed region here')
     args = ap.parse_args()
 
     import torch
@@ -158,7 +160,8 @@ def main():
                         f'({B},16,16,24,4) -> hi-res ({B},80,80,288,2) per GPU '
                         'per step, inputs resident in HBM, random-init weights',
             'batch_per_gpu': B, 'precision': args.precision,
-            'activations': 'fp32 NDHWC',
+            'activations': ('bf16 trunk / fp32 I/O, NDHWC'
+                            if args.precision == 'bf16' else 'fp32 NDHWC'),
             'parallelism': f'chunk-sharded x{world}, no collective'},
         'roofline': {
             'kernel': 'conv3_mfma_kernel (Conv3D 64->64 k3, reflect-pad fused)',
@@ -172,6 +175,14 @@ def main():
             'conv_ms_per_step': conv_ms, 'all_ops_ms_per_step': sum(ms),
             'forwards_profiled': n_prof},
     }
+    if args.dump_ops:
+        with open(args.dump_ops, 'w') as f:
+            for i, op in enumerate(ph.plan.ops):
+                f.write('{:3d} kind={} cin={} cout={} out={} mfma={} ms={:.4f}\n'
+                        .format(i, op['kind'], op.get('cin'), op.get('cout'),
+                                'x'.join(str(v) for v in
+                                         ph.plan.tensors[op['out']]),
+                                int(ph.op_is_mfma(i)), ms[i]))
     if world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(spec)
         result['speedup_vs_cpu_baseline'] = \

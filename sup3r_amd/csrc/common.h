@@ -69,9 +69,15 @@ __host__ __device__ inline int s3_reflect(int i, int n) {
 }
 
 // ---- launchers (defined in the .hip files) ------------------------------
-int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x,
+// element types of a fused conv's activations (0 = fp32, 1 = bf16)
+struct ConvIO {
+  int in_bf16 = 0, out_bf16 = 0, res_bf16 = 0;
+};
+int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x,
                             const float* w, const float* bias,
-                            const float* res, float* y);
+                            const float* res, void* y, int out_bf16,
+                            int in_bf16);
+bool conv_small_supported(const ConvGeom& g, int in_bf16);
 int launch_conv_generic_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,
                               const float* w, float* dx);
 int launch_conv_generic_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,
@@ -85,10 +91,12 @@ size_t conv_mfma_packed_bytes(const ConvGeom& g, int precision);
 int launch_conv_mfma_pack(s3_ctx* ctx, const ConvGeom& g, int precision,
                           const float* w, void* packed);
 int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
-                         const float* x, const void* packed, const float* bias,
-                         const float* res, float* y);
+                         const void* x, const void* packed, const float* bias,
+                         const void* res, void* y, ConvIO io);
+bool conv_mfma_bf16_out_ok(const ConvGeom& g);
 
-int launch_gather(s3_ctx* ctx, const GatherGeom& g, const float* in, float* out);
+int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
+                  int esize);
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
                       float* din);
 int launch_act(s3_ctx* ctx, const float* x, float* y, int64_t n, int act,

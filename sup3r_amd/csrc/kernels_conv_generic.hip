@@ -39,7 +39,8 @@ template <int CO_T, int CI_V>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ bias, const float* __restrict__ res,
-    float* __restrict__ y, ConvGeom g, int n_cgroups) {
+    void* __restrict__ yv, ConvGeom g, int n_cgroups, int out_bf16) {
+  float* __restrict__ y = reinterpret_cast<float*>(yv);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
@@ -117,7 +118,108 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
     }
     v = act_f(v, g.act, g.alpha);
     if (res) v += res[dst];
-    y[dst] = v;
+    if (out_bf16) {
+      unsigned u = __float_as_uint(v);
+      u += 0x7FFFu + ((u >> 16) & 1u);
+      reinterpret_cast<unsigned short*>(yv)[dst] = (unsigned short)(u >> 16);
+    } else {
+      y[dst] = v;
+    }
+  }
+}
+
+// ---- small-channel 3x3x3 stride-1 conv (generator tail 8->2 on the hi-res
+// grid: AI ~ 21 FLOP/B, HBM-bound).  One thread owns TT consecutive outputs
+// along t at one (s1, s2): for each of the 9 (a, b) neighbour columns it loads
+// the TT+2 input cells once (32-B cells, contiguous along t -> coalesced 16-B
+// loads, adjacent lanes overlap in L1) and slides the 3 t-taps over them in
+// registers; the 27*CIN*COUT filter lives in LDS and is read as wave-uniform
+// broadcasts.  Index / boundary math is paid once per column, not per tap.
+template <int CIN, int COUT, int TT, bool IN16>
+__global__ __launch_bounds__(256) void conv_small_kernel(
+    const void* __restrict__ xv, const float* __restrict__ w,
+    const float* __restrict__ bias, float* __restrict__ y, ConvGeom g) {
+  static_assert(!IN16 || CIN == 8, "bf16 cells are one 16-B load of 8 channels");
+  __shared__ __attribute__((aligned(16))) float ws[27 * CIN * COUT];
+  for (int i = threadIdx.x; i < 27 * CIN * COUT; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const int chunks2 = (g.O[2] + TT - 1) / TT;
+  const int64_t total = (int64_t)g.N * g.O[0] * g.O[1] * chunks2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int64_t r = idx;
+  const int tc = (int)(r % chunks2); r /= chunks2;
+  const int o1 = (int)(r % g.O[1]); r /= g.O[1];
+  const int o0 = (int)(r % g.O[0]); r /= g.O[0];
+  const int n = (int)r;
+  const int t0 = tc * TT;
+  float acc[TT][COUT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t)
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[t][co] = bias ? bias[co] : 0.f;
+  // source t indices of the TT+2 cells of a column (shared by all 9 columns)
+  int i2s[TT + 2];
+  bool v2s[TT + 2];
+#pragma unroll
+  for (int q = 0; q < TT + 2; ++q) {
+    bool v = true;
+    i2s[q] = src_index(t0 + q, 0, 1, g.lo[2], g.D[2], g.pad_mode, v);
+    v2s[q] = v;
+  }
+  for (int a = 0; a < 3; ++a) {
+    bool v0 = true;
+    const int i0 = src_index(o0, a, 1, g.lo[0], g.D[0], g.pad_mode, v0);
+    for (int b = 0; b < 3; ++b) {
+      bool v1 = v0;
+      const int i1 = src_index(o1, b, 1, g.lo[1], g.D[1], g.pad_mode, v1);
+      const int64_t col = (((int64_t)n * g.D[0] + i0) * g.D[1] + i1) * (int64_t)g.D[2] * CIN;
+      float xc[TT + 2][CIN];
+#pragma unroll
+      for (int q = 0; q < TT + 2; ++q) {
+        const float m = (v1 && v2s[q]) ? 1.f : 0.f;
+        if (IN16) {
+          const uint4 v = *reinterpret_cast<const uint4*>(
+              reinterpret_cast<const unsigned short*>(xv) + col + (int64_t)i2s[q] * CIN);
+          const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xc[q][(2 * e) % CIN] = __uint_as_float(u[e] << 16) * m;
+            xc[q][(2 * e + 1) % CIN] = __uint_as_float(u[e] & 0xFFFF0000u) * m;
+          }
+        } else {
+          const float* p = reinterpret_cast<const float*>(xv) + col + (int64_t)i2s[q] * CIN;
+#pragma unroll
+          for (int ci = 0; ci < CIN; ci += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(p + ci);
+            xc[q][ci] = v.x * m; xc[q][ci + 1] = v.y * m;
+            xc[q][ci + 2] = v.z * m; xc[q][ci + 3] = v.w * m;
+          }
+        }
+      }
+      const float* wt = ws + (a * 3 + b) * 3 * CIN * COUT;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) {
+            const float wv = wt[(c * CIN + ci) * COUT + co];
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+              acc[t][co] = fmaf(xc[t + c][ci], wv, acc[t][co]);
+          }
+        }
+      }
+    }
+  }
+  const int64_t base = ((((int64_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + t0) * COUT;
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    if (t0 + t >= g.O[2]) break;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+      y[base + t * COUT + co] = act_f(acc[t][co], g.act, g.alpha);
   }
 }
 
@@ -303,9 +405,33 @@ int wgrad_slabs(const ConvGeom& g) {
 
 }  // namespace
 
-int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x,
+// the sliding-window kernel covers 3x3x3 stride-1 convs with C_in in {4, 8}
+// and C_out == 2 (generator tails); C_in == 8 may also be read as bf16
+bool conv_small_supported(const ConvGeom& g, int in_bf16) {
+  if (!(g.d2s == 1 && g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3 && g.s[0] == 1 &&
+        g.s[1] == 1 && g.s[2] == 1 && g.Cout == 2 && g.O[2] >= 8))
+    return false;
+  return in_bf16 ? g.Cin == 8 : (g.Cin == 8 || g.Cin == 4);
+}
+
+int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x,
                             const float* w, const float* bias,
-                            const float* res, float* y) {
+                            const float* res, void* y, int out_bf16,
+                            int in_bf16) {
+  if (!out_bf16 && !res && conv_small_supported(g, in_bf16)) {
+    constexpr int TT = 4;
+    const int64_t total = (int64_t)g.N * g.O[0] * g.O[1] * ((g.O[2] + TT - 1) / TT);
+    dim3 gridS((unsigned)((total + 255) / 256)), blockS(256);
+    if (in_bf16)
+      hipLaunchKernelGGL((conv_small_kernel<8, 2, TT, true>), gridS, blockS, 0, ctx->stream, x, w, bias, (float*)y, g);
+    else if (g.Cin == 8)
+      hipLaunchKernelGGL((conv_small_kernel<8, 2, TT, false>), gridS, blockS, 0, ctx->stream, x, w, bias, (float*)y, g);
+    else
+      hipLaunchKernelGGL((conv_small_kernel<4, 2, TT, false>), gridS, blockS, 0, ctx->stream, x, w, bias, (float*)y, g);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
+  if (in_bf16) S3_FAIL(ctx, S3_EINVAL, "direct conv: bf16 input not supported for this geometry");
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
   int co_t = g.Cout >= 16 ? 16 : (g.Cout >= 8 ? 8 : (g.Cout >= 4 ? 4 : (g.Cout >= 2 ? 2 : 1)));
   int n_cg = (g.Cout + co_t - 1) / co_t;
@@ -314,7 +440,7 @@ int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x,
   int civ = (g.Cin % 4 == 0) ? 4 : ((g.Cin % 2 == 0) ? 2 : 1);
 #define S3_LAUNCH_FWD(CO, CI)                                                 \
   hipLaunchKernelGGL((conv_fwd_kernel<CO, CI>), grid, block, 0, ctx->stream, \
-                     x, w, bias, res, y, g, n_cg)
+                     (const float*)x, w, bias, res, y, g, n_cg, out_bf16)
 #define S3_FWD_CI(CO)                                  \
   if (civ == 4) S3_LAUNCH_FWD(CO, 4);                  \
   else if (civ == 2) S3_LAUNCH_FWD(CO, 2);             \

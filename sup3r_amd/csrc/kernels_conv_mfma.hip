@@ -16,9 +16,15 @@
 // (one barrier per tap).  K = 27 * 64 = 1728 is contracted on MFMA:
 //
 //   S3_PREC_BF16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Halo and filter
-//                  rows are 128 B (64 x bf16); 16-B chunks are XOR-swizzled by
-//                  ((row >> 1) & 7) so that the 16-lane groups of ds_read_b128
-//                  hit 16 distinct 16-B slots of the 256-B bank row.
+//                  rows are 128 B (64 x bf16); 16-B chunks are XOR-swizzled
+//                  (halo: by the cell's t coordinate, filters: by the row) so
+//                  that the 16-lane groups of ds_read_b128 hit 16 distinct
+//                  16-B slots of the 256-B bank row.  Every LDS read address
+//                  in the 27-tap loop is (per-lane register) + (immediate):
+//                  the loop is ds_read_b128 + MFMA only.  Activations may be
+//                  fp32 or bf16 in HBM (IN16 / OUT16): inference plans keep
+//                  the 64-channel trunk in bf16, which halves the halo and
+//                  epilogue bytes and removes the convert from the staging.
 //   S3_PREC_F32  : v_mfma_f32_16x16x4_f32 (exact fp32, == fmaf chain): parity
 //                  mode.  Halo rows padded to 66 dwords, filter rows to 80, so
 //                  the per-lane ds_read_b32 of the (row, k) fragments are
@@ -34,6 +40,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TS2 = 16;
 constexpr int H2 = TS2 + 2;
@@ -42,13 +50,13 @@ constexpr int CT = 64;          // cout tile
 constexpr int F32_ROW = 66;     // halo row stride (dwords), f32 mode
 constexpr int F32_BROW = 80;    // filter row stride (dwords), f32 mode
 
-typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
-typedef float hf32x2 __attribute__((ext_vector_type(2)));
 // two fp32 -> packed bf16x2 (v_cvt_pk_bf16_f32, round-to-nearest-even)
 __device__ inline unsigned pack_bf16(float a, float b) {
   hf32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
 }
+__device__ inline float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ inline float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
 __device__ inline unsigned short f2bf(float f) {
   unsigned u = __float_as_uint(f);
@@ -69,7 +77,9 @@ struct Tile {
   static constexpr int MFW = TS0 * TS1 / NW;     // M fragments per wave
   static constexpr int NT = NW * 64;             // threads per workgroup
   static constexpr int NPOS = TS0 * TS1 * TS2;
-  static constexpr size_t lds_bf16 = (size_t)HP * 128 + 2 * 8192;
+  static constexpr size_t stage_bytes = (size_t)NPOS * (CT + 4) * 4;
+  static constexpr size_t lds_bf16_raw = (size_t)HP * 128 + 2 * 8192;
+  static constexpr size_t lds_bf16 = lds_bf16_raw > stage_bytes ? lds_bf16_raw : stage_bytes;
   static constexpr size_t lds_f32 = (size_t)HP * F32_ROW * 4 + 2 * CIN * F32_BROW * 4;
 };
 
@@ -94,14 +104,16 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w,
   }
 }
 
-template <int PREC, int TS0, int TS1, int NW>
+template <int PREC, int TS0, int TS1, int NW, bool IN16, bool OUT16>
 __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
-    const float* __restrict__ x, const void* __restrict__ wpk,
-    const float* __restrict__ bias, const float* __restrict__ res,
-    float* __restrict__ y, ConvGeom g, int tiles0, int tiles1, int tiles2) {
+    const void* __restrict__ xv, const void* __restrict__ wpk,
+    const float* __restrict__ bias, const void* __restrict__ resv,
+    void* __restrict__ yv, ConvGeom g, int tiles0, int tiles1, int tiles2,
+    int res16) {
   using T = Tile<TS0, TS1, NW>;
   constexpr int H1 = T::H1, HP = T::HP, MFW = T::MFW, NT = T::NT;
   static_assert(MFW >= 1 && MFW * NW == TS0 * TS1, "tile / wave split");
+  static_assert(PREC == S3_PREC_BF16 || (!IN16 && !OUT16), "bf16 I/O needs bf16 MFMA");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -175,19 +187,19 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   b_issue(0);
 
   // ---- stage the input halo (boundary handled here, once per element).
-  // 4 items per thread per trip: all global loads of a trip are issued before
-  // the first convert/ds_write so >= 8 x 16-B loads per lane are in flight.
+  // UN items per thread per trip: all global loads of a trip are issued before
+  // the first convert/ds_write so many 16-B loads per lane are in flight.
   {
     constexpr int CHUNKS = PREC == S3_PREC_BF16 ? 8 : 16;  // per position
     constexpr int ITEMS = HP * CHUNKS;
-    constexpr int UN = 4;
+    constexpr int UN = IN16 ? 8 : 4;
     for (int base = tid; base < ITEMS; base += NT * UN) {
-      float4 va[UN], vb[UN];
+      uint4 va[UN], vb[IN16 ? 1 : UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const int item = base + u * NT;
-        va[u] = make_float4(0, 0, 0, 0);
-        vb[u] = va[u];
+        va[u] = make_uint4(0, 0, 0, 0);
+        if (!IN16) vb[u] = va[u];
         if (item < ITEMS) {
           const int hp = item / CHUNKS, ch = item % CHUNKS;
           int h = hp;
@@ -205,13 +217,18 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
           i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
           i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
           i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
-          const float* src = x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * CIN;
+          const size_t pos = (((size_t)n * D0 + i0) * D1 + i1) * D2 + i2;
           if (valid) {
-            if (PREC == S3_PREC_BF16) {
-              va[u] = *reinterpret_cast<const float4*>(src + ch * 8);
-              vb[u] = *reinterpret_cast<const float4*>(src + ch * 8 + 4);
+            if (IN16) {
+              va[u] = *reinterpret_cast<const uint4*>(
+                  reinterpret_cast<const unsigned short*>(xv) + pos * CIN + ch * 8);
+            } else if (PREC == S3_PREC_BF16) {
+              const float* src = reinterpret_cast<const float*>(xv) + pos * CIN + ch * 8;
+              va[u] = *reinterpret_cast<const uint4*>(src);
+              vb[u] = *reinterpret_cast<const uint4*>(src + 4);
             } else {
-              va[u] = *reinterpret_cast<const float4*>(src + ch * 4);
+              va[u] = *reinterpret_cast<const uint4*>(
+                  reinterpret_cast<const float*>(xv) + pos * CIN + ch * 4);
             }
           }
         }
@@ -222,21 +239,25 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
         if (item < ITEMS) {
           const int hp = item / CHUNKS, ch = item % CHUNKS;
           if (PREC == S3_PREC_BF16) {
-            const float4 a = va[u], b = vb[u];
             uint4 o;
-            o.x = pack_bf16(a.x, a.y);
-            o.y = pack_bf16(a.z, a.w);
-            o.z = pack_bf16(b.x, b.y);
-            o.w = pack_bf16(b.z, b.w);
+            if (IN16) {
+              o = va[u];
+            } else {
+              const uint4 a = va[u], b = vb[IN16 ? 0 : u];
+              o.x = pack_bf16(__uint_as_float(a.x), __uint_as_float(a.y));
+              o.y = pack_bf16(__uint_as_float(a.z), __uint_as_float(a.w));
+              o.z = pack_bf16(__uint_as_float(b.x), __uint_as_float(b.y));
+              o.w = pack_bf16(__uint_as_float(b.z), __uint_as_float(b.w));
+            }
             // swizzle keyed on the t coordinate of the halo cell so that the
             // read-side key depends on the tap's t-shift only (3 variants)
             const int slot = ch ^ (((hp % H2) >> 1) & 7);
             *reinterpret_cast<uint4*>(halo + (size_t)hp * 128 + slot * 16) = o;
           } else {
-            const float4 a = va[u];
-            float2* d = reinterpret_cast<float2*>(halo + ((size_t)hp * F32_ROW + ch * 4) * 4);
-            d[0] = make_float2(a.x, a.y);
-            d[1] = make_float2(a.z, a.w);
+            const uint4 a = va[u];
+            uint2* d = reinterpret_cast<uint2*>(halo + ((size_t)hp * F32_ROW + ch * 4) * 4);
+            d[0] = make_uint2(a.x, a.y);
+            d[1] = make_uint2(a.z, a.w);
           }
         }
       }
@@ -247,13 +268,6 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
 
   // ---- per-wave fragment coordinates
   const int frow = lane & 15, kq = lane >> 4;
-  int hp_base[MFW];
-#pragma unroll
-  for (int m = 0; m < MFW; ++m) {
-    const int mf = wave * MFW + m;       // (s1, s2) pair inside the tile
-    const int s1 = mf / TS1, s2 = mf % TS1;
-    hp_base[m] = (s1 * H1 + s2) * H2 + frow;
-  }
   f32x4 acc[MFW][4];
 #pragma unroll
   for (int m = 0; m < MFW; ++m)
@@ -290,7 +304,6 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
       for (int tb = 0; tb < 3; ++tb) {
 #pragma unroll
         for (int tc = 0; tc < 3; ++tc) {
-          constexpr int dummy = 0; (void)dummy;
           const int tap = (ta * 3 + tb) * 3 + tc;
           if (tap + 1 < 27) b_issue(tap + 1);
 #pragma unroll
@@ -314,6 +327,12 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
       }
     }
   } else {
+    int hp_base[MFW];
+#pragma unroll
+    for (int m = 0; m < MFW; ++m) {
+      const int mf = wave * MFW + m;       // (s1, s2) pair inside the tile
+      hp_base[m] = ((mf / TS1) * H1 + mf % TS1) * H2 + frow;
+    }
     for (int tap = 0; tap < taps; ++tap) {
       if (tap + 1 < taps) b_issue(tap + 1);
       const int ta = tap / (KK1 * KK2), tb = (tap / KK2) % KK1, tc = tap % KK2;
@@ -340,10 +359,10 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
     }
   }
 
-  // ---- epilogue.  The accumulators go through LDS (the halo is dead after
-  // the last barrier) so that every thread handles 4 consecutive output
-  // channels of one position: 16-B coalesced residual loads / stores, all
-  // independent, instead of 64 scalar 4-B accesses per lane.
+  // ---- epilogue.  The accumulators go through LDS (halo + slabs are dead
+  // after the last barrier) so that every thread handles CPT consecutive
+  // output channels of one position: 16-B coalesced residual loads / stores,
+  // all independent, instead of 64 scalar 4-B accesses per lane.
   constexpr int SROW = CT + 4;   // 68: keeps float4 alignment, conflict-free
   float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -357,25 +376,33 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   }
   __syncthreads();
   {
-    const int c4 = (tid & 15) * 4;
-    const int co = ct * CT + c4;
-    const bool co_ok = co < g.Cout;   // C_out % 4 == 0 (checked at dispatch)
-    float4 bv = make_float4(0, 0, 0, 0);
-    if (bias && co_ok) bv = *reinterpret_cast<const float4*>(bias + co);
+    constexpr int CPT = OUT16 ? 8 : 4;     // channels per thread (16-B store)
+    constexpr int GPP = CT / CPT;          // thread groups per position
+    constexpr int PPP = NT / GPP;          // positions per pass
+    constexpr int NIT = T::NPOS / PPP;
+    const int c0 = (tid % GPP) * CPT;
+    const int co = ct * CT + c0;
+    const bool co_ok = co < g.Cout;   // C_out % CPT == 0 (checked at dispatch)
+    float bv[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) bv[q] = (bias && co_ok) ? bias[co + q] : 0.f;
     const int b = g.d2s;
     const int cpo = g.Cout / (b * b);
     const int blk = co / cpo, cc = co % cpo;
     const int act = g.act;
     const float alpha = g.alpha;
-    constexpr int PPP = NT / 16;          // positions per pass
-    constexpr int NIT = T::NPOS / PPP;
 #pragma unroll 4
     for (int j = 0; j < NIT; ++j) {
-      const int pl = (tid >> 4) + PPP * j;     // local position
+      const int pl = (tid / GPP) + PPP * j;     // local position
       const int mf = pl / TS2, o2 = org2 + pl % TS2;
       const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1;
       if (!co_ok || o0 >= g.O[0] || o1 >= g.O[1] || o2 >= g.O[2]) continue;
-      float4 v = *reinterpret_cast<const float4*>(stage + pl * SROW + c4);
+      float v[CPT];
+#pragma unroll
+      for (int q = 0; q < CPT; q += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(stage + pl * SROW + c0 + q);
+        v[q] = t.x; v[q + 1] = t.y; v[q + 2] = t.z; v[q + 3] = t.w;
+      }
       size_t dst;
       if (b == 1) {
         dst = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co;
@@ -383,23 +410,48 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
         dst = ((((size_t)n * g.O[0] * b + o0 * b + blk / b) * (g.O[1] * b) +
                 o1 * b + blk % b) * g.O[2] + o2) * cpo + cc;
       }
-      v.x = act_f(v.x + bv.x, act, alpha); v.y = act_f(v.y + bv.y, act, alpha);
-      v.z = act_f(v.z + bv.z, act, alpha); v.w = act_f(v.w + bv.w, act, alpha);
-      if (res) {
-        const float4 rv = *reinterpret_cast<const float4*>(res + dst);
-        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) v[q] = act_f(v[q] + bv[q], act, alpha);
+      if (resv) {
+        if (res16) {
+          const unsigned short* rp = reinterpret_cast<const unsigned short*>(resv) + dst;
+          if (CPT == 8) {
+            const uint4 r = *reinterpret_cast<const uint4*>(rp);
+            v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
+            v[4 % CPT] += bf_lo(r.z); v[5 % CPT] += bf_hi(r.z);
+            v[6 % CPT] += bf_lo(r.w); v[7 % CPT] += bf_hi(r.w);
+          } else {
+            const uint2 r = *reinterpret_cast<const uint2*>(rp);
+            v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
+          }
+        } else {
+          const float* rp = reinterpret_cast<const float*>(resv) + dst;
+#pragma unroll
+          for (int q = 0; q < CPT; q += 4) {
+            const float4 r = *reinterpret_cast<const float4*>(rp + q);
+            v[q] += r.x; v[q + 1] += r.y; v[q + 2] += r.z; v[q + 3] += r.w;
+          }
+        }
       }
-      *reinterpret_cast<float4*>(y + dst) = v;
+      if (OUT16) {
+        uint4 o;
+        o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]);
+        o.z = pack_bf16(v[4 % CPT], v[5 % CPT]); o.w = pack_bf16(v[6 % CPT], v[7 % CPT]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(yv) + dst) = o;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + dst) =
+            make_float4(v[0], v[1], v[2], v[3]);
+      }
     }
   }
 }
 
-template <int PREC, int TS0, int TS1, int NW = 4>
-int launch_cfg(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* wpk,
-               const float* bias, const float* res, float* y) {
+template <int PREC, int TS0, int TS1, int NW, bool IN16, bool OUT16>
+int launch_io(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* wpk,
+              const float* bias, const void* res, void* y, int res16) {
   using T = Tile<TS0, TS1, NW>;
   const size_t lds = PREC == S3_PREC_BF16 ? T::lds_bf16 : T::lds_f32;
-  auto kern = conv3_mfma_kernel<PREC, TS0, TS1, NW>;
+  auto kern = conv3_mfma_kernel<PREC, TS0, TS1, NW, IN16, OUT16>;
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -409,9 +461,21 @@ int launch_cfg(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* wpk,
   const int tiles0 = (g.O[0] + TS0 - 1) / TS0, tiles1 = (g.O[1] + TS1 - 1) / TS1,
             tiles2 = (g.O[2] + TS2 - 1) / TS2;
   dim3 grid((unsigned)(g.N * tiles0 * tiles1 * tiles2), (unsigned)((g.Cout + CT - 1) / CT));
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, ctx->stream, x, wpk, bias, res, y, g, tiles0, tiles1, tiles2);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, ctx->stream, x, wpk, bias, res, y, g, tiles0, tiles1, tiles2, res16);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
+}
+
+template <int TS0, int TS1, int NW>
+int launch_bf16(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* wpk,
+                const float* bias, const void* res, void* y, ConvIO io) {
+  if (io.in_bf16 && io.out_bf16)
+    return launch_io<S3_PREC_BF16, TS0, TS1, NW, true, true>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
+  if (io.in_bf16)
+    return launch_io<S3_PREC_BF16, TS0, TS1, NW, true, false>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
+  if (io.out_bf16)
+    return launch_io<S3_PREC_BF16, TS0, TS1, NW, false, true>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
+  return launch_io<S3_PREC_BF16, TS0, TS1, NW, false, false>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
 }
 
 }  // namespace
@@ -430,6 +494,11 @@ bool conv_mfma_supported(const ConvGeom& g, int precision) {
   if (g.k[2] == 1) return false;   // 2-D nets stay on the direct kernel for now
   if (g.D[2] < 8) return false;    // 16-long t runs would be mostly masked
   return true;
+}
+
+// the bf16 store handles 8 consecutive channels per thread
+bool conv_mfma_bf16_out_ok(const ConvGeom& g) {
+  return g.Cout % 8 == 0 && (g.Cout / (g.d2s * g.d2s)) % 8 == 0;
 }
 
 size_t conv_mfma_packed_bytes(const ConvGeom& g, int precision) {
@@ -454,18 +523,24 @@ int launch_conv_mfma_pack(s3_ctx* ctx, const ConvGeom& g, int precision,
 }
 
 int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
-                         const float* x, const void* packed, const float* bias,
-                         const float* res, float* y) {
+                         const void* x, const void* packed, const float* bias,
+                         const void* res, void* y, ConvIO io) {
   if (precision == S3_PREC_BF16) {
-    static const int tile = getenv("SUP3R_AMD_MFMA_TILE") ? atoi(getenv("SUP3R_AMD_MFMA_TILE")) : 0;
-    if (tile == 1) return launch_cfg<S3_PREC_BF16, 2, 4>(ctx, g, x, packed, bias, res, y);
-    if (tile == 2) return launch_cfg<S3_PREC_BF16, 4, 4, 8>(ctx, g, x, packed, bias, res, y);
-    if (tile == 3) return launch_cfg<S3_PREC_BF16, 2, 4, 8>(ctx, g, x, packed, bias, res, y);
-    if (tile == 4) return launch_cfg<S3_PREC_BF16, 4, 8, 16>(ctx, g, x, packed, bias, res, y);
-    if (tile == 5) return launch_cfg<S3_PREC_BF16, 4, 4, 16>(ctx, g, x, packed, bias, res, y);
-    if (tile == 6) return launch_cfg<S3_PREC_BF16, 4, 8, 8>(ctx, g, x, packed, bias, res, y);
-    return launch_cfg<S3_PREC_BF16, 4, 4>(ctx, g, x, packed, bias, res, y);
+    // tile / wave configuration (SUP3R_AMD_MFMA_TILE overrides for A/B probes)
+    static const int tile_env = getenv("SUP3R_AMD_MFMA_TILE") ? atoi(getenv("SUP3R_AMD_MFMA_TILE")) : -1;
+    int tile = tile_env;
+    if (tile < 0) {
+      // 512-position workgroups (16 waves) amortise the filter slabs best;
+      // fall back to 128-position ones when the grid would not fill the chip
+      const int64_t big = (int64_t)g.N * ((g.O[0] + 3) / 4) * ((g.O[1] + 7) / 8) * ((g.O[2] + 15) / 16);
+      tile = big >= ctx->num_cu ? 4 : 3;
+    }
+    if (tile == 1) return launch_bf16<2, 4, 4>(ctx, g, x, packed, bias, res, y, io);
+    if (tile == 2) return launch_bf16<4, 4, 8>(ctx, g, x, packed, bias, res, y, io);
+    if (tile == 3) return launch_bf16<2, 4, 8>(ctx, g, x, packed, bias, res, y, io);
+    if (tile == 4) return launch_bf16<4, 8, 16>(ctx, g, x, packed, bias, res, y, io);
+    return launch_bf16<4, 4, 4>(ctx, g, x, packed, bias, res, y, io);
   }
   // f32: the filters are read in canonical layout; `packed` is unused
-  return launch_cfg<S3_PREC_F32, 2, 4>(ctx, g, x, packed, bias, res, y);
+  return launch_io<S3_PREC_F32, 2, 4, 4, false, false>(ctx, g, x, packed, bias, res, y, 0);
 }

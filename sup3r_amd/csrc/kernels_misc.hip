@@ -19,9 +19,9 @@ inline int grid_for(int64_t n_threads, int num_cu) {
 
 // ------------------------------------------------------------------ gather
 // out[n, o0, o1, o2, c] = in[map(...)]; V = channels per thread (1 or 4)
-template <int V>
-__global__ void gather_kernel(const float* __restrict__ in,
-                              float* __restrict__ out, GatherGeom g) {
+template <int V, typename T>
+__global__ void gather_kernel(const T* __restrict__ in, T* __restrict__ out,
+                              GatherGeom g) {
   const int cg_out = g.Co / V;
   const int64_t total = (int64_t)g.N * g.Do[0] * g.Do[1] * g.Do[2] * cg_out;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,12 +70,12 @@ __global__ void gather_kernel(const float* __restrict__ in,
     int co_total = (g.kind == S3_OP_CONCAT) ? g.rep : g.Co;  // rep = C of out
     int64_t dst = ((((int64_t)n * g.Do[0] + o0) * g.Do[1] + o1) * g.Do[2] + o2) *
                       co_total + out_c;
-    if (V == 4) {
-      float4 v = zero ? make_float4(0, 0, 0, 0)
-                      : *reinterpret_cast<const float4*>(in + src);
-      *reinterpret_cast<float4*>(out + dst) = v;
+    if (V * sizeof(T) == 16) {
+      uint4 v = zero ? make_uint4(0, 0, 0, 0)
+                     : *reinterpret_cast<const uint4*>(in + src);
+      *reinterpret_cast<uint4*>(out + dst) = v;
     } else {
-      out[dst] = zero ? 0.f : in[src];
+      out[dst] = zero ? (T)0 : in[src];
     }
   }
 }
@@ -463,13 +463,20 @@ int ensure_scratch(s3_ctx* ctx, size_t bytes) {
   return S3_OK;
 }
 
-int launch_gather(s3_ctx* ctx, const GatherGeom& g, const float* in, float* out) {
-  bool vec = (g.Co % 4 == 0) && (g.Ci % 4 == 0) &&
-             (g.kind != S3_OP_CONCAT || (g.c_off % 4 == 0 && g.rep % 4 == 0));
-  int64_t n = (int64_t)g.N * g.Do[0] * g.Do[1] * g.Do[2] * (g.Co / (vec ? 4 : 1));
+int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
+                  int esize) {
+  const int vw = 16 / esize;   // elements per 16-B access
+  bool vec = (g.Co % vw == 0) && (g.Ci % vw == 0) &&
+             (g.kind != S3_OP_CONCAT || (g.c_off % vw == 0 && g.rep % vw == 0));
+  int64_t n = (int64_t)g.N * g.Do[0] * g.Do[1] * g.Do[2] * (g.Co / (vec ? vw : 1));
   int grid = grid_for(n, ctx->num_cu);
-  if (vec) hipLaunchKernelGGL(gather_kernel<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, in, out, g);
-  else hipLaunchKernelGGL(gather_kernel<1>, dim3(grid), dim3(kBlock), 0, ctx->stream, in, out, g);
+  if (esize == 4) {
+    if (vec) hipLaunchKernelGGL((gather_kernel<4, float>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const float*)in, (float*)out, g);
+    else hipLaunchKernelGGL((gather_kernel<1, float>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const float*)in, (float*)out, g);
+  } else {
+    if (vec) hipLaunchKernelGGL((gather_kernel<8, unsigned short>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const unsigned short*)in, (unsigned short*)out, g);
+    else hipLaunchKernelGGL((gather_kernel<1, unsigned short>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const unsigned short*)in, (unsigned short*)out, g);
+  }
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

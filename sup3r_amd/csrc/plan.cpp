@@ -6,6 +6,7 @@
 // the same list in reverse.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -31,6 +32,8 @@ struct TensorRec {
   float* ptr = nullptr;
   float* gptr = nullptr;  // gradient buffer (training plans)
   bool is_input = false;
+  int dtype = 0;        // 0 = fp32, 1 = bf16 (inference plans, bf16 mode)
+  size_t bytes() const { return (size_t)numel * (dtype ? 2 : 4); }
 };
 
 struct OpRec {
@@ -38,6 +41,7 @@ struct OpRec {
   ConvGeom cg;
   GatherGeom gg;
   bool mfma = false;
+  ConvIO io;
   void* packed = nullptr;
   uint64_t packed_version = 0;
 };
@@ -354,6 +358,69 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
         return bad("plan: unknown op kind");
     }
   }
+  // ---- activation dtypes.  Inference plans in bf16 mode keep a tensor in
+  // bf16 when its producer can write it (MFMA conv, direct conv, index op) and
+  // EVERY consumer can read it (MFMA conv input / residual, index op);
+  // everything else — plan inputs/outputs, training plans, f32 mode — is fp32.
+  if (!training && precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_FP32_ACT")) {
+    std::vector<int> dt(n_tensors, 1);
+    auto demote = [&](int id, bool& changed) {
+      if (id < 0) return;
+      int r = root_of(pl, id);
+      if (dt[r]) { dt[r] = 0; changed = true; }
+    };
+    bool changed = true;
+    {
+      bool c0 = false;
+      for (int id : pl->inputs) demote(id, c0);
+      demote(output, c0);
+      // tensors nobody produces (defensive) stay fp32
+      std::vector<char> produced(n_tensors, 0);
+      for (auto& o : pl->ops) produced[root_of(pl, o.d.out)] = 1;
+      for (int i = 0; i < n_tensors; ++i)
+        if (!produced[root_of(pl, i)]) demote(i, c0);
+    }
+    while (changed) {
+      changed = false;
+      for (auto& o : pl->ops) {
+        const s3_op_desc& d = o.d;
+        switch (d.kind) {
+          case S3_OP_CONV:
+            if (o.mfma) {
+              if (!conv_mfma_bf16_out_ok(o.cg)) demote(d.out, changed);
+            } else {
+              // the direct kernels read fp32, except the sliding-window
+              // small-channel conv which also takes bf16 cells
+              if (!(d.res < 0 && conv_small_supported(o.cg, 1))) demote(d.in0, changed);
+              demote(d.res, changed);
+              if (d.res < 0 && conv_small_supported(o.cg, 1)) demote(d.out, changed);
+            }
+            break;
+          case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
+          case S3_OP_ROLL_T:
+            if (dt[root_of(pl, d.in0)] != dt[root_of(pl, d.out)]) {
+              demote(d.in0, changed);
+              demote(d.out, changed);
+            }
+            break;
+          case S3_OP_VIEW:
+            break;  // alias: one root, one dtype (element count is preserved)
+          default:
+            demote(d.in0, changed); demote(d.in1, changed);
+            demote(d.res, changed); demote(d.out, changed);
+            break;
+        }
+      }
+    }
+    for (int i = 0; i < n_tensors; ++i) pl->t[i].dtype = dt[root_of(pl, i)];
+  }
+  for (auto& o : pl->ops) {
+    if (o.d.kind != S3_OP_CONV) continue;
+    o.io.in_bf16 = pl->t[root_of(pl, o.d.in0)].dtype;
+    o.io.out_bf16 = pl->t[root_of(pl, o.d.out)].dtype;
+    o.io.res_bf16 = o.d.res >= 0 ? pl->t[root_of(pl, o.d.res)].dtype : 0;
+  }
+
   // ---- static arena planning.  Training keeps every tensor; inference
   // reuses buffers by liveness (greedy best-fit).
   std::vector<int> last_use(n_tensors, -1);
@@ -370,7 +437,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     const s3_op_desc& d = pl->ops[i].d;
     if (d.kind == S3_OP_VIEW) continue;
     TensorRec& ot = pl->t[d.out];
-    size_t need = (size_t)ot.numel * sizeof(float);
+    size_t need = ot.bytes();
     int pick = -1;
     if (!training) {
       for (int b = 0; b < (int)bsize.size(); ++b)
@@ -436,6 +503,7 @@ extern "C" int64_t s3_plan_workspace_bytes(const s3_plan* pl) {
 }
 
 static float* tptr(s3_plan* pl, int id) { return pl->t[root_of(pl, id)].ptr; }
+static int tdtype(s3_plan* pl, int id) { return pl->t[root_of(pl, id)].dtype; }
 static float* gptr(s3_plan* pl, int id) { return pl->t[root_of(pl, id)].gptr; }
 
 static int run_op_forward(s3_plan* pl, OpRec& o) {
@@ -456,9 +524,9 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
           o.packed_version = P->version;
         }
         const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.packed : (const void*)w;
-        return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out));
+        return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out), o.io);
       }
-      return launch_conv_generic_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out));
+      return launch_conv_generic_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out), o.io.out_bf16, o.io.in_bf16);
     }
     case S3_OP_DENSE: {
       const TensorRec& it = pl->t[d.in0];
@@ -469,7 +537,7 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
     }
     case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
     case S3_OP_ROLL_T:
-      return launch_gather(ctx, o.gg, tptr(pl, d.in0), tptr(pl, d.out));
+      return launch_gather(ctx, o.gg, tptr(pl, d.in0), tptr(pl, d.out), tdtype(pl, d.out) ? 2 : 4);
     case S3_OP_CONCAT: {
       // two channel-range copies: x -> out[..., :Cx], exo -> out[..., Cx:]
       const TensorRec& a = pl->t[d.in0];
