@@ -31,9 +31,10 @@ HR_SHAPE = (80, 80, 288, 2)
 GEN_FLOP_PER_SAMPLE = 598.9e9
 # dominant kernel: Conv3D 64->64 3x3x3 on (16,16,288): 2*73728*64*1728 FLOP
 BODY_CONV_FLOP_PER_SAMPLE = 2.0 * 16 * 16 * 288 * 64 * 27 * 64
-# ... and its algorithmic HBM bytes (read un-padded input once, write output
-# once, fp32 activations) per sample
-BODY_CONV_BYTES_PER_SAMPLE = 2.0 * 16 * 16 * 288 * 64 * 4
+# ... and its algorithmic HBM bytes per sample: read the un-padded input once +
+# write the output once (bf16 mode keeps the 64-channel trunk in bf16)
+BODY_CONV_ELEMS_PER_SAMPLE = 2.0 * 16 * 16 * 288 * 64
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r01', 'traffic.json')
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}   # MI355X_MICROARCH.md (dense)
 PEAK_HBM_GBS = 8000.0
 
@@ -142,6 +143,15 @@ def main():
     body_ms = float(np.mean([ms[i] for i in body])) if body else float('nan')
     flop = BODY_CONV_FLOP_PER_SAMPLE * B
     achieved = flop / (body_ms * 1e-3) / 1e12
+    esize = 2 if args.precision == 'bf16' else 4
+    body_bytes = BODY_CONV_ELEMS_PER_SAMPLE * esize * B
+    # measured HBM traffic of this kernel (PMC, separate rocprofv3 passes of
+    # the same command; committed under profiles/), scaled to this batch
+    traffic = None
+    if args.precision == 'bf16' and os.path.exists(TRAFFIC_JSON):
+        with open(TRAFFIC_JSON) as f:
+            tj = json.load(f)
+        traffic = tj['traffic_bytes_per_launch'] * B / tj['batch']
     peak = PEAK_TFLOPS[args.precision]
     conv_ms = sum(ms[i] for i, op in enumerate(ph.plan.ops) if 'cout' in op)
     result = {
@@ -166,12 +176,11 @@ def main():
         'roofline': {
             'kernel': 'conv3_mfma_kernel (Conv3D 64->64 k3, reflect-pad fused)',
             'bound': 'mfma', 'achieved': achieved, 'peak': peak,
-            'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+            'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
+            'algorithmic_bytes_per_launch': body_bytes,
             'launches_per_step': len(body), 'avg_launch_ms': body_ms,
-            'hbm_algorithmic_GBps': BODY_CONV_BYTES_PER_SAMPLE * B
-            / (body_ms * 1e-3) / 1e9,
-            'hbm_frac': BODY_CONV_BYTES_PER_SAMPLE * B / (body_ms * 1e-3)
-            / 1e9 / PEAK_HBM_GBS,
+            'hbm_algorithmic_GBps': body_bytes / (body_ms * 1e-3) / 1e9,
+            'hbm_frac': body_bytes / (body_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             'conv_ms_per_step': conv_ms, 'all_ops_ms_per_step': sum(ms),
             'forwards_profiled': n_prof},
     }
