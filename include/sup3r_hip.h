@@ -163,6 +163,12 @@ int s3_plan_op_is_mfma(const s3_plan* plan, int op_index);
 int s3_loss_content(s3_ctx* ctx, int kind, const float* a, int c_a,
                     const float* b, int c_b, int c_used, int64_t n_pos,
                     float weight, float* loss_out, float* d_a, int accumulate);
+/* masked variant used by Sup3rCondMom.calc_loss_cond_mom
+ * (sup3r/models/conditional.py:221-241): loss(a * mask, b * mask). */
+int s3_loss_content_masked(s3_ctx* ctx, int kind, const float* a, int c_a,
+                           const float* b, int c_b, const float* mask, int c_m,
+                           int c_used, int64_t n_pos, float weight,
+                           float* loss_out, float* d_a, int accumulate);
 /* relativistic BCE of Sup3rGan.calc_loss_disc (base.py:505-549).
  * loss_out: device float; d_true / d_gen nullable (n floats each), scaled by
  * `scale` (weight_gen_advers for the adversarial term). */

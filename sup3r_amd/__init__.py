@@ -11,5 +11,8 @@ kernels for gfx950, C-ABI in include/sup3r_hip.h).  There is no CPU fallback.
 __version__ = '0.1.0'
 
 from .gan import Sup3rGan  # noqa: E402,F401
+from .condmom import Sup3rCondMom  # noqa: E402,F401
+from .forward_pass import ChunkSlicer, ForwardPass  # noqa: E402,F401
 
-__all__ = ['Sup3rGan', '__version__']
+__all__ = ['Sup3rGan', 'Sup3rCondMom', 'ForwardPass', 'ChunkSlicer',
+           '__version__']

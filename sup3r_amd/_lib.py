@@ -24,7 +24,7 @@ EXPORTS = [
     's3_plan_create', 's3_plan_destroy', 's3_plan_forward',
     's3_plan_backward', 's3_plan_tensor', 's3_plan_workspace_bytes',
     's3_plan_profile_begin', 's3_plan_profile_end',
-    's3_plan_op_is_mfma', 's3_loss_content', 's3_loss_rel_bce',
+    's3_plan_op_is_mfma', 's3_loss_content', 's3_loss_content_masked', 's3_loss_rel_bce',
     's3_copy_channels', 's3_affine_channels', 's3_fill',
     's3_comm_unique_id', 's3_comm_init', 's3_params_allreduce_grads',
     's3_allreduce_sum', 's3_version',
@@ -95,6 +95,8 @@ def lib():
         's3_plan_op_is_mfma': (i32, [vp, i32]),
         's3_loss_content': (i32, [vp, i32, vp, i32, vp, i32, i32, i64, f32,
                                   vp, vp, i32]),
+        's3_loss_content_masked': (i32, [vp, i32, vp, i32, vp, i32, vp, i32,
+                                         i32, i64, f32, vp, vp, i32]),
         's3_loss_rel_bce': (i32, [vp, vp, vp, i32, f32, vp, vp, vp]),
         's3_copy_channels': (i32, [vp, vp, i32, i32, vp, i32, i32, i32, i64,
                                    i32]),

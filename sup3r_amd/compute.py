@@ -94,7 +94,7 @@ class HipGanCompute:
     def loss_and_grads(self, low_res, hi_res_true, loss_terms,
                        weight_gen_advers=0.001, train_gen=True,
                        train_disc=False, compute_disc=False, exo_names=(),
-                       backward=True, hi_res_gen=None):
+                       backward=True, hi_res_gen=None, mask=None):
         """One ``_get_hr_exo_and_loss`` + ``tape.gradient``.
 
         ``backward=False`` evaluates ``calc_loss`` only (validation).  When
@@ -134,6 +134,12 @@ class HipGanCompute:
                 'config and data handlers.'.format(tuple(gen_full.shape),
                                                    tuple(hr_true.shape)))
         c_used = c_true - n_exo
+        mask_d = None
+        if mask is not None:
+            # Sup3rCondMom: loss(gen * mask, true * mask) over ALL channels
+            # (conditional.py:221-241)
+            mask_d = dev.to_device(mask)
+            c_used = c_true
         scal = self._scalars()
         L.s3_fill(dev.ctx, self._ptr(scal), 16, 0.0)
         details = {}
@@ -164,11 +170,19 @@ class HipGanCompute:
                           0.0)
             n_pos = gen_full.numel() // c_true
             for i, (name, kind, w) in enumerate(loss_terms):
-                rc = L.s3_loss_content(
-                    dev.ctx, kind, self._ptr(gen_full), c_true,
-                    self._ptr(hr_true), c_true, c_used, n_pos, w,
-                    self._ptr(scal, 4 + i),
-                    self._ptr(d_gen_full) if gen_train else None, 1)
+                if mask_d is None:
+                    rc = L.s3_loss_content(
+                        dev.ctx, kind, self._ptr(gen_full), c_true,
+                        self._ptr(hr_true), c_true, c_used, n_pos, w,
+                        self._ptr(scal, 4 + i),
+                        self._ptr(d_gen_full) if gen_train else None, 1)
+                else:
+                    rc = L.s3_loss_content_masked(
+                        dev.ctx, kind, self._ptr(gen_full), c_true,
+                        self._ptr(hr_true), c_true, self._ptr(mask_d),
+                        mask_d.shape[-1], c_used, n_pos, w,
+                        self._ptr(scal, 4 + i),
+                        self._ptr(d_gen_full) if gen_train else None, 1)
                 _lib.check(rc, dev.ctx, 's3_loss_content')
             if need_disc:
                 # adversarial term: roles swapped (base.py:899-901); only
@@ -182,7 +196,7 @@ class HipGanCompute:
             if gen_train:
                 if need_disc and weight_gen_advers != 0:
                     dx = dph_g.backward(g_adv, need_dx=True, need_wgrad=False)
-                    self._copy_channels(dx, 0, d_gen_full, 0, c_used,
+                    self._copy_channels(dx, 0, d_gen_full, 0, c_gen,
                                         accumulate=True)
                 if c_true > c_gen:
                     d_hr_gen = dev.empty(tuple(hr_gen.shape))

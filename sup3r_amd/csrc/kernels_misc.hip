@@ -286,6 +286,17 @@ __global__ void bias_grad_stage2(const float* __restrict__ partial, int nblk,
   db[ch] = accumulate ? db[ch] + t : t;
 }
 
+// wide-channel variant (dense layers: few rows, thousands of channels): one
+// thread per channel walks the rows, lanes coalesce along channels
+__global__ void bias_grad_cols(const float* __restrict__ dy, int64_t n_pos,
+                               int c, float* __restrict__ db, int accumulate) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float t = 0.f;
+  for (int64_t p = 0; p < n_pos; ++p) t += dy[p * c + ch];
+  db[ch] = accumulate ? db[ch] + t : t;
+}
+
 __global__ void mean_abs_stage1(const float* __restrict__ p, int64_t n,
                                 float* __restrict__ partial) {
   __shared__ float sm[8];
@@ -311,7 +322,8 @@ __global__ void sum_stage2(const float* __restrict__ partial, int nblk,
 // content loss over the first c_used channels; grad wrt a (c_a channels)
 __global__ void loss_content_kernel(int kind, const float* __restrict__ a,
                                     int c_a, const float* __restrict__ b,
-                                    int c_b, int c_used, int64_t n_pos,
+                                    int c_b, const float* __restrict__ mask,
+                                    int c_m, int c_used, int64_t n_pos,
                                     float gscale, float* __restrict__ partial,
                                     float* __restrict__ d_a, int accumulate) {
   __shared__ float sm[8];
@@ -321,7 +333,8 @@ __global__ void loss_content_kernel(int kind, const float* __restrict__ a,
        i += (int64_t)gridDim.x * blockDim.x) {
     int64_t p = i / c_used;
     int c = (int)(i % c_used);
-    float d = a[p * c_a + c] - b[p * c_b + c];
+    const float mk = mask ? mask[p * c_m + c] : 1.f;
+    float d = (a[p * c_a + c] - b[p * c_b + c]) * mk;
     float g;
     if (kind == S3_LOSS_MAE) {
       acc += fabsf(d);
@@ -331,7 +344,7 @@ __global__ void loss_content_kernel(int kind, const float* __restrict__ a,
       g = 2.f * d;
     }
     if (d_a) {
-      float v = g * gscale;
+      float v = g * gscale * mk;
       d_a[p * c_a + c] = accumulate ? d_a[p * c_a + c] + v : v;
     }
   }
@@ -532,7 +545,11 @@ int launch_fill(s3_ctx* ctx, float* p, int64_t n, float v) {
 
 int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
                      float* db, int accumulate) {
-  if (c > 1024) S3_FAIL(ctx, S3_EINVAL, "bias_grad: more than 1024 channels");
+  if (c > 256) {
+    hipLaunchKernelGGL(bias_grad_cols, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, dy, n_pos, c, db, accumulate);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   int block = c <= 256 ? 256 : 1024;
   int rows = block / c;
   int64_t want = (n_pos + rows - 1) / rows;
@@ -563,10 +580,10 @@ int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
   return S3_OK;
 }
 
-extern "C" int s3_loss_content(s3_ctx* ctx, int kind, const float* a, int c_a,
-                               const float* b, int c_b, int c_used,
-                               int64_t n_pos, float weight, float* loss_out,
-                               float* d_a, int accumulate) {
+static int loss_content_impl(s3_ctx* ctx, int kind, const float* a, int c_a,
+                             const float* b, int c_b, const float* mask,
+                             int c_m, int c_used, int64_t n_pos, float weight,
+                             float* loss_out, float* d_a, int accumulate) {
   if (!ctx) return S3_EINVAL;
   if (c_used > c_a || c_used > c_b) S3_FAIL(ctx, S3_EINVAL, "loss_content: c_used exceeds channel counts");
   int64_t total = n_pos * c_used;
@@ -575,10 +592,29 @@ extern "C" int s3_loss_content(s3_ctx* ctx, int kind, const float* a, int c_a,
   int rc = ensure_scratch(ctx, (size_t)(nblk + 4) * sizeof(float));
   if (rc) return rc;
   float gscale = weight / (float)total;
-  hipLaunchKernelGGL(loss_content_kernel, dim3(nblk), dim3(kBlock), 0, ctx->stream, kind, a, c_a, b, c_b, c_used, n_pos, gscale, ctx->scratch, d_a, accumulate);
+  hipLaunchKernelGGL(loss_content_kernel, dim3(nblk), dim3(kBlock), 0, ctx->stream, kind, a, c_a, b, c_b, mask, c_m, c_used, n_pos, gscale, ctx->scratch, d_a, accumulate);
   hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->scratch, nblk, 1.f / (float)total, loss_out, 0);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
+}
+
+extern "C" int s3_loss_content(s3_ctx* ctx, int kind, const float* a, int c_a,
+                               const float* b, int c_b, int c_used,
+                               int64_t n_pos, float weight, float* loss_out,
+                               float* d_a, int accumulate) {
+  return loss_content_impl(ctx, kind, a, c_a, b, c_b, nullptr, 0, c_used, n_pos,
+                           weight, loss_out, d_a, accumulate);
+}
+
+extern "C" int s3_loss_content_masked(s3_ctx* ctx, int kind, const float* a,
+                                      int c_a, const float* b, int c_b,
+                                      const float* mask, int c_m, int c_used,
+                                      int64_t n_pos, float weight,
+                                      float* loss_out, float* d_a,
+                                      int accumulate) {
+  if (!mask || c_used > c_m) { if (ctx) ctx->err = "loss_content_masked: bad mask"; return S3_EINVAL; }
+  return loss_content_impl(ctx, kind, a, c_a, b, c_b, mask, c_m, c_used, n_pos,
+                           weight, loss_out, d_a, accumulate);
 }
 
 extern "C" int s3_loss_rel_bce(s3_ctx* ctx, const float* disc_true,

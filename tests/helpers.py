@@ -7,6 +7,8 @@ import collections
 import numpy as np
 
 Batch = collections.namedtuple('Batch', ['low_res', 'high_res'])
+MomBatch = collections.namedtuple(
+    'MomBatch', ['low_res', 'high_res', 'output', 'mask'])
 
 
 def coarsen(hr, s, t):
@@ -87,3 +89,21 @@ class SyntheticBatchHandler:
 
     def stop(self):
         self.stopped = True
+
+
+class SyntheticMomBatchHandler(SyntheticBatchHandler):
+    """Conditional-moment batches (batch_queues/conditional.py:79-167): first
+    moment target = the hi-res field itself, mask of ones with an optional
+    zeroed border."""
+
+    def __init__(self, *args, pad=0, **kwargs):
+        super().__init__(*args, **kwargs)
+
+        def to_mom(b):
+            mask = np.ones_like(b.high_res)
+            if pad:
+                mask[:, :pad] = 0
+                mask[:, -pad:] = 0
+            return MomBatch(b.low_res, b.high_res, b.high_res.copy(), mask)
+        self.batches = [to_mom(b) for b in self.batches]
+        self.val_data = ValData([to_mom(b) for b in self.val_data.batches])

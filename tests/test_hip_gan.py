@@ -226,3 +226,60 @@ def test_train_disc_and_errors():
             bad.train(bh, input_resolution={'spatial': '7km',
                                             'temporal': '40min'}, n_epoch=1,
                       out_dir=os.path.join(td, 'x_{epoch}'))
+
+
+def test_condmom_masked_mse_and_train():
+    """Sup3rCondMom (BASELINE config C5 topology at test size): masked MSE and
+    its gradient vs the oracle, then the reference's training behaviour
+    (tests/training/test_train_conditional.py: loss decreases, save/load)."""
+    from oracle.network import Network as ONet
+    from sup3r_amd import Sup3rCondMom
+    from tests.helpers import SyntheticMomBatchHandler
+    rng = np.random.default_rng(3)
+    gspec = _load('test_gen_st_2x_4x_2f.json')
+    lr = rng.standard_normal((3, 4, 4, 4, 2)).astype(np.float32)
+    ogen = ONet(gspec)
+    ogen.init_weights(lr, seed=2, bias_scale=0.05)
+    y = ogen.forward(lr)
+    true = rng.standard_normal(y.shape).astype(np.float32)
+    mask = (rng.uniform(size=y.shape) > 0.3).astype(np.float32)
+    d = (y - true) * mask
+    loss_ref = float((d.astype(np.float64) ** 2).mean())
+    ogen.backward((2.0 * d * mask / d.size).astype(np.float32))
+    g_ref = [g.copy() for g in ogen.grads]
+    model = Sup3rCondMom(gspec, learning_rate=1e-3)
+    model.generator.set_weights(ogen.weights)
+    model.init_weights(lr.shape, true.shape)
+    which, det = model.get_single_grad(lr, true, mask=mask)
+    assert which == 'gen'
+    assert set(det) == {'mean_squared_error', 'loss_gen'}
+    assert abs(float(det['loss_gen']) - loss_ref) < 1e-5 * max(1, loss_ref)
+    _cmp_grads(model.generator.grads, g_ref)
+    out = model._tf_generate(lr)
+    loss, det2 = model.calc_loss(true, out, mask)
+    assert abs(loss.numpy() - loss_ref) < 1e-5 * max(1, loss_ref)
+
+    Sup3rCondMom.seed()
+    model = Sup3rCondMom(_cfg('test_gen_st_2x_4x_2f.json'), learning_rate=5e-4)
+    bh = SyntheticMomBatchHandler((8, 8, 16), 2, 4, ['u', 'v'], batch_size=4,
+                                  n_batches=4, pad=1)
+    with tempfile.TemporaryDirectory() as td:
+        model.train(bh, input_resolution={'spatial': '8km',
+                                          'temporal': '40min'},
+                    n_epoch=4, checkpoint_int=2,
+                    out_dir=os.path.join(td, 'test_{epoch}'))
+        assert len(model.history) == 4
+        assert np.sum(np.diff(model.history['train_loss_gen'].values)) < 0
+        assert 'val_loss_gen' in model.history
+        assert 'learning_rate_gen' in model.history
+        assert 'model_gen.pkl' in os.listdir(os.path.join(td, 'test_2'))
+        assert 'model_disc.pkl' not in os.listdir(os.path.join(td, 'test_2'))
+        out_dir = os.path.join(td, 'cm')
+        model.save(out_dir)
+        loaded = Sup3rCondMom.load(out_dir)
+        b = bh.batches[0]
+        assert (model._tf_generate(b.low_res)
+                == loaded._tf_generate(b.low_res)).all().item()
+        with open(os.path.join(out_dir, 'model_params.json')) as f:
+            assert json.load(f)['num_par'] == sum(
+                w.size for w in model.generator_weights)

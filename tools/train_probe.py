@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Times one Sup3rGan._train_batch (generator step + discriminator step) on
+synthetic batches: python tools/train_probe.py --gen ... --disc ... --lr-shape N,s1,s2,t,f"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CFG = os.path.join(ROOT, 'sup3r_amd', 'configs')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gen', default='gen_3x_4x_2f.json')
+    ap.add_argument('--disc', default='disc_st_same.json')
+    ap.add_argument('--lr-shape', default='4,4,4,4,2')
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--precision', default='f32')
+    args = ap.parse_args()
+    import torch
+    from sup3r_amd import Sup3rGan
+    lr_shape = tuple(int(v) for v in args.lr_shape.split(','))
+    model = Sup3rGan(os.path.join(CFG, args.gen), os.path.join(CFG, args.disc),
+                     loss='MeanAbsoluteError', precision=args.precision)
+    s, t = model.s_enhance, model.t_enhance
+    hr_shape = (lr_shape[0], lr_shape[1] * s, lr_shape[2] * s) + (
+        (lr_shape[3] * t, lr_shape[4]) if len(lr_shape) == 5 else (lr_shape[3],))
+    rng = np.random.default_rng(0)
+    lr = rng.standard_normal(lr_shape).astype(np.float32)
+    hr = rng.standard_normal(hr_shape).astype(np.float32)
+    model.init_weights(lr_shape, hr_shape)
+
+    class B:
+        low_res, high_res = lr, hr
+    step = lambda: model._train_batch(B, True, False, False, True, False, False, 1e-3)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        d = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.iters
+    print(f'{args.gen} + {args.disc} lr{lr_shape} -> hr{hr_shape}: '
+          f'{dt * 1e3:.2f} ms per train batch ({lr_shape[0] / dt:.1f} samples/s) '
+          f'loss_gen={d["loss_gen"]:.4f} loss_disc={d["loss_disc"]:.4f}')
+    for k, v in model.timer.log.items():
+        print('   ', k, f'{v * 1e3:.2f} ms')
+
+
+if __name__ == '__main__':
+    main()
