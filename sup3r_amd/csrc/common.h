@@ -95,6 +95,21 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
                          const void* res, void* y, ConvIO io);
 bool conv_mfma_bf16_out_ok(const ConvGeom& g);
 
+// MFMA backward of the 3x3x3 stride-1 trunk convs.
+// wgrad: persistent-workgroup kernel (kernels_conv_wgrad_mfma.hip)
+bool conv_wgrad_mfma_supported(const ConvGeom& g);
+size_t conv_wgrad_mfma_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
+int launch_conv_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x,
+                           const float* dy, float* dw, float* partial,
+                           size_t partial_bytes, int accumulate);
+// dgrad: the forward halo kernel run on dPre with the flipped / transposed
+// filter over the (D+2)^3 padded frame (zero boundary), followed by the
+// adjoint of the virtual padding (fold) — kernels_conv_mfma.hip
+bool conv_dgrad_mfma_supported(const ConvGeom& g, int precision);
+ConvGeom conv_dgrad_geom(const ConvGeom& g);
+int launch_conv_dgrad_pack(s3_ctx* ctx, const ConvGeom& g, const float* w,
+                           float* wt);
+
 int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
                   int esize);
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,

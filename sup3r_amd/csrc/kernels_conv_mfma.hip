@@ -488,12 +488,59 @@ bool conv_mfma_supported(const ConvGeom& g, int precision) {
   for (int d = 0; d < 3; ++d) {
     if (g.s[d] != 1) return false;
     const int lo = g.k[d] == 3 ? 1 : 0;
-    if (g.lo[d] != lo || g.O[d] != g.D[d]) return false;
+    const bool same = g.lo[d] == lo && g.O[d] == g.D[d];
+    // dgrad frame: full correlation over the padded extent, zero boundary
+    const bool full = g.k[d] == 3 && g.lo[d] == 2 && g.O[d] == g.D[d] + 2 &&
+                      g.pad_mode == S3_PAD_ZERO;
+    if (!same && !full) return false;
   }
   if (g.d2s > 1 && (g.Cout / (g.d2s * g.d2s)) % 4 != 0) return false;
   if (g.k[2] == 1) return false;   // 2-D nets stay on the direct kernel for now
   if (g.D[2] < 8) return false;    // 16-long t runs would be mostly masked
   return true;
+}
+
+// transposed + flipped filter of the data gradient:
+// wt[tap'][co][ci] = w[26 - tap'][ci][co]
+__global__ void pack_dgrad_kernel(const float* __restrict__ w,
+                                  float* __restrict__ wt, int cin, int cout) {
+  const int64_t total = (int64_t)27 * cin * cout;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx;
+    const int ci = (int)(r % cin); r /= cin;
+    const int co = (int)(r % cout); r /= cout;
+    const int tp = (int)r;
+    wt[idx] = w[((int64_t)(26 - tp) * cin + ci) * cout + co];
+  }
+}
+
+ConvGeom conv_dgrad_geom(const ConvGeom& g) {
+  ConvGeom d = g;
+  for (int q = 0; q < 3; ++q) {
+    d.D[q] = g.O[q];            // input of the dgrad conv = dPre
+    d.O[q] = g.D[q] + 2;        // padded frame of x
+    d.lo[q] = 2;
+  }
+  d.Cin = g.Cout; d.Cout = g.Cin;
+  d.pad_mode = S3_PAD_ZERO; d.act = S3_ACT_NONE; d.alpha = 0.f; d.d2s = 1;
+  return d;
+}
+
+bool conv_dgrad_mfma_supported(const ConvGeom& g, int precision) {
+  for (int q = 0; q < 3; ++q)
+    if (g.k[q] != 3 || g.s[q] != 1 || g.lo[q] != 1 || g.O[q] != g.D[q]) return false;
+  return conv_mfma_supported(conv_dgrad_geom(g), precision);
+}
+
+int launch_conv_dgrad_pack(s3_ctx* ctx, const ConvGeom& g, const float* w,
+                           float* wt) {
+  const int64_t total = (int64_t)27 * g.Cin * g.Cout;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, wt, g.Cin, g.Cout);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
 }
 
 // the bf16 store handles 8 consecutive channels per thread

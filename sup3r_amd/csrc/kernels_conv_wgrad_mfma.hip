@@ -1,0 +1,191 @@
+// Weight gradient of the 3x3x3 stride-1 trunk convs (C_in = 64) on MFMA:
+//
+//   dW[tap][ci][co] = sum_{n, p} Xpad[n, p + tap - 1][ci] * dPre[n, p][co]
+//
+// i.e. 27 GEMMs  (64 x P)(P x 64)  with K = P = all output positions.
+// PERSISTENT workgroups (one per CU, 8 waves), each owning a 32-wide cout
+// tile: wave w holds the 16x16 block (ci-block w/2, co-block w%2) of ALL 27
+// taps — 27 f32x4 accumulators = 108 VGPRs — so the 27x64x32 gradient tile
+// (42 % of the CU's register file) lives in registers while the workgroup
+// streams position tiles (2 x 4 x 16) through LDS: the x halo
+// (4 x 6 x 18 cells x 64 ch fp32, boundary handled at the load) and the dPre
+// tile.  v_mfma_f32_16x16x4_f32 (exact fp32): A[i = ci][k = pos] and
+// B[k = pos][j = co] are single-dword LDS reads, conflict-free with the
+// (row & 1) << 4 channel swizzle.  dPre fragments are shared by the 27 taps.
+// Each workgroup writes one partial; a fixed-order reduction makes the result
+// deterministic (identical on every rank).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WT0 = 2, WT1 = 4, WT2 = 16;
+constexpr int WH0 = WT0 + 2, WH1 = WT1 + 2, WH2 = WT2 + 2;
+constexpr int WHP = WH0 * WH1 * WH2;          // 432 halo cells
+constexpr int WNP = WT0 * WT1 * WT2;          // 128 positions per tile
+constexpr int WNT = 512;
+constexpr int WCT = 32;                         // cout tile per workgroup
+constexpr size_t WG_LDS = (size_t)WHP * 64 * 4 + (size_t)WNP * WCT * 4;   // 126,976 B
+
+__global__ __launch_bounds__(512) void conv3_wgrad_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy,
+    float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
+    int tiles2, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = reinterpret_cast<float*>(smem);              // [WHP][64] swizzled
+  float* ds = xs + (size_t)WHP * 64;                       // [WNP][32] swizzled
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, kq = lane >> 4;
+  const int cib = (wave >> 1) * 16, cob = (wave & 1) * 16;
+  const int ct = blockIdx.y;                                // cout tile of 32
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int tr = tile;
+    const int t2i = tr % tiles2; tr /= tiles2;
+    const int t1i = tr % tiles1; tr /= tiles1;
+    const int t0i = tr % tiles0; tr /= tiles0;
+    const int n = tr;
+    const int org0 = t0i * WT0, org1 = t1i * WT1, org2 = t2i * WT2;
+    __syncthreads();   // previous tile fully consumed
+    // ---- stage x halo: 432 cells x 16 float4
+    for (int item = tid; item < WHP * 16; item += WNT) {
+      const int hp = item >> 4, ch = item & 15;
+      int h = hp;
+      const int c2 = h % WH2; h /= WH2;
+      const int c1 = h % WH1; h /= WH1;
+      const int c0 = h;
+      int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
+      bool valid = true;
+      if (g.pad_mode == S3_PAD_REFLECT) {
+        i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
+      } else {
+        valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
+      }
+      // cells feeding only out-of-range outputs are multiplied by zero dPre
+      i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
+      i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
+      i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
+      float4 v = make_float4(0, 0, 0, 0);
+      if (valid)
+        v = *reinterpret_cast<const float4*>(
+            x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * 64 + ch * 4);
+      const int col = (ch * 4) ^ ((hp & 1) << 4);
+      *reinterpret_cast<float4*>(xs + (size_t)hp * 64 + col) = v;
+    }
+    // ---- stage dPre tile: 128 positions x 8 float4 (zero outside / beyond C_out)
+    for (int item = tid; item < WNP * (WCT / 4); item += WNT) {
+      const int pl = item >> 3, ch = item & 7;
+      const int row = pl / WT2, tt = pl % WT2;
+      const int o0 = org0 + row / WT1, o1 = org1 + row % WT1, o2 = org2 + tt;
+      const int co = ct * WCT + ch * 4;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && co < g.Cout)
+        v = *reinterpret_cast<const float4*>(
+            dy + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co);
+      const int col = (ch * 4) ^ ((pl & 1) << 4);
+      *reinterpret_cast<float4*>(ds + (size_t)pl * WCT + col) = v;
+    }
+    __syncthreads();
+    // ---- accumulate: 8 (s1,s2) rows x 4 k-steps of 4 consecutive t
+    for (int row = 0; row < WT0 * WT1; ++row) {
+      const int r0 = row / WT1, r1 = row % WT1;
+#pragma unroll 1
+      for (int tq = 0; tq < WT2 / 4; ++tq) {
+        const int pl = row * WT2 + tq * 4 + kq;              // this lane's k
+        const float bv = ds[(size_t)pl * WCT + ((cob + fi) ^ ((pl & 1) << 4))];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const int hp = ((r0 + a) * WH1 + (r1 + b)) * WH2 + tq * 4 + kq + c;
+              const float av = xs[(size_t)hp * 64 + ((cib + fi) ^ ((hp & 1) << 4))];
+              acc[(a * 3 + b) * 3 + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                  av, bv, acc[(a * 3 + b) * 3 + c], 0, 0, 0);
+            }
+      }
+    }
+  }
+  // ---- partial[bid][tap][ci][co]: C/D map col = lane&15 (co), row = kq*4 + r (ci)
+  float* out = partial + (size_t)blockIdx.x * 27 * 64 * g.Cout;
+  const int co = ct * WCT + cob + fi;
+  if (co < g.Cout) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[((size_t)t * 64 + cib + kq * 4 + r) * g.Cout + co] = acc[t][r];
+  }
+}
+
+__global__ void wgrad_partial_reduce(const float* __restrict__ partial,
+                                     int n_part, int64_t wsize,
+                                     float* __restrict__ dw, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < wsize;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int s = 0; s < n_part; ++s) t += partial[(int64_t)s * wsize + i];
+    dw[i] = accumulate ? dw[i] + t : t;
+  }
+}
+
+int wgrad_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles_out, int* t0,
+               int* t1, int* t2) {
+  const int tiles0 = (g.O[0] + WT0 - 1) / WT0, tiles1 = (g.O[1] + WT1 - 1) / WT1,
+            tiles2 = (g.O[2] + WT2 - 1) / WT2;
+  const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
+  *n_tiles_out = n_tiles; *t0 = tiles0; *t1 = tiles1; *t2 = tiles2;
+  const int n_ct = (g.Cout + WCT - 1) / WCT;
+  int grid = ctx->num_cu / n_ct;
+  if (grid < 1) grid = 1;
+  if (grid > n_tiles) grid = n_tiles;
+  return grid;
+}
+
+}  // namespace
+
+bool conv_wgrad_mfma_supported(const ConvGeom& g) {
+  if (g.Cin != 64 || g.Cout % 4 != 0 || g.Cout < 16) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] != 1 || g.O[d] != g.D[d]) return false;
+  return g.D[2] >= 8;
+}
+
+size_t conv_wgrad_mfma_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
+  int nt, a, b, c;
+  const int grid = wgrad_grid(ctx, g, &nt, &a, &b, &c);
+  return (size_t)grid * 27 * 64 * g.Cout * sizeof(float);
+}
+
+int launch_conv_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x,
+                           const float* dy, float* dw, float* partial,
+                           size_t partial_bytes, int accumulate) {
+  int n_tiles, tiles0, tiles1, tiles2;
+  const int grid = wgrad_grid(ctx, g, &n_tiles, &tiles0, &tiles1, &tiles2);
+  if (partial_bytes < conv_wgrad_mfma_partial_bytes(ctx, g))
+    S3_FAIL(ctx, S3_EINVAL, "wgrad_mfma: partial buffer too small");
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_mfma_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
+    attr_set = true;
+  }
+  const int n_ct = (g.Cout + WCT - 1) / WCT;
+  hipLaunchKernelGGL(conv3_wgrad_mfma_kernel, dim3(grid, n_ct), dim3(WNT), WG_LDS,
+                     ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles);
+  const int64_t wsize = (int64_t)27 * 64 * g.Cout;
+  int rg = (int)((wsize + 255) / 256);
+  if (rg > 2048) rg = 2048;
+  hipLaunchKernelGGL(wgrad_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream,
+                     partial, grid, wsize, dw, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}

@@ -44,6 +44,12 @@ struct OpRec {
   ConvIO io;
   void* packed = nullptr;
   uint64_t packed_version = 0;
+  // MFMA backward (training plans)
+  bool wgrad_mfma = false, dgrad_mfma = false;
+  ConvGeom dg;                 // geometry of the dgrad-as-conv launch
+  float* dg_w32 = nullptr;     // flipped / transposed fp32 filter
+  void* dg_wbf = nullptr;      // its bf16 slabs (bf16 mode)
+  uint64_t dg_version = 0;
 };
 
 struct s3_plan {
@@ -62,6 +68,7 @@ struct s3_plan {
   float* gtmp = nullptr;      // gradient staging when a tensor has >1 consumer
   float* wg_partial = nullptr;
   size_t wg_partial_bytes = 0;
+  float* dxp = nullptr;       // padded-frame data gradient of the MFMA dgrad
   size_t total_bytes = 0;
   bool forward_done = false;
   std::vector<hipEvent_t> prof_ev;  // prof_cap * (n_ops + 1)
@@ -299,7 +306,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
   auto bad = [&](const char* m) { ctx->err = m; delete pl; return S3_EINVAL; };
   const int np = (int)params->p.size();
   pl->ops.resize(n_ops);
-  size_t max_dpre = 0, max_partial = 0, max_t = 0;
+  size_t max_dpre = 0, max_partial = 0, max_t = 0, max_dxp = 0;
   for (int i = 0; i < n_ops; ++i) {
     OpRec& o = pl->ops[i];
     o.d = ops[i];
@@ -331,6 +338,16 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
         size_t ysz = (size_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout * sizeof(float);
         max_dpre = std::max(max_dpre, ysz);
         max_partial = std::max(max_partial, conv_generic_wgrad_partial_bytes(g));
+        if (training && !getenv("SUP3R_AMD_NO_MFMA_BWD")) {
+          o.wgrad_mfma = conv_wgrad_mfma_supported(g);
+          if (o.wgrad_mfma)
+            max_partial = std::max(max_partial, conv_wgrad_mfma_partial_bytes(ctx, g));
+          o.dgrad_mfma = conv_dgrad_mfma_supported(g, precision);
+          if (o.dgrad_mfma) {
+            o.dg = conv_dgrad_geom(g);
+            max_dxp = std::max(max_dxp, (size_t)o.dg.N * o.dg.O[0] * o.dg.O[1] * o.dg.O[2] * o.dg.Cout * sizeof(float));
+          }
+        }
       } break;
       case S3_OP_DENSE: {
         if (d.w < 0) return bad("plan: dense without weights");
@@ -470,6 +487,13 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     if (!rc && max_partial) {
       rc = plan_alloc(pl, (void**)&pl->wg_partial, max_partial);
       pl->wg_partial_bytes = max_partial;
+    }
+    if (!rc && max_dxp) rc = plan_alloc(pl, (void**)&pl->dxp, max_dxp);
+    for (auto& o : pl->ops) {
+      if (rc || o.d.kind != S3_OP_CONV || !o.dgrad_mfma) continue;
+      rc = plan_alloc(pl, (void**)&o.dg_w32, (size_t)27 * o.cg.Cin * o.cg.Cout * sizeof(float));
+      if (!rc && precision == S3_PREC_BF16)
+        rc = plan_alloc(pl, &o.dg_wbf, conv_mfma_packed_bytes(o.dg, precision));
     }
     if (rc) { s3_plan_destroy(pl); return rc; }
   }
@@ -702,12 +726,36 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             rc = launch_bias_grad(ctx, dpre, npos, g.Cout, G + P->p[d.b].offset, accumulate_wgrad);
             if (rc) return rc;
           }
-          rc = launch_conv_generic_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+          if (o.wgrad_mfma)
+            rc = launch_conv_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+          else
+            rc = launch_conv_generic_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           if (rc) return rc;
         }
         if (wants_grad(d.in0)) {
           float* dst = grad_dest(pl, d.in0);
-          rc = launch_conv_generic_dgrad(ctx, g, dpre, W + P->p[d.w].offset, dst);
+          if (o.dgrad_mfma) {
+            // dXpad = conv_zero(dPre, flip(W)^T) over the padded frame, then
+            // the adjoint of the virtual padding folds the border back
+            if (o.dg_version != P->version) {
+              rc = launch_conv_dgrad_pack(ctx, g, W + P->p[d.w].offset, o.dg_w32);
+              if (!rc && pl->precision == S3_PREC_BF16)
+                rc = launch_conv_mfma_pack(ctx, o.dg, pl->precision, o.dg_w32, o.dg_wbf);
+              if (rc) return rc;
+              o.dg_version = P->version;
+            }
+            const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.dg_wbf : (const void*)o.dg_w32;
+            rc = launch_conv_mfma_fwd(ctx, o.dg, pl->precision, dpre, wp, nullptr, nullptr, pl->dxp, ConvIO());
+            if (rc) return rc;
+            GatherGeom fg;
+            fg.kind = S3_OP_PAD; fg.N = g.N;
+            for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2; fg.lo[q] = 1; }
+            fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
+            fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
+            rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+          } else {
+            rc = launch_conv_generic_dgrad(ctx, g, dpre, W + P->p[d.w].offset, dst);
+          }
           if (rc) return rc;
           rc = grad_deliver(pl, d.in0, dst);
         }

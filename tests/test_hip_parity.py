@@ -105,6 +105,46 @@ def test_mfma_conv_edge_shapes():
         assert err < tol, (prec, err)
 
 
+def test_mfma_backward_edge_shapes():
+    """MFMA dgrad (flipped-filter conv over the padded frame + fold) and the
+    persistent-workgroup MFMA wgrad on ragged tiles, C_out = 64 and 200, with
+    LeakyReLU / residual / depth-to-space epilogues: fp32 vs oracle."""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(6)
+    spec = pcc(3, 64) + [{'class': 'SkipConnection', 'name': 'a'}] + \
+        pcc(3, 64) + pcc(3, 64, act=False) + \
+        [{'class': 'SkipConnection', 'name': 'a'}] + \
+        pcc(3, 200, act=False) + \
+        [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
+         {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    shape = (2, 5, 7, 19, 4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = ref.backward(dy)
+    net = _hip_net(spec, ref.weights, precision='f32')
+    dev = net.dev
+    ph = net.plan(shape, training=True)
+    y = ph.forward(dev.to_device(x)).cpu().numpy()
+    assert np.abs(y - y_ref).max() < 1e-4 * max(1.0, np.abs(y_ref).max())
+    dx = ph.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
+    assert np.abs(dx - dx_ref).max() < 1e-3 * np.abs(dx_ref).max()
+    gmax = max(float(np.abs(g).max()) for g in ref.grads)
+    for g, g_ref in zip(net.grads, ref.grads):
+        assert np.abs(g - g_ref).max() < 1e-3 * np.abs(g_ref).max() + 1e-5 * gmax
+    # accumulate_wgrad adds on top (discriminator true + generated batches)
+    ph.backward(dev.to_device(dy), need_wgrad=True, accumulate_wgrad=True)
+    for g, g_ref in zip(net.grads, ref.grads):
+        assert np.abs(g - 2 * g_ref).max() < 2e-3 * np.abs(g_ref).max() + 2e-5 * gmax
+    # bf16 MFMA mode backward: looser bound
+    net16 = _hip_net(spec, ref.weights, precision='bf16')
+    ph16 = net16.plan(shape, training=True)
+    ph16.forward(dev.to_device(x))
+    dx16 = ph16.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
+    assert np.abs(dx16 - dx_ref).max() < 5e-2 * np.abs(dx_ref).max()
+
+
 def test_bf16_mode_tolerance_c2_topology():
     """bf16 MFMA throughput mode on the 64-channel residual topology; states
     its own tolerance (bf16 inputs, fp32 accumulate, 10 stacked convs)."""
