@@ -110,6 +110,21 @@ ConvGeom conv_dgrad_geom(const ConvGeom& g);
 int launch_conv_dgrad_pack(s3_ctx* ctx, const ConvGeom& g, const float* w,
                            float* wt);
 
+// few-positions / many-channels convs as weight-streaming GEMMs
+// (kernels_conv_fewpos.hip)
+bool conv_fewpos_supported(const ConvGeom& g);
+size_t conv_fewpos_partial_bytes(const ConvGeom& g);
+int launch_conv_fewpos_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x,
+                           const float* w, const float* bias, const float* res,
+                           float* y, float* partial, size_t partial_bytes);
+int launch_conv_fewpos_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,
+                             const float* wt, float* dx, float* partial,
+                             size_t partial_bytes);
+int launch_conv_fewpos_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,
+                             const float* dy, float* dw, int accumulate);
+int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
+                                 float* wt);
+
 int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
                   int esize);
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,

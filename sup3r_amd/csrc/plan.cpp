@@ -50,6 +50,10 @@ struct OpRec {
   float* dg_w32 = nullptr;     // flipped / transposed fp32 filter
   void* dg_wbf = nullptr;      // its bf16 slabs (bf16 mode)
   uint64_t dg_version = 0;
+  // few-positions GEMM path
+  bool fewpos = false;
+  float* fp_wt = nullptr;      // [tap][co][ci] transposed filter (dgrad)
+  uint64_t fp_version = 0;
 };
 
 struct s3_plan {
@@ -69,6 +73,8 @@ struct s3_plan {
   float* wg_partial = nullptr;
   size_t wg_partial_bytes = 0;
   float* dxp = nullptr;       // padded-frame data gradient of the MFMA dgrad
+  float* fp_partial = nullptr;   // per-tap partials of the few-positions path
+  size_t fp_partial_bytes = 0;
   size_t total_bytes = 0;
   bool forward_done = false;
   std::vector<hipEvent_t> prof_ev;  // prof_cap * (n_ops + 1)
@@ -306,7 +312,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
   auto bad = [&](const char* m) { ctx->err = m; delete pl; return S3_EINVAL; };
   const int np = (int)params->p.size();
   pl->ops.resize(n_ops);
-  size_t max_dpre = 0, max_partial = 0, max_t = 0, max_dxp = 0;
+  size_t max_dpre = 0, max_partial = 0, max_t = 0, max_dxp = 0, max_fp = 0;
   for (int i = 0; i < n_ops; ++i) {
     OpRec& o = pl->ops[i];
     o.d = ops[i];
@@ -335,6 +341,8 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
         }
         if (d.res >= 0 && pl->t[d.res].numel != ot.numel) return bad("plan: residual shape mismatch");
         o.mfma = conv_mfma_supported(g, precision);
+        o.fewpos = !o.mfma && !getenv("SUP3R_AMD_NO_FEWPOS") && conv_fewpos_supported(g);
+        if (o.fewpos) max_fp = std::max(max_fp, conv_fewpos_partial_bytes(g));
         size_t ysz = (size_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout * sizeof(float);
         max_dpre = std::max(max_dpre, ysz);
         max_partial = std::max(max_partial, conv_generic_wgrad_partial_bytes(g));
@@ -408,9 +416,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             } else {
               // the direct kernels read fp32, except the sliding-window
               // small-channel conv which also takes bf16 cells
-              if (!(d.res < 0 && conv_small_supported(o.cg, 1))) demote(d.in0, changed);
+              const bool small = d.res < 0 && !o.fewpos && conv_small_supported(o.cg, 1);
+              if (!small) demote(d.in0, changed);
               demote(d.res, changed);
-              if (d.res < 0 && conv_small_supported(o.cg, 1)) demote(d.out, changed);
+              if (small || o.fewpos) demote(d.out, changed);
             }
             break;
           case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
@@ -497,6 +506,18 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     }
     if (rc) { s3_plan_destroy(pl); return rc; }
   }
+  if (max_fp) {
+    int rc = plan_alloc(pl, (void**)&pl->fp_partial, max_fp);
+    if (rc) { s3_plan_destroy(pl); return rc; }
+    pl->fp_partial_bytes = max_fp;
+  }
+  if (training) {
+    for (auto& o : pl->ops) {
+      if (o.d.kind != S3_OP_CONV || !o.fewpos || o.cg.pad_mode != S3_PAD_ZERO) continue;
+      int rc = plan_alloc(pl, (void**)&o.fp_wt, (size_t)o.cg.k[0] * o.cg.k[1] * o.cg.k[2] * o.cg.Cin * o.cg.Cout * sizeof(float));
+      if (rc) { s3_plan_destroy(pl); return rc; }
+    }
+  }
   // packed weights of the MFMA convs
   for (auto& o : pl->ops) {
     if (o.d.kind == S3_OP_CONV && o.mfma) {
@@ -550,6 +571,8 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
         const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.packed : (const void*)w;
         return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out), o.io);
       }
+      if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16)
+        return launch_conv_fewpos_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out), pl->fp_partial, pl->fp_partial_bytes);
       return launch_conv_generic_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out), o.io.out_bf16, o.io.in_bf16);
     }
     case S3_OP_DENSE: {
@@ -726,7 +749,9 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             rc = launch_bias_grad(ctx, dpre, npos, g.Cout, G + P->p[d.b].offset, accumulate_wgrad);
             if (rc) return rc;
           }
-          if (o.wgrad_mfma)
+          if (o.fewpos)
+            rc = launch_conv_fewpos_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, accumulate_wgrad);
+          else if (o.wgrad_mfma)
             rc = launch_conv_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else
             rc = launch_conv_generic_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
@@ -753,6 +778,13 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
             fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
             rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+          } else if (o.fewpos && o.fp_wt) {
+            if (o.fp_version != P->version) {
+              rc = launch_conv_fewpos_transpose(ctx, g, W + P->p[d.w].offset, o.fp_wt);
+              if (rc) return rc;
+              o.fp_version = P->version;
+            }
+            rc = launch_conv_fewpos_dgrad(ctx, g, dpre, o.fp_wt, dst, pl->fp_partial, pl->fp_partial_bytes);
           } else {
             rc = launch_conv_generic_dgrad(ctx, g, dpre, W + P->p[d.w].offset, dst);
           }
