@@ -586,6 +586,7 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
     if (tile == 2) return launch_bf16<4, 4, 8>(ctx, g, x, packed, bias, res, y, io);
     if (tile == 3) return launch_bf16<2, 4, 8>(ctx, g, x, packed, bias, res, y, io);
     if (tile == 4) return launch_bf16<4, 8, 16>(ctx, g, x, packed, bias, res, y, io);
+    if (tile == 6) return launch_bf16<4, 8, 8>(ctx, g, x, packed, bias, res, y, io);
     return launch_bf16<4, 4, 4>(ctx, g, x, packed, bias, res, y, io);
   }
   // f32: the filters are read in canonical layout; `packed` is unused

@@ -553,7 +553,8 @@ int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
   int block = c <= 256 ? 256 : 1024;
   int rows = block / c;
   int64_t want = (n_pos + rows - 1) / rows;
-  int nblk = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
+  // few partial slabs: stage 2 walks them serially per channel
+  int nblk = (int)(want < 48 ? (want < 1 ? 1 : want) : 48);
   int rc = ensure_scratch(ctx, (size_t)nblk * c * sizeof(float));
   if (rc) return rc;
   hipLaunchKernelGGL(bias_grad_stage1, dim3(nblk), dim3(block), block * sizeof(float), ctx->stream, dy, n_pos, c, ctx->scratch);
