@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
     const void* __restrict__ xv, const void* __restrict__ wpk,
     const float* __restrict__ bias, const void* __restrict__ resv,
     void* __restrict__ yv, ConvGeom g, int tiles0, int tiles1, int tiles2,
-    int res16) {
+    int res16, int dbg) {
   using T = Tile<TS0, TS1, NW>;
   constexpr int H1 = T::H1, HP = T::HP, MFW = T::MFW, NT = T::NT;
   static_assert(MFW >= 1 && MFW * NW == TS0 * TS1, "tile / wave split");
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   {
     constexpr int CHUNKS = PREC == S3_PREC_BF16 ? 8 : 16;  // per position
     constexpr int ITEMS = HP * CHUNKS;
-    constexpr int UN = IN16 ? 8 : 4;
-    for (int base = tid; base < ITEMS; base += NT * UN) {
+    constexpr int UN = IN16 ? (ITEMS + NT - 1) / NT : 4;   // bf16 in: one trip
+    for (int base = tid; base < ((dbg & 1) ? 0 : ITEMS); base += NT * UN) {
       uint4 va[UN], vb[IN16 ? 1 : UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
@@ -266,6 +266,53 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   b_commit(0);
   __syncthreads();
 
+  // ---- epilogue geometry (per thread: CPT consecutive channels of NIT
+  // positions) and residual prefetch: the residual rows are fetched NOW, into
+  // registers, so their HBM latency hides under the 27-tap MFMA loop
+  constexpr int CPT = OUT16 ? 8 : 4;     // channels per thread (16-B store)
+  constexpr int GPP = CT / CPT;          // thread groups per position
+  constexpr int PPP = NT / GPP;          // positions per pass
+  constexpr int NIT = T::NPOS / PPP;
+  const int e_c0 = (tid % GPP) * CPT;
+  const int e_co = ct * CT + e_c0;
+  const bool e_co_ok = e_co < g.Cout;    // C_out % CPT == 0 (checked at dispatch)
+  const int e_b = g.d2s;
+  const int e_cpo = g.Cout / (e_b * e_b);
+  const int e_blk = e_co / e_cpo, e_cc = e_co % e_cpo;
+  auto e_dst = [&](int j, bool& ok) -> size_t {
+    const int pl = (tid / GPP) + PPP * j;     // local position
+    const int mf = pl / TS2, o2 = org2 + pl % TS2;
+    const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1;
+    ok = e_co_ok && o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2];
+    if (!ok) return 0;
+    if (e_b == 1)
+      return ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + e_co;
+    return ((((size_t)n * g.O[0] * e_b + o0 * e_b + e_blk / e_b) * (g.O[1] * e_b) +
+             o1 * e_b + e_blk % e_b) * g.O[2] + o2) * e_cpo + e_cc;
+  };
+  uint4 rres[NIT];
+  if (resv) {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      bool ok;
+      const size_t dst = e_dst(j, ok);
+      rres[j] = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        if (res16) {
+          const unsigned short* rp = reinterpret_cast<const unsigned short*>(resv) + dst;
+          if (CPT == 8) {
+            rres[j] = *reinterpret_cast<const uint4*>(rp);
+          } else {
+            const uint2 r2 = *reinterpret_cast<const uint2*>(rp);
+            rres[j].x = r2.x; rres[j].y = r2.y;
+          }
+        } else if (CPT == 4) {
+          rres[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(resv) + dst);
+        }
+      }
+    }
+  }
+
   // ---- per-wave fragment coordinates
   const int frow = lane & 15, kq = lane >> 4;
   f32x4 acc[MFW][4];
@@ -299,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
         b_addr[nf][ks] = (unsigned)(HP * 128 + row * 128 + (((ks * 4 + kq) ^ ((row >> 1) & 7)) << 4));
     }
 #pragma unroll
-    for (int ta = 0; ta < 3; ++ta) {
+    for (int ta = 0; ta < ((dbg & 4) ? 0 : 3); ++ta) {
 #pragma unroll
       for (int tb = 0; tb < 3; ++tb) {
 #pragma unroll
@@ -363,6 +410,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   // after the last barrier) so that every thread handles CPT consecutive
   // output channels of one position: 16-B coalesced residual loads / stores,
   // all independent, instead of 64 scalar 4-B accesses per lane.
+  if (dbg & 2) return;   // probe: tap loop only
   constexpr int SROW = CT + 4;   // 68: keeps float4 alignment, conflict-free
   float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -376,60 +424,43 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   }
   __syncthreads();
   {
-    constexpr int CPT = OUT16 ? 8 : 4;     // channels per thread (16-B store)
-    constexpr int GPP = CT / CPT;          // thread groups per position
-    constexpr int PPP = NT / GPP;          // positions per pass
-    constexpr int NIT = T::NPOS / PPP;
-    const int c0 = (tid % GPP) * CPT;
-    const int co = ct * CT + c0;
-    const bool co_ok = co < g.Cout;   // C_out % CPT == 0 (checked at dispatch)
     float bv[CPT];
 #pragma unroll
-    for (int q = 0; q < CPT; ++q) bv[q] = (bias && co_ok) ? bias[co + q] : 0.f;
-    const int b = g.d2s;
-    const int cpo = g.Cout / (b * b);
-    const int blk = co / cpo, cc = co % cpo;
+    for (int q = 0; q < CPT; ++q) bv[q] = (bias && e_co_ok) ? bias[e_co + q] : 0.f;
     const int act = g.act;
     const float alpha = g.alpha;
-#pragma unroll 4
+#pragma unroll
     for (int j = 0; j < NIT; ++j) {
-      const int pl = (tid / GPP) + PPP * j;     // local position
-      const int mf = pl / TS2, o2 = org2 + pl % TS2;
-      const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1;
-      if (!co_ok || o0 >= g.O[0] || o1 >= g.O[1] || o2 >= g.O[2]) continue;
+      bool ok;
+      const size_t dst = e_dst(j, ok);
+      if (!ok) continue;
+      const int pl = (tid / GPP) + PPP * j;
       float v[CPT];
 #pragma unroll
       for (int q = 0; q < CPT; q += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(stage + pl * SROW + c0 + q);
+        const float4 t = *reinterpret_cast<const float4*>(stage + pl * SROW + e_c0 + q);
         v[q] = t.x; v[q + 1] = t.y; v[q + 2] = t.z; v[q + 3] = t.w;
-      }
-      size_t dst;
-      if (b == 1) {
-        dst = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co;
-      } else {
-        dst = ((((size_t)n * g.O[0] * b + o0 * b + blk / b) * (g.O[1] * b) +
-                o1 * b + blk % b) * g.O[2] + o2) * cpo + cc;
       }
 #pragma unroll
       for (int q = 0; q < CPT; ++q) v[q] = act_f(v[q] + bv[q], act, alpha);
       if (resv) {
+        const uint4 r = rres[j];
         if (res16) {
-          const unsigned short* rp = reinterpret_cast<const unsigned short*>(resv) + dst;
+          v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
           if (CPT == 8) {
-            const uint4 r = *reinterpret_cast<const uint4*>(rp);
-            v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
             v[4 % CPT] += bf_lo(r.z); v[5 % CPT] += bf_hi(r.z);
             v[6 % CPT] += bf_lo(r.w); v[7 % CPT] += bf_hi(r.w);
-          } else {
-            const uint2 r = *reinterpret_cast<const uint2*>(rp);
-            v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
           }
+        } else if (CPT == 4) {
+          v[0] += __uint_as_float(r.x); v[1] += __uint_as_float(r.y);
+          v[2] += __uint_as_float(r.z); v[3] += __uint_as_float(r.w);
         } else {
+          // fp32 residual with a bf16 store: 8 floats, read here
           const float* rp = reinterpret_cast<const float*>(resv) + dst;
 #pragma unroll
           for (int q = 0; q < CPT; q += 4) {
-            const float4 r = *reinterpret_cast<const float4*>(rp + q);
-            v[q] += r.x; v[q + 1] += r.y; v[q + 2] += r.z; v[q + 3] += r.w;
+            const float4 r4 = *reinterpret_cast<const float4*>(rp + q);
+            v[q] += r4.x; v[q + 1] += r4.y; v[q + 2] += r4.z; v[q + 3] += r4.w;
           }
         }
       }
@@ -461,7 +492,8 @@ int launch_io(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* wpk,
   const int tiles0 = (g.O[0] + TS0 - 1) / TS0, tiles1 = (g.O[1] + TS1 - 1) / TS1,
             tiles2 = (g.O[2] + TS2 - 1) / TS2;
   dim3 grid((unsigned)(g.N * tiles0 * tiles1 * tiles2), (unsigned)((g.Cout + CT - 1) / CT));
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, ctx->stream, x, wpk, bias, res, y, g, tiles0, tiles1, tiles2, res16);
+  static const int dbg = getenv("SUP3R_AMD_MFMA_DBG") ? atoi(getenv("SUP3R_AMD_MFMA_DBG")) : 0;
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, ctx->stream, x, wpk, bias, res, y, g, tiles0, tiles1, tiles2, res16, dbg);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
