@@ -151,7 +151,8 @@ int64_t s3_plan_workspace_bytes(const s3_plan* plan);
  * and returns the number of forwards averaged (or a negative error). */
 int s3_plan_profile_begin(s3_plan* plan, int max_forwards);
 int s3_plan_profile_end(s3_plan* plan, float* ms_per_op, int cap);
-/* 1 if op i of the plan runs on the MFMA halo-tile kernel, else 0 */
+/* 0: op i is not on MFMA; 1: MFMA halo-tile kernel (one tile per workgroup);
+ * 2: its persistent variant (all-bf16 64 -> 64 trunk convs, >= 1 tile per CU) */
 int s3_plan_op_is_mfma(const s3_plan* plan, int op_index);
 
 /* ---- losses ------------------------------------------------------------

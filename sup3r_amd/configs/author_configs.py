@@ -95,6 +95,8 @@ def main():
         'gen_5x_12x_2f.json': st_gen(5, [2, 2, 3], 2),
         # C4/C5 body: the 3x/4x 2-feature topology (16 blocks x 64 ch)
         'gen_3x_4x_2f.json': st_gen(3, [2, 2], 2),
+        # C1: spatial 2x generator of the Conv2DTranspose archetype
+        'gen_2x_2f.json': s_gen(2, 2),
         'disc_st.json': disc(3, 'valid'),
         'disc_s.json': disc(2, 'valid', dense=(1024,)),
         'disc_st_same.json': disc(3, 'same'),

@@ -94,6 +94,12 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
                          const void* x, const void* packed, const float* bias,
                          const void* res, void* y, ConvIO io);
 bool conv_mfma_bf16_out_ok(const ConvGeom& g);
+// persistent one-workgroup-per-CU variant for the all-bf16 64 -> 64 trunk
+bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
+                                 bool has_res);
+int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
+                             const void* packed, const float* bias,
+                             const void* res, void* y);
 
 // MFMA backward of the 3x3x3 stride-1 trunk convs.
 // wgrad: persistent-workgroup kernel (kernels_conv_wgrad_mfma.hip)

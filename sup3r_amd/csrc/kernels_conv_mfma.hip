@@ -17,7 +17,9 @@
 //
 //   S3_PREC_BF16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Halo and filter
 //                  rows are 128 B (64 x bf16); 16-B chunks are XOR-swizzled
-//                  (halo: by the cell's t coordinate, filters: by the row) so
+//                  (halo: chunk ^ (cell_t & 7) — conflict-free for all three
+//                  tap t-shifts, checked by brute force over the four 16-lane
+//                  groups; filters: chunk ^ ((row >> 1) & 7)) so
 //                  that the 16-lane groups of ds_read_b128 hit 16 distinct
 //                  16-B slots of the 256-B bank row.  Every LDS read address
 //                  in the 27-tap loop is (per-lane register) + (immediate):
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
             }
             // swizzle keyed on the t coordinate of the halo cell so that the
             // read-side key depends on the tap's t-shift only (3 variants)
-            const int slot = ch ^ (((hp % H2) >> 1) & 7);
+            const int slot = ch ^ ((hp % H2) & 7);
             *reinterpret_cast<uint4*>(halo + (size_t)hp * 128 + slot * 16) = o;
           } else {
             const uint4 a = va[u];
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
     unsigned a_addr[3][2], b_addr[4][2];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const int sw = ((frow + c) >> 1) & 7;
+      const int sw = (frow + c) & 7;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
         a_addr[c][ks] = (unsigned)((row0 * H2 + frow + c) * 128 + (((ks * 4 + kq) ^ sw) << 4));
@@ -605,6 +607,8 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
                          const void* x, const void* packed, const float* bias,
                          const void* res, void* y, ConvIO io) {
   if (precision == S3_PREC_BF16) {
+    if (conv_mfma_persist_supported(ctx, g, io, res != nullptr))
+      return launch_conv_mfma_persist(ctx, g, x, packed, bias, res, y);
     // tile / wave configuration (SUP3R_AMD_MFMA_TILE overrides for A/B probes)
     static const int tile_env = getenv("SUP3R_AMD_MFMA_TILE") ? atoi(getenv("SUP3R_AMD_MFMA_TILE")) : -1;
     int tile = tile_env;

@@ -677,7 +677,12 @@ extern "C" int s3_plan_profile_end(s3_plan* pl, float* ms_per_op, int cap) {
 
 extern "C" int s3_plan_op_is_mfma(const s3_plan* pl, int i) {
   if (!pl || i < 0 || i >= (int)pl->ops.size()) return 0;
-  return pl->ops[i].d.kind == S3_OP_CONV && pl->ops[i].mfma ? 1 : 0;
+  const auto& o = pl->ops[i];
+  if (o.d.kind != S3_OP_CONV || !o.mfma) return 0;
+  if (pl->precision == S3_PREC_BF16 &&
+      conv_mfma_persist_supported(pl->ctx, o.cg, o.io, o.d.res >= 0))
+    return 2;
+  return 1;
 }
 
 // deliver a gradient contribution `src` (numel floats) to tensor `id`

@@ -192,6 +192,10 @@ class PlanHandle:
     def op_is_mfma(self, i):
         return bool(_lib.lib().s3_plan_op_is_mfma(self.h, i))
 
+    def op_kernel_class(self, i):
+        """0 = direct/generic, 1 = MFMA halo tile, 2 = persistent MFMA."""
+        return int(_lib.lib().s3_plan_op_is_mfma(self.h, i))
+
     @property
     def workspace_bytes(self):
         return int(_lib.lib().s3_plan_workspace_bytes(self.h))

@@ -160,6 +160,38 @@ def test_bf16_mode_tolerance_c2_topology():
     assert err < 3e-2, err
 
 
+def test_persistent_trunk_kernel_matches_tile_kernel_and_oracle():
+    """All-bf16 64 -> 64 trunk convs on >= 256 tiles take the persistent
+    kernel (register-prefetched halo, permuted-row direct epilogue).  Ragged
+    in every dim (18 % 4, 20 % 8, 72 % 16 != 0), with and without the skip
+    add.  Bound vs the oracle: the bf16 mode's 3e-2; vs the one-tile kernel
+    (same bf16 operands, fp32 accumulation, bias added first instead of last):
+    a few bf16 ulps after 4 stacked convs."""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(11)
+    spec = pcc(3, 64) + [{'class': 'SkipConnection', 'name': 'a'}] + \
+        pcc(3, 64) + pcc(3, 64, act=False) + \
+        [{'class': 'SkipConnection', 'name': 'a'}] + pcc(3, 64) + \
+        pcc(3, 64) + pcc(3, 2, act=False)
+    shape = (5, 18, 20, 72, 4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    net = _hip_net(spec, ref.weights, precision='bf16')
+    ph = net.plan(shape, training=False)
+    classes = [ph.op_kernel_class(i) for i in range(len(ph.plan.ops))]
+    assert classes.count(2) >= 3, classes
+    y = net(x).cpu().numpy()
+    scale = max(1.0, np.abs(y_ref).max())
+    assert np.abs(y - y_ref).max() / scale < 3e-2
+    os.environ['SUP3R_AMD_NO_PERSIST'] = '1'
+    try:
+        y_tile = net(x).cpu().numpy()
+    finally:
+        del os.environ['SUP3R_AMD_NO_PERSIST']
+    assert np.abs(y - y_tile).max() / scale < 1e-2
+
+
 def test_c2_generator_forward_vs_oracle():
     """BASELINE config C2 at its full size: (1,16,16,24,4) ->
     (1,80,80,288,2), fp32 parity mode, L-inf < 1e-3 (north_star)."""
