@@ -94,11 +94,15 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
                          const void* x, const void* packed, const float* bias,
                          const void* res, void* y, ConvIO io);
 bool conv_mfma_bf16_out_ok(const ConvGeom& g);
-// persistent one-workgroup-per-CU variant for the all-bf16 64 -> 64 trunk
+// persistent wave-specialised variant for the all-bf16 64 -> 64 trunk; its
+// filter image (LDS layout) is appended to the packed buffer of the conv
+bool conv_mfma_persist_geom_ok(const ConvGeom& g);
 bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
                                  bool has_res);
+size_t conv_mfma_persist_image_bytes();
+int launch_conv_mfma_persist_pack(s3_ctx* ctx, const float* w, void* image);
 int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
-                             const void* packed, const float* bias,
+                             const void* image, const float* bias,
                              const void* res, void* y);
 
 // MFMA backward of the 3x3x3 stride-1 trunk convs.

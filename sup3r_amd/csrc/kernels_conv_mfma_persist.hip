@@ -1,29 +1,36 @@
-// Persistent variant of the halo-tile implicit-GEMM Conv3D (kernels_conv_mfma.hip)
-// for the bf16 trunk of the generator: 64 -> 64 channels, 3x3x3, stride 1,
-// bf16 activations in and out (+ optional bf16 skip tensor), gfx950 only.
+// Persistent, wave-specialised variant of the halo-tile implicit-GEMM Conv3D
+// (kernels_conv_mfma.hip) for the bf16 trunk of the generator: 64 -> 64
+// channels, 3x3x3, stride 1, bf16 activations in and out (+ optional bf16
+// skip tensor), gfx950 only.
 //
 // The one-tile-per-workgroup kernel runs its three phases back to back —
-// halo staging (HBM/L2 latency), 27 taps on MFMA, epilogue through LDS — and
+// halo staging (HBM/L2 latency), 27 taps on MFMA, epilogue — on every CU at
+// the same time, so HBM sees bursts and the matrix cores idle in between;
 // one 138 KB halo per CU leaves no room for a second workgroup to overlap
-// them.  Here ONE workgroup per CU walks a list of 4 x 8 x 16 position tiles:
+// them.  Here ONE 12-wave workgroup per CU walks a list of 4 x 8 x 16
+// position tiles with two kinds of waves:
 //
-//   * the halo of tile i+1 is fetched into REGISTERS (17 x 16 B per lane)
-//     at the top of tile i and lands in LDS after tile i's last tap, so its
-//     HBM/L2 latency hides under 27 taps of MFMA;
-//   * the MFMA operands are swapped (A = filter rows, B = positions) and the
-//     filter rows of a slab are permuted, so that the C/D fragment of a lane
-//     is 8 consecutive output channels of ONE position per pair of N
-//     fragments: the epilogue is bias-init + activation + residual + 16-B
-//     stores straight from the accumulators (4 lanes cover 64 contiguous
-//     bytes), with no LDS round trip and no barrier;
-//   * the filter slabs run through a 3-slot LDS ring (27 = 9 x 3, so slot =
-//     tap % 3 is a compile-time immediate in every tile) and the tap pipeline
-//     is continuous across tiles: taps 25/26 of tile i prefetch taps 0/1 of
-//     tile i+1.
+//   consumers (waves 0-7): nothing but ds_read_b128 + MFMA in the 27-tap
+//     loop — no vector-memory instruction, so no vmcnt wait can ever park
+//     them — then the epilogue straight from the accumulators.  The MFMA
+//     operands are swapped (A = filter rows, B = positions) and the filter
+//     rows of a slab are permuted so that a lane's C/D fragments are 8
+//     consecutive output channels of ONE position per pair of N fragments:
+//     bias-init, activation, residual add and 16-B stores (4 lanes = 64
+//     contiguous bytes) need no LDS round trip.
+//   producers (waves 8-11): stream the 8 KB filter slab of tap + 2 into a
+//     3-slot LDS ring with LDS-DMA (global_load_lds_dwordx4; the global image
+//     IS the swizzled LDS image) and fetch the NEXT tile's halo into registers
+//     (34 x 16 B per lane), two chunks per tap, so the HBM traffic of the
+//     halo is spread over the tap loop instead of bursting; after the last
+//     tap they drop the halo into LDS.  Their vmcnt waits are counted
+//     (never 0 inside the loop): slab t+1 has two taps to arrive.
 //
-// LDS: halo 1080 cells x 128 B | 3 slabs x 8 KB | 64 biases = 163,072 B.
-// Swizzles as in kernels_conv_mfma.hip (halo chunk ^ (cell_t & 7), slab chunk
-// ^ ((row >> 1) & 7)), all conflict-free for ds_read_b128.
+// One s_barrier per tap orders slab hand-over both ways (27 = 9 x 3: the ring
+// slot tap % 3 is a compile-time immediate and the tap pipeline is continuous
+// across tiles).  LDS: halo 1080 cells x 128 B | 3 slabs x 8 KB | 64 biases
+// = 163,072 B.  Swizzles as in kernels_conv_mfma.hip (halo chunk ^ (cell_t &
+// 7), slab chunk ^ ((row >> 1) & 7)); all ds_read_b128 are conflict-free.
 #include <cstdlib>
 
 #include "common.h"
@@ -42,6 +49,28 @@ constexpr int HALO_BYTES = HP * 128;             // 138,240
 constexpr int SLAB_OFF = HALO_BYTES;
 constexpr int BIAS_OFF = SLAB_OFF + 3 * 8192;    // 162,816
 constexpr int LDS_BYTES = BIAS_OFF + 256;        // 163,072
+
+constexpr int NCW = 8;                           // consumer (MFMA) waves
+constexpr int NPW = 4;                           // producer (memory) waves
+constexpr int NTHR = (NCW + NPW) * 64;           // 768
+constexpr int MFW = TS0 * TS1 / NCW;             // 4 M fragments per consumer
+constexpr int PT = NPW * 64;                     // producer threads
+constexpr int ROWC = H1 * H2;                    // 180 cells per halo row (fixed c0)
+constexpr int JR = (ROWC * 8 + PT - 1) / PT;     // 6 chunks per row per producer lane
+constexpr int NLATE = (H0 - 2) * JR;             // 24: rows 2..5, parked in registers
+static_assert(MFW * NCW == TS0 * TS1 && TS1 % MFW == 0, "tile / wave split");
+static_assert(JR <= 6 && NLATE <= 24, "producer tap schedule");
+
+// Producer schedule of the NEXT tile's halo over the 27 taps of this one.
+// Halo row c0 is last read in tap 9*c0 + 8 for c0 = 0, 1 (output row s0 reads
+// halo rows s0 + ta), so rows 0 and 1 go through a 6-chunk register buffer
+// and land in LDS in mid-loop; rows 2..5 are parked in 24 chunks of
+// registers until the last tap is over.
+//   taps 0..5  : one chunk of row 0      taps 9..14 : one chunk of row 1
+//   taps 0..23 : one chunk of rows 2..5
+constexpr int early_k(int t) { return (t >= 0 && t < JR) || (t >= 9 && t < 9 + JR) ? 1 : 0; }
+constexpr int late_k(int t) { return t >= 0 && t < NLATE ? 1 : 0; }
+constexpr int halo_k(int t) { return early_k(t) + late_k(t); }
 
 __device__ inline unsigned pk_bf16(float a, float b) {
   hf32x2 v = {a, b};
@@ -63,21 +92,61 @@ __device__ __host__ inline int slab_row_cout(int rho) {
   return (nf >> 1) * 32 + kq * 8 + (nf & 1) * 4 + r;
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void conv3_mfma_persist_kernel(
-    const unsigned short* __restrict__ x, const char* __restrict__ wpk,
+// workgroup barrier without the fence of __syncthreads(): LDS hand-over is
+// ordered by the explicit waits next to it ("memory": no compiler motion)
+#define WG_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+template <int N>
+__device__ inline void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// 16-B global load the compiler can neither sink nor wait on: the producer
+// loop orders it by hand (asm volatile keeps program order with the counted
+// s_waitcnt / s_barrier statements).  saddr + 32-bit byte offset.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline u32x4 ld16_async(const void* sbase, unsigned voff) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  return v;
+}
+// n is a constant after unrolling: the switch folds to one s_waitcnt
+__device__ inline void wait_vm_n(int n) {
+  switch (n) {
+    case 0: wait_vm<0>(); break;
+    case 1: wait_vm<1>(); break;
+    case 2: wait_vm<2>(); break;
+    case 3: wait_vm<3>(); break;
+    case 4: wait_vm<4>(); break;
+    case 5: wait_vm<5>(); break;
+    default: wait_vm<6>(); break;
+  }
+}
+
+// canonical fp32 w[tap][ci][co] -> bf16 LDS images [tap][rho 64][ci 64] with
+// rows in rho order and 16-B chunks swizzled by rho
+__global__ void pack_persist_kernel(const float* __restrict__ w,
+                                    unsigned short* __restrict__ out) {
+  const int total = 27 * 64 * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += gridDim.x * blockDim.x) {
+    const int ci = idx & 63, rho = (idx >> 6) & 63, tap = idx >> 12;
+    const int co = slab_row_cout(rho);
+    const float v = w[((size_t)tap * 64 + ci) * 64 + co];
+    const unsigned u = pk_bf16(v, 0.f);
+    const int slot = (ci >> 3) ^ ((rho >> 1) & 7);
+    out[((size_t)tap * 64 + rho) * 64 + slot * 8 + (ci & 7)] = (unsigned short)(u & 0xFFFFu);
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
+    const unsigned short* __restrict__ x, const char* __restrict__ wimg,
     const float* __restrict__ bias, const unsigned short* __restrict__ res,
     unsigned short* __restrict__ y, ConvGeom g, int tiles0, int tiles1,
-    int tiles2, int n_tiles, int dbg) {
-  constexpr int NT = NW * 64;
-  constexpr int MFW = TS0 * TS1 / NW;            // M fragments (16-t rows) per wave
-  static_assert(MFW * NW == TS0 * TS1 && TS1 % MFW == 0, "tile / wave split");
-  constexpr int ITEMS = HP * 8;                  // 16-B halo chunks
-  constexpr int NH = (ITEMS + NT - 1) / NT;      // per lane (17 @ 512 threads)
+    int tiles2, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int frow = lane & 15, kq = lane >> 4;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
 
   // ---- this workgroup's tile list.  Block b sits on XCD b % 8; each XCD owns
@@ -93,84 +162,148 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_persist_kernel(
     const int cnt = xcd < r ? q + 1 : q;
     t_first = lo + k; t_end = lo + cnt; t_step = wpx;
   }
-
-  // ---- filter slab copy: one 16-B chunk per thread (512 chunks per slab)
-  // global image row = channel, LDS row = rho (channel permuted), both
-  // swizzled by their own row index
-  const bool b_thr = tid < 512;
-  int b_src = 0, b_dst = 0;
-  {
-    const int rho = (tid & 511) >> 3, slot = tid & 7;
-    const int chunk = slot ^ ((rho >> 1) & 7);
-    const int co = slab_row_cout(rho);
-    b_src = co * 128 + ((chunk ^ ((co >> 1) & 7)) << 4);
-    b_dst = SLAB_OFF + rho * 128 + (slot << 4);
-  }
-  uint4 breg = make_uint4(0, 0, 0, 0);
-  auto b_issue = [&](int tap) {   // tap in [0, 27)
-    if (b_thr) breg = *reinterpret_cast<const uint4*>(wpk + (size_t)tap * 8192 + b_src);
-  };
-  auto b_commit = [&](int slot) {
-    if (b_thr) *reinterpret_cast<uint4*>(smem + b_dst + slot * 8192) = breg;
-  };
-
-  // ---- halo prefetch registers
-  uint4 hreg[NH];
-  auto tile_org = [&](int tile, int& n, int& o0, int& o1, int& o2) {
+  auto tile_org = [&](int tile, int& n, int& o0, int& o1, int& o2) __attribute__((always_inline)) {
     int tr = tile;
     o2 = (tr % tiles2) * TS2; tr /= tiles2;
     o1 = (tr % tiles1) * TS1; tr /= tiles1;
     o0 = (tr % tiles0) * TS0; tr /= tiles0;
     n = tr;
   };
-  auto halo_issue = [&](int tile) {
-    int n, org0, org1, org2;
-    tile_org(tile, n, org0, org1, org2);
-    // the cell coordinates are recomputed per tile from an opaque copy of the
-    // thread id: hoisted out of the tile loop they would pin ~70 VGPRs
-    int tv;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(tv) : "v"(tid));
-#pragma unroll
-    for (int u = 0; u < NH; ++u) {
-      const int item = tv + u * NT;
-      hreg[u] = make_uint4(0, 0, 0, 0);
-      if (item < ITEMS) {
-        const int hp = item >> 3, ch = item & 7;
-        int h = hp;
-        const int c2 = h % H2; h /= H2;
-        const int c1 = h % H1; h /= H1;
-        const int c0 = h;
-        int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
-        bool valid = true;
-        if (g.pad_mode == S3_PAD_REFLECT) {
-          i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
-        } else {
-          valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
-        }
-        // ragged tiles: keep addresses legal (results are masked at the store)
-        i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
-        i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
-        i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
-        const size_t pos = (((size_t)n * D0 + i0) * D1 + i1) * D2 + i2;
-        if (valid) hreg[u] = *reinterpret_cast<const uint4*>(x + pos * 64 + ch * 8);
-      }
-    }
-  };
-  auto halo_commit = [&]() {
-    int tv;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(tv) : "v"(tid));
-#pragma unroll
-    for (int u = 0; u < NH; ++u) {
-      const int item = tv + u * NT;
-      if (item < ITEMS) {
-        const int hp = item >> 3, ch = item & 7;
-        const int slot = ch ^ ((hp % H2) & 7);
-        *reinterpret_cast<uint4*>(smem + hp * 128 + (slot << 4)) = hreg[u];
-      }
-    }
-  };
 
-  // ---- LDS read addresses: (per-lane register) + (compile-time immediate)
+  if (wave >= NCW) {
+    // =================================================== producer waves
+    const int pt = tid - NCW * 64;               // 0 .. 255
+    const int pw = wave - NCW;                   // 0 .. 3
+    // slab DMA: wave pw copies bytes [pw*2048, pw*2048 + 2048) of the 8 KB
+    // image (scalar base + one per-lane offset register)
+    const unsigned dma_voff = (unsigned)(pw * 2048 + lane * 16);
+    auto dma_slab = [&](int tap, int slot) __attribute__((always_inline)) {
+      // opaque per-call copy: 54 hoisted 64-bit addresses would not fit
+      unsigned vo;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(vo) : "v"(dma_voff));
+      const char* sb = wimg + (size_t)tap * 8192 + vo;
+      char* d = smem + SLAB_OFF + slot * 8192 + pw * 2048;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)sb,
+          (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(sb + 1024),
+          (__attribute__((address_space(3))) void*)(d + 1024), 16, 0, 0);
+    };
+    // Halo chunk (row r, j) of this lane: cell r*180 + (pt >> 3) + 32 j,
+    // 16-B chunk pt & 7.  The reflect rule is evaluated ONCE per tile and
+    // axis into a 34-entry element-offset table held across the lanes of one
+    // VGPR (lanes 0-5: axis 0, 6-15: axis 1, 16-33: axis 2); the row offset
+    // is a scalar (readlane), the in-row offset of chunk j two ds_bpermute
+    // lookups per tile, so a chunk's address is one add.
+    const int pcell = pt >> 3, pch = pt & 7;
+    u32x4 hlate[NLATE], hrow[JR];
+    unsigned in_off[JR];      // element offset of chunk j inside a halo row
+    unsigned lds_off[JR];     // byte offset of chunk j inside a halo row (swizzled)
+    int htab = 0;
+    const unsigned short* hx = x;
+#pragma unroll
+    for (int j = 0; j < JR; ++j) {
+      int cell = pcell + 32 * j;
+      if (cell > ROWC - 1) cell = ROWC - 1;      // tail lanes duplicate the last cell
+      lds_off[j] = (unsigned)(cell * 128 + ((pch ^ ((cell % H2) & 7)) << 4));
+    }
+    // (a macro, not a lambda: state written through a by-reference capture
+    // would be pinned to scratch memory by the "memory" clobbers below)
+#define HALO_TABLE(tile_expr)                                                          \
+    {                                                                                  \
+      int n_, o0_, o1_, o2_;                                                           \
+      tile_org((tile_expr), n_, o0_, o1_, o2_);                                        \
+      n_ = __builtin_amdgcn_readfirstlane(n_);                                         \
+      const int ax = lane < H0 ? 0 : (lane < H0 + H1 ? 1 : 2);                         \
+      const int c = lane - (ax == 0 ? 0 : (ax == 1 ? H0 : H0 + H1));                   \
+      const int org = ax == 0 ? o0_ : (ax == 1 ? o1_ : o2_);                           \
+      const int D = ax == 0 ? D0 : (ax == 1 ? D1 : D2);                                \
+      const int stride = ax == 0 ? D1 * D2 * 64 : (ax == 1 ? D2 * 64 : 64);            \
+      int i = s3_reflect(org + c - g.lo[ax], D);                                       \
+      /* ragged tiles: keep addresses legal (results are masked at the store) */      \
+      i = i < 0 ? 0 : (i > D - 1 ? D - 1 : i);                                         \
+      htab = i * stride;                                                               \
+      hx = x + (size_t)n_ * D0 * D1 * D2 * 64;                                         \
+      _Pragma("unroll") for (int j = 0; j < JR; ++j) {                                 \
+        int cell = pcell + 32 * j;                                                     \
+        if (cell > ROWC - 1) cell = ROWC - 1;                                          \
+        const int c1 = cell / H2, c2 = cell - c1 * H2;                                 \
+        in_off[j] = (unsigned)__builtin_amdgcn_ds_bpermute((H0 + c1) << 2, htab) +     \
+                    (unsigned)__builtin_amdgcn_ds_bpermute((H0 + H1 + c2) << 2, htab) + \
+                    pch * 8;                                                           \
+      }                                                                                \
+    }
+    // in-loop loads are hand-ordered (ld16_async): every tap's counted wait
+    // retires all but the youngest <= 6 vector-memory ops, so a chunk issued
+    // >= 2 taps before its halo_put has landed without a wait of its own
+    auto halo_load = [&](int r, int j) __attribute__((always_inline)) {
+      const unsigned row = (unsigned)__builtin_amdgcn_readlane(htab, r);
+      return ld16_async(hx, (row + in_off[j]) * 2);
+    };
+    auto halo_put = [&](int r, int j, const u32x4& v) __attribute__((always_inline)) {
+      if (pcell + 32 * j < ROWC)
+        *reinterpret_cast<u32x4*>(smem + r * (ROWC * 128) + lds_off[j]) = v;
+    };
+
+    // ---- prologue: biases (rho order), first halo, slabs of taps 0 and 1
+    if (pt < 64)
+      reinterpret_cast<float*>(smem + BIAS_OFF)[pt] = bias ? bias[slab_row_cout(pt)] : 0.f;
+    dma_slab(0, 0);
+    dma_slab(1, 1);
+    if (t_first < t_end) {
+      HALO_TABLE(t_first);
+#pragma unroll
+      for (int r = 0; r < H0; ++r) {
+#pragma unroll
+        for (int j = 0; j < JR; ++j) hrow[j] = halo_load(r, j);
+        wait_vm<0>();
+#pragma unroll
+        for (int j = 0; j < JR; ++j) halo_put(r, j, hrow[j]);
+      }
+    }
+    wait_vm<0>();
+    WAIT_LGKM0();
+    WG_BARRIER();
+
+    for (int tile = t_first; tile < t_end; tile += t_step) {
+      const int next = tile + t_step;
+      const bool has_next = next < t_end;
+      // without a next tile the prefetch re-reads this one (same op count)
+      HALO_TABLE(has_next ? next : tile);
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        // rows 0 / 1 of the current halo were last read in taps 8 / 17
+        if ((tap == 9 || tap == 18) && has_next) {
+#pragma unroll
+          for (int j = 0; j < JR; ++j) halo_put(tap == 9 ? 0 : 1, j, hrow[j]);
+        }
+        // slot (tap+2)%3 was read during tap-1: free since the last barrier
+        dma_slab((tap + 2) % 27, (tap + 2) % 3);
+        if (tap < JR) hrow[tap % JR] = halo_load(0, tap % JR);
+        if (tap >= 9 && tap < 9 + JR) hrow[(tap - 9) % JR] = halo_load(1, (tap - 9) % JR);
+        if (tap < NLATE) hlate[tap % NLATE] = halo_load(2 + (tap % NLATE) / JR, (tap % NLATE) % JR);
+        // slab tap+1 (DMA issued one tap ago) must have landed before the
+        // consumers pass this barrier.  Younger vector-memory ops: the halo
+        // chunks of the previous tap (issued after its DMA), this tap's 2 DMA
+        // pieces and its chunks.
+        wait_vm_n(2 + halo_k(tap) + halo_k(tap - 1));
+        WG_BARRIER();
+      }
+      // every consumer is past its last halo read: rows 2..5 may land
+      if (has_next) {
+#pragma unroll
+        for (int u = 0; u < NLATE; ++u) halo_put(2 + u / JR, u % JR, hlate[u]);
+      }
+      WAIT_LGKM0();
+      WG_BARRIER();
+    }
+#undef HALO_TABLE
+    return;
+  }
+
+  // ===================================================== consumer waves
+  const int frow = lane & 15, kq = lane >> 4;
   const int mf0 = wave * MFW;
   const int row0 = (mf0 / TS1) * H1 + (mf0 % TS1);
   unsigned a_addr[3][2], b_addr[4][2];
@@ -188,28 +321,14 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_persist_kernel(
     for (int ks = 0; ks < 2; ++ks)
       b_addr[nf][ks] = (unsigned)(SLAB_OFF + rho * 128 + (((ks * 4 + kq) ^ ((rho >> 1) & 7)) << 4));
   }
-
-  // ---- prologue: bias table (rho order), first halo, slabs of taps 0 and 1
-  if (tid < 64)
-    reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = bias ? bias[slab_row_cout(tid)] : 0.f;
-  if (t_first < t_end) {
-    halo_issue(t_first);
-    halo_commit();
-  }
-  b_issue(0); b_commit(0);
-  b_issue(1); b_commit(1);
-  __syncthreads();
-
   const int act = g.act;
   const float alpha = g.alpha;
+  WG_BARRIER();   // prologue
+
   for (int tile = t_first; tile < t_end; tile += t_step) {
-    const int next = tile + t_step;
-    const bool has_next = next < t_end;
     int n, org0, org1, org2;
     tile_org(tile, n, org0, org1, org2);
-    if (has_next && !(dbg & 1)) halo_issue(next);
-
-    // output addresses (element offsets)
+    // output addresses (element offsets within sample n)
     unsigned e_dst[MFW];
     bool e_ok[MFW];
     const size_t e_base = (size_t)n * g.O[0] * g.O[1] * g.O[2] * 64;
@@ -235,15 +354,13 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_persist_kernel(
       for (int tb = 0; tb < 3; ++tb) {
 #pragma unroll
         for (int tc = 0; tc < 3; ++tc) {
-          const int tap = (ta * 3 + tb) * 3 + tc;
-          // slab of tap + 2 (of the next tile when past 26: same filters)
-          if (!(dbg & 4)) b_issue((tap + 2) % 27);
+          // ring slot of tap = (ta*9 + tb*3 + tc) % 3 = tc
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             bf16x8 bfr[4];
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
-              bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][ks] + (tap % 3) * 8192);
+              bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][ks] + tc * 8192);
 #pragma unroll
             for (int m = 0; m < MFW; ++m) {
               const int roff = ((m + ta * H1 + tb) * H2) * 128;
@@ -253,17 +370,13 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_persist_kernel(
                 acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nf], afr, acc[m][nf], 0, 0, 0);
             }
           }
-          if (!(dbg & 4)) b_commit((tap + 2) % 3);
-          if (!(dbg & 8)) __syncthreads();
+          WG_BARRIER();
         }
       }
     }
-    // every wave is past its last halo read: the next halo may land
-    if (has_next && !(dbg & 1)) halo_commit();
 
     // ---- epilogue straight from the accumulators: residual rows first
     // (all loads in flight together), then activation + add + 16-B stores
-    if (dbg & 2) continue;
     uint4 rres[MFW][2];
     if (res) {
 #pragma unroll
@@ -295,11 +408,21 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_persist_kernel(
         *reinterpret_cast<uint4*>(y + e_base + e_dst[m] + h * 32) = o;
       }
     }
-    __syncthreads();   // next halo visible
+    WG_BARRIER();   // next halo visible
   }
 }
 
 }  // namespace
+
+bool conv_mfma_persist_geom_ok(const ConvGeom& g) {
+  if (g.Cin != 64 || g.Cout != 64 || g.d2s != 1) return false;
+  if (g.pad_mode != S3_PAD_REFLECT) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g.k[d] != 3 || g.s[d] != 1) return false;
+  // 32-bit element offsets inside one sample
+  return (int64_t)g.D[0] * g.D[1] * g.D[2] * 64 < (int64_t)1 << 31 &&
+         (int64_t)g.O[0] * g.O[1] * g.O[2] * 64 < (int64_t)1 << 31;
+}
 
 bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
                                  bool has_res) {
@@ -307,19 +430,25 @@ bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io
   const char* off = getenv("SUP3R_AMD_NO_PERSIST");
   if (off && atoi(off)) return false;
   if (!io.in_bf16 || !io.out_bf16 || (has_res && !io.res_bf16)) return false;
-  if (g.Cin != 64 || g.Cout != 64 || g.d2s != 1) return false;
-  for (int d = 0; d < 3; ++d)
-    if (g.k[d] != 3 || g.s[d] != 1) return false;
+  if (!conv_mfma_persist_geom_ok(g)) return false;
   const int64_t tiles = (int64_t)g.N * ((g.O[0] + TS0 - 1) / TS0) *
                         ((g.O[1] + TS1 - 1) / TS1) * ((g.O[2] + TS2 - 1) / TS2);
   return tiles >= ctx->num_cu;
 }
 
+size_t conv_mfma_persist_image_bytes() { return (size_t)27 * 64 * 64 * 2; }
+
+int launch_conv_mfma_persist_pack(s3_ctx* ctx, const float* w, void* image) {
+  hipLaunchKernelGGL(pack_persist_kernel, dim3(108), dim3(256), 0, ctx->stream,
+                     w, (unsigned short*)image);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
-                             const void* packed, const float* bias,
+                             const void* image, const float* bias,
                              const void* res, void* y) {
-  constexpr int NW = 8;
-  auto kern = conv3_mfma_persist_kernel<NW>;
+  auto kern = conv3_mfma_persist_kernel;
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -329,13 +458,12 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
   const int tiles0 = (g.O[0] + TS0 - 1) / TS0, tiles1 = (g.O[1] + TS1 - 1) / TS1,
             tiles2 = (g.O[2] + TS2 - 1) / TS2;
   const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
-  static const int dbg = getenv("SUP3R_AMD_MFMA_DBG") ? atoi(getenv("SUP3R_AMD_MFMA_DBG")) : 0;
   int grid = ctx->num_cu;
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS_BYTES, ctx->stream,
-                     (const unsigned short*)x, (const char*)packed, bias,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
+                     (const unsigned short*)x, (const char*)image, bias,
                      (const unsigned short*)res, (unsigned short*)y, g, tiles0,
-                     tiles1, tiles2, n_tiles, dbg);
+                     tiles1, tiles2, n_tiles);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
