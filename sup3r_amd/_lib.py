@@ -64,6 +64,11 @@ def lib():
         raise RuntimeError(
             f'sup3r_amd: HIP library {LIB_PATH} not found; {build_hint()}. '
             'There is no CPU fallback.')
+    # torch first: its wheel bundles its own libamdhip64 / libhsa-runtime64.
+    # Loading ours (linked against /opt/rocm) before torch's leaves two HIP
+    # runtimes in the process and hipSetDevice then reports "no ROCm-capable
+    # device"; after torch, the already-loaded runtime is shared.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     pf = C.POINTER(C.c_float)

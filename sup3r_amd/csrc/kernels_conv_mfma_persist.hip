@@ -58,7 +58,7 @@ constexpr int PT = NPW * 64;                     // producer threads
 constexpr int ROWC = H1 * H2;                    // 180 cells per halo row (fixed c0)
 constexpr int JR = (ROWC * 8 + PT - 1) / PT;     // 6 chunks per row per producer lane
 constexpr int NLATE = (H0 - 2) * JR;             // 24: rows 2..5, parked in registers
-static_assert(MFW * NCW == TS0 * TS1 && TS1 % MFW == 0, "tile / wave split");
+static_assert(MFW * NCW == TS0 * TS1 && TS1 % MFW == 0 && MFW == 4, "tile / wave split");
 static_assert(JR <= 6 && NLATE <= 24, "producer tap schedule");
 
 // Producer schedule of the NEXT tile's halo over the 27 taps of this one.
@@ -348,26 +348,54 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       for (int m = 0; m < MFW; ++m) acc[m][nf] = bv;
     }
 
+    // The halo is static during a tile, so the A (position) fragments of the
+    // NEXT tap's first k-step are fetched before this tap's barrier: after the
+    // barrier only the four filter fragments stand between a wave and its
+    // first MFMA.
+    bf16x8 apre[MFW];
+#pragma unroll
+    for (int m = 0; m < MFW; ++m)
+      apre[m] = *reinterpret_cast<const bf16x8*>(smem + a_addr[0][0] + (m * H2) * 128);
 #pragma unroll 1
     for (int ta = 0; ta < 3; ++ta) {
+      const unsigned ta_off = (unsigned)(ta * H1 * H2 * 128);
 #pragma unroll
       for (int tb = 0; tb < 3; ++tb) {
 #pragma unroll
         for (int tc = 0; tc < 3; ++tc) {
           // ring slot of tap = (ta*9 + tb*3 + tc) % 3 = tc
+          bf16x8 bfr[4];
+          // ---- k-step 0: prefetched A, fresh B
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 bfr[4];
+          for (int nf = 0; nf < 4; ++nf)
+            bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][0] + tc * 8192);
+#pragma unroll
+          for (int m = 0; m < MFW; ++m)
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
-              bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][ks] + tc * 8192);
+              acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nf], apre[m], acc[m][nf], 0, 0, 0);
+          // ---- k-step 1
 #pragma unroll
-            for (int m = 0; m < MFW; ++m) {
-              const int roff = ((m + ta * H1 + tb) * H2) * 128;
-              const bf16x8 afr = *reinterpret_cast<const bf16x8*>(smem + a_addr[tc][ks] + roff);
+          for (int nf = 0; nf < 4; ++nf)
+            bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][1] + tc * 8192);
 #pragma unroll
-              for (int nf = 0; nf < 4; ++nf)
-                acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nf], afr, acc[m][nf], 0, 0, 0);
+          for (int m = 0; m < MFW; ++m) {
+            const bf16x8 afr = *reinterpret_cast<const bf16x8*>(
+                smem + a_addr[tc][1] + ta_off + ((m + tb) * H2) * 128);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+              acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nf], afr, acc[m][nf], 0, 0, 0);
+          }
+          // ---- A fragments of the next tap (k-step 0)
+          {
+            const int ntc = tc < 2 ? tc + 1 : 0;
+            const int ntb = tc < 2 ? tb : (tb < 2 ? tb + 1 : 0);
+            const unsigned nta_off = (tc == 2 && tb == 2) ? ta_off + H1 * H2 * 128 : ta_off;
+            if (!(tc == 2 && tb == 2) || ta < 2) {
+#pragma unroll
+              for (int m = 0; m < MFW; ++m)
+                apre[m] = *reinterpret_cast<const bf16x8*>(
+                    smem + a_addr[ntc][0] + nta_off + ((m + ntb) * H2) * 128);
             }
           }
           WG_BARRIER();
