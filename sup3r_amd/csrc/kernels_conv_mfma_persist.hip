@@ -324,6 +324,9 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
   const int act = g.act;
   const float alpha = g.alpha;
   WG_BARRIER();   // prologue
+  // the matrix-core waves outrank the producer wave sharing their SIMD
+  // (A/B in one run: 0.1228 -> 0.1055 ms per 64->64 conv launch)
+  __builtin_amdgcn_s_setprio(2);
 
   for (int tile = t_first; tile < t_end; tile += t_step) {
     int n, org0, org1, org2;
