@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libsup3r_hip.so')
+# SUP3R_AMD_LIB: alternative build of the same library (A/B kernel probes)
+LIB_PATH = os.environ.get('SUP3R_AMD_LIB') or os.path.join(
+    HERE, 'lib', 'libsup3r_hip.so')
 
 # enums (include/sup3r_hip.h)
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2

@@ -149,19 +149,32 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
 
-  // ---- this workgroup's tile list.  Block b sits on XCD b % 8; each XCD owns
-  // a contiguous range of tiles (neighbouring halos share its L2) and its
-  // workgroups stride through that range.
-  int t_first, t_end, t_step;
+  // ---- this workgroup's work list.  The unit is HALF a tile (two s0 rows =
+  // the four consumer waves of one row pair, one per SIMD): workgroup rank w
+  // owns the half-tiles [w H / G, (w+1) H / G) and walks them as whole tiles
+  // where it can.  That balances the tail (1152 tiles on 256 CUs is 4.5 tiles
+  // each, not 5 rounds) and puts neighbouring workgroups half a tile out of
+  // phase, so their epilogue / halo traffic does not hit HBM in the same
+  // microsecond.  Ranks are XCD-major (block b sits on XCD b % 8): each XCD
+  // owns a contiguous run of tiles and neighbouring halos share its L2.
+  int h_cur, h_end;
   {
     const int nblk = gridDim.x, b = blockIdx.x;
     const int xcd = b % 8, k = b / 8;
-    const int wpx = (nblk - xcd + 7) / 8;        // workgroups on this XCD
-    const int q = n_tiles / 8, r = n_tiles % 8;
-    const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const int cnt = xcd < r ? q + 1 : q;
-    t_first = lo + k; t_end = lo + cnt; t_step = wpx;
+    int rank = k;
+    for (int xx = 0; xx < xcd; ++xx) rank += (nblk - xx + 7) / 8;
+    const long long H = 2ll * n_tiles;
+    h_cur = (int)((rank * H) / nblk);
+    h_end = (int)(((rank + 1) * H) / nblk);
   }
+  // work item starting at half-tile h: tile, first row, rows; returns next h
+  auto item_at = [&](int h, int& tile, int& r0, int& nr) __attribute__((always_inline)) {
+    tile = h >> 1;
+    if (h & 1) { r0 = 2; nr = 2; return h + 1; }
+    if (h + 1 < h_end) { r0 = 0; nr = 4; return h + 2; }
+    r0 = 0; nr = 2;
+    return h + 1;
+  };
   auto tile_org = [&](int tile, int& n, int& o0, int& o1, int& o2) __attribute__((always_inline)) {
     int tr = tile;
     o2 = (tr % tiles2) * TS2; tr /= tiles2;
@@ -251,8 +264,8 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       reinterpret_cast<float*>(smem + BIAS_OFF)[pt] = bias ? bias[slab_row_cout(pt)] : 0.f;
     dma_slab(0, 0);
     dma_slab(1, 1);
-    if (t_first < t_end) {
-      HALO_TABLE(t_first);
+    if (h_cur < h_end) {
+      HALO_TABLE(h_cur >> 1);
 #pragma unroll
       for (int r = 0; r < H0; ++r) {
 #pragma unroll
@@ -266,11 +279,12 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     WAIT_LGKM0();
     WG_BARRIER();
 
-    for (int tile = t_first; tile < t_end; tile += t_step) {
-      const int next = tile + t_step;
-      const bool has_next = next < t_end;
-      // without a next tile the prefetch re-reads this one (same op count)
-      HALO_TABLE(has_next ? next : tile);
+    for (int h = h_cur; h < h_end;) {
+      int tile, r0_, nr_;
+      h = item_at(h, tile, r0_, nr_);
+      const bool has_next = h < h_end;
+      // without a next item the prefetch re-reads this tile (same op count)
+      HALO_TABLE(has_next ? (h >> 1) : tile);
 #pragma unroll
       for (int tap = 0; tap < 27; ++tap) {
         // rows 0 / 1 of the current halo were last read in taps 8 / 17
@@ -328,7 +342,16 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
   // (A/B in one run: 0.1228 -> 0.1055 ms per 64->64 conv launch)
   __builtin_amdgcn_s_setprio(2);
 
-  for (int tile = t_first; tile < t_end; tile += t_step) {
+  const int my_row = mf0 / TS1;                 // s0 row of this wave's fragments
+  for (int h = h_cur; h < h_end;) {
+    int tile, r0, nr;
+    h = item_at(h, tile, r0, nr);
+    if (my_row < r0 || my_row >= r0 + nr) {
+      // half-tile item owned by the other row pair: keep the barrier count
+#pragma unroll 1
+      for (int t = 0; t < 28; ++t) WG_BARRIER();
+      continue;
+    }
     int n, org0, org1, org2;
     tile_org(tile, n, org0, org1, org2);
     // output addresses (element offsets within sample n)
