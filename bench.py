@@ -181,7 +181,10 @@ def main():
                             if args.precision == 'bf16' else 'fp32 NDHWC'),
             'parallelism': f'chunk-sharded x{world}, no collective'},
         'roofline': {
-            'kernel': 'conv3_mfma_kernel (Conv3D 64->64 k3, reflect-pad fused)',
+            'kernel': ('conv3_mfma_persist_kernel'
+                       if body and ph.op_kernel_class(body[0]) == 2
+                       else 'conv3_mfma_kernel') +
+                      ' (Conv3D 64->64 k3, reflect-pad fused)',
             'bound': 'mfma', 'achieved': achieved, 'peak': peak,
             'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
             'algorithmic_bytes_per_launch': body_bytes,
