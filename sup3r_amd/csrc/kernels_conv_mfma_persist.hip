@@ -335,8 +335,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     for (int ks = 0; ks < 2; ++ks)
       b_addr[nf][ks] = (unsigned)(SLAB_OFF + rho * 128 + (((ks * 4 + kq) ^ ((rho >> 1) & 7)) << 4));
   }
-  const int act = g.act;
-  const float alpha = g.alpha;
+  const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
   WG_BARRIER();   // prologue
   // the matrix-core waves outrank the producer wave sharing their SIMD
   // (A/B in one run: 0.1228 -> 0.1055 ms per 64->64 conv launch)
@@ -450,7 +449,13 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       for (int h = 0; h < 2; ++h) {
         float v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = actf(acc[m][2 * h + (q >> 2)][q & 3], act, alpha);
+        for (int q = 0; q < 8; ++q) {
+          // branch-free activation: max(v, slope v) is identity (slope 1),
+          // ReLU (0) or LeakyReLU (0 <= alpha <= 1); a per-element test of
+          // the kind compiles to two scalar branches per value
+          const float a = acc[m][2 * h + (q >> 2)][q & 3];
+          v[q] = fmaxf(a, slope * a);
+        }
         if (res) {
           const uint4 r = rres[m][h];
           v[0] += lo_f(r.x); v[1] += hi_f(r.x); v[2] += lo_f(r.y); v[3] += hi_f(r.y);
@@ -471,6 +476,8 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
 bool conv_mfma_persist_geom_ok(const ConvGeom& g) {
   if (g.Cin != 64 || g.Cout != 64 || g.d2s != 1) return false;
   if (g.pad_mode != S3_PAD_REFLECT) return false;
+  // the epilogue's branch-free max(v, alpha v)
+  if (g.act == S3_ACT_LEAKY && !(g.alpha >= 0.f && g.alpha <= 1.f)) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 1) return false;
   // 32-bit element offsets inside one sample
