@@ -78,11 +78,6 @@ __device__ inline unsigned pk_bf16(float a, float b) {
 }
 __device__ inline float lo_f(unsigned u) { return __uint_as_float(u << 16); }
 __device__ inline float hi_f(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
-__device__ inline float actf(float v, int act, float alpha) {
-  if (act == S3_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == S3_ACT_LEAKY) return v > 0.f ? v : alpha * v;
-  return v;
-}
 
 // LDS slab row rho = nf*16 + kq*4 + r  <->  output channel
 //   (nf >> 1)*32 + kq*8 + (nf & 1)*4 + r

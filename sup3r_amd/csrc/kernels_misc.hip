@@ -149,9 +149,10 @@ __global__ void gather_bwd_kernel(const float* __restrict__ dout,
 
 // ------------------------------------------------------------- elementwise
 __device__ inline float act_f(float v, int act, float alpha) {
-  if (act == S3_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == S3_ACT_LEAKY) return v > 0.f ? v : alpha * v;
-  return v;
+  // one select for every kind (slope 1 = identity, 0 = ReLU, alpha = Leaky):
+  // testing the kind per element compiles to two scalar branches per value
+  const float s = act == S3_ACT_LEAKY ? alpha : (act == S3_ACT_RELU ? 0.f : 1.f);
+  return v > 0.f ? v : s * v;
 }
 __device__ inline float act_d(float y, int act, float alpha) {
   if (act == S3_ACT_RELU) return y > 0.f ? 1.f : 0.f;
