@@ -78,6 +78,10 @@ int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x,
                             const float* res, void* y, int out_bf16,
                             int in_bf16);
 bool conv_small_supported(const ConvGeom& g, int in_bf16);
+// hi-res tail conv C_in = 8 (bf16 cells) -> C_out <= 16 (fp32) on MFMA
+bool conv_tail_mfma_supported(const ConvGeom& g);
+int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
+                          const float* w, const float* bias, float* y);
 int launch_conv_generic_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,
                               const float* w, float* dx);
 int launch_conv_generic_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,

@@ -11,6 +11,8 @@
 // compiler emits scalar (SMEM) loads; x is read per lane, vectorised over
 // C_in when C_in % 4 == 0.  No MFMA here on purpose: these layers have
 // arithmetic intensity <= ~20 FLOP/B and are bound by HBM / L2, not math.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -419,6 +421,9 @@ int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x,
                             const float* w, const float* bias,
                             const float* res, void* y, int out_bf16,
                             int in_bf16) {
+  if (in_bf16 && !out_bf16 && !res && conv_tail_mfma_supported(g) &&
+      !getenv("SUP3R_AMD_NO_TAIL_MFMA"))
+    return launch_conv_tail_mfma(ctx, g, x, w, bias, (float*)y);
   if (!out_bf16 && !res && conv_small_supported(g, in_bf16)) {
     constexpr int TT = 4;
     const int64_t total = (int64_t)g.N * g.O[0] * g.O[1] * ((g.O[2] + TT - 1) / TT);

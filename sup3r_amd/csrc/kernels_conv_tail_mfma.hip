@@ -1,0 +1,204 @@
+// Hi-res tail conv of the generator (Conv3D 8 -> C_out <= 16, k 3, stride 1,
+// bf16 input from the depth-to-space store, fp32 output = the model output) on
+// the matrix cores.  K2 "8 -> 2 @ (80,80,288)" of SURVEY.md §8: 0.8 GMAC and
+// 44 MB per sample, AI ~ 36 FLOP/B — an HBM-class op that the direct kernel ran
+// at ~1 TB/s because 27 x 8 x 2 scalar FMAs per position with 13x re-read
+// of every cell through L1 is VALU/L1-bound.
+//
+// With C_in = 8 a halo cell IS one 16-B MFMA operand chunk (8 bf16), so the
+// im2col is free: K = 27 taps x 8 channels is walked in 7 k-steps of 32 = 4
+// taps x 8 ci, and lane (position p, k-group kq) of a B fragment simply reads
+// the cell of position p shifted by tap 4s + kq — one ds_read_b128 at
+// (per-lane base) + (per-lane tap offset).  The A operand is the filter,
+// rows = output channels (zero-padded to 16), 7 fragments held in 28 VGPRs
+// for the whole workgroup.  D[co][pos]: lane (pos, kq) owns channels
+// kq*4 .. kq*4+3 of one position, so C_out <= 4 stores one float2/float4 per
+// position, contiguous across the 16 lanes of a fragment.
+//
+// Persistent workgroups (one per CU, 8 waves) walk 4 x 8 x 64-position tiles
+// with a DOUBLE-BUFFERED halo (2 x 62 KB of LDS): while the matrix cores chew
+// tile i, the halo of tile i+1 arrives by LDS-DMA (global_load_lds_dwordx4:
+// lane l of a wave-instruction fills LDS cell hp0 + l from its own, reflect-
+// resolved global address — no VGPR staging, no exposed load latency).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int T0 = 4, T1 = 8, T2 = 64;
+constexpr int H0 = T0 + 2, H1 = T1 + 2, H2 = T2 + 2;
+constexpr int HP = H0 * H1 * H2;                 // 3960 cells
+constexpr int NTH = 512;
+constexpr int NDMA = (HP + 63) / 64;             // 62 wave-instructions per halo
+constexpr int BUF_BYTES = NDMA * 64 * 16;        // 63,488 (tail lanes land in the pad)
+constexpr int GROUPS = T0 * T1 * (T2 / 16);      // 128 fragments of 16 positions
+constexpr int KS = 7;                            // ceil(27 / 4) k-steps
+
+__device__ inline unsigned pk2(float a, float b) {
+  hf32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
+}
+__device__ inline float act_sel(float v, float slope) { return v > 0.f ? v : slope * v; }
+
+__global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
+    const unsigned short* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ bias, float* __restrict__ y, ConvGeom g,
+    int tiles0, int tiles1, int tiles2, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, kq = lane >> 4;
+  const int Cout = g.Cout;
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+
+  auto tile_org = [&](int tile, int& n, int& o0, int& o1, int& o2) __attribute__((always_inline)) {
+    int tr = tile;
+    o2 = (tr % tiles2) * T2; tr /= tiles2;
+    o1 = (tr % tiles1) * T1; tr /= tiles1;
+    o0 = (tr % tiles0) * T0; tr /= tiles0;
+    n = tr;
+  };
+  // halo of `tile` -> buffer `buf`: 62 wave-instructions shared by the 8 waves
+  auto stage = [&](int tile, int buf) __attribute__((always_inline)) {
+    int n, org0, org1, org2;
+    tile_org(tile, n, org0, org1, org2);
+    const unsigned short* xn = x + (size_t)n * D0 * D1 * D2 * 8;
+    for (int i = wave; i < NDMA; i += NTH / 64) {
+      int hp = i * 64 + lane;
+      if (hp > HP - 1) hp = HP - 1;              // pad lanes re-read the last cell
+      int h = hp;
+      const int c2 = h % H2; h /= H2;
+      const int c1 = h % H1; h /= H1;
+      const int c0 = h;
+      int i0 = s3_reflect(org0 + c0 - g.lo[0], D0);
+      int i1 = s3_reflect(org1 + c1 - g.lo[1], D1);
+      int i2 = s3_reflect(org2 + c2 - g.lo[2], D2);
+      // ragged tiles: keep addresses legal (results are masked at the store)
+      i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
+      i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
+      i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
+      const unsigned short* src = xn + (((size_t)i0 * D1 + i1) * D2 + i2) * 8;
+      char* dst = smem + buf * BUF_BYTES + i * 1024;     // wave-uniform; + lane*16 by the DMA
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  // ---- filter fragments: lane (row = co = lane & 15, k-group kq) of k-step s
+  // holds w[tap 4s+kq][ci 0..7][co] as bf16 (zero beyond 27 taps / C_out)
+  bf16x8 wf[KS];
+  unsigned toff[KS];       // byte offset of tap 4s+kq in the halo (B operand)
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int tap = 4 * s + kq;
+    unsigned u[4] = {0u, 0u, 0u, 0u};
+    if (tap < 27 && p < Cout) {
+      const float* wp = w + (size_t)tap * 8 * Cout + p;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] = pk2(wp[(2 * e) * Cout], wp[(2 * e + 1) * Cout]);
+    }
+    uint4 uv = make_uint4(u[0], u[1], u[2], u[3]);
+    wf[s] = __builtin_bit_cast(bf16x8, uv);
+    const int tt = tap < 27 ? tap : 0;
+    const int a = tt / 9, b = (tt / 3) % 3, c = tt % 3;
+    toff[s] = (unsigned)(((a * H1 + b) * H2 + c) * 16);
+  }
+  // bias of this lane's four channels
+  float bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = (bias && kq * 4 + r < Cout) ? bias[kq * 4 + r] : 0.f;
+  const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+
+  int cur = 0;
+  if ((int)blockIdx.x < n_tiles) stage(blockIdx.x, 0);
+  __syncthreads();     // (carries the vmcnt(0) of the LDS-DMA)
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < n_tiles) stage(next, cur ^ 1);
+    int n, org0, org1, org2;
+    tile_org(tile, n, org0, org1, org2);
+    const char* halo = smem + cur * BUF_BYTES;
+    // ---- 128 fragments of 16 positions, 16 per wave, four at a time: four
+    // independent accumulator chains keep the matrix pipe issuing (one chain
+    // of 7 dependent MFMAs would wait out the full MFMA latency 7 times)
+    constexpr int GU = 4;
+    for (int g0 = wave * GU; g0 < GROUPS; g0 += (NTH / 64) * GU) {
+      unsigned base[GU];
+      f32x4 acc[GU];
+#pragma unroll
+      for (int j = 0; j < GU; ++j) {
+        const int gi = g0 + j;
+        const int tq = gi % (T2 / 16);
+        const int r1 = (gi / (T2 / 16)) % T1;
+        const int r0 = gi / ((T2 / 16) * T1);
+        base[j] = (unsigned)(((r0 * H1 + r1) * H2 + tq * 16 + p) * 16);
+        acc[j] = (f32x4){bv[0], bv[1], bv[2], bv[3]};
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < GU; ++j) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(halo + base[j] + toff[s]);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf, acc[j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int j = 0; j < GU; ++j) {
+        const int gi = g0 + j;
+        const int tq = gi % (T2 / 16);
+        const int r1 = (gi / (T2 / 16)) % T1;
+        const int r0 = gi / ((T2 / 16) * T1);
+        const int o0 = org0 + r0, o1 = org1 + r1, o2 = org2 + tq * 16 + p;
+        if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && kq * 4 < Cout) {
+          float* yp = y + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * Cout + kq * 4;
+          if (Cout == 2) {
+            *reinterpret_cast<float2*>(yp) =
+                make_float2(act_sel(acc[j][0], slope), act_sel(acc[j][1], slope));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kq * 4 + r < Cout) yp[r] = act_sel(acc[j][r], slope);
+          }
+        }
+      }
+    }
+    __syncthreads();   // next halo landed (vmcnt(0)), this one free
+    cur ^= 1;
+  }
+}
+
+}  // namespace
+
+bool conv_tail_mfma_supported(const ConvGeom& g) {
+  if (g.Cin != 8 || g.Cout < 1 || g.Cout > 16 || g.d2s != 1) return false;
+  if (g.pad_mode != S3_PAD_REFLECT) return false;   // LDS-DMA cannot write the zeros
+  for (int d = 0; d < 3; ++d)
+    if (g.k[d] != 3 || g.s[d] != 1) return false;
+  // tiles of 64 along t would be mostly masked on short series
+  return g.O[2] >= 16;
+}
+
+int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
+                          const float* w, const float* bias, float* y) {
+  const int tiles0 = (g.O[0] + T0 - 1) / T0, tiles1 = (g.O[1] + T1 - 1) / T1,
+            tiles2 = (g.O[2] + T2 - 1) / T2;
+  const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail_mfma_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES));
+    attr_set = true;
+  }
+  int grid = ctx->num_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  hipLaunchKernelGGL(conv_tail_mfma_kernel, dim3(grid), dim3(NTH), 2 * BUF_BYTES, ctx->stream,
+                     (const unsigned short*)x, w, bias, y, g, tiles0, tiles1, tiles2, n_tiles);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}

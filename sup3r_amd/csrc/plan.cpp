@@ -414,9 +414,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             if (o.mfma) {
               if (!conv_mfma_bf16_out_ok(o.cg)) demote(d.out, changed);
             } else {
-              // the direct kernels read fp32, except the sliding-window
-              // small-channel conv which also takes bf16 cells
-              const bool small = d.res < 0 && !o.fewpos && conv_small_supported(o.cg, 1);
+              // the direct kernels read fp32, except the small-channel tail
+              // convs (MFMA C_in = 8 / sliding window) which take bf16 cells
+              const bool small = d.res < 0 && !o.fewpos &&
+                                 (conv_small_supported(o.cg, 1) || conv_tail_mfma_supported(o.cg));
               if (!small) demote(d.in0, changed);
               demote(d.res, changed);
               if (small || o.fewpos) demote(d.out, changed);

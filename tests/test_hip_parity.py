@@ -192,6 +192,36 @@ def test_persistent_trunk_kernel_matches_tile_kernel_and_oracle():
     assert np.abs(y - y_tile).max() / scale < 1e-2
 
 
+@pytest.mark.parametrize('n_out', [2, 3])
+def test_tail_conv_mfma_vs_oracle_and_direct_kernel(n_out):
+    """Hi-res tail conv 8 -> n_out after the depth-to-space store (bf16 cells
+    in, fp32 out) on MFMA: ragged tiles (t = 40 is not a multiple of 64, s1 =
+    25 not of 4, s2 = 35 not of 8).  bf16-mode bound vs the oracle; vs the
+    direct sliding-window kernel (fp32 weights) only the bf16 rounding of
+    the 27*8 filter taps differs."""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(7)
+    spec = pcc(3, 64) + pcc(3, 200, act=False) + \
+        [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
+         {'alpha': 0.2, 'class': 'LeakyReLU'}] + pcc(3, n_out, act=False)
+    shape = (2, 5, 7, 40, 4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    net = _hip_net(spec, ref.weights, precision='bf16')
+    y = net(x).cpu().numpy()
+    assert y.shape == (2, 25, 35, 40, n_out)
+    scale = max(1.0, np.abs(y_ref).max())
+    assert np.abs(y - y_ref).max() / scale < 3e-2
+    if n_out == 2:
+        os.environ['SUP3R_AMD_NO_TAIL_MFMA'] = '1'
+        try:
+            y_direct = net(x).cpu().numpy()
+        finally:
+            del os.environ['SUP3R_AMD_NO_TAIL_MFMA']
+        assert np.abs(y - y_direct).max() / scale < 1e-2
+
+
 def test_c2_generator_forward_vs_oracle():
     """BASELINE config C2 at its full size: (1,16,16,24,4) ->
     (1,80,80,288,2), fp32 parity mode, L-inf < 1e-3 (north_star)."""
