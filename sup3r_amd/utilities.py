@@ -105,6 +105,16 @@ class ExoData(dict):
                     '"data" and "combine_type" key.')
         self.update(steps)
 
+    def get_model_step_exo(self, model_step):
+        """Entries of every feature whose 'model' index is ``model_step``
+        (exo.py:108-130)."""
+        out = {}
+        for feature, entry in self.items():
+            steps = [s for s in entry['steps'] if s.get('model') == model_step]
+            if steps:
+                out[feature] = {'steps': steps}
+        return ExoData(out)
+
     def get_combine_type_data(self, feature, combine_type, model_step=None):
         steps = self[feature]['steps']
         if model_step is not None:

@@ -63,3 +63,30 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src,
                                      flags=re.M), f
+
+
+def test_persistent_kernel_has_no_scratch(tmp_path):
+    """The producer waves of conv3_mfma_persist_kernel order their halo loads
+    by hand (asm volatile loads + counted s_waitcnt): a register spill or
+    copy of an in-flight destination would read garbage.  Pin the property
+    the hand-ordering relies on: the kernel compiles without scratch."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    root = os.path.join(os.path.dirname(__file__), '..')
+    src = os.path.join(root, 'sup3r_amd', 'csrc', 'kernels_conv_mfma_persist.hip')
+    out = subprocess.run(
+        [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-c', src,
+         '-o', str(tmp_path / 'p.o'),
+         '-Rpass-analysis=kernel-resource-usage'],
+        capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = out.stderr.split('Function Name:')
+    mine = [b for b in blocks if 'conv3_mfma_persist_kernel' in b]
+    assert mine, out.stderr[-2000:]
+    scratch = int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', mine[0]).group(1))
+    spills = int(re.search(r'VGPRs Spill: (\d+)', mine[0]).group(1))
+    assert scratch == 0 and spills == 0, (scratch, spills)
