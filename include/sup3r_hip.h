@@ -189,6 +189,32 @@ int s3_affine_channels(s3_ctx* ctx, const float* src, float* dst, int c,
                        const float* shift_host);
 int s3_fill(s3_ctx* ctx, float* dst, int64_t n, float value);
 
+/* ---- batch transform on the device ----------------------
+ * replaces the host numpy of SingleBatchQueue.transform
+ * (sup3r/preprocessing/batch_queues/base.py:32-87):
+ *   s3_coarsen         = spatial_coarsening (sup3r/utilities/utilities.py:
+ *                        406-523, s x s block mean) fused with
+ *                        temporal_coarsening (:345-403; t_method one of
+ *                        S3_TC_*; t_enhance <= 1 = spatial only).  hr is
+ *                        (n, s1, s2, t, c) fp32 (4-D batches: t = 1), lr is
+ *                        (n, s1/s, s2/s, t/t_enhance, c).
+ *   s3_gaussian_smooth = smooth_data (batch_queues/utilities.py:57-103):
+ *                        scipy gaussian_filter(mode='nearest') over the two
+ *                        spatial axes of every (obs, t, feature) slice of
+ *                        channels whose bit is set in channel_mask; weights =
+ *                        the 2*radius+1 normalised taps (host), tmp = scratch
+ *                        of the size of x. */
+#define S3_TC_SUBSAMPLE 0
+#define S3_TC_AVERAGE 1
+#define S3_TC_TOTAL 2
+#define S3_TC_MAX 3
+#define S3_TC_MIN 4
+int s3_coarsen(s3_ctx* ctx, const float* hr, int n, int s1, int s2, int t, int c,
+               int s_enhance, int t_enhance, int t_method, float* lr);
+int s3_gaussian_smooth(s3_ctx* ctx, const float* x, int n, int s1, int s2, int t,
+                       int c, const float* weights_host, int radius,
+                       unsigned channel_mask, float* tmp, float* y);
+
 /* ---- data-parallel gradient sync (RCCL over xGMI) -----------------------
  * replaces: the host-side python sum of per-GPU gradient lists,
  * AbstractSingleModel._sum_parallel_grad (abstract.py:785-805): elementwise

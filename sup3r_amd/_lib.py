@@ -28,6 +28,7 @@ EXPORTS = [
     's3_plan_profile_begin', 's3_plan_profile_end',
     's3_plan_op_is_mfma', 's3_loss_content', 's3_loss_content_masked', 's3_loss_rel_bce',
     's3_copy_channels', 's3_affine_channels', 's3_fill',
+    's3_coarsen', 's3_gaussian_smooth',
     's3_comm_unique_id', 's3_comm_init', 's3_params_allreduce_grads',
     's3_allreduce_sum', 's3_version',
 ]
@@ -109,6 +110,10 @@ def lib():
                                    i32]),
         's3_affine_channels': (i32, [vp, vp, vp, i32, i64, pf, pf]),
         's3_fill': (i32, [vp, vp, i64, f32]),
+        's3_coarsen': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+                             vp]),
+        's3_gaussian_smooth': (i32, [vp, vp, i32, i32, i32, i32, i32, pf, i32,
+                                     C.c_uint32, vp, vp]),
         's3_comm_unique_id': (i32, [vp]),
         's3_comm_init': (i32, [vp, i32, i32, vp]),
         's3_params_allreduce_grads': (i32, [vp]),
@@ -120,6 +125,9 @@ def lib():
         fn.restype, fn.argtypes = sig[name]
     _lib = L
     return L
+
+
+TC_METHODS = {'subsample': 0, 'average': 1, 'total': 2, 'max': 3, 'min': 4}
 
 
 def check(rc, ctx=None, what=''):

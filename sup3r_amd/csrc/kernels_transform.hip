@@ -1,0 +1,133 @@
+// Batch transform on the device: the step immediately
+// before the hot path.  SingleBatchQueue.transform (batch_queues/base.py:
+// 32-87) derives the low-res batch from the hi-res samples on the host with
+//   spatial_coarsening   (utilities/utilities.py:406-523: s x s block mean),
+//   temporal_coarsening  (utilities/utilities.py:345-403: subsample / average
+//                         / total / max / min over t_enhance steps),
+//   smooth_data          (batch_queues/utilities.py:57-103: scipy
+//                         gaussian_filter(sigma, mode='nearest') over the two
+//                         spatial axes of every (obs, t, feature) slice).
+// All three are HBM-bound streaming ops; coarsening reads the hi-res batch
+// once and writes the low-res one (fused spatial + temporal), the filter is
+// separable (two passes, weights in a kernel argument).
+#include "common.h"
+
+namespace {
+
+constexpr int kBlk = 256;
+constexpr int kMaxRadius = 32;
+
+struct GaussW {
+  float w[2 * kMaxRadius + 1];
+};
+
+// y[n, a, b, q, c] = reduce_{i<s, j<s, r<t} x[n, a s + i, b s + j, q t + r, c]
+// summation order = numpy's: the block sum over (i, j) first (/ s^2), then the
+// temporal reduction of the spatial means
+__global__ void coarsen_kernel(const float* __restrict__ x, float* __restrict__ y,
+                               int N, int S1, int S2, int T, int C, int s, int t,
+                               int method) {
+  const int O1 = S1 / s, O2 = S2 / s, OT = method < 0 ? T : T / t;
+  const int64_t total = (int64_t)N * O1 * O2 * OT * C;
+  const float inv = 1.f / (float)(s * s);
+  for (int64_t idx = (int64_t)blockIdx.x * kBlk + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * kBlk) {
+    int64_t r = idx;
+    const int c = (int)(r % C); r /= C;
+    const int q = (int)(r % OT); r /= OT;
+    const int b = (int)(r % O2); r /= O2;
+    const int a = (int)(r % O1); r /= O1;
+    const int n = (int)r;
+    const int nt = method < 0 ? 1 : (method == S3_TC_SUBSAMPLE ? 1 : t);
+    const int tq = method < 0 ? q : q * t;
+    float accv = 0.f;
+    for (int rr = 0; rr < nt; ++rr) {
+      float sm = 0.f;
+      for (int i = 0; i < s; ++i)
+        for (int j = 0; j < s; ++j)
+          sm += x[((((int64_t)n * S1 + a * s + i) * S2 + b * s + j) * T + tq + rr) * C + c];
+      sm *= inv;
+      if (rr == 0) accv = sm;
+      else if (method == S3_TC_MAX) accv = fmaxf(accv, sm);
+      else if (method == S3_TC_MIN) accv = fminf(accv, sm);
+      else accv += sm;
+    }
+    if (method == S3_TC_AVERAGE) accv /= (float)t;
+    y[idx] = accv;
+  }
+}
+
+// one separable pass of scipy's gaussian_filter(mode='nearest') along spatial
+// axis `axis` (0: s1, 1: s2) of x (N, S1, S2, T, C); channels whose bit is not
+// set in `cmask` are copied
+__global__ void gauss_pass_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                  int N, int S1, int S2, int T, int C, int axis,
+                                  int radius, GaussW gw, unsigned cmask) {
+  const int64_t total = (int64_t)N * S1 * S2 * T * C;
+  const int L = axis == 0 ? S1 : S2;
+  const int64_t stride = axis == 0 ? (int64_t)S2 * T * C : (int64_t)T * C;
+  for (int64_t idx = (int64_t)blockIdx.x * kBlk + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * kBlk) {
+    const int c = (int)(idx % C);
+    if (!((cmask >> c) & 1u)) { y[idx] = x[idx]; continue; }
+    const int pos = (int)((idx / stride) % L);
+    const int64_t base = idx - (int64_t)pos * stride;
+    float acc = 0.f;
+    for (int k = -radius; k <= radius; ++k) {
+      int p = pos + k;
+      p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);       // mode='nearest'
+      acc += gw.w[k + radius] * x[base + (int64_t)p * stride];
+    }
+    y[idx] = acc;
+  }
+}
+
+int grid_of(int64_t n, int num_cu) {
+  int64_t g = (n + kBlk - 1) / kBlk;
+  const int64_t cap = (int64_t)num_cu * 16;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int s3_coarsen(s3_ctx* ctx, const float* hr, int n, int s1, int s2,
+                          int t, int c, int s_enhance, int t_enhance,
+                          int t_method, float* lr) {
+  if (!ctx) return S3_EINVAL;
+  if (s_enhance < 1 || s1 % s_enhance || s2 % s_enhance)
+    S3_FAIL(ctx, S3_EINVAL, "s_enhance must evenly divide grid size");
+  int method = t_method;
+  if (t_enhance <= 1) method = -1;                   // spatial only
+  else if (t % t_enhance)
+    S3_FAIL(ctx, S3_EINVAL, "t_enhance must evenly divide the time axis");
+  else if (method < S3_TC_SUBSAMPLE || method > S3_TC_MIN)
+    S3_FAIL(ctx, S3_EINVAL, "unknown temporal coarsening method");
+  const int ot = method < 0 ? t : t / t_enhance;
+  const int64_t total = (int64_t)n * (s1 / s_enhance) * (s2 / s_enhance) * ot * c;
+  hipLaunchKernelGGL(coarsen_kernel, dim3(grid_of(total, ctx->num_cu)), dim3(kBlk), 0,
+                     ctx->stream, hr, lr, n, s1, s2, t, c, s_enhance,
+                     t_enhance < 1 ? 1 : t_enhance, method);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_gaussian_smooth(s3_ctx* ctx, const float* x, int n, int s1,
+                                  int s2, int t, int c, const float* weights_host,
+                                  int radius, unsigned channel_mask, float* tmp,
+                                  float* y) {
+  if (!ctx) return S3_EINVAL;
+  if (radius < 0 || radius > kMaxRadius)
+    S3_FAIL(ctx, S3_EINVAL, "gaussian radius out of range (<= 32)");
+  if (c > 32) S3_FAIL(ctx, S3_EINVAL, "gaussian_smooth supports at most 32 channels");
+  GaussW gw;
+  for (int i = 0; i < 2 * radius + 1; ++i) gw.w[i] = weights_host[i];
+  const int64_t total = (int64_t)n * s1 * s2 * t * c;
+  const int grid = grid_of(total, ctx->num_cu);
+  // scipy filters axis 0 first, then axis 1 (ndimage.gaussian_filter)
+  hipLaunchKernelGGL(gauss_pass_kernel, dim3(grid), dim3(kBlk), 0, ctx->stream, x, tmp,
+                     n, s1, s2, t, c, 0, radius, gw, channel_mask);
+  hipLaunchKernelGGL(gauss_pass_kernel, dim3(grid), dim3(kBlk), 0, ctx->stream, tmp, y,
+                     n, s1, s2, t, c, 1, radius, gw, channel_mask);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
