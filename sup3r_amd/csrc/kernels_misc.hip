@@ -265,9 +265,18 @@ __global__ void bias_grad_stage1(const float* __restrict__ dy, int64_t n_pos,
   const int my_c = threadIdx.x % c, my_r = threadIdx.x / c;
   float acc = 0.f;
   if (my_r < rows) {
-    for (int64_t p = (int64_t)blockIdx.x * rows + my_r; p < n_pos;
-         p += (int64_t)gridDim.x * rows)
-      acc += dy[p * c + my_c];
+    // four loads in flight per lane (fixed order: still deterministic)
+    const int64_t step = (int64_t)gridDim.x * rows;
+    int64_t p = (int64_t)blockIdx.x * rows + my_r;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (; p + 3 * step < n_pos; p += 4 * step) {
+      a0 += dy[p * c + my_c];
+      a1 += dy[(p + step) * c + my_c];
+      a2 += dy[(p + 2 * step) * c + my_c];
+      a3 += dy[(p + 3 * step) * c + my_c];
+    }
+    for (; p < n_pos; p += step) a0 += dy[p * c + my_c];
+    acc = (a0 + a1) + (a2 + a3);
   }
   sm[threadIdx.x] = (my_r < rows) ? acc : 0.f;
   __syncthreads();
@@ -554,8 +563,10 @@ int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
   int block = c <= 256 ? 256 : 1024;
   int rows = block / c;
   int64_t want = (n_pos + rows - 1) / rows;
-  // few partial slabs: stage 2 walks them serially per channel
-  int nblk = (int)(want < 48 ? (want < 1 ? 1 : want) : 48);
+  // stage 2 walks the partial slabs serially per channel (deterministic);
+  // enough slabs to put four blocks on every CU
+  const int cap = 4 * ctx->num_cu;
+  int nblk = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
   int rc = ensure_scratch(ctx, (size_t)nblk * c * sizeof(float));
   if (rc) return rc;
   hipLaunchKernelGGL(bias_grad_stage1, dim3(nblk), dim3(block), block * sizeof(float), ctx->stream, dy, n_pos, c, ctx->scratch);
