@@ -311,3 +311,33 @@ def test_losses_adam_utils():
         o2.cpu().numpy(), a * np.array([2, 3], np.float32)
         + np.array([-1, .5], np.float32), rtol=1e-6)
     torch.cuda.synchronize()
+
+
+def test_hipgraph_replay_is_bit_identical(monkeypatch):
+    """SUP3R_AMD_GRAPH=1: the forward op list is captured into a hipGraph
+    (staged inputs, fixed pointers) and replayed; outputs must equal the eager
+    launches bit for bit, also after a weight update (re-capture)."""
+    rng = np.random.default_rng(4)
+    spec = _load('test_gen_st_2x_4x_2f.json')
+    shape = (2, 5, 6, 4, 3)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    net = _hip_net(spec, ref.weights)
+    y_eager = net(x).cpu().numpy()
+    monkeypatch.setenv('SUP3R_AMD_GRAPH', '1')
+    for _ in range(4):                      # eager warm-up, capture, replays
+        y = net(x).cpu().numpy()
+        np.testing.assert_array_equal(y, y_eager)
+    x2 = rng.standard_normal(shape).astype(np.float32)
+    y2 = net(x2).cpu().numpy()
+    monkeypatch.delenv('SUP3R_AMD_GRAPH')
+    np.testing.assert_array_equal(y2, net(x2).cpu().numpy())
+    monkeypatch.setenv('SUP3R_AMD_GRAPH', '1')
+    w = [v * 1.01 for v in net.weights]
+    net.set_weights(w)
+    y3 = net(x).cpu().numpy()
+    y3b = net(x).cpu().numpy()
+    monkeypatch.delenv('SUP3R_AMD_GRAPH')
+    np.testing.assert_array_equal(y3, net(x).cpu().numpy())
+    np.testing.assert_array_equal(y3b, y3)
+    assert np.abs(y3 - y_eager).max() > 0
