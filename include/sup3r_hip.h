@@ -188,6 +188,12 @@ int s3_affine_channels(s3_ctx* ctx, const float* src, float* dst, int c,
                        int64_t n_pos, const float* scale_host,
                        const float* shift_host);
 int s3_fill(s3_ctx* ctx, float* dst, int64_t n, float value);
+/* device half of ForwardPass._output_check (sup3r/pipeline/forward_pass.py:
+ * 384-425: NaNs or a constant output channel mean the chunk failed): for x =
+ * (n_chunks, pos_per_chunk, c) writes partial[n_chunks][64][c][3] = (min, max,
+ * NaN count) per slab of positions; the caller folds the 64 slabs. */
+int s3_chunk_stats(s3_ctx* ctx, const float* x, int n_chunks,
+                   int64_t pos_per_chunk, int c, float* partial);
 
 /* ---- batch transform on the device ----------------------
  * replaces the host numpy of SingleBatchQueue.transform

@@ -466,7 +466,45 @@ __global__ void affine_channels_kernel(const float* __restrict__ src,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     int ch = (int)(i % c);
-    dst[i] = src[i] * a.scale[ch] + a.shift[ch];
+    // two roundings, as numpy's (x * scale) + shift: the empty asm keeps the
+    // compiler from contracting the pair into one fma
+    float t = src[i] * a.scale[ch];
+    asm volatile("" : "+v"(t));
+    dst[i] = t + a.shift[ch];
+  }
+}
+
+// per-(chunk, slab) min / max / NaN count of every channel: the device half of
+// ForwardPass._output_check (forward_pass.py:384-425)
+constexpr int kStatSlabs = 64;
+__global__ void chunk_stats_kernel(const float* __restrict__ x, int64_t pos_per_chunk,
+                                   int c, float* __restrict__ partial) {
+  const int chunk = blockIdx.y, slab = blockIdx.x;
+  const float* xc = x + (int64_t)chunk * pos_per_chunk * c;
+  __shared__ float smin[256], smax[256], snan[256];
+  for (int ch = 0; ch < c; ++ch) {
+    float mn = INFINITY, mx = -INFINITY, nn = 0.f;
+    for (int64_t p = (int64_t)slab * blockDim.x + threadIdx.x; p < pos_per_chunk;
+         p += (int64_t)kStatSlabs * blockDim.x) {
+      const float v = xc[p * c + ch];
+      if (v != v) nn += 1.f;
+      else { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    }
+    smin[threadIdx.x] = mn; smax[threadIdx.x] = mx; snan[threadIdx.x] = nn;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) {
+        smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
+        smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+        snan[threadIdx.x] += snan[threadIdx.x + s];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      float* o = partial + (((int64_t)chunk * kStatSlabs + slab) * c + ch) * 3;
+      o[0] = smin[0]; o[1] = smax[0]; o[2] = snan[0];
+    }
+    __syncthreads();
   }
 }
 
@@ -657,6 +695,16 @@ extern "C" int s3_affine_channels(s3_ctx* ctx, const float* src, float* dst,
   for (int i = 0; i < c; ++i) { a.scale[i] = scale_host[i]; a.shift[i] = shift_host[i]; }
   int64_t n = n_pos * c;
   hipLaunchKernelGGL(affine_channels_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, src, dst, c, n, a);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_chunk_stats(s3_ctx* ctx, const float* x, int n_chunks,
+                              int64_t pos_per_chunk, int c, float* partial) {
+  if (!ctx) return S3_EINVAL;
+  if (n_chunks < 1 || c < 1) S3_FAIL(ctx, S3_EINVAL, "chunk_stats: empty input");
+  hipLaunchKernelGGL(chunk_stats_kernel, dim3(kStatSlabs, n_chunks), dim3(256), 0,
+                     ctx->stream, x, pos_per_chunk, c, partial);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
