@@ -109,6 +109,17 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                              const void* image, const float* bias,
                              const void* res, void* y);
 
+// general gather-MFMA conv (any stride / padding, C_in % 32 == 0, fp32 I/O,
+// bf16 operands): forward and data gradient
+bool conv_gconv_supported(const ConvGeom& g, int precision);
+bool conv_gconv_dgrad_supported(const ConvGeom& g, int precision);
+size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad);
+int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad);
+int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
+                     const float* bias, const float* res, float* y);
+int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* packed_t,
+                       float* dx, int accumulate);
+
 // MFMA backward of the 3x3x3 stride-1 trunk convs.
 // wgrad: persistent-workgroup kernel (kernels_conv_wgrad_mfma.hip)
 bool conv_wgrad_mfma_supported(const ConvGeom& g);

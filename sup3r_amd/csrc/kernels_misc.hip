@@ -287,13 +287,21 @@ __global__ void bias_grad_stage1(const float* __restrict__ dy, int64_t n_pos,
   }
 }
 
+// one block per channel: 256 lanes stride over the slabs, fixed-shape tree
+// (deterministic)
 __global__ void bias_grad_stage2(const float* __restrict__ partial, int nblk,
                                  int c, float* __restrict__ db, int accumulate) {
-  int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+  __shared__ float sm[256];
+  const int ch = blockIdx.x;
   float t = 0.f;
-  for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * c + ch];
-  db[ch] = accumulate ? db[ch] + t : t;
+  for (int b = threadIdx.x; b < nblk; b += 256) t += partial[(int64_t)b * c + ch];
+  sm[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) db[ch] = accumulate ? db[ch] + sm[0] : sm[0];
 }
 
 // wide-channel variant (dense layers: few rows, thousands of channels): one
@@ -608,7 +616,7 @@ int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
   int rc = ensure_scratch(ctx, (size_t)nblk * c * sizeof(float));
   if (rc) return rc;
   hipLaunchKernelGGL(bias_grad_stage1, dim3(nblk), dim3(block), block * sizeof(float), ctx->stream, dy, n_pos, c, ctx->scratch);
-  hipLaunchKernelGGL(bias_grad_stage2, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, ctx->scratch, nblk, c, db, accumulate);
+  hipLaunchKernelGGL(bias_grad_stage2, dim3(c), dim3(256), 0, ctx->stream, ctx->scratch, nblk, c, db, accumulate);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -50,6 +50,11 @@ struct OpRec {
   float* dg_w32 = nullptr;     // flipped / transposed fp32 filter
   void* dg_wbf = nullptr;      // its bf16 slabs (bf16 mode)
   uint64_t dg_version = 0;
+  // general gather-MFMA conv (strided / valid-padded, C_in % 32 == 0)
+  bool gconv = false, gconv_dgrad = false;
+  void* gc_w = nullptr;        // bf16 [tap][co][ci]
+  void* gc_wt = nullptr;       // bf16 [tap][ci][co] (data gradient)
+  uint64_t gc_version = 0, gct_version = 0;
   // few-positions GEMM path
   bool fewpos = false;
   float* fp_wt = nullptr;      // [tap][co][ci] transposed filter (dgrad)
@@ -352,6 +357,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
         if (d.res >= 0 && pl->t[d.res].numel != ot.numel) return bad("plan: residual shape mismatch");
         o.mfma = conv_mfma_supported(g, precision);
         o.fewpos = !o.mfma && !getenv("SUP3R_AMD_NO_FEWPOS") && conv_fewpos_supported(g);
+        o.gconv = !o.mfma && !o.fewpos && conv_gconv_supported(g, precision);
         if (o.fewpos) max_fp = std::max(max_fp, conv_fewpos_partial_bytes(g));
         size_t ysz = (size_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout * sizeof(float);
         max_dpre = std::max(max_dpre, ysz);
@@ -361,6 +367,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
           if (o.wgrad_mfma)
             max_partial = std::max(max_partial, conv_wgrad_mfma_partial_bytes(ctx, g));
           o.dgrad_mfma = conv_dgrad_mfma_supported(g, precision);
+          o.gconv_dgrad = !o.dgrad_mfma && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
           if (o.dgrad_mfma) {
             o.dg = conv_dgrad_geom(g);
             max_dxp = std::max(max_dxp, (size_t)o.dg.N * o.dg.O[0] * o.dg.O[1] * o.dg.O[2] * o.dg.Cout * sizeof(float));
@@ -536,6 +543,17 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
   }
+  for (auto& o : pl->ops) {
+    if (o.d.kind != S3_OP_CONV) continue;
+    if (o.gconv) {
+      int rc = plan_alloc(pl, &o.gc_w, conv_gconv_packed_bytes(o.cg, 0));
+      if (rc) { s3_plan_destroy(pl); return rc; }
+    }
+    if (o.gconv_dgrad) {
+      int rc = plan_alloc(pl, &o.gc_wt, conv_gconv_packed_bytes(o.cg, 1));
+      if (rc) { s3_plan_destroy(pl); return rc; }
+    }
+  }
   // staging copies of the graph inputs: fixed pointers for the hipGraph replay
   if (!training) {
     for (size_t i = 0; i < pl->inputs.size(); ++i) {
@@ -599,6 +617,14 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
         }
         const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.packed : (const void*)w;
         return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out), o.io);
+      }
+      if (o.gconv && !o.io.in_bf16 && !o.io.out_bf16 && !o.io.res_bf16) {
+        if (o.gc_version != P->version) {
+          int rc = launch_gconv_pack(ctx, o.cg, w, o.gc_w, 0);
+          if (rc) return rc;
+          o.gc_version = P->version;
+        }
+        return launch_gconv_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.gc_w, b, res, (float*)tptr(pl, d.out));
       }
       if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16)
         return launch_conv_fewpos_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out), pl->fp_partial, pl->fp_partial_bytes);
@@ -891,6 +917,13 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
             fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
             rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+          } else if (o.gconv_dgrad) {
+            if (o.gct_version != P->version) {
+              rc = launch_gconv_pack(ctx, g, W + P->p[d.w].offset, o.gc_wt, 1);
+              if (rc) return rc;
+              o.gct_version = P->version;
+            }
+            rc = launch_gconv_dgrad(ctx, g, dpre, o.gc_wt, dst, 0);
           } else if (o.fewpos && o.fp_wt) {
             if (o.fp_version != P->version) {
               rc = launch_conv_fewpos_transpose(ctx, g, W + P->p[d.w].offset, o.fp_wt);

@@ -192,6 +192,38 @@ def test_persistent_trunk_kernel_matches_tile_kernel_and_oracle():
     assert np.abs(y - y_tile).max() / scale < 1e-2
 
 
+def test_gather_mfma_conv_strided_valid_vs_oracle():
+    """Discriminator-style stack (valid padding, strides 1 / 2, channels 32 /
+    64 / 96) on the general gather-MFMA kernels in bf16 mode: forward, data
+    gradient and weight gradients against the oracle (bf16 operands, fp32
+    accumulate: 5e-2 of the largest value), and against the direct fp32
+    kernels of the same library (SUP3R_AMD_NO_GCONV)."""
+    rng = np.random.default_rng(12)
+
+    def conv(f, s, pad='valid'):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': pad},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(32, 2) + conv(64, 1, 'same') + conv(96, 2) + \
+        [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (2, 21, 18, 23, 2)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = ref.backward(dy)
+    net = _hip_net(spec, ref.weights, precision='bf16')
+    dev = net.dev
+    ph = net.plan(shape, training=True)
+    y = ph.forward(dev.to_device(x)).cpu().numpy()
+    assert np.abs(y - y_ref).max() < 5e-2 * max(1.0, np.abs(y_ref).max())
+    dx = ph.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
+    assert np.abs(dx - dx_ref).max() < 5e-2 * np.abs(dx_ref).max()
+    gmax = max(float(np.abs(g).max()) for g in ref.grads)
+    for g, g_ref in zip(net.grads, ref.grads):
+        assert np.abs(g - g_ref).max() < 5e-2 * np.abs(g_ref).max() + 1e-3 * gmax
+
+
 @pytest.mark.parametrize('n_out', [2, 3])
 def test_tail_conv_mfma_vs_oracle_and_direct_kernel(n_out):
     """Hi-res tail conv 8 -> n_out after the depth-to-space store (bf16 cells
