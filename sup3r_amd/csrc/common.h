@@ -109,6 +109,12 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                              const void* image, const float* bias,
                              const void* res, void* y);
 
+// general fp32-MFMA weight gradient (C_in <= 64, stride 1 / 2, any padding)
+bool conv_wgrad_gen_supported(const ConvGeom& g);
+size_t conv_wgrad_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
+int launch_conv_wgrad_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                          float* dw, float* partial, size_t partial_bytes, int accumulate);
+
 // general gather-MFMA conv (any stride / padding, C_in % 32 == 0, fp32 I/O,
 // bf16 operands): forward and data gradient
 bool conv_gconv_supported(const ConvGeom& g, int precision);

@@ -14,6 +14,8 @@
 // (row & 1) << 4 channel swizzle.  dPre fragments are shared by the 27 taps.
 // Each workgroup writes one partial; a fixed-order reduction makes the result
 // deterministic (identical on every rank).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -188,4 +190,224 @@ int launch_conv_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x,
                      partial, grid, wsize, dw, accumulate);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
+}
+
+// ===========================================================================
+// General variant: any C_in <= 64 (padded to CIB blocks of 16), any C_out,
+// stride 1 or 2, any low padding / valid extents — the discriminator convs
+// (32->32 s2, 32->64, 64->64 s2, 64->128, 4->32) and the generator's small
+// head / tail convs.  Same scheme as above: persistent workgroups of 8 waves,
+// wave = one 16 x 16 (ci, co) block of ALL 27 taps in registers, exact fp32
+// v_mfma_f32_16x16x4_f32 with single-dword LDS operand reads (A[i = ci][k =
+// position] needs no transpose and tolerates any tap shift / stride).
+//   CIB = 1 : 16 input channels x 128 output channels per workgroup
+//   CIB = 2 : 32 x 64        CIB = 4 : 64 x 32
+//   stride 1: 2 x 4 x 16 positions per tile (halo 4 x 6 x 18 cells)
+//   stride 2: 1 x 2 x 16 positions per tile (halo 3 x 5 x 33 cells)
+namespace {
+
+template <int CIB, int STR>
+struct GenW {
+  static constexpr int CIP = CIB * 16;              // padded input channels
+  static constexpr int COB = 8 / CIB;               // co blocks (one per wave group)
+  static constexpr int COT = COB * 16;              // output-channel tile
+  static constexpr int T0 = STR == 1 ? 2 : 1, T1 = STR == 1 ? 4 : 2, T2 = 16;
+  static constexpr int G0 = (T0 - 1) * STR + 3, G1 = (T1 - 1) * STR + 3, G2 = (T2 - 1) * STR + 3;
+  static constexpr int HP = G0 * G1 * G2;
+  static constexpr int NP = T0 * T1 * T2;
+  static constexpr size_t LDS = (size_t)HP * CIP * 4 + (size_t)NP * COT * 4;
+};
+
+template <int CIB, int STR>
+__global__ __launch_bounds__(512) void conv_wgrad_gen_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy,
+    float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1, int tiles2,
+    int n_tiles) {
+  using W = GenW<CIB, STR>;
+  constexpr int CIP = W::CIP, COT = W::COT, T1 = W::T1, T2 = W::T2;
+  constexpr int G1 = W::G1, G2 = W::G2, HP = W::HP, NP = W::NP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = reinterpret_cast<float*>(smem);              // [HP][CIP] swizzled
+  float* ds = xs + (size_t)HP * CIP;                       // [NP][COT] swizzled
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, kq = lane >> 4;
+  const int cib = (wave % CIB) * 16, cob = (wave / CIB) * 16;
+  const int ct = blockIdx.y;
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+  const int Cin = g.Cin, Cout = g.Cout;
+  // swizzles: the two positions a 32-lane ds_read_b32 group touches must not
+  // share banks (x: key on the cell's t index / stride; dy: position parity)
+  constexpr int XSW = CIP >= 32 ? 16 : 0;
+  constexpr int DSW = COT >= 32 ? 16 : 0;
+
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int tr = tile;
+    const int t2i = tr % tiles2; tr /= tiles2;
+    const int t1i = tr % tiles1; tr /= tiles1;
+    const int t0i = tr % tiles0; tr /= tiles0;
+    const int n = tr;
+    const int org0 = t0i * W::T0, org1 = t1i * T1, org2 = t2i * T2;
+    __syncthreads();   // previous tile fully consumed
+    // ---- stage the x halo: cells x (CIP / 4) float4 (zero beyond C_in)
+    constexpr int CH = CIP / 4;
+    for (int item = tid; item < HP * CH; item += 512) {
+      const int hp = item / CH, ch = item % CH;
+      int h = hp;
+      const int c2 = h % G2; h /= G2;
+      const int c1 = h % G1; h /= G1;
+      const int c0 = h;
+      int i0 = org0 * STR + c0 - g.lo[0], i1 = org1 * STR + c1 - g.lo[1],
+          i2 = org2 * STR + c2 - g.lo[2];
+      bool valid = true;
+      if (g.pad_mode == S3_PAD_REFLECT) {
+        i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
+      }
+      // outside the tensor: zero padding, or cells feeding only masked outputs
+      valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        const float* src = x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * Cin + ch * 4;
+        if ((Cin & 3) == 0 && ch * 4 + 3 < Cin) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ch * 4 + e < Cin) v[e] = src[e];
+        }
+      }
+      const int col = (ch * 4) ^ (((c2 / STR) & 1) * XSW);
+      *reinterpret_cast<float4*>(xs + (size_t)hp * CIP + col) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    // ---- stage the dPre tile: NP positions x (COT / 4) float4
+    constexpr int DH = COT / 4;
+    for (int item = tid; item < NP * DH; item += 512) {
+      const int pl = item / DH, ch = item % DH;
+      const int row = pl / T2, tt = pl % T2;
+      const int o0 = org0 + row / T1, o1 = org1 + row % T1, o2 = org2 + tt;
+      const int co = ct * COT + ch * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && co < Cout) {
+        const float* src = dy + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * Cout + co;
+        if ((Cout & 3) == 0) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < Cout) v[e] = src[e];
+        }
+      }
+      const int col = (ch * 4) ^ ((pl & 1) * DSW);
+      *reinterpret_cast<float4*>(ds + (size_t)pl * COT + col) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    // ---- accumulate: (s1, s2) rows x k-steps of 4 consecutive t
+    for (int row = 0; row < W::T0 * T1; ++row) {
+      const int r0 = row / T1, r1 = row % T1;
+#pragma unroll 1
+      for (int tq = 0; tq < T2 / 4; ++tq) {
+        const int pl = row * T2 + tq * 4 + kq;               // this lane's k
+        const float bv = ds[(size_t)pl * COT + ((cob + fi) ^ ((pl & 1) * DSW))];
+        const int tcell = (tq * 4 + kq) * STR;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const int hp = ((r0 * STR + a) * G1 + (r1 * STR + b)) * G2 + tcell + c;
+              const float av = xs[(size_t)hp * CIP + ((cib + fi) ^ ((((tcell + c) / STR) & 1) * XSW))];
+              acc[(a * 3 + b) * 3 + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                  av, bv, acc[(a * 3 + b) * 3 + c], 0, 0, 0);
+            }
+      }
+    }
+  }
+  // ---- partial[bid][tap][ci][co]: C/D map col = lane&15 (co), row = kq*4 + r (ci)
+  float* out = partial + (size_t)blockIdx.x * 27 * Cin * Cout;
+  const int co = ct * COT + cob + fi;
+  if (co < Cout) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = cib + kq * 4 + r;
+        if (ci < Cin) out[((size_t)t * Cin + ci) * Cout + co] = acc[t][r];
+      }
+  }
+}
+
+template <int CIB, int STR>
+int wgrad_gen_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t0, int* t1, int* t2) {
+  using W = GenW<CIB, STR>;
+  *t0 = (g.O[0] + W::T0 - 1) / W::T0; *t1 = (g.O[1] + W::T1 - 1) / W::T1;
+  *t2 = (g.O[2] + W::T2 - 1) / W::T2;
+  *n_tiles = g.N * *t0 * *t1 * *t2;
+  const int n_ct = (g.Cout + W::COT - 1) / W::COT;
+  int grid = ctx->num_cu / n_ct;
+  if (grid < 1) grid = 1;
+  if (grid > *n_tiles) grid = *n_tiles;
+  return grid;
+}
+
+template <int CIB, int STR>
+int wgrad_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                     float* dw, float* partial, size_t partial_bytes, int accumulate) {
+  using W = GenW<CIB, STR>;
+  int n_tiles, t0, t1, t2;
+  const int grid = wgrad_gen_grid<CIB, STR>(ctx, g, &n_tiles, &t0, &t1, &t2);
+  const size_t need = (size_t)grid * 27 * g.Cin * g.Cout * sizeof(float);
+  if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_gen: partial buffer too small");
+  auto kern = conv_wgrad_gen_kernel<CIB, STR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS));
+    attr_set = true;
+  }
+  const int n_ct = (g.Cout + W::COT - 1) / W::COT;
+  hipLaunchKernelGGL(kern, dim3(grid, n_ct), dim3(512), W::LDS, ctx->stream, x, dy, partial, g,
+                     t0, t1, t2, n_tiles);
+  const int64_t wsize = (int64_t)27 * g.Cin * g.Cout;
+  int rg = (int)((wsize + 255) / 256);
+  if (rg > 2048) rg = 2048;
+  hipLaunchKernelGGL(wgrad_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial, grid,
+                     wsize, dw, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int wgrad_gen_cib(const ConvGeom& g) { return g.Cin <= 16 ? 1 : (g.Cin <= 32 ? 2 : 4); }
+
+}  // namespace
+
+bool conv_wgrad_gen_supported(const ConvGeom& g) {
+  if (getenv("SUP3R_AMD_NO_GCONV")) return false;
+  if (g.Cin > 64 || g.d2s != 1) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g.k[d] != 3 || g.s[d] != g.s[0] || (g.s[d] != 1 && g.s[d] != 2)) return false;
+  return g.O[2] >= 4;
+}
+
+size_t conv_wgrad_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
+  // one partial per workgroup; the grid never exceeds the CU count
+  return (size_t)ctx->num_cu * 27 * g.Cin * g.Cout * sizeof(float);
+}
+
+int launch_conv_wgrad_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                          float* dw, float* partial, size_t partial_bytes, int accumulate) {
+  const int cib = wgrad_gen_cib(g);
+  const bool s2 = g.s[0] == 2;
+#define S3_WG(C, S) return wgrad_gen_launch<C, S>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
+  if (cib == 1) { if (s2) S3_WG(1, 2); S3_WG(1, 1); }
+  if (cib == 2) { if (s2) S3_WG(2, 2); S3_WG(2, 1); }
+  if (s2) S3_WG(4, 2);
+  S3_WG(4, 1);
+#undef S3_WG
 }

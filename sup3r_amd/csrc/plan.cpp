@@ -51,7 +51,7 @@ struct OpRec {
   void* dg_wbf = nullptr;      // its bf16 slabs (bf16 mode)
   uint64_t dg_version = 0;
   // general gather-MFMA conv (strided / valid-padded, C_in % 32 == 0)
-  bool gconv = false, gconv_dgrad = false;
+  bool gconv = false, gconv_dgrad = false, wgrad_gen = false;
   void* gc_w = nullptr;        // bf16 [tap][co][ci]
   void* gc_wt = nullptr;       // bf16 [tap][ci][co] (data gradient)
   uint64_t gc_version = 0, gct_version = 0;
@@ -366,6 +366,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
           o.wgrad_mfma = conv_wgrad_mfma_supported(g);
           if (o.wgrad_mfma)
             max_partial = std::max(max_partial, conv_wgrad_mfma_partial_bytes(ctx, g));
+          if (!o.wgrad_mfma && !o.fewpos && conv_wgrad_gen_supported(g)) {
+            o.wgrad_gen = true;
+            max_partial = std::max(max_partial, conv_wgrad_gen_partial_bytes(ctx, g));
+          }
           o.dgrad_mfma = conv_dgrad_mfma_supported(g, precision);
           o.gconv_dgrad = !o.dgrad_mfma && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
           if (o.dgrad_mfma) {
@@ -890,6 +894,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           }
           if (o.fewpos)
             rc = launch_conv_fewpos_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, accumulate_wgrad);
+          else if (o.wgrad_gen)
+            rc = launch_conv_wgrad_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_mfma)
             rc = launch_conv_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else
