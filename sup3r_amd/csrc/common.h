@@ -124,7 +124,7 @@ int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* pack
 int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
                      const float* bias, const float* res, float* y);
 int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* packed_t,
-                       float* dx, int accumulate);
+                       float* dx, int accumulate, int frame);
 
 // MFMA backward of the 3x3x3 stride-1 trunk convs.
 // wgrad: persistent-workgroup kernel (kernels_conv_wgrad_mfma.hip)

@@ -74,14 +74,19 @@ template <bool ADJ>
 __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, const float* __restrict__ res,
-    float* __restrict__ y, ConvGeom g, int64_t P, int rows_pad, int accumulate) {
+    float* __restrict__ y, ConvGeom g, int64_t P, int rows_pad, int accumulate, int frame) {
   // in ADJ mode: g is the FORWARD conv's geometry; positions run over its
   // input grid D, the gathered tensor x is dY on its output grid O, K = C_out
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p16 = lane & 15, kq = lane >> 4;
   const int K = ADJ ? g.Cout : g.Cin;          // contraction channels per tap
   const int R = ADJ ? g.Cin : g.Cout;          // output channels
-  const int G0 = ADJ ? g.D[0] : g.O[0], G1 = ADJ ? g.D[1] : g.O[1], G2 = ADJ ? g.D[2] : g.O[2];
+  // frame (ADJ only): positions run over the virtually padded input frame
+  // (D + 2 lo per axis); the caller folds the border back (reflect adjoint)
+  const int f0 = (ADJ && frame) ? g.lo[0] : 0, f1 = (ADJ && frame) ? g.lo[1] : 0,
+            f2 = (ADJ && frame) ? g.lo[2] : 0;
+  const int G0 = ADJ ? g.D[0] + 2 * f0 : g.O[0], G1 = ADJ ? g.D[1] + 2 * f1 : g.O[1],
+            G2 = ADJ ? g.D[2] + 2 * f2 : g.O[2];
   const int S0 = ADJ ? g.O[0] : g.D[0], S1 = ADJ ? g.O[1] : g.D[1], S2 = ADJ ? g.O[2] : g.D[2];
   const int ct = blockIdx.y;
   const int64_t pbase = (int64_t)blockIdx.x * GT_POS + wave * (GT_MF * 16);
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
 
   const int nfv = (R - ct * GT_N + 15) / 16 < 4 ? (R - ct * GT_N + 15) / 16 : 4;
   const int k0n = g.k[0], k1n = g.k[1], k2n = g.k[2];
-  const int kchunks = K / 32;
+  const int kchunks = (K + 31) / 32;      // K % 8 == 0: a lane's 8-channel group is whole or absent
   for (int ta = 0; ta < k0n; ++ta)
     for (int tb = 0; tb < k1n; ++tb)
       for (int tc = 0; tc < k2n; ++tc) {
@@ -126,7 +131,8 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
               i0 = s3_reflect(i0, S0); i1 = s3_reflect(i1, S1); i2 = s3_reflect(i2, S2);
             }
           } else {
-            const int n0 = c0[m] + g.lo[0] - ta, n1 = c1[m] + g.lo[1] - tb, n2 = c2[m] + g.lo[2] - tc;
+            const int n0 = c0[m] - f0 + g.lo[0] - ta, n1 = c1[m] - f1 + g.lo[1] - tb,
+                      n2 = c2[m] - f2 + g.lo[2] - tc;
             ok = n0 >= 0 && n1 >= 0 && n2 >= 0 && n0 % g.s[0] == 0 && n1 % g.s[1] == 0 &&
                  n2 % g.s[2] == 0;
             i0 = n0 / g.s[0]; i1 = n1 / g.s[1]; i2 = n2 / g.s[2];
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
 #pragma unroll
           for (int m = 0; m < GT_MF; ++m) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (sok[m]) {
+            if (sok[m] && kc * 32 + kq * 8 < K) {
               a = *reinterpret_cast<const float4*>(src[m] + kc * 32);
               b = *reinterpret_cast<const float4*>(src[m] + kc * 32 + 4);
             }
@@ -213,7 +219,7 @@ bool conv_gconv_supported(const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16) return false;
   if (getenv("SUP3R_AMD_NO_GCONV")) return false;
   if (g.d2s != 1) return false;
-  if (g.Cin % 32 != 0 || g.Cin < 32) return false;
+  if (g.Cin % 8 != 0 || g.Cin < 32) return false;
   return true;
 }
 
@@ -221,8 +227,12 @@ bool conv_gconv_supported(const ConvGeom& g, int precision) {
 bool conv_gconv_dgrad_supported(const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16) return false;
   if (getenv("SUP3R_AMD_NO_GCONV")) return false;
-  if (g.d2s != 1 || g.pad_mode == S3_PAD_REFLECT) return false;   // reflect adjoint folds: direct kernel
-  return g.Cout % 32 == 0 && g.Cout >= 32;
+  if (g.d2s != 1) return false;
+  // reflect padding: stride-1 'same' frame + fold only
+  if (g.pad_mode == S3_PAD_REFLECT)
+    for (int d = 0; d < 3; ++d)
+      if (g.s[d] != 1) return false;
+  return g.Cout % 8 == 0 && g.Cout >= 32;
 }
 
 static int rows_padded(int r) { return (r + GT_N - 1) / GT_N * GT_N; }
@@ -230,7 +240,7 @@ static int rows_padded(int r) { return (r + GT_N - 1) / GT_N * GT_N; }
 size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad) {
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int R = dgrad ? g.Cin : g.Cout, K = dgrad ? g.Cout : g.Cin;
-  return (size_t)taps * rows_padded(R) * K * 2;
+  return (size_t)taps * rows_padded(R) * K * 2 + 64;   // + over-read of a masked K tail
 }
 
 int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad) {
@@ -250,18 +260,20 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
   dim3 grid((unsigned)((P + GT_POS - 1) / GT_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
   hipLaunchKernelGGL(gconv_mfma_kernel<false>, grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
-                     (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0);
+                     (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
 
 int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* packed_t,
-                       float* dx, int accumulate) {
-  const int64_t P = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
+                       float* dx, int accumulate, int frame) {
+  const int64_t P = frame ? (int64_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
+                                (g.D[2] + 2 * g.lo[2])
+                          : (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
   dim3 grid((unsigned)((P + GT_POS - 1) / GT_POS), (unsigned)((g.Cin + GT_N - 1) / GT_N));
   hipLaunchKernelGGL(gconv_mfma_kernel<true>, grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
                      (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
-                     rows_padded(g.Cin), accumulate);
+                     rows_padded(g.Cin), accumulate, frame);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -200,17 +200,20 @@ int launch_conv_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x,
 // wave = one 16 x 16 (ci, co) block of ALL 27 taps in registers, exact fp32
 // v_mfma_f32_16x16x4_f32 with single-dword LDS operand reads (A[i = ci][k =
 // position] needs no transpose and tolerates any tap shift / stride).
-//   CIB = 1 : 16 input channels x 128 output channels per workgroup
-//   CIB = 2 : 32 x 64        CIB = 4 : 64 x 32
+//   CIB blocks of 16 input channels x NB blocks of 16 output channels per
+//   workgroup; when CIB * NB < 8 (small C_out: the hi-res 4->32, 8->2 convs)
+//   the spare waves split the positions of a tile PS = 8 / (CIB NB) ways and
+//   write their own partials (the fixed-order reduction sums them).
 //   stride 1: 2 x 4 x 16 positions per tile (halo 4 x 6 x 18 cells)
 //   stride 2: 1 x 2 x 16 positions per tile (halo 3 x 5 x 33 cells)
 namespace {
 
-template <int CIB, int STR>
+template <int CIB, int STR, int NB>
 struct GenW {
   static constexpr int CIP = CIB * 16;              // padded input channels
-  static constexpr int COB = 8 / CIB;               // co blocks (one per wave group)
-  static constexpr int COT = COB * 16;              // output-channel tile
+  static constexpr int COT = NB * 16;               // output-channel tile
+  static constexpr int PS = 8 / (CIB * NB);         // position splits
+  static_assert(PS >= 1 && PS * CIB * NB == 8, "8 waves = CIB x NB x PS");
   static constexpr int T0 = STR == 1 ? 2 : 1, T1 = STR == 1 ? 4 : 2, T2 = 16;
   static constexpr int G0 = (T0 - 1) * STR + 3, G1 = (T1 - 1) * STR + 3, G2 = (T2 - 1) * STR + 3;
   static constexpr int HP = G0 * G1 * G2;
@@ -218,13 +221,13 @@ struct GenW {
   static constexpr size_t LDS = (size_t)HP * CIP * 4 + (size_t)NP * COT * 4;
 };
 
-template <int CIB, int STR>
+template <int CIB, int STR, int NB>
 __global__ __launch_bounds__(512) void conv_wgrad_gen_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1, int tiles2,
     int n_tiles) {
-  using W = GenW<CIB, STR>;
-  constexpr int CIP = W::CIP, COT = W::COT, T1 = W::T1, T2 = W::T2;
+  using W = GenW<CIB, STR, NB>;
+  constexpr int CIP = W::CIP, COT = W::COT, T1 = W::T1, T2 = W::T2, PS = W::PS;
   constexpr int G1 = W::G1, G2 = W::G2, HP = W::HP, NP = W::NP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xs = reinterpret_cast<float*>(smem);              // [HP][CIP] swizzled
@@ -232,7 +235,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_gen_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, kq = lane >> 4;
-  const int cib = (wave % CIB) * 16, cob = (wave / CIB) * 16;
+  const int cib = (wave % CIB) * 16, cob = ((wave / CIB) % NB) * 16;
+  const int ps_id = wave / (CIB * NB);
   const int ct = blockIdx.y;
   const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
   const int Cin = g.Cin, Cout = g.Cout;
@@ -308,10 +312,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_gen_kernel(
     }
     __syncthreads();
     // ---- accumulate: (s1, s2) rows x k-steps of 4 consecutive t
-    for (int row = 0; row < W::T0 * T1; ++row) {
-      const int r0 = row / T1, r1 = row % T1;
 #pragma unroll 1
-      for (int tq = 0; tq < T2 / 4; ++tq) {
+    for (int ks = ps_id; ks < W::T0 * T1 * (T2 / 4); ks += PS) {
+      const int row = ks / (T2 / 4), tq = ks % (T2 / 4);
+      const int r0 = row / T1, r1 = row % T1;
+      {
         const int pl = row * T2 + tq * 4 + kq;               // this lane's k
         const float bv = ds[(size_t)pl * COT + ((cob + fi) ^ ((pl & 1) * DSW))];
         const int tcell = (tq * 4 + kq) * STR;
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_gen_kernel(
     }
   }
   // ---- partial[bid][tap][ci][co]: C/D map col = lane&15 (co), row = kq*4 + r (ci)
-  float* out = partial + (size_t)blockIdx.x * 27 * Cin * Cout;
+  float* out = partial + ((size_t)blockIdx.x * PS + ps_id) * 27 * Cin * Cout;
   const int co = ct * COT + cob + fi;
   if (co < Cout) {
 #pragma unroll
@@ -343,9 +348,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_gen_kernel(
   }
 }
 
-template <int CIB, int STR>
+template <int CIB, int STR, int NB>
 int wgrad_gen_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t0, int* t1, int* t2) {
-  using W = GenW<CIB, STR>;
+  using W = GenW<CIB, STR, NB>;
   *t0 = (g.O[0] + W::T0 - 1) / W::T0; *t1 = (g.O[1] + W::T1 - 1) / W::T1;
   *t2 = (g.O[2] + W::T2 - 1) / W::T2;
   *n_tiles = g.N * *t0 * *t1 * *t2;
@@ -356,15 +361,15 @@ int wgrad_gen_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t0, 
   return grid;
 }
 
-template <int CIB, int STR>
+template <int CIB, int STR, int NB>
 int wgrad_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
                      float* dw, float* partial, size_t partial_bytes, int accumulate) {
-  using W = GenW<CIB, STR>;
+  using W = GenW<CIB, STR, NB>;
   int n_tiles, t0, t1, t2;
-  const int grid = wgrad_gen_grid<CIB, STR>(ctx, g, &n_tiles, &t0, &t1, &t2);
-  const size_t need = (size_t)grid * 27 * g.Cin * g.Cout * sizeof(float);
+  const int grid = wgrad_gen_grid<CIB, STR, NB>(ctx, g, &n_tiles, &t0, &t1, &t2);
+  const size_t need = (size_t)grid * W::PS * 27 * g.Cin * g.Cout * sizeof(float);
   if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_gen: partial buffer too small");
-  auto kern = conv_wgrad_gen_kernel<CIB, STR>;
+  auto kern = conv_wgrad_gen_kernel<CIB, STR, NB>;
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -377,8 +382,8 @@ int wgrad_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float
   const int64_t wsize = (int64_t)27 * g.Cin * g.Cout;
   int rg = (int)((wsize + 255) / 256);
   if (rg > 2048) rg = 2048;
-  hipLaunchKernelGGL(wgrad_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial, grid,
-                     wsize, dw, accumulate);
+  hipLaunchKernelGGL(wgrad_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial,
+                     grid * W::PS, wsize, dw, accumulate);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -395,19 +400,34 @@ bool conv_wgrad_gen_supported(const ConvGeom& g) {
   return g.O[2] >= 4;
 }
 
+// co blocks per workgroup: as many as the conv has, rounded to a power of two
+int wgrad_gen_nb(const ConvGeom& g) {
+  const int cap = 8 / wgrad_gen_cib(g);
+  const int want = (g.Cout + 15) / 16;
+  int nb = 1;
+  while (nb < want && nb < cap) nb *= 2;
+  return nb;
+}
+
 size_t conv_wgrad_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
-  // one partial per workgroup; the grid never exceeds the CU count
-  return (size_t)ctx->num_cu * 27 * g.Cin * g.Cout * sizeof(float);
+  // one partial per (workgroup, position split); the grid never exceeds the
+  // CU count
+  const int ps = 8 / (wgrad_gen_cib(g) * wgrad_gen_nb(g));
+  return (size_t)ctx->num_cu * ps * 27 * g.Cin * g.Cout * sizeof(float);
 }
 
 int launch_conv_wgrad_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
                           float* dw, float* partial, size_t partial_bytes, int accumulate) {
-  const int cib = wgrad_gen_cib(g);
+  const int cib = wgrad_gen_cib(g), nb = wgrad_gen_nb(g);
   const bool s2 = g.s[0] == 2;
-#define S3_WG(C, S) return wgrad_gen_launch<C, S>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
-  if (cib == 1) { if (s2) S3_WG(1, 2); S3_WG(1, 1); }
-  if (cib == 2) { if (s2) S3_WG(2, 2); S3_WG(2, 1); }
-  if (s2) S3_WG(4, 2);
-  S3_WG(4, 1);
+#define S3_WG(C, B)                                                                          \
+  if (cib == C && nb == B) {                                                                 \
+    if (s2) return wgrad_gen_launch<C, 2, B>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate); \
+    return wgrad_gen_launch<C, 1, B>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);  \
+  }
+  S3_WG(1, 1) S3_WG(1, 2) S3_WG(1, 4) S3_WG(1, 8)
+  S3_WG(2, 1) S3_WG(2, 2) S3_WG(2, 4)
+  S3_WG(4, 1) S3_WG(4, 2)
 #undef S3_WG
+  S3_FAIL(ctx, S3_EINVAL, "wgrad_gen: no kernel for this channel split");
 }

@@ -372,6 +372,9 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
           }
           o.dgrad_mfma = conv_dgrad_mfma_supported(g, precision);
           o.gconv_dgrad = !o.dgrad_mfma && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
+          if (o.gconv_dgrad && g.pad_mode == S3_PAD_REFLECT)
+            max_dxp = std::max(max_dxp, (size_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
+                                            (g.D[2] + 2 * g.lo[2]) * g.Cin * sizeof(float));
           if (o.dgrad_mfma) {
             o.dg = conv_dgrad_geom(g);
             max_dxp = std::max(max_dxp, (size_t)o.dg.N * o.dg.O[0] * o.dg.O[1] * o.dg.O[2] * o.dg.Cout * sizeof(float));
@@ -929,7 +932,19 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               if (rc) return rc;
               o.gct_version = P->version;
             }
-            rc = launch_gconv_dgrad(ctx, g, dpre, o.gc_wt, dst, 0);
+            if (g.pad_mode == S3_PAD_REFLECT) {
+              // dXpad over the reflect-padded frame, then fold the border back
+              rc = launch_gconv_dgrad(ctx, g, dpre, o.gc_wt, pl->dxp, 0, 1);
+              if (rc) return rc;
+              GatherGeom fg;
+              fg.kind = S3_OP_PAD; fg.N = g.N;
+              for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2 * g.lo[q]; fg.lo[q] = g.lo[q]; }
+              fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
+              fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
+              rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+            } else {
+              rc = launch_gconv_dgrad(ctx, g, dpre, o.gc_wt, dst, 0, 0);
+            }
           } else if (o.fewpos && o.fp_wt) {
             if (o.fp_version != P->version) {
               rc = launch_conv_fewpos_transpose(ctx, g, W + P->p[d.w].offset, o.fp_wt);
