@@ -227,7 +227,8 @@ bool conv_gconv_supported(const ConvGeom& g, int precision) {
 bool conv_gconv_dgrad_supported(const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16) return false;
   if (getenv("SUP3R_AMD_NO_GCONV")) return false;
-  if (g.d2s != 1) return false;
+  // (a depth-to-space store is undone by the epilogue adjoint: dPre arrives in
+  // the conv's own output layout)
   // reflect padding: stride-1 'same' frame + fold only
   if (g.pad_mode == S3_PAD_REFLECT)
     for (int d = 0; d < 3; ++d)
