@@ -193,7 +193,7 @@ int launch_conv_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x,
 }
 
 // ===========================================================================
-// General variant: any C_in <= 64 (padded to CIB blocks of 16), any C_out,
+// General variant: any C_in (tiles of <= 64, padded to CIB blocks of 16), any C_out,
 // stride 1 or 2, any low padding / valid extents — the discriminator convs
 // (32->32 s2, 32->64, 64->64 s2, 64->128, 4->32) and the generator's small
 // head / tail convs.  Same scheme as above: persistent workgroups of 8 waves,
@@ -238,6 +238,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_gen_kernel(
   const int cib = (wave % CIB) * 16, cob = ((wave / CIB) % NB) * 16;
   const int ps_id = wave / (CIB * NB);
   const int ct = blockIdx.y;
+  const int ci0 = blockIdx.z * CIP;                 // input-channel tile
   const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
   const int Cin = g.Cin, Cout = g.Cout;
   // swizzles: the two positions a 32-lane ds_read_b32 group touches must not
@@ -275,14 +276,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_gen_kernel(
       valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (valid) {
-        const float* src = x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * Cin + ch * 4;
-        if ((Cin & 3) == 0 && ch * 4 + 3 < Cin) {
+        const float* src = x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * Cin + ci0 + ch * 4;
+        if ((Cin & 3) == 0 && ci0 + ch * 4 + 3 < Cin) {
           const float4 q = *reinterpret_cast<const float4*>(src);
           v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (ch * 4 + e < Cin) v[e] = src[e];
+            if (ci0 + ch * 4 + e < Cin) v[e] = src[e];
         }
       }
       const int col = (ch * 4) ^ (((c2 / STR) & 1) * XSW);
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_gen_kernel(
     for (int t = 0; t < 27; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ci = cib + kq * 4 + r;
+        const int ci = ci0 + cib + kq * 4 + r;
         if (ci < Cin) out[((size_t)t * Cin + ci) * Cout + co] = acc[t][r];
       }
   }
@@ -355,7 +356,8 @@ int wgrad_gen_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t0, 
   *t2 = (g.O[2] + W::T2 - 1) / W::T2;
   *n_tiles = g.N * *t0 * *t1 * *t2;
   const int n_ct = (g.Cout + W::COT - 1) / W::COT;
-  int grid = ctx->num_cu / n_ct;
+  const int n_cit = (g.Cin + W::CIP - 1) / W::CIP;
+  int grid = ctx->num_cu / (n_ct * n_cit);
   if (grid < 1) grid = 1;
   if (grid > *n_tiles) grid = *n_tiles;
   return grid;
@@ -377,8 +379,9 @@ int wgrad_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float
     attr_set = true;
   }
   const int n_ct = (g.Cout + W::COT - 1) / W::COT;
-  hipLaunchKernelGGL(kern, dim3(grid, n_ct), dim3(512), W::LDS, ctx->stream, x, dy, partial, g,
-                     t0, t1, t2, n_tiles);
+  const int n_cit = (g.Cin + W::CIP - 1) / W::CIP;
+  hipLaunchKernelGGL(kern, dim3(grid, n_ct, n_cit), dim3(512), W::LDS, ctx->stream, x, dy,
+                     partial, g, t0, t1, t2, n_tiles);
   const int64_t wsize = (int64_t)27 * g.Cin * g.Cout;
   int rg = (int)((wsize + 255) / 256);
   if (rg > 2048) rg = 2048;
@@ -388,13 +391,13 @@ int wgrad_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float
   return S3_OK;
 }
 
-int wgrad_gen_cib(const ConvGeom& g) { return g.Cin <= 16 ? 1 : (g.Cin <= 32 ? 2 : 4); }
+int wgrad_gen_cib(const ConvGeom& g) { return g.Cin <= 16 ? 1 : (g.Cin <= 32 ? 2 : 4); }   // C_in > 64: tiles of 64
 
 }  // namespace
 
 bool conv_wgrad_gen_supported(const ConvGeom& g) {
   if (getenv("SUP3R_AMD_NO_GCONV")) return false;
-  if (g.Cin > 64 || g.d2s != 1) return false;
+  if (g.d2s != 1) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != g.s[0] || (g.s[d] != 1 && g.s[d] != 2)) return false;
   return g.O[2] >= 4;

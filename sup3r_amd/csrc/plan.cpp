@@ -357,6 +357,12 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
         if (d.res >= 0 && pl->t[d.res].numel != ot.numel) return bad("plan: residual shape mismatch");
         o.mfma = conv_mfma_supported(g, precision);
         o.fewpos = !o.mfma && !getenv("SUP3R_AMD_NO_FEWPOS") && conv_fewpos_supported(g);
+        // bf16 plans: the weight-streaming fp32 path only for really few
+        // positions; mid-size layers go to the gather-MFMA kernels
+        if (o.fewpos && (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 256 &&
+            conv_gconv_supported(g, precision) && conv_gconv_dgrad_supported(g, precision) &&
+            conv_wgrad_gen_supported(g))
+          o.fewpos = false;
         o.gconv = !o.mfma && !o.fewpos && conv_gconv_supported(g, precision);
         if (o.fewpos) max_fp = std::max(max_fp, conv_fewpos_partial_bytes(g));
         size_t ysz = (size_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout * sizeof(float);
