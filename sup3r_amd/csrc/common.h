@@ -103,8 +103,8 @@ bool conv_mfma_bf16_out_ok(const ConvGeom& g);
 bool conv_mfma_persist_geom_ok(const ConvGeom& g);
 bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
                                  bool has_res);
-size_t conv_mfma_persist_image_bytes();
-int launch_conv_mfma_persist_pack(s3_ctx* ctx, const float* w, void* image);
+size_t conv_mfma_persist_image_bytes(const ConvGeom& g);
+int launch_conv_mfma_persist_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
 int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                              const void* image, const float* bias,
                              const void* res, void* y);

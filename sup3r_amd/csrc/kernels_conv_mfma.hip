@@ -587,7 +587,7 @@ size_t conv_mfma_packed_bytes(const ConvGeom& g, int precision) {
   if (precision == S3_PREC_BF16) {
     const int n_ct = (g.Cout + CT - 1) / CT;
     size_t b = (size_t)n_ct * g.k[0] * g.k[1] * g.k[2] * CT * CIN * 2;
-    if (conv_mfma_persist_geom_ok(g)) b += conv_mfma_persist_image_bytes();
+    if (conv_mfma_persist_geom_ok(g)) b += conv_mfma_persist_image_bytes(g);
     return b;
   }
   return 16;  // f32 mode reads the canonical weights directly
@@ -604,7 +604,7 @@ int launch_conv_mfma_pack(s3_ctx* ctx, const ConvGeom& g, int precision,
   hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, (unsigned short*)packed, taps, g.Cout, n_ct);
   S3_HIP(ctx, hipGetLastError());
   if (conv_mfma_persist_geom_ok(g))
-    return launch_conv_mfma_persist_pack(ctx, w, (char*)packed + total * 2);
+    return launch_conv_mfma_persist_pack(ctx, g, w, (char*)packed + total * 2);
   return S3_OK;
 }
 
@@ -613,7 +613,7 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
                          const void* res, void* y, ConvIO io) {
   if (precision == S3_PREC_BF16) {
     if (conv_mfma_persist_supported(ctx, g, io, res != nullptr))
-      return launch_conv_mfma_persist(ctx, g, x, (const char*)packed + (size_t)27 * CT * CIN * 2, bias, res, y);
+      return launch_conv_mfma_persist(ctx, g, x, (const char*)packed + (size_t)((g.Cout + CT - 1) / CT) * 27 * CT * CIN * 2, bias, res, y);
     // tile / wave configuration (SUP3R_AMD_MFMA_TILE overrides for A/B probes)
     static const int tile_env = getenv("SUP3R_AMD_MFMA_TILE") ? atoi(getenv("SUP3R_AMD_MFMA_TILE")) : -1;
     int tile = tile_env;

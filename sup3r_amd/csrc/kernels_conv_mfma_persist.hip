@@ -120,16 +120,16 @@ __device__ inline void wait_vm_n(int n) {
 // canonical fp32 w[tap][ci][co] -> bf16 LDS images [tap][rho 64][ci 64] with
 // rows in rho order and 16-B chunks swizzled by rho
 __global__ void pack_persist_kernel(const float* __restrict__ w,
-                                    unsigned short* __restrict__ out) {
-  const int total = 27 * 64 * 64;
+                                    unsigned short* __restrict__ out, int cout, int n_ct) {
+  const int total = n_ct * 27 * 64 * 64;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += gridDim.x * blockDim.x) {
-    const int ci = idx & 63, rho = (idx >> 6) & 63, tap = idx >> 12;
-    const int co = slab_row_cout(rho);
-    const float v = w[((size_t)tap * 64 + ci) * 64 + co];
+    const int ci = idx & 63, rho = (idx >> 6) & 63, tap = (idx >> 12) % 27, ct = (idx >> 12) / 27;
+    const int co = ct * 64 + slab_row_cout(rho);
+    const float v = co < cout ? w[((size_t)tap * 64 + ci) * cout + co] : 0.f;
     const unsigned u = pk_bf16(v, 0.f);
     const int slot = (ci >> 3) ^ ((rho >> 1) & 7);
-    out[((size_t)tap * 64 + rho) * 64 + slot * 8 + (ci & 7)] = (unsigned short)(u & 0xFFFFu);
+    out[(((size_t)ct * 27 + tap) * 64 + rho) * 64 + slot * 8 + (ci & 7)] = (unsigned short)(u & 0xFFFFu);
   }
 }
 
@@ -137,7 +137,9 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg,
     const float* __restrict__ bias, const unsigned short* __restrict__ res,
     unsigned short* __restrict__ y, ConvGeom g, int tiles0, int tiles1,
-    int tiles2, int n_tiles) {
+    int tiles2, int n_tiles, int ct) {
+  // ct: which 64-wide output-channel tile this launch computes (C_out > 64:
+  // one launch per tile; wimg / bias already point at the tile's image)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -256,7 +258,8 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
 
     // ---- prologue: biases (rho order), first halo, slabs of taps 0 and 1
     if (pt < 64)
-      reinterpret_cast<float*>(smem + BIAS_OFF)[pt] = bias ? bias[slab_row_cout(pt)] : 0.f;
+      reinterpret_cast<float*>(smem + BIAS_OFF)[pt] =
+          (bias && ct * 64 + slab_row_cout(pt) < g.Cout) ? bias[ct * 64 + slab_row_cout(pt)] : 0.f;
     dma_slab(0, 0);
     dma_slab(1, 1);
     if (h_cur < h_end) {
@@ -331,6 +334,18 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       b_addr[nf][ks] = (unsigned)(SLAB_OFF + rho * 128 + (((ks * 4 + kq) ^ ((rho >> 1) & 7)) << 4));
   }
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+  // this lane's two 8-channel chunks: block (bi, bj) and channel offset cc of
+  // the depth-to-space store (b = 1: bi = bj = 0, cc = the channel itself)
+  const int db = g.d2s, cpo = g.Cout / (db * db);
+  unsigned c_off[2];
+  bool c_ok[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int co = ct * 64 + h * 32 + kq * 8;
+    c_ok[h] = co < g.Cout;
+    const int blk = co / cpo;
+    c_off[h] = (unsigned)((((blk / db) * (g.O[1] * db) + blk % db) * g.O[2]) * cpo + co % cpo);
+  }
   WG_BARRIER();   // prologue
   // the matrix-core waves outrank the producer wave sharing their SIMD
   // (A/B in one run: 0.1228 -> 0.1055 ms per 64->64 conv launch)
@@ -348,18 +363,6 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     }
     int n, org0, org1, org2;
     tile_org(tile, n, org0, org1, org2);
-    // output addresses (element offsets within sample n)
-    unsigned e_dst[MFW];
-    bool e_ok[MFW];
-    const size_t e_base = (size_t)n * g.O[0] * g.O[1] * g.O[2] * 64;
-#pragma unroll
-    for (int m = 0; m < MFW; ++m) {
-      const int mf = mf0 + m;
-      const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1, o2 = org2 + frow;
-      e_ok[m] = o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2];
-      e_dst[m] = (unsigned)(((o0 * g.O[1] + o1) * g.O[2] + o2) * 64 + kq * 8);
-    }
-
     f32x4 acc[MFW][4];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
@@ -423,25 +426,47 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       }
     }
 
-    // ---- epilogue straight from the accumulators: residual rows first
-    // (all loads in flight together), then activation + add + 16-B stores
+    // ---- epilogue straight from the accumulators.  A lane owns two
+    // 8-channel chunks per position.  With a depth-to-space store (block b,
+    // C_out / b^2 channels per hi-res cell, a multiple of 8) a chunk is one
+    // hi-res cell's channels: block (i, j) = chunk / (C_out / b^2) lands at
+    // (o0 b + i, o1 b + j, o2).  Addresses are element offsets within sample n.
+    const size_t e_base = (size_t)n * g.O[0] * g.O[1] * g.O[2] * g.Cout;
+    // offset(m, h) = position part (m) + chunk part (h): both per-lane scalars
+    unsigned e_pos[MFW];
+    bool e_ok[MFW];
+#pragma unroll
+    for (int m = 0; m < MFW; ++m) {
+      const int mf = mf0 + m;
+      const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1, o2 = org2 + frow;
+      e_ok[m] = o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2];
+      e_pos[m] = (unsigned)(((o0 * db * (g.O[1] * db) + o1 * db) * g.O[2] + o2) * cpo);
+    }
+    auto chunk_off = [&](int m, int h, bool& ok) __attribute__((always_inline)) {
+      ok = c_ok[h] && e_ok[m];
+      return e_pos[m] + c_off[h];
+    };
+    // residual rows first (all loads in flight together), then activation +
+    // add + 16-B stores
     uint4 rres[MFW][2];
     if (res) {
 #pragma unroll
-      for (int m = 0; m < MFW; ++m) {
-        rres[m][0] = make_uint4(0, 0, 0, 0);
-        rres[m][1] = rres[m][0];
-        if (e_ok[m]) {
-          rres[m][0] = *reinterpret_cast<const uint4*>(res + e_base + e_dst[m]);
-          rres[m][1] = *reinterpret_cast<const uint4*>(res + e_base + e_dst[m] + 32);
+      for (int m = 0; m < MFW; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bool ok;
+          const unsigned off = chunk_off(m, h, ok);
+          rres[m][h] = make_uint4(0, 0, 0, 0);
+          if (ok) rres[m][h] = *reinterpret_cast<const uint4*>(res + e_base + off);
         }
-      }
     }
 #pragma unroll
     for (int m = 0; m < MFW; ++m) {
-      if (!e_ok[m]) continue;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+        bool ok;
+        const unsigned off = chunk_off(m, h, ok);
+        if (!ok) continue;
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -459,7 +484,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
         uint4 o;
         o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]);
         o.z = pk_bf16(v[4], v[5]); o.w = pk_bf16(v[6], v[7]);
-        *reinterpret_cast<uint4*>(y + e_base + e_dst[m] + h * 32) = o;
+        *reinterpret_cast<uint4*>(y + e_base + off) = o;
       }
     }
     WG_BARRIER();   // next halo visible
@@ -469,7 +494,9 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
 }  // namespace
 
 bool conv_mfma_persist_geom_ok(const ConvGeom& g) {
-  if (g.Cin != 64 || g.Cout != 64 || g.d2s != 1) return false;
+  if (g.Cin != 64 || g.Cout % 8 != 0 || g.Cout < 64 || g.d2s < 1) return false;
+  if (g.d2s > 1 && (g.Cout % (g.d2s * g.d2s) != 0 || (g.Cout / (g.d2s * g.d2s)) % 8 != 0))
+    return false;
   if (g.pad_mode != S3_PAD_REFLECT) return false;
   // the epilogue's branch-free max(v, alpha v)
   if (g.act == S3_ACT_LEAKY && !(g.alpha >= 0.f && g.alpha <= 1.f)) return false;
@@ -477,7 +504,7 @@ bool conv_mfma_persist_geom_ok(const ConvGeom& g) {
     if (g.k[d] != 3 || g.s[d] != 1) return false;
   // 32-bit element offsets inside one sample
   return (int64_t)g.D[0] * g.D[1] * g.D[2] * 64 < (int64_t)1 << 31 &&
-         (int64_t)g.O[0] * g.O[1] * g.O[2] * 64 < (int64_t)1 << 31;
+         (int64_t)g.O[0] * g.O[1] * g.O[2] * g.Cout < (int64_t)1 << 31;
 }
 
 bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
@@ -487,16 +514,20 @@ bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io
   if (off && atoi(off)) return false;
   if (!io.in_bf16 || !io.out_bf16 || (has_res && !io.res_bf16)) return false;
   if (!conv_mfma_persist_geom_ok(g)) return false;
+  if (has_res && g.d2s != 1) return false;
   const int64_t tiles = (int64_t)g.N * ((g.O[0] + TS0 - 1) / TS0) *
                         ((g.O[1] + TS1 - 1) / TS1) * ((g.O[2] + TS2 - 1) / TS2);
   return tiles >= ctx->num_cu;
 }
 
-size_t conv_mfma_persist_image_bytes() { return (size_t)27 * 64 * 64 * 2; }
+size_t conv_mfma_persist_image_bytes(const ConvGeom& g) {
+  return (size_t)((g.Cout + 63) / 64) * 27 * 64 * 64 * 2;
+}
 
-int launch_conv_mfma_persist_pack(s3_ctx* ctx, const float* w, void* image) {
-  hipLaunchKernelGGL(pack_persist_kernel, dim3(108), dim3(256), 0, ctx->stream,
-                     w, (unsigned short*)image);
+int launch_conv_mfma_persist_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image) {
+  const int n_ct = (g.Cout + 63) / 64;
+  hipLaunchKernelGGL(pack_persist_kernel, dim3(108 * n_ct), dim3(256), 0, ctx->stream,
+                     w, (unsigned short*)image, g.Cout, n_ct);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -516,10 +547,12 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
   const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
   int grid = ctx->num_cu;
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
-                     (const unsigned short*)x, (const char*)image, bias,
-                     (const unsigned short*)res, (unsigned short*)y, g, tiles0,
-                     tiles1, tiles2, n_tiles);
+  const int n_ct = (g.Cout + 63) / 64;
+  for (int ct = 0; ct < n_ct; ++ct)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
+                       (const unsigned short*)x, (const char*)image + (size_t)ct * 27 * 8192, bias,
+                       (const unsigned short*)res, (unsigned short*)y, g, tiles0,
+                       tiles1, tiles2, n_tiles, ct);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

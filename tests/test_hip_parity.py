@@ -192,6 +192,36 @@ def test_persistent_trunk_kernel_matches_tile_kernel_and_oracle():
     assert np.abs(y - y_tile).max() / scale < 1e-2
 
 
+def test_persistent_kernel_cout_tiles_and_depth_to_space():
+    """64 -> 200 with the depth-to-space (b = 5) store on the persistent
+    kernel: one launch per 64-wide output-channel tile (the 4th holds 8 valid
+    channels), a lane's 8-channel chunk = one hi-res cell.  Ragged in s1 / s2 /
+    t; against the oracle (bf16 bound) and the tile kernel (same operands)."""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(13)
+    spec = pcc(3, 64) + pcc(3, 64) + pcc(3, 200, act=False) + \
+        [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
+         {'alpha': 0.2, 'class': 'LeakyReLU'}] + pcc(3, 2, act=False)
+    shape = (6, 15, 18, 52, 4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    net = _hip_net(spec, ref.weights, precision='bf16')
+    ph = net.plan(shape, training=False)
+    classes = [ph.op_kernel_class(i) for i in range(len(ph.plan.ops))]
+    assert classes.count(2) >= 2, classes
+    y = net(x).cpu().numpy()
+    assert y.shape == (6, 75, 90, 52, 2)
+    scale = max(1.0, np.abs(y_ref).max())
+    assert np.abs(y - y_ref).max() / scale < 3e-2
+    os.environ['SUP3R_AMD_NO_PERSIST'] = '1'
+    try:
+        y_tile = net(x).cpu().numpy()
+    finally:
+        del os.environ['SUP3R_AMD_NO_PERSIST']
+    assert np.abs(y - y_tile).max() / scale < 1e-2
+
+
 def test_gather_mfma_conv_strided_valid_vs_oracle():
     """Discriminator-style stack (valid padding, strides 1 / 2, channels 32 /
     64 / 96) on the general gather-MFMA kernels in bf16 mode: forward, data
