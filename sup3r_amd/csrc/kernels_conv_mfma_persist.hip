@@ -133,6 +133,9 @@ __global__ void pack_persist_kernel(const float* __restrict__ w,
   }
 }
 
+// NFV: N fragments computed (4 = all 64 channels of the tile; 2 = the first
+// 32, for a last tile holding <= 32 valid channels)
+template <int NFV>
 __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg,
     const float* __restrict__ bias, const unsigned short* __restrict__ res,
@@ -363,9 +366,9 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     }
     int n, org0, org1, org2;
     tile_org(tile, n, org0, org1, org2);
-    f32x4 acc[MFW][4];
+    f32x4 acc[MFW][NFV];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
+    for (int nf = 0; nf < NFV; ++nf) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (nf * 16 + kq * 4) * 4);
 #pragma unroll
       for (int m = 0; m < MFW; ++m) acc[m][nf] = bv;
@@ -387,26 +390,26 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
 #pragma unroll
         for (int tc = 0; tc < 3; ++tc) {
           // ring slot of tap = (ta*9 + tb*3 + tc) % 3 = tc
-          bf16x8 bfr[4];
+          bf16x8 bfr[NFV];
           // ---- k-step 0: prefetched A, fresh B
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf)
+          for (int nf = 0; nf < NFV; ++nf)
             bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][0] + tc * 8192);
 #pragma unroll
           for (int m = 0; m < MFW; ++m)
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < NFV; ++nf)
               acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nf], apre[m], acc[m][nf], 0, 0, 0);
           // ---- k-step 1
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf)
+          for (int nf = 0; nf < NFV; ++nf)
             bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][1] + tc * 8192);
 #pragma unroll
           for (int m = 0; m < MFW; ++m) {
             const bf16x8 afr = *reinterpret_cast<const bf16x8*>(
                 smem + a_addr[tc][1] + ta_off + ((m + tb) * H2) * 128);
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < NFV; ++nf)
               acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nf], afr, acc[m][nf], 0, 0, 0);
           }
           // ---- A fragments of the next tap (k-step 0)
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       e_pos[m] = (unsigned)(((o0 * db * (g.O[1] * db) + o1 * db) * g.O[2] + o2) * cpo);
     }
     auto chunk_off = [&](int m, int h, bool& ok) __attribute__((always_inline)) {
-      ok = c_ok[h] && e_ok[m];
+      ok = c_ok[h] && e_ok[m] && 2 * h < NFV;
       return e_pos[m] + c_off[h];
     };
     // residual rows first (all loads in flight together), then activation +
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
           // branch-free activation: max(v, slope v) is identity (slope 1),
           // ReLU (0) or LeakyReLU (0 <= alpha <= 1); a per-element test of
           // the kind compiles to two scalar branches per value
-          const float a = acc[m][2 * h + (q >> 2)][q & 3];
+          const float a = acc[m][(2 * h + (q >> 2)) % NFV][q & 3];
           v[q] = fmaxf(a, slope * a);
         }
         if (res) {
@@ -535,10 +538,11 @@ int launch_conv_mfma_persist_pack(s3_ctx* ctx, const ConvGeom& g, const float* w
 int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                              const void* image, const float* bias,
                              const void* res, void* y) {
-  auto kern = conv3_mfma_persist_kernel;
   static bool attr_set = false;
   if (!attr_set) {
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
@@ -548,11 +552,14 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
   int grid = ctx->num_cu;
   if (grid > n_tiles) grid = n_tiles;
   const int n_ct = (g.Cout + 63) / 64;
-  for (int ct = 0; ct < n_ct; ++ct)
+  for (int ct = 0; ct < n_ct; ++ct) {
+    // a last tile with <= 32 valid channels computes two N fragments only
+    auto kern = g.Cout - ct * 64 <= 32 ? conv3_mfma_persist_kernel<2> : conv3_mfma_persist_kernel<4>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
                        (const unsigned short*)x, (const char*)image + (size_t)ct * 27 * 8192, bias,
                        (const unsigned short*)res, (unsigned short*)y, g, tiles0,
                        tiles1, tiles2, n_tiles, ct);
+  }
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
