@@ -86,6 +86,8 @@ def main():
                     help='lo-res chunks per GPU per step')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity-mode', action='store_true',
+                    help='skip the extra fp32 parity-mode measurement')
     ap.add_argument('--dump-ops', default=None,
                     help='write per-op mean ms of the timed region here')
     args = ap.parse_args()
@@ -202,6 +204,37 @@ def main():
                                 'x'.join(str(v) for v in
                                          ph.plan.tensors[op['out']]),
                                 int(ph.op_is_mfma(i)), ms[i]))
+    if world == 1 and args.precision == 'bf16' and not args.no_parity_mode:
+        # the same workload in the exact-fp32 parity mode (the mode that owns
+        # the L-inf < 1e-3 claim of tests/test_hip_parity.py), untimed by the
+        # contract, reported beside the headline
+        net32 = Network(spec, name='generator', device=dev, precision='f32')
+        net32.set_weights(net.weights)
+        ph32 = net32.plan(shape, training=False)
+        for _ in range(2):
+            ph32.forward(x, out=out)
+        torch.cuda.synchronize()
+        ph32.profile_begin(5)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ph32.forward(x, out=out)
+        torch.cuda.synchronize()
+        dt32 = (time.perf_counter() - t1) / 5
+        _, ms32 = ph32.profile_end()
+        body32 = [i for i, op in enumerate(ph32.plan.ops)
+                  if ph32.op_is_mfma(i) and op['cout'] == 64
+                  and ph32.plan.tensors[op['out']][1:4] == [16, 16, 288]]
+        b32 = float(np.mean([ms32[i] for i in body32]))
+        a32 = flop / (b32 * 1e-3) / 1e12
+        result['parity_mode'] = {
+            'dtype': 'f32', 'value': B / dt32, 'unit': 'samples/s',
+            'ms_per_step': dt32 * 1e3,
+            'kernel': 'conv3_mfma_kernel (v_mfma_f32_16x16x4_f32, exact fp32)',
+            'achieved': a32, 'peak': PEAK_TFLOPS['f32'], 'unit_roofline':
+            'TFLOP/s', 'frac': a32 / PEAK_TFLOPS['f32'],
+            'tolerance': 'L-inf < 1e-3 vs the oracle at full C2 size '
+                         '(tests/test_hip_parity.py); bf16 mode: 3e-2 rel.'}
+        del ph32, net32
     if world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(spec)
         result['speedup_vs_cpu_baseline'] = \
