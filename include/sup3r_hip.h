@@ -194,6 +194,19 @@ int s3_fill(s3_ctx* ctx, float* dst, int64_t n, float value);
  * NaN count) per slab of positions; the caller folds the 64 slabs. */
 int s3_chunk_stats(s3_ctx* ctx, const float* x, int n_chunks,
                    int64_t pos_per_chunk, int c, float* partial);
+/* placement of a cropped hi-res chunk straight into the caller's host array
+ * (the `out[hr_slice] = chunk` of the forward pass, sup3r/pipeline/
+ * forward_pass.py:582-673 + the writers' window placement): one pitched
+ * device -> host DMA of a contiguous (d0, d1, row_elems) device block into the
+ * window dst_host[i * dst_stride0 + j * dst_stride1 + 0..row_elems) (strides
+ * in elements).  The host array must be registered once (s3_host_register)
+ * for the copy to be asynchronous; `stream` = a hipStream_t or NULL for the
+ * context stream. */
+int s3_host_register(s3_ctx* ctx, void* ptr, size_t bytes);
+int s3_host_unregister(s3_ctx* ctx, void* ptr);
+int s3_d2h_window(s3_ctx* ctx, const float* src, float* dst_host, int64_t d0,
+                  int64_t d1, int64_t row_elems, int64_t dst_stride0,
+                  int64_t dst_stride1, void* stream);
 
 /* ---- batch transform on the device ----------------------
  * replaces the host numpy of SingleBatchQueue.transform

@@ -29,6 +29,7 @@ EXPORTS = [
     's3_plan_op_is_mfma', 's3_loss_content', 's3_loss_content_masked', 's3_loss_rel_bce',
     's3_copy_channels', 's3_affine_channels', 's3_fill',
     's3_coarsen', 's3_gaussian_smooth', 's3_chunk_stats',
+    's3_host_register', 's3_host_unregister', 's3_d2h_window',
     's3_comm_unique_id', 's3_comm_init', 's3_params_allreduce_grads',
     's3_allreduce_sum', 's3_version',
 ]
@@ -111,6 +112,9 @@ def lib():
         's3_affine_channels': (i32, [vp, vp, vp, i32, i64, pf, pf]),
         's3_fill': (i32, [vp, vp, i64, f32]),
         's3_chunk_stats': (i32, [vp, vp, i32, i64, i32, vp]),
+        's3_host_register': (i32, [vp, vp, C.c_size_t]),
+        's3_host_unregister': (i32, [vp, vp]),
+        's3_d2h_window': (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
         's3_coarsen': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                              vp]),
         's3_gaussian_smooth': (i32, [vp, vp, i32, i32, i32, i32, i32, pf, i32,

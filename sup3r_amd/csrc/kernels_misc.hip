@@ -717,6 +717,37 @@ extern "C" int s3_chunk_stats(s3_ctx* ctx, const float* x, int n_chunks,
   return S3_OK;
 }
 
+// ---- direct device -> host placement of a cropped chunk -------------------
+extern "C" int s3_host_register(s3_ctx* ctx, void* ptr, size_t bytes) {
+  if (!ctx || !ptr) return S3_EINVAL;
+  S3_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return S3_OK;
+}
+
+extern "C" int s3_host_unregister(s3_ctx* ctx, void* ptr) {
+  if (!ctx || !ptr) return S3_EINVAL;
+  S3_HIP(ctx, hipHostUnregister(ptr));
+  return S3_OK;
+}
+
+extern "C" int s3_d2h_window(s3_ctx* ctx, const float* src, float* dst_host, int64_t d0,
+                             int64_t d1, int64_t row_elems, int64_t dst_stride0,
+                             int64_t dst_stride1, void* stream) {
+  if (!ctx || !src || !dst_host) return S3_EINVAL;
+  if (d0 < 1 || d1 < 1 || row_elems < 1 || dst_stride1 < row_elems ||
+      dst_stride0 % dst_stride1 != 0 || dst_stride0 / dst_stride1 < d1)
+    S3_FAIL(ctx, S3_EINVAL, "d2h_window: the destination is not a pitched (d0, d1, row) window");
+  hipMemcpy3DParms p = {};
+  const size_t row_bytes = (size_t)row_elems * sizeof(float);
+  p.srcPtr = make_hipPitchedPtr(const_cast<float*>(src), row_bytes, row_bytes, (size_t)d1);
+  p.dstPtr = make_hipPitchedPtr(dst_host, (size_t)dst_stride1 * sizeof(float), row_bytes,
+                                (size_t)(dst_stride0 / dst_stride1));
+  p.extent = make_hipExtent(row_bytes, (size_t)d1, (size_t)d0);
+  p.kind = hipMemcpyDeviceToHost;
+  S3_HIP(ctx, hipMemcpy3DAsync(&p, stream ? (hipStream_t)stream : ctx->stream));
+  return S3_OK;
+}
+
 extern "C" int s3_fill(s3_ctx* ctx, float* dst, int64_t n, float value) {
   if (!ctx) return S3_EINVAL;
   return launch_fill(ctx, dst, n, value);

@@ -18,6 +18,8 @@ def main():
     ap.add_argument('--domain', default='80,80,192')
     ap.add_argument('--batched', action='store_true')
     ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--threads', type=int, default=16)
+    ap.add_argument('--direct', action='store_true')
     args = ap.parse_args()
     import torch
     from sup3r_amd import ChunkSlicer, ForwardPass, Sup3rGan
@@ -42,7 +44,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if args.batched:
-        n = fwp.run_batched(domain, out=out, batch=args.batch)
+        n = fwp.run_batched(domain, out=out, batch=args.batch,
+                            n_host_threads=args.threads,
+                            direct_placement=args.direct)
     else:
         n = fwp.run(domain, out=out)
     torch.cuda.synchronize()
