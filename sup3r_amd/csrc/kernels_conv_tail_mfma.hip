@@ -15,11 +15,14 @@
 // kq*4 .. kq*4+3 of one position, so C_out <= 4 stores one float2/float4 per
 // position, contiguous across the 16 lanes of a fragment.
 //
-// Persistent workgroups (one per CU, 8 waves) walk 4 x 8 x 64-position tiles
-// with a DOUBLE-BUFFERED halo (2 x 62 KB of LDS): while the matrix cores chew
-// tile i, the halo of tile i+1 arrives by LDS-DMA (global_load_lds_dwordx4:
+// Persistent workgroups (one per CU) walk 4 x 8 x 64-position tiles with a
+// DOUBLE-BUFFERED halo (2 x 62 KB of LDS) and two kinds of waves: 8 compute
+// waves (ds_read_b128 + MFMA + stores — they never execute a load, so they
+// never wait on vmcnt, and their stores are fire-and-forget) and 4 staging
+// waves that bring in the halo of tile i+1 by LDS-DMA (global_load_lds_dwordx4:
 // lane l of a wave-instruction fills LDS cell hp0 + l from its own, reflect-
-// resolved global address — no VGPR staging, no exposed load latency).
+// resolved global address — no VGPR staging) while tile i is on the matrix
+// cores.  One raw s_barrier per tile hands the buffers over.
 #include "common.h"
 
 namespace {
@@ -32,7 +35,9 @@ typedef float hf32x2 __attribute__((ext_vector_type(2)));
 constexpr int T0 = 4, T1 = 8, T2 = 64;
 constexpr int H0 = T0 + 2, H1 = T1 + 2, H2 = T2 + 2;
 constexpr int HP = H0 * H1 * H2;                 // 3960 cells
-constexpr int NTH = 512;
+constexpr int NCW = 8;                           // compute (MFMA + store) waves
+constexpr int NDW = 4;                           // staging (LDS-DMA) waves
+constexpr int NTH = (NCW + NDW) * 64;            // 768
 constexpr int NDMA = (HP + 63) / 64;             // 62 wave-instructions per halo
 constexpr int BUF_BYTES = NDMA * 64 * 16;        // 63,488 (tail lanes land in the pad)
 constexpr int GROUPS = T0 * T1 * (T2 / 16);      // 128 fragments of 16 positions
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
     int n, org0, org1, org2;
     tile_org(tile, n, org0, org1, org2);
     const unsigned short* xn = x + (size_t)n * D0 * D1 * D2 * 8;
-    for (int i = wave; i < NDMA; i += NTH / 64) {
+    for (int i = wave - NCW; i < NDMA; i += NDW) {
       int hp = i * 64 + lane;
       if (hp > HP - 1) hp = HP - 1;              // pad lanes re-read the last cell
       int h = hp;
@@ -115,13 +120,27 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
   for (int r = 0; r < 4; ++r) bv[r] = (bias && kq * 4 + r < Cout) ? bias[kq * 4 + r] : 0.f;
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
 
+  // raw workgroup barrier: the hand-over is ordered by the staging waves'
+  // own vmcnt(0) before it ("memory": no compiler motion across it)
+#define TAIL_BARRIER() asm volatile("s_barrier" ::: "memory")
   int cur = 0;
-  if ((int)blockIdx.x < n_tiles) stage(blockIdx.x, 0);
-  __syncthreads();     // (carries the vmcnt(0) of the LDS-DMA)
-
+  if (wave >= NCW) {
+    // ---------------------------------------------------- staging waves
+    if ((int)blockIdx.x < n_tiles) stage(blockIdx.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TAIL_BARRIER();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      const int next = tile + gridDim.x;
+      if (next < n_tiles) stage(next, cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TAIL_BARRIER();   // next halo landed, this one free
+      cur ^= 1;
+    }
+    return;
+  }
+  // ------------------------------------------------------ compute waves
+  TAIL_BARRIER();
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int next = tile + gridDim.x;
-    if (next < n_tiles) stage(next, cur ^ 1);
     int n, org0, org1, org2;
     tile_org(tile, n, org0, org1, org2);
     const char* halo = smem + cur * BUF_BYTES;
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
     // independent accumulator chains keep the matrix pipe issuing (one chain
     // of 7 dependent MFMAs would wait out the full MFMA latency 7 times)
     constexpr int GU = 4;
-    for (int g0 = wave * GU; g0 < GROUPS; g0 += (NTH / 64) * GU) {
+    for (int g0 = wave * GU; g0 < GROUPS; g0 += NCW * GU) {
       unsigned base[GU];
       f32x4 acc[GU];
 #pragma unroll
@@ -148,19 +167,41 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
           const bf16x8 xf = *reinterpret_cast<const bf16x8*>(halo + base[j] + toff[s]);
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf, acc[j], 0, 0, 0);
         }
+      if (Cout == 2) {
+        // the four fragments are the 64 consecutive t positions of one
+        // (s0, s1) row and lane (p, kq = 0) of fragment j holds position
+        // 16 j + p: gather them so that lane L stores position L — one
+        // full-wave 512-B store instead of four quarter-wave ones
+        const int src = (lane & 15) << 2;             // byte index of lane p (kq = 0)
+        float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-      for (int j = 0; j < GU; ++j) {
-        const int gi = g0 + j;
-        const int tq = gi % (T2 / 16);
+        for (int j = 0; j < GU; ++j) {
+          const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
+              src, __builtin_bit_cast(int, act_sel(acc[j][0], slope))));
+          const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(
+              src, __builtin_bit_cast(int, act_sel(acc[j][1], slope))));
+          if ((lane >> 4) == j) { v0 = a0; v1 = a1; }
+        }
+        const int gi = g0;
         const int r1 = (gi / (T2 / 16)) % T1;
         const int r0 = gi / ((T2 / 16) * T1);
-        const int o0 = org0 + r0, o1 = org1 + r1, o2 = org2 + tq * 16 + p;
-        if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && kq * 4 < Cout) {
-          float* yp = y + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * Cout + kq * 4;
-          if (Cout == 2) {
-            *reinterpret_cast<float2*>(yp) =
-                make_float2(act_sel(acc[j][0], slope), act_sel(acc[j][1], slope));
-          } else {
+        const int o0 = org0 + r0, o1 = org1 + r1, o2 = org2 + lane;
+        if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2]) {
+          float* yp = y + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * 2;
+          // (the model output is never re-read on the device)
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          __builtin_nontemporal_store((f32x2){v0, v1}, reinterpret_cast<f32x2*>(yp));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < GU; ++j) {
+          const int gi = g0 + j;
+          const int tq = gi % (T2 / 16);
+          const int r1 = (gi / (T2 / 16)) % T1;
+          const int r0 = gi / ((T2 / 16) * T1);
+          const int o0 = org0 + r0, o1 = org1 + r1, o2 = org2 + tq * 16 + p;
+          if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && kq * 4 < Cout) {
+            float* yp = y + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * Cout + kq * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (kq * 4 + r < Cout) yp[r] = act_sel(acc[j][r], slope);
@@ -168,9 +209,10 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
         }
       }
     }
-    __syncthreads();   // next halo landed (vmcnt(0)), this one free
+    TAIL_BARRIER();
     cur ^= 1;
   }
+#undef TAIL_BARRIER
 }
 
 }  // namespace
