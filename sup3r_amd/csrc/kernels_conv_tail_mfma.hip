@@ -23,6 +23,8 @@
 // lane l of a wave-instruction fills LDS cell hp0 + l from its own, reflect-
 // resolved global address — no VGPR staging) while tile i is on the matrix
 // cores.  One raw s_barrier per tile hands the buffers over.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -49,6 +51,10 @@ __device__ inline unsigned pk2(float a, float b) {
 }
 __device__ inline float act_sel(float v, float slope) { return v > 0.f ? v : slope * v; }
 
+// BAND (C_out == 2 only): the 16 MFMA rows are 8 consecutive output positions
+// x 2 channels instead of 2 channels + 14 rows of padding — see the compute
+// loop.
+template <bool BAND>
 __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
     const unsigned short* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ bias, float* __restrict__ y, ConvGeom g,
@@ -95,24 +101,48 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
     }
   };
 
-  // ---- filter fragments: lane (row = co = lane & 15, k-group kq) of k-step s
-  // holds w[tap 4s+kq][ci 0..7][co] as bf16 (zero beyond 27 taps / C_out)
-  bf16x8 wf[KS];
+  // ---- filter fragments (plain): lane (row = co = lane & 15, k-group kq) of
+  // k-step s holds w[tap 4s+kq][ci 0..7][co] as bf16 (zero beyond 27 taps / C_out)
+  constexpr int NWF = BAND ? 27 : KS;
+  bf16x8 wf[NWF];
   unsigned toff[KS];       // byte offset of tap 4s+kq in the halo (B operand)
+  if constexpr (!BAND) {
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int tap = 4 * s + kq;
-    unsigned u[4] = {0u, 0u, 0u, 0u};
-    if (tap < 27 && p < Cout) {
-      const float* wp = w + (size_t)tap * 8 * Cout + p;
+    for (int s = 0; s < KS; ++s) {
+      const int tap = 4 * s + kq;
+      unsigned u[4] = {0u, 0u, 0u, 0u};
+      if (tap < 27 && p < Cout) {
+        const float* wp = w + (size_t)tap * 8 * Cout + p;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) u[e] = pk2(wp[(2 * e) * Cout], wp[(2 * e + 1) * Cout]);
+        for (int e = 0; e < 4; ++e) u[e] = pk2(wp[(2 * e) * Cout], wp[(2 * e + 1) * Cout]);
+      }
+      uint4 uv = make_uint4(u[0], u[1], u[2], u[3]);
+      wf[s] = __builtin_bit_cast(bf16x8, uv);
+      const int tt = tap < 27 ? tap : 0;
+      const int a = tt / 9, b = tt / 3 % 3, c = tt % 3;
+      toff[s] = (unsigned)(((a * H1 + b) * H2 + c) * 16);
     }
-    uint4 uv = make_uint4(u[0], u[1], u[2], u[3]);
-    wf[s] = __builtin_bit_cast(bf16x8, uv);
-    const int tt = tap < 27 ? tap : 0;
-    const int a = tt / 9, b = (tt / 3) % 3, c = tt % 3;
-    toff[s] = (unsigned)(((a * H1 + b) * H2 + c) * 16);
+  } else {
+    // BAND: MFMA row i = (delta = i >> 1, co = i & 1) is output position
+    // base + delta, column j is base position 8 j; per (a, b) the contraction
+    // runs over the 12 cells e = 0..11 after the base (10 are touched):
+    // A[(delta, co)][(e, ci)] = w[a, b, c = e - delta][ci][co] for 0 <= c <= 2,
+    // else 0.  27 fragments = 9 (a, b) x 3 k-steps of 4 cells, 108 VGPRs;
+    // 27 MFMAs per 128 positions instead of 56.
+    const int delta = p >> 1, co = p & 1;
+#pragma unroll
+    for (int f = 0; f < 27; ++f) {
+      const int ab = f / 3, s = f % 3;
+      const int c = 4 * s + kq - delta;
+      unsigned u[4] = {0u, 0u, 0u, 0u};
+      if (c >= 0 && c <= 2) {
+        const float* wp = w + (size_t)(ab * 3 + c) * 8 * 2 + co;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = pk2(wp[(2 * e) * 2], wp[(2 * e + 1) * 2]);
+      }
+      uint4 uv = make_uint4(u[0], u[1], u[2], u[3]);
+      wf[f] = __builtin_bit_cast(bf16x8, uv);
+    }
   }
   // bias of this lane's four channels
   float bv[4];
@@ -144,6 +174,52 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
     int n, org0, org1, org2;
     tile_org(tile, n, org0, org1, org2);
     const char* halo = smem + cur * BUF_BYTES;
+    if constexpr (BAND) {
+      // 16 fragment sets of 128 positions (two s1 rows x 64 t); a compute wave
+      // owns sets `wave` and `wave + 8`, each accumulated in two chains (four
+      // independent MFMA chains per wave).  Column j = lane & 15: s1 row
+      // j >> 3, base t = (j & 7) * 8; k-group kq reads cell e = 4 s + kq.
+      const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
+      unsigned base[2];
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = wave + u * NCW;
+        const int r0 = q >> 2, r1 = 2 * (q & 3) + (p >> 3);
+        base[u] = (unsigned)(((r0 * H1 + r1) * H2 + (p & 7) * 8 + kq) * 16);
+        acc[u][0] = (f32x4){b0, b1, b0, b1};
+        acc[u][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int f = 0; f < 27; ++f) {
+        const int ab = f / 3, s = f % 3;
+        const unsigned off = (unsigned)((((ab / 3) * H1 + ab % 3) * H2 + 4 * s) * 16);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(halo + base[u] + off);
+          acc[u][f & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], xf, acc[u][f & 1], 0, 0, 0);
+        }
+      }
+      // lane (j, kq) holds positions base t + 2 kq, + 1 x channels 0, 1: one
+      // float4; a wave stores 1 KB contiguous per s1 row pair
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = wave + u * NCW;
+        const int o0 = org0 + (q >> 2), o1 = org1 + 2 * (q & 3) + (p >> 3);
+        const int o2 = org2 + (p & 7) * 8 + 2 * kq;
+        if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2]) {
+          float* yp = y + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * 2;
+          const f32x4 t = acc[u][0] + acc[u][1];
+          const float v0 = act_sel(t[0], slope), v1 = act_sel(t[1], slope),
+                      v2 = act_sel(t[2], slope), v3 = act_sel(t[3], slope);
+          if (o2 + 1 < g.O[2]) {
+            __builtin_nontemporal_store((f32x4){v0, v1, v2, v3}, reinterpret_cast<f32x4*>(yp));
+          } else {
+            yp[0] = v0; yp[1] = v1;
+          }
+        }
+      }
+    } else {
     // ---- 128 fragments of 16 positions, 16 per wave, four at a time: four
     // independent accumulator chains keep the matrix pipe issuing (one chain
     // of 7 dependent MFMAs would wait out the full MFMA latency 7 times)
@@ -209,6 +285,7 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
         }
       }
     }
+    }   // !BAND
     TAIL_BARRIER();
     cur ^= 1;
   }
@@ -233,13 +310,17 @@ int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
   const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
   static bool attr_set = false;
   if (!attr_set) {
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail_mfma_kernel),
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail_mfma_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail_mfma_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES));
     attr_set = true;
   }
   int grid = ctx->num_cu;
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(conv_tail_mfma_kernel, dim3(grid), dim3(NTH), 2 * BUF_BYTES, ctx->stream,
+  const bool band = g.Cout == 2 && !getenv("SUP3R_AMD_NO_TAIL_BAND");
+  auto kern = band ? conv_tail_mfma_kernel<true> : conv_tail_mfma_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), 2 * BUF_BYTES, ctx->stream,
                      (const unsigned short*)x, w, bias, y, g, tiles0, tiles1, tiles2, n_tiles);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
