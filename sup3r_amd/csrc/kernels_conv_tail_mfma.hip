@@ -74,30 +74,39 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
     o0 = (tr % tiles0) * T0; tr /= tiles0;
     n = tr;
   };
-  // halo of `tile` -> buffer `buf`: 62 wave-instructions shared by the 8 waves
+  // halo of `tile` -> buffer `buf`, by the 4 staging waves.  One LDS-DMA
+  // wave-instruction per halo row (c0, c1) brings its first 64 cells: the lane
+  // = the cell's t index, so the per-lane part of the address (reflect of t)
+  // is computed once per tile and the row part is scalar.  The two remaining
+  // cells of each of the 60 rows go through registers (120 lanes, one 16-B
+  // load + ds_write each).
   auto stage = [&](int tile, int buf) __attribute__((always_inline)) {
     int n, org0, org1, org2;
     tile_org(tile, n, org0, org1, org2);
     const unsigned short* xn = x + (size_t)n * D0 * D1 * D2 * 8;
-    for (int i = wave - NCW; i < NDMA; i += NDW) {
-      int hp = i * 64 + lane;
-      if (hp > HP - 1) hp = HP - 1;              // pad lanes re-read the last cell
-      int h = hp;
-      const int c2 = h % H2; h /= H2;
-      const int c1 = h % H1; h /= H1;
-      const int c0 = h;
-      int i0 = s3_reflect(org0 + c0 - g.lo[0], D0);
-      int i1 = s3_reflect(org1 + c1 - g.lo[1], D1);
-      int i2 = s3_reflect(org2 + c2 - g.lo[2], D2);
-      // ragged tiles: keep addresses legal (results are masked at the store)
-      i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
-      i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
-      i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
+    auto clampi = [](int i, int d) { return i < 0 ? 0 : (i > d - 1 ? d - 1 : i); };
+    // (ragged tiles: clamped addresses stay legal; results are masked at the store)
+    const int i2 = clampi(s3_reflect(org2 + lane - g.lo[2], D2), D2);
+    char* bufp = smem + buf * BUF_BYTES;
+    const int sw = wave - NCW;
+    for (int row = sw; row < H0 * H1; row += NDW) {
+      const int c0 = row / H1, c1 = row % H1;
+      const int i0 = clampi(s3_reflect(org0 + c0 - g.lo[0], D0), D0);
+      const int i1 = clampi(s3_reflect(org1 + c1 - g.lo[1], D1), D1);
       const unsigned short* src = xn + (((size_t)i0 * D1 + i1) * D2 + i2) * 8;
-      char* dst = smem + buf * BUF_BYTES + i * 1024;     // wave-uniform; + lane*16 by the DMA
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,
-          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+          (__attribute__((address_space(3))) void*)(bufp + row * (H2 * 16)), 16, 0, 0);
+    }
+    const int st = (tid - NCW * 64);               // 0 .. 255
+    if (st < 2 * H0 * H1) {
+      const int row = st >> 1, c2 = 64 + (st & 1);
+      const int c0 = row / H1, c1 = row % H1;
+      const int i0 = clampi(s3_reflect(org0 + c0 - g.lo[0], D0), D0);
+      const int i1 = clampi(s3_reflect(org1 + c1 - g.lo[1], D1), D1);
+      const int j2 = clampi(s3_reflect(org2 + c2 - g.lo[2], D2), D2);
+      const uint4 v = *reinterpret_cast<const uint4*>(xn + (((size_t)i0 * D1 + i1) * D2 + j2) * 8);
+      *reinterpret_cast<uint4*>(bufp + (row * H2 + c2) * 16) = v;
     }
   };
 
@@ -156,13 +165,21 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
   int cur = 0;
   if (wave >= NCW) {
     // ---------------------------------------------------- staging waves
+    // the pad cells behind each halo are read (against zero filter taps) by
+    // the last fragments: keep them finite
+    {
+      const int st = tid - NCW * 64;
+      if (st < 2 * (NDMA * 64 - HP))
+        *reinterpret_cast<uint4*>(smem + (st & 1) * BUF_BYTES + (HP + (st >> 1)) * 16) =
+            make_uint4(0, 0, 0, 0);
+    }
     if ((int)blockIdx.x < n_tiles) stage(blockIdx.x, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     TAIL_BARRIER();
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       const int next = tile + gridDim.x;
       if (next < n_tiles) stage(next, cur ^ 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       TAIL_BARRIER();   // next halo landed, this one free
       cur ^= 1;
     }
