@@ -122,7 +122,7 @@ bool conv_gconv_dgrad_supported(const ConvGeom& g, int precision);
 size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad);
 int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad);
 int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
-                     const float* bias, const float* res, float* y);
+                     const float* bias, const float* res, void* y, int out_bf16);
 int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* packed_t,
                        float* dx, int accumulate, int frame);
 

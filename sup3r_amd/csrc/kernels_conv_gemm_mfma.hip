@@ -51,7 +51,8 @@ __device__ inline bf16x8 pack8(const float4& a, const float4& b) {
 // 1: rows = ci, K = co (data gradient; tap order is handled by the kernel)
 __global__ void gconv_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                   int taps, int cin, int cout, int rows_pad, int mode) {
-  const int R = mode == 0 ? cout : cin, K = mode == 0 ? cin : cout;
+  const int R = mode == 0 ? cout : cin, Kx = mode == 0 ? cin : cout;
+  const int K = (Kx + 7) / 8 * 8;              // rows padded to whole 16-B chunks
   const int64_t total = (int64_t)taps * rows_pad * K;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -60,7 +61,7 @@ __global__ void gconv_pack_kernel(const float* __restrict__ w, unsigned short* _
     const int row = (int)(r % rows_pad); r /= rows_pad;
     const int tap = (int)r;
     float v = 0.f;
-    if (row < R) {
+    if (row < R && k < Kx) {
       const int ci = mode == 0 ? k : row, co = mode == 0 ? row : k;
       v = w[((int64_t)tap * cin + ci) * cout + co];
     }
@@ -74,12 +75,15 @@ template <bool ADJ>
 __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, const float* __restrict__ res,
-    float* __restrict__ y, ConvGeom g, int64_t P, int rows_pad, int accumulate, int frame) {
+    void* __restrict__ yv, ConvGeom g, int64_t P, int rows_pad, int accumulate, int frame,
+    int out_bf16) {
+  float* __restrict__ y = reinterpret_cast<float*>(yv);
   // in ADJ mode: g is the FORWARD conv's geometry; positions run over its
   // input grid D, the gathered tensor x is dY on its output grid O, K = C_out
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p16 = lane & 15, kq = lane >> 4;
-  const int K = ADJ ? g.Cout : g.Cin;          // contraction channels per tap
+  const int K = ADJ ? g.Cout : g.Cin;          // contraction channels per tap (a cell)
+  const int Kp = (K + 7) / 8 * 8;              // row length of the packed filter image
   const int R = ADJ ? g.Cin : g.Cout;          // output channels
   // frame (ADJ only): positions run over the virtually padded input frame
   // (D + 2 lo per axis); the caller folds the border back (reflect adjoint)
@@ -144,18 +148,18 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
           sok[m] = ok;
           src[m] = x + ((((int64_t)pn[m] * S0 + i0) * S1 + i1) * S2 + i2) * K + kq * 8;
         }
-        const unsigned short* wt = wpk + ((int64_t)tap * rows_pad + ct * GT_N + p16) * K + kq * 8;
+        const unsigned short* wt = wpk + ((int64_t)tap * rows_pad + ct * GT_N + p16) * Kp + kq * 8;
         for (int kc = 0; kc < kchunks; ++kc) {
           bf16x8 wf[4], xf[GT_MF];
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf)
-            if (nf < nfv) wf[nf] = *reinterpret_cast<const bf16x8*>(wt + (int64_t)nf * 16 * K + kc * 32);
+            if (nf < nfv) wf[nf] = *reinterpret_cast<const bf16x8*>(wt + (int64_t)nf * 16 * Kp + kc * 32);
 #pragma unroll
           for (int m = 0; m < GT_MF; ++m) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
             if (sok[m] && kc * 32 + kq * 8 < K) {
               a = *reinterpret_cast<const float4*>(src[m] + kc * 32);
-              b = *reinterpret_cast<const float4*>(src[m] + kc * 32 + 4);
+              if (kc * 32 + kq * 8 + 4 < K) b = *reinterpret_cast<const float4*>(src[m] + kc * 32 + 4);
             }
             xf[m] = pack8(a, b);
           }
@@ -188,6 +192,15 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
           v[r] = v[r] > 0.f ? v[r] : slope * v[r];
         }
       }
+      if (out_bf16) {            // (forward only, R % 4 == 0, no accumulate)
+        if (!ADJ && res) {
+          const float4 rr = *reinterpret_cast<const float4*>(res + p * R + ch);
+          v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(yv) + p * R + ch) =
+            make_uint2(pk2(v[0], v[1]), pk2(v[2], v[3]));
+        continue;
+      }
       float* yp = y + p * R + ch;
       if ((R & 3) == 0) {
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -219,7 +232,8 @@ bool conv_gconv_supported(const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16) return false;
   if (getenv("SUP3R_AMD_NO_GCONV")) return false;
   if (g.d2s != 1) return false;
-  if (g.Cin % 8 != 0 || g.Cin < 32) return false;
+  // C_in = 4: the generator's first conv (a cell is one float4)
+  if (!(g.Cin == 4 || (g.Cin % 8 == 0 && g.Cin >= 32))) return false;
   return true;
 }
 
@@ -241,13 +255,13 @@ static int rows_padded(int r) { return (r + GT_N - 1) / GT_N * GT_N; }
 size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad) {
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int R = dgrad ? g.Cin : g.Cout, K = dgrad ? g.Cout : g.Cin;
-  return (size_t)taps * rows_padded(R) * K * 2 + 64;   // + over-read of a masked K tail
+  return (size_t)taps * rows_padded(R) * ((K + 7) / 8 * 8) * 2 + 64;   // + over-read of a masked K tail
 }
 
 int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad) {
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int R = dgrad ? g.Cin : g.Cout, K = dgrad ? g.Cout : g.Cin;
-  const int64_t total = (int64_t)taps * rows_padded(R) * K;
+  const int64_t total = (int64_t)taps * rows_padded(R) * ((K + 7) / 8 * 8);
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(gconv_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, w,
@@ -257,11 +271,12 @@ int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* pack
 }
 
 int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
-                     const float* bias, const float* res, float* y) {
+                     const float* bias, const float* res, void* y, int out_bf16) {
+  if (out_bf16 && g.Cout % 4 != 0) S3_FAIL(ctx, S3_EINVAL, "gconv: bf16 output needs C_out % 4 == 0");
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
   dim3 grid((unsigned)((P + GT_POS - 1) / GT_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
   hipLaunchKernelGGL(gconv_mfma_kernel<false>, grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
-                     (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0);
+                     (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -274,7 +289,7 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
   dim3 grid((unsigned)((P + GT_POS - 1) / GT_POS), (unsigned)((g.Cin + GT_N - 1) / GT_N));
   hipLaunchKernelGGL(gconv_mfma_kernel<true>, grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
                      (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
-                     rows_padded(g.Cin), accumulate, frame);
+                     rows_padded(g.Cin), accumulate, frame, 0);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

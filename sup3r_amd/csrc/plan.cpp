@@ -631,13 +631,13 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
         const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.packed : (const void*)w;
         return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out), o.io);
       }
-      if (o.gconv && !o.io.in_bf16 && !o.io.out_bf16 && !o.io.res_bf16) {
+      if (o.gconv && !o.io.in_bf16 && !o.io.res_bf16 && (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
         if (o.gc_version != P->version) {
           int rc = launch_gconv_pack(ctx, o.cg, w, o.gc_w, 0);
           if (rc) return rc;
           o.gc_version = P->version;
         }
-        return launch_gconv_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.gc_w, b, res, (float*)tptr(pl, d.out));
+        return launch_gconv_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.gc_w, b, res, tptr(pl, d.out), o.io.out_bf16);
       }
       if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16)
         return launch_conv_fewpos_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out), pl->fp_partial, pl->fp_partial_bytes);

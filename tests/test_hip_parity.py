@@ -137,12 +137,13 @@ def test_mfma_backward_edge_shapes():
     ph.backward(dev.to_device(dy), need_wgrad=True, accumulate_wgrad=True)
     for g, g_ref in zip(net.grads, ref.grads):
         assert np.abs(g - 2 * g_ref).max() < 2e-3 * np.abs(g_ref).max() + 2e-5 * gmax
-    # bf16 MFMA mode backward: looser bound
+    # bf16 MFMA mode backward (every conv incl. the 4 -> 64 head on bf16
+    # operands): the bf16-mode gradient bound, 1e-1 of the largest value
     net16 = _hip_net(spec, ref.weights, precision='bf16')
     ph16 = net16.plan(shape, training=True)
     ph16.forward(dev.to_device(x))
     dx16 = ph16.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
-    assert np.abs(dx16 - dx_ref).max() < 5e-2 * np.abs(dx_ref).max()
+    assert np.abs(dx16 - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
 
 
 def test_bf16_mode_tolerance_c2_topology():
