@@ -158,8 +158,13 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
           for (int m = 0; m < GT_MF; ++m) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
             if (sok[m] && kc * 32 + kq * 8 < K) {
-              a = *reinterpret_cast<const float4*>(src[m] + kc * 32);
-              if (kc * 32 + kq * 8 + 4 < K) b = *reinterpret_cast<const float4*>(src[m] + kc * 32 + 4);
+              if (K >= 4) {
+                a = *reinterpret_cast<const float4*>(src[m] + kc * 32);
+                if (kc * 32 + kq * 8 + 4 < K) b = *reinterpret_cast<const float4*>(src[m] + kc * 32 + 4);
+              } else {               // 2-channel cells (hi-res fields into the discriminator)
+                const float2 t = *reinterpret_cast<const float2*>(src[m]);
+                a.x = t.x; a.y = t.y;
+              }
             }
             xf[m] = pack8(a, b);
           }
@@ -233,7 +238,8 @@ bool conv_gconv_supported(const ConvGeom& g, int precision) {
   if (getenv("SUP3R_AMD_NO_GCONV")) return false;
   if (g.d2s != 1) return false;
   // C_in = 4: the generator's first conv (a cell is one float4)
-  if (!(g.Cin == 4 || (g.Cin % 8 == 0 && g.Cin >= 32))) return false;
+  // C_in = 2: hi-res fields into the discriminator (a cell is one float2)
+  if (!(g.Cin == 2 || g.Cin == 4 || (g.Cin % 8 == 0 && g.Cin >= 32))) return false;
   return true;
 }
 

@@ -20,6 +20,8 @@ def main():
     ap.add_argument('--lr-shape', default='4,4,4,4,2')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--precision', default='f32')
+    ap.add_argument('--hr-features', type=int, default=2,
+                    help='output features of the generator')
     args = ap.parse_args()
     import torch
     from sup3r_amd import Sup3rGan
@@ -27,8 +29,9 @@ def main():
     model = Sup3rGan(os.path.join(CFG, args.gen), os.path.join(CFG, args.disc),
                      loss='MeanAbsoluteError', precision=args.precision)
     s, t = model.s_enhance, model.t_enhance
+    n_out = args.hr_features
     hr_shape = (lr_shape[0], lr_shape[1] * s, lr_shape[2] * s) + (
-        (lr_shape[3] * t, lr_shape[4]) if len(lr_shape) == 5 else (lr_shape[3],))
+        (lr_shape[3] * t, n_out) if len(lr_shape) == 5 else (n_out,))
     rng = np.random.default_rng(0)
     lr = rng.standard_normal(lr_shape).astype(np.float32)
     hr = rng.standard_normal(hr_shape).astype(np.float32)
