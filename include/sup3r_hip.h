@@ -234,6 +234,24 @@ int s3_gaussian_smooth(s3_ctx* ctx, const float* x, int n, int s1, int s2, int t
                        int c, const float* weights_host, int radius,
                        unsigned channel_mask, float* tmp, float* y);
 
+/* ---- output epilogue on the device ----------------------
+ * replaces the host numpy of OutputHandler._transform_output
+ * (sup3r/writers/base.py:304-345) on a hi-res chunk (s1*s2, t, c) fp32:
+ *   s3_invert_uv     = invert_uv_single_pair (writers/base.py:283-302) /
+ *                      invert_uv (preprocessing/derivers/utilities.py:204-258):
+ *                      rotate (u, v) by the grid angle theta(s1, s2) — its
+ *                      cos / sin are device tables of s1*s2 floats — and
+ *                      overwrite channel u_idx with the windspeed and v_idx
+ *                      with the direction in degrees [0, 360).
+ *   s3_clip_channels = enforce_limits(nn_fill=False) (sup3r/utilities/
+ *                      utilities.py:155-220): per-channel clipping to
+ *                      [min, max] (host arrays; +-inf = no limit). */
+int s3_invert_uv(s3_ctx* ctx, float* data, int64_t n_sp, int64_t t, int c,
+                 int u_idx, int v_idx, const float* cos_theta,
+                 const float* sin_theta);
+int s3_clip_channels(s3_ctx* ctx, float* data, int c, int64_t n_pos,
+                     const float* min_host, const float* max_host);
+
 /* ---- data-parallel gradient sync (RCCL over xGMI) -----------------------
  * replaces: the host-side python sum of per-GPU gradient lists,
  * AbstractSingleModel._sum_parallel_grad (abstract.py:785-805): elementwise

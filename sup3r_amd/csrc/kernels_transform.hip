@@ -82,6 +82,39 @@ __global__ void gauss_pass_kernel(const float* __restrict__ x, float* __restrict
   }
 }
 
+// u/v -> windspeed / winddirection in place (writers/base.py:233-302 +
+// derivers/utilities.py:204-258): rotate by the grid angle theta(s1, s2) back
+// to the meridian frame, ws = hypot, wd = (degrees(atan2(u, v)) + 360) % 360
+__global__ void invert_uv_kernel(float* __restrict__ data, int64_t n_sp, int64_t t, int c,
+                                 int u_idx, int v_idx, const float* __restrict__ cos_t,
+                                 const float* __restrict__ sin_t) {
+  const int64_t total = n_sp * t;
+  for (int64_t idx = (int64_t)blockIdx.x * kBlk + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * kBlk) {
+    const int64_t sp = idx / t;
+    const float cs = cos_t[sp], sn = sin_t[sp];
+    float* cell = data + idx * c;
+    const float u = cell[u_idx], v = cell[v_idx];
+    const float ur = cs * u - sn * v, vr = sn * u + cs * v;
+    cell[u_idx] = hypotf(ur, vr);
+    cell[v_idx] = fmodf(atan2f(ur, vr) * 57.29577951308232f + 360.f, 360.f);
+  }
+}
+
+struct Clip16 { float lo[16]; float hi[16]; };
+// enforce_limits with clipping (utilities/utilities.py:155-220): NaNs pass
+// through np.maximum / np.minimum unchanged, so they do here
+__global__ void clip_channels_kernel(float* __restrict__ data, int c, int64_t n, Clip16 lim) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlk + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * kBlk) {
+    const int ch = (int)(i % c);
+    float v = data[i];
+    if (v < lim.lo[ch]) v = lim.lo[ch];
+    if (v > lim.hi[ch]) v = lim.hi[ch];
+    data[i] = v;
+  }
+}
+
 int grid_of(int64_t n, int num_cu) {
   int64_t g = (n + kBlk - 1) / kBlk;
   const int64_t cap = (int64_t)num_cu * 16;
@@ -128,6 +161,30 @@ extern "C" int s3_gaussian_smooth(s3_ctx* ctx, const float* x, int n, int s1,
                      n, s1, s2, t, c, 0, radius, gw, channel_mask);
   hipLaunchKernelGGL(gauss_pass_kernel, dim3(grid), dim3(kBlk), 0, ctx->stream, tmp, y,
                      n, s1, s2, t, c, 1, radius, gw, channel_mask);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_invert_uv(s3_ctx* ctx, float* data, int64_t n_sp, int64_t t, int c,
+                            int u_idx, int v_idx, const float* cos_theta,
+                            const float* sin_theta) {
+  if (!ctx || !data || !cos_theta || !sin_theta) return S3_EINVAL;
+  if (u_idx < 0 || v_idx < 0 || u_idx >= c || v_idx >= c || u_idx == v_idx)
+    S3_FAIL(ctx, S3_EINVAL, "invert_uv: bad channel indices");
+  hipLaunchKernelGGL(invert_uv_kernel, dim3(grid_of(n_sp * t, ctx->num_cu)), dim3(kBlk), 0,
+                     ctx->stream, data, n_sp, t, c, u_idx, v_idx, cos_theta, sin_theta);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_clip_channels(s3_ctx* ctx, float* data, int c, int64_t n_pos,
+                                const float* min_host, const float* max_host) {
+  if (!ctx || !data) return S3_EINVAL;
+  if (c > 16) S3_FAIL(ctx, S3_EINVAL, "clip_channels supports at most 16 channels");
+  Clip16 lim;
+  for (int i = 0; i < c; ++i) { lim.lo[i] = min_host[i]; lim.hi[i] = max_host[i]; }
+  hipLaunchKernelGGL(clip_channels_kernel, dim3(grid_of(n_pos * c, ctx->num_cu)), dim3(kBlk), 0,
+                     ctx->stream, data, c, n_pos * c, lim);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
