@@ -11,15 +11,22 @@ import numpy as np
 from scipy.ndimage import gaussian_filter
 
 
-def spatial_coarsening(data, s_enhance=2):
+def spatial_coarsening(data, s_enhance=2, obs_axis=True):
+    """utilities.py:406-523 — block mean over the two spatial axes; these are
+    axes (1, 2) with an observation axis and (0, 1) without one"""
+    nd = len(data.shape)
+    if nd < 2 or (obs_axis and nd < 3):
+        raise ValueError('Data must be 2D-5D (3D-5D with obs_axis) to do '
+                         f'spatial coarsening, but received: {data.shape}')
     if s_enhance is None or s_enhance <= 1:
         return data
-    if data.shape[1] % s_enhance or data.shape[2] % s_enhance:
+    a = 1 if obs_axis else 0
+    if data.shape[a] % s_enhance or data.shape[a + 1] % s_enhance:
         raise ValueError('s_enhance must evenly divide grid size.')
-    data = np.reshape(data, (data.shape[0], data.shape[1] // s_enhance,
-                             s_enhance, data.shape[2] // s_enhance, s_enhance,
-                             *data.shape[3:]))
-    return data.sum(axis=(2, 4)) / s_enhance ** 2
+    data = np.reshape(data, (*data.shape[:a], data.shape[a] // s_enhance,
+                             s_enhance, data.shape[a + 1] // s_enhance,
+                             s_enhance, *data.shape[a + 2:]))
+    return data.sum(axis=(a + 1, a + 3)) / s_enhance ** 2
 
 
 def temporal_coarsening(data, t_enhance=4, method='subsample'):

@@ -80,3 +80,74 @@ def test_device_output_transform_vs_oracle(ascending):
     np.testing.assert_array_equal(out2.cpu().numpy(), ref2)
     with pytest.raises(KeyError):
         DeviceOutputTransform().transform_output(data, ['a'] * 5, ll)
+
+
+# --- the reference's own known-answer tests for the wind rotation pair
+# (/root/reference/tests/utilities/test_utilities.py:360-452 test_transform_rotate,
+# /root/reference/tests/output/test_output_handling.py:60-91 test_invert_uv),
+# run on the oracle (CPU) and the device kernel (GPU).
+
+def _ref_lat_lon():
+    lats = np.array([[1, 1, 1], [0, 0, 0]])
+    lons = np.array([[-120, -100, -80], [-120, -100, -80]])
+    return np.stack([lats, lons], axis=-1).astype(np.float64)
+
+
+_KNOWN_UV = [(0, 0, -1), (90, -1, 0), (270, 1, 0), (180, 0, 1),
+             (45, -1 / np.sqrt(2), -1 / np.sqrt(2))]
+
+
+@pytest.mark.parametrize('wd,u_t,v_t', _KNOWN_UV)
+def test_oracle_transform_rotate_known_answers(wd, u_t, v_t):
+    from oracle.output import invert_uv, transform_rotate_wind
+    ll = _ref_lat_lon()
+    ws = np.ones((2, 3, 1), np.float32)
+    u, v = transform_rotate_wind(ws, np.full((2, 3, 1), wd, np.float32), ll)
+    assert np.allclose(u, u_t, atol=1e-5) and np.allclose(v, v_t, atol=1e-5)
+    ws2, wd2 = invert_uv(u, v, ll)
+    assert np.allclose(ws2, 1, atol=1e-5)
+    assert np.allclose(wd2 % 360, wd, atol=1e-3)
+
+
+@pytest.mark.parametrize('flip', [False, True])
+def test_oracle_invert_uv_reference_procedure(flip):
+    from oracle.output import invert_uv, transform_rotate_wind
+    rng = np.random.default_rng(3)
+    ll = _ref_lat_lon()[::-1] if flip else _ref_lat_lon()
+    ws = rng.random((2, 3, 5))
+    wd = 360 * rng.random((2, 3, 5))
+    u, v = transform_rotate_wind(ws.astype(np.float32), wd.astype(np.float32),
+                                 ll)
+    ws2, wd2 = invert_uv(u, v, ll)
+    assert np.allclose(ws, ws2) and np.allclose(wd, wd2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('flip', [False, True])
+def test_device_invert_uv_known_answers(flip):
+    """device inversion of the reference's known (u, v) pairs gives speed 1
+    and the stated direction; random pairs round-trip (test_invert_uv)"""
+    from oracle.output import transform_rotate_wind
+    from sup3r_amd.output_transform import DeviceOutputTransform
+    ll = _ref_lat_lon()[::-1].copy() if flip else _ref_lat_lon()
+    feats = ['u_100m', 'v_100m']
+    tr = DeviceOutputTransform()
+    for wd, _, _ in _KNOWN_UV:
+        u, v = transform_rotate_wind(np.ones((2, 3, 1)),
+                                     np.full((2, 3, 1), float(wd)), ll)
+        data = np.stack([u, v], axis=-1).astype(np.float32)
+        out, names = tr.transform_output(data, feats, ll, invert_uv=True)
+        out = out.cpu().numpy()
+        assert names == ['windspeed_100m', 'winddirection_100m']
+        assert np.allclose(out[..., 0], 1, atol=1e-5)
+        d = np.abs(out[..., 1] - wd)
+        assert np.minimum(d, 360 - d).max() < 1e-2
+    rng = np.random.default_rng(4)
+    ws = rng.random((2, 3, 5)) + 0.05
+    wd = 360 * rng.random((2, 3, 5))
+    u, v = transform_rotate_wind(ws, wd, ll)
+    data = np.stack([u, v], axis=-1).astype(np.float32)
+    out = tr.transform_output(data, feats, ll, invert_uv=True)[0].cpu().numpy()
+    assert np.allclose(out[..., 0], ws, atol=1e-5)
+    d = np.abs(out[..., 1] - wd)
+    assert np.minimum(d, 360 - d).max() < 1e-2
