@@ -1,0 +1,257 @@
+// Trunk weight gradient on bf16 MFMA (gfx950) — S3_PREC_BF16 training plans.
+//
+//   dW[tap][ci][co] = sum_{n, p} Xpad[n, p + tap - 1][ci] * dPre[n, p][co]
+//
+// = 27 GEMMs (64 x P)(P x C_out) whose contraction index is the POSITION, while
+// both operands live channels-last.  v_mfma_f32_16x16x32_bf16 wants 8
+// consecutive k per lane, i.e. 8 positions of one channel: the operands are
+// read with ds_read_b64_tr_b16 (LDS transpose read: within a 16-lane group
+// lane q gets column q of the 4 x 16 bf16 block whose row r is the 32 B that
+// lanes 4r..4r+3 point at; the row addresses are free), so the LDS images stay
+// in the natural [cell][channel] order — the tap shift is a cell offset and
+// the staging is a plain convert + 8-byte store.
+//
+// PERSISTENT workgroups of 12 waves (3 per SIMD), each owning a 32-wide cout
+// tile of the whole 27 x 64 x 32 gradient in registers: wave w = (ci block
+// w & 3, s1-tap a = w >> 2) holds 9 taps x 2 cout blocks = 18 f32x4
+// accumulators.  Position tiles of 4 x 4 x 16 stream through LDS: x halo
+// 6 x 6 x 18 cells x 128 B (bf16, 32-B segments XOR-swizzled by the cell's t
+// index) + dPre 256 x 64 B.  Per 32-position k-step a wave issues 18 A + 4 B
+// transpose reads (2 LDS cycles each) for 18 MFMAs (16 cycles each).
+// Partials per workgroup, reduced in fixed order (deterministic on every rank).
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BT0 = 4, BT1 = 4, BT2 = 16;
+constexpr int BH0 = BT0 + 2, BH1 = BT1 + 2, BH2 = BT2 + 2;
+constexpr int BHP = BH0 * BH1 * BH2;            // 648 halo cells
+constexpr int BNP = BT0 * BT1 * BT2;            // 256 positions per tile
+constexpr int BNT = 768;                        // 12 waves
+constexpr int BCT = 32;                         // cout tile per workgroup
+constexpr int XS_BYTES = BHP * 128;             // 82,944
+constexpr int DS_BYTES = BNP * 64;              // 16,384
+constexpr size_t BF_LDS = (size_t)XS_BYTES + DS_BYTES;
+
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+  hf32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
+}
+
+// 32-B segment swizzle of a halo cell: cells of equal parity among the 8 cells
+// one half-wave transpose read touches ({t..t+3} U {t+8..t+11}) get distinct keys
+__device__ __forceinline__ int xs_key(int th) { return ((th >> 1) & 1) | (((th >> 3) & 1) << 1); }
+
+__device__ __forceinline__ s16x4 lds_tr(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4 __attribute__((address_space(3)))*)(p));
+}
+
+__global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy,
+    float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
+    int tiles2, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;                       // [BHP cells][4 segs of 32 B] bf16
+  char* ds = smem + XS_BYTES;            // [BNP positions][2 segs of 32 B] bf16
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane & 15, kg = lane >> 4;
+  const int cb = wave & 3, ta = wave >> 2;                 // ci block, s1 tap
+  const int ct = blockIdx.y;                                // cout tile of 32
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // per-lane operand addresses.  k = 8 kg + e  <->  tile row 2 ks + (kg >> 1),
+  // t = 8 (kg & 1) + e; transpose read h covers e = 4 h .. 4 h + 3 and this
+  // lane points at row e = 4 h + (q >> 2), chunk q & 3 of the 16-channel block
+  int a_off[3][2];                       // [c][h], without the k-step / b part
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int th = 8 * (kg & 1) + 4 * h + (q >> 2) + c;
+      a_off[c][h] = ((ta * BH1 + (kg >> 1)) * BH2 + th) * 128 +
+                    ((cb ^ xs_key(th)) << 5) + ((q & 3) << 3);
+    }
+  int b_off[2][2];                       // [cout block][h]
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pl = 8 * kg + 4 * h + (q >> 2);
+      b_off[nb][h] = pl * 64 + ((nb ^ ((pl >> 3) & 1)) << 5) + ((q & 3) << 3);
+    }
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int tr = tile;
+    const int t2i = tr % tiles2; tr /= tiles2;
+    const int t1i = tr % tiles1; tr /= tiles1;
+    const int t0i = tr % tiles0; tr /= tiles0;
+    const int n = tr;
+    const int org0 = t0i * BT0, org1 = t1i * BT1, org2 = t2i * BT2;
+    __syncthreads();   // previous tile fully consumed
+    // ---- stage x halo: 648 cells x 16 float4 -> bf16
+    for (int item = tid; item < BHP * 16; item += BNT) {
+      const int hp = item >> 4, ch = item & 15;
+      int h = hp;
+      const int c2 = h % BH2; h /= BH2;
+      const int c1 = h % BH1; h /= BH1;
+      const int c0 = h;
+      int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
+      bool valid = true;
+      if (g.pad_mode == S3_PAD_REFLECT) {
+        i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
+      } else {
+        valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
+      }
+      // cells feeding only out-of-range outputs are multiplied by zero dPre
+      i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
+      i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
+      i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
+      float4 v = make_float4(0, 0, 0, 0);
+      if (valid)
+        v = *reinterpret_cast<const float4*>(
+            x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * 64 + ch * 4);
+      uint2 pk = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+      *reinterpret_cast<uint2*>(xs + hp * 128 + (((ch >> 2) ^ xs_key(c2)) << 5) + ((ch & 3) << 3)) = pk;
+    }
+    // ---- stage dPre tile: 256 positions x 8 float4 (zero outside / beyond C_out)
+    for (int item = tid; item < BNP * (BCT / 4); item += BNT) {
+      const int pl = item >> 3, ch = item & 7;
+      const int row = pl / BT2, tt = pl % BT2;
+      const int o0 = org0 + row / BT1, o1 = org1 + row % BT1, o2 = org2 + tt;
+      const int co = ct * BCT + ch * 4;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && co < g.Cout)
+        v = *reinterpret_cast<const float4*>(
+            dy + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co);
+      uint2 pk = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+      *reinterpret_cast<uint2*>(ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3)) = pk;
+    }
+    __syncthreads();
+    // ---- 8 k-steps of 32 positions (2 rows x 16 t)
+#pragma unroll
+    for (int ks = 0; ks < BNP / 32; ++ks) {
+      // rows 2 ks, 2 ks + 1: r0 = ks >> 1, r1 = 2 (ks & 1) + (kg >> 1)
+      const int rowb = (((ks >> 1) * BH1) + 2 * (ks & 1)) * BH2 * 128;
+      bf16x8 bfr[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const s16x4 lo = lds_tr(ds + b_off[nb][0] + ks * 32 * 64);
+        const s16x4 hi = lds_tr(ds + b_off[nb][1] + ks * 32 * 64);
+        bfr[nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const s16x4 lo = lds_tr(xs + a_off[c][0] + rowb + b * BH2 * 128);
+          const s16x4 hi = lds_tr(xs + a_off[c][1] + rowb + b * BH2 * 128);
+          const bf16x8 afr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[b * 3 + c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[0], acc[b * 3 + c][0], 0, 0, 0);
+          acc[b * 3 + c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[1], acc[b * 3 + c][1], 0, 0, 0);
+        }
+    }
+  }
+  // ---- partial[bid][tap][ci][co]: C/D map col = lane & 15 (co), row = 4 kg + r (ci)
+  float* out = partial + (size_t)blockIdx.x * 27 * 64 * g.Cout;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int co = ct * BCT + nb * 16 + q;
+    if (co < g.Cout) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[((size_t)(ta * 9 + t) * 64 + cb * 16 + kg * 4 + r) * g.Cout + co] = acc[t][nb][r];
+    }
+  }
+}
+
+__global__ void wgrad_bf16_partial_reduce(const float* __restrict__ partial,
+                                          int n_part, int64_t wsize,
+                                          float* __restrict__ dw, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < wsize;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= n_part; s += 4) {
+      t0 += partial[(int64_t)s * wsize + i];
+      t1 += partial[(int64_t)(s + 1) * wsize + i];
+      t2 += partial[(int64_t)(s + 2) * wsize + i];
+      t3 += partial[(int64_t)(s + 3) * wsize + i];
+    }
+    for (; s < n_part; ++s) t0 += partial[(int64_t)s * wsize + i];
+    const float t = (t0 + t1) + (t2 + t3);
+    dw[i] = accumulate ? dw[i] + t : t;
+  }
+}
+
+int bf_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles_out, int* t0,
+            int* t1, int* t2) {
+  const int tiles0 = (g.O[0] + BT0 - 1) / BT0, tiles1 = (g.O[1] + BT1 - 1) / BT1,
+            tiles2 = (g.O[2] + BT2 - 1) / BT2;
+  const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
+  *n_tiles_out = n_tiles; *t0 = tiles0; *t1 = tiles1; *t2 = tiles2;
+  const int n_ct = (g.Cout + BCT - 1) / BCT;
+  int grid = ctx->num_cu / n_ct;
+  if (grid < 1) grid = 1;
+  if (grid > n_tiles) grid = n_tiles;
+  return grid;
+}
+
+}  // namespace
+
+bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision) {
+  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_WGRAD_BF16")) return false;
+  if (g.Cin != 64 || g.Cout % 4 != 0 || g.Cout < 16) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] != 1 || g.O[d] != g.D[d]) return false;
+  // enough positions to amortise the 27 x 64 x C_out partial per workgroup
+  return g.D[2] >= 8 && (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 2048;
+}
+
+size_t conv_wgrad_bf16_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
+  int nt, a, b, c;
+  const int grid = bf_grid(ctx, g, &nt, &a, &b, &c);
+  return (size_t)grid * 27 * 64 * g.Cout * sizeof(float);
+}
+
+int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
+                           const float* dy, float* dw, float* partial,
+                           size_t partial_bytes, int accumulate) {
+  int n_tiles, tiles0, tiles1, tiles2;
+  const int grid = bf_grid(ctx, g, &n_tiles, &tiles0, &tiles1, &tiles2);
+  if (partial_bytes < conv_wgrad_bf16_partial_bytes(ctx, g))
+    S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16: partial buffer too small");
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
+    attr_set = true;
+  }
+  const int n_ct = (g.Cout + BCT - 1) / BCT;
+  hipLaunchKernelGGL(conv3_wgrad_bf16_kernel, dim3(grid, n_ct), dim3(BNT), BF_LDS,
+                     ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles);
+  S3_HIP(ctx, hipGetLastError());
+  const int64_t wsize = (int64_t)27 * 64 * g.Cout;
+  hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3((unsigned)((wsize + 255) / 256)), dim3(256), 0,
+                     ctx->stream, partial, grid, wsize, dw, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}

@@ -446,3 +446,37 @@ def test_hipgraph_replay_is_bit_identical(monkeypatch):
     np.testing.assert_array_equal(y3, net(x).cpu().numpy())
     np.testing.assert_array_equal(y3b, y3)
     assert np.abs(y3 - y_eager).max() > 0
+
+
+def test_trunk_wgrad_bf16_transpose_read_kernel(monkeypatch):
+    """conv3_wgrad_bf16_kernel (bf16 MFMA fed by ds_read_b64_tr_b16) on ragged
+    tiles (s1 = 9, s2 = 10 not multiples of 4, t = 37 not of 16) with the
+    reflect halo: the 64 -> 64 and 64 -> 72 weight gradients against the
+    oracle (bf16-mode bound 1e-1 of the largest value) and against the exact
+    fp32-MFMA kernel of the same plan (SUP3R_AMD_NO_WGRAD_BF16=1; only the bf16
+    rounding of x and dPre differs: rel. rms < 1e-2)."""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(31)
+    spec = pcc(3, 64) + pcc(3, 64) + pcc(3, 72, act=False)
+    shape = (2, 9, 10, 37, 4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    ref.backward(dy)
+
+    def grads():
+        net = _hip_net(spec, ref.weights, precision='bf16')
+        ph = net.plan(shape, training=True)
+        ph.forward(net.dev.to_device(x))
+        ph.backward(net.dev.to_device(dy), need_dx=False)
+        return [np.array(g) for g in net.grads]
+    g_bf = grads()
+    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_BF16', '1')
+    g_32 = grads()
+    for i, (a, b, r) in enumerate(zip(g_bf, g_32, ref.grads)):
+        assert np.abs(a - r).max() < 1e-1 * np.abs(r).max(), i
+        rms = np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean())
+        assert rms < 1e-2, (i, rms)
+    # the two kernels were really different ones
+    assert any(np.abs(a - b).max() > 0 for a, b in zip(g_bf, g_32))
