@@ -112,6 +112,21 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
   for (int m = 0; m < GT_MF; ++m)
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) acc[m][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // forward, no padding: the gather address is base(position) + offset(tap)
+  bool inrange = !ADJ && g.pad_mode != S3_PAD_REFLECT;
+  int64_t fbase[GT_MF];
+#pragma unroll
+  for (int m = 0; m < GT_MF; ++m) fbase[m] = 0;
+  if (!ADJ) {
+    for (int d = 0; d < 3; ++d)
+      inrange = inrange && g.lo[d] == 0 && (g.O[d] - 1) * g.s[d] + g.k[d] <= g.D[d];
+    if (inrange) {
+#pragma unroll
+      for (int m = 0; m < GT_MF; ++m)
+        fbase[m] = ((((int64_t)pn[m] * S0 + c0[m] * g.s[0]) * S1 + c1[m] * g.s[1]) * S2 +
+                    c2[m] * g.s[2]) * K;
+    }
+  }
 
   const int nfv = (R - ct * GT_N + 15) / 16 < 4 ? (R - ct * GT_N + 15) / 16 : 4;
   const int k0n = g.k[0], k1n = g.k[1], k2n = g.k[2];
@@ -127,6 +142,12 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
         for (int m = 0; m < GT_MF; ++m) {
           int i0, i1, i2;
           bool ok = true;
+          if (!ADJ && inrange) {
+            // valid padding: every tap of every output position is inside the input
+            sok[m] = true;
+            src[m] = x + fbase[m] + (((int64_t)ta * S1 + tb) * S2 + tc) * K + kq * 8;
+            continue;
+          }
           if (!ADJ) {
             i0 = c0[m] * g.s[0] + ta - g.lo[0];
             i1 = c1[m] * g.s[1] + tb - g.lo[1];
@@ -231,6 +252,166 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Few input channels (C_in = 2: hi-res fields into the discriminator, C_in = 4:
+// the generator's first conv): the taps are packed INTO the contraction index,
+// k = tap * C_in + ci (27 C_in = 54 / 108 -> 2 / 4 chunks of 32), instead of
+// one mostly-empty K = 32 MFMA per tap.  Lane (position, kq) of a chunk gathers
+// its 8 / C_in own taps (one float2 / float4 each); the per-lane tap offsets
+// are computed once, the filter fragments live in registers for the whole
+// workgroup, and each wave walks FC_MF position fragments.  These layers are
+// bound by the store of the C_out-wide output.
+constexpr int FC_MF = 4;                       // position fragments per wave
+constexpr int FC_POS = GT_WAVES * FC_MF * 16;  // 256 positions per workgroup
+
+template <int CIN>
+__global__ __launch_bounds__(GT_WAVES * 64) void gconv_fewch_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wpk,
+    const float* __restrict__ bias, const float* __restrict__ res,
+    void* __restrict__ yv, ConvGeom g, int64_t P, int out_bf16) {
+  constexpr int TPL = 8 / CIN;                 // taps per lane per chunk
+  constexpr int KC = (27 * CIN + 31) / 32;     // chunks of 32
+  constexpr int KP = KC * 32;
+  float* __restrict__ y = reinterpret_cast<float*>(yv);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p16 = lane & 15, kq = lane >> 4;
+  const int R = g.Cout, ct = blockIdx.y;
+  const int S0 = g.D[0], S1 = g.D[1], S2 = g.D[2];
+  const int nfv = (R - ct * GT_N + 15) / 16 < 4 ? (R - ct * GT_N + 15) / 16 : 4;
+  bool inrange = g.pad_mode != S3_PAD_REFLECT;
+  for (int d = 0; d < 3; ++d)
+    inrange = inrange && g.lo[d] == 0 && (g.O[d] - 1) * g.s[d] + g.k[d] <= g.D[d];
+
+  // this lane's taps: chunk kc, slot j -> tap = (kc*32 + kq*8) / CIN + j
+  int toff[KC][TPL], tdel[KC][TPL];            // element offset; packed (ta, tb, tc), -1 = none
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+    for (int j = 0; j < TPL; ++j) {
+      const int tap = (kc * 32 + kq * 8) / CIN + j;
+      const int ta = tap / 9, tb = (tap / 3) % 3, tc = tap % 3;
+      toff[kc][j] = tap < 27 ? ((ta * S1 + tb) * S2 + tc) * CIN : 0;
+      tdel[kc][j] = tap < 27 ? (ta | (tb << 8) | (tc << 16)) : -1;
+    }
+  // filter fragments (A operand: rows = output channels)
+  bf16x8 wf[KC][4];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+      if (nf < nfv)
+        wf[kc][nf] = *reinterpret_cast<const bf16x8*>(
+            wpk + ((int64_t)ct * GT_N + nf * 16 + p16) * KP + kc * 32 + kq * 8);
+  const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+  float bv[4][4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = ct * GT_N + nf * 16 + kq * 4 + r;
+      bv[nf][r] = (bias && ch < R) ? bias[ch] : 0.f;
+    }
+
+  const int64_t pbase = (int64_t)blockIdx.x * FC_POS + wave * (FC_MF * 16);
+#pragma unroll 1
+  for (int m = 0; m < FC_MF; ++m) {
+    int64_t p = pbase + m * 16 + p16;
+    const bool pok = p < P;
+    if (!pok) p = P - 1;
+    const int64_t pp = p;
+    const int c2 = (int)(p % g.O[2]); p /= g.O[2];
+    const int c1 = (int)(p % g.O[1]); p /= g.O[1];
+    const int c0 = (int)(p % g.O[0]); p /= g.O[0];
+    const int pn = (int)p;
+    const int b0 = c0 * g.s[0] - g.lo[0], b1 = c1 * g.s[1] - g.lo[1], b2 = c2 * g.s[2] - g.lo[2];
+    const float* xb = x + ((((int64_t)pn * S0 + b0) * S1 + b1) * S2 + b2) * CIN;
+    f32x4 acc[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < TPL; ++j) {
+        const float* src = xb + toff[kc][j];
+        bool ok = tdel[kc][j] >= 0;
+        if (!inrange) {
+          const int ta = tdel[kc][j] & 255, tb = (tdel[kc][j] >> 8) & 255, tc = (tdel[kc][j] >> 16) & 255;
+          int i0 = b0 + ta, i1 = b1 + tb, i2 = b2 + tc;
+          if (g.pad_mode == S3_PAD_REFLECT) {
+            i0 = s3_reflect(i0, S0); i1 = s3_reflect(i1, S1); i2 = s3_reflect(i2, S2);
+          }
+          ok = ok && i0 >= 0 && i0 < S0 && i1 >= 0 && i1 < S1 && i2 >= 0 && i2 < S2;
+          i0 = i0 < 0 ? 0 : (i0 > S0 - 1 ? S0 - 1 : i0);
+          i1 = i1 < 0 ? 0 : (i1 > S1 - 1 ? S1 - 1 : i1);
+          i2 = i2 < 0 ? 0 : (i2 > S2 - 1 ? S2 - 1 : i2);
+          src = x + ((((int64_t)pn * S0 + i0) * S1 + i1) * S2 + i2) * CIN;
+        }
+        if (CIN == 2) {
+          float2 t = make_float2(0.f, 0.f);
+          if (ok) t = *reinterpret_cast<const float2*>(src);
+          v[2 * j] = t.x; v[2 * j + 1] = t.y;
+        } else {
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) t = *reinterpret_cast<const float4*>(src);
+          v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        }
+      }
+      const uint4 u = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        if (nf < nfv)
+          acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kc][nf], xf, acc[nf], 0, 0, 0);
+    }
+    if (!pok) continue;
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int ch = ct * GT_N + nf * 16 + kq * 4;
+      if (nf >= nfv || ch >= R) continue;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[r] = acc[nf][r] + bv[nf][r];
+        o[r] = o[r] > 0.f ? o[r] : slope * o[r];
+      }
+      if ((R & 3) == 0) {
+        if (res) {
+          const float4 rr = *reinterpret_cast<const float4*>(res + pp * R + ch);
+          o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
+        }
+        if (out_bf16)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(yv) + pp * R + ch) =
+              make_uint2(pk2(o[0], o[1]), pk2(o[2], o[3]));
+        else
+          *reinterpret_cast<float4*>(y + pp * R + ch) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ch + r < R) y[pp * R + ch + r] = o[r] + (res ? res[pp * R + ch + r] : 0.f);
+      }
+    }
+  }
+}
+
+// fp32 [27][cin][cout] -> bf16 [rows_pad][KP], k = tap * cin + ci
+__global__ void gconv_fewch_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                        int cin, int cout, int rows_pad, int kp) {
+  const int total = rows_pad * kp;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int k = idx % kp, row = idx / kp;
+    float v = 0.f;
+    if (row < cout && k < 27 * cin) v = w[(int64_t)k * cout + row];
+    out[idx] = (unsigned short)(pk2(v, 0.f) & 0xFFFFu);
+  }
+}
+
+bool fewch_geom(const ConvGeom& g) {
+  return (g.Cin == 2 || g.Cin == 4) && g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3 &&
+         !getenv("SUP3R_AMD_NO_FEWCH");
+}
+
 }  // namespace
 
 bool conv_gconv_supported(const ConvGeom& g, int precision) {
@@ -261,7 +442,15 @@ static int rows_padded(int r) { return (r + GT_N - 1) / GT_N * GT_N; }
 size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad) {
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int R = dgrad ? g.Cin : g.Cout, K = dgrad ? g.Cout : g.Cin;
-  return (size_t)taps * rows_padded(R) * ((K + 7) / 8 * 8) * 2 + 64;   // + over-read of a masked K tail
+  size_t fewch = 0;
+  if (!dgrad && fewch_geom(g)) fewch = (size_t)rows_padded(g.Cout) * ((27 * g.Cin + 31) / 32 * 32) * 2;
+  return (size_t)taps * rows_padded(R) * ((K + 7) / 8 * 8) * 2 + 64 + fewch;   // + over-read of a masked K tail
+}
+
+// the taps-in-K image of the few-channel kernel sits behind the per-tap image
+static size_t fewch_image_offset(const ConvGeom& g) {
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  return (size_t)taps * rows_padded(g.Cout) * ((g.Cin + 7) / 8 * 8) * 2 + 64;
 }
 
 int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad) {
@@ -273,6 +462,13 @@ int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* pack
   hipLaunchKernelGGL(gconv_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, w,
                      (unsigned short*)packed, taps, g.Cin, g.Cout, rows_padded(R), dgrad);
   S3_HIP(ctx, hipGetLastError());
+  if (!dgrad && fewch_geom(g)) {
+    const int kp = (27 * g.Cin + 31) / 32 * 32;
+    hipLaunchKernelGGL(gconv_fewch_pack_kernel, dim3((rows_padded(g.Cout) * kp + 255) / 256), dim3(256), 0,
+                       ctx->stream, w, (unsigned short*)((char*)packed + fewch_image_offset(g)), g.Cin,
+                       g.Cout, rows_padded(g.Cout), kp);
+    S3_HIP(ctx, hipGetLastError());
+  }
   return S3_OK;
 }
 
@@ -280,6 +476,18 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
                      const float* bias, const float* res, void* y, int out_bf16) {
   if (out_bf16 && g.Cout % 4 != 0) S3_FAIL(ctx, S3_EINVAL, "gconv: bf16 output needs C_out % 4 == 0");
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  if (fewch_geom(g)) {
+    dim3 fgrid((unsigned)((P + FC_POS - 1) / FC_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
+    const unsigned short* img = (const unsigned short*)((const char*)packed + fewch_image_offset(g));
+    if (g.Cin == 2)
+      hipLaunchKernelGGL(gconv_fewch_kernel<2>, fgrid, dim3(GT_WAVES * 64), 0, ctx->stream, x, img,
+                         bias, res, y, g, P, out_bf16);
+    else
+      hipLaunchKernelGGL(gconv_fewch_kernel<4>, fgrid, dim3(GT_WAVES * 64), 0, ctx->stream, x, img,
+                         bias, res, y, g, P, out_bf16);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   dim3 grid((unsigned)((P + GT_POS - 1) / GT_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
   hipLaunchKernelGGL(gconv_mfma_kernel<false>, grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
                      (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16);
