@@ -95,17 +95,42 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
   const int ct = blockIdx.y;
   const int64_t pbase = (int64_t)blockIdx.x * GT_POS + wave * (GT_MF * 16);
 
+  // strided data gradient: positions are enumerated per residue class
+  // (c mod s per axis, blockIdx.z) — all lanes of a workgroup then share the
+  // taps that reach them (ta = (r + lo) mod s, step s) instead of masking
+  // 1 - 1/(s0 s1 s2) of the 27 taps
+  const bool strided = ADJ && (g.s[0] > 1 || g.s[1] > 1 || g.s[2] > 1);
+  int r0 = 0, r1 = 0, r2 = 0, E0 = G0, E1 = G1, E2 = G2;
+  int64_t Pc = P;
+  if (strided) {
+    const int cls = blockIdx.z;
+    r2 = cls % g.s[2]; r1 = (cls / g.s[2]) % g.s[1]; r0 = cls / (g.s[2] * g.s[1]);
+    E0 = (G0 - r0 + g.s[0] - 1) / g.s[0]; E1 = (G1 - r1 + g.s[1] - 1) / g.s[1];
+    E2 = (G2 - r2 + g.s[2] - 1) / g.s[2];
+    Pc = (int64_t)g.N * E0 * E1 * E2;
+    if ((int64_t)blockIdx.x * GT_POS >= Pc) return;
+  }
+  const int st0 = strided ? g.s[0] : 1, st1 = strided ? g.s[1] : 1, st2 = strided ? g.s[2] : 1;
+  const int ta0 = strided ? (r0 + g.lo[0]) % g.s[0] : 0, tb0 = strided ? (r1 + g.lo[1]) % g.s[1] : 0,
+            tc0 = strided ? (r2 + g.lo[2]) % g.s[2] : 0;
+
   int pn[GT_MF], c0[GT_MF], c1[GT_MF], c2[GT_MF];
+  int64_t plin[GT_MF];
   bool pok[GT_MF];
 #pragma unroll
   for (int m = 0; m < GT_MF; ++m) {
     int64_t p = pbase + m * 16 + p16;
-    pok[m] = p < P;
-    if (!pok[m]) p = P - 1;
-    c2[m] = (int)(p % G2); p /= G2;
-    c1[m] = (int)(p % G1); p /= G1;
-    c0[m] = (int)(p % G0); p /= G0;
+    pok[m] = p < Pc;
+    if (!pok[m]) p = Pc - 1;
+    plin[m] = p;
+    c2[m] = (int)(p % E2); p /= E2;
+    c1[m] = (int)(p % E1); p /= E1;
+    c0[m] = (int)(p % E0); p /= E0;
     pn[m] = (int)p;
+    if (strided) {
+      c0[m] = c0[m] * g.s[0] + r0; c1[m] = c1[m] * g.s[1] + r1; c2[m] = c2[m] * g.s[2] + r2;
+      plin[m] = (((int64_t)pn[m] * G0 + c0[m]) * G1 + c1[m]) * G2 + c2[m];
+    }
   }
   f32x4 acc[GT_MF][4];
 #pragma unroll
@@ -131,9 +156,9 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
   const int nfv = (R - ct * GT_N + 15) / 16 < 4 ? (R - ct * GT_N + 15) / 16 : 4;
   const int k0n = g.k[0], k1n = g.k[1], k2n = g.k[2];
   const int kchunks = (K + 31) / 32;      // K % 8 == 0: a lane's 8-channel group is whole or absent
-  for (int ta = 0; ta < k0n; ++ta)
-    for (int tb = 0; tb < k1n; ++tb)
-      for (int tc = 0; tc < k2n; ++tc) {
+  for (int ta = ta0; ta < k0n; ta += st0)
+    for (int tb = tb0; tb < k1n; tb += st1)
+      for (int tc = tc0; tc < k2n; tc += st2) {
         const int tap = (ta * k1n + tb) * k2n + tc;
         // source cell of each position under this tap
         const float* src[GT_MF];
@@ -204,7 +229,7 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
 #pragma unroll
   for (int m = 0; m < GT_MF; ++m) {
     if (!pok[m]) continue;
-    const int64_t p = pbase + m * 16 + p16;
+    const int64_t p = plin[m];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
       const int ch = ct * GT_N + nf * 16 + kq * 4;
@@ -501,6 +526,13 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
                                 (g.D[2] + 2 * g.lo[2])
                           : (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
   dim3 grid((unsigned)((P + GT_POS - 1) / GT_POS), (unsigned)((g.Cin + GT_N - 1) / GT_N));
+  if (g.s[0] > 1 || g.s[1] > 1 || g.s[2] > 1) {
+    // one grid slice per residue class, sized for the largest class (residue 0)
+    int64_t pc = g.N;
+    for (int d = 0; d < 3; ++d) pc *= (g.D[d] + g.s[d] - 1) / g.s[d];
+    grid.x = (unsigned)((pc + GT_POS - 1) / GT_POS);
+    grid.z = (unsigned)(g.s[0] * g.s[1] * g.s[2]);
+  }
   hipLaunchKernelGGL(gconv_mfma_kernel<true>, grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
                      (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
                      rows_padded(g.Cin), accumulate, frame, 0);
