@@ -127,6 +127,11 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
                        float* dx, int accumulate, int frame);
 
 // MFMA backward of the 3x3x3 stride-1 trunk convs.
+// wgrad of the 2-channel hi-res conv, LDS-free bf16 MFMA (kernels_conv_wgrad_fewch.hip)
+bool conv_wgrad_c2_supported(const ConvGeom& g, int precision);
+size_t conv_wgrad_c2_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
+int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                         float* dw, float* partial, size_t partial_bytes, int accumulate);
 // trunk wgrad on bf16 MFMA with LDS transpose reads (kernels_conv_wgrad_bf16.hip)
 bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
