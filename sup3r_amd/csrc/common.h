@@ -127,6 +127,10 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
                        float* dx, int accumulate, int frame);
 
 // MFMA backward of the 3x3x3 stride-1 trunk convs.
+bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision);
+size_t conv_wgrad_bf16_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
+int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                               float* dw, float* partial, size_t partial_bytes, int accumulate);
 // wgrad of the 2-channel hi-res conv, LDS-free bf16 MFMA (kernels_conv_wgrad_fewch.hip)
 bool conv_wgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_c2_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);

@@ -215,6 +215,214 @@ int bf_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles_out, int* t0,
   return grid;
 }
 
+
+// ===========================================================================
+// General variant for the discriminator convs: C_in = 32 (CIB = 2 blocks of 16)
+// or tiles of 64 channels (CIB = 4; blockIdx.z walks C_in = 128 / 256), stride 1
+// or 2, any low padding / valid extents.  Same scheme: 12 waves = (s1 tap a) x
+// (ci block, and for CIB = 2 the cout block), 9 taps x NBW accumulators per
+// wave, operands by LDS transpose reads from the natural [cell][channel] bf16
+// images.
+//   stride 1: 4 x 4 x 16 positions per tile (halo 6 x 6 x 18 cells)
+//   stride 2: 2 x 2 x 16 positions per tile (halo 5 x 5 x 33 cells, stored with
+//             the t index de-interleaved by parity so that the cells 2 t + c of
+//             consecutive positions are consecutive in LDS)
+template <int CIB, int STR>
+struct BfGen {
+  static constexpr int T0 = STR == 1 ? 4 : 2, T1 = STR == 1 ? 4 : 2, T2 = 16;
+  static constexpr int G0 = (T0 - 1) * STR + 3, G1 = (T1 - 1) * STR + 3, G2 = (T2 - 1) * STR + 3;
+  static constexpr int HP = G0 * G1 * G2;
+  static constexpr int NP = T0 * T1 * T2;
+  static constexpr int CB = CIB * 32;               // bytes per halo cell
+  static constexpr int NBW = CIB / 2;               // cout blocks per wave
+  static constexpr int XS = HP * CB;
+  static constexpr size_t LDS = (size_t)XS + NP * 64;
+  // LDS slot of halo t index th
+  __device__ static __forceinline__ int tau(int th) {
+    return STR == 1 ? th : (th & 1) * ((G2 + 1) / 2) + (th >> 1);
+  }
+  // 32-B segment swizzle key of LDS slot u (see conv3_wgrad_bf16_kernel)
+  __device__ static __forceinline__ int key(int u) {
+    return CIB == 4 ? (((u >> 1) & 1) | (((u >> 3) & 1) << 1)) : ((u >> 3) & 1);
+  }
+};
+
+template <int CIB, int STR>
+__global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy,
+    float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
+    int tiles2, int n_tiles) {
+  using W = BfGen<CIB, STR>;
+  constexpr int T1 = W::T1, T2 = W::T2, G1 = W::G1, G2 = W::G2, HP = W::HP, NP = W::NP;
+  constexpr int CB = W::CB, NBW = W::NBW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;
+  char* ds = smem + W::XS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane & 15, kg = lane >> 4;
+  const int ta = wave >> 2, w4 = wave & 3;
+  const int cb = CIB == 4 ? w4 : (w4 & 1);
+  const int nb0 = CIB == 4 ? 0 : (w4 >> 1);
+  const int ct = blockIdx.y;
+  const int ci0 = blockIdx.z * (CIB * 16);
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+  const int Cin = g.Cin, Cout = g.Cout;
+
+  f32x4 acc[9][NBW];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int a_off[3][2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int th = (8 * (kg & 1) + 4 * h + (q >> 2)) * STR + c;
+      const int u = W::tau(th);
+      a_off[c][h] = ((ta * G1 + (kg >> 1) * STR) * G2 + u) * CB + ((cb ^ W::key(u)) << 5) + ((q & 3) << 3);
+    }
+  int b_off[NBW][2];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pl = 8 * kg + 4 * h + (q >> 2);
+      b_off[nb][h] = pl * 64 + (((nb0 + nb) ^ ((pl >> 3) & 1)) << 5) + ((q & 3) << 3);
+    }
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int tr = tile;
+    const int t2i = tr % tiles2; tr /= tiles2;
+    const int t1i = tr % tiles1; tr /= tiles1;
+    const int t0i = tr % tiles0; tr /= tiles0;
+    const int n = tr;
+    const int org0 = t0i * W::T0, org1 = t1i * T1, org2 = t2i * T2;
+    __syncthreads();
+    // ---- stage the x halo: cells x (CIB * 4) float4 -> bf16
+    constexpr int CH = CIB * 4;
+    for (int item = tid; item < HP * CH; item += BNT) {
+      const int hp = item / CH, ch = item % CH;
+      int h = hp;
+      const int c2 = h % G2; h /= G2;
+      const int c1 = h % G1; h /= G1;
+      const int c0 = h;
+      int i0 = org0 * STR + c0 - g.lo[0], i1 = org1 * STR + c1 - g.lo[1],
+          i2 = org2 * STR + c2 - g.lo[2];
+      if (g.pad_mode == S3_PAD_REFLECT) {
+        i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
+      }
+      // outside the tensor: zero padding, or cells feeding only masked outputs
+      const bool valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2 &&
+                         ci0 + ch * 4 < Cin;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (valid)
+        v = *reinterpret_cast<const float4*>(
+            x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * Cin + ci0 + ch * 4);
+      const int u = W::tau(c2);
+      *reinterpret_cast<uint2*>(xs + ((c0 * G1 + c1) * G2 + u) * CB + (((ch >> 2) ^ W::key(u)) << 5) +
+                                ((ch & 3) << 3)) = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+    }
+    // ---- stage the dPre tile: NP positions x 8 float4
+    for (int item = tid; item < NP * (BCT / 4); item += BNT) {
+      const int pl = item >> 3, ch = item & 7;
+      const int row = pl / T2, tt = pl % T2;
+      const int o0 = org0 + row / T1, o1 = org1 + row % T1, o2 = org2 + tt;
+      const int co = ct * BCT + ch * 4;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && co < Cout)
+        v = *reinterpret_cast<const float4*>(
+            dy + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * Cout + co);
+      *reinterpret_cast<uint2*>(ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3)) =
+          make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+    }
+    __syncthreads();
+    // ---- k-steps of 32 positions (2 rows x 16 t)
+#pragma unroll
+    for (int ks = 0; ks < NP / 32; ++ks) {
+      // rows 2 ks, 2 ks + 1 of the tile: r0 = (2 ks) / T1, r1 = (2 ks) % T1 + (kg >> 1)
+      const int rowb = ((((2 * ks) / T1) * STR * G1) + ((2 * ks) % T1) * STR) * G2 * CB;
+      bf16x8 bfr[NBW];
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        const s16x4 lo = lds_tr(ds + b_off[nb][0] + ks * 32 * 64);
+        const s16x4 hi = lds_tr(ds + b_off[nb][1] + ks * 32 * 64);
+        bfr[nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const s16x4 lo = lds_tr(xs + a_off[c][0] + rowb + b * G2 * CB);
+          const s16x4 hi = lds_tr(xs + a_off[c][1] + rowb + b * G2 * CB);
+          const bf16x8 afr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb)
+            acc[b * 3 + c][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nb], acc[b * 3 + c][nb], 0, 0, 0);
+        }
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * 27 * Cin * Cout;
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int co = ct * BCT + (nb0 + nb) * 16 + q;
+    if (co < Cout) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = ci0 + cb * 16 + kg * 4 + r;
+          if (ci < Cin) out[((size_t)(ta * 9 + t) * Cin + ci) * Cout + co] = acc[t][nb][r];
+        }
+    }
+  }
+}
+
+template <int CIB, int STR>
+int bf_gen_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t0, int* t1, int* t2) {
+  using W = BfGen<CIB, STR>;
+  *t0 = (g.O[0] + W::T0 - 1) / W::T0; *t1 = (g.O[1] + W::T1 - 1) / W::T1;
+  *t2 = (g.O[2] + W::T2 - 1) / W::T2;
+  *n_tiles = g.N * *t0 * *t1 * *t2;
+  const int n_ct = (g.Cout + BCT - 1) / BCT;
+  const int n_cit = (g.Cin + CIB * 16 - 1) / (CIB * 16);
+  int grid = ctx->num_cu / (n_ct * n_cit);
+  if (grid < 1) grid = 1;
+  if (grid > *n_tiles) grid = *n_tiles;
+  return grid;
+}
+
+template <int CIB, int STR>
+int bf_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy, float* dw,
+                  float* partial, size_t partial_bytes, int accumulate) {
+  using W = BfGen<CIB, STR>;
+  int n_tiles, t0, t1, t2;
+  const int grid = bf_gen_grid<CIB, STR>(ctx, g, &n_tiles, &t0, &t1, &t2);
+  const size_t need = (size_t)grid * 27 * g.Cin * g.Cout * sizeof(float);
+  if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_gen: partial buffer too small");
+  auto kern = conv_wgrad_bf16_gen_kernel<CIB, STR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS));
+    attr_set = true;
+  }
+  const int n_ct = (g.Cout + BCT - 1) / BCT;
+  const int n_cit = (g.Cin + CIB * 16 - 1) / (CIB * 16);
+  hipLaunchKernelGGL(kern, dim3(grid, n_ct, n_cit), dim3(BNT), W::LDS, ctx->stream, x, dy, partial,
+                     g, t0, t1, t2, n_tiles);
+  S3_HIP(ctx, hipGetLastError());
+  const int64_t wsize = (int64_t)27 * g.Cin * g.Cout;
+  int rg = (int)((wsize + 255) / 256);
+  if (rg > 4096) rg = 4096;
+  hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial, grid,
+                     wsize, dw, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 }  // namespace
 
 bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision) {
@@ -254,4 +462,28 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                      ctx->stream, partial, grid, wsize, dw, accumulate);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
+}
+
+// ---- general variant (discriminator convs)
+bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision) {
+  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_WGRAD_BF16")) return false;
+  if (g.d2s != 1 || g.Cin % 32 != 0 || g.Cin < 32 || g.Cout % 4 != 0 || g.Cout < 16) return false;
+  if (g.Cin > 64 && g.Cin % 64 != 0) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g.k[d] != 3 || g.s[d] != g.s[0] || (g.s[d] != 1 && g.s[d] != 2)) return false;
+  return g.O[2] >= 8 && (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 512;
+}
+
+size_t conv_wgrad_bf16_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
+  return (size_t)ctx->num_cu * 27 * g.Cin * g.Cout * sizeof(float);   // grid <= CU count
+}
+
+int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                               float* dw, float* partial, size_t partial_bytes, int accumulate) {
+  const bool s2 = g.s[0] == 2;
+  if (g.Cin == 32)
+    return s2 ? bf_gen_launch<2, 2>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
+              : bf_gen_launch<2, 1>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
+  return s2 ? bf_gen_launch<4, 2>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
+            : bf_gen_launch<4, 1>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
 }

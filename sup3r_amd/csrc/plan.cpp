@@ -45,7 +45,7 @@ struct OpRec {
   void* packed = nullptr;
   uint64_t packed_version = 0;
   // MFMA backward (training plans)
-  bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false;
+  bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false;
   ConvGeom dg;                 // geometry of the dgrad-as-conv launch
   float* dg_w32 = nullptr;     // flipped / transposed fp32 filter
   void* dg_wbf = nullptr;      // its bf16 slabs (bf16 mode)
@@ -378,7 +378,11 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
           o.wgrad_c2 = !o.fewpos && conv_wgrad_c2_supported(g, precision);
           if (o.wgrad_c2)
             max_partial = std::max(max_partial, conv_wgrad_c2_partial_bytes(ctx, g));
-          if (!o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && conv_wgrad_gen_supported(g)) {
+          o.wgrad_bf16_gen = !o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 &&
+                             conv_wgrad_bf16_gen_supported(g, precision);
+          if (o.wgrad_bf16_gen)
+            max_partial = std::max(max_partial, conv_wgrad_bf16_gen_partial_bytes(ctx, g));
+          if (!o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_bf16_gen && conv_wgrad_gen_supported(g)) {
             o.wgrad_gen = true;
             max_partial = std::max(max_partial, conv_wgrad_gen_partial_bytes(ctx, g));
           }
@@ -911,6 +915,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             rc = launch_conv_fewpos_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, accumulate_wgrad);
           else if (o.wgrad_c2)
             rc = launch_conv_wgrad_c2(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+          else if (o.wgrad_bf16_gen)
+            rc = launch_conv_wgrad_bf16_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_gen)
             rc = launch_conv_wgrad_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16)

@@ -480,3 +480,43 @@ def test_trunk_wgrad_bf16_transpose_read_kernel(monkeypatch):
         assert rms < 1e-2, (i, rms)
     # the two kernels were really different ones
     assert any(np.abs(a - b).max() > 0 for a, b in zip(g_bf, g_32))
+
+
+def test_disc_wgrad_bf16_transpose_read_general_kernel(monkeypatch):
+    """conv_wgrad_bf16_gen_kernel — C_in 32 / 64 / 128 (two channel tiles),
+    strides 1 and 2, valid and zero 'same' padding, ragged tiles — and the
+    LDS-free 2-channel kernel of the first layer: weight gradients against
+    the oracle (bf16-mode bound) and against the exact fp32-MFMA kernels of
+    the same plan (SUP3R_AMD_NO_WGRAD_BF16 / _C2: rel. rms < 1e-2)."""
+    rng = np.random.default_rng(33)
+
+    def conv(f, s, pad='valid'):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': pad},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(32, 2) + conv(64, 1, 'same') + conv(128, 2) + \
+        conv(128, 1, 'same') + [{'class': 'Flatten'},
+                                {'class': 'Dense', 'units': 1}]
+    shape = (2, 31, 30, 69, 2)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    ref.backward(dy)
+
+    def grads():
+        net = _hip_net(spec, ref.weights, precision='bf16')
+        ph = net.plan(shape, training=True)
+        ph.forward(net.dev.to_device(x))
+        ph.backward(net.dev.to_device(dy), need_dx=False)
+        return [np.array(g) for g in net.grads]
+    g_bf = grads()
+    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_BF16', '1')
+    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_C2', '1')
+    g_32 = grads()
+    gmax = max(float(np.abs(g).max()) for g in ref.grads)
+    for i, (a, b, r) in enumerate(zip(g_bf, g_32, ref.grads)):
+        assert np.abs(a - r).max() < 1e-1 * np.abs(r).max() + 1e-3 * gmax, i
+        rms = np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean())
+        assert rms < 1e-2, (i, rms)
+    assert sum(np.abs(a - b).max() > 0 for a, b in zip(g_bf, g_32)) >= 5
