@@ -152,6 +152,8 @@ int launch_conv_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x,
 // filter over the (D+2)^3 padded frame (zero boundary), followed by the
 // adjoint of the virtual padding (fold) — kernels_conv_mfma.hip
 bool conv_dgrad_mfma_supported(const ConvGeom& g, int precision);
+ConvGeom conv_dgrad_valid_geom(const ConvGeom& g);
+bool conv_dgrad_mfma_valid_supported(const ConvGeom& g, int precision);
 ConvGeom conv_dgrad_geom(const ConvGeom& g);
 int launch_conv_dgrad_pack(s3_ctx* ctx, const ConvGeom& g, const float* w,
                            float* wt);

@@ -568,6 +568,22 @@ bool conv_dgrad_mfma_supported(const ConvGeom& g, int precision) {
   return conv_mfma_supported(conv_dgrad_geom(g), precision);
 }
 
+// valid-padded forward conv (lo = 0, O = D - 2): its data gradient is the full
+// correlation of dPre with the flipped filter and lands directly on x's grid
+// (no padded frame, no fold)
+ConvGeom conv_dgrad_valid_geom(const ConvGeom& g) {
+  ConvGeom d = conv_dgrad_geom(g);
+  for (int q = 0; q < 3; ++q) d.O[q] = g.D[q];
+  return d;
+}
+
+bool conv_dgrad_mfma_valid_supported(const ConvGeom& g, int precision) {
+  if (g.pad_mode == S3_PAD_REFLECT || g.d2s != 1) return false;
+  for (int q = 0; q < 3; ++q)
+    if (g.k[q] != 3 || g.s[q] != 1 || g.lo[q] != 0 || g.O[q] != g.D[q] - 2) return false;
+  return conv_mfma_supported(conv_dgrad_valid_geom(g), precision);
+}
+
 int launch_conv_dgrad_pack(s3_ctx* ctx, const ConvGeom& g, const float* w,
                            float* wt) {
   const int64_t total = (int64_t)27 * g.Cin * g.Cout;

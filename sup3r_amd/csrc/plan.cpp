@@ -46,6 +46,7 @@ struct OpRec {
   uint64_t packed_version = 0;
   // MFMA backward (training plans)
   bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false;
+  bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
   ConvGeom dg;                 // geometry of the dgrad-as-conv launch
   float* dg_w32 = nullptr;     // flipped / transposed fp32 filter
   void* dg_wbf = nullptr;      // its bf16 slabs (bf16 mode)
@@ -387,12 +388,16 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             max_partial = std::max(max_partial, conv_wgrad_gen_partial_bytes(ctx, g));
           }
           o.dgrad_mfma = conv_dgrad_mfma_supported(g, precision);
+          if (!o.dgrad_mfma && !o.fewpos && precision == S3_PREC_BF16 &&
+              conv_dgrad_mfma_valid_supported(g, precision)) {
+            o.dgrad_mfma = o.dgrad_valid = true;
+          }
           o.gconv_dgrad = !o.dgrad_mfma && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
           if (o.gconv_dgrad && g.pad_mode == S3_PAD_REFLECT)
             max_dxp = std::max(max_dxp, (size_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
                                             (g.D[2] + 2 * g.lo[2]) * g.Cin * sizeof(float));
           if (o.dgrad_mfma) {
-            o.dg = conv_dgrad_geom(g);
+            o.dg = o.dgrad_valid ? conv_dgrad_valid_geom(g) : conv_dgrad_geom(g);
             max_dxp = std::max(max_dxp, (size_t)o.dg.N * o.dg.O[0] * o.dg.O[1] * o.dg.O[2] * o.dg.Cout * sizeof(float));
           }
         }
@@ -940,8 +945,14 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               o.dg_version = P->version;
             }
             const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.dg_wbf : (const void*)o.dg_w32;
-            rc = launch_conv_mfma_fwd(ctx, o.dg, pl->precision, dpre, wp, nullptr, nullptr, pl->dxp, ConvIO());
+            rc = launch_conv_mfma_fwd(ctx, o.dg, pl->precision, dpre, wp, nullptr, nullptr,
+                                      o.dgrad_valid ? dst : pl->dxp, ConvIO());
             if (rc) return rc;
+            if (o.dgrad_valid) {
+              rc = grad_deliver(pl, d.in0, dst);
+              if (rc) return rc;
+              break;
+            }
             GatherGeom fg;
             fg.kind = S3_OP_PAD; fg.N = g.N;
             for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2; fg.lo[q] = 1; }

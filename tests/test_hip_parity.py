@@ -520,3 +520,41 @@ def test_disc_wgrad_bf16_transpose_read_general_kernel(monkeypatch):
         rms = np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean())
         assert rms < 1e-2, (i, rms)
     assert sum(np.abs(a - b).max() > 0 for a, b in zip(g_bf, g_32)) >= 5
+
+
+def test_valid_conv_dgrad_on_halo_tile_kernel(monkeypatch):
+    """Data gradient of valid-padded stride-1 convs with 64 output channels
+    (discriminator 32 -> 64, 64 -> 64) as a full correlation on the halo-tile
+    MFMA kernel, written straight onto x's grid: against the oracle
+    (bf16-mode bound) and against the gather-MFMA data gradient
+    (SUP3R_AMD_NO_MFMA_BWD=1, same bf16 operands: rel. rms < 1e-2)."""
+    rng = np.random.default_rng(35)
+
+    def conv(f, s, pad='valid'):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': pad},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(64, 1) + conv(64, 1) + \
+        [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (2, 15, 17, 31, 2)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = ref.backward(dy)
+
+    def run():
+        net = _hip_net(spec, ref.weights, precision='bf16')
+        ph = net.plan(shape, training=True)
+        ph.forward(net.dev.to_device(x))
+        dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
+        return dx, [np.array(g) for g in net.grads]
+    dx, g = run()
+    monkeypatch.setenv('SUP3R_AMD_NO_MFMA_BWD', '1')
+    dx2, g2 = run()
+    assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
+    rms = np.sqrt(((dx - dx2) ** 2).mean()) / np.sqrt((dx2 ** 2).mean())
+    assert rms < 1e-2, rms
+    for a, b, r in zip(g, g2, ref.grads):
+        assert np.abs(a - r).max() < 1e-1 * np.abs(r).max() + 1e-3
+        assert np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()) < 2e-2
