@@ -638,12 +638,21 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
       // fall back to 128-position ones when the grid would not fill the chip
       const int64_t big = (int64_t)g.N * ((g.O[0] + 3) / 4) * ((g.O[1] + 7) / 8) * ((g.O[2] + 15) / 16);
       tile = big >= ctx->num_cu ? 4 : 3;
+      // extents that are multiples of 6 rather than of 4 / 8 (the 18 x 18 x 290
+      // padded frame of the trunk's data gradient): 6 x 6 x 16 tiles waste
+      // 5 % of the positions instead of 55 %; compare rounds x tile size
+      const int64_t six = (int64_t)g.N * ((g.O[0] + 5) / 6) * ((g.O[1] + 5) / 6) * ((g.O[2] + 15) / 16);
+      const int64_t ncu = ctx->num_cu;
+      if (tile == 4 && six >= ncu && ((six + ncu - 1) / ncu) * 576 < ((big + ncu - 1) / ncu) * 512 &&
+          !getenv("SUP3R_AMD_NO_TILE66"))
+        tile = 7;
     }
     if (tile == 1) return launch_bf16<2, 4, 4>(ctx, g, x, packed, bias, res, y, io);
     if (tile == 2) return launch_bf16<4, 4, 8>(ctx, g, x, packed, bias, res, y, io);
     if (tile == 3) return launch_bf16<2, 4, 8>(ctx, g, x, packed, bias, res, y, io);
     if (tile == 4) return launch_bf16<4, 8, 16>(ctx, g, x, packed, bias, res, y, io);
     if (tile == 6) return launch_bf16<4, 8, 8>(ctx, g, x, packed, bias, res, y, io);
+    if (tile == 7) return launch_bf16<6, 6, 12>(ctx, g, x, packed, bias, res, y, io);
     return launch_bf16<4, 4, 4>(ctx, g, x, packed, bias, res, y, io);
   }
   // f32: the filters are read in canonical layout; `packed` is unused
