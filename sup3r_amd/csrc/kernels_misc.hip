@@ -147,6 +147,46 @@ __global__ void gather_bwd_kernel(const float* __restrict__ dout,
   }
 }
 
+// fold of a reflect / zero padded frame (adjoint of S3_OP_PAD) on float4
+// channel groups: the index math of a cell is shared by 4 channels
+__global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
+                                       float* __restrict__ din, GatherGeom g) {
+  const int c4n = g.Ci >> 2;
+  const int64_t total = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * c4n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx;
+    const int c4 = (int)(r % c4n); r /= c4n;
+    const int i2 = (int)(r % g.Di[2]); r /= g.Di[2];
+    const int i1 = (int)(r % g.Di[1]); r /= g.Di[1];
+    const int i0 = (int)(r % g.Di[0]); r /= g.Di[0];
+    const int n = (int)r;
+    int cand[3][3], cnt[3];
+    const int ii[3] = {i0, i1, i2};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int nI = g.Di[d], lo = g.lo[d], nO = g.Do[d];
+      cnt[d] = 0;
+      cand[d][cnt[d]++] = ii[d] + lo;
+      if (g.pad_mode == S3_PAD_REFLECT) {
+        if (ii[d] >= 1 && ii[d] <= lo) cand[d][cnt[d]++] = lo - ii[d];
+        const int m = 2 * (nI - 1) - ii[d] + lo;
+        if (ii[d] <= nI - 2 && m < nO && m >= nI + lo) cand[d][cnt[d]++] = m;
+      }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < cnt[0]; ++a)
+      for (int b = 0; b < cnt[1]; ++b)
+        for (int e = 0; e < cnt[2]; ++e) {
+          const float4 v = *reinterpret_cast<const float4*>(
+              dout + ((((int64_t)n * g.Do[0] + cand[0][a]) * g.Do[1] + cand[1][b]) * g.Do[2] +
+                      cand[2][e]) * g.Co + c4 * 4);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    *reinterpret_cast<float4*>(din + idx * 4) = acc;
+  }
+}
+
 // ------------------------------------------------------------- elementwise
 __device__ inline float act_f(float v, int act, float alpha) {
   // one select for every kind (slope 1 = identity, 0 = ReLU, alpha = Leaky):
@@ -553,6 +593,12 @@ int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
                       float* din) {
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  if (g.kind == S3_OP_PAD && g.Ci == g.Co && (g.Ci & 3) == 0) {
+    hipLaunchKernelGGL(gather_bwd_pad4_kernel, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,
+                       ctx->stream, dout, din, g);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, dout, din, g);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
