@@ -54,7 +54,7 @@ enum {
   S3_PREC_BF16 = 1,  /* v_mfma_f32_16x16x32_bf16, fp32 accumulate            */
   S3_PREC_BF16X3 = 2 /* 3-term bf16 split (hi*hi + hi*lo + lo*hi), ~fp32     */
 };
-enum { S3_LOSS_MAE = 0, S3_LOSS_MSE = 1 };
+enum { S3_LOSS_MAE = 0, S3_LOSS_MSE = 1, S3_LOSS_EXP = 2 };
 enum { S3_BUF_W = 0, S3_BUF_G = 1, S3_BUF_M = 2, S3_BUF_V = 3 };
 
 typedef struct s3_ctx s3_ctx;
@@ -176,6 +176,43 @@ int s3_loss_content_masked(s3_ctx* ctx, int kind, const float* a, int c_a,
 int s3_loss_rel_bce(s3_ctx* ctx, const float* disc_true, const float* disc_gen,
                     int n, float scale, float* loss_out, float* d_true,
                     float* d_gen);
+
+/* ---- structured content losses -----------------------------
+ * sup3r/utilities/loss_metrics.py: every loss there is M(F(gen), F(true)) with
+ * M = MeanAbsoluteError / MeanSquaredError (s3_loss_content) and F a feature
+ * map.  s3_lossmap_fwd writes F(x) for x = (n, s1, s2, t, c) fp32 (t = 1 for
+ * 4-D), first c_used channels; s3_lossmap_bwd ADDS F'(x)^T g_out into
+ * d_x[..., :c_used].  Shapes of F(x):
+ *   S3_LMAP_DERIV_S  (n, s1, s2, t, c_used)   d/ds1 + d/ds2, np.gradient scheme
+ *                                             (SpatialDerivativeLoss :228-260)
+ *   S3_LMAP_DERIV_T  (n, s1, s2, t, c_used)   d/dt (TemporalDerivativeLoss :263-294)
+ *   S3_LMAP_MATERIAL (n, s1, s2, t, c_used/2) du/dt + u du/ds1 + v du/ds2 of each
+ *                                             (u, v) pair (MaterialDerivativeLoss :150-225)
+ *   S3_LMAP_MEAN_S   (n, t, c_used)           mean over (s1, s2) (CoarseMseLoss :297-322)
+ *   S3_LMAP_EXT_S    2 x (n, t, c_used)       [min | max] over (s1, s2) (:325-357)
+ *   S3_LMAP_EXT_T    2 x (n, s1, s2, c_used)  [min | max] over t (:360-392)
+ *   S3_LMAP_COARSEN  backward only (forward = s3_coarsen): p0 = s_enhance, p1 =
+ *                    t_enhance, p2 = S3_TC_AVERAGE | S3_TC_SUBSAMPLE; g_out has
+ *                    c channels (LowResLoss :488-638)
+ * work: spatial reductions n * 64 * t * c_used floats; extremes adjoint
+ * additionally 2 * (size of one extremum) in front.  fx (bwd, extremes only) =
+ * the forward map of the same x.  Ties share the gradient equally, as
+ * tf.reduce_min / reduce_max do. */
+enum { S3_LMAP_DERIV_S = 0, S3_LMAP_DERIV_T = 1, S3_LMAP_MATERIAL = 2, S3_LMAP_MEAN_S = 3,
+       S3_LMAP_EXT_S = 4, S3_LMAP_EXT_T = 5, S3_LMAP_COARSEN = 6 };
+int s3_lossmap_fwd(s3_ctx* ctx, int kind, const float* x, int n, int s1, int s2,
+                   int t, int c, int c_used, int p0, int p1, int p2, float* out,
+                   float* work);
+int s3_lossmap_bwd(s3_ctx* ctx, int kind, const float* x, const float* fx,
+                   const float* g_out, int n, int s1, int s2, int t, int c,
+                   int c_used, int p0, int p1, int p2, float* d_x, float* work);
+/* MmdLoss (loss_metrics.py:62-147): gaussian-kernel maximum mean discrepancy
+ * over all pairs of the n observations at every one of the n_pos positions;
+ * a, b = (n, n_pos, c_*).  loss_out = unweighted value; d_a (nullable) +=
+ * weight * d loss / d a. */
+int s3_loss_mmd(s3_ctx* ctx, const float* a, int c_a, const float* b, int c_b, int n,
+                int64_t n_pos, int c_used, float sigma, float weight, float* loss_out,
+                float* d_a);
 
 /* ---- small tensor utilities on the ctx stream --------------------------
  * channel slice/concat used by _combine_loss_input / get_hr_exo_input

@@ -12,9 +12,10 @@ __version__ = '0.1.0'
 
 from .gan import Sup3rGan  # noqa: E402,F401
 from .condmom import Sup3rCondMom  # noqa: E402,F401
+from .dc import Sup3rGanDC  # noqa: E402,F401
 from .forward_pass import ChunkSlicer, ForwardPass  # noqa: E402,F401
 from .multi_step import MultiStepGan  # noqa: E402,F401
 
-__all__ = ['Sup3rGan', 'Sup3rCondMom', 'MultiStepGan', 'ForwardPass',
+__all__ = ['Sup3rGan', 'Sup3rCondMom', 'Sup3rGanDC', 'MultiStepGan', 'ForwardPass',
            'ChunkSlicer',
            '__version__']

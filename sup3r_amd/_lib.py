@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('SUP3R_AMD_LIB') or os.path.join(
 
 # enums (include/sup3r_hip.h)
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
-LOSS_MAE, LOSS_MSE = 0, 1
+LOSS_MAE, LOSS_MSE, LOSS_EXP = 0, 1, 2
 BUF_W, BUF_G, BUF_M, BUF_V = 0, 1, 2, 3
 PRECISIONS = {'f32': PREC_F32, 'bf16': PREC_BF16}
 
@@ -27,6 +27,7 @@ EXPORTS = [
     's3_plan_backward', 's3_plan_tensor', 's3_plan_workspace_bytes',
     's3_plan_profile_begin', 's3_plan_profile_end',
     's3_plan_op_is_mfma', 's3_loss_content', 's3_loss_content_masked', 's3_loss_rel_bce',
+    's3_lossmap_fwd', 's3_lossmap_bwd', 's3_loss_mmd',
     's3_copy_channels', 's3_affine_channels', 's3_fill',
     's3_coarsen', 's3_gaussian_smooth', 's3_chunk_stats',
     's3_host_register', 's3_host_unregister', 's3_d2h_window',
@@ -108,6 +109,12 @@ def lib():
         's3_loss_content_masked': (i32, [vp, i32, vp, i32, vp, i32, vp, i32,
                                          i32, i64, f32, vp, vp, i32]),
         's3_loss_rel_bce': (i32, [vp, vp, vp, i32, f32, vp, vp, vp]),
+        's3_lossmap_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32,
+                                 i32, i32, i32, vp, vp]),
+        's3_lossmap_bwd': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32,
+                                 i32, i32, i32, i32, vp, vp]),
+        's3_loss_mmd': (i32, [vp, vp, i32, vp, i32, i32, i64, i32, f32, f32,
+                              vp, vp]),
         's3_copy_channels': (i32, [vp, vp, i32, i32, vp, i32, i32, i32, i64,
                                    i32]),
         's3_affine_channels': (i32, [vp, vp, vp, i32, i64, pf, pf]),

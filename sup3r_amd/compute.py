@@ -17,25 +17,75 @@ from .engine import Device, Network
 from .utilities import LossValue, camel_to_underscore
 
 CONTENT_KINDS = {'MeanAbsoluteError': _lib.LOSS_MAE,
-                 'MeanSquaredError': _lib.LOSS_MSE}
+                 'MeanSquaredError': _lib.LOSS_MSE,
+                 'ExpLoss': _lib.LOSS_EXP}
+
+# structured content losses of sup3r/utilities/loss_metrics.py that have
+# MI355X kernels (kernels_loss.hip): name -> (feature map, metric on the map)
+STRUCTURED_KINDS = {
+    'SpatialDerivativeLoss': ('deriv_s', _lib.LOSS_MAE),
+    'TemporalDerivativeLoss': ('deriv_t', _lib.LOSS_MAE),
+    'MaterialDerivativeLoss': ('material', _lib.LOSS_MAE),
+    'CoarseMseLoss': ('mean_s', _lib.LOSS_MSE),
+    'SpatialExtremesLoss': ('ext_s', _lib.LOSS_MAE),
+    'TemporalExtremesLoss': ('ext_t', _lib.LOSS_MAE),
+    'LowResLoss': ('lowres', None),
+    'MmdLoss': ('mmd', None),
+}
+LMAP = {'deriv_s': 0, 'deriv_t': 1, 'material': 2, 'mean_s': 3, 'ext_s': 4,
+        'ext_t': 5, 'coarsen': 6}
+SLOTS_PER_TERM = 4          # scalar slots a term may use (value = sum coef * slot)
+MAX_TERMS = 14
+
+
+def _lowres_kwargs(kw):
+    """LowResLoss.__init__ (loss_metrics.py:500-540)"""
+    out = {'s_enhance': 1, 't_enhance': 1, 't_method': 'average',
+           'tf_loss': 'MeanSquaredError', 'ex_loss': None}
+    for k, v in kw.items():
+        if k not in out:
+            raise TypeError(f"LowResLoss got an unexpected keyword '{k}'")
+        out[k] = v
+    out['t_method'] = str(out['t_method']).casefold()
+    if out['tf_loss'] not in ('MeanSquaredError', 'MeanAbsoluteError'):
+        raise KeyError(f"LowResLoss tf_loss \"{out['tf_loss']}\" has no MI355X "
+                       "kernel (MeanSquaredError | MeanAbsoluteError)")
+    if out['ex_loss'] not in (None, 'SpatialExtremesLoss',
+                              'TemporalExtremesLoss'):
+        raise KeyError(out['ex_loss'])       # EX_LOSS_METRICS lookup
+    return out
 
 
 def parse_loss_spec(loss):
     """``get_loss_fun`` spec handling (abstract.py:461-502): str | dict with
-    optional ``term_weights``.  Returns [(name, kind, weight), ...]."""
+    optional ``term_weights``.  Returns [(name, kind, weight, kwargs), ...];
+    kind is a pointwise S3_LOSS_* code or the name of a feature map."""
     spec = {loss: {}} if isinstance(loss, str) else dict(loss)
     names = [k for k in spec if k != 'term_weights']
     weights = spec.get('term_weights', [1.0] * len(names))
+    if len(names) > MAX_TERMS:
+        raise ValueError(f'at most {MAX_TERMS} loss terms')
     terms = []
     for n, w in zip(names, weights):
-        if n not in CONTENT_KINDS:
+        kw = dict(spec[n] or {})
+        if n in CONTENT_KINDS:
+            if kw:
+                raise TypeError(f'loss "{n}" takes no kwargs: {kw}')
+            terms.append((n, CONTENT_KINDS[n], float(w), {}))
+        elif n in STRUCTURED_KINDS:
+            if n == 'LowResLoss':
+                kw = _lowres_kwargs(kw)
+            elif n == 'MmdLoss':
+                if set(kw) - {'sigma'}:
+                    raise TypeError(f'MmdLoss kwargs: {kw}')
+            elif kw:
+                raise TypeError(f'loss "{n}" takes no kwargs: {kw}')
+            terms.append((n, STRUCTURED_KINDS[n][0], float(w), kw))
+        else:
             raise KeyError(
                 'Could not find requested loss function "{}" among the '
                 'content losses with an MI355X kernel ({}).'.format(
-                    n, list(CONTENT_KINDS)))
-        if spec[n]:
-            raise KeyError(f'loss "{n}" takes no kwargs here: {spec[n]}')
-        terms.append((n, CONTENT_KINDS[n], float(w)))
+                    n, list(CONTENT_KINDS) + list(STRUCTURED_KINDS)))
     return terms
 
 
@@ -52,7 +102,7 @@ class HipGanCompute:
     # ---------------------------------------------------------------- utils
     def _scalars(self):
         if self._scal is None:
-            self._scal = self.dev.empty((16,))
+            self._scal = self.dev.empty((4 + SLOTS_PER_TERM * MAX_TERMS,))
         return self._scal
 
     def _ptr(self, t, offset=0):
@@ -141,7 +191,7 @@ class HipGanCompute:
             mask_d = dev.to_device(mask)
             c_used = c_true
         scal = self._scalars()
-        L.s3_fill(dev.ctx, self._ptr(scal), 16, 0.0)
+        L.s3_fill(dev.ctx, self._ptr(scal), scal.numel(), 0.0)
         details = {}
         need_disc = self.disc is not None
         dph_t = dph_g = None
@@ -169,20 +219,32 @@ class HipGanCompute:
                 L.s3_fill(dev.ctx, self._ptr(d_gen_full), d_gen_full.numel(),
                           0.0)
             n_pos = gen_full.numel() // c_true
-            for i, (name, kind, w) in enumerate(loss_terms):
+            term_coefs = []
+            for i, (name, kind, w, kw) in enumerate(loss_terms):
+                slot = 4 + SLOTS_PER_TERM * i
+                dg = d_gen_full if gen_train else None
+                if isinstance(kind, str):
+                    if mask_d is not None:
+                        raise RuntimeError(
+                            f'{name} has no masked (Sup3rCondMom) form')
+                    term_coefs.append(self._structured_term(
+                        name, kind, kw, gen_full, hr_true, c_used, w, scal,
+                        slot, dg))
+                    continue
+                term_coefs.append([1.0])
                 if mask_d is None:
                     rc = L.s3_loss_content(
                         dev.ctx, kind, self._ptr(gen_full), c_true,
                         self._ptr(hr_true), c_true, c_used, n_pos, w,
-                        self._ptr(scal, 4 + i),
-                        self._ptr(d_gen_full) if gen_train else None, 1)
+                        self._ptr(scal, slot),
+                        self._ptr(dg) if gen_train else None, 1)
                 else:
                     rc = L.s3_loss_content_masked(
                         dev.ctx, kind, self._ptr(gen_full), c_true,
                         self._ptr(hr_true), c_true, self._ptr(mask_d),
                         mask_d.shape[-1], c_used, n_pos, w,
-                        self._ptr(scal, 4 + i),
-                        self._ptr(d_gen_full) if gen_train else None, 1)
+                        self._ptr(scal, slot),
+                        self._ptr(dg) if gen_train else None, 1)
                 _lib.check(rc, dev.ctx, 's3_loss_content')
             if need_disc:
                 # adversarial term: roles swapped (base.py:899-901); only
@@ -215,9 +277,12 @@ class HipGanCompute:
             details['loss_disc'] = LossValue(vals[0])
         if train_gen:
             content = 0.0
-            for i, (name, kind, w) in enumerate(loss_terms):
-                details[camel_to_underscore(name)] = LossValue(vals[4 + i])
-                content += w * float(vals[4 + i])
+            for i, (name, kind, w, kw) in enumerate(loss_terms):
+                slot = 4 + SLOTS_PER_TERM * i
+                val = sum(cf * float(vals[slot + j])
+                          for j, cf in enumerate(term_coefs[i]))
+                details[camel_to_underscore(name)] = LossValue(val)
+                content += w * val
             advers = float(vals[1]) if need_disc else 0.0
             details['loss_gen_content'] = LossValue(content)
             details['loss_gen_advers'] = LossValue(advers)
@@ -225,6 +290,145 @@ class HipGanCompute:
                 content + weight_gen_advers * advers)
         loss = details.get(loss_key) if loss_key else None
         return loss, details, hr_gen
+
+    # ------------------------------------------------- structured content losses
+    def _structured_term(self, name, kind, kw, gen, true, c_used, w, scal,
+                         slot, d_gen):
+        """One M(F(gen), F(true)) term of sup3r/utilities/loss_metrics.py on
+        the device: feature maps (s3_lossmap_fwd / s3_coarsen), keras MAE / MSE
+        on the maps (s3_loss_content), adjoint back into ``d_gen``
+        (s3_lossmap_bwd).  Returns the coefficients of the scalar slots whose
+        weighted sum is the term's value."""
+        L, dev = _lib.lib(), self.dev
+        is_5d = gen.dim() == 5
+        n, s1, s2 = (int(v) for v in gen.shape[:3])
+        t = int(gen.shape[3]) if is_5d else 1
+        c = int(gen.shape[-1])
+        dims = (n, s1, s2, t, c, c_used)
+        cls = name
+        if kind in ('deriv_t', 'material', 'ext_t'):
+            assert is_5d, (f'The {cls} is meant to be used on spatiotemporal '
+                           'data only. Received tensor(s) that are not 5D')
+
+        def fmap(code, x, shape, work=None):
+            out = dev.empty(shape)
+            rc = L.s3_lossmap_fwd(dev.ctx, code, self._ptr(x), *dims, 0, 0, 0,
+                                  self._ptr(out),
+                                  self._ptr(work) if work is not None else None)
+            _lib.check(rc, dev.ctx, 's3_lossmap_fwd')
+            return out
+
+        def metric(m, fa, fb, cf, cu, npos, weight, sl, off=0):
+            """loss value -> scal[sl]; returns d loss / d fa (or None)"""
+            d_fa = None
+            if d_gen is not None:
+                d_fa = dev.empty((npos * cf,))
+                L.s3_fill(dev.ctx, self._ptr(d_fa), npos * cf, 0.0)
+            rc = L.s3_loss_content(
+                dev.ctx, m, self._ptr(fa, off), cf, self._ptr(fb, off), cf, cu,
+                npos, weight, self._ptr(scal, sl),
+                self._ptr(d_fa) if d_fa is not None else None, 0)
+            _lib.check(rc, dev.ctx, 's3_loss_content')
+            return d_fa
+
+        def fbwd(code, fx, g_out, p=(0, 0, 0), work=None):
+            rc = L.s3_lossmap_bwd(
+                dev.ctx, code, self._ptr(gen),
+                self._ptr(fx) if fx is not None else None, self._ptr(g_out),
+                *dims, *p, self._ptr(d_gen),
+                self._ptr(work) if work is not None else None)
+            _lib.check(rc, dev.ctx, 's3_lossmap_bwd')
+
+        def extremes(spatial, weight, sl):
+            """(MAE(min) + MAE(max)) / 2 (loss_metrics.py:325-392)"""
+            code = LMAP['ext_s' if spatial else 'ext_t']
+            ne = n * t * c_used if spatial else n * s1 * s2 * c_used
+            slab = n * 64 * t * c_used
+            work = dev.empty((2 * ne + slab,))
+            fa = fmap(code, gen, (2 * ne,), work)
+            fb = fmap(code, true, (2 * ne,), work)
+            g = [metric(_lib.LOSS_MAE, fa, fb, c_used, c_used, ne // c_used,
+                        0.5 * weight, sl + q, off=q * ne) for q in range(2)]
+            if d_gen is not None:
+                import torch
+                fbwd(code, fa, torch.cat(g), work=work)
+            return [0.5, 0.5]
+
+        if kind in ('deriv_s', 'deriv_t'):
+            npos = n * s1 * s2 * t
+            fa = fmap(LMAP[kind], gen, (npos * c_used,))
+            fb = fmap(LMAP[kind], true, (npos * c_used,))
+            g = metric(_lib.LOSS_MAE, fa, fb, c_used, c_used, npos, w, slot)
+            if g is not None:
+                fbwd(LMAP[kind], None, g)
+            return [1.0]
+        if kind == 'material':
+            hub = c_used // 2
+            npos = n * s1 * s2 * t
+            fa = fmap(LMAP[kind], gen, (npos * hub,))
+            fb = fmap(LMAP[kind], true, (npos * hub,))
+            g = metric(_lib.LOSS_MAE, fa, fb, hub, hub, npos, w, slot)
+            if g is not None:
+                fbwd(LMAP[kind], None, g)
+            return [1.0]
+        if kind == 'mean_s':
+            work = dev.empty((n * 64 * t * c_used,))
+            fa = fmap(LMAP[kind], gen, (n * t * c_used,), work)
+            fb = fmap(LMAP[kind], true, (n * t * c_used,), work)
+            g = metric(_lib.LOSS_MSE, fa, fb, c_used, c_used, n * t, w, slot)
+            if g is not None:
+                fbwd(LMAP[kind], None, g)
+            return [1.0]
+        if kind in ('ext_s', 'ext_t'):
+            return extremes(kind == 'ext_s', w, slot)
+        if kind == 'lowres':
+            s_e, t_e = int(kw['s_enhance']), int(kw['t_enhance'])
+            coefs = [1.0]
+            if kw['ex_loss'] is not None:
+                if kw['ex_loss'] == 'TemporalExtremesLoss':
+                    assert is_5d
+                extremes(kw['ex_loss'] == 'SpatialExtremesLoss', w, slot + 1)
+                coefs = [1.0, 0.5, 0.5]
+            if t_e > 1 and kw['t_method'] in ('average', 'subsample'):
+                assert is_5d
+            else:
+                t_e = 1
+            if s1 % s_e or s2 % s_e or t % t_e:
+                raise ValueError('LowResLoss enhancement factors must evenly '
+                                 f'divide the grid {tuple(gen.shape)}')
+            m = CONTENT_KINDS[kw['tf_loss']]
+            meth = _lib.TC_METHODS[kw['t_method'] if t_e > 1 else 'subsample']
+            if s_e <= 1 and t_e <= 1:
+                rc = L.s3_loss_content(
+                    dev.ctx, m, self._ptr(gen), c, self._ptr(true), c, c_used,
+                    n * s1 * s2 * t, w, self._ptr(scal, slot),
+                    self._ptr(d_gen) if d_gen is not None else None, 1)
+                _lib.check(rc, dev.ctx, 's3_loss_content')
+                return coefs
+            o = (n, s1 // s_e, s2 // s_e, t // t_e, c)
+            lo = []
+            for x in (gen, true):
+                y = dev.empty(o)
+                rc = L.s3_coarsen(dev.ctx, self._ptr(x), n, s1, s2, t, c, s_e,
+                                  t_e, meth, self._ptr(y))
+                _lib.check(rc, dev.ctx, 's3_coarsen')
+                lo.append(y)
+            g = metric(m, lo[0], lo[1], c, c_used, o[0] * o[1] * o[2] * o[3],
+                       w, slot)
+            if g is not None:
+                fbwd(LMAP['coarsen'], None, g, p=(s_e, t_e, meth))
+            return coefs
+        if kind == 'mmd':
+            if c_used > 8:
+                raise ValueError('MmdLoss kernel handles at most 8 features')
+            rc = L.s3_loss_mmd(
+                dev.ctx, self._ptr(gen), c, self._ptr(true), c, n,
+                s1 * s2 * t, c_used, float(kw.get('sigma', 1.0)), w,
+                self._ptr(scal, slot),
+                self._ptr(d_gen) if d_gen is not None else None)
+            _lib.check(rc, dev.ctx, 's3_loss_mmd')
+            return [1.0]
+        raise KeyError(kind)
 
     # ------------------------------------------------------------ optimizer
     def apply(self, which, optimizer):

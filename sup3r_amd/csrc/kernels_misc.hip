@@ -397,6 +397,11 @@ __global__ void loss_content_kernel(int kind, const float* __restrict__ a,
     if (kind == S3_LOSS_MAE) {
       acc += fabsf(d);
       g = (d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f);
+    } else if (kind == S3_LOSS_EXP) {
+      // ExpLoss: mean(1 - exp(-(x1 - x2)^2)) (loss_metrics.py:98-118)
+      const float e = __expf(-d * d);
+      acc += 1.f - e;
+      g = 2.f * d * e;
     } else {
       acc += d * d;
       g = 2.f * d;
