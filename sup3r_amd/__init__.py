@@ -15,7 +15,8 @@ from .condmom import Sup3rCondMom  # noqa: E402,F401
 from .dc import Sup3rGanDC  # noqa: E402,F401
 from .forward_pass import ChunkSlicer, ForwardPass  # noqa: E402,F401
 from .multi_step import MultiStepGan  # noqa: E402,F401
+from .batch_queue import DeviceBatchQueue, DsetTuple  # noqa: E402,F401
 
 __all__ = ['Sup3rGan', 'Sup3rCondMom', 'Sup3rGanDC', 'MultiStepGan', 'ForwardPass',
-           'ChunkSlicer',
+           'ChunkSlicer', 'DeviceBatchQueue', 'DsetTuple',
            '__version__']

@@ -1,0 +1,147 @@
+"""TF-free batch queue: the reference's own smoke tests
+(/root/reference/tests/batch_queues/test_bq_general.py:17-98) with a dummy
+sampler.  CPU: queue logic with the oracle transform injected; GPU: the default
+device transform against the oracle on the very same raw batches."""
+import numpy as np
+import pytest
+
+FEATURES = ['windspeed', 'winddirection']
+
+
+class DummySampler:
+    """random crops of random data (≙ sup3r.utilities.pytest.helpers.DummySampler)"""
+
+    def __init__(self, sample_shape, data_shape, batch_size, features, seed=0):
+        if len(sample_shape) == 2:
+            sample_shape = (*sample_shape, 1)
+        self.sample_shape = tuple(sample_shape)
+        self.batch_size = batch_size
+        self.features = list(features)
+        self.rng = np.random.default_rng(seed)
+        self.data = self.rng.standard_normal(
+            (*data_shape, len(features))).astype(np.float32)
+        self.size = self.data.size
+        self.drawn = []
+
+    def __next__(self):
+        out = []
+        for _ in range(self.batch_size):
+            o = [self.rng.integers(0, d - s + 1)
+                 for d, s in zip(self.data.shape[:3], self.sample_shape)]
+            out.append(self.data[o[0]:o[0] + self.sample_shape[0],
+                                 o[1]:o[1] + self.sample_shape[1],
+                                 o[2]:o[2] + self.sample_shape[2]])
+        batch = np.stack(out)
+        self.drawn.append(batch)
+        return batch
+
+
+def _oracle_transform(s_enhance, t_enhance, features):
+    from oracle.transform import transform
+
+    def f(samples, smoothing=None, smoothing_ignore=None,
+          temporal_coarsening_method='subsample'):
+        return transform(np.asarray(samples, np.float64), s_enhance, t_enhance,
+                         features, list(range(len(features))), smoothing,
+                         smoothing_ignore, temporal_coarsening_method)
+    return f
+
+
+def _samplers(sample_shape):
+    return [DummySampler(sample_shape, (10, 10, 20), 4, FEATURES, seed=1),
+            DummySampler(sample_shape, (12, 12, 15), 4, FEATURES, seed=2)]
+
+
+@pytest.mark.parametrize('max_workers', [1, 3])
+def test_batch_queue_reference_smoke(max_workers):
+    """test_batch_queue"""
+    from sup3r_amd.batch_queue import DeviceBatchQueue
+    batcher = DeviceBatchQueue(
+        samplers=_samplers((8, 8, 10)), n_batches=3, batch_size=4, s_enhance=2,
+        t_enhance=2, queue_cap=10, max_workers=max_workers,
+        transform_kwargs={'smoothing_ignore': [], 'smoothing': None},
+        transform=_oracle_transform(2, 2, FEATURES), seed=0)
+    batcher.start()
+    assert len(batcher) == 3
+    n = 0
+    for b in batcher:
+        assert b.low_res.shape == (4, 4, 4, 5, len(FEATURES))
+        assert b.high_res.shape == (4, 8, 8, 10, len(FEATURES))
+        n += 1
+    assert n == 3
+    assert batcher.shapes == ((4, 4, 4, 5, 2), (4, 8, 8, 10, 2))
+    batcher.stop()
+    assert not batcher.queue_thread.is_alive()
+    # a second epoch restarts the thread
+    assert sum(1 for _ in batcher) == 3
+    batcher.stop()
+
+
+def test_spatial_batch_queue_reference_smoke():
+    """test_spatial_batch_queue: time axis of length 1 is squeezed"""
+    from sup3r_amd.batch_queue import DeviceBatchQueue
+    batcher = DeviceBatchQueue(
+        samplers=_samplers((8, 8)), s_enhance=2, t_enhance=1, n_batches=3,
+        batch_size=4, queue_cap=10, max_workers=1,
+        transform_kwargs={'smoothing_ignore': [], 'smoothing': None},
+        transform=_oracle_transform(2, 1, FEATURES), seed=0)
+    batcher.start()
+    assert len(batcher) == 3
+    for b in batcher:
+        assert b.low_res.shape == (4, 4, 4, len(FEATURES))
+        assert b.high_res.shape == (4, 8, 8, len(FEATURES))
+    batcher.stop()
+    assert batcher.shapes == ((4, 4, 4, 2), (4, 8, 8, 2))
+
+
+def test_batch_queue_preflight_errors_and_eager_mode():
+    from sup3r_amd.batch_queue import DeviceBatchQueue
+    tr = _oracle_transform(2, 2, FEATURES)
+    with pytest.raises(AssertionError):          # enhancement vs sample shape
+        DeviceBatchQueue(_samplers((8, 8, 10)), batch_size=4, s_enhance=3,
+                         t_enhance=2, transform=tr)
+    with pytest.raises(AssertionError):          # batch size mismatch
+        DeviceBatchQueue(_samplers((8, 8, 10)), batch_size=8, s_enhance=2,
+                         t_enhance=2, transform=tr)
+    with pytest.raises(AssertionError):          # not a list
+        DeviceBatchQueue(tuple(_samplers((8, 8, 10))), batch_size=4,
+                         transform=tr)
+    bad = _samplers((8, 8, 10))
+    bad[1].features = ['u', 'v']
+    with pytest.raises(AssertionError):
+        DeviceBatchQueue(bad, batch_size=4, s_enhance=2, t_enhance=2,
+                         transform=tr)
+    q = DeviceBatchQueue(_samplers((8, 8, 10)), batch_size=4, n_batches=2,
+                         s_enhance=2, t_enhance=2, mode='eager', transform=tr,
+                         seed=3)
+    batches = list(q)
+    assert len(batches) == 2
+    assert not q.queue_thread.is_alive()         # no thread runs in eager mode
+    assert abs(q.container_weights.sum() - 1) < 1e-6
+
+
+@pytest.mark.gpu
+def test_device_batch_queue_matches_oracle_transform():
+    """default transform = DeviceBatchTransform: the batches handed out equal
+    the oracle transform of the raw batches the samplers produced (FIFO
+    order), smoothing included; tensors live on the device"""
+    import torch
+    from oracle.transform import transform
+    from sup3r_amd.batch_queue import DeviceBatchQueue
+    samplers = [DummySampler((12, 12, 8), (20, 20, 30), 4, FEATURES, seed=5)]
+    kw = {'smoothing': 0.8, 'smoothing_ignore': ['winddirection'],
+          'temporal_coarsening_method': 'average'}
+    q = DeviceBatchQueue(samplers, batch_size=4, n_batches=4, s_enhance=3,
+                         t_enhance=4, queue_cap=2, transform_kwargs=kw, seed=0)
+    got = list(q)
+    q.stop()
+    assert len(got) == 4
+    for b, raw in zip(got, samplers[0].drawn):
+        assert isinstance(b.low_res, torch.Tensor) and b.low_res.is_cuda
+        lr, hr = transform(raw.astype(np.float64), 3, 4, FEATURES, [0, 1],
+                           **{'smoothing': 0.8,
+                              'smoothing_ignore': ['winddirection'],
+                              'temporal_coarsening_method': 'average'})
+        np.testing.assert_allclose(b.low_res.cpu().numpy(), lr, atol=1e-5)
+        np.testing.assert_array_equal(b.high_res.cpu().numpy(),
+                                      hr.astype(np.float32))
