@@ -47,6 +47,9 @@ struct OpRec {
   // MFMA backward (training plans)
   bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false;
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
+  bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
+  void* dc2_w = nullptr;
+  int64_t dc2_version = -1;
   ConvGeom dg;                 // geometry of the dgrad-as-conv launch
   float* dg_w32 = nullptr;     // flipped / transposed fp32 filter
   void* dg_wbf = nullptr;      // its bf16 slabs (bf16 mode)
@@ -392,7 +395,8 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               conv_dgrad_mfma_valid_supported(g, precision)) {
             o.dgrad_mfma = o.dgrad_valid = true;
           }
-          o.gconv_dgrad = !o.dgrad_mfma && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
+          o.dgrad_c2 = !o.dgrad_mfma && !o.fewpos && conv_dgrad_c2_supported(g, precision);
+          o.gconv_dgrad = !o.dgrad_mfma && !o.dgrad_c2 && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
           if (o.gconv_dgrad && g.pad_mode == S3_PAD_REFLECT)
             max_dxp = std::max(max_dxp, (size_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
                                             (g.D[2] + 2 * g.lo[2]) * g.Cin * sizeof(float));
@@ -575,6 +579,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     if (o.d.kind != S3_OP_CONV) continue;
     if (o.gconv) {
       int rc = plan_alloc(pl, &o.gc_w, conv_gconv_packed_bytes(o.cg, 0));
+      if (rc) { s3_plan_destroy(pl); return rc; }
+    }
+    if (o.dgrad_c2) {
+      int rc = plan_alloc(pl, &o.dc2_w, conv_dgrad_c2_packed_bytes());
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
     if (o.gconv_dgrad) {
@@ -959,6 +967,13 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
             fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
             rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+          } else if (o.dgrad_c2) {
+            if (o.dc2_version != (int64_t)P->version) {
+              rc = launch_conv_dgrad_c2_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);
+              if (rc) return rc;
+              o.dc2_version = (int64_t)P->version;
+            }
+            rc = launch_conv_dgrad_c2(ctx, g, dpre, o.dc2_w, dst);
           } else if (o.gconv_dgrad) {
             if (o.gct_version != P->version) {
               rc = launch_gconv_pack(ctx, g, W + P->p[d.w].offset, o.gc_wt, 1);

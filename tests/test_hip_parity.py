@@ -525,7 +525,8 @@ def test_disc_wgrad_bf16_transpose_read_general_kernel(monkeypatch):
 def test_valid_conv_dgrad_on_halo_tile_kernel(monkeypatch):
     """Data gradient of valid-padded stride-1 convs with 64 output channels
     (discriminator 32 -> 64, 64 -> 64) as a full correlation on the halo-tile
-    MFMA kernel, written straight onto x's grid: against the oracle
+    MFMA kernel, written straight onto x's grid, and of the 2 -> 32 first
+    layer on the LDS-halo few-channel kernel: against the oracle
     (bf16-mode bound) and against the gather-MFMA data gradient
     (SUP3R_AMD_NO_MFMA_BWD=1, same bf16 operands: rel. rms < 1e-2)."""
     rng = np.random.default_rng(35)
@@ -536,7 +537,7 @@ def test_valid_conv_dgrad_on_halo_tile_kernel(monkeypatch):
                 {'alpha': 0.2, 'class': 'LeakyReLU'}]
     spec = conv(32, 1) + conv(64, 1) + conv(64, 1) + \
         [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
-    shape = (2, 15, 17, 31, 2)
+    shape = (2, 17, 18, 33, 2)       # ragged 4 x 8 x 16 tiles of the 2-channel dgrad
     x = rng.standard_normal(shape).astype(np.float32)
     ref = _oracle_net(spec, x, None)
     y_ref = ref.forward(x)
@@ -551,10 +552,15 @@ def test_valid_conv_dgrad_on_halo_tile_kernel(monkeypatch):
         return dx, [np.array(g) for g in net.grads]
     dx, g = run()
     monkeypatch.setenv('SUP3R_AMD_NO_MFMA_BWD', '1')
+    monkeypatch.setenv('SUP3R_AMD_NO_DGRAD_C2', '1')   # 32 -> 2: LDS-halo kernel off too
     dx2, g2 = run()
+    assert np.abs(dx - dx2).max() > 0
     assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
     rms = np.sqrt(((dx - dx2) ** 2).mean()) / np.sqrt((dx2 ** 2).mean())
     assert rms < 1e-2, rms
+    # bias gradients are cancellation-heavy sums over all positions: bound the
+    # relative rms (2e-1 in bf16 mode, cf. the production-config test) against
+    # the oracle, and the two bf16 kernel paths against each other tightly
     for a, b, r in zip(g, g2, ref.grads):
-        assert np.abs(a - r).max() < 1e-1 * np.abs(r).max() + 1e-3
+        assert np.sqrt(((a - r) ** 2).mean()) / np.sqrt((r ** 2).mean()) < 2e-1
         assert np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()) < 2e-2
