@@ -20,6 +20,9 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--threads', type=int, default=16)
     ap.add_argument('--direct', action='store_true')
+    ap.add_argument('--repeat', type=int, default=1,
+                    help='timed runs; the first one also pays the page faults '
+                         'of the fresh output array and the batched plan build')
     args = ap.parse_args()
     import torch
     from sup3r_amd import ChunkSlicer, ForwardPass, Sup3rGan
@@ -41,19 +44,21 @@ def main():
     fwp = ForwardPass(model, slicer)
     # warm-up (plans, weights)
     fwp.run_chunk(domain, 0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if args.batched:
-        n = fwp.run_batched(domain, out=out, batch=args.batch,
-                            n_host_threads=args.threads,
-                            direct_placement=args.direct)
-    else:
-        n = fwp.run(domain, out=out)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(f'domain {d}: {n} chunks in {dt:.2f} s = {n / dt:.1f} chunks/s '
-          f'({"batched" if args.batched else "sequential"}), hi-res '
-          f'{out.nbytes / 2**30:.2f} GiB, checksum {float(out.mean()):.6f}')
+    for rep in range(args.repeat):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if args.batched:
+            n = fwp.run_batched(domain, out=out, batch=args.batch,
+                                n_host_threads=args.threads,
+                                direct_placement=args.direct)
+        else:
+            n = fwp.run(domain, out=out)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f'run {rep}: domain {d}: {n} chunks in {dt:.3f} s = {n / dt:.1f} '
+              f'chunks/s ({"batched" if args.batched else "sequential"}), '
+              f'hi-res {out.nbytes / 2**30:.2f} GiB, checksum '
+              f'{float(out.mean()):.6f}')
 
 
 if __name__ == '__main__':
