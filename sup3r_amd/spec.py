@@ -15,7 +15,8 @@ fusion is exact index algebra, not an approximation:
 
     REFLECT pad P -> conv(k, valid, stride 1) -> crop C
       == conv over a *virtually* reflect-padded input with low offset P - C
-    REFLECT pad P -> Conv2DTranspose(k, stride 1, valid) -> crop C   (C >= k-1)
+    REFLECT pad P -> Conv2DTranspose | Conv3DTranspose(k, stride 1, valid)
+      -> crop C   (C >= k-1)
       == the same with the kernel flipped and (C_in, C_out) swapped,
          low offset (k - 1) + P - C
 
@@ -113,6 +114,7 @@ class LayerSpec:
 
 
 SUPPORTED = ('FlexiblePadding', 'Conv2D', 'Conv3D', 'Conv2DTranspose',
+             'Conv3DTranspose',
              'Cropping2D', 'Cropping3D', 'LeakyReLU', 'Activation', 'ReLU',
              'SkipConnection', 'SpatialExpansion', 'SpatioTemporalExpansion',
              'Flatten', 'Dense', 'Sup3rConcat', 'Sup3rAdder')
@@ -292,11 +294,11 @@ def build_plan(layers, in_shape, param_table=None, fuse=True):
                         mode=PAD_REFLECT if mode == 'REFLECT' else PAD_ZERO)
             if not fuse:
                 flush_pad()
-        elif cls in ('Conv2D', 'Conv3D', 'Conv2DTranspose'):
-            cnd = 3 if cls == 'Conv3D' else 2
+        elif cls in ('Conv2D', 'Conv3D', 'Conv2DTranspose', 'Conv3DTranspose'):
+            cnd = 3 if cls in ('Conv3D', 'Conv3DTranspose') else 2
             if cnd != nd:
                 raise RuntimeError(f'{cls} applied to rank-{nd + 2} tensor')
-            is_t = cls == 'Conv2DTranspose'
+            is_t = cls in ('Conv2DTranspose', 'Conv3DTranspose')
             filters = int(kw['filters'])
             k = list(_tup(kw['kernel_size'], cnd)) + [1] * (3 - cnd)
             s = list(_tup(kw.get('strides', 1), cnd)) + [1] * (3 - cnd)
@@ -312,21 +314,21 @@ def build_plan(layers, in_shape, param_table=None, fuse=True):
             ext = [sh[1 + d] + plo[d] + phi[d] for d in range(3)]
             if is_t:
                 if any(v != 1 for v in s) or padding != 'valid':
-                    raise KeyError('Conv2DTranspose with strides != 1 or '
+                    raise KeyError(f'{cls} with strides != 1 or '
                                    'padding != valid has no kernel mapping')
                 full = [ext[d] + k[d] - 1 for d in range(3)]
                 # look ahead for the crop that removes the zero-tail region
                 crop_lo, crop_hi = [0, 0, 0], [0, 0, 0]
-                if i + 1 < n_layers and layers[i + 1].cls == 'Cropping2D':
-                    c = _crop_list(layers[i + 1].kwargs.get('cropping', 0), 2)
-                    for d in range(2):
+                if i + 1 < n_layers and layers[i + 1].cls == f'Cropping{cnd}D':
+                    c = _crop_list(layers[i + 1].kwargs.get('cropping', 0), cnd)
+                    for d in range(cnd):
                         crop_lo[d], crop_hi[d] = c[d]
                     consumed = 2
                 need = [k[d] - 1 for d in range(3)]
                 if any(crop_lo[d] < need[d] or crop_hi[d] < need[d]
                        for d in range(3)):
                     raise KeyError(
-                        'Conv2DTranspose whose zero tails are not cropped '
+                        f'{cls} whose zero tails are not cropped '
                         '(cropping < kernel_size - 1) has no kernel mapping')
                 out_sp = [full[d] - crop_lo[d] - crop_hi[d] for d in range(3)]
                 lo = [(k[d] - 1) + plo[d] - crop_lo[d] for d in range(3)]

@@ -44,6 +44,9 @@ CASES = [
     ('test_disc_s_same.json', (2, 20, 20, 2), None, (2, 1)),
     ('test_disc_st_valid.json', (2, 14, 13, 15, 2), None, (2, 1)),
     ('test_gen_st_64ch.json', (1, 6, 5, 12, 3), None, (1, 12, 10, 24, 2)),
+    # Conv3DTranspose (named in north_star; 0 occurrences in the reference's
+    # configs): same flipped-kernel identity as the 2-D case
+    ('test_gen_st_convT3d.json', (2, 5, 6, 4, 3), None, (2, 10, 12, 8, 2)),
 ]
 
 

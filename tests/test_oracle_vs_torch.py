@@ -36,6 +36,7 @@ CASES = [
     ('test_disc_st_same.json', (2, 12, 12, 16, 2), None),
     ('test_disc_s_same.json', (2, 20, 20, 2), None),
     ('test_disc_st_valid.json', (2, 14, 13, 15, 2), None),
+    ('test_gen_st_convT3d.json', (2, 5, 6, 4, 3), None),    # Conv3DTranspose
 ]
 
 

@@ -93,13 +93,17 @@ class TorchNet:
                 act = spec.get('activation')
                 if act == 'relu':
                     x = F.relu(x)
-            elif cls == 'Conv2DTranspose':
+            elif cls in ('Conv2DTranspose', 'Conv3DTranspose'):
                 w, b = self.weights[wi], self.weights[wi + 1]
                 wi += 2
                 s = spec.get('strides', 1)
-                # keras (kh, kw, Co, Ci) -> torch conv_transpose (Ci, Co, kh, kw)
-                wt = w.permute(3, 2, 0, 1)
-                x = _cl(F.conv_transpose2d(_cf(x), wt, b, stride=s))
+                # keras (k.., Co, Ci) -> torch conv_transpose (Ci, Co, k..)
+                if cls == 'Conv2DTranspose':
+                    wt = w.permute(3, 2, 0, 1)
+                    x = _cl(F.conv_transpose2d(_cf(x), wt, b, stride=s))
+                else:
+                    wt = w.permute(4, 3, 0, 1, 2)
+                    x = _cl(F.conv_transpose3d(_cf(x), wt, b, stride=s))
                 if spec.get('activation') == 'relu':
                     x = F.relu(x)
             elif cls in ('Cropping2D', 'Cropping3D'):
