@@ -174,8 +174,11 @@ int launch_conv_fewpos_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x,
 int launch_conv_fewpos_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,
                              const float* wt, float* dx, float* partial,
                              size_t partial_bytes);
+size_t conv_fewpos_wgrad_partial_bytes(const ConvGeom& g);
+ConvGeom conv_fewpos_frame_geom(const ConvGeom& g);
 int launch_conv_fewpos_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,
-                             const float* dy, float* dw, int accumulate);
+                             const float* dy, float* dw, float* partial, size_t partial_bytes,
+                             int accumulate);
 int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
                                  float* wt);
 

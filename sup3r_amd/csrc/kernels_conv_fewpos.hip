@@ -147,21 +147,27 @@ __global__ void fewpos_epilogue_kernel(const float* __restrict__ partial,
 }
 
 // dW[tap][ci][co] (+)= sum_p x[src(p, tap)][ci] * dPre[p][co]
+// One thread per (tap, ci block of 4, co) walks a SLAB of the positions
+// (blockIdx.y / ci_blocks = slab; a serial walk over all of them is a chain of
+// dependent loads: 174 us for 1500 positions); slabs are summed in fixed
+// order by fewpos_wgrad_reduce.
 __global__ __launch_bounds__(256) void fewpos_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
-    float* __restrict__ dw, ConvGeom g, int64_t rows, int accumulate) {
+    float* __restrict__ part, ConvGeom g, int64_t rows, int ci_blocks, int slabs) {
   constexpr int CI_T = 4;
   const int tx = threadIdx.x & 63;
   const int ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int co = blockIdx.x * 64 + tx;
-  const int ci0 = (blockIdx.y * 4 + ty) * CI_T;
+  const int cib = blockIdx.y % ci_blocks, slab = blockIdx.y / ci_blocks;
+  const int ci0 = (cib * 4 + ty) * CI_T;
   const int tap = blockIdx.z;
   if (ci0 >= g.Cin) return;
   const bool live = co < g.Cout;
   float acc[CI_T];
 #pragma unroll
   for (int j = 0; j < CI_T; ++j) acc[j] = 0.f;
-  for (int64_t p = 0; p < rows; ++p) {
+  const int64_t p0 = rows * slab / slabs, p1 = rows * (slab + 1) / slabs;
+  for (int64_t p = p0; p < p1; ++p) {
     const int64_t s = fewpos_src(g, 0, p, tap);   // wave-uniform
     if (s < 0) continue;
     const float d = live ? dy[p * g.Cout + co] : 0.f;
@@ -171,11 +177,21 @@ __global__ __launch_bounds__(256) void fewpos_wgrad_kernel(
       acc[j] = fmaf((ci0 + j < g.Cin) ? xp[j] : 0.f, d, acc[j]);
   }
   if (!live) return;
+  const int64_t wsize = (int64_t)gridDim.z * g.Cin * g.Cout;
 #pragma unroll
   for (int j = 0; j < CI_T; ++j) {
     if (ci0 + j >= g.Cin) break;
-    float* o = dw + ((int64_t)tap * g.Cin + ci0 + j) * g.Cout + co;
-    *o = accumulate ? *o + acc[j] : acc[j];
+    part[slab * wsize + ((int64_t)tap * g.Cin + ci0 + j) * g.Cout + co] = acc[j];
+  }
+}
+
+__global__ void fewpos_wgrad_reduce(const float* __restrict__ part, int slabs, int64_t wsize,
+                                    float* __restrict__ dw, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < wsize;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int s = 0; s < slabs; ++s) t += part[(int64_t)s * wsize + i];
+    dw[i] = accumulate ? dw[i] + t : t;
   }
 }
 
@@ -207,7 +223,9 @@ size_t conv_fewpos_partial_bytes(const ConvGeom& g) {
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
   const int64_t Pin = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
-  const int64_t a = P * g.Cout, b = Pin * g.Cin;
+  int64_t Pf = g.N;                       // padded frame of the reflect dgrad
+  for (int d = 0; d < 3; ++d) Pf *= g.D[d] + 2 * g.lo[d];
+  const int64_t a = P * g.Cout, b = (Pin > Pf ? Pin : Pf) * g.Cin;
   return (size_t)taps * (a > b ? a : b) * sizeof(float);
 }
 
@@ -244,14 +262,46 @@ int launch_conv_fewpos_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,
   return S3_OK;
 }
 
+static int fewpos_wgrad_slabs(const ConvGeom& g) {
+  const int64_t rows = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  int64_t s = rows / 32;              // >= 32 positions per slab
+  if (s > 32) s = 32;
+  return (int)(s < 1 ? 1 : s);
+}
+
+size_t conv_fewpos_wgrad_partial_bytes(const ConvGeom& g) {
+  return (size_t)fewpos_wgrad_slabs(g) * g.k[0] * g.k[1] * g.k[2] * g.Cin * g.Cout * sizeof(float);
+}
+
 int launch_conv_fewpos_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,
-                             const float* dy, float* dw, int accumulate) {
+                             const float* dy, float* dw, float* partial, size_t partial_bytes,
+                             int accumulate) {
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int64_t rows = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
-  dim3 grid((g.Cout + 63) / 64, (g.Cin + 15) / 16, taps);
-  hipLaunchKernelGGL(fewpos_wgrad_kernel, grid, dim3(256), 0, ctx->stream, x, dy, dw, g, rows, accumulate);
+  const int slabs = fewpos_wgrad_slabs(g);
+  if (partial_bytes < conv_fewpos_wgrad_partial_bytes(g))
+    S3_FAIL(ctx, S3_EINVAL, "fewpos wgrad: partial buffer too small");
+  const int ci_blocks = (g.Cin + 15) / 16;
+  dim3 grid((g.Cout + 63) / 64, ci_blocks * slabs, taps);
+  hipLaunchKernelGGL(fewpos_wgrad_kernel, grid, dim3(256), 0, ctx->stream, x, dy, partial, g, rows,
+                     ci_blocks, slabs);
+  const int64_t wsize = (int64_t)taps * g.Cin * g.Cout;
+  int rg = (int)((wsize + 255) / 256);
+  if (rg > 2048) rg = 2048;
+  hipLaunchKernelGGL(fewpos_wgrad_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial, slabs, wsize,
+                     dw, accumulate);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
+}
+
+// geometry of the data gradient over the virtually padded frame of a
+// reflect-padded conv: positions run over D + 2 lo per axis with lo' = 0; the
+// caller folds the frame back onto x (adjoint of the reflect padding)
+ConvGeom conv_fewpos_frame_geom(const ConvGeom& g) {
+  ConvGeom f = g;
+  for (int d = 0; d < 3; ++d) { f.D[d] = g.D[d] + 2 * g.lo[d]; f.lo[d] = 0; }
+  f.pad_mode = S3_PAD_ZERO;
+  return f;
 }
 
 int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,

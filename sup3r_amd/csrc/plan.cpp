@@ -368,7 +368,17 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             conv_wgrad_gen_supported(g))
           o.fewpos = false;
         o.gconv = !o.mfma && !o.fewpos && conv_gconv_supported(g, precision);
-        if (o.fewpos) max_fp = std::max(max_fp, conv_fewpos_partial_bytes(g));
+        if (o.fewpos) {
+          max_fp = std::max(max_fp, conv_fewpos_partial_bytes(g));
+          if (training) {
+            max_partial = std::max(max_partial, conv_fewpos_wgrad_partial_bytes(g));
+            if (g.pad_mode == S3_PAD_REFLECT) {   // frame of the reflect dgrad
+              size_t fb = (size_t)g.N * g.Cin * sizeof(float);
+              for (int q = 0; q < 3; ++q) fb *= (size_t)(g.D[q] + 2 * g.lo[q]);
+              max_dxp = std::max(max_dxp, fb);
+            }
+          }
+        }
         size_t ysz = (size_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout * sizeof(float);
         max_dpre = std::max(max_dpre, ysz);
         max_partial = std::max(max_partial, conv_generic_wgrad_partial_bytes(g));
@@ -563,7 +573,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
   }
   if (training) {
     for (auto& o : pl->ops) {
-      if (o.d.kind != S3_OP_CONV || !o.fewpos || o.cg.pad_mode != S3_PAD_ZERO) continue;
+      if (o.d.kind != S3_OP_CONV || !o.fewpos) continue;
       int rc = plan_alloc(pl, (void**)&o.fp_wt, (size_t)o.cg.k[0] * o.cg.k[1] * o.cg.k[2] * o.cg.Cin * o.cg.Cout * sizeof(float));
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
@@ -925,7 +935,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             if (rc) return rc;
           }
           if (o.fewpos)
-            rc = launch_conv_fewpos_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, accumulate_wgrad);
+            rc = launch_conv_fewpos_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_c2)
             rc = launch_conv_wgrad_c2(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16_gen)
@@ -999,7 +1009,19 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               if (rc) return rc;
               o.fp_version = P->version;
             }
-            rc = launch_conv_fewpos_dgrad(ctx, g, dpre, o.fp_wt, dst, pl->fp_partial, pl->fp_partial_bytes);
+            if (g.pad_mode == S3_PAD_REFLECT) {
+              // dXpad over the padded frame (zero boundary), then fold the border back
+              rc = launch_conv_fewpos_dgrad(ctx, conv_fewpos_frame_geom(g), dpre, o.fp_wt, pl->dxp, pl->fp_partial, pl->fp_partial_bytes);
+              if (rc) return rc;
+              GatherGeom fg;
+              fg.kind = S3_OP_PAD; fg.N = g.N;
+              for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2 * g.lo[q]; fg.lo[q] = g.lo[q]; }
+              fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
+              fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
+              rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+            } else {
+              rc = launch_conv_fewpos_dgrad(ctx, g, dpre, o.fp_wt, dst, pl->fp_partial, pl->fp_partial_bytes);
+            }
           } else {
             rc = launch_conv_generic_dgrad(ctx, g, dpre, W + P->p[d.w].offset, dst);
           }
