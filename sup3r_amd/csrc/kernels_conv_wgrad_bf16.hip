@@ -58,7 +58,7 @@ __device__ __forceinline__ s16x4 lds_tr(const char* p) {
 __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
-    int tiles2, int n_tiles) {
+    int tiles2, int n_tiles, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;                       // [BHP cells][4 segs of 32 B] bf16
   char* ds = smem + XS_BYTES;            // [BNP positions][2 segs of 32 B] bf16
@@ -106,7 +106,9 @@ __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
     const int org0 = t0i * BT0, org1 = t1i * BT1, org2 = t2i * BT2;
     __syncthreads();   // previous tile fully consumed
     // ---- stage x halo: 648 cells x 16 float4 -> bf16
-    for (int item = tid; item < BHP * 16; item += BNT) {
+    // (dbg: timing-only ablations, results invalid — bit 0 stages the first
+    // tile only, bit 1 skips the MFMA loop)
+    for (int item = tid; item < (((dbg & 1) && tile != (int)blockIdx.x) ? 0 : BHP * 16); item += BNT) {
       const int hp = item >> 4, ch = item & 15;
       int h = hp;
       const int c2 = h % BH2; h /= BH2;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
       *reinterpret_cast<uint2*>(xs + hp * 128 + (((ch >> 2) ^ xs_key(c2)) << 5) + ((ch & 3) << 3)) = pk;
     }
     // ---- stage dPre tile: 256 positions x 8 float4 (zero outside / beyond C_out)
-    for (int item = tid; item < BNP * (BCT / 4); item += BNT) {
+    for (int item = tid; item < (((dbg & 1) && tile != (int)blockIdx.x) ? 0 : BNP * (BCT / 4)); item += BNT) {
       const int pl = item >> 3, ch = item & 7;
       const int row = pl / BT2, tt = pl % BT2;
       const int o0 = org0 + row / BT1, o1 = org1 + row % BT1, o2 = org2 + tt;
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
       *reinterpret_cast<uint2*>(ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3)) = pk;
     }
     __syncthreads();
+    if (dbg & 2) continue;
     // ---- 8 k-steps of 32 positions (2 rows x 16 t)
 #pragma unroll
     for (int ks = 0; ks < BNP / 32; ++ks) {
@@ -454,8 +457,9 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
     attr_set = true;
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
+  static const int dbg = getenv("SUP3R_AMD_WGRAD_DBG") ? atoi(getenv("SUP3R_AMD_WGRAD_DBG")) : 0;
   hipLaunchKernelGGL(conv3_wgrad_bf16_kernel, dim3(grid, n_ct), dim3(BNT), BF_LDS,
-                     ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles);
+                     ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles, dbg);
   S3_HIP(ctx, hipGetLastError());
   const int64_t wsize = (int64_t)27 * 64 * g.Cout;
   hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3((unsigned)((wsize + 255) / 256)), dim3(256), 0,
