@@ -15,8 +15,9 @@ from .condmom import Sup3rCondMom  # noqa: E402,F401
 from .dc import Sup3rGanDC  # noqa: E402,F401
 from .forward_pass import ChunkSlicer, ForwardPass  # noqa: E402,F401
 from .multi_step import MultiStepGan  # noqa: E402,F401
-from .batch_queue import DeviceBatchQueue, DsetTuple  # noqa: E402,F401
+from .batch_queue import (DeviceBatchHandler, DeviceBatchQueue,  # noqa: E402,F401
+                          DsetTuple)
 
 __all__ = ['Sup3rGan', 'Sup3rCondMom', 'Sup3rGanDC', 'MultiStepGan', 'ForwardPass',
-           'ChunkSlicer', 'DeviceBatchQueue', 'DsetTuple',
+           'ChunkSlicer', 'DeviceBatchQueue', 'DeviceBatchHandler', 'DsetTuple',
            '__version__']

@@ -337,3 +337,63 @@ class DeviceBatchQueue:
             lr_shape = (*lr_shape[:2], lr_shape[-1])
             hr_shape = (*hr_shape[:2], hr_shape[-1])
         return (self.batch_size, *lr_shape), (self.batch_size, *hr_shape)
+
+
+class DeviceBatchHandler(DeviceBatchQueue):
+    """Training queue + validation queue + normalisation stats: the object
+    ``Sup3rGan.train`` consumes (``BatchHandlerFactory``,
+    sup3r/preprocessing/batch_handlers/factory.py:33-310).  The reference
+    builds its samplers from data containers; here ready samplers are handed
+    in (duck-typed, see the module docstring) and ``means`` / ``stds`` are the
+    per-feature dicts the model stores for ``norm_input`` / ``un_norm_output``
+    (``StatsCollection`` is part of the data layer)."""
+
+    def __init__(self, train_samplers, val_samplers=None, batch_size=16,
+                 n_batches=64, s_enhance=1, t_enhance=1, means=None, stds=None,
+                 queue_cap=None, transform_kwargs=None, max_workers=1,
+                 mode='lazy', transform=None, seed=None):
+        feats = list(train_samplers[0].features)
+        self.means = dict(means) if means is not None else {
+            f: np.float32(0.0) for f in feats}
+        self.stds = dict(stds) if stds is not None else {
+            f: np.float32(1.0) for f in feats}
+        if not val_samplers:
+            self.val_data = []
+        else:
+            self.val_data = DeviceBatchQueue(
+                samplers=val_samplers, n_batches=n_batches,
+                thread_name='validation', batch_size=batch_size,
+                s_enhance=s_enhance, t_enhance=t_enhance, queue_cap=queue_cap,
+                transform_kwargs=transform_kwargs, max_workers=max_workers,
+                mode=mode, transform=transform, seed=seed)
+        super().__init__(samplers=train_samplers, n_batches=n_batches,
+                         batch_size=batch_size, s_enhance=s_enhance,
+                         t_enhance=t_enhance, queue_cap=queue_cap,
+                         transform_kwargs=transform_kwargs,
+                         max_workers=max_workers, mode=mode,
+                         transform=transform, seed=seed)
+
+    @property
+    def smoothing(self):
+        return self.transform_kwargs.get('smoothing', None)
+
+    @property
+    def smoothed_features(self):
+        ignore = self.transform_kwargs.get('smoothing_ignore', None) or []
+        if self.smoothing is None:
+            return []
+        return [f for f in self.lr_features if f not in ignore]
+
+    def start(self):
+        """Start the val data batch queue in addition to the train batch
+        queue."""
+        if hasattr(self.val_data, 'start'):
+            self.val_data.start()
+        super().start()
+
+    def stop(self):
+        """Stop the val data batch queue in addition to the train batch
+        queue."""
+        if hasattr(self.val_data, 'stop'):
+            self.val_data.stop()
+        super().stop()

@@ -145,3 +145,56 @@ def test_device_batch_queue_matches_oracle_transform():
         np.testing.assert_allclose(b.low_res.cpu().numpy(), lr, atol=1e-5)
         np.testing.assert_array_equal(b.high_res.cpu().numpy(),
                                       hr.astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_train_from_device_batch_handler(tmp_path):
+    """samplers -> DeviceBatchHandler (train + validation queues, device
+    coarsening / smoothing) -> Sup3rGan.train -> checkpoint -> load: the whole
+    training pipeline without TensorFlow (test_train_gan.py flow)."""
+    import os
+    from sup3r_amd import Sup3rGan
+    from sup3r_amd.batch_queue import DeviceBatchHandler
+    feats = ['u_10m', 'v_10m', 'topography']
+
+    class Smp(DummySampler):
+        lr_features = feats
+        hr_features = feats[:2]
+        hr_out_features = feats[:2]
+        hr_exo_features = []
+        hr_features_ind = [0, 1]
+
+    train = [Smp((10, 12, 16), (30, 30, 60), 4, feats, seed=s) for s in (1, 2)]
+    val = [Smp((10, 12, 16), (20, 20, 40), 4, feats, seed=3)]
+    means = {f: np.float32(0.0) for f in feats}
+    stds = {f: np.float32(1.0) for f in feats}
+    bh = DeviceBatchHandler(train, val, batch_size=4, n_batches=3, s_enhance=2,
+                            t_enhance=4, means=means, stds=stds, queue_cap=2,
+                            transform_kwargs={'smoothing': 0.6,
+                                              'smoothing_ignore': ['topography'],
+                                              'temporal_coarsening_method':
+                                              'average'}, seed=0)
+    assert bh.shapes == ((4, 5, 6, 4, 3), (4, 10, 12, 16, 2))
+    assert bh.smoothed_features == ['u_10m', 'v_10m'] and bh.smoothing == 0.6
+    cfg = os.path.join(os.path.dirname(__file__), '..', 'sup3r_amd', 'configs')
+    Sup3rGan.seed(0)
+    model = Sup3rGan(os.path.join(cfg, 'test_gen_st_2x_4x_2f.json'),
+                     os.path.join(cfg, 'test_disc_st_same.json'),
+                     learning_rate=1e-4, loss='MeanAbsoluteError')
+    out_dir = os.path.join(str(tmp_path), 'gan_{epoch}')
+    model.train(bh, input_resolution={'spatial': '8km', 'temporal': '60min'},
+                n_epoch=2, weight_gen_advers=1e-3, checkpoint_int=1,
+                out_dir=out_dir)
+    assert not bh.queue_thread.is_alive() and not bh.val_data.queue_thread.is_alive()
+    h = model.history
+    assert len(h) == 2 and int(h['total_batches'].iloc[-1]) == 6
+    for col in ('train_loss_gen', 'train_loss_disc', 'val_loss_gen',
+                'val_loss_gen_content', 'elapsed_time'):
+        assert col in h.columns
+        assert np.isfinite(np.asarray(h[col], dtype=np.float64)).all()
+    assert model.meta['s_enhance'] == 2 and model.meta['t_enhance'] == 4
+    assert model.meta['lr_features'] == feats
+    assert model.meta['smoothed_features'] == ['u_10m', 'v_10m']
+    loaded = Sup3rGan.load(out_dir.format(epoch=1))
+    x = np.random.default_rng(0).standard_normal((2, 5, 6, 4, 3)).astype(np.float32)
+    np.testing.assert_array_equal(loaded.generate(x), model.generate(x))
