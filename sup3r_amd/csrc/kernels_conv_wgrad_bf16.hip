@@ -426,6 +426,187 @@ int bf_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* d
   return S3_OK;
 }
 
+
+// ===========================================================================
+// 2-D convs (spatial models: k = 3 x 3 x 1 on (N, s1, s2, 1, C)): same scheme
+// with s2 as the 16-long run axis.  Tiles of 8 x 16 positions (halo 10 x 18
+// cells, stride 2: 17 x 33), 12 waves = (s1 tap) x (ci block[, cout block]),
+// 3 taps x NBW accumulators per wave, 4 k-steps per tile.
+template <int CIB, int STR>
+struct Bf2D {
+  static constexpr int T1 = 8, T2 = 16;
+  static constexpr int G1 = (T1 - 1) * STR + 3, G2 = (T2 - 1) * STR + 3;
+  static constexpr int HP = G1 * G2;
+  static constexpr int NP = T1 * T2;
+  static constexpr int CB = CIB * 32;
+  static constexpr int NBW = CIB / 2;
+  static constexpr int XS = HP * CB;
+  static constexpr size_t LDS = (size_t)XS + NP * 64;
+  __device__ static __forceinline__ int tau(int th) {
+    return STR == 1 ? th : (th & 1) * ((G2 + 1) / 2) + (th >> 1);
+  }
+  __device__ static __forceinline__ int key(int u) {
+    return CIB == 4 ? (((u >> 1) & 1) | (((u >> 3) & 1) << 1)) : ((u >> 3) & 1);
+  }
+};
+
+template <int CIB, int STR>
+__global__ __launch_bounds__(BNT) void conv2_wgrad_bf16_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy,
+    float* __restrict__ partial, ConvGeom g, int tiles1, int tiles2, int n_tiles) {
+  using W = Bf2D<CIB, STR>;
+  constexpr int T1 = W::T1, T2 = W::T2, G2 = W::G2, HP = W::HP, NP = W::NP;
+  constexpr int CB = W::CB, NBW = W::NBW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;
+  char* ds = smem + W::XS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane & 15, kg = lane >> 4;
+  const int tb = wave >> 2, w4 = wave & 3;
+  const int cb = CIB == 4 ? w4 : (w4 & 1);
+  const int nb0 = CIB == 4 ? 0 : (w4 >> 1);
+  const int ct = blockIdx.y;
+  const int ci0 = blockIdx.z * (CIB * 16);
+  const int D0 = g.D[0], D1 = g.D[1];
+  const int Cin = g.Cin, Cout = g.Cout;
+
+  f32x4 acc[3][NBW];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int a_off[3][2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int th = (8 * (kg & 1) + 4 * h + (q >> 2)) * STR + c;
+      const int u = W::tau(th);
+      a_off[c][h] = ((tb + (kg >> 1) * STR) * G2 + u) * CB + ((cb ^ W::key(u)) << 5) + ((q & 3) << 3);
+    }
+  int b_off[NBW][2];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pl = 8 * kg + 4 * h + (q >> 2);
+      b_off[nb][h] = pl * 64 + (((nb0 + nb) ^ ((pl >> 3) & 1)) << 5) + ((q & 3) << 3);
+    }
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int tr = tile;
+    const int t2i = tr % tiles2; tr /= tiles2;
+    const int t1i = tr % tiles1; tr /= tiles1;
+    const int n = tr;
+    const int org1 = t1i * T1, org2 = t2i * T2;
+    __syncthreads();
+    constexpr int CH = CIB * 4;
+    for (int item = tid; item < HP * CH; item += BNT) {
+      const int hp = item / CH, ch = item % CH;
+      const int c2 = hp % G2, c1 = hp / G2;
+      int i0 = org1 * STR + c1 - g.lo[0], i1 = org2 * STR + c2 - g.lo[1];
+      if (g.pad_mode == S3_PAD_REFLECT) { i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); }
+      const bool valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && ci0 + ch * 4 < Cin;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (valid)
+        v = *reinterpret_cast<const float4*>(x + (((size_t)n * D0 + i0) * D1 + i1) * Cin + ci0 + ch * 4);
+      const int u = W::tau(c2);
+      *reinterpret_cast<uint2*>(xs + (c1 * G2 + u) * CB + (((ch >> 2) ^ W::key(u)) << 5) +
+                                ((ch & 3) << 3)) = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+    }
+    for (int item = tid; item < NP * (BCT / 4); item += BNT) {
+      const int pl = item >> 3, ch = item & 7;
+      const int o0 = org1 + pl / T2, o1 = org2 + pl % T2;
+      const int co = ct * BCT + ch * 4;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (o0 < g.O[0] && o1 < g.O[1] && co < Cout)
+        v = *reinterpret_cast<const float4*>(dy + (((size_t)n * g.O[0] + o0) * g.O[1] + o1) * Cout + co);
+      *reinterpret_cast<uint2*>(ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3)) =
+          make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < NP / 32; ++ks) {
+      const int rowb = (2 * ks) * STR * G2 * CB;
+      bf16x8 bfr[NBW];
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        const s16x4 lo = lds_tr(ds + b_off[nb][0] + ks * 32 * 64);
+        const s16x4 hi = lds_tr(ds + b_off[nb][1] + ks * 32 * 64);
+        bfr[nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const s16x4 lo = lds_tr(xs + a_off[c][0] + rowb);
+        const s16x4 hi = lds_tr(xs + a_off[c][1] + rowb);
+        const bf16x8 afr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+          acc[c][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nb], acc[c][nb], 0, 0, 0);
+      }
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * 9 * Cin * Cout;
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int co = ct * BCT + (nb0 + nb) * 16 + q;
+    if (co < Cout) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = ci0 + cb * 16 + kg * 4 + r;
+          if (ci < Cin) out[((size_t)(tb * 3 + c) * Cin + ci) * Cout + co] = acc[c][nb][r];
+        }
+    }
+  }
+}
+
+template <int CIB, int STR>
+int bf_2d_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t1, int* t2) {
+  using W = Bf2D<CIB, STR>;
+  *t1 = (g.O[0] + W::T1 - 1) / W::T1; *t2 = (g.O[1] + W::T2 - 1) / W::T2;
+  *n_tiles = g.N * *t1 * *t2;
+  const int n_ct = (g.Cout + BCT - 1) / BCT;
+  const int n_cit = (g.Cin + CIB * 16 - 1) / (CIB * 16);
+  // the tiles are small (128 positions): several workgroups per CU
+  int grid = 4 * ctx->num_cu / (n_ct * n_cit);
+  if (grid < 1) grid = 1;
+  if (grid > *n_tiles) grid = *n_tiles;
+  return grid;
+}
+
+template <int CIB, int STR>
+int bf_2d_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy, float* dw,
+                 float* partial, size_t partial_bytes, int accumulate) {
+  using W = Bf2D<CIB, STR>;
+  int n_tiles, t1, t2;
+  const int grid = bf_2d_grid<CIB, STR>(ctx, g, &n_tiles, &t1, &t2);
+  const size_t need = (size_t)grid * 9 * g.Cin * g.Cout * sizeof(float);
+  if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_2d: partial buffer too small");
+  auto kern = conv2_wgrad_bf16_kernel<CIB, STR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS));
+    attr_set = true;
+  }
+  const int n_ct = (g.Cout + BCT - 1) / BCT;
+  const int n_cit = (g.Cin + CIB * 16 - 1) / (CIB * 16);
+  hipLaunchKernelGGL(kern, dim3(grid, n_ct, n_cit), dim3(BNT), W::LDS, ctx->stream, x, dy, partial,
+                     g, t1, t2, n_tiles);
+  S3_HIP(ctx, hipGetLastError());
+  const int64_t wsize = (int64_t)9 * g.Cin * g.Cout;
+  int rg = (int)((wsize + 255) / 256);
+  if (rg > 4096) rg = 4096;
+  hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial, grid,
+                     wsize, dw, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 }  // namespace
 
 bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision) {
@@ -490,4 +671,28 @@ int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, c
               : bf_gen_launch<2, 1>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
   return s2 ? bf_gen_launch<4, 2>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
             : bf_gen_launch<4, 1>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
+}
+
+// ---- 2-D variant (spatial models)
+bool conv_wgrad_bf16_2d_supported(const ConvGeom& g, int precision) {
+  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_WGRAD_BF16")) return false;
+  if (g.d2s != 1 || g.Cin % 32 != 0 || g.Cin < 32 || g.Cout % 4 != 0 || g.Cout < 16) return false;
+  if (g.Cin > 64 && g.Cin % 64 != 0) return false;
+  if (g.k[0] != 3 || g.k[1] != 3 || g.k[2] != 1 || g.D[2] != 1 || g.O[2] != 1) return false;
+  if (g.s[0] != g.s[1] || (g.s[0] != 1 && g.s[0] != 2)) return false;
+  return g.O[1] >= 8 && (int64_t)g.N * g.O[0] * g.O[1] >= 1024;
+}
+
+size_t conv_wgrad_bf16_2d_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
+  return (size_t)4 * ctx->num_cu * 9 * g.Cin * g.Cout * sizeof(float);   // grid <= 4 x CU count
+}
+
+int launch_conv_wgrad_bf16_2d(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                              float* dw, float* partial, size_t partial_bytes, int accumulate) {
+  const bool s2 = g.s[0] == 2;
+  if (g.Cin == 32)
+    return s2 ? bf_2d_launch<2, 2>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
+              : bf_2d_launch<2, 1>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
+  return s2 ? bf_2d_launch<4, 2>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
+            : bf_2d_launch<4, 1>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
 }

@@ -45,7 +45,7 @@ struct OpRec {
   void* packed = nullptr;
   uint64_t packed_version = 0;
   // MFMA backward (training plans)
-  bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false;
+  bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false, wgrad_bf16_2d = false;
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
   void* dc2_w = nullptr;
@@ -396,7 +396,12 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
                              conv_wgrad_bf16_gen_supported(g, precision);
           if (o.wgrad_bf16_gen)
             max_partial = std::max(max_partial, conv_wgrad_bf16_gen_partial_bytes(ctx, g));
-          if (!o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_bf16_gen && conv_wgrad_gen_supported(g)) {
+          o.wgrad_bf16_2d = !o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_bf16_gen &&
+                            conv_wgrad_bf16_2d_supported(g, precision);
+          if (o.wgrad_bf16_2d)
+            max_partial = std::max(max_partial, conv_wgrad_bf16_2d_partial_bytes(ctx, g));
+          if (!o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_bf16_gen && !o.wgrad_bf16_2d &&
+              conv_wgrad_gen_supported(g)) {
             o.wgrad_gen = true;
             max_partial = std::max(max_partial, conv_wgrad_gen_partial_bytes(ctx, g));
           }
@@ -938,6 +943,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             rc = launch_conv_fewpos_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_c2)
             rc = launch_conv_wgrad_c2(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+          else if (o.wgrad_bf16_2d)
+            rc = launch_conv_wgrad_bf16_2d(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16_gen)
             rc = launch_conv_wgrad_bf16_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_gen)
