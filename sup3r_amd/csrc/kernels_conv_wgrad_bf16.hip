@@ -571,8 +571,9 @@ int bf_2d_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t1, int*
   *n_tiles = g.N * *t1 * *t2;
   const int n_ct = (g.Cout + BCT - 1) / BCT;
   const int n_cit = (g.Cin + CIB * 16 - 1) / (CIB * 16);
-  // the tiles are small (128 positions): several workgroups per CU
-  int grid = 4 * ctx->num_cu / (n_ct * n_cit);
+  // one partial per workgroup: more workgroups than CUs would make the
+  // fixed-order reduction (grid x 9 x C_in x C_out floats) the larger kernel
+  int grid = ctx->num_cu / (n_ct * n_cit);
   if (grid < 1) grid = 1;
   if (grid > *n_tiles) grid = *n_tiles;
   return grid;
@@ -684,7 +685,7 @@ bool conv_wgrad_bf16_2d_supported(const ConvGeom& g, int precision) {
 }
 
 size_t conv_wgrad_bf16_2d_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
-  return (size_t)4 * ctx->num_cu * 9 * g.Cin * g.Cout * sizeof(float);   // grid <= 4 x CU count
+  return (size_t)ctx->num_cu * 9 * g.Cin * g.Cout * sizeof(float);   // grid <= CU count
 }
 
 int launch_conv_wgrad_bf16_2d(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
