@@ -214,6 +214,18 @@ int s3_loss_mmd(s3_ctx* ctx, const float* a, int c_a, const float* b, int c_b, i
                 int64_t n_pos, int c_used, float sigma, float weight, float* loss_out,
                 float* d_a);
 
+/* SpatialFftLoss / SpatiotemporalFftLoss (loss_metrics.py:395-485): separable
+ * direct DFT, one call per axis over a contiguous (outer, L, inner) view,
+ * unnormalised; sign < 0 = forward (tf.signal.fft2d / fft3d), > 0 = adjoint;
+ * in_im may be NULL (real input).  s3_specmap: backward == 0 writes out0 =
+ * log(1 + w |X|) with w = k1^2 k2^2 (kt^2 if mode3d) over (n, s1, s2, t, c);
+ * backward != 0 writes (out0, out1) = g_y * w / (1 + w |X|) * X / |X|. */
+int s3_dft_axis(s3_ctx* ctx, const float* in_re, const float* in_im, float* out_re,
+                float* out_im, int64_t outer, int L, int64_t inner, int sign);
+int s3_specmap(s3_ctx* ctx, int backward, const float* re, const float* im,
+               const float* g_y, int n, int s1, int s2, int t, int c, int mode3d,
+               float* out0, float* out1);
+
 /* ---- small tensor utilities on the ctx stream --------------------------
  * channel slice/concat used by _combine_loss_input / get_hr_exo_input
  * (abstract.py:415-459) and per-feature affine of norm_input /

@@ -5,7 +5,8 @@ Follows sup3r/utilities/loss_metrics.py: ``_derivative`` (:12-59), ExpLoss
 (:98-118), gaussian_kernel / MmdLoss (:62-147), MaterialDerivativeLoss
 (:150-225), SpatialDerivativeLoss (:228-260), TemporalDerivativeLoss (:263-294),
 CoarseMseLoss (:297-322), SpatialExtremesLoss (:325-357), TemporalExtremesLoss
-(:360-392), LowResLoss (:488-638), with keras MeanAbsoluteError /
+(:360-392), SpatialFftLoss / SpatiotemporalFftLoss (:395-485), LowResLoss
+(:488-638), with keras MeanAbsoluteError /
 MeanSquaredError = global means for equal shapes.  Pinned by
 the reference's own test procedures (tests/utilities/test_loss_metrics.py:
 ``test_md_loss`` against np.gradient, ``test_lr_loss`` against the coarsening
@@ -91,6 +92,29 @@ def mmd_loss(x1, x2, sigma=1.0):
                  np.mean(2 * gaussian_kernel(x1, x2, sigma)))
 
 
+def _fft_map(x, axes):
+    """log(1 + w |fftn(x)|), w = product of the squared un-wrapped frequency
+    indices of the transformed axes (loss_metrics.py:399-417, :445-465; numpy's
+    fftn is tf.signal.fft2d / fft3d up to complex64 round-off)"""
+    xh = np.abs(np.fft.fftn(x, axes=axes))
+    w = np.ones([1] * x.ndim)
+    for a in axes:
+        shape = [1] * x.ndim
+        shape[a] = x.shape[a]
+        w = w * (np.arange(x.shape[a], dtype=np.float64) ** 2).reshape(shape)
+    return np.log(1 + w * xh)
+
+
+def spatial_fft_loss(x1, x2):
+    assert x1.ndim == 4 and x2.ndim == 4
+    return mae(_fft_map(x1, (1, 2)), _fft_map(x2, (1, 2)))
+
+
+def spatiotemporal_fft_loss(x1, x2):
+    assert x1.ndim == 5 and x2.ndim == 5
+    return mae(_fft_map(x1, (1, 2, 3)), _fft_map(x2, (1, 2, 3)))
+
+
 def low_res_loss(x1, x2, s_enhance=1, t_enhance=1, t_method='average',
                  tf_loss='MeanSquaredError', ex_loss=None):
     assert x1.shape == x2.shape
@@ -119,6 +143,8 @@ LOSSES = {
     'SpatialExtremesLoss': spatial_extremes_loss,
     'TemporalExtremesLoss': temporal_extremes_loss,
     'LowResLoss': low_res_loss,
+    'SpatialFftLoss': spatial_fft_loss,
+    'SpatiotemporalFftLoss': spatiotemporal_fft_loss,
 }
 
 

@@ -31,6 +31,8 @@ STRUCTURED_KINDS = {
     'TemporalExtremesLoss': ('ext_t', _lib.LOSS_MAE),
     'LowResLoss': ('lowres', None),
     'MmdLoss': ('mmd', None),
+    'SpatialFftLoss': ('fft_s', _lib.LOSS_MAE),
+    'SpatiotemporalFftLoss': ('fft_st', _lib.LOSS_MAE),
 }
 LMAP = {'deriv_s': 0, 'deriv_t': 1, 'material': 2, 'mean_s': 3, 'ext_s': 4,
         'ext_t': 5, 'coarsen': 6}
@@ -418,6 +420,54 @@ class HipGanCompute:
             if g is not None:
                 fbwd(LMAP['coarsen'], None, g, p=(s_e, t_e, meth))
             return coefs
+        if kind in ('fft_s', 'fft_st'):
+            # log(1 + w |FFT|) of both fields, MAE, adjoint DFT of the spectral
+            # gradient (loss_metrics.py:395-485); tf.signal.fft2d needs 4-D,
+            # fft3d 5-D input
+            mode3d = kind == 'fft_st'
+            assert is_5d == mode3d, (f'{cls} expects '
+                                     f'{"5D" if mode3d else "4D"} tensors')
+            tot = n * s1 * s2 * t * c
+            axes = [(n, s1, s2 * t * c), (n * s1, s2, t * c)]
+            if mode3d:
+                axes.append((n * s1 * s2, t, c))
+
+            def dft(re, im, sign):
+                for outer, ln, inner in axes:
+                    ore, oim = dev.empty((tot,)), dev.empty((tot,))
+                    rc = L.s3_dft_axis(
+                        dev.ctx, self._ptr(re),
+                        self._ptr(im) if im is not None else None,
+                        self._ptr(ore), self._ptr(oim), outer, ln, inner, sign)
+                    _lib.check(rc, dev.ctx, 's3_dft_axis')
+                    re, im = ore, oim
+                return re, im
+            ys, spec = [], None
+            for x in (gen, true):
+                re, im = dft(x, None, -1)
+                y = dev.empty((tot,))
+                rc = L.s3_specmap(dev.ctx, 0, self._ptr(re), self._ptr(im),
+                                  None, n, s1, s2, t, c, int(mode3d),
+                                  self._ptr(y), None)
+                _lib.check(rc, dev.ctx, 's3_specmap')
+                ys.append(y)
+                if x is gen:
+                    spec = (re, im)
+            g = metric(_lib.LOSS_MAE, ys[0], ys[1], c, c_used,
+                       n * s1 * s2 * t, w, slot)
+            if g is not None:
+                gre, gim = dev.empty((tot,)), dev.empty((tot,))
+                rc = L.s3_specmap(dev.ctx, 1, self._ptr(spec[0]),
+                                  self._ptr(spec[1]), self._ptr(g), n, s1, s2,
+                                  t, c, int(mode3d), self._ptr(gre),
+                                  self._ptr(gim))
+                _lib.check(rc, dev.ctx, 's3_specmap')
+                dre, _ = dft(gre, gim, +1)
+                rc = L.s3_copy_channels(dev.ctx, self._ptr(dre), c, 0,
+                                        self._ptr(d_gen), c, 0, c_used,
+                                        n * s1 * s2 * t, 1)
+                _lib.check(rc, dev.ctx, 's3_copy_channels')
+            return [1.0]
         if kind == 'mmd':
             if c_used > 8:
                 raise ValueError('MmdLoss kernel handles at most 8 features')

@@ -445,3 +445,129 @@ extern "C" int s3_loss_mmd(s3_ctx* ctx, const float* a, int c_a, const float* b,
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
+
+// ===========================================================================
+// SpatialFftLoss / SpatiotemporalFftLoss (loss_metrics.py:395-485): MAE between
+// log(1 + w |FFT(x)|) of generated and true fields, w = product of the squared
+// (un-wrapped) frequency indices.  The transform is a separable direct DFT —
+// one pass per axis over a (outer, L, inner) view, L <= 512 here (80, 288):
+// a workgroup holds a panel of columns and the L twiddles in LDS.  Unnormalised,
+// sign = -1 forward (tf.signal.fft2d / fft3d), +1 for the adjoint.
+namespace {
+
+constexpr int DFT_COLS = 32;      // columns (outer x inner) per workgroup
+
+__global__ __launch_bounds__(256) void dft_axis_kernel(
+    const float* __restrict__ in_re, const float* __restrict__ in_im,
+    float* __restrict__ out_re, float* __restrict__ out_im, int64_t outer, int L, int64_t inner,
+    float sign) {
+  extern __shared__ float dsm[];
+  float* pre = dsm;                       // [L][DFT_COLS]
+  float* pim = pre + (size_t)L * DFT_COLS;
+  float* tc = pim + (size_t)L * DFT_COLS; // cos, sin of 2 pi m / L
+  float* ts = tc + L;
+  const int64_t ncol = outer * inner;
+  const int64_t col0 = (int64_t)blockIdx.x * DFT_COLS;
+  for (int m = threadIdx.x; m < L; m += blockDim.x) {
+    float s, c;
+    sincospif(2.f * (float)m / (float)L, &s, &c);
+    tc[m] = c; ts[m] = sign * s;
+  }
+  for (int e = threadIdx.x; e < L * DFT_COLS; e += blockDim.x) {
+    const int j = e / DFT_COLS, cc = e % DFT_COLS;
+    const int64_t col = col0 + cc;
+    float vr = 0.f, vi = 0.f;
+    if (col < ncol) {
+      const int64_t o = col / inner, i = col % inner;
+      const int64_t a = (o * L + j) * inner + i;
+      vr = in_re[a];
+      vi = in_im ? in_im[a] : 0.f;
+    }
+    pre[e] = vr; pim[e] = vi;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < L * DFT_COLS; e += blockDim.x) {
+    const int k = e / DFT_COLS, cc = e % DFT_COLS;
+    const int64_t col = col0 + cc;
+    if (col >= ncol) continue;
+    float ar = 0.f, ai = 0.f;
+    int idx = 0;
+    for (int j = 0; j < L; ++j) {
+      const float c = tc[idx], s = ts[idx];
+      const float xr = pre[j * DFT_COLS + cc], xi = pim[j * DFT_COLS + cc];
+      ar += xr * c - xi * s;
+      ai += xr * s + xi * c;
+      idx += k;
+      if (idx >= L) idx -= L;
+    }
+    const int64_t o = col / inner, i = col % inner;
+    const int64_t a = (o * L + k) * inner + i;
+    out_re[a] = ar; out_im[a] = ai;
+  }
+}
+
+// y = log(1 + w |X|); mode3d: w = k1^2 k2^2 kt^2, else k1^2 k2^2
+__global__ void specmap_fwd_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                                   float* __restrict__ y, LGeom g, int mode3d) {
+  const int64_t total = (int64_t)g.n * g.s1 * g.s2 * g.t * g.c;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int n, i1, i2, it, ch;
+    decode(idx, g, g.c, n, i1, i2, it, ch);
+    float w = (float)i1 * (float)i1 * (float)i2 * (float)i2;
+    if (mode3d) w *= (float)it * (float)it;
+    y[idx] = log1pf(w * sqrtf(re[idx] * re[idx] + im[idx] * im[idx]));
+  }
+}
+
+// G = g_y * w / (1 + w |X|) * X / |X|  (0 where |X| = 0, as tf.abs does)
+__global__ void specmap_bwd_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                                   const float* __restrict__ gy, float* __restrict__ gre,
+                                   float* __restrict__ gim, LGeom g, int mode3d) {
+  const int64_t total = (int64_t)g.n * g.s1 * g.s2 * g.t * g.c;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int n, i1, i2, it, ch;
+    decode(idx, g, g.c, n, i1, i2, it, ch);
+    float w = (float)i1 * (float)i1 * (float)i2 * (float)i2;
+    if (mode3d) w *= (float)it * (float)it;
+    const float xr = re[idx], xi = im[idx];
+    const float mag = sqrtf(xr * xr + xi * xi);
+    const float f = mag > 0.f ? gy[idx] * w / ((1.f + w * mag) * mag) : 0.f;
+    gre[idx] = f * xr; gim[idx] = f * xi;
+  }
+}
+
+}  // namespace
+
+extern "C" int s3_dft_axis(s3_ctx* ctx, const float* in_re, const float* in_im, float* out_re,
+                           float* out_im, int64_t outer, int L, int64_t inner, int sign) {
+  if (!ctx || L < 1 || outer < 1 || inner < 1) return S3_EINVAL;
+  if (L > 1024) S3_FAIL(ctx, S3_EINVAL, "dft_axis: axis longer than 1024");
+  const size_t lds = ((size_t)2 * L * DFT_COLS + 2 * L) * sizeof(float);
+  const int64_t ncol = outer * inner;
+  const void* kern = reinterpret_cast<const void*>(dft_axis_kernel);
+  if (lds > 64 * 1024)
+    S3_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(dft_axis_kernel, dim3((unsigned)((ncol + DFT_COLS - 1) / DFT_COLS)), dim3(256),
+                     lds, ctx->stream, in_re, in_im, out_re, out_im, outer, L, inner,
+                     sign < 0 ? -1.f : 1.f);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_specmap(s3_ctx* ctx, int backward, const float* re, const float* im,
+                          const float* g_y, int n, int s1, int s2, int t, int c, int mode3d,
+                          float* out0, float* out1) {
+  LGeom g{n, s1, s2, t, c, c};
+  if (!geom_ok(ctx, g)) return S3_EINVAL;
+  const int64_t total = (int64_t)n * s1 * s2 * t * c;
+  if (!backward)
+    hipLaunchKernelGGL(specmap_fwd_kernel, dim3(grid_of(total, ctx->num_cu)), dim3(kB), 0,
+                       ctx->stream, re, im, out0, g, mode3d);
+  else
+    hipLaunchKernelGGL(specmap_bwd_kernel, dim3(grid_of(total, ctx->num_cu)), dim3(kB), 0,
+                       ctx->stream, re, im, g_y, out0, out1, g, mode3d);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}

@@ -119,6 +119,7 @@ SPECS = [
                     'ex_loss': 'SpatialExtremesLoss'}},
     {'MaterialDerivativeLoss': {}, 'MeanAbsoluteError': {},
      'SpatialExtremesLoss': {}, 'term_weights': [0.2, 0.7, 0.1]},
+    'SpatiotemporalFftLoss',
 ]
 
 
@@ -200,6 +201,65 @@ def test_device_losses_4d_and_exo_channels():
         assert np.all(grad[..., 2] == 0)
     with pytest.raises(AssertionError):
         _device_loss_and_grad('TemporalDerivativeLoss', gen, true)
+
+
+def test_oracle_st_fft_loss_reference_procedure():
+    """test_st_fft_loss: the 1/4 (FFT + spatial extremes + temporal extremes +
+    MAE) combination on all-zero fields with one spike is > 1"""
+    def loss_obj(x, y):
+        return 0.25 * (OL.spatiotemporal_fft_loss(x, y) +
+                       OL.spatial_extremes_loss(x, y) +
+                       OL.temporal_extremes_loss(x, y) + OL.mae(x, y))
+    for sign in (1, -1):
+        x = np.zeros((1, 10, 10, 5, 1))
+        y = np.zeros((1, 10, 10, 5, 1))
+        assert OL.spatiotemporal_fft_loss(x, y) == 0
+        x[:, 5, 5, 2, 0] = sign * 100
+        y[:, 5, 5, 2, 0] = sign * 150
+        assert loss_obj(x, y) > 1.0
+        assert OL.spatiotemporal_fft_loss(x, y) > 0.2
+
+
+@pytest.mark.gpu
+def test_device_spatial_fft_loss_4d_and_dft_axis():
+    """s3_dft_axis against numpy's fft (1e-4 of the largest bin: fp32 direct
+    sums of up to 37 terms) and SpatialFftLoss on a 4-D batch with a trailing
+    exo channel"""
+    import torch
+    from sup3r_amd import _lib
+    from sup3r_amd.engine import Device
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    dev = Device.get()
+    L = _lib.lib()
+    x = rng.standard_normal((3, 37, 20)).astype(np.float32)
+    xi = rng.standard_normal((3, 37, 20)).astype(np.float32)
+    d = [dev.to_device(v) for v in (x, xi)]
+    ore, oim = torch.empty_like(d[0]), torch.empty_like(d[0])
+    for sign in (-1, 1):
+        rc = L.s3_dft_axis(dev.ctx, C.c_void_p(d[0].data_ptr()),
+                           C.c_void_p(d[1].data_ptr()),
+                           C.c_void_p(ore.data_ptr()), C.c_void_p(oim.data_ptr()),
+                           3, 37, 20, sign)
+        _lib.check(rc, dev.ctx, 's3_dft_axis')
+        z = x.astype(np.float64) + 1j * xi
+        ref = np.fft.fft(z, axis=1) if sign < 0 else np.fft.ifft(z, axis=1) * 37
+        got = ore.cpu().numpy() + 1j * oim.cpu().numpy()
+        assert np.abs(got - ref).max() < 1e-4 * np.abs(ref).max()
+    gen = rng.standard_normal((4, 10, 15, 3)).astype(np.float32)
+    true = rng.standard_normal((4, 10, 15, 3)).astype(np.float32)
+    loss, grad = _device_loss_and_grad('SpatialFftLoss', gen, true, n_exo=1)
+    ref = OL.spatial_fft_loss(gen[..., :2].astype(np.float64),
+                              true[..., :2].astype(np.float64))
+    assert abs(loss - ref) <= 1e-4 * max(1.0, abs(ref))
+    assert np.all(grad[..., 2] == 0) and np.abs(grad[..., :2]).max() > 0
+    g64, t64 = gen[..., :2].astype(np.float64), true[..., :2].astype(np.float64)
+    v = rng.standard_normal(g64.shape)
+    eps = 1e-5
+    fd = (OL.spatial_fft_loss(g64 + eps * v, t64) -
+          OL.spatial_fft_loss(g64 - eps * v, t64)) / (2 * eps)
+    an = float((grad[..., :2].astype(np.float64) * v).sum())
+    assert abs(an - fd) <= 5e-3 * max(abs(fd), 1e-3), (an, fd)
 
 
 @pytest.mark.gpu
