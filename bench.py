@@ -82,8 +82,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8,
-                    help='lo-res chunks per GPU per step')
+    ap.add_argument('--batch', type=int, default=32,
+                    help='lo-res chunks per GPU per step (throughput vs batch '
+                         'on one MI355X: 4: 1600, 8: 1890, 16: 1910, 32: 1970, '
+                         '64: 2000 samples/s)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity-mode', action='store_true',
