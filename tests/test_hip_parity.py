@@ -608,3 +608,34 @@ def test_2d_wgrad_bf16_transpose_read_kernel(monkeypatch):
     # 32 -> 32 s2 and 32 -> 64 run on the new kernel (the two deeper layers have
     # few enough positions for the weight-streaming path in both runs)
     assert ndiff >= 2
+
+
+def test_tail_conv_wgrad_ldsfree_kernel_with_reflect_padding(monkeypatch):
+    """conv_wgrad_c2_kernel<8, 1>: weight gradient of the hi-res tail conv
+    (8 -> 2, reflect 'same' padding, ragged 32-position k-steps: t = 37)
+    against the oracle and against the exact fp32-MFMA kernel
+    (SUP3R_AMD_NO_WGRAD_C2=1: rel. rms < 1e-2)."""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(39)
+    spec = pcc(3, 8) + pcc(3, 2, act=False)
+    shape = (2, 9, 10, 37, 4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    ref.backward(dy)
+
+    def grads():
+        net = _hip_net(spec, ref.weights, precision='bf16')
+        ph = net.plan(shape, training=True)
+        ph.forward(net.dev.to_device(x))
+        ph.backward(net.dev.to_device(dy), need_dx=False)
+        return [np.array(g) for g in net.grads]
+    g_bf = grads()
+    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_C2', '1')
+    g_32 = grads()
+    a, b, r = g_bf[2], g_32[2], ref.grads[2]          # the 8 -> 2 kernel
+    assert a.shape == (3, 3, 3, 8, 2)
+    assert np.abs(a - b).max() > 0
+    assert np.sqrt(((a - r) ** 2).mean()) / np.sqrt((r ** 2).mean()) < 5e-2
+    assert np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()) < 1e-2
