@@ -48,6 +48,7 @@ struct OpRec {
   bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false, wgrad_bf16_2d = false;
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
+  bool dgrad_fewch = false;    // C_out <= 4 'same' conv: dgrad = few-channel forward conv over the frame
   void* dc2_w = nullptr;
   int64_t dc2_version = -1;
   ConvGeom dg;                 // geometry of the dgrad-as-conv launch
@@ -410,6 +411,17 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               conv_dgrad_mfma_valid_supported(g, precision)) {
             o.dgrad_mfma = o.dgrad_valid = true;
           }
+          if (!o.dgrad_mfma && !o.fewpos && precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_NO_DGRAD_FEWCH") &&
+              (g.Cout == 2 || g.Cout == 4) && g.Cin % 4 == 0 && g.d2s == 1 &&
+              (int64_t)g.N * g.D[0] * g.D[1] * g.D[2] >= 4096) {
+            // hi-res tail conv (8 -> 2): its data gradient is a conv with 2 input
+            // channels — the taps-in-K few-channel kernel over the padded frame
+            bool same = true;
+            for (int q = 0; q < 3; ++q)
+              same = same && g.k[q] == 3 && g.s[q] == 1 && g.lo[q] == 1 && g.O[q] == g.D[q];
+            if (same && conv_gconv_supported(conv_dgrad_geom(g), precision))
+              o.dgrad_mfma = o.dgrad_fewch = true;
+          }
           o.dgrad_c2 = !o.dgrad_mfma && !o.fewpos && conv_dgrad_c2_supported(g, precision);
           o.gconv_dgrad = !o.dgrad_mfma && !o.dgrad_c2 && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
           if (o.gconv_dgrad && g.pad_mode == S3_PAD_REFLECT)
@@ -567,7 +579,8 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       if (rc || o.d.kind != S3_OP_CONV || !o.dgrad_mfma) continue;
       rc = plan_alloc(pl, (void**)&o.dg_w32, (size_t)27 * o.cg.Cin * o.cg.Cout * sizeof(float));
       if (!rc && precision == S3_PREC_BF16)
-        rc = plan_alloc(pl, &o.dg_wbf, conv_mfma_packed_bytes(o.dg, precision));
+        rc = plan_alloc(pl, &o.dg_wbf, o.dgrad_fewch ? conv_gconv_packed_bytes(o.dg, 0)
+                                                     : conv_mfma_packed_bytes(o.dg, precision));
     }
     if (rc) { s3_plan_destroy(pl); return rc; }
   }
@@ -964,14 +977,19 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             // the adjoint of the virtual padding folds the border back
             if (o.dg_version != P->version) {
               rc = launch_conv_dgrad_pack(ctx, g, W + P->p[d.w].offset, o.dg_w32);
-              if (!rc && pl->precision == S3_PREC_BF16)
+              if (!rc && o.dgrad_fewch)
+                rc = launch_gconv_pack(ctx, o.dg, o.dg_w32, o.dg_wbf, 0);
+              else if (!rc && pl->precision == S3_PREC_BF16)
                 rc = launch_conv_mfma_pack(ctx, o.dg, pl->precision, o.dg_w32, o.dg_wbf);
               if (rc) return rc;
               o.dg_version = P->version;
             }
             const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.dg_wbf : (const void*)o.dg_w32;
-            rc = launch_conv_mfma_fwd(ctx, o.dg, pl->precision, dpre, wp, nullptr, nullptr,
-                                      o.dgrad_valid ? dst : pl->dxp, ConvIO());
+            if (o.dgrad_fewch)
+              rc = launch_gconv_fwd(ctx, o.dg, dpre, o.dg_wbf, nullptr, nullptr, pl->dxp, 0);
+            else
+              rc = launch_conv_mfma_fwd(ctx, o.dg, pl->precision, dpre, wp, nullptr, nullptr,
+                                        o.dgrad_valid ? dst : pl->dxp, ConvIO());
             if (rc) return rc;
             if (o.dgrad_valid) {
               rc = grad_deliver(pl, d.in0, dst);

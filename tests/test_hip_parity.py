@@ -636,6 +636,14 @@ def test_tail_conv_wgrad_ldsfree_kernel_with_reflect_padding(monkeypatch):
     g_32 = grads()
     a, b, r = g_bf[2], g_32[2], ref.grads[2]          # the 8 -> 2 kernel
     assert a.shape == (3, 3, 3, 8, 2)
+    # its data gradient runs as a 2-channel forward conv over the padded frame
+    # (SUP3R_AMD_NO_DGRAD_FEWCH=1: direct kernel, fp32): the first conv's
+    # weight gradient sees it
+    monkeypatch.setenv('SUP3R_AMD_NO_DGRAD_FEWCH', '1')
+    g_dd = grads()
+    assert np.abs(g_32[0] - g_dd[0]).max() > 0
+    rms0 = np.sqrt(((g_32[0] - g_dd[0]) ** 2).mean()) / np.sqrt((g_dd[0] ** 2).mean())
+    assert rms0 < 1e-2, rms0
     assert np.abs(a - b).max() > 0
     assert np.sqrt(((a - r) ** 2).mean()) / np.sqrt((r ** 2).mean()) < 5e-2
     assert np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()) < 1e-2
