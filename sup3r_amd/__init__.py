@@ -12,7 +12,7 @@ __version__ = '0.1.0'
 
 from .gan import Sup3rGan  # noqa: E402,F401
 from .condmom import Sup3rCondMom  # noqa: E402,F401
-from .dc import Sup3rGanDC  # noqa: E402,F401
+from .data_centric import Sup3rGanDC  # noqa: E402,F401
 from .forward_pass import ChunkSlicer, ForwardPass  # noqa: E402,F401
 from .multi_step import MultiStepGan  # noqa: E402,F401
 from .batch_queue import (DeviceBatchHandler, DeviceBatchQueue,  # noqa: E402,F401

@@ -146,30 +146,34 @@ class DeviceBatchQueue:
 
     # --------------------------------------------------------------- checks
     def preflight(self):
+        """Consistency of the samplers with each other and with the queue
+        (feature lists, sample shape vs enhancement factors, batch size);
+        eager mode materialises the sampler data first."""
         self.check_features()
         self.check_enhancement_factors()
         self.check_shared_attr('sample_shape')
-        sampler_bs = self.check_shared_attr('batch_size')
-        msg = (f'Samplers have a different batch_size: {sampler_bs} than the '
-               f'BatchQueue: {self.batch_size}')
-        assert sampler_bs == self.batch_size, msg
+        sizes = {int(c.batch_size) for c in self.containers}
+        assert sizes == {int(self.batch_size)}, (
+            f'Samplers have a different batch_size: {sorted(sizes)} than the '
+            f'BatchQueue: {self.batch_size}')
         if self.mode == 'eager':
             logger.info('Received mode = "eager".')
             for c in self.containers:
-                if hasattr(c, 'compute'):
-                    c.compute()
+                getattr(c, 'compute', lambda: None)()
 
     def check_features(self):
-        feats = [list(c.features) for c in self.containers]
-        msg = 'Received samplers with different sets of features.'
-        assert all(f == feats[0] for f in feats), msg
+        ref = self.features
+        for c in self.containers[1:]:
+            assert list(c.features) == ref, \
+                'Received samplers with different sets of features.'
 
     def check_enhancement_factors(self):
-        msg = (f'The sample_shape {self.sample_shape} is not consistent with '
-               f'the enhancement factors {self.s_enhance, self.t_enhance}.')
-        assert all(samp % enh == 0 for samp, enh in zip(
-            self.sample_shape,
-            [self.s_enhance, self.s_enhance, self.t_enhance])), msg
+        s1, s2, t = self.sample_shape
+        ok = not (s1 % self.s_enhance or s2 % self.s_enhance
+                  or t % self.t_enhance)
+        assert ok, (f'The sample_shape {self.sample_shape} is not consistent '
+                    'with the enhancement factors '
+                    f'{self.s_enhance, self.t_enhance}.')
 
     # ------------------------------------------------------------ transform
     def transform(self, samples, smoothing=None, smoothing_ignore=None,
@@ -233,38 +237,39 @@ class DeviceBatchQueue:
         return self._training_flag.is_set()
 
     def sample_batches(self, n_batches):
-        """``n_batches`` raw batches, in serial or as thread-pool futures"""
-        if n_batches == 1 or self.max_workers == 1:
-            return [self.sample_batch() for _ in range(n_batches)]
-        return [self._thread_pool.submit(self.sample_batch)
-                for _ in range(n_batches)]
+        """``n_batches`` raw batches: a list of arrays, or of futures when the
+        thread pool has more than one worker"""
+        if self.max_workers > 1 and n_batches > 1:
+            return [self._thread_pool.submit(self.sample_batch)
+                    for _ in range(n_batches)]
+        return [self.sample_batch() for _ in range(n_batches)]
 
     def enqueue_batches(self):
-        """Queue-thread callback: fill the empty slots while training."""
-        log_time = time.time()
+        """Body of the queue thread: top the FIFO up to ``queue_cap`` until
+        ``stop()`` clears the flag."""
+        last_log = time.time()
         while self.running:
-            needed = max(self.queue_cap - self.queue.qsize(), 0)
-            if needed > 0:
-                batches = self.sample_batches(n_batches=needed)
-                if needed > 1 and self.max_workers > 1:
-                    for fut in as_completed(batches):
-                        self._put(fut.result())
-                else:
-                    for batch in batches:
-                        self._put(batch)
-            else:
+            room = self.queue_cap - self.queue.qsize()
+            if room <= 0:
                 time.sleep(0.001)
-            if time.time() > log_time + 60:
+            else:
+                for item in self.sample_batches(room):
+                    done = item.result() if hasattr(item, 'result') else item
+                    if not self._put(done):
+                        break
+            if time.time() - last_log > 60:
                 logger.debug(self.log_queue_info())
-                log_time = time.time()
+                last_log = time.time()
 
     def _put(self, batch):
+        """blocking put that gives up when the queue is stopped"""
         while self.running:
             try:
                 self.queue.put(batch, timeout=0.05)
-                return
+                return True
             except queue.Full:
-                continue
+                pass
+        return False
 
     def get_container_index(self):
         indices = np.arange(0, len(self.containers))
@@ -291,22 +296,24 @@ class DeviceBatchQueue:
         return self
 
     def get_batch(self):
-        if self.mode == 'eager' or self.queue_cap == 0 or \
-                not self.queue_thread.is_alive():
+        """next raw batch (from the FIFO while its thread is alive, otherwise
+        sampled on the spot), time axis squeezed for spatial-only samples,
+        then ``post_proc``"""
+        use_queue = (self.mode != 'eager' and self.queue_cap > 0
+                     and self.queue_thread.is_alive())
+        samples = None
+        while use_queue and samples is None:
+            try:
+                samples = self.queue.get(timeout=0.05)
+            except queue.Empty:
+                use_queue = self.queue_thread.is_alive()
+        if samples is None:
             samples = self.sample_batch()
-        else:
-            samples = None
-            while samples is None:
-                try:
-                    samples = self.queue.get(timeout=0.05)
-                except queue.Empty:
-                    if not self.queue_thread.is_alive():
-                        samples = self.sample_batch()
         if self.sample_shape[2] == 1:
-            if isinstance(samples, (list, tuple)):
-                samples = tuple(s[..., 0, :] for s in samples)
-            else:
-                samples = samples[..., 0, :]
+            squeeze = lambda a: a[..., 0, :]          # noqa: E731
+            samples = (tuple(squeeze(a) for a in samples)
+                       if isinstance(samples, (list, tuple))
+                       else squeeze(samples))
         return self.post_proc(samples)
 
     def __next__(self):
