@@ -151,7 +151,7 @@ bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                            const float* dy, float* dw, float* partial,
-                           size_t partial_bytes, int accumulate);
+                           size_t partial_bytes, int accumulate, int x_bf16);
 // wgrad: persistent-workgroup kernel (kernels_conv_wgrad_mfma.hip)
 bool conv_wgrad_mfma_supported(const ConvGeom& g);
 size_t conv_wgrad_mfma_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
@@ -197,7 +197,7 @@ int launch_act_bwd(s3_ctx* ctx, const float* y, const float* dy, float* dx,
                    int64_t n, int act, float alpha);
 // dpre[pos][c] = dy[d2s-permuted] * act'(y[d2s-permuted]) (conv epilogue adj.)
 int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
-                             const float* dy, float* dpre);
+                             const float* dy, float* dpre, int y_bf16);
 int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
                int c, int bcast_c);
 int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n);  // y += x

@@ -55,6 +55,7 @@ __device__ __forceinline__ s16x4 lds_tr(const char* p) {
       (s16x4 __attribute__((address_space(3)))*)(p));
 }
 
+template <bool IN16>
 __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
@@ -108,8 +109,10 @@ __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
     // ---- stage x halo: 648 cells x 16 float4 -> bf16
     // (dbg: timing-only ablations, results invalid — bit 0 stages the first
     // tile only, bit 1 skips the MFMA loop)
-    for (int item = tid; item < (((dbg & 1) && tile != (int)blockIdx.x) ? 0 : BHP * 16); item += BNT) {
-      const int hp = item >> 4, ch = item & 15;
+    // (IN16: x is a bf16 tensor — 16-B chunks of 8 channels, no convert)
+    constexpr int XCH = IN16 ? 8 : 16;          // chunks per cell
+    for (int item = tid; item < (((dbg & 1) && tile != (int)blockIdx.x) ? 0 : BHP * XCH); item += BNT) {
+      const int hp = item / XCH, ch = item % XCH;
       int h = hp;
       const int c2 = h % BH2; h /= BH2;
       const int c1 = h % BH1; h /= BH1;
@@ -125,12 +128,18 @@ __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
       i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
       i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
       i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
-      float4 v = make_float4(0, 0, 0, 0);
-      if (valid)
-        v = *reinterpret_cast<const float4*>(
-            x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * 64 + ch * 4);
-      uint2 pk = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
-      *reinterpret_cast<uint2*>(xs + hp * 128 + (((ch >> 2) ^ xs_key(c2)) << 5) + ((ch & 3) << 3)) = pk;
+      const size_t cell = (((size_t)n * D0 + i0) * D1 + i1) * D2 + i2;
+      if constexpr (IN16) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (valid)
+          v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(x) + cell * 64 + ch * 8);
+        *reinterpret_cast<uint4*>(xs + hp * 128 + (((ch >> 1) ^ xs_key(c2)) << 5) + ((ch & 1) << 4)) = v;
+      } else {
+        float4 v = make_float4(0, 0, 0, 0);
+        if (valid) v = *reinterpret_cast<const float4*>(x + cell * 64 + ch * 4);
+        uint2 pk = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+        *reinterpret_cast<uint2*>(xs + hp * 128 + (((ch >> 2) ^ xs_key(c2)) << 5) + ((ch & 3) << 3)) = pk;
+      }
     }
     // ---- stage dPre tile: 256 positions x 8 float4 (zero outside / beyond C_out)
     for (int item = tid; item < (((dbg & 1) && tile != (int)blockIdx.x) ? 0 : BNP * (BCT / 4)); item += BNT) {
@@ -627,21 +636,27 @@ size_t conv_wgrad_bf16_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
 
 int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                            const float* dy, float* dw, float* partial,
-                           size_t partial_bytes, int accumulate) {
+                           size_t partial_bytes, int accumulate, int x_bf16) {
   int n_tiles, tiles0, tiles1, tiles2;
   const int grid = bf_grid(ctx, g, &n_tiles, &tiles0, &tiles1, &tiles2);
   if (partial_bytes < conv_wgrad_bf16_partial_bytes(ctx, g))
     S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16: partial buffer too small");
   static bool attr_set = false;
   if (!attr_set) {
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel),
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
     attr_set = true;
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
   static const int dbg = getenv("SUP3R_AMD_WGRAD_DBG") ? atoi(getenv("SUP3R_AMD_WGRAD_DBG")) : 0;
-  hipLaunchKernelGGL(conv3_wgrad_bf16_kernel, dim3(grid, n_ct), dim3(BNT), BF_LDS,
-                     ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles, dbg);
+  if (x_bf16)
+    hipLaunchKernelGGL(conv3_wgrad_bf16_kernel<true>, dim3(grid, n_ct), dim3(BNT), BF_LDS,
+                       ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles, dbg);
+  else
+    hipLaunchKernelGGL(conv3_wgrad_bf16_kernel<false>, dim3(grid, n_ct), dim3(BNT), BF_LDS,
+                       ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles, dbg);
   S3_HIP(ctx, hipGetLastError());
   const int64_t wsize = (int64_t)27 * 64 * g.Cout;
   hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3((unsigned)((wsize + 255) / 256)), dim3(256), 0,

@@ -227,6 +227,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ y,
 }
 
 // dpre[n,o0,o1,o2,c] = dy[perm] * act'(y[perm]) with the d2s store permutation
+template <bool Y16>
 __global__ void conv_epilogue_bwd_kernel(const float* __restrict__ y,
                                          const float* __restrict__ dy,
                                          float* __restrict__ dpre, ConvGeom g) {
@@ -247,7 +248,11 @@ __global__ void conv_epilogue_bwd_kernel(const float* __restrict__ y,
       src = ((((int64_t)n * g.O[0] * b + o0 * b + blk / b) * (g.O[1] * b) +
               o1 * b + blk % b) * g.O[2] + o2) * co + cc;
     }
-    dpre[idx] = dy[src] * act_d(y[src], g.act, g.alpha);
+    // (Y16: the saved activation is a bf16 tensor; only its sign matters
+    // for ReLU / LeakyReLU)
+    const float yv = Y16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(y)[src] << 16)
+                         : y[src];
+    dpre[idx] = dy[src] * act_d(yv, g.act, g.alpha);
   }
 }
 
@@ -624,9 +629,12 @@ int launch_act_bwd(s3_ctx* ctx, const float* y, const float* dy, float* dx,
 }
 
 int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
-                             const float* dy, float* dpre) {
+                             const float* dy, float* dpre, int y_bf16) {
   int64_t n = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout;
-  hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, y, dy, dpre, g);
+  if (y_bf16)
+    hipLaunchKernelGGL(conv_epilogue_bwd_kernel<true>, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, y, dy, dpre, g);
+  else
+    hipLaunchKernelGGL(conv_epilogue_bwd_kernel<false>, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, y, dy, dpre, g);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

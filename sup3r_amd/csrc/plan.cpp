@@ -463,7 +463,15 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
   // bf16 when its producer can write it (MFMA conv, direct conv, index op) and
   // EVERY consumer can read it (MFMA conv input / residual, index op);
   // everything else — plan inputs/outputs, training plans, f32 mode — is fp32.
-  if (!training && precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_FP32_ACT")) {
+  // Training plans (SUP3R_AMD_BF16_TRAIN_ACT=0 opts out): the same, but a saved
+  // activation is also read by the backward pass — a tensor stays bf16 only if
+  // every conv that consumes it takes its weight gradient through the
+  // transpose-read bf16 kernel (which stages bf16 directly); the LeakyReLU
+  // mask pass reads the sign of a bf16 output; gradients stay fp32.  The
+  // forward is then bit-identical to the bf16 inference plan of the trunk.
+  const bool train16 = training && precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_FP32_ACT") &&
+                       !(getenv("SUP3R_AMD_BF16_TRAIN_ACT") && atoi(getenv("SUP3R_AMD_BF16_TRAIN_ACT")) == 0);
+  if ((!training || train16) && precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_FP32_ACT")) {
     std::vector<int> dt(n_tensors, 1);
     auto demote = [&](int id, bool& changed) {
       if (id < 0) return;
@@ -489,6 +497,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
           case S3_OP_CONV:
             if (o.mfma) {
               if (!conv_mfma_bf16_out_ok(o.cg)) demote(d.out, changed);
+              if (training && !o.wgrad_bf16) demote(d.in0, changed);
+            } else if (training) {
+              // every other conv reads / writes fp32 in training plans
+              demote(d.in0, changed); demote(d.res, changed); demote(d.out, changed);
             } else {
               // the direct kernels read fp32, except the small-channel tail
               // convs (MFMA C_in = 8 / sliding window) which take bf16 cells
@@ -522,6 +534,13 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     o.io.in_bf16 = pl->t[root_of(pl, o.d.in0)].dtype;
     o.io.out_bf16 = pl->t[root_of(pl, o.d.out)].dtype;
     o.io.res_bf16 = o.d.res >= 0 ? pl->t[root_of(pl, o.d.res)].dtype : 0;
+    if (getenv("SUP3R_AMD_TRACE"))
+      fprintf(stderr, "[plan] conv %d->%d %s: mfma %d fewpos %d gconv %d | in16 %d out16 %d res16 %d | "
+              "wgrad bf16 %d gen %d 2d %d c2 %d mfma %d | dgrad mfma %d c2 %d gconv %d\n",
+              o.cg.Cin, o.cg.Cout, training ? "train" : "infer", (int)o.mfma, (int)o.fewpos, (int)o.gconv,
+              o.io.in_bf16, o.io.out_bf16, o.io.res_bf16, (int)o.wgrad_bf16, (int)o.wgrad_bf16_gen,
+              (int)o.wgrad_bf16_2d, (int)o.wgrad_c2, (int)o.wgrad_mfma, (int)o.dgrad_mfma, (int)o.dgrad_c2,
+              (int)o.gconv_dgrad);
   }
 
   // ---- static arena planning.  Training keeps every tensor; inference
@@ -942,7 +961,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
         }
         const float* dpre = dy;
         if (g.act != S3_ACT_NONE || g.d2s > 1) {
-          rc = launch_conv_epilogue_bwd(ctx, g, tptr(pl, d.out), dy, pl->dpre);
+          rc = launch_conv_epilogue_bwd(ctx, g, tptr(pl, d.out), dy, pl->dpre, o.io.out_bf16);
           if (rc) return rc;
           dpre = pl->dpre;
         }
@@ -963,7 +982,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           else if (o.wgrad_gen)
             rc = launch_conv_wgrad_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16)
-            rc = launch_conv_wgrad_bf16(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+            rc = launch_conv_wgrad_bf16(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16);
           else if (o.wgrad_mfma)
             rc = launch_conv_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else
