@@ -131,6 +131,12 @@ bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
                                float* dw, float* partial, size_t partial_bytes, int accumulate);
+// forward conv with C_in = 32 on an LDS halo (kernels_conv_halo32.hip)
+bool conv_halo32_supported(const s3_ctx* ctx, const ConvGeom& g, int precision);
+size_t conv_halo32_packed_bytes(const ConvGeom& g);
+int launch_conv_halo32_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
+int launch_conv_halo32_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* img,
+                           const float* bias, float* y);
 // dgrad of the few-channel hi-res conv with an LDS halo (kernels_conv_dgrad_fewch.hip)
 bool conv_dgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_dgrad_c2_packed_bytes();

@@ -49,6 +49,9 @@ struct OpRec {
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
   bool dgrad_fewch = false;    // C_out <= 4 'same' conv: dgrad = few-channel forward conv over the frame
+  bool halo32 = false;         // C_in = 32 stride-1 conv: LDS-halo forward
+  void* h32_w = nullptr;
+  uint64_t h32_version = 0;
   void* dc2_w = nullptr;
   int64_t dc2_version = -1;
   ConvGeom dg;                 // geometry of the dgrad-as-conv launch
@@ -369,6 +372,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             conv_wgrad_gen_supported(g))
           o.fewpos = false;
         o.gconv = !o.mfma && !o.fewpos && conv_gconv_supported(g, precision);
+        o.halo32 = o.gconv && d.res < 0 && conv_halo32_supported(ctx, g, precision);
         if (o.fewpos) {
           max_fp = std::max(max_fp, conv_fewpos_partial_bytes(g));
           if (training) {
@@ -535,10 +539,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     o.io.out_bf16 = pl->t[root_of(pl, o.d.out)].dtype;
     o.io.res_bf16 = o.d.res >= 0 ? pl->t[root_of(pl, o.d.res)].dtype : 0;
     if (getenv("SUP3R_AMD_TRACE"))
-      fprintf(stderr, "[plan] conv %d->%d %s: mfma %d fewpos %d gconv %d | in16 %d out16 %d res16 %d | "
+      fprintf(stderr, "[plan] conv %d->%d %s: mfma %d fewpos %d gconv %d halo32 %d | in16 %d out16 %d res16 %d | "
               "wgrad bf16 %d gen %d 2d %d c2 %d mfma %d | dgrad mfma %d c2 %d gconv %d\n",
               o.cg.Cin, o.cg.Cout, training ? "train" : "infer", (int)o.mfma, (int)o.fewpos, (int)o.gconv,
-              o.io.in_bf16, o.io.out_bf16, o.io.res_bf16, (int)o.wgrad_bf16, (int)o.wgrad_bf16_gen,
+              (int)o.halo32, o.io.in_bf16, o.io.out_bf16, o.io.res_bf16, (int)o.wgrad_bf16, (int)o.wgrad_bf16_gen,
               (int)o.wgrad_bf16_2d, (int)o.wgrad_c2, (int)o.wgrad_mfma, (int)o.dgrad_mfma, (int)o.dgrad_c2,
               (int)o.gconv_dgrad);
   }
@@ -628,6 +632,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       int rc = plan_alloc(pl, &o.gc_w, conv_gconv_packed_bytes(o.cg, 0));
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
+    if (o.halo32) {
+      int rc = plan_alloc(pl, &o.h32_w, conv_halo32_packed_bytes(o.cg));
+      if (rc) { s3_plan_destroy(pl); return rc; }
+    }
     if (o.dgrad_c2) {
       int rc = plan_alloc(pl, &o.dc2_w, conv_dgrad_c2_packed_bytes());
       if (rc) { s3_plan_destroy(pl); return rc; }
@@ -700,6 +708,14 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
         }
         const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.packed : (const void*)w;
         return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out), o.io);
+      }
+      if (o.halo32 && !o.io.in_bf16 && !o.io.out_bf16 && !res) {
+        if (o.h32_version != P->version) {
+          int rc = launch_conv_halo32_pack(ctx, o.cg, w, o.h32_w);
+          if (rc) return rc;
+          o.h32_version = P->version;
+        }
+        return launch_conv_halo32_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.h32_w, b, (float*)tptr(pl, d.out));
       }
       if (o.gconv && !o.io.in_bf16 && !o.io.res_bf16 && (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
         if (o.gc_version != P->version) {

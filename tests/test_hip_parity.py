@@ -690,3 +690,41 @@ def test_training_plan_bf16_saved_activations(monkeypatch):
     for a, b, r in zip(g16, g32, ref.grads):
         assert rel_rms(a, r) < 1e-1
         assert rel_rms(a, b) < 3e-2
+
+
+def test_halo32_forward_conv_vs_oracle_and_gather_kernel(monkeypatch, capfd):
+    """conv_halo32_kernel (C_in = 32, stride 1, valid and zero 'same' padding,
+    C_out 64 and 24 -> NF = 4 / 2, ragged 4 x 8 x 16 tiles): forward against
+    the oracle (bf16-mode bound) and against the gather-MFMA kernel, which
+    rounds the same operands to bf16 (SUP3R_AMD_NO_HALO32=1: 1e-5 of the
+    largest value — fp32 summation order only)."""
+    rng = np.random.default_rng(43)
+
+    def conv(f, s, pad='valid'):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': pad},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(64, 1) + conv(32, 2) + conv(24, 1, 'same')
+    shape = (2, 21, 23, 69, 2)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    monkeypatch.setenv('SUP3R_AMD_HALO32_MIN_TILES', '1')
+    monkeypatch.setenv('SUP3R_AMD_TRACE', '1')
+    net = _hip_net(spec, ref.weights, precision='bf16')
+    y = net(x).cpu().numpy()
+    ph = net.plan(shape, training=True)
+    yt = ph.forward(net.dev.to_device(x)).cpu().numpy()
+    trace = capfd.readouterr().err
+    # 32 -> 64 (valid) and 32 -> 24 ('same'), inference and training plan
+    assert trace.count('halo32 1') == 4, trace
+    monkeypatch.setenv('SUP3R_AMD_NO_HALO32', '1')
+    net2 = _hip_net(spec, ref.weights, precision='bf16')
+    y2 = net2(x).cpu().numpy()
+    assert 'halo32 1' not in capfd.readouterr().err
+    scale = max(1.0, np.abs(y_ref).max())
+    assert y.shape == y_ref.shape
+    assert np.abs(y - y_ref).max() < 3e-2 * scale
+    # same bf16 operands, same tap order: at most fp32 round-off apart
+    assert np.abs(y - y2).max() < 1e-4 * scale
+    np.testing.assert_array_equal(y, yt)
