@@ -420,6 +420,166 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_fewch_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-halo variant for stride-1 few-channel convs with many positions (the
+// 2 -> 32 discriminator layer over 13.9 M positions, the 8 -> 2 tail conv's
+// data gradient as a 2-channel conv over the padded frame): the input halo of
+// a 4 x 8 x 32 output tile is tiny (2040 cells x 2 C_in bytes as bf16), so it
+// is staged once with the padding rule applied (reflect or zero), and the B
+// operand of a position fragment is 8 / C_in LDS reads at per-lane tap offsets
+// — no global gather, no per-fragment index math.  The layer is then bound by
+// its output stores.
+constexpr int FH0 = 4, FH1 = 8, FH2 = 32;
+constexpr int FG0 = FH0 + 2, FG1 = FH1 + 2, FG2 = FH2 + 2;
+constexpr int FHP = FG0 * FG1 * FG2;          // 2040 halo cells
+constexpr int FHW = 4;                        // waves; 16 fragments each
+
+template <int CIN>
+__global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wpk,
+    const float* __restrict__ bias, void* __restrict__ yv, ConvGeom g, int tiles0, int tiles1,
+    int tiles2, int out_bf16) {
+  constexpr int TPL = 8 / CIN;                 // taps per lane per chunk
+  constexpr int KC = (27 * CIN + 31) / 32;     // chunks of 32
+  constexpr int KP = KC * 32;
+  constexpr int CELLB = 2 * CIN;               // bytes per halo cell (bf16)
+  __shared__ __attribute__((aligned(16))) char halo[(FHP + 1) * CELLB];   // + one zero cell
+  float* __restrict__ y = reinterpret_cast<float*>(yv);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p16 = lane & 15, kq = lane >> 4;
+  const int R = g.Cout, ct = blockIdx.y;
+  int tr = blockIdx.x;
+  const int t2i = tr % tiles2; tr /= tiles2;
+  const int t1i = tr % tiles1; tr /= tiles1;
+  const int t0i = tr % tiles0; tr /= tiles0;
+  const int n = tr;
+  const int org0 = t0i * FH0, org1 = t1i * FH1, org2 = t2i * FH2;
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+  const int nfv = (R - ct * GT_N + 15) / 16 < 4 ? (R - ct * GT_N + 15) / 16 : 4;
+
+  // ---- stage the halo: cell (c0, c1, c2) = x[org + c - lo] under the padding rule
+  for (int hp = tid; hp < FHP + 1; hp += FHW * 64) {
+    int h = hp;
+    const int c2 = h % FG2; h /= FG2;
+    const int c1 = h % FG1; h /= FG1;
+    const int c0 = h;
+    int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
+    if (g.pad_mode == S3_PAD_REFLECT) {
+      i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
+    }
+    const bool ok = hp < FHP && i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
+    const float* src = x + ((((int64_t)n * D0 + i0) * D1 + i1) * D2 + i2) * CIN;
+    if (CIN == 2) {
+      float2 t = make_float2(0.f, 0.f);
+      if (ok) t = *reinterpret_cast<const float2*>(src);
+      *reinterpret_cast<unsigned*>(halo + hp * CELLB) = pk2(t.x, t.y);
+    } else {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) t = *reinterpret_cast<const float4*>(src);
+      *reinterpret_cast<uint2*>(halo + hp * CELLB) = make_uint2(pk2(t.x, t.y), pk2(t.z, t.w));
+    }
+  }
+  // this lane's taps: chunk kc, slot q -> tap = (kc*32 + kq*8) / CIN + q; byte offset
+  // of its cell relative to the output position's halo origin (zero cell if tap >= 27)
+  int toff[KC][TPL];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+    for (int q = 0; q < TPL; ++q) {
+      const int tap = (kc * 32 + kq * 8) / CIN + q;
+      const int ta = tap / 9, tb = (tap / 3) % 3, tc = tap % 3;
+      toff[kc][q] = tap < 27 ? ((ta * FG1 + tb) * FG2 + tc) * CELLB : -1;
+    }
+  bf16x8 wf[KC][4];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+      if (nf < nfv)
+        wf[kc][nf] = *reinterpret_cast<const bf16x8*>(
+            wpk + ((int64_t)ct * GT_N + nf * 16 + p16) * KP + kc * 32 + kq * 8);
+  const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+  float bv[4][4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = ct * GT_N + nf * 16 + kq * 4 + r;
+      bv[nf][r] = (bias && ch < R) ? bias[ch] : 0.f;
+    }
+  __syncthreads();
+
+  // ---- 64 fragments per tile (32 rows x 2 halves of t), 16 per wave
+#pragma unroll 2
+  for (int f = 0; f < 16; ++f) {
+    const int fr = wave * 16 + f;
+    const int row = fr >> 1, half = fr & 1;
+    const int r0 = row / FH1, r1 = row % FH1;
+    const int pos = ((r0 * FG1 + r1) * FG2 + half * 16 + p16) * CELLB;   // halo origin of this lane's position
+    f32x4 acc[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      unsigned u[4];
+#pragma unroll
+      for (int q = 0; q < TPL; ++q) {
+        const int a = toff[kc][q] >= 0 ? pos + toff[kc][q] : FHP * CELLB;
+        if (CIN == 2) {
+          u[q] = *reinterpret_cast<const unsigned*>(halo + a);
+        } else {
+          const uint2 t = *reinterpret_cast<const uint2*>(halo + a);
+          u[2 * q] = t.x; u[2 * q + 1] = t.y;
+        }
+      }
+      const uint4 uu = make_uint4(u[0], u[1], u[2], u[3]);
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, uu);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        if (nf < nfv)
+          acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kc][nf], xf, acc[nf], 0, 0, 0);
+    }
+    const int o0 = org0 + r0, o1 = org1 + r1, o2 = org2 + half * 16 + p16;
+    if (o0 >= g.O[0] || o1 >= g.O[1] || o2 >= g.O[2]) continue;
+    const int64_t pp = (((int64_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2;
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int ch = ct * GT_N + nf * 16 + kq * 4;
+      if (nf >= nfv || ch >= R) continue;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[r] = acc[nf][r] + bv[nf][r];
+        o[r] = o[r] > 0.f ? o[r] : slope * o[r];
+      }
+      if ((R & 3) == 0) {
+        if (out_bf16)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(yv) + pp * R + ch) =
+              make_uint2(pk2(o[0], o[1]), pk2(o[2], o[3]));
+        else
+          *reinterpret_cast<float4*>(y + pp * R + ch) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ch + r < R) y[pp * R + ch + r] = o[r];
+      }
+    }
+  }
+}
+
+// the halo variant needs stride 1, no residual and enough tiles to fill the chip
+bool fewch_halo_ok(const s3_ctx* ctx, const ConvGeom& g, const float* res, int out_bf16) {
+  if (res || getenv("SUP3R_AMD_NO_FEWCH_HALO")) return false;
+  if (out_bf16 && (g.Cout & 3)) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g.s[d] != 1 || g.lo[d] < 0 || g.lo[d] > 2) return false;
+  const int64_t tiles = (int64_t)g.N * ((g.O[0] + FH0 - 1) / FH0) * ((g.O[1] + FH1 - 1) / FH1) *
+                        ((g.O[2] + FH2 - 1) / FH2);
+  const int64_t min_tiles = getenv("SUP3R_AMD_FEWCH_HALO_MIN_TILES")
+                                ? atoll(getenv("SUP3R_AMD_FEWCH_HALO_MIN_TILES")) : 2 * ctx->num_cu;
+  return tiles >= min_tiles;
+}
+
 // fp32 [27][cin][cout] -> bf16 [rows_pad][KP], k = tap * cin + ci
 __global__ void gconv_fewch_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                         int cin, int cout, int rows_pad, int kp) {
@@ -504,6 +664,18 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
   if (fewch_geom(g)) {
     dim3 fgrid((unsigned)((P + FC_POS - 1) / FC_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
     const unsigned short* img = (const unsigned short*)((const char*)packed + fewch_image_offset(g));
+    if (fewch_halo_ok(ctx, g, res, out_bf16)) {
+      const int t0 = (g.O[0] + FH0 - 1) / FH0, t1 = (g.O[1] + FH1 - 1) / FH1, t2 = (g.O[2] + FH2 - 1) / FH2;
+      dim3 hgrid((unsigned)(g.N * t0 * t1 * t2), (unsigned)((g.Cout + GT_N - 1) / GT_N));
+      if (g.Cin == 2)
+        hipLaunchKernelGGL(gconv_fewch_halo_kernel<2>, hgrid, dim3(FHW * 64), 0, ctx->stream, x, img, bias,
+                           y, g, t0, t1, t2, out_bf16);
+      else
+        hipLaunchKernelGGL(gconv_fewch_halo_kernel<4>, hgrid, dim3(FHW * 64), 0, ctx->stream, x, img, bias,
+                           y, g, t0, t1, t2, out_bf16);
+      S3_HIP(ctx, hipGetLastError());
+      return S3_OK;
+    }
     if (g.Cin == 2)
       hipLaunchKernelGGL(gconv_fewch_kernel<2>, fgrid, dim3(GT_WAVES * 64), 0, ctx->stream, x, img,
                          bias, res, y, g, P, out_bf16);

@@ -728,3 +728,34 @@ def test_halo32_forward_conv_vs_oracle_and_gather_kernel(monkeypatch, capfd):
     # same bf16 operands, same tap order: at most fp32 round-off apart
     assert np.abs(y - y2).max() < 1e-4 * scale
     np.testing.assert_array_equal(y, yt)
+
+
+def test_fewch_halo_forward_conv_vs_oracle_and_gather_variant(monkeypatch):
+    """gconv_fewch_halo_kernel (C_in 2 / 4, stride 1; valid, zero 'same' and
+    reflect padding; ragged 4 x 8 x 32 tiles): forward against the oracle
+    (bf16-mode bound) and against the gather variant of the same taps-in-K
+    formulation (SUP3R_AMD_NO_FEWCH_HALO=1: identical bf16 operands and
+    k order -> 1e-5 of the largest value)."""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(45)
+
+    def conv(f, pad):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': 1, 'padding': pad},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    cases = [(conv(32, 'valid'), (2, 11, 13, 45, 2)),
+             (conv(24, 'same'), (2, 9, 10, 37, 2)),
+             (pcc(3, 64), (2, 9, 10, 37, 4))]
+    monkeypatch.setenv('SUP3R_AMD_FEWCH_HALO_MIN_TILES', '1')
+    for spec, shape in cases:
+        x = rng.standard_normal(shape).astype(np.float32)
+        ref = _oracle_net(spec, x, None)
+        y_ref = ref.forward(x)
+        monkeypatch.delenv('SUP3R_AMD_NO_FEWCH_HALO', raising=False)
+        y = _hip_net(spec, ref.weights, precision='bf16')(x).cpu().numpy()
+        monkeypatch.setenv('SUP3R_AMD_NO_FEWCH_HALO', '1')
+        y2 = _hip_net(spec, ref.weights, precision='bf16')(x).cpu().numpy()
+        scale = max(1.0, np.abs(y_ref).max())
+        assert y.shape == y_ref.shape
+        assert np.abs(y - y_ref).max() < 3e-2 * scale, shape
+        assert np.abs(y - y2).max() < 1e-5 * scale, shape
