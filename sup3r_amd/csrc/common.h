@@ -152,6 +152,11 @@ bool conv_wgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_c2_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
                          float* dw, float* partial, size_t partial_bytes, int accumulate);
+// LDS-halo wgrad of the hi-res tail conv (C_in = 8), kernels_conv_wgrad_fewch.hip
+bool conv_wgrad_tail_supported(const ConvGeom& g, int precision);
+size_t conv_wgrad_tail_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
+int launch_conv_wgrad_tail(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                           float* dw, float* partial, size_t partial_bytes, int accumulate);
 // trunk wgrad on bf16 MFMA with LDS transpose reads (kernels_conv_wgrad_bf16.hip)
 bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);

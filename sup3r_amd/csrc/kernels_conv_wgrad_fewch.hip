@@ -214,3 +214,176 @@ int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const f
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
+
+// ===========================================================================
+// LDS-halo weight gradient of the hi-res tail conv (C_in = 8 -> C_out <= 16,
+// stride 1, any padding): dW[(tap, ci)][co] = sum_p X[p + tap][ci] dPre[p][co].
+// The 8-channel bf16 cell is 16 B, so the 32-B row of an LDS transpose read
+// (ds_read_b64_tr_b16) is two cells adjacent in t = the taps (c, c + 1) of one
+// position: one M block of 16 rows = 2 taps x 8 channels, 18 blocks for the 27
+// taps (the second block of every (a, b) carries c = 2 and a discarded c = 3).
+// dPre sits transposed in LDS ([co][position], one ds_read_b128 per fragment).
+// A workgroup stages the halo of a 4 x 8 x 32 tile once (padding rule applied
+// there); its 4 waves split the 32 k-steps and keep all 18 accumulators, summed
+// through LDS at the end; one partial per workgroup.
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TW0 = 4, TW1 = 8, TW2 = 32;
+constexpr int TG0 = TW0 + 2, TG1 = TW1 + 2, TG2 = TW2 + 2;
+constexpr int TWP = TG0 * TG1 * TG2;            // 2040 halo cells of 16 B
+constexpr int TWN = TW0 * TW1 * TW2;            // 1024 positions
+constexpr int TW_XS = (TWP + 2) * 16;           // + over-read of the junk tap
+constexpr int TW_DS = 16 * TWN * 2;             // dPre^T: 16 rows x 1024 positions bf16
+constexpr int TW_LDS = TW_XS + TW_DS;           // 65,440 B
+
+__global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+    ConvGeom g, int tiles0, int tiles1, int tiles2, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;
+  unsigned short* dsT = reinterpret_cast<unsigned short*>(smem + TW_XS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane & 15, kg = lane >> 4;
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2], Cout = g.Cout;
+
+  f32x4 acc[18];
+#pragma unroll
+  for (int b = 0; b < 18; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int item = tid; item < (16 - Cout) * TWN; item += 256) dsT[Cout * TWN + item] = 0;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int tr = tile;
+    const int t2i = tr % tiles2; tr /= tiles2;
+    const int t1i = tr % tiles1; tr /= tiles1;
+    const int t0i = tr % tiles0; tr /= tiles0;
+    const int n = tr;
+    const int org0 = t0i * TW0, org1 = t1i * TW1, org2 = t2i * TW2;
+    __syncthreads();
+    // ---- x halo: cell = 8 channels -> 16 B of bf16
+    for (int hp = tid; hp < TWP; hp += 256) {
+      int h = hp;
+      const int c2 = h % TG2; h /= TG2;
+      const int c1 = h % TG1; h /= TG1;
+      const int c0 = h;
+      int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
+      if (g.pad_mode == S3_PAD_REFLECT) {
+        i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
+      }
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2) {
+        const float* src = x + ((((int64_t)n * D0 + i0) * D1 + i1) * D2 + i2) * 8;
+        a = *reinterpret_cast<const float4*>(src);
+        b = *reinterpret_cast<const float4*>(src + 4);
+      }
+      *reinterpret_cast<uint4*>(xs + hp * 16) =
+          make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
+    }
+    if (tid < 2) *reinterpret_cast<uint4*>(xs + (TWP + tid) * 16) = make_uint4(0, 0, 0, 0);
+    // ---- dPre tile, transposed: dsT[co][pl] (rows >= C_out were zeroed once)
+    for (int item = tid; item < Cout * TWN; item += 256) {
+      const int pl = item % TWN, co = item / TWN;
+      const int row = pl / TW2, tt = pl % TW2;
+      const int o0 = org0 + row / TW1, o1 = org1 + row % TW1, o2 = org2 + tt;
+      float v = 0.f;
+      if (co < Cout && o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2])
+        v = dy[((((int64_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * Cout + co];
+      dsT[co * TWN + pl] = (unsigned short)(pk2(v, 0.f) & 0xFFFFu);
+    }
+    __syncthreads();
+    // ---- 32 k-steps (one (s1, s2) row of 32 t each), 8 per wave
+    for (int ks = wave; ks < TW0 * TW1; ks += 4) {
+      const int r0 = ks / TW1, r1 = ks % TW1;
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(dsT + q * TWN + ks * TW2 + kg * 8);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int cp = 0; cp < 2; ++cp) {
+            // rows of the transpose read: positions t = 8 kg + 4 h + (q >> 2)
+            const char* base = xs + ((((r0 + a) * TG1 + (r1 + b)) * TG2) + 8 * kg + (q >> 2) + 2 * cp) * 16 +
+                               ((q & 3) << 3);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(base + 4 * 16));
+            const bf16x8 afr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[(a * 3 + b) * 2 + cp] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[(a * 3 + b) * 2 + cp], 0, 0, 0);
+          }
+    }
+  }
+  // ---- sum the 4 waves: red[wave][block][row 16][co 16] (only lanes co < C_out matter)
+  __syncthreads();
+  // 4 waves x 9 blocks x 256 floats = 36,864 B of the (dead) LDS image per half
+  float* red = reinterpret_cast<float*>(smem);
+  float* out = partial + (size_t)blockIdx.x * 27 * 8 * Cout;
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 9; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[((wave * 9 + b) * 16 + kg * 4 + r) * 16 + q] = acc[half * 9 + b][r];
+    __syncthreads();
+    for (int item = tid; item < 9 * 256; item += 256) {
+      const int co = item & 15, m16 = (item >> 4) & 15, b = item >> 8;
+      const int blk = half * 9 + b;
+      const int ab = blk >> 1, cp = blk & 1;
+      const int c = 2 * cp + (m16 >> 3), ci = m16 & 7;
+      if (c < 3 && co < Cout) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t += red[((w * 9 + b) * 16 + m16) * 16 + co];
+        out[((size_t)(ab * 3 + c) * 8 + ci) * Cout + co] = t;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool conv_wgrad_tail_supported(const ConvGeom& g, int precision) {
+  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_WGRAD_TAIL")) return false;
+  if (g.Cin != 8 || g.Cout > 16 || g.Cout < 1 || g.d2s != 1) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] < 0 || g.lo[d] > 2) return false;
+  return (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 65536;
+}
+
+static int tail_grid(const s3_ctx* ctx, const ConvGeom& g, int* t0, int* t1, int* t2, int* n_tiles) {
+  *t0 = (g.O[0] + TW0 - 1) / TW0; *t1 = (g.O[1] + TW1 - 1) / TW1; *t2 = (g.O[2] + TW2 - 1) / TW2;
+  *n_tiles = g.N * *t0 * *t1 * *t2;
+  int grid = 2 * ctx->num_cu;
+  if (grid > *n_tiles) grid = *n_tiles;
+  return grid;
+}
+
+size_t conv_wgrad_tail_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
+  int a, b, c, nt;
+  return (size_t)tail_grid(ctx, g, &a, &b, &c, &nt) * 27 * 8 * g.Cout * sizeof(float);
+}
+
+int launch_conv_wgrad_tail(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                           float* dw, float* partial, size_t partial_bytes, int accumulate) {
+  int t0, t1, t2, n_tiles;
+  const int grid = tail_grid(ctx, g, &t0, &t1, &t2, &n_tiles);
+  if (partial_bytes < conv_wgrad_tail_partial_bytes(ctx, g))
+    S3_FAIL(ctx, S3_EINVAL, "wgrad_tail: partial buffer too small");
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tail_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad_tail_kernel, dim3(grid), dim3(256), TW_LDS, ctx->stream, x, dy,
+                     partial, g, t0, t1, t2, n_tiles);
+  S3_HIP(ctx, hipGetLastError());
+  const int wsize = 27 * 8 * g.Cout;
+  hipLaunchKernelGGL(wgrad_c2_partial_reduce, dim3((wsize + 63) / 64), dim3(256), 0, ctx->stream,
+                     partial, grid, wsize, dw, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}

@@ -45,7 +45,7 @@ struct OpRec {
   void* packed = nullptr;
   uint64_t packed_version = 0;
   // MFMA backward (training plans)
-  bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false, wgrad_bf16_2d = false;
+  bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false, wgrad_bf16_2d = false, wgrad_tail = false;
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
   bool dgrad_fewch = false;    // C_out <= 4 'same' conv: dgrad = few-channel forward conv over the frame
@@ -394,18 +394,21 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             max_partial = std::max(max_partial, conv_wgrad_bf16_partial_bytes(ctx, g));
           else if (o.wgrad_mfma)
             max_partial = std::max(max_partial, conv_wgrad_mfma_partial_bytes(ctx, g));
-          o.wgrad_c2 = !o.fewpos && conv_wgrad_c2_supported(g, precision);
+          o.wgrad_tail = !o.fewpos && conv_wgrad_tail_supported(g, precision);
+          if (o.wgrad_tail)
+            max_partial = std::max(max_partial, conv_wgrad_tail_partial_bytes(ctx, g));
+          o.wgrad_c2 = !o.fewpos && !o.wgrad_tail && conv_wgrad_c2_supported(g, precision);
           if (o.wgrad_c2)
             max_partial = std::max(max_partial, conv_wgrad_c2_partial_bytes(ctx, g));
-          o.wgrad_bf16_gen = !o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 &&
+          o.wgrad_bf16_gen = !o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_tail &&
                              conv_wgrad_bf16_gen_supported(g, precision);
           if (o.wgrad_bf16_gen)
             max_partial = std::max(max_partial, conv_wgrad_bf16_gen_partial_bytes(ctx, g));
-          o.wgrad_bf16_2d = !o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_bf16_gen &&
+          o.wgrad_bf16_2d = !o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_tail && !o.wgrad_bf16_gen &&
                             conv_wgrad_bf16_2d_supported(g, precision);
           if (o.wgrad_bf16_2d)
             max_partial = std::max(max_partial, conv_wgrad_bf16_2d_partial_bytes(ctx, g));
-          if (!o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_bf16_gen && !o.wgrad_bf16_2d &&
+          if (!o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_tail && !o.wgrad_bf16_gen && !o.wgrad_bf16_2d &&
               conv_wgrad_gen_supported(g)) {
             o.wgrad_gen = true;
             max_partial = std::max(max_partial, conv_wgrad_gen_partial_bytes(ctx, g));
@@ -989,6 +992,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           }
           if (o.fewpos)
             rc = launch_conv_fewpos_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+          else if (o.wgrad_tail)
+            rc = launch_conv_wgrad_tail(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_c2)
             rc = launch_conv_wgrad_c2(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16_2d)

@@ -611,10 +611,11 @@ def test_2d_wgrad_bf16_transpose_read_kernel(monkeypatch):
 
 
 def test_tail_conv_wgrad_ldsfree_kernel_with_reflect_padding(monkeypatch):
-    """conv_wgrad_c2_kernel<8, 1>: weight gradient of the hi-res tail conv
-    (8 -> 2, reflect 'same' padding, ragged 32-position k-steps: t = 37)
-    against the oracle and against the exact fp32-MFMA kernel
-    (SUP3R_AMD_NO_WGRAD_C2=1: rel. rms < 1e-2)."""
+    """Weight gradient of the hi-res tail conv (8 -> 2, reflect 'same'
+    padding, ragged tiles: t = 37): the LDS-free kernel
+    conv_wgrad_c2_kernel<8, 1> (below 65536 positions) against the oracle and
+    against the exact fp32-MFMA kernel (SUP3R_AMD_NO_WGRAD_C2=1: rel. rms <
+    1e-2)."""
     from sup3r_amd.configs.author_configs import pcc
     rng = np.random.default_rng(39)
     spec = pcc(3, 8) + pcc(3, 2, act=False)
@@ -759,3 +760,36 @@ def test_fewch_halo_forward_conv_vs_oracle_and_gather_variant(monkeypatch):
         assert y.shape == y_ref.shape
         assert np.abs(y - y_ref).max() < 3e-2 * scale, shape
         assert np.abs(y - y2).max() < 1e-5 * scale, shape
+
+
+def test_tail_conv_wgrad_halo_transpose_read_kernel(monkeypatch):
+    """conv_wgrad_tail_kernel (8 -> 2 / 8 -> 3, reflect 'same' padding, LDS
+    halo + transpose reads pairing the taps (c, c + 1); ragged 4 x 8 x 32
+    tiles: 25 x 35 x 40) against the oracle and against the LDS-free kernel
+    (SUP3R_AMD_NO_WGRAD_TAIL=1; both round x and dPre to bf16: rel. rms 2e-3)."""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(47)
+    for n_out in (2, 3):
+        spec = pcc(3, 8) + pcc(3, n_out, act=False)
+        shape = (2, 25, 35, 40, 4)               # 70 000 positions
+        x = rng.standard_normal(shape).astype(np.float32)
+        ref = _oracle_net(spec, x, None)
+        y_ref = ref.forward(x)
+        dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+        ref.backward(dy)
+
+        def grads():
+            net = _hip_net(spec, ref.weights, precision='bf16')
+            ph = net.plan(shape, training=True)
+            ph.forward(net.dev.to_device(x))
+            ph.backward(net.dev.to_device(dy), need_dx=False)
+            return np.array(net.grads[2])
+        monkeypatch.delenv('SUP3R_AMD_NO_WGRAD_TAIL', raising=False)
+        a = grads()
+        monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_TAIL', '1')
+        b = grads()
+        r = ref.grads[2]
+        assert a.shape == (3, 3, 3, 8, n_out)
+        assert np.abs(a - b).max() > 0
+        assert np.sqrt(((a - r) ** 2).mean()) / np.sqrt((r ** 2).mean()) < 5e-2
+        assert np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()) < 2e-3
