@@ -156,7 +156,8 @@ int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const f
 bool conv_wgrad_tail_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_tail_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_tail(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                           float* dw, float* partial, size_t partial_bytes, int accumulate);
+                           float* dw, float* partial, size_t partial_bytes, int accumulate,
+                           int x_bf16);
 // trunk wgrad on bf16 MFMA with LDS transpose reads (kernels_conv_wgrad_bf16.hip)
 bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);

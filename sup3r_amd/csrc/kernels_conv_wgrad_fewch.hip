@@ -238,6 +238,7 @@ constexpr int TW_XS = (TWP + 2) * 16;           // + over-read of the junk tap
 constexpr int TW_DS = 16 * TWN * 2;             // dPre^T: 16 rows x 1024 positions bf16
 constexpr int TW_LDS = TW_XS + TW_DS;           // 65,440 B
 
+template <bool IN16>
 __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
     ConvGeom g, int tiles0, int tiles1, int tiles2, int n_tiles) {
@@ -271,14 +272,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
       if (g.pad_mode == S3_PAD_REFLECT) {
         i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
       }
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      if (i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2) {
-        const float* src = x + ((((int64_t)n * D0 + i0) * D1 + i1) * D2 + i2) * 8;
-        a = *reinterpret_cast<const float4*>(src);
-        b = *reinterpret_cast<const float4*>(src + 4);
+      const bool ok = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
+      const int64_t cell = (((int64_t)n * D0 + i0) * D1 + i1) * D2 + i2;
+      if constexpr (IN16) {                      // bf16 cells (bf16 saved activations)
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(x) + cell * 8);
+        *reinterpret_cast<uint4*>(xs + hp * 16) = v;
+      } else {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (ok) {
+          a = *reinterpret_cast<const float4*>(x + cell * 8);
+          b = *reinterpret_cast<const float4*>(x + cell * 8 + 4);
+        }
+        *reinterpret_cast<uint4*>(xs + hp * 16) =
+            make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
       }
-      *reinterpret_cast<uint4*>(xs + hp * 16) =
-          make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
     }
     if (tid < 2) *reinterpret_cast<uint4*>(xs + (TWP + tid) * 16) = make_uint4(0, 0, 0, 0);
     // ---- dPre tile, transposed: dsT[co][pl] (rows >= C_out were zeroed once)
@@ -367,19 +375,26 @@ size_t conv_wgrad_tail_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
 }
 
 int launch_conv_wgrad_tail(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                           float* dw, float* partial, size_t partial_bytes, int accumulate) {
+                           float* dw, float* partial, size_t partial_bytes, int accumulate,
+                           int x_bf16) {
   int t0, t1, t2, n_tiles;
   const int grid = tail_grid(ctx, g, &t0, &t1, &t2, &n_tiles);
   if (partial_bytes < conv_wgrad_tail_partial_bytes(ctx, g))
     S3_FAIL(ctx, S3_EINVAL, "wgrad_tail: partial buffer too small");
   static bool attr_set = false;
   if (!attr_set) {
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tail_kernel),
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tail_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tail_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_wgrad_tail_kernel, dim3(grid), dim3(256), TW_LDS, ctx->stream, x, dy,
-                     partial, g, t0, t1, t2, n_tiles);
+  if (x_bf16)
+    hipLaunchKernelGGL(conv_wgrad_tail_kernel<true>, dim3(grid), dim3(256), TW_LDS, ctx->stream, x, dy,
+                       partial, g, t0, t1, t2, n_tiles);
+  else
+    hipLaunchKernelGGL(conv_wgrad_tail_kernel<false>, dim3(grid), dim3(256), TW_LDS, ctx->stream, x, dy,
+                       partial, g, t0, t1, t2, n_tiles);
   S3_HIP(ctx, hipGetLastError());
   const int wsize = 27 * 8 * g.Cout;
   hipLaunchKernelGGL(wgrad_c2_partial_reduce, dim3((wsize + 63) / 64), dim3(256), 0, ctx->stream,

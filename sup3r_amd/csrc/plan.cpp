@@ -506,8 +506,12 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               if (!conv_mfma_bf16_out_ok(o.cg)) demote(d.out, changed);
               if (training && !o.wgrad_bf16) demote(d.in0, changed);
             } else if (training) {
-              // every other conv reads / writes fp32 in training plans
-              demote(d.in0, changed); demote(d.res, changed); demote(d.out, changed);
+              // every other conv reads / writes fp32 in training plans — except
+              // the hi-res tail conv, whose MFMA forward takes bf16 cells and
+              // whose weight gradient (conv_wgrad_tail_kernel) stages them as is
+              const bool tail16 = d.res < 0 && !o.fewpos && o.wgrad_tail && conv_tail_mfma_supported(o.cg);
+              if (!tail16) demote(d.in0, changed);
+              demote(d.res, changed); demote(d.out, changed);
             } else {
               // the direct kernels read fp32, except the small-channel tail
               // convs (MFMA C_in = 8 / sliding window) which take bf16 cells
@@ -993,7 +997,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           if (o.fewpos)
             rc = launch_conv_fewpos_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_tail)
-            rc = launch_conv_wgrad_tail(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+            rc = launch_conv_wgrad_tail(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16);
           else if (o.wgrad_c2)
             rc = launch_conv_wgrad_c2(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16_2d)
