@@ -137,6 +137,12 @@ size_t conv_halo32_packed_bytes(const ConvGeom& g);
 int launch_conv_halo32_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
 int launch_conv_halo32_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* img,
                            const float* bias, float* y);
+// dgrad of a stride-2 valid conv with 32 output channels, per residue class on an
+// LDS halo (kernels_conv_dgrad_s2.hip)
+bool conv_dgrad_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision);
+size_t conv_dgrad_s2_packed_bytes(const ConvGeom& g);
+int launch_conv_dgrad_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
+int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx);
 // dgrad of the few-channel hi-res conv with an LDS halo (kernels_conv_dgrad_fewch.hip)
 bool conv_dgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_dgrad_c2_packed_bytes();

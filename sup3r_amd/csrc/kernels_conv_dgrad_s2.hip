@@ -1,0 +1,203 @@
+// Data gradient of a stride-2, valid-padded conv with 32 output channels
+// (discriminator 32 -> 32 s2 over 13.9 M input positions) on bf16 MFMA with an
+// LDS halo — S3_PREC_BF16 training plans.
+//
+//   dx[i][ci] = sum_{tap : (i - tap) even per axis} sum_co W[tap][ci][co] dPre[(i - tap) / 2][co]
+//
+// With i = 2 u + p per axis the taps split by the parity class p: p = 0 gets the
+// taps {0, 2} (dPre cells u, u - 1), p = 1 the tap {1} (cell u), so each of the
+// 8 classes is a small stride-1 correlation over the dPre grid (8, 4, 4, 2, 4,
+// 2, 2, 1 taps = 27 in total).  A workgroup owns a 4 x 8 x 16 tile of u (= 8 x
+// 16 x 32 positions of x), stages the (4+1) x (8+1) x (16+1) dPre halo once
+// (fp32 -> bf16, 64-B cells, the (t >> 1) & 3 chunk swizzle of
+// conv_dgrad_c2_kernel) and walks the classes: per class the taps' filter rows
+// (A operand, L1-resident packed image) against the shifted halo window (B
+// operand), 8 rows x 2 channel fragments of accumulators per wave, stored to
+// x's grid at stride 2.  The gather kernel iterates the same taps per residue
+// class but re-reads every dPre cell through L1 (1.31 ms at C2 batch 8).
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int ST0 = 4, ST1 = 8, ST2 = 16;
+constexpr int SG0 = ST0 + 1, SG1 = ST1 + 1, SG2 = ST2 + 1;
+constexpr int SHP = SG0 * SG1 * SG2;          // 765 halo cells
+constexpr int SNW = 4;
+constexpr int SNT = SNW * 64;
+constexpr int SLDS = SHP * 64;                // 48,960 B
+
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+  hf32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
+}
+
+// fp32 w[tap][cin][32] -> bf16 img[tap][cin_pad][32]  (rows = ci, K = co)
+__global__ void dgrad_s2_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ img,
+                                     int cin, int rows_pad) {
+  const int total = 27 * rows_pad * 32;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int co = idx & 31, row = (idx >> 5) % rows_pad, tp = idx / (32 * rows_pad);
+    const float v = row < cin ? w[((size_t)tp * cin + row) * 32 + co] : 0.f;
+    img[idx] = (unsigned short)(pk2(v, 0.f) & 0xFFFFu);
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
+    const float* __restrict__ dy, const unsigned short* __restrict__ img,
+    float* __restrict__ dx, ConvGeom g, int rows_pad, int tiles0, int tiles1, int tiles2) {
+  extern __shared__ __attribute__((aligned(16))) char halo[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  const int ct = blockIdx.y;
+  int tr = blockIdx.x;
+  const int t2i = tr % tiles2; tr /= tiles2;
+  const int t1i = tr % tiles1; tr /= tiles1;
+  const int t0i = tr % tiles0; tr /= tiles0;
+  const int n = tr;
+  const int u0 = t0i * ST0, u1 = t1i * ST1, u2 = t2i * ST2;   // tile origin on the u grid
+  const int O0 = g.O[0], O1 = g.O[1], O2 = g.O[2];
+
+  // ---- stage the dPre halo: cell (c0, c1, c2) = dPre[u + c - 1], zero outside
+  for (int base = tid; base < SHP * 4; base += SNT * 3) {
+    float4 va[3], vb[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int item = base + u * SNT;
+      va[u] = make_float4(0.f, 0.f, 0.f, 0.f); vb[u] = va[u];
+      if (item < SHP * 4) {
+        const int hp = item >> 2, ch = item & 3;
+        int h = hp;
+        const int c2 = h % SG2; h /= SG2;
+        const int c1 = h % SG1; h /= SG1;
+        const int c0 = h;
+        const int i0 = u0 + c0 - 1, i1 = u1 + c1 - 1, i2 = u2 + c2 - 1;
+        if (i0 >= 0 && i0 < O0 && i1 >= 0 && i1 < O1 && i2 >= 0 && i2 < O2) {
+          const float* src = dy + ((((size_t)n * O0 + i0) * O1 + i1) * O2 + i2) * 32 + ch * 8;
+          va[u] = *reinterpret_cast<const float4*>(src);
+          vb[u] = *reinterpret_cast<const float4*>(src + 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int item = base + u * SNT;
+      if (item < SHP * 4) {
+        const int hp = item >> 2, ch = item & 3;
+        const int key = ((hp % SG2) >> 1) & 3;
+        *reinterpret_cast<uint4*>(halo + hp * 64 + ((ch ^ key) << 4)) =
+            make_uint4(pk2(va[u].x, va[u].y), pk2(va[u].z, va[u].w), pk2(vb[u].x, vb[u].y),
+                       pk2(vb[u].z, vb[u].w));
+      }
+    }
+  }
+  __syncthreads();
+
+  // B-operand offsets of this lane for the two t shifts: halo t index = j + 1 - d, d in {0, 1}
+  int off_d[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int th = j + 1 - d;
+    off_d[d] = th * 64 + ((kg ^ ((th >> 1) & 3)) << 4);
+  }
+  const unsigned short* wrow = img + ((size_t)ct * 64 + j) * 32 + kg * 8;
+  const int R = g.Cin;
+  // wave w owns the u rows (r0 = w, r1 = 0..7)
+#pragma unroll 1
+  for (int cls = 0; cls < 8; ++cls) {
+    const int p0 = cls >> 2, p1 = (cls >> 1) & 1, p2 = cls & 1;
+    const int n0 = p0 ? 1 : 2, n1 = p1 ? 1 : 2, n2 = p2 ? 1 : 2;   // taps per axis
+    f32x4 acc[8][NF];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) acc[m][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < n0; ++a)
+      for (int b = 0; b < n1; ++b)
+        for (int c = 0; c < n2; ++c) {
+          // tap index per axis: parity 1 -> tap 1 (shift 0); parity 0 -> taps 0 / 2 (shift 0 / 1)
+          const int ta = p0 ? 1 : 2 * a, tb = p1 ? 1 : 2 * b, tc = p2 ? 1 : 2 * c;
+          const int d0 = p0 ? 0 : a, d1 = p1 ? 0 : b, d2 = p2 ? 0 : c;
+          const int tp = (ta * 3 + tb) * 3 + tc;
+          bf16x8 afr[NF];
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf)
+            afr[nf] = *reinterpret_cast<const bf16x8*>(wrow + ((size_t)tp * rows_pad + nf * 16) * 32);
+          const char* hb = halo + (((wave + 1 - d0) * SG1 + (1 - d1)) * SG2) * 64 + off_d[d2];
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(hb + m * SG2 * 64);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+              acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[nf], bfr, acc[m][nf], 0, 0, 0);
+          }
+        }
+    // ---- store the class: x position i = 2 u + p
+    const int i0 = 2 * (u0 + wave) + p0, i2 = 2 * (u2 + j) + p2;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int ch = ct * 64 + nf * 16 + kg * 4;
+      if (ch >= R) continue;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int i1 = 2 * (u1 + m) + p1;
+        if (i0 >= g.D[0] || i1 >= g.D[1] || i2 >= g.D[2]) continue;
+        float* dst = dx + ((((size_t)n * g.D[0] + i0) * g.D[1] + i1) * g.D[2] + i2) * R + ch;
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[m][nf][0], acc[m][nf][1], acc[m][nf][2], acc[m][nf][3]);
+      }
+    }
+  }
+}
+
+int s2_rows_pad(int cin) { return (cin + 63) / 64 * 64; }
+
+}  // namespace
+
+bool conv_dgrad_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision) {
+  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_DGRAD_S2")) return false;
+  if (g.Cout != 32 || g.Cin % 16 != 0 || g.Cin < 16 || g.d2s != 1) return false;
+  for (int d = 0; d < 3; ++d) {
+    if (g.k[d] != 3 || g.s[d] != 2 || g.lo[d] != 0) return false;
+    // valid padding: every x position i < D has its sources inside or zero; u grid covers D
+    if ((g.O[d] - 1) * 2 + 3 > g.D[d]) return false;
+  }
+  const int64_t min_tiles = getenv("SUP3R_AMD_DGRAD_S2_MIN_TILES") ? atoll(getenv("SUP3R_AMD_DGRAD_S2_MIN_TILES"))
+                                                                   : ctx->num_cu;
+  int64_t tiles = g.N;
+  const int T[3] = {ST0, ST1, ST2};
+  for (int d = 0; d < 3; ++d) tiles *= ((g.D[d] + 1) / 2 + T[d] - 1) / T[d];
+  return tiles >= min_tiles;
+}
+
+size_t conv_dgrad_s2_packed_bytes(const ConvGeom& g) { return (size_t)27 * s2_rows_pad(g.Cin) * 32 * 2; }
+
+int launch_conv_dgrad_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img) {
+  const int rp = s2_rows_pad(g.Cin);
+  hipLaunchKernelGGL(dgrad_s2_pack_kernel, dim3((27 * rp * 32 + 255) / 256), dim3(256), 0, ctx->stream, w,
+                     (unsigned short*)img, g.Cin, rp);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx) {
+  const int U0 = (g.D[0] + 1) / 2, U1 = (g.D[1] + 1) / 2, U2 = (g.D[2] + 1) / 2;
+  const int tiles0 = (U0 + ST0 - 1) / ST0, tiles1 = (U1 + ST1 - 1) / ST1, tiles2 = (U2 + ST2 - 1) / ST2;
+  const int n_ct = (g.Cin + 63) / 64;
+  dim3 grid((unsigned)(g.N * tiles0 * tiles1 * tiles2), (unsigned)n_ct);
+  const int rp = s2_rows_pad(g.Cin);
+  if (g.Cin <= 32)
+    hipLaunchKernelGGL(conv_dgrad_s2_kernel<2>, grid, dim3(SNT), SLDS, ctx->stream, dy,
+                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2);
+  else
+    hipLaunchKernelGGL(conv_dgrad_s2_kernel<4>, grid, dim3(SNT), SLDS, ctx->stream, dy,
+                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}

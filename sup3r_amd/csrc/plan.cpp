@@ -48,6 +48,7 @@ struct OpRec {
   bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false, wgrad_bf16_2d = false, wgrad_tail = false;
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
+  bool dgrad_s2 = false;       // stride-2 valid conv, C_out = 32: residue classes on an LDS halo
   bool dgrad_fewch = false;    // C_out <= 4 'same' conv: dgrad = few-channel forward conv over the frame
   bool halo32 = false;         // C_in = 32 stride-1 conv: LDS-halo forward
   void* h32_w = nullptr;
@@ -430,7 +431,8 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               o.dgrad_mfma = o.dgrad_fewch = true;
           }
           o.dgrad_c2 = !o.dgrad_mfma && !o.fewpos && conv_dgrad_c2_supported(g, precision);
-          o.gconv_dgrad = !o.dgrad_mfma && !o.dgrad_c2 && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
+          o.dgrad_s2 = !o.dgrad_mfma && !o.dgrad_c2 && !o.fewpos && conv_dgrad_s2_supported(ctx, g, precision);
+          o.gconv_dgrad = !o.dgrad_mfma && !o.dgrad_c2 && !o.dgrad_s2 && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
           if (o.gconv_dgrad && g.pad_mode == S3_PAD_REFLECT)
             max_dxp = std::max(max_dxp, (size_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
                                             (g.D[2] + 2 * g.lo[2]) * g.Cin * sizeof(float));
@@ -547,11 +549,11 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     o.io.res_bf16 = o.d.res >= 0 ? pl->t[root_of(pl, o.d.res)].dtype : 0;
     if (getenv("SUP3R_AMD_TRACE"))
       fprintf(stderr, "[plan] conv %d->%d %s: mfma %d fewpos %d gconv %d halo32 %d | in16 %d out16 %d res16 %d | "
-              "wgrad bf16 %d gen %d 2d %d c2 %d mfma %d | dgrad mfma %d c2 %d gconv %d\n",
+              "wgrad bf16 %d gen %d 2d %d c2 %d tail %d mfma %d | dgrad mfma %d c2 %d s2 %d gconv %d\n",
               o.cg.Cin, o.cg.Cout, training ? "train" : "infer", (int)o.mfma, (int)o.fewpos, (int)o.gconv,
               (int)o.halo32, o.io.in_bf16, o.io.out_bf16, o.io.res_bf16, (int)o.wgrad_bf16, (int)o.wgrad_bf16_gen,
-              (int)o.wgrad_bf16_2d, (int)o.wgrad_c2, (int)o.wgrad_mfma, (int)o.dgrad_mfma, (int)o.dgrad_c2,
-              (int)o.gconv_dgrad);
+              (int)o.wgrad_bf16_2d, (int)o.wgrad_c2, (int)o.wgrad_tail, (int)o.wgrad_mfma, (int)o.dgrad_mfma,
+              (int)o.dgrad_c2, (int)o.dgrad_s2, (int)o.gconv_dgrad);
   }
 
   // ---- static arena planning.  Training keeps every tensor; inference
@@ -641,6 +643,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     }
     if (o.halo32) {
       int rc = plan_alloc(pl, &o.h32_w, conv_halo32_packed_bytes(o.cg));
+      if (rc) { s3_plan_destroy(pl); return rc; }
+    }
+    if (o.dgrad_s2) {
+      int rc = plan_alloc(pl, &o.dc2_w, conv_dgrad_s2_packed_bytes(o.cg));
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
     if (o.dgrad_c2) {
@@ -1046,6 +1052,13 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
             fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
             rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+          } else if (o.dgrad_s2) {
+            if (o.dc2_version != (int64_t)P->version) {
+              rc = launch_conv_dgrad_s2_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);
+              if (rc) return rc;
+              o.dc2_version = (int64_t)P->version;
+            }
+            rc = launch_conv_dgrad_s2(ctx, g, dpre, o.dc2_w, dst);
           } else if (o.dgrad_c2) {
             if (o.dc2_version != (int64_t)P->version) {
               rc = launch_conv_dgrad_c2_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);

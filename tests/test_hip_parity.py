@@ -793,3 +793,44 @@ def test_tail_conv_wgrad_halo_transpose_read_kernel(monkeypatch):
         assert np.abs(a - b).max() > 0
         assert np.sqrt(((a - r) ** 2).mean()) / np.sqrt((r ** 2).mean()) < 5e-2
         assert np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()) < 2e-3
+
+
+def test_stride2_dgrad_residue_class_halo_kernel(monkeypatch, capfd):
+    """conv_dgrad_s2_kernel (stride-2 valid conv, 32 output channels, C_in 32
+    and 64, odd and even extents, ragged tiles): the input gradient against
+    the oracle (bf16-mode bound) and against the gather kernel that walks the
+    same taps per residue class (SUP3R_AMD_NO_DGRAD_S2=1; identical bf16
+    operands, different summation order over taps: 1e-5 of the largest value)."""
+    rng = np.random.default_rng(49)
+
+    def conv(f, s, pad='valid'):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': pad},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    monkeypatch.setenv('SUP3R_AMD_DGRAD_S2_MIN_TILES', '1')
+    for cin, shape in ((32, (2, 21, 18, 39, 2)), (64, (2, 20, 19, 38, 2))):
+        spec = conv(cin, 1) + conv(32, 2) + [{'class': 'Flatten'},
+                                             {'class': 'Dense', 'units': 1}]
+        x = rng.standard_normal(shape).astype(np.float32)
+        ref = _oracle_net(spec, x, None)
+        y_ref = ref.forward(x)
+        dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+        dx_ref = ref.backward(dy)
+
+        def run():
+            net = _hip_net(spec, ref.weights, precision='bf16')
+            ph = net.plan(shape, training=True)
+            ph.forward(net.dev.to_device(x))
+            dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
+            return dx, np.array(net.grads[0])
+        monkeypatch.setenv('SUP3R_AMD_TRACE', '1')
+        monkeypatch.delenv('SUP3R_AMD_NO_DGRAD_S2', raising=False)
+        capfd.readouterr()
+        dx, g0 = run()
+        assert ' s2 1 ' in capfd.readouterr().err          # the halo kernel was planned ...
+        monkeypatch.setenv('SUP3R_AMD_NO_DGRAD_S2', '1')
+        dx2, g02 = run()
+        assert ' s2 1 ' not in capfd.readouterr().err      # ... and the gather kernel here
+        assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
+        assert np.abs(g0 - g02).max() < 1e-4 * np.abs(g02).max()
+        assert np.abs(dx - dx2).max() < 1e-4 * np.abs(dx2).max()
