@@ -142,7 +142,8 @@ int launch_conv_halo32_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const
 bool conv_dgrad_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision);
 size_t conv_dgrad_s2_packed_bytes(const ConvGeom& g);
 int launch_conv_dgrad_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
-int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx);
+int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx,
+                         const float* mask_y, float mask_slope);
 // dgrad of the few-channel hi-res conv with an LDS halo (kernels_conv_dgrad_fewch.hip)
 bool conv_dgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_dgrad_c2_packed_bytes();

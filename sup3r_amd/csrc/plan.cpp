@@ -49,6 +49,7 @@ struct OpRec {
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
   bool dgrad_s2 = false;       // stride-2 valid conv, C_out = 32: residue classes on an LDS halo
+  int mask_prod = -1;          // dgrad_s2: producer conv of in0 whose activation adjoint is fused into the store
   bool dgrad_fewch = false;    // C_out <= 4 'same' conv: dgrad = few-channel forward conv over the frame
   bool halo32 = false;         // C_in = 32 stride-1 conv: LDS-halo forward
   void* h32_w = nullptr;
@@ -94,6 +95,7 @@ struct s3_plan {
   std::vector<hipEvent_t> prof_ev;  // prof_cap * (n_ops + 1)
   int prof_cap = 0, prof_n = 0;
   std::vector<char> gwritten;
+  std::vector<char> premasked;   // tensor gradient already carries its producer's activation adjoint
   // hipGraph replay of the forward op list (inference plans): inputs are
   // copied into plan-owned staging buffers so every pointer inside the
   // captured graph is fixed; re-captured when the weights change
@@ -556,6 +558,28 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               (int)o.dgrad_c2, (int)o.dgrad_s2, (int)o.gconv_dgrad);
   }
 
+  // ---- activation-adjoint fusion (training): a conv whose data gradient runs
+  // on conv_dgrad_s2_kernel and whose input is the fp32 output of an activated
+  // conv with no other consumer applies that conv's mask in its own store
+  if (training) {
+    std::vector<int> ncons(n_tensors, 0), prod(n_tensors, -1);
+    for (int i = 0; i < n_ops; ++i) {
+      const s3_op_desc& d = pl->ops[i].d;
+      for (int id : {d.in0, d.in1, d.res})
+        if (id >= 0) ++ncons[root_of(pl, id)];
+      if (d.kind != S3_OP_VIEW) prod[root_of(pl, d.out)] = i;
+    }
+    for (auto& o : pl->ops) {
+      if (o.d.kind != S3_OP_CONV || !o.dgrad_s2) continue;
+      const int r = root_of(pl, o.d.in0);
+      const int pi = prod[r];
+      if (pi < 0 || ncons[r] != 1 || r == root_of(pl, output) || pl->t[r].is_input || pl->t[r].dtype) continue;
+      const OpRec& po = pl->ops[pi];
+      if (po.d.kind == S3_OP_CONV && po.cg.act != S3_ACT_NONE && po.cg.d2s == 1 && po.d.res < 0)
+        o.mask_prod = pi;
+    }
+  }
+
   // ---- static arena planning.  Training keeps every tensor; inference
   // reuses buffers by liveness (greedy best-fit).
   std::vector<int> last_use(n_tensors, -1);
@@ -961,6 +985,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
   float* W = P->buf[S3_BUF_W];
   float* G = P->buf[S3_BUF_G];
   std::fill(pl->gwritten.begin(), pl->gwritten.end(), 0);
+  pl->premasked.assign(pl->gwritten.size(), 0);
   {
     int r = root_of(pl, pl->output);
     S3_HIP(ctx, hipMemcpyAsync(pl->t[r].gptr, d_output, (size_t)pl->t[r].numel * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
@@ -989,7 +1014,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           if (rc) return rc;
         }
         const float* dpre = dy;
-        if (g.act != S3_ACT_NONE || g.d2s > 1) {
+        if ((g.act != S3_ACT_NONE || g.d2s > 1) && !pl->premasked[ro]) {
           rc = launch_conv_epilogue_bwd(ctx, g, tptr(pl, d.out), dy, pl->dpre, o.io.out_bf16);
           if (rc) return rc;
           dpre = pl->dpre;
@@ -1058,7 +1083,13 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               if (rc) return rc;
               o.dc2_version = (int64_t)P->version;
             }
-            rc = launch_conv_dgrad_s2(ctx, g, dpre, o.dc2_w, dst);
+            // single consumer of an activated conv output: its LeakyReLU / ReLU
+            // adjoint is applied in the store (the producer then skips its mask pass)
+            const bool fuse = o.mask_prod >= 0 && !pl->gwritten[root_of(pl, d.in0)] && !getenv("SUP3R_AMD_NO_MASK_FUSE");
+            const ConvGeom& pg = pl->ops[fuse ? o.mask_prod : i].cg;
+            rc = launch_conv_dgrad_s2(ctx, g, dpre, o.dc2_w, dst, fuse ? tptr(pl, d.in0) : nullptr,
+                                      pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f);
+            if (!rc && fuse) pl->premasked[root_of(pl, d.in0)] = 1;
           } else if (o.dgrad_c2) {
             if (o.dc2_version != (int64_t)P->version) {
               rc = launch_conv_dgrad_c2_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);
