@@ -47,6 +47,11 @@ struct ConvGeom {
   int act;
   float alpha;
   int d2s;    // block size (1 = none)
+  // halo-tile kernel only: read a 64-channel slice of a wider fp32 tensor — cells
+  // are in_cstride floats apart and only the first in_cvalid channels of the
+  // slice exist (0 = the tensor has exactly C_in channels).  Used by the
+  // chunked data gradient of convs with C_out > 64.
+  int in_cstride = 0, in_cvalid = 0;
 };
 
 // generic gather op (pad / crop / repeat / roll / d2s / concat): out <- in
@@ -182,6 +187,9 @@ int launch_conv_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x,
 // adjoint of the virtual padding (fold) — kernels_conv_mfma.hip
 bool conv_dgrad_mfma_supported(const ConvGeom& g, int precision);
 ConvGeom conv_dgrad_valid_geom(const ConvGeom& g);
+ConvGeom conv_dgrad_chunk_geom(const ConvGeom& g, int k);
+bool conv_dgrad_chunked_supported(const ConvGeom& g, int precision);
+int launch_conv_dgrad_chunk_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, float* wt, int k);
 bool conv_dgrad_mfma_valid_supported(const ConvGeom& g, int precision);
 ConvGeom conv_dgrad_geom(const ConvGeom& g);
 int launch_conv_dgrad_pack(s3_ctx* ctx, const ConvGeom& g, const float* w,

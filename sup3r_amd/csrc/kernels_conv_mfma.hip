@@ -226,9 +226,13 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
               va[u] = *reinterpret_cast<const uint4*>(
                   reinterpret_cast<const unsigned short*>(xv) + pos * CIN + ch * 8);
             } else if (PREC == S3_PREC_BF16) {
-              const float* src = reinterpret_cast<const float*>(xv) + pos * CIN + ch * 8;
-              va[u] = *reinterpret_cast<const uint4*>(src);
-              vb[u] = *reinterpret_cast<const uint4*>(src + 4);
+              // (channel slice of a wider tensor: chunks past in_cvalid stay zero)
+              const int cstr = g.in_cstride ? g.in_cstride : CIN;
+              if (!g.in_cstride || ch * 8 < g.in_cvalid) {
+                const float* src = reinterpret_cast<const float*>(xv) + pos * cstr + ch * 8;
+                va[u] = *reinterpret_cast<const uint4*>(src);
+                vb[u] = *reinterpret_cast<const uint4*>(src + 4);
+              }
             } else {
               va[u] = *reinterpret_cast<const uint4*>(
                   reinterpret_cast<const float*>(xv) + pos * CIN + ch * 4);
@@ -550,6 +554,18 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w,
   }
 }
 
+// chunk k of the data-gradient filter of a 64 -> C_out conv (C_out > 64):
+// wt[tap'][ci' = co - 64 k][co' = ci] = w[26 - tap'][ci][co], zero rows past C_out
+__global__ void pack_dgrad_chunk_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                        int cout, int k) {
+  const int total = 27 * 64 * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int ci = idx & 63, cr = (idx >> 6) & 63, tp = idx >> 12;
+    const int co = 64 * k + cr;
+    wt[idx] = co < cout ? w[((size_t)(26 - tp) * 64 + ci) * cout + co] : 0.f;
+  }
+}
+
 ConvGeom conv_dgrad_geom(const ConvGeom& g) {
   ConvGeom d = g;
   for (int q = 0; q < 3; ++q) {
@@ -566,6 +582,33 @@ bool conv_dgrad_mfma_supported(const ConvGeom& g, int precision) {
   for (int q = 0; q < 3; ++q)
     if (g.k[q] != 3 || g.s[q] != 1 || g.lo[q] != 1 || g.O[q] != g.D[q]) return false;
   return conv_mfma_supported(conv_dgrad_geom(g), precision);
+}
+
+// 64 -> C_out 'same' conv with C_out > 64 (the 64 -> 200 expansion conv): its
+// data gradient contracts over C_out; run it as ceil(C_out / 64) passes of the
+// 64 -> 64 halo-tile kernel over 64-channel slices of dPre, accumulating in place
+ConvGeom conv_dgrad_chunk_geom(const ConvGeom& g, int k) {
+  ConvGeom d = conv_dgrad_geom(g);
+  d.Cin = 64; d.Cout = 64;
+  d.in_cstride = g.Cout;
+  d.in_cvalid = g.Cout - 64 * k < 64 ? g.Cout - 64 * k : 64;
+  return d;
+}
+
+bool conv_dgrad_chunked_supported(const ConvGeom& g, int precision) {
+  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_DGRAD_CHUNKED")) return false;
+  if (g.Cin != 64 || g.Cout <= 64 || g.Cout % 8 != 0 || g.Cout > 512) return false;
+  for (int q = 0; q < 3; ++q)
+    if (g.k[q] != 3 || g.s[q] != 1 || g.lo[q] != 1 || g.O[q] != g.D[q]) return false;
+  ConvGeom base = g;
+  base.Cout = 64; base.d2s = 1;
+  return conv_mfma_supported(conv_dgrad_geom(base), precision);
+}
+
+int launch_conv_dgrad_chunk_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, float* wt, int k) {
+  hipLaunchKernelGGL(pack_dgrad_chunk_kernel, dim3(432), dim3(256), 0, ctx->stream, w, wt, g.Cout, k);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
 }
 
 // valid-padded forward conv (lo = 0, O = D - 2): its data gradient is the full
@@ -628,7 +671,7 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
                          const void* x, const void* packed, const float* bias,
                          const void* res, void* y, ConvIO io) {
   if (precision == S3_PREC_BF16) {
-    if (conv_mfma_persist_supported(ctx, g, io, res != nullptr))
+    if (!g.in_cstride && conv_mfma_persist_supported(ctx, g, io, res != nullptr))
       return launch_conv_mfma_persist(ctx, g, x, (const char*)packed + (size_t)((g.Cout + CT - 1) / CT) * 27 * CT * CIN * 2, bias, res, y);
     // tile / wave configuration (SUP3R_AMD_MFMA_TILE overrides for A/B probes)
     static const int tile_env = getenv("SUP3R_AMD_MFMA_TILE") ? atoi(getenv("SUP3R_AMD_MFMA_TILE")) : -1;

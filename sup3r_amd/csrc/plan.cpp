@@ -51,6 +51,8 @@ struct OpRec {
   bool dgrad_s2 = false;       // stride-2 valid conv, C_out = 32: residue classes on an LDS halo
   int mask_prod = -1;          // dgrad_s2: producer conv of in0 whose activation adjoint is fused into the store
   bool dgrad_fewch = false;    // C_out <= 4 'same' conv: dgrad = few-channel forward conv over the frame
+  bool dgrad_chunked = false;  // 64 -> C_out > 64 'same' conv: 64-channel slices of dPre through the tile kernel
+  void* dgc_wbf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool halo32 = false;         // C_in = 32 stride-1 conv: LDS-halo forward
   void* h32_w = nullptr;
   uint64_t h32_version = 0;
@@ -432,6 +434,8 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             if (same && conv_gconv_supported(conv_dgrad_geom(g), precision))
               o.dgrad_mfma = o.dgrad_fewch = true;
           }
+          if (!o.dgrad_mfma && !o.fewpos && conv_dgrad_chunked_supported(g, precision))
+            o.dgrad_mfma = o.dgrad_chunked = true;
           o.dgrad_c2 = !o.dgrad_mfma && !o.fewpos && conv_dgrad_c2_supported(g, precision);
           o.dgrad_s2 = !o.dgrad_mfma && !o.dgrad_c2 && !o.fewpos && conv_dgrad_s2_supported(ctx, g, precision);
           o.gconv_dgrad = !o.dgrad_mfma && !o.dgrad_c2 && !o.dgrad_s2 && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
@@ -439,7 +443,8 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             max_dxp = std::max(max_dxp, (size_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
                                             (g.D[2] + 2 * g.lo[2]) * g.Cin * sizeof(float));
           if (o.dgrad_mfma) {
-            o.dg = o.dgrad_valid ? conv_dgrad_valid_geom(g) : conv_dgrad_geom(g);
+            o.dg = o.dgrad_valid ? conv_dgrad_valid_geom(g)
+                                 : (o.dgrad_chunked ? conv_dgrad_chunk_geom(g, 0) : conv_dgrad_geom(g));
             max_dxp = std::max(max_dxp, (size_t)o.dg.N * o.dg.O[0] * o.dg.O[1] * o.dg.O[2] * o.dg.Cout * sizeof(float));
           }
         }
@@ -634,6 +639,11 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     for (auto& o : pl->ops) {
       if (rc || o.d.kind != S3_OP_CONV || !o.dgrad_mfma) continue;
       rc = plan_alloc(pl, (void**)&o.dg_w32, (size_t)27 * o.cg.Cin * o.cg.Cout * sizeof(float));
+      if (!rc && o.dgrad_chunked) {
+        for (int k = 0; !rc && k < (o.cg.Cout + 63) / 64; ++k)
+          rc = plan_alloc(pl, &o.dgc_wbf[k], conv_mfma_packed_bytes(o.dg, precision));
+        continue;
+      }
       if (!rc && precision == S3_PREC_BF16)
         rc = plan_alloc(pl, &o.dg_wbf, o.dgrad_fewch ? conv_gconv_packed_bytes(o.dg, 0)
                                                      : conv_mfma_packed_bytes(o.dg, precision));
@@ -1047,7 +1057,30 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
         }
         if (wants_grad(d.in0)) {
           float* dst = grad_dest(pl, d.in0);
-          if (o.dgrad_mfma) {
+          if (o.dgrad_chunked) {
+            // 64-channel slices of dPre through the 64 -> 64 halo-tile kernel,
+            // accumulated in place over the padded frame, then the fold
+            const int nk = (g.Cout + 63) / 64;
+            if (o.dg_version != P->version) {
+              for (int k = 0; k < nk; ++k) {
+                rc = launch_conv_dgrad_chunk_pack(ctx, g, W + P->p[d.w].offset, o.dg_w32, k);
+                if (!rc) rc = launch_conv_mfma_pack(ctx, conv_dgrad_chunk_geom(g, k), pl->precision, o.dg_w32, o.dgc_wbf[k]);
+                if (rc) return rc;
+              }
+              o.dg_version = P->version;
+            }
+            for (int k = 0; k < nk; ++k) {
+              rc = launch_conv_mfma_fwd(ctx, conv_dgrad_chunk_geom(g, k), pl->precision, dpre + 64 * k, o.dgc_wbf[k],
+                                        nullptr, k ? pl->dxp : nullptr, pl->dxp, ConvIO());
+              if (rc) return rc;
+            }
+            GatherGeom fg;
+            fg.kind = S3_OP_PAD; fg.N = g.N;
+            for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2; fg.lo[q] = 1; }
+            fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
+            fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
+            rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+          } else if (o.dgrad_mfma) {
             // dXpad = conv_zero(dPre, flip(W)^T) over the padded frame, then
             // the adjoint of the virtual padding folds the border back
             if (o.dg_version != P->version) {

@@ -834,3 +834,38 @@ def test_stride2_dgrad_residue_class_halo_kernel(monkeypatch, capfd):
         assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
         assert np.abs(g0 - g02).max() < 1e-4 * np.abs(g02).max()
         assert np.abs(dx - dx2).max() < 1e-4 * np.abs(dx2).max()
+
+
+def test_chunked_dgrad_of_wide_conv_on_tile_kernel(monkeypatch):
+    """Data gradient of the 64 -> 200 (+ depth-to-space) conv as four passes of
+    the 64 -> 64 halo-tile kernel over 64-channel slices of dPre (the last
+    slice has 8 channels), accumulated in place: against the oracle
+    (bf16-mode bound) and against the gather-MFMA kernel
+    (SUP3R_AMD_NO_DGRAD_CHUNKED=1, same bf16 operands: rel. rms < 2e-3)."""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(51)
+    spec = pcc(3, 64) + pcc(3, 200, act=False) + \
+        [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
+         {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    shape = (2, 5, 7, 19, 4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = ref.backward(dy)
+
+    def run():
+        net = _hip_net(spec, ref.weights, precision='bf16')
+        ph = net.plan(shape, training=True)
+        ph.forward(net.dev.to_device(x))
+        dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
+        return dx, np.array(net.grads[0])
+    dx, g0 = run()
+    monkeypatch.setenv('SUP3R_AMD_NO_DGRAD_CHUNKED', '1')
+    dx2, g02 = run()
+
+    def rel_rms(a, b):
+        return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
+    assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
+    assert np.abs(g0 - g02).max() > 0
+    assert rel_rms(g0, g02) < 2e-3 and rel_rms(dx, dx2) < 2e-3
