@@ -5,6 +5,6 @@
 for rep in 1 2; do
 for v in "$@"; do
   echo -n "$v  "
-  SUP3R_AMD_LIB=$PWD/$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode 2>/dev/null | python -c "
+  SUP3R_AMD_LIB=$PWD/$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-train 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'samples/s', round(d['ms_per_step'],3), 'ms/step', round(d['roofline']['achieved'],1), 'TF', round(d['roofline']['avg_launch_ms'],4), 'ms/launch')"
 done; done

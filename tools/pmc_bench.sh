@@ -6,7 +6,7 @@
 OUT=${1:-gpurun_out/pmc_bench}; shift
 ROOTD=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOTD/$OUT"; cd /tmp; export TMPDIR=/tmp
-CMD="python $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline $@"
+CMD="python $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train $@"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOTD/$OUT/stats" -- $CMD > "$ROOTD/$OUT/stats.log" 2>&1
 i=0
 for grp in \
