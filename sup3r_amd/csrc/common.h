@@ -217,6 +217,9 @@ int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
                   int esize);
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
                       float* din);
+bool gather_bwd_mask_ok(const GatherGeom& g);
+int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
+                             const void* mask_y, int y_bf16, float slope);
 int launch_act(s3_ctx* ctx, const float* x, float* y, int64_t n, int act,
                float alpha);
 // dx = dy * act'(y)  (y is the activation OUTPUT; sign-preserving acts only)

@@ -149,8 +149,12 @@ __global__ void gather_bwd_kernel(const float* __restrict__ dout,
 
 // fold of a reflect / zero padded frame (adjoint of S3_OP_PAD) on float4
 // channel groups: the index math of a cell is shared by 4 channels
+// MASK: 0 none, 1 fp32 y, 2 bf16 y — multiplies by the activation adjoint of the
+// conv that produced the folded tensor (y = act(pre): 1 where y > 0, else slope)
+template <int MASK>
 __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
-                                       float* __restrict__ din, GatherGeom g) {
+                                       float* __restrict__ din, GatherGeom g,
+                                       const void* __restrict__ mask_y, float slope) {
   const int c4n = g.Ci >> 2;
   const int64_t total = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * c4n;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,6 +187,17 @@ __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
                       cand[2][e]) * g.Co + c4 * 4);
           acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+    if (MASK == 1) {
+      const float4 y = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(mask_y) + idx * 4);
+      acc.x *= y.x > 0.f ? 1.f : slope; acc.y *= y.y > 0.f ? 1.f : slope;
+      acc.z *= y.z > 0.f ? 1.f : slope; acc.w *= y.w > 0.f ? 1.f : slope;
+    } else if (MASK == 2) {
+      // bf16: the sign bit is bit 15 of each half word; zero is not > 0
+      const uint2 y = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(mask_y) + idx * 4);
+      auto pos = [](unsigned h) { return (h & 0x8000u) == 0 && (h & 0x7FFFu) != 0; };
+      acc.x *= pos(y.x & 0xFFFFu) ? 1.f : slope; acc.y *= pos(y.x >> 16) ? 1.f : slope;
+      acc.z *= pos(y.y & 0xFFFFu) ? 1.f : slope; acc.w *= pos(y.y >> 16) ? 1.f : slope;
+    }
     *reinterpret_cast<float4*>(din + idx * 4) = acc;
   }
 }
@@ -600,12 +615,31 @@ int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
   return S3_OK;
 }
 
+bool gather_bwd_mask_ok(const GatherGeom& g) {
+  return g.kind == S3_OP_PAD && g.Ci == g.Co && (g.Ci & 3) == 0;
+}
+
+// fold of a padded frame with the producer's activation adjoint applied
+// (mask_y: the producer's output, fp32 or bf16)
+int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
+                             const void* mask_y, int y_bf16, float slope) {
+  if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_masked: unsupported geometry");
+  int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  const dim3 grid(grid_for(n / 4, ctx->num_cu));
+  if (y_bf16)
+    hipLaunchKernelGGL(gather_bwd_pad4_kernel<2>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope);
+  else
+    hipLaunchKernelGGL(gather_bwd_pad4_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
                       float* din) {
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
   if (g.kind == S3_OP_PAD && g.Ci == g.Co && (g.Ci & 3) == 0) {
-    hipLaunchKernelGGL(gather_bwd_pad4_kernel, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,
-                       ctx->stream, dout, din, g);
+    hipLaunchKernelGGL(gather_bwd_pad4_kernel<0>, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,
+                       ctx->stream, dout, din, g, (const void*)nullptr, 0.f);
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }

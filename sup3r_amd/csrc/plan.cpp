@@ -49,7 +49,7 @@ struct OpRec {
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
   bool dgrad_s2 = false;       // stride-2 valid conv, C_out = 32: residue classes on an LDS halo
-  int mask_prod = -1;          // dgrad_s2: producer conv of in0 whose activation adjoint is fused into the store
+  int mask_prod = -1;          // producer conv of in0 whose activation adjoint is fused into this conv's dgrad store / fold
   bool dgrad_fewch = false;    // C_out <= 4 'same' conv: dgrad = few-channel forward conv over the frame
   bool dgrad_chunked = false;  // 64 -> C_out > 64 'same' conv: 64-channel slices of dPre through the tile kernel
   void* dgc_wbf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -575,10 +575,15 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       if (d.kind != S3_OP_VIEW) prod[root_of(pl, d.out)] = i;
     }
     for (auto& o : pl->ops) {
-      if (o.d.kind != S3_OP_CONV || !o.dgrad_s2) continue;
+      // (the stride-2 dgrad kernel masks from an fp32 y; the frame fold of the
+      // halo-tile dgrad from fp32 or bf16)
+      const bool fold = o.dgrad_mfma && !o.dgrad_valid;
+      if (o.d.kind != S3_OP_CONV || !(o.dgrad_s2 || fold)) continue;
       const int r = root_of(pl, o.d.in0);
       const int pi = prod[r];
-      if (pi < 0 || ncons[r] != 1 || r == root_of(pl, output) || pl->t[r].is_input || pl->t[r].dtype) continue;
+      if (pi < 0 || ncons[r] != 1 || r == root_of(pl, output) || pl->t[r].is_input) continue;
+      if (o.dgrad_s2 && pl->t[r].dtype) continue;
+      if (fold && (o.cg.Cin & 3)) continue;
       const OpRec& po = pl->ops[pi];
       if (po.d.kind == S3_OP_CONV && po.cg.act != S3_ACT_NONE && po.cg.d2s == 1 && po.d.res < 0)
         o.mask_prod = pi;
@@ -1057,6 +1062,20 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
         }
         if (wants_grad(d.in0)) {
           float* dst = grad_dest(pl, d.in0);
+          // fold of the padded-frame data gradient; when this conv is the only
+          // consumer of an activated conv's output the fold applies that
+          // activation's adjoint (the producer then skips its mask pass)
+          auto fold_frame = [&](const GatherGeom& fg, float* out) -> int {
+            const int rin = root_of(pl, d.in0);
+            const bool fuse = o.mask_prod >= 0 && !pl->gwritten[rin] && gather_bwd_mask_ok(fg) &&
+                              !getenv("SUP3R_AMD_NO_MASK_FUSE");
+            if (!fuse) return launch_gather_bwd(ctx, fg, pl->dxp, out);
+            const ConvGeom& pg = pl->ops[o.mask_prod].cg;
+            int frc = launch_gather_bwd_masked(ctx, fg, pl->dxp, out, tptr(pl, d.in0), pl->t[rin].dtype,
+                                               pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f);
+            if (!frc) pl->premasked[rin] = 1;
+            return frc;
+          };
           if (o.dgrad_chunked) {
             // 64-channel slices of dPre through the 64 -> 64 halo-tile kernel,
             // accumulated in place over the padded frame, then the fold
@@ -1079,7 +1098,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2; fg.lo[q] = 1; }
             fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
             fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
-            rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+            rc = fold_frame(fg, dst);
           } else if (o.dgrad_mfma) {
             // dXpad = conv_zero(dPre, flip(W)^T) over the padded frame, then
             // the adjoint of the virtual padding folds the border back
@@ -1109,7 +1128,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2; fg.lo[q] = 1; }
             fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
             fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
-            rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+            rc = fold_frame(fg, dst);
           } else if (o.dgrad_s2) {
             if (o.dc2_version != (int64_t)P->version) {
               rc = launch_conv_dgrad_s2_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);
