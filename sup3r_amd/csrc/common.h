@@ -127,7 +127,7 @@ bool conv_gconv_dgrad_supported(const ConvGeom& g, int precision);
 size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad);
 int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad);
 int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
-                     const float* bias, const float* res, void* y, int out_bf16);
+                     const float* bias, const float* res, void* y, int out_bf16, int in_bf16 = 0);
 int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* packed_t,
                        float* dx, int accumulate, int frame);
 
@@ -135,7 +135,8 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
 bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                               float* dw, float* partial, size_t partial_bytes, int accumulate);
+                               float* dw, float* partial, size_t partial_bytes, int accumulate,
+                               int x_bf16 = 0);
 // forward conv with C_in = 32 on an LDS halo (kernels_conv_halo32.hip)
 bool conv_halo32_supported(const s3_ctx* ctx, const ConvGeom& g, int precision);
 size_t conv_halo32_packed_bytes(const ConvGeom& g);
@@ -148,7 +149,7 @@ bool conv_dgrad_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision
 size_t conv_dgrad_s2_packed_bytes(const ConvGeom& g);
 int launch_conv_dgrad_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
 int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx,
-                         const float* mask_y, float mask_slope);
+                         const void* mask_y, float mask_slope, int mask_bf16 = 0);
 // dgrad of the few-channel hi-res conv with an LDS halo (kernels_conv_dgrad_fewch.hip)
 bool conv_dgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_dgrad_c2_packed_bytes();

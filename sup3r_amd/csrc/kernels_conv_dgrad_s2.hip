@@ -53,7 +53,7 @@ template <int NF>
 __global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
     const float* __restrict__ dy, const unsigned short* __restrict__ img,
     float* __restrict__ dx, ConvGeom g, int rows_pad, int tiles0, int tiles1, int tiles2,
-    const float* __restrict__ mask_y, float mask_slope) {
+    const void* __restrict__ mask_y, float mask_slope, int mask_bf16) {
   extern __shared__ __attribute__((aligned(16))) char halo[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kg = lane >> 4;
@@ -154,7 +154,14 @@ __global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
         float4 v = make_float4(acc[m][nf][0], acc[m][nf][1], acc[m][nf][2], acc[m][nf][3]);
         if (mask_y) {
           // fused activation adjoint of the PRODUCER of x (x = act(pre)): dPre = dx * act'(x)
-          const float4 yv = *reinterpret_cast<const float4*>(mask_y + e);
+          float4 yv;
+          if (mask_bf16) {
+            const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(mask_y) + e);
+            yv = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xFFFF0000u),
+                             __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xFFFF0000u));
+          } else {
+            yv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(mask_y) + e);
+          }
           v.x *= yv.x > 0.f ? 1.f : mask_slope; v.y *= yv.y > 0.f ? 1.f : mask_slope;
           v.z *= yv.z > 0.f ? 1.f : mask_slope; v.w *= yv.w > 0.f ? 1.f : mask_slope;
         }
@@ -195,7 +202,7 @@ int launch_conv_dgrad_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, vo
 }
 
 int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx,
-                         const float* mask_y, float mask_slope) {
+                         const void* mask_y, float mask_slope, int mask_bf16) {
   const int U0 = (g.D[0] + 1) / 2, U1 = (g.D[1] + 1) / 2, U2 = (g.D[2] + 1) / 2;
   const int tiles0 = (U0 + ST0 - 1) / ST0, tiles1 = (U1 + ST1 - 1) / ST1, tiles2 = (U2 + ST2 - 1) / ST2;
   const int n_ct = (g.Cin + 63) / 64;
@@ -203,10 +210,10 @@ int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const 
   const int rp = s2_rows_pad(g.Cin);
   if (g.Cin <= 32)
     hipLaunchKernelGGL(conv_dgrad_s2_kernel<2>, grid, dim3(SNT), SLDS, ctx->stream, dy,
-                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_y, mask_slope);
+                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_y, mask_slope, mask_bf16);
   else
     hipLaunchKernelGGL(conv_dgrad_s2_kernel<4>, grid, dim3(SNT), SLDS, ctx->stream, dy,
-                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_y, mask_slope);
+                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_y, mask_slope, mask_bf16);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

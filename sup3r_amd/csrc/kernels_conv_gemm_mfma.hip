@@ -76,7 +76,7 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, const float* __restrict__ res,
     void* __restrict__ yv, ConvGeom g, int64_t P, int rows_pad, int accumulate, int frame,
-    int out_bf16) {
+    int out_bf16, int x16) {
   float* __restrict__ y = reinterpret_cast<float*>(yv);
   // in ADJ mode: g is the FORWARD conv's geometry; positions run over its
   // input grid D, the gathered tensor x is dY on its output grid O, K = C_out
@@ -202,6 +202,16 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
             if (nf < nfv) wf[nf] = *reinterpret_cast<const bf16x8*>(wt + (int64_t)nf * 16 * Kp + kc * 32);
 #pragma unroll
           for (int m = 0; m < GT_MF; ++m) {
+            if (x16) {
+              // bf16 cells (bf16 saved activations, K % 8 == 0): the lane's 8
+              // channels are one 16-B load; src[] was computed in fp32 elements
+              uint4 u = make_uint4(0, 0, 0, 0);
+              if (sok[m] && kc * 32 + kq * 8 < K)
+                u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(x) +
+                                                    (src[m] - x) + kc * 32);
+              xf[m] = __builtin_bit_cast(bf16x8, u);
+              continue;
+            }
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
             if (sok[m] && kc * 32 + kq * 8 < K) {
               if (K >= 4) {
@@ -658,8 +668,9 @@ int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* pack
 }
 
 int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
-                     const float* bias, const float* res, void* y, int out_bf16) {
+                     const float* bias, const float* res, void* y, int out_bf16, int in_bf16) {
   if (out_bf16 && g.Cout % 4 != 0) S3_FAIL(ctx, S3_EINVAL, "gconv: bf16 output needs C_out % 4 == 0");
+  if (in_bf16 && (g.Cin % 8 != 0 || fewch_geom(g))) S3_FAIL(ctx, S3_EINVAL, "gconv: bf16 input needs C_in % 8 == 0");
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
   if (fewch_geom(g)) {
     dim3 fgrid((unsigned)((P + FC_POS - 1) / FC_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
@@ -687,7 +698,7 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
   }
   dim3 grid((unsigned)((P + GT_POS - 1) / GT_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
   hipLaunchKernelGGL(gconv_mfma_kernel<false>, grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
-                     (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16);
+                     (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16, in_bf16);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -707,7 +718,7 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
   }
   hipLaunchKernelGGL(gconv_mfma_kernel<true>, grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
                      (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
-                     rows_padded(g.Cin), accumulate, frame, 0);
+                     rows_padded(g.Cin), accumulate, frame, 0, 0);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -259,7 +259,7 @@ struct BfGen {
   }
 };
 
-template <int CIB, int STR>
+template <int CIB, int STR, bool IN16>
 __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
@@ -313,8 +313,10 @@ __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
     const int n = tr;
     const int org0 = t0i * W::T0, org1 = t1i * T1, org2 = t2i * T2;
     __syncthreads();
-    // ---- stage the x halo: cells x (CIB * 4) float4 -> bf16
-    constexpr int CH = CIB * 4;
+    // ---- stage the x halo: cells x (CIB * 4) float4 -> bf16 (IN16: CIB * 2
+    // 16-B chunks of a bf16 tensor, no convert)
+    constexpr int CH = IN16 ? CIB * 2 : CIB * 4;
+    constexpr int CW = IN16 ? 8 : 4;              // channels per item
     for (int item = tid; item < HP * CH; item += BNT) {
       const int hp = item / CH, ch = item % CH;
       int h = hp;
@@ -328,14 +330,20 @@ __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
       }
       // outside the tensor: zero padding, or cells feeding only masked outputs
       const bool valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2 &&
-                         ci0 + ch * 4 < Cin;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (valid)
-        v = *reinterpret_cast<const float4*>(
-            x + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * Cin + ci0 + ch * 4);
+                         ci0 + ch * CW < Cin;
+      const size_t e = ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * Cin + ci0 + ch * CW;
       const int u = W::tau(c2);
-      *reinterpret_cast<uint2*>(xs + ((c0 * G1 + c1) * G2 + u) * CB + (((ch >> 2) ^ W::key(u)) << 5) +
-                                ((ch & 3) << 3)) = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+      char* cell = xs + ((c0 * G1 + c1) * G2 + u) * CB;
+      if constexpr (IN16) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (valid) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(x) + e);
+        *reinterpret_cast<uint4*>(cell + (((ch >> 1) ^ W::key(u)) << 5) + ((ch & 1) << 4)) = v;
+      } else {
+        float4 v = make_float4(0, 0, 0, 0);
+        if (valid) v = *reinterpret_cast<const float4*>(x + e);
+        *reinterpret_cast<uint2*>(cell + (((ch >> 2) ^ W::key(u)) << 5) + ((ch & 3) << 3)) =
+            make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+      }
     }
     // ---- stage the dPre tile: NP positions x 8 float4
     for (int item = tid; item < NP * (BCT / 4); item += BNT) {
@@ -406,7 +414,7 @@ int bf_gen_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t0, int
   return grid;
 }
 
-template <int CIB, int STR>
+template <int CIB, int STR, bool IN16 = false>
 int bf_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy, float* dw,
                   float* partial, size_t partial_bytes, int accumulate) {
   using W = BfGen<CIB, STR>;
@@ -414,7 +422,7 @@ int bf_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* d
   const int grid = bf_gen_grid<CIB, STR>(ctx, g, &n_tiles, &t0, &t1, &t2);
   const size_t need = (size_t)grid * 27 * g.Cin * g.Cout * sizeof(float);
   if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_gen: partial buffer too small");
-  auto kern = conv_wgrad_bf16_gen_kernel<CIB, STR>;
+  auto kern = conv_wgrad_bf16_gen_kernel<CIB, STR, IN16>;
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -680,8 +688,16 @@ size_t conv_wgrad_bf16_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
 }
 
 int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                               float* dw, float* partial, size_t partial_bytes, int accumulate) {
+                               float* dw, float* partial, size_t partial_bytes, int accumulate,
+                               int x_bf16) {
   const bool s2 = g.s[0] == 2;
+  if (x_bf16) {
+    if (g.Cin == 32)
+      return s2 ? bf_gen_launch<2, 2, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
+                : bf_gen_launch<2, 1, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
+    return s2 ? bf_gen_launch<4, 2, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
+              : bf_gen_launch<4, 1, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
+  }
   if (g.Cin == 32)
     return s2 ? bf_gen_launch<2, 2>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
               : bf_gen_launch<2, 1>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);

@@ -505,12 +505,19 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       for (int i = 0; i < n_tensors; ++i)
         if (!produced[root_of(pl, i)]) demote(i, c0);
     }
+    // outputs of the few-channel gather conv: bf16 only towards a conv INPUT
+    // (the consumer rounds to bf16 when it stages anyway, so nothing changes
+    // numerically); as a residual the fp32 value is kept
+    std::vector<char> fewch_out(n_tensors, 0);
+    for (auto& o : pl->ops)
+      if (o.d.kind == S3_OP_CONV && !o.mfma && o.gconv && o.cg.Cin <= 4) fewch_out[root_of(pl, o.d.out)] = 1;
     while (changed) {
       changed = false;
       for (auto& o : pl->ops) {
         const s3_op_desc& d = o.d;
         switch (d.kind) {
           case S3_OP_CONV:
+            if (training && d.res >= 0 && fewch_out[root_of(pl, d.res)]) demote(d.res, changed);
             if (o.mfma) {
               if (!conv_mfma_bf16_out_ok(o.cg)) demote(d.out, changed);
               if (training && !o.wgrad_bf16) demote(d.in0, changed);
@@ -519,8 +526,17 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               // the hi-res tail conv, whose MFMA forward takes bf16 cells and
               // whose weight gradient (conv_wgrad_tail_kernel) stages them as is
               const bool tail16 = d.res < 0 && !o.fewpos && o.wgrad_tail && conv_tail_mfma_supported(o.cg);
-              if (!tail16) demote(d.in0, changed);
-              demote(d.res, changed); demote(d.out, changed);
+              // ... and the hi-res discriminator pair: the few-channel conv
+              // (C_in <= 4) may write bf16 when its consumer is a gather-MFMA
+              // conv (bf16 cells in, C_in % 8 == 0) whose weight gradient is
+              // the general transpose-read kernel (bf16 staging)
+              const bool gc_in16 = o.gconv && !o.halo32 && d.res < 0 && o.wgrad_bf16_gen && o.cg.Cin % 8 == 0 &&
+                                   !getenv("SUP3R_AMD_NO_DISC_BF16");
+              const bool gc_out16 = o.gconv && d.res < 0 && (o.cg.Cin == 2 || o.cg.Cin == 4) &&
+                                    o.cg.Cout % 8 == 0 && !getenv("SUP3R_AMD_NO_DISC_BF16");
+              if (!tail16 && !gc_in16) demote(d.in0, changed);
+              demote(d.res, changed);
+              if (!gc_out16) demote(d.out, changed);
             } else {
               // the direct kernels read fp32, except the small-channel tail
               // convs (MFMA C_in = 8 / sliding window) which take bf16 cells
@@ -582,7 +598,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       const int r = root_of(pl, o.d.in0);
       const int pi = prod[r];
       if (pi < 0 || ncons[r] != 1 || r == root_of(pl, output) || pl->t[r].is_input) continue;
-      if (o.dgrad_s2 && pl->t[r].dtype) continue;
+
       if (fold && (o.cg.Cin & 3)) continue;
       const OpRec& po = pl->ops[pi];
       if (po.d.kind == S3_OP_CONV && po.cg.act != S3_ACT_NONE && po.cg.d2s == 1 && po.d.res < 0)
@@ -769,13 +785,14 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
         }
         return launch_conv_halo32_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.h32_w, b, (float*)tptr(pl, d.out));
       }
-      if (o.gconv && !o.io.in_bf16 && !o.io.res_bf16 && (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
+      if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
+          (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
         if (o.gc_version != P->version) {
           int rc = launch_gconv_pack(ctx, o.cg, w, o.gc_w, 0);
           if (rc) return rc;
           o.gc_version = P->version;
         }
-        return launch_gconv_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.gc_w, b, res, tptr(pl, d.out), o.io.out_bf16);
+        return launch_gconv_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.gc_w, b, res, tptr(pl, d.out), o.io.out_bf16, o.io.in_bf16);
       }
       if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16)
         return launch_conv_fewpos_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out), pl->fp_partial, pl->fp_partial_bytes);
@@ -1049,7 +1066,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           else if (o.wgrad_bf16_2d)
             rc = launch_conv_wgrad_bf16_2d(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16_gen)
-            rc = launch_conv_wgrad_bf16_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+            rc = launch_conv_wgrad_bf16_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16);
           else if (o.wgrad_gen)
             rc = launch_conv_wgrad_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16)
@@ -1140,7 +1157,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             const bool fuse = o.mask_prod >= 0 && !pl->gwritten[root_of(pl, d.in0)] && !getenv("SUP3R_AMD_NO_MASK_FUSE");
             const ConvGeom& pg = pl->ops[fuse ? o.mask_prod : i].cg;
             rc = launch_conv_dgrad_s2(ctx, g, dpre, o.dc2_w, dst, fuse ? tptr(pl, d.in0) : nullptr,
-                                      pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f);
+                                      pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, o.io.in_bf16);
             if (!rc && fuse) pl->premasked[root_of(pl, d.in0)] = 1;
           } else if (o.dgrad_c2) {
             if (o.dc2_version != (int64_t)P->version) {

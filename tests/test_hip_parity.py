@@ -693,6 +693,56 @@ def test_training_plan_bf16_saved_activations(monkeypatch):
         assert rel_rms(a, b) < 3e-2
 
 
+def test_training_plan_bf16_first_discriminator_activation(monkeypatch, capfd):
+    """bf16 training plans store the few-channel first conv's output in bf16
+    when its consumer is a gather-MFMA conv (bf16 cells in; weight gradient =
+    transpose-read kernel staging bf16; the stride-2 data gradient applies the
+    producer's LeakyReLU mask from the bf16 sign).  The consumer rounds that
+    tensor to bf16 when it stages anyway, so against the fp32-stored plan
+    (SUP3R_AMD_NO_DISC_BF16=1) every result agrees to fp32 summation order."""
+    rng = np.random.default_rng(47)
+
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(32, 2) + conv(16, 1)
+    shape = (2, 21, 23, 37, 2)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = ref.backward(dy)
+    monkeypatch.setenv('SUP3R_AMD_TRACE', '1')
+
+    def run():
+        net = _hip_net(spec, ref.weights, precision='bf16')
+        ph = net.plan(shape, training=True)
+        y = ph.forward(net.dev.to_device(x)).cpu().numpy()
+        dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
+        return y, dx, [np.array(g) for g in net.grads]
+    y16, dx16, g16 = run()
+    trace = capfd.readouterr().err
+    first = [ln for ln in trace.splitlines() if 'conv 2->32 train' in ln]
+    second = [ln for ln in trace.splitlines() if 'conv 32->32 train' in ln]
+    assert first and 'out16 1' in first[0], trace
+    assert second and 'in16 1' in second[0] and 'gen 1' in second[0], trace
+    monkeypatch.setenv('SUP3R_AMD_NO_DISC_BF16', '1')
+    y32, dx32, g32 = run()
+    trace = capfd.readouterr().err
+    assert 'out16 1' not in [ln for ln in trace.splitlines() if 'conv 2->32 train' in ln][0]
+
+    def rel_rms(a, b):
+        return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
+    scale = max(1.0, np.abs(y_ref).max())
+    assert np.abs(y16 - y_ref).max() < 3e-2 * scale
+    assert np.abs(y16 - y32).max() < 1e-5 * scale
+    assert rel_rms(dx16, dx_ref) < 1e-1 and rel_rms(dx16, dx32) < 1e-4
+    for a, b, r in zip(g16, g32, ref.grads):
+        assert rel_rms(a, r) < 2e-1
+        assert rel_rms(a, b) < 1e-4
+
+
 def test_halo32_forward_conv_vs_oracle_and_gather_kernel(monkeypatch, capfd):
     """conv_halo32_kernel (C_in = 32, stride 1, valid and zero 'same' padding,
     C_out 64 and 24 -> NF = 4 / 2, ragged 4 x 8 x 16 tiles): forward against
