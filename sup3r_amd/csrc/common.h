@@ -232,6 +232,7 @@ int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
 int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
                int c, int bcast_c);
 int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n);  // y += x
+int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add);
 int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
                      float* db, int accumulate);
 int launch_dense_fwd(s3_ctx* ctx, const float* x, const float* w,

@@ -150,7 +150,8 @@ __global__ void gather_bwd_kernel(const float* __restrict__ dout,
 // fold of a reflect / zero padded frame (adjoint of S3_OP_PAD) on float4
 // channel groups: the index math of a cell is shared by 4 channels
 // MASK: 0 none, 1 fp32 y, 2 bf16 y — multiplies by the activation adjoint of the
-// conv that produced the folded tensor (y = act(pre): 1 where y > 0, else slope)
+// conv that produced the folded tensor (y = act(pre): 1 where y > 0, else slope);
+// 3: mask_y is an fp32 tensor ADDED to the fold (an earlier gradient contribution)
 template <int MASK>
 __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
                                        float* __restrict__ din, GatherGeom g,
@@ -159,12 +160,23 @@ __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
   const int64_t total = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * c4n;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
        idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = idx;
-    const int c4 = (int)(r % c4n); r /= c4n;
-    const int i2 = (int)(r % g.Di[2]); r /= g.Di[2];
-    const int i1 = (int)(r % g.Di[1]); r /= g.Di[1];
-    const int i0 = (int)(r % g.Di[0]); r /= g.Di[0];
-    const int n = (int)r;
+    // (32-bit divisions whenever the element count allows: the 64-bit ones
+    // cost more than the memory traffic of this kernel)
+    int c4, i2, i1, i0, n;
+    if (total <= 0x7fffffffLL) {
+      unsigned r = (unsigned)idx, q;
+      q = r / (unsigned)c4n; c4 = (int)(r - q * (unsigned)c4n); r = q;
+      q = r / (unsigned)g.Di[2]; i2 = (int)(r - q * (unsigned)g.Di[2]); r = q;
+      q = r / (unsigned)g.Di[1]; i1 = (int)(r - q * (unsigned)g.Di[1]); r = q;
+      q = r / (unsigned)g.Di[0]; i0 = (int)(r - q * (unsigned)g.Di[0]); n = (int)q;
+    } else {
+      int64_t r = idx;
+      c4 = (int)(r % c4n); r /= c4n;
+      i2 = (int)(r % g.Di[2]); r /= g.Di[2];
+      i1 = (int)(r % g.Di[1]); r /= g.Di[1];
+      i0 = (int)(r % g.Di[0]); r /= g.Di[0];
+      n = (int)r;
+    }
     int cand[3][3], cnt[3];
     const int ii[3] = {i0, i1, i2};
 #pragma unroll
@@ -197,6 +209,10 @@ __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
       auto pos = [](unsigned h) { return (h & 0x8000u) == 0 && (h & 0x7FFFu) != 0; };
       acc.x *= pos(y.x & 0xFFFFu) ? 1.f : slope; acc.y *= pos(y.x >> 16) ? 1.f : slope;
       acc.z *= pos(y.y & 0xFFFFu) ? 1.f : slope; acc.w *= pos(y.y >> 16) ? 1.f : slope;
+    }
+    if (MASK == 3) {
+      const float4 y = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(mask_y) + idx * 4);
+      acc.x += y.x; acc.y += y.y; acc.z += y.z; acc.w += y.w;
     }
     *reinterpret_cast<float4*>(din + idx * 4) = acc;
   }
@@ -271,6 +287,26 @@ __global__ void conv_epilogue_bwd_kernel(const float* __restrict__ y,
   }
 }
 
+// the same without a store permutation, four channels per lane
+template <bool Y16>
+__global__ void conv_epilogue_bwd4_kernel(const void* __restrict__ y, const float4* __restrict__ dy,
+                                          float4* __restrict__ dpre, int64_t n4, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 d = dy[i];
+    if (Y16) {
+      const uint2 h = reinterpret_cast<const uint2*>(y)[i];
+      auto pos = [](unsigned v) { return (v & 0x8000u) == 0 && (v & 0x7FFFu) != 0; };
+      d.x *= pos(h.x & 0xFFFFu) ? 1.f : slope; d.y *= pos(h.x >> 16) ? 1.f : slope;
+      d.z *= pos(h.y & 0xFFFFu) ? 1.f : slope; d.w *= pos(h.y >> 16) ? 1.f : slope;
+    } else {
+      const float4 v = reinterpret_cast<const float4*>(y)[i];
+      d.x *= v.x > 0.f ? 1.f : slope; d.y *= v.y > 0.f ? 1.f : slope;
+      d.z *= v.z > 0.f ? 1.f : slope; d.w *= v.w > 0.f ? 1.f : slope;
+    }
+    dpre[i] = d;
+  }
+}
+
 __global__ void add_kernel(const float* __restrict__ a,
                            const float* __restrict__ b, float* __restrict__ y,
                            int64_t n, int c, int bcast_c) {
@@ -286,6 +322,15 @@ __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += stride)
     y[i] += x[i];
+}
+__global__ void axpy4_kernel(const float4* __restrict__ x, float4* __restrict__ y, int64_t n4) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 a = x[i];
+    float4 b = y[i];
+    b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+    y[i] = b;
+  }
 }
 
 __global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
@@ -344,6 +389,38 @@ __global__ void bias_grad_stage1(const float* __restrict__ dy, int64_t n_pos,
     float t = 0.f;
     for (int r = 0; r < rows; ++r) t += sm[r * c + threadIdx.x];
     partial[(int64_t)blockIdx.x * c + threadIdx.x] = t;
+  }
+}
+
+// four channels per lane (c % 4 == 0): a row of c floats is c / 4 lanes wide
+__global__ void bias_grad_stage1_v4(const float4* __restrict__ dy, int64_t n_pos, int c4,
+                                    float* __restrict__ partial) {
+  extern __shared__ float4 sm4[];
+  const int rows = blockDim.x / c4;
+  const int my_c = threadIdx.x % c4, my_r = threadIdx.x / c4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (my_r < rows) {
+    const int64_t step = (int64_t)gridDim.x * rows;
+    int64_t p = (int64_t)blockIdx.x * rows + my_r;
+    float4 a0 = acc, a1 = acc;
+    auto add4 = [](float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    for (; p + step < n_pos; p += 2 * step) {
+      const float4 v0 = dy[p * c4 + my_c];
+      const float4 v1 = dy[(p + step) * c4 + my_c];
+      add4(a0, v0); add4(a1, v1);
+    }
+    if (p < n_pos) add4(a0, dy[p * c4 + my_c]);
+    acc = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  }
+  sm4[threadIdx.x] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < c4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < rows; ++r) {
+      const float4 v = sm4[r * c4 + threadIdx.x];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(partial)[(int64_t)blockIdx.x * c4 + threadIdx.x] = t;
   }
 }
 
@@ -634,6 +711,16 @@ int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout
   return S3_OK;
 }
 
+// fold of a padded frame plus an earlier contribution: din = fold(dout) + add
+int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add) {
+  if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_add: unsupported geometry");
+  int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  hipLaunchKernelGGL(gather_bwd_pad4_kernel<3>, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0, ctx->stream,
+                     dout, din, g, (const void*)add, 0.f);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
                       float* din) {
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
@@ -665,6 +752,20 @@ int launch_act_bwd(s3_ctx* ctx, const float* y, const float* dy, float* dx,
 int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
                              const float* dy, float* dpre, int y_bf16) {
   int64_t n = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout;
+  if (g.d2s <= 1 && (n & 3) == 0 && (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU)) {
+    const float slope = g.act == S3_ACT_LEAKY ? g.alpha : 0.f;
+    const int64_t n4 = n / 4;
+    const int64_t want = (n4 + kBlock - 1) / kBlock;
+    const dim3 grid((unsigned)(want < 32 * ctx->num_cu ? (want < 1 ? 1 : want) : 32 * ctx->num_cu));
+    if (y_bf16)
+      hipLaunchKernelGGL(conv_epilogue_bwd4_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, (const void*)y,
+                         (const float4*)dy, (float4*)dpre, n4, slope);
+    else
+      hipLaunchKernelGGL(conv_epilogue_bwd4_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, (const void*)y,
+                         (const float4*)dy, (float4*)dpre, n4, slope);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   if (y_bf16)
     hipLaunchKernelGGL(conv_epilogue_bwd_kernel<true>, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, y, dy, dpre, g);
   else
@@ -681,6 +782,12 @@ int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
 }
 
 int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n) {
+  if ((n & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    hipLaunchKernelGGL(axpy4_kernel, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0, ctx->stream,
+                       (const float4*)x, (float4*)y, n / 4);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, x, y, n);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
@@ -708,6 +815,13 @@ int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
   int nblk = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
   int rc = ensure_scratch(ctx, (size_t)nblk * c * sizeof(float));
   if (rc) return rc;
+  if ((c & 3) == 0 && (((uintptr_t)dy) & 15) == 0) {
+    const int c4 = c / 4, rows4 = block / c4;
+    int64_t want4 = (n_pos + rows4 - 1) / rows4;
+    if (want4 < nblk) nblk = (int)(want4 < 1 ? 1 : want4);
+    hipLaunchKernelGGL(bias_grad_stage1_v4, dim3(nblk), dim3(block), block * sizeof(float4), ctx->stream,
+                       (const float4*)dy, n_pos, c4, ctx->scratch);
+  } else
   hipLaunchKernelGGL(bias_grad_stage1, dim3(nblk), dim3(block), block * sizeof(float), ctx->stream, dy, n_pos, c, ctx->scratch);
   hipLaunchKernelGGL(bias_grad_stage2, dim3(c), dim3(256), 0, ctx->stream, ctx->scratch, nblk, c, db, accumulate);
   S3_HIP(ctx, hipGetLastError());

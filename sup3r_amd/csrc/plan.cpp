@@ -96,7 +96,8 @@ struct s3_plan {
   bool forward_done = false;
   std::vector<hipEvent_t> prof_ev;  // prof_cap * (n_ops + 1)
   int prof_cap = 0, prof_n = 0;
-  std::vector<char> gwritten;
+  std::vector<char> gwritten;          // 0 none, 1 in gptr, 2 = one contribution, aliased (gsrc)
+  std::vector<const float*> gsrc;      // the aliased first contribution (a finished gradient buffer)
   std::vector<char> premasked;   // tensor gradient already carries its producer's activation adjoint
   // hipGraph replay of the forward op list (inference plans): inputs are
   // copied into plan-owned staging buffers so every pointer inside the
@@ -987,24 +988,41 @@ extern "C" int s3_plan_op_is_mfma(const s3_plan* pl, int i) {
   return 1;
 }
 
-// deliver a gradient contribution `src` (numel floats) to tensor `id`
+// deliver a gradient contribution `src` (numel floats) to tensor `id`.
+// The first contribution that lives in another finished buffer (the gradient
+// of a consumer's output: skip adds, residuals, views) is not copied: the
+// tensor's gradient aliases it (state 2) until a second contribution arrives,
+// which then lands as one add / in-place accumulate instead of copy + axpy.
 static int grad_deliver(s3_plan* pl, int id, const float* src) {
   int r = root_of(pl, id);
   TensorRec& t = pl->t[r];
   s3_ctx* ctx = pl->ctx;
   if (!pl->gwritten[r]) {
-    if (src != t.gptr)
-      S3_HIP(ctx, hipMemcpyAsync(t.gptr, src, (size_t)t.numel * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-    pl->gwritten[r] = 1;
+    if (src == t.gptr) { pl->gwritten[r] = 1; return S3_OK; }
+    pl->gsrc[r] = src;
+    pl->gwritten[r] = 2;
     return S3_OK;
   }
+  if (pl->gwritten[r] == 2) {
+    const float* first = pl->gsrc[r];
+    pl->gsrc[r] = nullptr;
+    pl->gwritten[r] = 1;
+    if (src == t.gptr) return launch_axpy(ctx, first, t.gptr, t.numel);
+    return launch_add(ctx, first, src, t.gptr, t.numel, 1, 0);
+  }
+  if (src == t.gptr) return S3_OK;  // accumulated in place by the producer
   return launch_axpy(ctx, src, t.gptr, t.numel);
 }
 
 // destination a backward kernel should write dL/d(tensor id) into
 static float* grad_dest(s3_plan* pl, int id) {
   int r = root_of(pl, id);
-  return pl->gwritten[r] ? pl->gtmp : pl->t[r].gptr;
+  return pl->gwritten[r] == 1 ? pl->gtmp : pl->t[r].gptr;
+}
+
+// the finished gradient of tensor root r
+static const float* grad_of(s3_plan* pl, int r) {
+  return pl->gwritten[r] == 2 ? pl->gsrc[r] : pl->t[r].gptr;
 }
 
 extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input,
@@ -1018,10 +1036,12 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
   float* G = P->buf[S3_BUF_G];
   std::fill(pl->gwritten.begin(), pl->gwritten.end(), 0);
   pl->premasked.assign(pl->gwritten.size(), 0);
+  pl->gsrc.assign(pl->gwritten.size(), nullptr);
   {
+    // the caller's buffer is read-only for the duration of the call: alias it
     int r = root_of(pl, pl->output);
-    S3_HIP(ctx, hipMemcpyAsync(pl->t[r].gptr, d_output, (size_t)pl->t[r].numel * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-    pl->gwritten[r] = 1;
+    pl->gsrc[r] = (const float*)d_output;
+    pl->gwritten[r] = 2;
   }
   const int x_id = pl->inputs.empty() ? -1 : root_of(pl, pl->inputs[0]);
   auto wants_grad = [&](int id) {
@@ -1035,7 +1055,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
     if (d.kind == S3_OP_VIEW) continue;
     const int ro = root_of(pl, d.out);
     if (!pl->gwritten[ro]) continue;  // nothing flows through this op
-    const float* dy = pl->t[ro].gptr;
+    const float* dy = grad_of(pl, ro);
     const TensorRec& ot = pl->t[d.out];
     int rc = S3_OK;
     switch (d.kind) {
@@ -1086,6 +1106,14 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             const int rin = root_of(pl, d.in0);
             const bool fuse = o.mask_prod >= 0 && !pl->gwritten[rin] && gather_bwd_mask_ok(fg) &&
                               !getenv("SUP3R_AMD_NO_MASK_FUSE");
+            if (!fuse && pl->gwritten[rin] == 2 && out == pl->t[rin].gptr && gather_bwd_mask_ok(fg)) {
+              // second contribution to a skip tensor: fold + the aliased first
+              // one in a single store (no staging buffer, no axpy)
+              const float* first = pl->gsrc[rin];
+              pl->gsrc[rin] = nullptr;
+              pl->gwritten[rin] = 1;
+              return launch_gather_bwd_add(ctx, fg, pl->dxp, out, first);
+            }
             if (!fuse) return launch_gather_bwd(ctx, fg, pl->dxp, out);
             const ConvGeom& pg = pl->ops[o.mask_prod].cg;
             int frc = launch_gather_bwd_masked(ctx, fg, pl->dxp, out, tptr(pl, d.in0), pl->t[rin].dtype,
@@ -1272,7 +1300,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
   }
   if (d_input) {
     if (x_id < 0 || !pl->gwritten[x_id]) S3_FAIL(ctx, S3_ESTATE, "backward: no gradient reached the input");
-    S3_HIP(ctx, hipMemcpyAsync(d_input, pl->t[x_id].gptr, (size_t)pl->t[x_id].numel * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    S3_HIP(ctx, hipMemcpyAsync(d_input, grad_of(pl, x_id), (size_t)pl->t[x_id].numel * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   }
   return S3_OK;
 }
