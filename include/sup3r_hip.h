@@ -214,6 +214,21 @@ int s3_loss_mmd(s3_ctx* ctx, const float* a, int c_a, const float* b, int c_b, i
                 int64_t n_pos, int c_used, float sigma, float weight, float* loss_out,
                 float* d_a);
 
+/* SlicedWassersteinLoss (loss_metrics.py:724-789): n_proj (<= 4096) random unit
+ * directions over the n_pos positions, the n * c_used (observation, feature)
+ * columns of a, b = (n, n_pos, c_*) projected, each column's projections
+ * sorted, mean squared difference of the sorted values.  The directions are a
+ * counter-based draw from `seed` (Philox4x32-10 + Box-Muller), regenerated in
+ * the backward pass instead of stored; the reference draws new directions per
+ * call (tf.random.normal, :777), the caller does the same by passing a new
+ * seed.  loss_out = unweighted value; d_a (nullable) += weight * d loss / d a.
+ * s3_sw_directions writes the raw (un-normalised) direction matrix
+ * [n_proj][n_pos] of a seed — how the parity tests feed the oracle. */
+int s3_loss_sliced_wasserstein(s3_ctx* ctx, const float* a, int c_a, const float* b, int c_b,
+                               int n, int64_t n_pos, int c_used, int n_proj, uint64_t seed,
+                               float weight, float* loss_out, float* d_a);
+int s3_sw_directions(s3_ctx* ctx, uint64_t seed, int n_proj, int64_t n_pos, float* out);
+
 /* SpatialFftLoss / SpatiotemporalFftLoss (loss_metrics.py:395-485): separable
  * direct DFT, one call per axis over a contiguous (outer, L, inner) view,
  * unnormalised; sign < 0 = forward (tf.signal.fft2d / fft3d), > 0 = adjoint;

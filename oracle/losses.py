@@ -92,6 +92,24 @@ def mmd_loss(x1, x2, sigma=1.0):
                  np.mean(2 * gaussian_kernel(x1, x2, sigma)))
 
 
+def sliced_wasserstein_loss(x1, x2, proj):
+    """SlicedWassersteinLoss.__call__ (loss_metrics.py:743-789) with the random
+    directions given: ``proj`` = the raw normal draws (n_projections, H*W*T)
+    that tf.random.normal produces at :777 (l2-normalised here as at :778).
+    (B, H, W[, T], C) -> (B, HWT, C); proj @ x -> (B, n_proj, C); sort along
+    the projection axis (:786-787); mean squared difference."""
+    assert x1.ndim in (4, 5) and x1.shape == x2.shape
+    b, c = x1.shape[0], x1.shape[-1]
+    f1 = x1.reshape(b, -1, c).astype(np.float64)
+    f2 = x2.reshape(b, -1, c).astype(np.float64)
+    pr = np.asarray(proj, dtype=np.float64)
+    assert pr.shape[1] == f1.shape[1]
+    pr = pr / np.sqrt((pr ** 2).sum(axis=-1, keepdims=True))
+    p1 = np.sort(pr @ f1, axis=1)
+    p2 = np.sort(pr @ f2, axis=1)
+    return float(np.mean((p1 - p2) ** 2))
+
+
 def _fft_map(x, axes):
     """log(1 + w |fftn(x)|), w = product of the squared un-wrapped frequency
     indices of the transformed axes (loss_metrics.py:399-417, :445-465; numpy's

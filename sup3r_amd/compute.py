@@ -9,6 +9,7 @@ calls, content loss, relativistic BCE) -> ``tape.gradient`` — and
 ``optimizer.apply_gradients`` (abstract.py:899,912).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -31,6 +32,7 @@ STRUCTURED_KINDS = {
     'TemporalExtremesLoss': ('ext_t', _lib.LOSS_MAE),
     'LowResLoss': ('lowres', None),
     'MmdLoss': ('mmd', None),
+    'SlicedWassersteinLoss': ('sw', None),
     'SpatialFftLoss': ('fft_s', _lib.LOSS_MAE),
     'SpatiotemporalFftLoss': ('fft_st', _lib.LOSS_MAE),
 }
@@ -80,6 +82,9 @@ def parse_loss_spec(loss):
             elif n == 'MmdLoss':
                 if set(kw) - {'sigma'}:
                     raise TypeError(f'MmdLoss kwargs: {kw}')
+            elif n == 'SlicedWassersteinLoss':
+                if set(kw) - {'n_projections'}:
+                    raise TypeError(f'SlicedWassersteinLoss kwargs: {kw}')
             elif kw:
                 raise TypeError(f'loss "{n}" takes no kwargs: {kw}')
             terms.append((n, STRUCTURED_KINDS[n][0], float(w), kw))
@@ -477,6 +482,20 @@ class HipGanCompute:
                 self._ptr(scal, slot),
                 self._ptr(d_gen) if d_gen is not None else None)
             _lib.check(rc, dev.ctx, 's3_loss_mmd')
+            return [1.0]
+        if kind == 'sw':
+            # new random directions per call (tf.random.normal in the
+            # reference, loss_metrics.py:777): a fresh Philox seed each time
+            seed = getattr(self, 'sw_seed', None)
+            if seed is None:
+                seed = int.from_bytes(os.urandom(8), 'little')
+            self.sw_seed = (int(seed) + 0x9E3779B97F4A7C15) % (1 << 64)
+            rc = L.s3_loss_sliced_wasserstein(
+                dev.ctx, self._ptr(gen), c, self._ptr(true), c, n,
+                s1 * s2 * t, c_used, int(kw.get('n_projections', 1024)),
+                int(seed) % (1 << 64), w, self._ptr(scal, slot),
+                self._ptr(d_gen) if d_gen is not None else None)
+            _lib.check(rc, dev.ctx, 's3_loss_sliced_wasserstein')
             return [1.0]
         raise KeyError(kind)
 

@@ -358,3 +358,107 @@ def test_sup3r_gan_dc_validation_updates_sampling_weights():
     assert abs(np.sum(bh.temporal_weights) - 1) < 1e-6
     assert np.argmax(bh.spatial_weights) == 1
     assert np.argmax(bh.temporal_weights) == 2
+
+
+def test_oracle_sliced_wasserstein_properties():
+    """SlicedWassersteinLoss has no test in the reference; the restatement is
+    checked on what its definition implies: zero for identical fields and for
+    a permutation of the observations' positions that the directions cannot
+    see after sorting only when the fields agree; positive and growing with a
+    shift; invariant to the scale of the raw directions (l2-normalised)."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 5, 6, 4, 3))
+    proj = rng.standard_normal((64, 5 * 6 * 4))
+    assert OL.sliced_wasserstein_loss(x, x, proj) == 0.0
+    l1 = OL.sliced_wasserstein_loss(x, x + 0.5, proj)
+    l2 = OL.sliced_wasserstein_loss(x, x + 1.0, proj)
+    assert 0 < l1 < l2
+    assert abs(OL.sliced_wasserstein_loss(x, x + 0.5, 7.0 * proj) - l1) < 1e-12
+    x4 = rng.standard_normal((2, 5, 6, 3))
+    p4 = rng.standard_normal((16, 30))
+    assert OL.sliced_wasserstein_loss(x4, x4 * 1.1, p4) > 0
+
+
+def test_parse_sliced_wasserstein_spec():
+    from sup3r_amd.compute import parse_loss_spec
+    t = parse_loss_spec({'SlicedWassersteinLoss': {'n_projections': 64},
+                         'MeanAbsoluteError': {}, 'term_weights': [0.3, 0.7]})
+    assert t[0][:3] == ('SlicedWassersteinLoss', 'sw', 0.3)
+    assert t[0][3] == {'n_projections': 64}
+    with pytest.raises(TypeError):
+        parse_loss_spec({'SlicedWassersteinLoss': {'sigma': 1.0}})
+
+
+def _sw_device(gen, true, n_proj, seed, want_grad=True, n_exo=0):
+    import torch
+    from sup3r_amd import _lib
+    from sup3r_amd.engine import Device
+    dev = Device.get()
+    L = _lib.lib()
+    g, t = dev.to_device(gen), dev.to_device(true)
+    c = gen.shape[-1]
+    npos = int(np.prod(gen.shape[1:-1]))
+    out = dev.empty((4,))
+    L.s3_fill(dev.ctx, out.data_ptr(), 4, 0.0)
+    d = torch.zeros_like(g)
+    rc = L.s3_loss_sliced_wasserstein(
+        dev.ctx, g.data_ptr(), c, t.data_ptr(), c, gen.shape[0], npos,
+        c - n_exo, n_proj, seed, 1.0, out.data_ptr(),
+        d.data_ptr() if want_grad else None)
+    _lib.check(rc, dev.ctx, 's3_loss_sliced_wasserstein')
+    proj = dev.empty((n_proj, npos))
+    rc = L.s3_sw_directions(dev.ctx, seed, n_proj, npos, proj.data_ptr())
+    _lib.check(rc, dev.ctx, 's3_sw_directions')
+    return float(out.cpu().numpy()[0]), d.cpu().numpy(), proj.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,n_proj', [((3, 7, 6, 9, 2), 50),
+                                          ((2, 9, 5, 3), 128),
+                                          ((5, 6, 7, 11, 5), 33)])
+def test_device_sliced_wasserstein_vs_oracle(shape, n_proj):
+    """s3_loss_sliced_wasserstein against the oracle fed with the directions
+    the device drew (s3_sw_directions): value to 2e-5, gradient against central
+    differences of the float64 oracle; ragged position counts (not a multiple
+    of 4 / 256), n_proj not a power of two, > 16 (observation, feature)
+    columns (two column passes); the directions are standard normal draws."""
+    rng = np.random.default_rng(21)
+    gen = rng.standard_normal(shape).astype(np.float32)
+    true = (rng.standard_normal(shape) * 1.3 + 0.2).astype(np.float32)
+    seed = 0x1234_5678_9ABC_DEF0
+    loss, grad, proj = _sw_device(gen, true, n_proj, seed)
+    assert abs(proj.mean()) < 5 / np.sqrt(proj.size)
+    assert abs(proj.std() - 1) < 5 / np.sqrt(proj.size)
+    g64, t64 = gen.astype(np.float64), true.astype(np.float64)
+    ref = OL.sliced_wasserstein_loss(g64, t64, proj)
+    assert abs(loss - ref) <= 2e-5 * max(1.0, abs(ref)), (loss, ref)
+    for k in range(3):
+        v = rng.standard_normal(shape)
+        eps = 1e-6
+        fd = (OL.sliced_wasserstein_loss(g64 + eps * v, t64, proj) -
+              OL.sliced_wasserstein_loss(g64 - eps * v, t64, proj)) / (2 * eps)
+        an = float((grad.astype(np.float64) * v).sum())
+        assert abs(an - fd) <= 2e-3 * max(abs(fd), 1e-3), (an, fd)
+    # another seed: other directions, the same seed: the same bits
+    loss2, _, proj2 = _sw_device(gen, true, n_proj, seed + 1, want_grad=False)
+    assert np.abs(proj2 - proj).max() > 0.1 and loss2 != loss
+    loss3, grad3, _ = _sw_device(gen, true, n_proj, seed)
+    assert loss3 == loss and np.array_equal(grad3, grad)
+
+
+@pytest.mark.gpu
+def test_device_sliced_wasserstein_through_calc_loss_spec():
+    """as a ``get_loss_fun`` term next to MAE, with an exo channel that takes
+    no part; identical fields -> 0 and zero gradient"""
+    rng = np.random.default_rng(22)
+    shape = (2, 8, 8, 6, 3)
+    gen = rng.standard_normal(shape).astype(np.float32)
+    true = rng.standard_normal(shape).astype(np.float32)
+    spec = {'SlicedWassersteinLoss': {'n_projections': 64},
+            'MeanAbsoluteError': {}, 'term_weights': [0.4, 0.6]}
+    loss, grad = _device_loss_and_grad(spec, gen, true, n_exo=1)
+    mae = OL.mae(gen[..., :2].astype(np.float64), true[..., :2].astype(np.float64))
+    assert loss > 0.6 * mae and np.isfinite(grad).all()
+    assert np.all(grad[..., 2] == 0)
+    l0, g0, _ = _sw_device(gen, gen.copy(), 64, 5)
+    assert l0 == 0.0 and not g0.any()

@@ -35,7 +35,7 @@ def main():
              'SpatialDerivativeLoss', 'TemporalDerivativeLoss', 'CoarseMseLoss',
              'SpatialExtremesLoss', 'TemporalExtremesLoss',
              {'LowResLoss': {'s_enhance': 5, 't_enhance': 12}}, 'MmdLoss',
-             'SpatiotemporalFftLoss']
+             'SpatiotemporalFftLoss', 'SlicedWassersteinLoss']
     for spec in specs:
         (name, kind, w, kw), = parse_loss_spec(spec)
 
