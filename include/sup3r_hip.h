@@ -229,6 +229,18 @@ int s3_loss_sliced_wasserstein(s3_ctx* ctx, const float* a, int c_a, const float
                                float weight, float* loss_out, float* d_a);
 int s3_sw_directions(s3_ctx* ctx, uint64_t seed, int n_proj, int64_t n_pos, float* out);
 
+/* Time windows of a (outer = n * s1 * s2, t, c) field, as SolarCC.calc_loss
+ * slices the hi-res tensors (sup3r/models/solar_cc.py:155-232).
+ * s3_time_window: adjoint == 0 copies full[:, t0:t0+len, :] into the contiguous
+ * `window`; adjoint != 0 adds scale * window back into that slice of `full`.
+ * s3_time_mean: adjoint == 0 writes mean[o][c] = tf.reduce_mean(full[:, t0:t0+len,
+ * :], axis=time); adjoint != 0 adds (scale / len) * mean[o][c] to every step of
+ * the slice. */
+int s3_time_window(s3_ctx* ctx, float* full, int64_t outer, int t, int c, int t0, int len,
+                   float* window, int adjoint, float scale);
+int s3_time_mean(s3_ctx* ctx, float* full, int64_t outer, int t, int c, int t0, int len,
+                 float* mean, int adjoint, float scale);
+
 /* SpatialFftLoss / SpatiotemporalFftLoss (loss_metrics.py:395-485): separable
  * direct DFT, one call per axis over a contiguous (outer, L, inner) view,
  * unnormalised; sign < 0 = forward (tf.signal.fft2d / fft3d), > 0 = adjoint;

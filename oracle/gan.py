@@ -219,3 +219,75 @@ def un_norm_output(output, means, stdevs):
     means = np.array([np.float32(m) for m in means])
     stdevs = np.array([np.float32(s) for s in stdevs])
     return (output * stdevs) + means
+
+
+class SolarCCOracle(GanOracle):
+    """SolarCC.calc_loss + tape.gradient (sup3r/models/solar_cc.py:93-251):
+    discriminator on the centre DAYLIGHT_HOURS of every true day and on
+    ``time_samples`` windows of the synthetic field (:176-199, the random draw
+    of :185-186 is an argument here), content loss on the centre
+    POINT_LOSS_HOURS plus on the 24-h synthetic mean against the daylight true
+    mean, averaged over the days (:207-232)."""
+
+    STARTING_HOUR, DAYLIGHT_HOURS, POINT_LOSS_HOURS = 8, 8, 2
+
+    def loss_and_grads(self, low_res, hi_res_true, weight_gen_advers=0.001,
+                       train_gen=True, train_disc=False, compute_disc=False,
+                       time_samples=(), hi_res_gen=None):
+        hr_gen = self.gen.forward(low_res) if hi_res_gen is None else hi_res_gen
+        if hr_gen.shape != hi_res_true.shape:
+            raise RuntimeError('shape mismatch {} vs {}'.format(
+                hr_gen.shape, hi_res_true.shape))
+        assert hi_res_true.shape[3] % 24 == 0
+        t_len = hi_res_true.shape[3]
+        n_days = t_len // 24
+        dl, s0, pl = self.DAYLIGHT_HOURS, self.STARTING_HOUR, self.POINT_LOSS_HOURS
+        day = [slice(x, x + 24) for x in range(0, 24 * n_days, 24)]
+        sub = [slice(s0 + x, s0 + x + dl) for x in range(0, 24 * n_days, 24)]
+        pnt = [slice((24 - pl) // 2 + x, (24 - pl) // 2 + x + pl)
+               for x in range(0, 24 * n_days, 24)]
+        ts = [int(v) for v in time_samples]
+        assert len(ts) == n_days
+        nb = hi_res_true.shape[0]
+        win_g = np.concatenate([hr_gen[:, :, :, t0:t0 + dl] for t0 in ts], axis=0)
+        win_t = np.concatenate([hi_res_true[:, :, :, s] for s in sub], axis=0)
+        nw = win_t.shape[0]
+        d_both = self.disc.forward(np.concatenate((win_t, win_g), axis=0))
+        d_true, d_gen = d_both[:nw], d_both[nw:]
+        details = {}
+        if compute_disc or train_disc:
+            ld, g_dt, g_dg = rel_bce(d_true, d_gen)
+            details['loss_disc'] = ld
+        if train_gen:
+            g = np.zeros(hr_gen.shape, dtype=np.float64)
+            lc = 0.0
+            for i in range(n_days):
+                l1, det1, g1 = content_loss(self.loss, hr_gen[:, :, :, pnt[i]],
+                                            hi_res_true[:, :, :, pnt[i]])
+                g[:, :, :, pnt[i]] += g1 / n_days
+                t_mean = hi_res_true[:, :, :, sub[i]].mean(axis=3)
+                g_mean = hr_gen[:, :, :, day[i]].mean(axis=3)
+                l2, det2, g2 = content_loss(self.loss, g_mean, t_mean)
+                g[:, :, :, day[i]] += g2[:, :, :, None, :] / 24 / n_days
+                lc += (l1 + l2) / n_days
+                for k, v in det1.items():
+                    details['c_sub_' + k] = details.get('c_sub_' + k, 0) + v / n_days
+                for k, v in det2.items():
+                    details['c_24h_' + k] = details.get('c_24h_' + k, 0) + v / n_days
+            la, g_as_true, _ = rel_bce(d_gen, d_true)
+            loss = lc + weight_gen_advers * la
+            details.update(loss_gen=loss, loss_gen_content=lc, loss_gen_advers=la)
+            if hi_res_gen is not None:
+                return loss, details, None
+            d_d = np.concatenate((np.zeros_like(d_true),
+                                  weight_gen_advers * g_as_true), axis=0)
+            d_in = self.disc.backward(d_d.astype(d_both.dtype))[nw:]
+            for i, t0 in enumerate(ts):
+                g[:, :, :, t0:t0 + dl] += d_in[i * nb:(i + 1) * nb]
+            self.gen.backward(g.astype(hr_gen.dtype))
+            return loss, details, self.gen.grads
+        if train_disc:
+            d_d = np.concatenate((g_dt, g_dg), axis=0)
+            self.disc.backward(d_d.astype(d_both.dtype))
+            return details['loss_disc'], details, self.disc.grads
+        return None, details, None

@@ -28,7 +28,8 @@ EXPORTS = [
     's3_plan_profile_begin', 's3_plan_profile_end',
     's3_plan_op_is_mfma', 's3_loss_content', 's3_loss_content_masked', 's3_loss_rel_bce',
     's3_lossmap_fwd', 's3_lossmap_bwd', 's3_loss_mmd',
-    's3_loss_sliced_wasserstein', 's3_sw_directions', 's3_dft_axis',
+    's3_loss_sliced_wasserstein', 's3_sw_directions', 's3_time_window',
+    's3_time_mean', 's3_dft_axis',
     's3_specmap',
     's3_copy_channels', 's3_affine_channels', 's3_fill',
     's3_coarsen', 's3_gaussian_smooth', 's3_chunk_stats',
@@ -121,6 +122,9 @@ def lib():
         's3_loss_sliced_wasserstein': (i32, [vp, vp, i32, vp, i32, i32, i64,
                                              i32, i32, u64, f32, vp, vp]),
         's3_sw_directions': (i32, [vp, u64, i32, i64, vp]),
+        's3_time_window': (i32, [vp, vp, i64, i32, i32, i32, i32, vp, i32,
+                                 f32]),
+        's3_time_mean': (i32, [vp, vp, i64, i32, i32, i32, i32, vp, i32, f32]),
         's3_dft_axis': (i32, [vp, vp, vp, vp, vp, i64, i32, i64, i32]),
         's3_specmap': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32,
                              i32, vp, vp]),
