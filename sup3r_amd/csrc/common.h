@@ -141,8 +141,8 @@ int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, c
 bool conv_halo32_supported(const s3_ctx* ctx, const ConvGeom& g, int precision);
 size_t conv_halo32_packed_bytes(const ConvGeom& g);
 int launch_conv_halo32_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
-int launch_conv_halo32_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* img,
-                           const float* bias, float* y);
+int launch_conv_halo32_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* img,
+                           const float* bias, void* y, int in_bf16 = 0, int out_bf16 = 0);
 // dgrad of a stride-2 valid conv with 32 output channels, per residue class on an
 // LDS halo (kernels_conv_dgrad_s2.hip)
 bool conv_dgrad_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision);

@@ -1,6 +1,6 @@
 // Forward conv with 32 input channels on bf16 MFMA with an LDS halo — the
 // valid / zero-padded stride-1 discriminator layer 32 -> 64 (S3_PREC_BF16
-// plans, fp32 activations).
+// plans; fp32 or bf16 activations on either side).
 //
 // The gather kernel re-reads every input cell 27 times through L1 (0.94 ms at
 // C2 batch 8, 170 TFLOP/s).  Here a workgroup stages the (4+2) x (8+2) x (16+2)
@@ -49,7 +49,7 @@ template <int NF>
 __global__ __launch_bounds__(HNT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_halo32_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ img,
     const float* __restrict__ bias, float* __restrict__ y, ConvGeom g, int rows_pad,
-    int tiles0, int tiles1, int tiles2) {
+    int tiles0, int tiles1, int tiles2, int in16, int out16) {
   extern __shared__ __attribute__((aligned(16))) char halo[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kg = lane >> 4;
@@ -63,6 +63,38 @@ __global__ __launch_bounds__(HNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
 
   // ---- stage the input halo: cell (c0, c1, c2) = x[org + c - lo], zero outside
+  // (bf16 cells: one 16-B chunk per item, no convert)
+  if (in16) {
+    const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
+    for (int base = tid; base < HHP * 4; base += HNT * 3) {
+      uint4 v[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int item = base + u * HNT;
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (item < HHP * 4) {
+          const int hp = item >> 2, ch = item & 3;
+          int h = hp;
+          const int c2 = h % HH2; h /= HH2;
+          const int c1 = h % HH1; h /= HH1;
+          const int c0 = h;
+          const int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
+          if (i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2)
+            v[u] = *reinterpret_cast<const uint4*>(
+                x16 + ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * 32 + ch * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int item = base + u * HNT;
+        if (item < HHP * 4) {
+          const int hp = item >> 2, ch = item & 3;
+          const int key = ((hp % HH2) >> 1) & 3;
+          *reinterpret_cast<uint4*>(halo + hp * 64 + ((ch ^ key) << 4)) = v[u];
+        }
+      }
+    }
+  } else
   for (int base = tid; base < HHP * 4; base += HNT * 3) {
     float4 va[3], vb[3];
 #pragma unroll
@@ -144,8 +176,12 @@ __global__ __launch_bounds__(HNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         v[r] = acc[m][nf][r] + bv[r];
         v[r] = v[r] > 0.f ? v[r] : slope * v[r];
       }
-      float* dst = y + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * R + ch;
-      *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      const size_t oi = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * R + ch;
+      if (out16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + oi) =
+            make_uint2(pk2(v[0], v[1]), pk2(v[2], v[3]));
+      else
+        *reinterpret_cast<float4*>(y + oi) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -180,8 +216,10 @@ int launch_conv_halo32_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void
   return S3_OK;
 }
 
-int launch_conv_halo32_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* img,
-                           const float* bias, float* y) {
+int launch_conv_halo32_fwd(s3_ctx* ctx, const ConvGeom& g, const void* xv, const void* img,
+                           const float* bias, void* yv, int in_bf16, int out_bf16) {
+  const float* x = (const float*)xv;
+  float* y = (float*)yv;
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo32_kernel<4>),
@@ -197,10 +235,10 @@ int launch_conv_halo32_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const
   dim3 grid((unsigned)(g.N * tiles0 * tiles1 * tiles2), (unsigned)n_ct);
   if (g.Cout <= 32)
     hipLaunchKernelGGL(conv_halo32_kernel<2>, grid, dim3(HNT), HLDS, ctx->stream, x,
-                       (const unsigned short*)img, bias, y, g, rp, tiles0, tiles1, tiles2);
+                       (const unsigned short*)img, bias, y, g, rp, tiles0, tiles1, tiles2, in_bf16, out_bf16);
   else
     hipLaunchKernelGGL(conv_halo32_kernel<4>, grid, dim3(HNT), HLDS, ctx->stream, x,
-                       (const unsigned short*)img, bias, y, g, rp, tiles0, tiles1, tiles2);
+                       (const unsigned short*)img, bias, y, g, rp, tiles0, tiles1, tiles2, in_bf16, out_bf16);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

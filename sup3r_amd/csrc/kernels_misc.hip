@@ -670,6 +670,7 @@ int ensure_scratch(s3_ctx* ctx, size_t bytes) {
   }
   size_t want = bytes < (size_t)(1 << 20) ? (size_t)(1 << 20) : bytes;
   S3_HIP(ctx, hipMalloc((void**)&ctx->scratch, want));
+  S3_HIP(ctx, hipMemsetAsync(ctx->scratch, getenv("SUP3R_AMD_POISON_ALLOC") ? 0xFF : 0, want, ctx->stream));
   ctx->scratch_bytes = want;
   return S3_OK;
 }

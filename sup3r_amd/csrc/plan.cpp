@@ -115,6 +115,12 @@ static int plan_alloc(s3_plan* pl, void** out, size_t bytes) {
   s3_ctx* ctx = pl->ctx;
   if (bytes == 0) bytes = 16;
   S3_HIP(ctx, hipMalloc(out, bytes));
+  // every plan buffer starts zeroed (hipMalloc hands back stale bytes of freed
+  // buffers: padding rows / halo borders that no kernel writes must not depend
+  // on what ran before).  SUP3R_AMD_POISON_ALLOC=1 fills all-ones bytes instead
+  // (NaN as fp32 and as bf16): a debugging aid that makes any read of a plan
+  // buffer before its first write show up in the results.
+  S3_HIP(ctx, hipMemsetAsync(*out, getenv("SUP3R_AMD_POISON_ALLOC") ? 0xFF : 0, bytes, ctx->stream));
   pl->owned.push_back(*out);
   pl->total_bytes += bytes;
   return S3_OK;
@@ -531,10 +537,15 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               // (C_in <= 4) may write bf16 when its consumer is a gather-MFMA
               // conv (bf16 cells in, C_in % 8 == 0) whose weight gradient is
               // the general transpose-read kernel (bf16 staging)
-              const bool gc_in16 = o.gconv && !o.halo32 && d.res < 0 && o.wgrad_bf16_gen && o.cg.Cin % 8 == 0 &&
-                                   !getenv("SUP3R_AMD_NO_DISC_BF16");
-              const bool gc_out16 = o.gconv && d.res < 0 && (o.cg.Cin == 2 || o.cg.Cin == 4) &&
-                                    o.cg.Cout % 8 == 0 && !getenv("SUP3R_AMD_NO_DISC_BF16");
+              // ... and so on down the stack: every gather-MFMA / LDS-halo conv with
+              // C_in % 8 == 0 takes and writes bf16 cells (SUP3R_AMD_DISC_BF16=1
+              // keeps it to the first pair, SUP3R_AMD_NO_DISC_BF16 turns it off)
+              const bool disc16 = !getenv("SUP3R_AMD_NO_DISC_BF16");
+              const bool deep16 = disc16 && !(getenv("SUP3R_AMD_DISC_BF16") && atoi(getenv("SUP3R_AMD_DISC_BF16")) == 1);
+              const bool gc_in16 = disc16 && o.gconv && (!o.halo32 || deep16) && d.res < 0 && o.wgrad_bf16_gen &&
+                                   o.cg.Cin % 8 == 0;
+              const bool gc_out16 = disc16 && o.gconv && d.res < 0 && o.cg.Cout % 8 == 0 &&
+                                    (o.cg.Cin == 2 || o.cg.Cin == 4 || (deep16 && o.cg.Cin % 8 == 0));
               if (!tail16 && !gc_in16) demote(d.in0, changed);
               demote(d.res, changed);
               if (!gc_out16) demote(d.out, changed);
@@ -778,13 +789,14 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
         const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.packed : (const void*)w;
         return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out), o.io);
       }
-      if (o.halo32 && !o.io.in_bf16 && !o.io.out_bf16 && !res) {
+      if (o.halo32 && !res) {
         if (o.h32_version != P->version) {
           int rc = launch_conv_halo32_pack(ctx, o.cg, w, o.h32_w);
           if (rc) return rc;
           o.h32_version = P->version;
         }
-        return launch_conv_halo32_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.h32_w, b, (float*)tptr(pl, d.out));
+        return launch_conv_halo32_fwd(ctx, o.cg, tptr(pl, d.in0), o.h32_w, b, tptr(pl, d.out), o.io.in_bf16,
+                                      o.io.out_bf16);
       }
       if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
           (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {

@@ -694,7 +694,8 @@ def test_training_plan_bf16_saved_activations(monkeypatch):
 
 
 def test_training_plan_bf16_first_discriminator_activation(monkeypatch, capfd):
-    """bf16 training plans store the few-channel first conv's output in bf16
+    """bf16 training plans store the few-channel first conv's output — and
+    every later activation between gather-MFMA / LDS-halo convs — in bf16
     when its consumer is a gather-MFMA conv (bf16 cells in; weight gradient =
     transpose-read kernel staging bf16; the stride-2 data gradient applies the
     producer's LeakyReLU mask from the bf16 sign).  The consumer rounds that
@@ -727,10 +728,14 @@ def test_training_plan_bf16_first_discriminator_activation(monkeypatch, capfd):
     second = [ln for ln in trace.splitlines() if 'conv 32->32 train' in ln]
     assert first and 'out16 1' in first[0], trace
     assert second and 'in16 1' in second[0] and 'gen 1' in second[0], trace
+    # ... and the stride-2 conv hands bf16 cells on to the third conv
+    third = [ln for ln in trace.splitlines() if 'conv 32->16 train' in ln]
+    assert 'out16 1' in second[0] and third and 'in16 1' in third[0], trace
     monkeypatch.setenv('SUP3R_AMD_NO_DISC_BF16', '1')
     y32, dx32, g32 = run()
     trace = capfd.readouterr().err
-    assert 'out16 1' not in [ln for ln in trace.splitlines() if 'conv 2->32 train' in ln][0]
+    assert not [ln for ln in trace.splitlines()
+                if ' train' in ln and ('in16 1' in ln or 'out16 1' in ln)], trace
 
     def rel_rms(a, b):
         return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
