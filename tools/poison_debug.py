@@ -39,6 +39,14 @@ def main():
                     [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
                      {'alpha': 0.2, 'class': 'LeakyReLU'}], (2, 5, 7, 19, 4)),
     }
+    full = json.load(open(os.path.join(cfgd, 'gen_2x_2f.json')))['hidden_layers']
+    cases = {
+        'pad+convT(2->64,relu)+crop': (full[0:3], (3, 9, 8, 2)),
+        'pad+convT(64->64)+crop': (full[5:8], (3, 9, 8, 64)),
+        'pad+convT(64->256)+crop+d2s+relu': (full[9:14], (3, 9, 8, 64)),
+        'pad+convT(64->2)+crop': (full[14:17], (3, 18, 16, 64)),
+        'chunked': cases['chunked'],
+    }
     for name, (spec, shape) in cases.items():
         if isinstance(spec, dict):
             spec = spec['hidden_layers']
@@ -50,6 +58,13 @@ def main():
                 os.environ['SUP3R_AMD_TRACE'] = '1'
             dirty = run(spec, shape, training)
             os.environ.pop('SUP3R_AMD_TRACE', None)
+            if name == 'chunked' and training:
+                os.environ['SUP3R_AMD_NO_DGRAD_CHUNKED'] = '1'
+                d2 = run(spec, shape, training)
+                os.environ.pop('SUP3R_AMD_NO_DGRAD_CHUNKED', None)
+                for k in d2:
+                    if np.isnan(d2[k]).any():
+                        print('chunked (gather dgrad)', k, 'nan at', np.argwhere(np.isnan(d2[k]))[:4].tolist())
             for k in clean:
                 a, b = clean[k], dirty[k]
                 bad = ~np.isclose(a, b, rtol=0, atol=0, equal_nan=False)
