@@ -220,7 +220,7 @@ int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
                       float* din);
 bool gather_bwd_mask_ok(const GatherGeom& g);
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
-                             const void* mask_y, int y_bf16, float slope);
+                             const void* mask_y, int y_bf16, float slope, float* bsum = nullptr);
 int launch_act(s3_ctx* ctx, const float* x, float* y, int64_t n, int act,
                float alpha);
 // dx = dy * act'(y)  (y is the activation OUTPUT; sign-preserving acts only)
@@ -232,7 +232,11 @@ int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
 int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
                int c, int bcast_c);
 int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n);  // y += x
-int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add);
+int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add,
+                          float* bsum = nullptr);
+bool gather_bwd_bsum_ok(const GatherGeom& g);
+int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g);
+int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, int c, float* db, int accumulate);
 int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
                      float* db, int accumulate);
 int launch_dense_fwd(s3_ctx* ctx, const float* x, const float* w,

@@ -155,7 +155,13 @@ __global__ void gather_bwd_kernel(const float* __restrict__ dout,
 template <int MASK>
 __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
                                        float* __restrict__ din, GatherGeom g,
-                                       const void* __restrict__ mask_y, float slope) {
+                                       const void* __restrict__ mask_y, float slope,
+                                       float* __restrict__ bsum) {
+  // bsum (nullable, needs c4n | 256): per-workgroup channel sums of the stored
+  // values, partial[block][Ci] — the bias gradient of the conv that produced
+  // the folded tensor, for bias_grad_stage2 (a lane keeps one channel group:
+  // the grid stride is a multiple of c4n)
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
   const int c4n = g.Ci >> 2;
   const int64_t total = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * c4n;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,6 +221,20 @@ __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
       acc.x += y.x; acc.y += y.y; acc.z += y.z; acc.w += y.w;
     }
     *reinterpret_cast<float4*>(din + idx * 4) = acc;
+    bs.x += acc.x; bs.y += acc.y; bs.z += acc.z; bs.w += acc.w;
+  }
+  if (bsum) {
+    __shared__ float4 bred[256];
+    bred[threadIdx.x] = bs;
+    __syncthreads();
+    if ((int)threadIdx.x < c4n) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = threadIdx.x; q < 256; q += c4n) {
+        const float4 v = bred[q];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      reinterpret_cast<float4*>(bsum)[(int64_t)blockIdx.x * c4n + threadIdx.x] = t;
+    }
   }
 }
 
@@ -699,25 +719,43 @@ bool gather_bwd_mask_ok(const GatherGeom& g) {
 
 // fold of a padded frame with the producer's activation adjoint applied
 // (mask_y: the producer's output, fp32 or bf16)
+// channel sums ride along when the geometry allows (see the kernel)
+bool gather_bwd_bsum_ok(const GatherGeom& g) {
+  const int c4n = g.Ci >> 2;
+  return gather_bwd_mask_ok(g) && c4n >= 1 && c4n <= 64 && (256 % c4n) == 0 && kBlock == 256;
+}
+int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g) {
+  int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  return grid_for(n / 4, ctx->num_cu);
+}
+
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
-                             const void* mask_y, int y_bf16, float slope) {
+                             const void* mask_y, int y_bf16, float slope, float* bsum) {
   if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_masked: unsupported geometry");
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
   const dim3 grid(grid_for(n / 4, ctx->num_cu));
   if (y_bf16)
-    hipLaunchKernelGGL(gather_bwd_pad4_kernel<2>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope);
+    hipLaunchKernelGGL(gather_bwd_pad4_kernel<2>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum);
   else
-    hipLaunchKernelGGL(gather_bwd_pad4_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope);
+    hipLaunchKernelGGL(gather_bwd_pad4_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+// stage 2 of the bias gradient from channel sums a fold kernel left behind
+int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, int c, float* db, int accumulate) {
+  hipLaunchKernelGGL(bias_grad_stage2, dim3(c), dim3(256), 0, ctx->stream, partial, nblk, c, db, accumulate);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
 
 // fold of a padded frame plus an earlier contribution: din = fold(dout) + add
-int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add) {
+int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add,
+                          float* bsum) {
   if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_add: unsupported geometry");
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
   hipLaunchKernelGGL(gather_bwd_pad4_kernel<3>, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0, ctx->stream,
-                     dout, din, g, (const void*)add, 0.f);
+                     dout, din, g, (const void*)add, 0.f, bsum);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -727,7 +765,7 @@ int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
   if (g.kind == S3_OP_PAD && g.Ci == g.Co && (g.Ci & 3) == 0) {
     hipLaunchKernelGGL(gather_bwd_pad4_kernel<0>, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,
-                       ctx->stream, dout, din, g, (const void*)nullptr, 0.f);
+                       ctx->stream, dout, din, g, (const void*)nullptr, 0.f, (float*)nullptr);
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }

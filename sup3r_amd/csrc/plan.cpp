@@ -98,6 +98,8 @@ struct s3_plan {
   int prof_cap = 0, prof_n = 0;
   std::vector<char> gwritten;          // 0 none, 1 in gptr, 2 = one contribution, aliased (gsrc)
   std::vector<const float*> gsrc;      // the aliased first contribution (a finished gradient buffer)
+  float* bsum = nullptr;               // channel sums left by a frame fold (bias gradient of the producer)
+  int bsum_for = -1, bsum_nblk = 0;    // tensor root they belong to (-1: none), slabs
   std::vector<char> premasked;   // tensor gradient already carries its producer's activation adjoint
   // hipGraph replay of the forward op list (inference plans): inputs are
   // copied into plan-owned staging buffers so every pointer inside the
@@ -664,6 +666,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     }
     int rc = plan_alloc(pl, (void**)&pl->dpre, max_dpre);
     if (!rc) rc = plan_alloc(pl, (void**)&pl->gtmp, max_t);
+    if (!rc) rc = plan_alloc(pl, (void**)&pl->bsum, (size_t)4096 * 256 * sizeof(float));
     if (!rc && max_partial) {
       rc = plan_alloc(pl, (void**)&pl->wg_partial, max_partial);
       pl->wg_partial_bytes = max_partial;
@@ -1016,6 +1019,7 @@ static int grad_deliver(s3_plan* pl, int id, const float* src) {
     return S3_OK;
   }
   if (pl->gwritten[r] == 2) {
+    if (pl->bsum_for == r) pl->bsum_for = -1;   // the tensor changes: its channel sums are stale
     const float* first = pl->gsrc[r];
     pl->gsrc[r] = nullptr;
     pl->gwritten[r] = 1;
@@ -1023,6 +1027,7 @@ static int grad_deliver(s3_plan* pl, int id, const float* src) {
     return launch_add(ctx, first, src, t.gptr, t.numel, 1, 0);
   }
   if (src == t.gptr) return S3_OK;  // accumulated in place by the producer
+  if (pl->bsum_for == r) pl->bsum_for = -1;
   return launch_axpy(ctx, src, t.gptr, t.numel);
 }
 
@@ -1049,6 +1054,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
   std::fill(pl->gwritten.begin(), pl->gwritten.end(), 0);
   pl->premasked.assign(pl->gwritten.size(), 0);
   pl->gsrc.assign(pl->gwritten.size(), nullptr);
+  pl->bsum_for = -1;
   {
     // the caller's buffer is read-only for the duration of the call: alias it
     int r = root_of(pl, pl->output);
@@ -1086,7 +1092,11 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
         const int64_t npos = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
         if (need_wgrad) {
           if (d.b >= 0) {
-            rc = launch_bias_grad(ctx, dpre, npos, g.Cout, G + P->p[d.b].offset, accumulate_wgrad);
+            if (pl->bsum_for == ro && dpre == pl->t[ro].gptr && pl->gwritten[ro] == 1)
+              rc = launch_bias_grad_from_partial(ctx, pl->bsum, pl->bsum_nblk, g.Cout, G + P->p[d.b].offset,
+                                                 accumulate_wgrad);
+            else
+              rc = launch_bias_grad(ctx, dpre, npos, g.Cout, G + P->p[d.b].offset, accumulate_wgrad);
             if (rc) return rc;
           }
           if (o.fewpos)
@@ -1118,18 +1128,31 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             const int rin = root_of(pl, d.in0);
             const bool fuse = o.mask_prod >= 0 && !pl->gwritten[rin] && gather_bwd_mask_ok(fg) &&
                               !getenv("SUP3R_AMD_NO_MASK_FUSE");
+            // the stored tensor is (so far) the whole gradient of d.in0: its
+            // channel sums = the bias gradient of the conv that produced it
+            // ride along (grad_deliver drops them if the tensor changes later)
+            float* bs = nullptr;
+            if (need_wgrad && pl->bsum && out == pl->t[rin].gptr && gather_bwd_bsum_ok(fg) &&
+                gather_bwd_bsum_blocks(ctx, fg) <= 4096 && !getenv("SUP3R_AMD_NO_BIAS_FUSE")) {
+              bs = pl->bsum;
+              pl->bsum_for = rin;
+              pl->bsum_nblk = gather_bwd_bsum_blocks(ctx, fg);
+            }
             if (!fuse && pl->gwritten[rin] == 2 && out == pl->t[rin].gptr && gather_bwd_mask_ok(fg)) {
               // second contribution to a skip tensor: fold + the aliased first
               // one in a single store (no staging buffer, no axpy)
               const float* first = pl->gsrc[rin];
               pl->gsrc[rin] = nullptr;
               pl->gwritten[rin] = 1;
-              return launch_gather_bwd_add(ctx, fg, pl->dxp, out, first);
+              return launch_gather_bwd_add(ctx, fg, pl->dxp, out, first, bs);
             }
-            if (!fuse) return launch_gather_bwd(ctx, fg, pl->dxp, out);
+            if (!fuse) {
+              if (bs) pl->bsum_for = -1;   // plain fold: no side output
+              return launch_gather_bwd(ctx, fg, pl->dxp, out);
+            }
             const ConvGeom& pg = pl->ops[o.mask_prod].cg;
             int frc = launch_gather_bwd_masked(ctx, fg, pl->dxp, out, tptr(pl, d.in0), pl->t[rin].dtype,
-                                               pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f);
+                                               pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, bs);
             if (!frc) pl->premasked[rin] = 1;
             return frc;
           };

@@ -60,7 +60,7 @@ def main():
                SUP3R_AMD_NO_WGRAD_TAIL='1', SUP3R_AMD_NO_WGRAD_C2='1',
                SUP3R_AMD_NO_DGRAD_CHUNKED='1', SUP3R_AMD_NO_DGRAD_FEWCH='1',
                SUP3R_AMD_NO_MASK_FUSE='1', SUP3R_AMD_BF16_TRAIN_ACT='0',
-               SUP3R_AMD_NO_DISC_BF16='1')
+               SUP3R_AMD_NO_DISC_BF16='1', SUP3R_AMD_NO_BIAS_FUSE='1')
     worst = 0.0
     for it in range(args.n):
         kind = it % 3
