@@ -154,6 +154,46 @@ int s3_plan_profile_end(s3_plan* plan, float* ms_per_op, int cap);
 /* 0: op i is not on MFMA; 1: MFMA halo-tile kernel (one tile per workgroup);
  * 2: its persistent variant (all-bf16 64 -> 64 trunk convs, >= 1 tile per CU) */
 int s3_plan_op_is_mfma(const s3_plan* plan, int op_index);
+/* introspection of the kernel selection (what SUP3R_AMD_TRACE prints), used by
+ * the parity tests to assert which kernels a configuration runs on and to
+ * build the bf16-emulating oracle (which convs round their operands / store
+ * bf16).  Fills out[0..min(cap, S3_OPINFO_COUNT)) and returns S3_OPINFO_COUNT.
+ * No reference counterpart: keras picks its conv algorithm inside TF. */
+enum {
+  S3_OPINFO_KIND = 0,          /* S3_OP_*                                      */
+  S3_OPINFO_FWD = 1,           /* S3_FWD_* (convs)                             */
+  S3_OPINFO_IN16 = 2,          /* input / output / residual stored as bf16     */
+  S3_OPINFO_OUT16 = 3,
+  S3_OPINFO_RES16 = 4,
+  S3_OPINFO_FWD_BF16_OPS = 5,  /* forward kernel rounds x and w to bf16        */
+  S3_OPINFO_WGRAD = 6,         /* S3_WGRAD_* (training plans)                  */
+  S3_OPINFO_DGRAD = 7,         /* S3_DGRAD_*                                   */
+  S3_OPINFO_MASK_FUSED_FROM = 8, /* op whose activation adjoint this conv's
+                                  dgrad store applies, or -1                  */
+  S3_OPINFO_COUNT = 9
+};
+enum {
+  S3_FWD_DIRECT = 0, S3_FWD_MFMA_TILE = 1, S3_FWD_MFMA_PERSIST = 2, S3_FWD_GCONV = 3,
+  S3_FWD_GCONV_FEWCH = 4, S3_FWD_HALO32 = 5, S3_FWD_FEWPOS = 6, S3_FWD_TAIL_MFMA = 7,
+  S3_FWD_SMALL = 8
+};
+enum {
+  S3_WGRAD_DIRECT = 0, S3_WGRAD_F32_TRUNK = 1, S3_WGRAD_BF16_TRUNK = 2, S3_WGRAD_F32_GEN = 3,
+  S3_WGRAD_BF16_GEN = 4, S3_WGRAD_BF16_2D = 5, S3_WGRAD_C2 = 6, S3_WGRAD_TAIL = 7,
+  S3_WGRAD_FEWPOS = 8
+};
+enum {
+  S3_DGRAD_DIRECT = 0, S3_DGRAD_MFMA_FRAME = 1, S3_DGRAD_MFMA_VALID = 2,
+  S3_DGRAD_MFMA_CHUNKED = 3, S3_DGRAD_FEWCH_FRAME = 4, S3_DGRAD_S2 = 5, S3_DGRAD_C2 = 6,
+  S3_DGRAD_GCONV = 7, S3_DGRAD_FEWPOS = 8
+};
+int s3_plan_op_info(const s3_plan* plan, int op_index, int32_t* out, int cap);
+/* 0 = fp32, 1 = bf16 storage of a plan tensor (bf16 plans keep the trunk in bf16) */
+int s3_plan_tensor_dtype(const s3_plan* plan, int32_t tensor_id);
+/* raw bytes of a plan tensor (in its storage dtype) to host memory after a
+ * stream sync; returns the byte count or a negative error.  Training plans
+ * keep every activation: the tests read the LeakyReLU masks the device used. */
+int64_t s3_plan_tensor_read(s3_plan* plan, int32_t tensor_id, void* host, size_t cap_bytes);
 
 /* ---- losses ------------------------------------------------------------
  * content loss: keras MeanAbsoluteError / MeanSquaredError as used by
@@ -264,6 +304,14 @@ int s3_affine_channels(s3_ctx* ctx, const float* src, float* dst, int c,
                        int64_t n_pos, const float* scale_host,
                        const float* shift_host);
 int s3_fill(s3_ctx* ctx, float* dst, int64_t n, float value);
+/* device -> device copy of a (d0, d1, row_elems) fp32 block between two
+ * strided layouts (strides in elements; rows are contiguous): the lo-res chunk
+ * window `data[lr_pad_slice]` (strategy.py:474-518) cut out of the resident
+ * domain, and the halo crop `hi_res[0][hr_crop_slices]` of the generated chunk
+ * (forward_pass.py:272). */
+int s3_copy_block(s3_ctx* ctx, const float* src, float* dst, int64_t d0, int64_t d1,
+                  int64_t row_elems, int64_t src_stride0, int64_t src_stride1,
+                  int64_t dst_stride0, int64_t dst_stride1);
 /* device half of ForwardPass._output_check (sup3r/pipeline/forward_pass.py:
  * 384-425: NaNs or a constant output channel mean the chunk failed): for x =
  * (n_chunks, pos_per_chunk, c) writes partial[n_chunks][64][c][3] = (min, max,
@@ -336,6 +384,12 @@ int s3_comm_unique_id(void* out128); /* rank 0; 128 bytes                  */
 int s3_comm_init(s3_ctx* ctx, int rank, int nranks, const void* unique_id128);
 int s3_params_allreduce_grads(s3_params* p);
 int s3_allreduce_sum(s3_ctx* ctx, float* buf, int64_t n);
+/* replicas must start from identical weights (the reference's towers read ONE
+ * set of tf.Variables, abstract.py:827-841): ncclBroadcast of a store buffer
+ * (S3_BUF_*) / any fp32 buffer from rank `root` */
+int s3_params_broadcast(s3_params* p, int which, int root);
+int s3_broadcast(s3_ctx* ctx, float* buf, int64_t n, int root);
+void s3_comm_destroy(s3_ctx* ctx);
 
 /* library / build information */
 const char* s3_version(void);

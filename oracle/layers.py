@@ -13,8 +13,28 @@ Every layer has ``forward(x, *extra)`` and ``backward(dy)`` (returns dx and
 fills ``self.grads`` in keras weight order).  Arrays are channels-last,
 ``(N, s1, s2, C)`` or ``(N, s1, s2, t, C)``; dtype follows the input so the
 same code runs fp32 (parity) and fp64 (finite-difference checks).
+
+Emulation switches (test infrastructure for the bf16 throughput mode of the
+HIP path; all off by default, i.e. the reference's fp32 arithmetic):
+``emu_fwd_round`` / ``emu_wgrad_round`` / ``emu_dgrad_round`` on a Conv layer round its matrix
+operands to bfloat16 (round-to-nearest-even, as ``v_cvt_pk_bf16_f32``) before
+the contraction, which then accumulates in the working dtype (run the network
+in float64 to get the exact sum of the rounded products); ``emu_mask`` on an
+activation (or a conv with a fused one) replaces the sign pattern used by the
+backward pass — the tests pass the masks the DEVICE used, so that a
+pre-activation within round-off of zero cannot make the two backward passes
+differ by a whole flipped unit.
 """
 import numpy as np
+
+
+def round_bf16(x):
+    """fp32 -> bfloat16 (round to nearest even) -> back, any float dtype."""
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    out = u.astype(np.uint32).view(np.float32).reshape(a.shape)
+    return out.astype(np.asarray(x).dtype, copy=False)
 
 
 def _tuple(v, n):
@@ -136,13 +156,14 @@ def _act_forward(name, x, alpha=None):
     raise KeyError(f'activation {name!r} not restated in the oracle')
 
 
-def _act_backward(name, y_pre, y, dy, alpha=None):
+def _act_backward(name, y_pre, y, dy, alpha=None, mask=None):
     if name is None or name == 'linear':
         return dy
+    pos = (y_pre > 0) if mask is None else np.asarray(mask, bool)
     if name == 'relu':
-        return dy * (y_pre > 0)
+        return dy * pos
     if name == 'leaky_relu':
-        return dy * np.where(y_pre > 0, 1.0, alpha).astype(dy.dtype)
+        return dy * np.where(pos, 1.0, alpha).astype(dy.dtype)
     if name == 'sigmoid':
         return dy * y * (1 - y)
     if name == 'tanh':
@@ -200,6 +221,8 @@ class ConvND(Layer):
         n = x.shape[0]
         cin = x.shape[-1]
         w = self.kernel.astype(x.dtype, copy=False)
+        if getattr(self, 'emu_fwd_round', False):
+            x, w = round_bf16(x), round_bf16(w)
         y = np.zeros((n * int(np.prod(out_sp)), self.filters), dtype=x.dtype)
         for tap in np.ndindex(*self.kernel_size):
             xs = x[self._tap_slices(tap)]
@@ -220,19 +243,28 @@ class ConvND(Layer):
         return tuple(sl)
 
     def backward(self, dy):
-        dy = _act_backward(self.activation, self._pre, self._y, dy)
+        dy = _act_backward(self.activation, self._pre, self._y, dy,
+                           mask=getattr(self, 'emu_mask', None))
         x = self._xp
         cin = x.shape[-1]
         w = self.kernel.astype(dy.dtype, copy=False)
         dy2 = dy.reshape(-1, self.filters)
+        db = dy2.sum(axis=0)
+        # (device kernels: the weight gradient rounds x and dPre, the data
+        # gradient dPre and w)
+        dyw = dyd = dy2
+        if getattr(self, 'emu_wgrad_round', False):
+            x, dyw = round_bf16(x), round_bf16(dy2)
+        if getattr(self, 'emu_dgrad_round', False):
+            w, dyd = round_bf16(w), round_bf16(dy2)
         dw = np.zeros(self.kernel.shape, dtype=dy.dtype)
         dxp = np.zeros(x.shape, dtype=dy.dtype)
         for tap in np.ndindex(*self.kernel_size):
             sl = self._tap_slices(tap)
             xs = x[sl]
-            dw[tap] = xs.reshape(-1, cin).T @ dy2
-            dxp[sl] += (dy2 @ w[tap].T).reshape(xs.shape)
-        self.grads = [dw, dy2.sum(axis=0)] if self.use_bias else [dw]
+            dw[tap] = xs.reshape(-1, cin).T @ dyw
+            dxp[sl] += (dyd @ w[tap].T).reshape(xs.shape)
+        self.grads = [dw, db] if self.use_bias else [dw]
         sl = [slice(None)]
         for d, (lo, hi) in enumerate(self._pads):
             sl.append(slice(lo, dxp.shape[1 + d] - hi))
@@ -284,6 +316,8 @@ class ConvTransposeND(Layer):
                        for d in range(nd))
         self._x = x
         w = self.kernel.astype(x.dtype, copy=False)
+        if getattr(self, 'emu_fwd_round', False):
+            x, w = round_bf16(x), round_bf16(w)
         y = np.zeros((x.shape[0],) + out_sp + (self.filters,), dtype=x.dtype)
         x2 = x.reshape(-1, x.shape[-1])
         for tap in np.ndindex(*self.kernel_size):
@@ -296,19 +330,25 @@ class ConvTransposeND(Layer):
         return self._y
 
     def backward(self, dy):
-        dy = _act_backward(self.activation, self._pre, self._y, dy)
+        dy = _act_backward(self.activation, self._pre, self._y, dy,
+                           mask=getattr(self, 'emu_mask', None))
         x = self._x
         in_sp = x.shape[1:1 + self.nd]
         w = self.kernel.astype(dy.dtype, copy=False)
         x2 = x.reshape(-1, x.shape[-1])
+        db = dy.reshape(-1, self.filters).sum(axis=0)
+        dyw = dyd = dy
+        if getattr(self, 'emu_wgrad_round', False):
+            x2, dyw = round_bf16(x2), round_bf16(dy)
+        if getattr(self, 'emu_dgrad_round', False):
+            w, dyd = round_bf16(w), round_bf16(dy)
         dw = np.zeros(self.kernel.shape, dtype=dy.dtype)
         dx = np.zeros(x2.shape, dtype=dy.dtype)
         for tap in np.ndindex(*self.kernel_size):
-            dys = dy[self._tap_slices(tap, in_sp)].reshape(-1, self.filters)
-            dw[tap] = dys.T @ x2
-            dx += dys @ w[tap]
-        self.grads = ([dw, dy.reshape(-1, self.filters).sum(axis=0)]
-                      if self.use_bias else [dw])
+            sl = self._tap_slices(tap, in_sp)
+            dw[tap] = dyw[sl].reshape(-1, self.filters).T @ x2
+            dx += dyd[sl].reshape(-1, self.filters) @ w[tap]
+        self.grads = [dw, db] if self.use_bias else [dw]
         return dx.reshape(x.shape)
 
 
@@ -323,7 +363,9 @@ class LeakyReLU(Layer):
         return np.where(x > 0, x, self.alpha * x).astype(x.dtype)
 
     def backward(self, dy):
-        return dy * np.where(self._x > 0, 1.0, self.alpha).astype(dy.dtype)
+        m = getattr(self, 'emu_mask', None)
+        pos = (self._x > 0) if m is None else np.asarray(m, bool)
+        return dy * np.where(pos, 1.0, self.alpha).astype(dy.dtype)
 
 
 class Activation(Layer):
@@ -338,7 +380,8 @@ class Activation(Layer):
         return self._y
 
     def backward(self, dy):
-        return _act_backward(self.activation, self._x, self._y, dy)
+        return _act_backward(self.activation, self._x, self._y, dy,
+                             mask=getattr(self, 'emu_mask', None))
 
 
 def depth_to_space(x, b):
@@ -502,7 +545,10 @@ class Dense(Layer):
         if self.kernel is None:
             self.build(x.shape[-1], dtype=x.dtype)
         self._x = x
-        y = x @ self.kernel.astype(x.dtype, copy=False)
+        w = self.kernel.astype(x.dtype, copy=False)
+        if getattr(self, 'emu_fwd_round', False):
+            x, w = round_bf16(x), round_bf16(w)
+        y = x @ w
         if self.use_bias:
             y = y + self.bias.astype(x.dtype, copy=False)
         self._pre = y
@@ -510,7 +556,8 @@ class Dense(Layer):
         return self._y
 
     def backward(self, dy):
-        dy = _act_backward(self.activation, self._pre, self._y, dy)
+        dy = _act_backward(self.activation, self._pre, self._y, dy,
+                           mask=getattr(self, 'emu_mask', None))
         x2 = self._x.reshape(-1, self._x.shape[-1])
         dy2 = dy.reshape(-1, self.units)
         dw = x2.T @ dy2

@@ -81,6 +81,9 @@ class Network:
             hidden_layers = hidden_layers['hidden_layers']
         self.name = name
         self.layers = []
+        # emulation of bf16 STORAGE in the HIP plan (tests): indices of layers
+        # whose output is rounded to bfloat16 before the next layer sees it
+        self.emu_store_round = set()
         skips = {}
         for spec in expand_repeats(hidden_layers):
             spec = dict(spec)
@@ -162,6 +165,8 @@ class Network:
                                       else exo.get(layer.name))
                 else:
                     x = layer.forward(x)
+                if i in self.emu_store_round:
+                    x = L.round_bf16(x)
             except Exception as e:
                 raise RuntimeError(
                     'Could not run layer #{} "{}" on tensor of shape {}'

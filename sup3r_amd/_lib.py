@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('SUP3R_AMD_LIB') or os.path.join(
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 LOSS_MAE, LOSS_MSE, LOSS_EXP = 0, 1, 2
 BUF_W, BUF_G, BUF_M, BUF_V = 0, 1, 2, 3
-PRECISIONS = {'f32': PREC_F32, 'bf16': PREC_BF16}
+PRECISIONS = {'f32': PREC_F32, 'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
 
 EXPORTS = [
     's3_ctx_create', 's3_ctx_destroy', 's3_last_error', 's3_ctx_sync',
@@ -26,17 +26,19 @@ EXPORTS = [
     's3_plan_create', 's3_plan_destroy', 's3_plan_forward',
     's3_plan_backward', 's3_plan_tensor', 's3_plan_workspace_bytes',
     's3_plan_profile_begin', 's3_plan_profile_end',
-    's3_plan_op_is_mfma', 's3_loss_content', 's3_loss_content_masked', 's3_loss_rel_bce',
+    's3_plan_op_is_mfma', 's3_plan_op_info', 's3_plan_tensor_dtype', 's3_plan_tensor_read',
+    's3_loss_content', 's3_loss_content_masked', 's3_loss_rel_bce',
     's3_lossmap_fwd', 's3_lossmap_bwd', 's3_loss_mmd',
     's3_loss_sliced_wasserstein', 's3_sw_directions', 's3_time_window',
     's3_time_mean', 's3_dft_axis',
     's3_specmap',
-    's3_copy_channels', 's3_affine_channels', 's3_fill',
+    's3_copy_channels', 's3_affine_channels', 's3_fill', 's3_copy_block',
     's3_coarsen', 's3_gaussian_smooth', 's3_chunk_stats',
     's3_host_register', 's3_host_unregister', 's3_d2h_window',
     's3_invert_uv', 's3_clip_channels',
     's3_comm_unique_id', 's3_comm_init', 's3_params_allreduce_grads',
-    's3_allreduce_sum', 's3_version',
+    's3_allreduce_sum', 's3_params_broadcast', 's3_broadcast',
+    's3_comm_destroy', 's3_version',
 ]
 
 
@@ -108,6 +110,9 @@ def lib():
         's3_plan_profile_begin': (i32, [vp, i32]),
         's3_plan_profile_end': (i32, [vp, pf, i32]),
         's3_plan_op_is_mfma': (i32, [vp, i32]),
+        's3_plan_op_info': (i32, [vp, i32, C.POINTER(i32), i32]),
+        's3_plan_tensor_dtype': (i32, [vp, i32]),
+        's3_plan_tensor_read': (i64, [vp, i32, vp, C.c_size_t]),
         's3_loss_content': (i32, [vp, i32, vp, i32, vp, i32, i32, i64, f32,
                                   vp, vp, i32]),
         's3_loss_content_masked': (i32, [vp, i32, vp, i32, vp, i32, vp, i32,
@@ -132,6 +137,7 @@ def lib():
                                    i32]),
         's3_affine_channels': (i32, [vp, vp, vp, i32, i64, pf, pf]),
         's3_fill': (i32, [vp, vp, i64, f32]),
+        's3_copy_block': (i32, [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64]),
         's3_chunk_stats': (i32, [vp, vp, i32, i64, i32, vp]),
         's3_invert_uv': (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp]),
         's3_clip_channels': (i32, [vp, vp, i32, i64, pf, pf]),
@@ -146,6 +152,9 @@ def lib():
         's3_comm_init': (i32, [vp, i32, i32, vp]),
         's3_params_allreduce_grads': (i32, [vp]),
         's3_allreduce_sum': (i32, [vp, vp, i64]),
+        's3_params_broadcast': (i32, [vp, i32, i32]),
+        's3_broadcast': (i32, [vp, vp, i64, i32]),
+        's3_comm_destroy': (None, [vp]),
         's3_version': (C.c_char_p, []),
     }
     for name in EXPORTS:
@@ -154,6 +163,16 @@ def lib():
     _lib = L
     return L
 
+
+# s3_plan_op_info fields / codes (include/sup3r_hip.h)
+OPINFO_FIELDS = ('kind', 'fwd', 'in16', 'out16', 'res16', 'fwd_bf16_ops',
+                 'wgrad', 'dgrad', 'mask_fused_from')
+FWD_KERNELS = ('direct', 'mfma_tile', 'mfma_persist', 'gconv', 'gconv_fewch',
+               'halo32', 'fewpos', 'tail_mfma', 'small')
+WGRAD_KERNELS = ('direct', 'f32_trunk', 'bf16_trunk', 'f32_gen', 'bf16_gen',
+                 'bf16_2d', 'c2', 'tail', 'fewpos')
+DGRAD_KERNELS = ('direct', 'mfma_frame', 'mfma_valid', 'mfma_chunked',
+                 'fewch_frame', 's2', 'c2', 'gconv', 'fewpos')
 
 TC_METHODS = {'subsample': 0, 'average': 1, 'total': 2, 'max': 3, 'min': 4}
 

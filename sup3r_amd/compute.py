@@ -96,8 +96,51 @@ def parse_loss_spec(loss):
     return terms
 
 
+def details_from_scalars(vals, loss_terms, coefs, with_disc, train_gen,
+                         with_advers, weight_gen_advers):
+    """``loss_details`` of ``Sup3rGan.calc_loss`` (base.py:903-911) from the
+    loss-scalar buffer: [0] loss_disc, [1] adversarial term, [4 + 4 i ...] the
+    slots of content term i (value = sum coef * slot)."""
+    details = {}
+    if with_disc:
+        details['loss_disc'] = LossValue(vals[0])
+    if train_gen:
+        content = 0.0
+        for i, (name, kind, w, kw) in enumerate(loss_terms):
+            slot = 4 + SLOTS_PER_TERM * i
+            val = sum(cf * float(vals[slot + j])
+                      for j, cf in enumerate(coefs[i]))
+            details[camel_to_underscore(name)] = LossValue(val)
+            content += w * val
+        advers = float(vals[1]) if with_advers else 0.0
+        details['loss_gen_content'] = LossValue(content)
+        details['loss_gen_advers'] = LossValue(advers)
+        details['loss_gen'] = LossValue(content + weight_gen_advers * advers)
+    return details
+
+
+class LossFuture:
+    """Loss scalars of one ``loss_and_grads`` call that are still on the
+    device.  ``resolve()`` does the one device -> host read (a stream sync) and
+    returns the ``loss_details`` dict; until then the host keeps enqueuing the
+    all-reduce, the Adam step and the next network's work."""
+
+    def __init__(self, scal, recipe, scale=1.0):
+        self._scal, self._recipe, self._scale = scal, recipe, float(scale)
+        self._details = None
+
+    def resolve(self):
+        if self._details is None:
+            vals = self._scal.cpu().numpy().astype(np.float64) * self._scale
+            self._details = self._recipe(vals)
+            self._scal = None
+        return self._details
+
+
 class HipGanCompute:
     """Generator / discriminator pair on one GPU."""
+
+    supports_defer = True
 
     def __init__(self, gen_layers, disc_layers, device=None, precision=None):
         self.dev = device or Device.get()
@@ -107,10 +150,28 @@ class HipGanCompute:
         self._scal = None
 
     # ---------------------------------------------------------------- utils
+    def _zero(self, scal):
+        rc = _lib.lib().s3_fill(self.dev.ctx, self._ptr(scal), scal.numel(),
+                                0.0)
+        _lib.check(rc, self.dev.ctx, 's3_fill')
+        return scal
+
     def _scalars(self):
+        """the shared, zeroed loss-scalar buffer of synchronous calls"""
         if self._scal is None:
             self._scal = self.dev.empty((4 + SLOTS_PER_TERM * MAX_TERMS,))
-        return self._scal
+        return self._zero(self._scal)
+
+    def new_scalars(self):
+        """a private, zeroed loss-scalar buffer (deferred reads outlive the
+        call; the shards of a split mini-batch accumulate into one)"""
+        return self._zero(self.dev.empty((4 + SLOTS_PER_TERM * MAX_TERMS,)))
+
+    def allreduce_scalars(self, scal):
+        """SUM of a loss-scalar buffer over the data-parallel ranks"""
+        rc = _lib.lib().s3_allreduce_sum(self.dev.ctx, self._ptr(scal),
+                                         scal.numel())
+        _lib.check(rc, self.dev.ctx, 's3_allreduce_sum')
 
     def _ptr(self, t, offset=0):
         return C.c_void_p(t.data_ptr() + 4 * offset)
@@ -151,13 +212,18 @@ class HipGanCompute:
     def loss_and_grads(self, low_res, hi_res_true, loss_terms,
                        weight_gen_advers=0.001, train_gen=True,
                        train_disc=False, compute_disc=False, exo_names=(),
-                       backward=True, hi_res_gen=None, mask=None):
+                       backward=True, hi_res_gen=None, mask=None,
+                       accumulate_wgrad=False, scal=None, defer=False):
         """One ``_get_hr_exo_and_loss`` + ``tape.gradient``.
 
         ``backward=False`` evaluates ``calc_loss`` only (validation).  When
         ``hi_res_gen`` is given (public ``calc_loss(hi_res_true, hi_res_gen)``)
         the generator forward is skipped.  Gradients of the trained network are
-        left in its device gradient buffer.  Returns (loss, details, hr_gen).
+        left in its device gradient buffer (``accumulate_wgrad``: ADDED to what
+        is there — the next shard of a split mini-batch, abstract.py:785-805).
+        ``scal``: device scalar buffer to accumulate the loss values into (not
+        zeroed here); ``defer``: return a ``LossFuture`` in place of the
+        details and do not synchronise.  Returns (loss, details, hr_gen).
         """
         L = _lib.lib()
         dev = self.dev
@@ -197,9 +263,8 @@ class HipGanCompute:
             # (conditional.py:221-241)
             mask_d = dev.to_device(mask)
             c_used = c_true
-        scal = self._scalars()
-        L.s3_fill(dev.ctx, self._ptr(scal), scal.numel(), 0.0)
-        details = {}
+        if scal is None:
+            scal = self.new_scalars() if defer else self._scalars()
         need_disc = self.disc is not None
         dph_t = dph_g = None
         if need_disc:
@@ -272,29 +337,25 @@ class HipGanCompute:
                     self._copy_channels(d_gen_full, 0, d_hr_gen, 0, c_gen)
                 else:
                     d_hr_gen = d_gen_full
-                gph.backward(d_hr_gen, need_wgrad=True)
+                gph.backward(d_hr_gen, need_wgrad=True,
+                             accumulate_wgrad=accumulate_wgrad)
             loss_key = 'loss_gen'
         elif train_disc:
             if disc_train:
-                dph_t.backward(g_t, need_wgrad=True, accumulate_wgrad=False)
+                dph_t.backward(g_t, need_wgrad=True,
+                               accumulate_wgrad=accumulate_wgrad)
                 dph_g.backward(g_g, need_wgrad=True, accumulate_wgrad=True)
             loss_key = 'loss_disc'
-        vals = scal.cpu().numpy()          # one sync per mini-batch
-        if need_disc and (compute_disc or train_disc):
-            details['loss_disc'] = LossValue(vals[0])
-        if train_gen:
-            content = 0.0
-            for i, (name, kind, w, kw) in enumerate(loss_terms):
-                slot = 4 + SLOTS_PER_TERM * i
-                val = sum(cf * float(vals[slot + j])
-                          for j, cf in enumerate(term_coefs[i]))
-                details[camel_to_underscore(name)] = LossValue(val)
-                content += w * val
-            advers = float(vals[1]) if need_disc else 0.0
-            details['loss_gen_content'] = LossValue(content)
-            details['loss_gen_advers'] = LossValue(advers)
-            details['loss_gen'] = LossValue(
-                content + weight_gen_advers * advers)
+        with_disc = need_disc and (compute_disc or train_disc)
+        coefs = term_coefs if train_gen else None
+
+        def recipe(vals):
+            return details_from_scalars(vals, loss_terms, coefs, with_disc,
+                                        train_gen, need_disc,
+                                        weight_gen_advers)
+        if defer:
+            return None, LossFuture(scal, recipe), hr_gen
+        details = recipe(scal.cpu().numpy())   # one sync per mini-batch
         loss = details.get(loss_key) if loss_key else None
         return loss, details, hr_gen
 
@@ -325,16 +386,20 @@ class HipGanCompute:
             _lib.check(rc, dev.ctx, 's3_lossmap_fwd')
             return out
 
-        def metric(m, fa, fb, cf, cu, npos, weight, sl, off=0):
-            """loss value -> scal[sl]; returns d loss / d fa (or None)"""
-            d_fa = None
-            if d_gen is not None:
-                d_fa = dev.empty((npos * cf,))
-                L.s3_fill(dev.ctx, self._ptr(d_fa), npos * cf, 0.0)
+        def metric(m, fa, fb, cf, cu, npos, weight, sl, off=0, d_out=None):
+            """loss value -> scal[sl]; returns d loss / d fa (or None),
+            written at ``off`` into ``d_out`` when the caller provides it"""
+            d_fa, d_off = d_out, off
+            if d_gen is None:
+                d_fa = None
+            elif d_fa is None:
+                d_fa, d_off = dev.empty((npos * cf,)), 0
+            if d_fa is not None:
+                L.s3_fill(dev.ctx, self._ptr(d_fa, d_off), npos * cf, 0.0)
             rc = L.s3_loss_content(
                 dev.ctx, m, self._ptr(fa, off), cf, self._ptr(fb, off), cf, cu,
                 npos, weight, self._ptr(scal, sl),
-                self._ptr(d_fa) if d_fa is not None else None, 0)
+                self._ptr(d_fa, d_off) if d_fa is not None else None, 0)
             _lib.check(rc, dev.ctx, 's3_loss_content')
             return d_fa
 
@@ -354,11 +419,13 @@ class HipGanCompute:
             work = dev.empty((2 * ne + slab,))
             fa = fmap(code, gen, (2 * ne,), work)
             fb = fmap(code, true, (2 * ne,), work)
-            g = [metric(_lib.LOSS_MAE, fa, fb, c_used, c_used, ne // c_used,
-                        0.5 * weight, sl + q, off=q * ne) for q in range(2)]
+            # both gradients side by side in one buffer: [d min | d max]
+            g = dev.empty((2 * ne,)) if d_gen is not None else None
+            for q in range(2):
+                metric(_lib.LOSS_MAE, fa, fb, c_used, c_used, ne // c_used,
+                       0.5 * weight, sl + q, off=q * ne, d_out=g)
             if d_gen is not None:
-                import torch
-                fbwd(code, fa, torch.cat(g), work=work)
+                fbwd(code, fa, g, work=work)
             return [0.5, 0.5]
 
         if kind in ('deriv_s', 'deriv_t'):
@@ -513,3 +580,11 @@ class HipGanCompute:
     def allreduce_grads(self, which):
         net = self.gen if which == 'gen' else self.disc
         net.allreduce_grads()
+
+    def broadcast_state(self, root=0):
+        """Every rank starts from rank ``root``'s weights and Adam slots (the
+        reference's towers read one set of variables, abstract.py:827-841)."""
+        for net in (self.gen, self.disc):
+            if net is not None and net.built:
+                for which in (_lib.BUF_W, _lib.BUF_M, _lib.BUF_V):
+                    net.broadcast(which, root)

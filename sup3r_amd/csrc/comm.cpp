@@ -19,6 +19,7 @@ typedef struct { char internal[128]; } ncclUniqueId_t;
 typedef int (*fn_get_uid)(ncclUniqueId_t*);
 typedef int (*fn_init_rank)(void**, int, ncclUniqueId_t, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_bcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*fn_errstr)(int);
 typedef int (*fn_destroy)(void*);
 
@@ -27,6 +28,7 @@ struct Rccl {
   fn_get_uid get_uid = nullptr;
   fn_init_rank init_rank = nullptr;
   fn_allreduce allreduce = nullptr;
+  fn_bcast bcast = nullptr;
   fn_errstr errstr = nullptr;
   fn_destroy destroy = nullptr;
   bool load(std::string& err) {
@@ -40,6 +42,7 @@ struct Rccl {
     get_uid = (fn_get_uid)dlsym(h, "ncclGetUniqueId");
     init_rank = (fn_init_rank)dlsym(h, "ncclCommInitRank");
     allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
+    bcast = (fn_bcast)dlsym(h, "ncclBroadcast");
     errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
     destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
     if (!get_uid || !init_rank || !allreduce) { err = "librccl.so lacks nccl symbols"; return false; }
@@ -86,6 +89,37 @@ extern "C" int s3_allreduce_sum(s3_ctx* ctx, float* buf, int64_t n) {
     return S3_ERCCL;
   }
   return S3_OK;
+}
+
+extern "C" int s3_broadcast(s3_ctx* ctx, float* buf, int64_t n, int root) {
+  if (!ctx || !buf || n < 0) return S3_EINVAL;
+  if (ctx->nranks <= 1 && !ctx->comm) return S3_OK;
+  if (!ctx->comm) S3_FAIL(ctx, S3_ESTATE, "broadcast before s3_comm_init");
+  if (!g_rccl.bcast) S3_FAIL(ctx, S3_ERCCL, "librccl.so lacks ncclBroadcast");
+  if (root < 0 || root >= ctx->nranks) return S3_EINVAL;
+  int rc = g_rccl.bcast(buf, buf, (size_t)n, kNcclFloat32, root, ctx->comm, ctx->stream);
+  if (rc != 0) {
+    ctx->err = std::string("ncclBroadcast: ") + (g_rccl.errstr ? g_rccl.errstr(rc) : "error");
+    return S3_ERCCL;
+  }
+  return S3_OK;
+}
+
+extern "C" void s3_comm_destroy(s3_ctx* ctx) {
+  if (!ctx || !ctx->comm) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (g_rccl.destroy) g_rccl.destroy(ctx->comm);
+  ctx->comm = nullptr;
+  ctx->rank = 0;
+  ctx->nranks = 1;
+}
+
+extern "C" int s3_params_broadcast(s3_params* p, int which, int root) {
+  if (!p || which < 0 || which > 3) return S3_EINVAL;
+  s3_ctx* ctx = reinterpret_cast<s3_params_view*>(p)->ctx;
+  int rc = s3_broadcast(ctx, (float*)s3_params_dptr(p, which, -1), s3_params_total(p), root);
+  if (rc == S3_OK && which == S3_BUF_W) s3_params_touch(p);
+  return rc;
 }
 
 extern "C" int s3_params_allreduce_grads(s3_params* p) {

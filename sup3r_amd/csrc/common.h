@@ -251,3 +251,4 @@ int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
 int launch_fill(s3_ctx* ctx, float* p, int64_t n, float v);
 int launch_mean_abs(s3_ctx* ctx, const float* p, int64_t n, float* out_dev);
 int ensure_scratch(s3_ctx* ctx, size_t bytes);
+void s3_params_touch(s3_params* p);   // weights changed behind the store's back: bump the version

@@ -27,6 +27,16 @@
 //                  fp32 or bf16 in HBM (IN16 / OUT16): inference plans keep
 //                  the 64-channel trunk in bf16, which halves the halo and
 //                  epilogue bytes and removes the convert from the staging.
+//   S3_PREC_BF16X3 : fp32 activations and weights split on the fly into bf16
+//                  pairs (hi = bf16(v), lo = bf16(v - hi)); every product is
+//                  hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate —
+//                  the dropped lo*lo term and the split residue are ~2^-16
+//                  relative, i.e. fp32-class results at a third of the bf16
+//                  rate (5x the fp32-MFMA rate).  A 128-B LDS cell holds 32
+//                  channels as [hi x 32 | lo x 32], so the tile, the swizzles
+//                  and the read addresses are those of the bf16 mode; the
+//                  K = 64 channels are contracted in two passes of 32 with the
+//                  halo re-staged in between (accumulators stay in registers).
 //   S3_PREC_F32  : v_mfma_f32_16x16x4_f32 (exact fp32, == fmaf chain): parity
 //                  mode.  Halo rows padded to 66 dwords, filter rows to 80, so
 //                  the per-lane ds_read_b32 of the (row, k) fragments are
@@ -107,6 +117,32 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w,
   }
 }
 
+// BF16X3: canonical fp32 w[tap][ci][co] -> slabs [ct][pass 2][tap][co 64][128 B],
+// a row = channels 32 pass .. 32 pass + 31 as [hi x 32 | lo x 32], 16-B chunks
+// pre-swizzled like the bf16 slabs
+__global__ void pack_bf16x3_kernel(const float* __restrict__ w,
+                                   unsigned short* __restrict__ out, int taps,
+                                   int cout, int n_ct) {
+  const int64_t total = (int64_t)n_ct * 2 * taps * CT * 32;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx;
+    const int cl = (int)(r % 32); r /= 32;
+    const int row = (int)(r % CT); r /= CT;
+    const int tap = (int)(r % taps); r /= taps;
+    const int pass = (int)(r % 2); r /= 2;
+    const int ct = (int)r;
+    const int co = ct * CT + row, ci = pass * 32 + cl;
+    const float v = co < cout ? w[((int64_t)tap * CIN + ci) * cout + co] : 0.f;
+    const unsigned short hi = f2bf(v);
+    const unsigned short lo = f2bf(v - __uint_as_float((unsigned)hi << 16));
+    const int sw = (row >> 1) & 7;
+    unsigned short* o = out + ((((int64_t)ct * 2 + pass) * taps + tap) * CT + row) * CIN;
+    o[(((cl >> 3)) ^ sw) * 8 + (cl & 7)] = hi;
+    o[((4 + (cl >> 3)) ^ sw) * 8 + (cl & 7)] = lo;
+  }
+}
+
 template <int PREC, int TS0, int TS1, int NW, bool IN16, bool OUT16>
 __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
     const void* __restrict__ xv, const void* __restrict__ wpk,
@@ -117,6 +153,8 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   constexpr int H1 = T::H1, HP = T::HP, MFW = T::MFW, NT = T::NT;
   static_assert(MFW >= 1 && MFW * NW == TS0 * TS1, "tile / wave split");
   static_assert(PREC == S3_PREC_BF16 || (!IN16 && !OUT16), "bf16 I/O needs bf16 MFMA");
+  constexpr bool X3 = PREC == S3_PREC_BF16X3;
+  constexpr bool BF = PREC == S3_PREC_BF16 || X3;   // bf16 MFMA, 128-B LDS cells
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -142,19 +180,19 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   const int KK1 = g.k[1], KK2 = g.k[2];
 
   char* halo = smem;
-  char* bslab = smem + (PREC == S3_PREC_BF16 ? (size_t)HP * 128
-                                             : (size_t)HP * F32_ROW * 4);
-  constexpr int BSLAB_BYTES = PREC == S3_PREC_BF16 ? 8192 : CIN * F32_BROW * 4;
+  char* bslab = smem + (BF ? (size_t)HP * 128 : (size_t)HP * F32_ROW * 4);
+  constexpr int BSLAB_BYTES = BF ? 8192 : CIN * F32_BROW * 4;
 
   // ---- B slab register prefetch helpers (one slab = 512 x 16 B in bf16,
   // 1024 x 16 B in f32; NT threads share it)
-  constexpr int SLAB16 = PREC == S3_PREC_BF16 ? 512 : 1024;  // 16-B units
+  constexpr int SLAB16 = BF ? 512 : 1024;  // 16-B units
   constexpr int NBQ = SLAB16 >= NT ? SLAB16 / NT : 1;
   uint4 breg[NBQ];
+  // (BF16X3: `tap` runs over 2 x 27 slabs, pass-major)
   auto b_issue = [&](int tap) {
-    if (PREC == S3_PREC_BF16) {
+    if (BF) {
       const uint4* src = reinterpret_cast<const uint4*>(
-          (const char*)wpk + ((size_t)ct * taps + tap) * 8192);
+          (const char*)wpk + ((size_t)ct * (X3 ? 2 * taps : taps) + tap) * 8192);
 #pragma unroll
       for (int q = 0; q < NBQ; ++q)
         if (tid + q * NT < SLAB16) breg[q] = src[tid + q * NT];
@@ -173,7 +211,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   };
   auto b_commit = [&](int buf) {
     char* dst = bslab + buf * BSLAB_BYTES;
-    if (PREC == S3_PREC_BF16) {
+    if (BF) {
 #pragma unroll
       for (int q = 0; q < NBQ; ++q)
         if (tid + q * NT < SLAB16) reinterpret_cast<uint4*>(dst)[tid + q * NT] = breg[q];
@@ -192,8 +230,10 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   // ---- stage the input halo (boundary handled here, once per element).
   // UN items per thread per trip: all global loads of a trip are issued before
   // the first convert/ds_write so many 16-B loads per lane are in flight.
-  {
-    constexpr int CHUNKS = PREC == S3_PREC_BF16 ? 8 : 16;  // per position
+  // BF16X3: `pass` selects the 32-channel half; an item is 8 fp32 channels that
+  // become one hi and one lo 16-B chunk of the cell.
+  auto stage_halo = [&](int pass) __attribute__((always_inline)) {
+    constexpr int CHUNKS = X3 ? 4 : (BF ? 8 : 16);  // items per position
     constexpr int ITEMS = HP * CHUNKS;
     constexpr int UN = IN16 ? (ITEMS + NT - 1) / NT : 4;   // bf16 in: one trip
     for (int base = tid; base < ((dbg & 1) ? 0 : ITEMS); base += NT * UN) {
@@ -225,7 +265,11 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
             if (IN16) {
               va[u] = *reinterpret_cast<const uint4*>(
                   reinterpret_cast<const unsigned short*>(xv) + pos * CIN + ch * 8);
-            } else if (PREC == S3_PREC_BF16) {
+            } else if (X3) {
+              const float* src = reinterpret_cast<const float*>(xv) + pos * CIN + pass * 32 + ch * 8;
+              va[u] = *reinterpret_cast<const uint4*>(src);
+              vb[u] = *reinterpret_cast<const uint4*>(src + 4);
+            } else if (BF) {
               // (channel slice of a wider tensor: chunks past in_cvalid stay zero)
               const int cstr = g.in_cstride ? g.in_cstride : CIN;
               if (!g.in_cstride || ch * 8 < g.in_cvalid) {
@@ -245,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
         const int item = base + u * NT;
         if (item < ITEMS) {
           const int hp = item / CHUNKS, ch = item % CHUNKS;
-          if (PREC == S3_PREC_BF16) {
+          if (BF) {
             uint4 o;
             if (IN16) {
               o = va[u];
@@ -255,6 +299,16 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
               o.y = pack_bf16(__uint_as_float(a.z), __uint_as_float(a.w));
               o.z = pack_bf16(__uint_as_float(b.x), __uint_as_float(b.y));
               o.w = pack_bf16(__uint_as_float(b.z), __uint_as_float(b.w));
+              if (X3) {
+                // lo = bf16(v - hi): the residue of the first rounding
+                uint4 l;
+                l.x = pack_bf16(__uint_as_float(a.x) - bf_lo(o.x), __uint_as_float(a.y) - bf_hi(o.x));
+                l.y = pack_bf16(__uint_as_float(a.z) - bf_lo(o.y), __uint_as_float(a.w) - bf_hi(o.y));
+                l.z = pack_bf16(__uint_as_float(b.x) - bf_lo(o.z), __uint_as_float(b.y) - bf_hi(o.z));
+                l.w = pack_bf16(__uint_as_float(b.z) - bf_lo(o.w), __uint_as_float(b.w) - bf_hi(o.w));
+                const int slot_lo = (4 + ch) ^ ((hp % H2) & 7);
+                *reinterpret_cast<uint4*>(halo + (size_t)hp * 128 + slot_lo * 16) = l;
+              }
             }
             // swizzle keyed on the t coordinate of the halo cell so that the
             // read-side key depends on the tap's t-shift only (3 variants)
@@ -269,7 +323,8 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
         }
       }
     }
-  }
+  };
+  stage_halo(0);
   b_commit(0);
   __syncthreads();
 
@@ -297,8 +352,10 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
     return ((((size_t)n * g.O[0] * e_b + o0 * e_b + e_blk / e_b) * (g.O[1] * e_b) +
              o1 * e_b + e_blk % e_b) * g.O[2] + o2) * e_cpo + e_cc;
   };
-  uint4 rres[NIT];
-  if (resv) {
+  // (BF16X3 is register-bound: its residual rows are read in the epilogue)
+  constexpr bool RES_PRE = !X3;
+  uint4 rres[RES_PRE ? NIT : 1];
+  if (resv && RES_PRE) {
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
       bool ok;
@@ -328,12 +385,13 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) acc[m][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if constexpr (PREC == S3_PREC_BF16) {
+  if constexpr (BF) {
     // All LDS read addresses are (per-lane register) + (compile-time
     // immediate): the 27-tap loop below is nothing but ds_read_b128 + MFMA
     // (+ the filter prefetch).  a_addr[c][ks]: byte offset of this lane's
     // 16-B A chunk in the halo row of M-fragment 0, tap t-shift c, k-step ks;
     // b_addr[nf][ks]: the same for the B fragment rows of the filter slab.
+    // BF16X3: "k-step" 0 is the hi half of the 128-B cell / row, 1 the lo half.
     static_assert(MFW <= TS1 ? (TS1 % MFW == 0) : (MFW % TS1 == 0), "tile/wave split");
     const int mf0 = wave * MFW;
     const int row0 = (mf0 / TS1) * H1 + (mf0 % TS1);
@@ -352,31 +410,68 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
       for (int ks = 0; ks < 2; ++ks)
         b_addr[nf][ks] = (unsigned)(HP * 128 + row * 128 + (((ks * 4 + kq) ^ ((row >> 1) & 7)) << 4));
     }
+#pragma unroll 1
+    for (int pass = 0; pass < (X3 ? 2 : 1); ++pass) {
+      if (X3 && pass) {
+        // every wave is past its last read of the first channel half (barrier
+        // of tap 26); the slab of step 27 is already committed
+        stage_halo(1);
+        __syncthreads();
+      }
 #pragma unroll
-    for (int ta = 0; ta < ((dbg & 4) ? 0 : 3); ++ta) {
+      for (int ta = 0; ta < ((dbg & 4) ? 0 : 3); ++ta) {
 #pragma unroll
-      for (int tb = 0; tb < 3; ++tb) {
+        for (int tb = 0; tb < 3; ++tb) {
 #pragma unroll
-        for (int tc = 0; tc < 3; ++tc) {
-          const int tap = (ta * 3 + tb) * 3 + tc;
-          if (tap + 1 < 27) b_issue(tap + 1);
+          for (int tc = 0; tc < 3; ++tc) {
+            const int tap = (ta * 3 + tb) * 3 + tc;
+            // slab step: 27 = odd, so the ring slot of step 27 pass + tap is
+            // (tap + pass) & 1
+            const int slot = X3 ? ((tap + pass) & 1) : (tap & 1);
+            if (X3 ? (pass == 0 || tap + 1 < 27) : (tap + 1 < 27)) b_issue(pass * 27 + tap + 1);
+            if constexpr (X3) {
+              bf16x8 bh[4], bl[4];
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 bfr[4];
+              for (int nf = 0; nf < 4; ++nf) {
+                bh[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][0] + slot * 8192);
+                bl[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][1] + slot * 8192);
+              }
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-              bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][ks] + (tap & 1) * 8192);
+              for (int m = 0; m < MFW; ++m) {
+                const int roff = ((m / TS1) * H1 + (m % TS1) + ta * H1 + tb) * H2 * 128;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(smem + a_addr[tc][0] + roff);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(smem + a_addr[tc][1] + roff);
+                // small terms first
 #pragma unroll
-            for (int m = 0; m < MFW; ++m) {
-              const int roff = ((m / TS1) * H1 + (m % TS1) + ta * H1 + tb) * H2 * 128;
-              const bf16x8 afr = *reinterpret_cast<const bf16x8*>(smem + a_addr[tc][ks] + roff);
+                for (int nf = 0; nf < 4; ++nf)
+                  acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nf], acc[m][nf], 0, 0, 0);
 #pragma unroll
-              for (int nf = 0; nf < 4; ++nf)
-                acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nf], acc[m][nf], 0, 0, 0);
+                for (int nf = 0; nf < 4; ++nf)
+                  acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nf], acc[m][nf], 0, 0, 0);
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+                  acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nf], acc[m][nf], 0, 0, 0);
+              }
+            } else {
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 bfr[4];
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+                  bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][ks] + slot * 8192);
+#pragma unroll
+                for (int m = 0; m < MFW; ++m) {
+                  const int roff = ((m / TS1) * H1 + (m % TS1) + ta * H1 + tb) * H2 * 128;
+                  const bf16x8 afr = *reinterpret_cast<const bf16x8*>(smem + a_addr[tc][ks] + roff);
+#pragma unroll
+                  for (int nf = 0; nf < 4; ++nf)
+                    acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nf], acc[m][nf], 0, 0, 0);
+                }
+              }
             }
+            if (X3 ? (pass == 0 || tap + 1 < 27) : (tap + 1 < 27)) b_commit(slot ^ 1);
+            __syncthreads();
           }
-          if (tap + 1 < 27) b_commit((tap + 1) & 1);
-          __syncthreads();
         }
       }
     }
@@ -451,7 +546,8 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
 #pragma unroll
       for (int q = 0; q < CPT; ++q) v[q] = act_f(v[q] + bv[q], act, alpha);
       if (resv) {
-        const uint4 r = rres[j];
+        uint4 r = rres[RES_PRE ? j : 0];
+        if (!RES_PRE) r = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(resv) + dst);
         if (res16) {
           v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
           if (CPT == 8) {
@@ -488,7 +584,7 @@ template <int PREC, int TS0, int TS1, int NW, bool IN16, bool OUT16>
 int launch_io(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* wpk,
               const float* bias, const void* res, void* y, int res16) {
   using T = Tile<TS0, TS1, NW>;
-  const size_t lds = PREC == S3_PREC_BF16 ? T::lds_bf16 : T::lds_f32;
+  const size_t lds = PREC == S3_PREC_F32 ? T::lds_f32 : T::lds_bf16;
   auto kern = conv3_mfma_kernel<PREC, TS0, TS1, NW, IN16, OUT16>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -520,7 +616,7 @@ int launch_bf16(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* wpk,
 }  // namespace
 
 bool conv_mfma_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_F32 && precision != S3_PREC_BF16) return false;
+  if (precision != S3_PREC_F32 && precision != S3_PREC_BF16 && precision != S3_PREC_BF16X3) return false;
   if (g.Cin != CIN) return false;
   if (g.Cout % 4 != 0 || g.Cout < 16) return false;
   if (g.k[0] != 3 || g.k[1] != 3 || (g.k[2] != 3 && g.k[2] != 1)) return false;
@@ -649,11 +745,23 @@ size_t conv_mfma_packed_bytes(const ConvGeom& g, int precision) {
     if (conv_mfma_persist_geom_ok(g)) b += conv_mfma_persist_image_bytes(g);
     return b;
   }
+  if (precision == S3_PREC_BF16X3)   // hi | lo images of both channel halves
+    return (size_t)((g.Cout + CT - 1) / CT) * 2 * g.k[0] * g.k[1] * g.k[2] * CT * CIN * 2;
   return 16;  // f32 mode reads the canonical weights directly
 }
 
 int launch_conv_mfma_pack(s3_ctx* ctx, const ConvGeom& g, int precision,
                           const float* w, void* packed) {
+  if (precision == S3_PREC_BF16X3) {
+    const int taps3 = g.k[0] * g.k[1] * g.k[2];
+    const int n_ct3 = (g.Cout + CT - 1) / CT;
+    const int64_t total3 = (int64_t)n_ct3 * 2 * taps3 * CT * 32;
+    int grid3 = (int)((total3 + 255) / 256);
+    if (grid3 > 2048) grid3 = 2048;
+    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(grid3), dim3(256), 0, ctx->stream, w, (unsigned short*)packed, taps3, g.Cout, n_ct3);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   if (precision != S3_PREC_BF16) return S3_OK;
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int n_ct = (g.Cout + CT - 1) / CT;
@@ -697,6 +805,14 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
     if (tile == 6) return launch_bf16<4, 8, 8>(ctx, g, x, packed, bias, res, y, io);
     if (tile == 7) return launch_bf16<6, 6, 12>(ctx, g, x, packed, bias, res, y, io);
     return launch_bf16<4, 4, 4>(ctx, g, x, packed, bias, res, y, io);
+  }
+  if (precision == S3_PREC_BF16X3) {
+    // fp32 activations, split on the fly; the 512-position tile when it fills
+    // the chip, the 128-position one otherwise
+    const int64_t big = (int64_t)g.N * ((g.O[0] + 3) / 4) * ((g.O[1] + 7) / 8) * ((g.O[2] + 15) / 16);
+    if (big >= ctx->num_cu)
+      return launch_io<S3_PREC_BF16X3, 4, 8, 8, false, false>(ctx, g, x, packed, bias, res, y, 0);
+    return launch_io<S3_PREC_BF16X3, 2, 4, 8, false, false>(ctx, g, x, packed, bias, res, y, 0);
   }
   // f32: the filters are read in canonical layout; `packed` is unused
   return launch_io<S3_PREC_F32, 2, 4, 4, false, false>(ctx, g, x, packed, bias, res, y, 0);

@@ -953,6 +953,31 @@ extern "C" int s3_affine_channels(s3_ctx* ctx, const float* src, float* dst,
   return S3_OK;
 }
 
+// strided (d0, d1, row) block copy, fp32, device -> device: the chunk windows
+// cut out of the resident lo-res domain and the halo crop of the hi-res output
+__global__ void copy_block_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                  int64_t d1, int64_t row, int64_t ss0, int64_t ss1,
+                                  int64_t ds0, int64_t ds1, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i % row, q = i / row;
+    const int64_t b = q % d1, a = q / d1;
+    dst[a * ds0 + b * ds1 + r] = src[a * ss0 + b * ss1 + r];
+  }
+}
+
+extern "C" int s3_copy_block(s3_ctx* ctx, const float* src, float* dst, int64_t d0, int64_t d1,
+                             int64_t row_elems, int64_t src_stride0, int64_t src_stride1,
+                             int64_t dst_stride0, int64_t dst_stride1) {
+  if (!ctx || !src || !dst) return S3_EINVAL;
+  if (d0 < 1 || d1 < 1 || row_elems < 1) S3_FAIL(ctx, S3_EINVAL, "copy_block: empty block");
+  const int64_t total = d0 * d1 * row_elems;
+  hipLaunchKernelGGL(copy_block_kernel, dim3(grid_for(total, ctx->num_cu)), dim3(kBlock), 0, ctx->stream,
+                     src, dst, d1, row_elems, src_stride0, src_stride1, dst_stride0, dst_stride1, total);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 extern "C" int s3_chunk_stats(s3_ctx* ctx, const float* x, int n_chunks,
                               int64_t pos_per_chunk, int c, float* partial) {
   if (!ctx) return S3_EINVAL;

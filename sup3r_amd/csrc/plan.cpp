@@ -255,6 +255,8 @@ extern "C" void* s3_params_dptr(s3_params* p, int which, int idx) {
   return p->buf[which] + p->p[idx].offset;
 }
 
+void s3_params_touch(s3_params* p) { if (p) p->version++; }
+
 extern "C" int s3_params_zero_grad(s3_params* p) {
   if (!p) return S3_EINVAL;
   s3_ctx* ctx = p->ctx;
@@ -680,7 +682,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
           rc = plan_alloc(pl, &o.dgc_wbf[k], conv_mfma_packed_bytes(o.dg, precision));
         continue;
       }
-      if (!rc && precision == S3_PREC_BF16)
+      if (!rc && precision != S3_PREC_F32)
         rc = plan_alloc(pl, &o.dg_wbf, o.dgrad_fewch ? conv_gconv_packed_bytes(o.dg, 0)
                                                      : conv_mfma_packed_bytes(o.dg, precision));
     }
@@ -789,7 +791,7 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
           if (rc) return rc;
           o.packed_version = P->version;
         }
-        const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.packed : (const void*)w;
+        const void* wp = pl->precision != S3_PREC_F32 ? (const void*)o.packed : (const void*)w;
         return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out), o.io);
       }
       if (o.halo32 && !res) {
@@ -1003,6 +1005,84 @@ extern "C" int s3_plan_op_is_mfma(const s3_plan* pl, int i) {
   return 1;
 }
 
+extern "C" int s3_plan_tensor_dtype(const s3_plan* pl, int32_t id) {
+  if (!pl || id < 0 || id >= (int)pl->t.size()) return S3_EINVAL;
+  int r = id;
+  while (pl->t[r].alias_root >= 0) r = pl->t[r].alias_root;
+  return pl->t[r].dtype;
+}
+
+extern "C" int64_t s3_plan_tensor_read(s3_plan* pl, int32_t id, void* host, size_t cap) {
+  if (!pl || !host || id < 0 || id >= (int)pl->t.size()) return S3_EINVAL;
+  s3_ctx* ctx = pl->ctx;
+  const TensorRec& t = pl->t[root_of(pl, id)];
+  if (!t.ptr) S3_FAIL(ctx, S3_ESTATE, "tensor_read: tensor has no buffer yet");
+  const size_t bytes = (size_t)pl->t[id].numel * (t.dtype ? 2 : 4);
+  if (bytes > cap) S3_FAIL(ctx, S3_EINVAL, "tensor_read: host buffer too small");
+  S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  S3_HIP(ctx, hipMemcpy(host, t.ptr, bytes, hipMemcpyDeviceToHost));
+  return (int64_t)bytes;
+}
+
+extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) {
+  if (!pl || !out || i < 0 || i >= (int)pl->ops.size()) return S3_EINVAL;
+  const OpRec& o = pl->ops[i];
+  int32_t v[S3_OPINFO_COUNT] = {0};
+  v[S3_OPINFO_KIND] = o.d.kind;
+  if (o.d.kind == S3_OP_CONV) {
+    const bool res = o.d.res >= 0;
+    const bool bfp = pl->precision == S3_PREC_BF16;
+    int fwd = S3_FWD_DIRECT;
+    // mirrors run_op_forward / launch_conv_generic_fwd
+    if (o.mfma) {
+      fwd = bfp && conv_mfma_persist_supported(pl->ctx, o.cg, o.io, res) ? S3_FWD_MFMA_PERSIST : S3_FWD_MFMA_TILE;
+    } else if (o.halo32 && !res) {
+      fwd = S3_FWD_HALO32;
+    } else if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
+               (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
+      fwd = o.cg.Cin <= 4 ? S3_FWD_GCONV_FEWCH : S3_FWD_GCONV;
+    } else if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16) {
+      fwd = S3_FWD_FEWPOS;
+    } else if (o.io.in_bf16 && !o.io.out_bf16 && !res && conv_tail_mfma_supported(o.cg) &&
+               !getenv("SUP3R_AMD_NO_TAIL_MFMA")) {
+      fwd = S3_FWD_TAIL_MFMA;
+    } else if (!o.io.out_bf16 && !res && conv_small_supported(o.cg, o.io.in_bf16)) {
+      fwd = S3_FWD_SMALL;
+    }
+    v[S3_OPINFO_FWD] = fwd;
+    v[S3_OPINFO_IN16] = o.io.in_bf16; v[S3_OPINFO_OUT16] = o.io.out_bf16; v[S3_OPINFO_RES16] = o.io.res_bf16;
+    // operands rounded to bf16 by the forward kernel
+    v[S3_OPINFO_FWD_BF16_OPS] = (pl->precision == S3_PREC_BF16 &&
+                                 (fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 ||
+                                  fwd == S3_FWD_GCONV || fwd == S3_FWD_GCONV_FEWCH || fwd == S3_FWD_TAIL_MFMA)) ? 1 : 0;
+    if (pl->training) {
+      int wg = S3_WGRAD_DIRECT;
+      if (o.fewpos) wg = S3_WGRAD_FEWPOS;
+      else if (o.wgrad_tail) wg = S3_WGRAD_TAIL;
+      else if (o.wgrad_c2) wg = S3_WGRAD_C2;
+      else if (o.wgrad_bf16_2d) wg = S3_WGRAD_BF16_2D;
+      else if (o.wgrad_bf16_gen) wg = S3_WGRAD_BF16_GEN;
+      else if (o.wgrad_gen) wg = S3_WGRAD_F32_GEN;
+      else if (o.wgrad_bf16) wg = S3_WGRAD_BF16_TRUNK;
+      else if (o.wgrad_mfma) wg = S3_WGRAD_F32_TRUNK;
+      v[S3_OPINFO_WGRAD] = wg;
+      int dg = S3_DGRAD_DIRECT;
+      if (o.dgrad_chunked) dg = S3_DGRAD_MFMA_CHUNKED;
+      else if (o.dgrad_fewch) dg = S3_DGRAD_FEWCH_FRAME;
+      else if (o.dgrad_valid) dg = S3_DGRAD_MFMA_VALID;
+      else if (o.dgrad_mfma) dg = S3_DGRAD_MFMA_FRAME;
+      else if (o.dgrad_s2) dg = S3_DGRAD_S2;
+      else if (o.dgrad_c2) dg = S3_DGRAD_C2;
+      else if (o.gconv_dgrad) dg = S3_DGRAD_GCONV;
+      else if (o.fewpos && o.fp_wt) dg = S3_DGRAD_FEWPOS;
+      v[S3_OPINFO_DGRAD] = dg;
+      v[S3_OPINFO_MASK_FUSED_FROM] = o.mask_prod;
+    }
+  }
+  for (int q = 0; q < cap && q < S3_OPINFO_COUNT; ++q) out[q] = v[q];
+  return S3_OPINFO_COUNT;
+}
+
 // deliver a gradient contribution `src` (numel floats) to tensor `id`.
 // The first contribution that lives in another finished buffer (the gradient
 // of a consumer's output: skip adds, residuals, views) is not copied: the
@@ -1186,12 +1266,12 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               rc = launch_conv_dgrad_pack(ctx, g, W + P->p[d.w].offset, o.dg_w32);
               if (!rc && o.dgrad_fewch)
                 rc = launch_gconv_pack(ctx, o.dg, o.dg_w32, o.dg_wbf, 0);
-              else if (!rc && pl->precision == S3_PREC_BF16)
+              else if (!rc && pl->precision != S3_PREC_F32)
                 rc = launch_conv_mfma_pack(ctx, o.dg, pl->precision, o.dg_w32, o.dg_wbf);
               if (rc) return rc;
               o.dg_version = P->version;
             }
-            const void* wp = pl->precision == S3_PREC_BF16 ? (const void*)o.dg_wbf : (const void*)o.dg_w32;
+            const void* wp = pl->precision != S3_PREC_F32 ? (const void*)o.dg_wbf : (const void*)o.dg_w32;
             if (o.dgrad_fewch)
               rc = launch_gconv_fwd(ctx, o.dg, dpre, o.dg_wbf, nullptr, nullptr, pl->dxp, 0);
             else

@@ -95,6 +95,7 @@ class PlanHandle:
         L = _lib.lib()
         self.net, self.plan = net, plan
         self.dev = net.dev
+        self.precision, self.training = precision, bool(training)
         nt, nops = len(plan.tensors), len(plan.ops)
         tens = (_lib.TensorDesc * nt)()
         for i, sh in enumerate(plan.tensors):
@@ -196,6 +197,40 @@ class PlanHandle:
         """0 = direct/generic, 1 = MFMA halo tile, 2 = persistent MFMA."""
         return int(_lib.lib().s3_plan_op_is_mfma(self.h, i))
 
+    def op_info(self, i):
+        """Kernel selection of op ``i`` (s3_plan_op_info) as a dict with the
+        kernel names of ``_lib.FWD_KERNELS`` / ``WGRAD_KERNELS`` /
+        ``DGRAD_KERNELS``."""
+        n = len(_lib.OPINFO_FIELDS)
+        buf = (C.c_int32 * n)()
+        rc = _lib.lib().s3_plan_op_info(self.h, int(i), buf, n)
+        if rc < 0:
+            _lib.check(rc, self.dev.ctx, 's3_plan_op_info')
+        d = dict(zip(_lib.OPINFO_FIELDS, [int(v) for v in buf]))
+        d['fwd'] = _lib.FWD_KERNELS[d['fwd']]
+        d['wgrad'] = _lib.WGRAD_KERNELS[d['wgrad']]
+        d['dgrad'] = _lib.DGRAD_KERNELS[d['dgrad']]
+        return d
+
+    def tensor_is_bf16(self, tensor_id):
+        return int(_lib.lib().s3_plan_tensor_dtype(self.h, int(tensor_id))) == 1
+
+    def tensor(self, tensor_id):
+        """fp32 numpy copy of a plan tensor (training plans keep every
+        activation; bf16-stored tensors are widened exactly)."""
+        shape = self.plan.tensors[tensor_id]
+        n = int(np.prod(shape))
+        bf16 = self.tensor_is_bf16(tensor_id)
+        host = np.empty(n, np.uint16 if bf16 else np.float32)
+        rc = _lib.lib().s3_plan_tensor_read(
+            self.h, int(tensor_id), host.ctypes.data_as(C.c_void_p),
+            host.nbytes)
+        if rc < 0:
+            _lib.check(rc, self.dev.ctx, 's3_plan_tensor_read')
+        if bf16:
+            host = (host.astype(np.uint32) << 16).view(np.float32)
+        return host.reshape(shape)
+
     @property
     def workspace_bytes(self):
         return int(_lib.lib().s3_plan_workspace_bytes(self.h))
@@ -216,6 +251,7 @@ class Network:
         self.param_table = None
         self._plans = {}
         self._pending = None   # keras-layout weights set before build
+        self._from_file = False
         self._seed = None
 
     # -- iteration over layers like ``for layer in model.generator``
@@ -295,8 +331,12 @@ class Network:
 
     @property
     def weights(self):
+        """keras-order weight arrays.  Before the store is built (a network
+        loaded from disk that has not run yet) these are the loaded arrays, so
+        ``load -> save`` round-trips without a forward pass in between."""
         if not self.built:
-            return []
+            return [np.array(a) for a in self._pending] \
+                if self._pending is not None else []
         return self._get(_lib.BUF_W)
 
     @property
@@ -346,6 +386,16 @@ class Network:
         rc = _lib.lib().s3_params_allreduce_grads(self.params)
         _lib.check(rc, self.dev.ctx, 's3_params_allreduce_grads')
 
+    def broadcast(self, which, root=0):
+        rc = _lib.lib().s3_params_broadcast(self.params, int(which), int(root))
+        _lib.check(rc, self.dev.ctx, 's3_params_broadcast')
+        self.clear_graph_state()
+
+    def clear_graph_state(self):
+        """weights changed behind the plans' back (broadcast): nothing to do —
+        the store's version counter makes every plan re-pack its filter
+        images on the next forward"""
+
     # -- convenience: numpy in / numpy out
     def __call__(self, x, exo=None, training=False, precision=None):
         dev = self.dev
@@ -358,6 +408,11 @@ class Network:
     # -- persistence (replaces CustomNetwork.save / .load of the phygnn pkl:
     # same role, own schema — phygnn's pickle format is not available here)
     def save(self, fp):
+        if not self.built and self._pending is None and self._from_file:
+            raise RuntimeError(
+                f'network "{self.name}" was created from a weight file but '
+                'holds no weights; refusing to overwrite a checkpoint with an '
+                'empty one')
         with open(fp, 'wb') as f:
             pickle.dump({'format': 'sup3r_amd.network.v1', 'name': self.name,
                          'hidden_layers': [dict(L.kwargs, **{'class': L.cls})
@@ -375,6 +430,7 @@ class Network:
                 'need phygnn to be converted)')
         net = cls(d['hidden_layers'], name=d['name'], device=device,
                   precision=precision)
+        net._from_file = True
         if d['weights']:
             net._pending = d['weights']
         return net

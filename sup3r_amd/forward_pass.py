@@ -115,12 +115,18 @@ class ForwardPass:
     """Run a generator over the chunks of an in-memory lo-res domain."""
 
     def __init__(self, model, slicer, rank=0, nranks=1, shard='interleave',
-                 output_check=True):
+                 output_check=True, allowed_const=False):
+        """``allowed_const`` (ForwardPassStrategy.allowed_const,
+        strategy.py:186-196): False = a constant output channel fails the
+        chunk, True = any constant is fine, a value / list = only these
+        constants are (0 for night-time clearsky ratio).  ``output_check=False``
+        switches the whole check off."""
         self.model = model
         self.slicer = slicer
         self.rank, self.nranks = rank, nranks
         self.shard = shard
         self.output_check = output_check
+        self.allowed_const = allowed_const
         if model.s_enhance != slicer.s_enhance or \
                 model.t_enhance != slicer.t_enhance:
             raise RuntimeError(
@@ -199,19 +205,36 @@ class ForwardPass:
         return hi_res[0][tuple(hr_crop_slices)]
 
     @staticmethod
-    def _output_check(out_data, features=None, chunk_index=None):
-        """forward_pass.py:384-425: NaNs or a constant output channel mean the
-        chunk failed."""
-        failed = bool(np.isnan(out_data).any())
-        if not failed:
-            for idf in range(out_data.shape[-1]):
-                ch = out_data[..., idf]
-                if ch.size > 1 and np.all(ch == ch.flat[0]):
-                    failed = True
-                    name = features[idf] if features else idf
-                    logger.error('Forward pass output for "%s" is constant on '
-                                 'chunk %s', name, chunk_index)
-        return failed
+    def _const_ok(allowed_const):
+        """-> (skip the check entirely, tuple of permitted constants)"""
+        if allowed_const is True:
+            return True, ()
+        if allowed_const is False or allowed_const is None:
+            return False, ()
+        if isinstance(allowed_const, (list, tuple)):
+            return False, tuple(allowed_const)
+        return False, (allowed_const,)
+
+    @classmethod
+    def _output_check(cls, out_data, features=None, chunk_index=None,
+                      allowed_const=False):
+        """forward_pass.py:384-425: NaNs, or an output channel that is one
+        constant not listed in ``allowed_const``, mean the chunk failed."""
+        skip, allowed = cls._const_ok(allowed_const)
+        if skip:
+            return False
+        if np.isnan(out_data).any():
+            logger.error('chunk %s: NaN in the generated output', chunk_index)
+            return True
+        for idf in range(out_data.shape[-1]):
+            ch = out_data[..., idf]
+            v0 = ch.flat[0]
+            if ch.size > 1 and np.all(ch == v0) and v0 not in allowed:
+                logger.error('chunk %s: output channel "%s" is constant (%s)',
+                             chunk_index, features[idf] if features else idf,
+                             v0)
+                return True
+        return False
 
     # -- execution ---------------------------------------------------------
     def chunk_input(self, domain, chunk_index):
@@ -234,7 +257,8 @@ class ForwardPass:
                                  s_enhance=self.slicer.s_enhance,
                                  t_enhance=self.slicer.t_enhance)
         if self.output_check and self._output_check(
-                out, self.model.hr_out_features, chunk_index):
+                out, self.model.hr_out_features, chunk_index,
+                allowed_const=self.allowed_const):
             raise MemoryError(
                 f'Forward pass output check failed on chunk {chunk_index}')
         return out
@@ -298,6 +322,7 @@ class ForwardPass:
         if model.means is not None:
             padded = np.asarray(model.norm_input(padded), dtype=np.float32)
         dom_d = dev.to_device(padded)
+        n_in = int(dom_d.shape[-1])
         n_out = len(model.hr_out_features)
         if model.means is not None:
             mu, sd = model._stats_for(model.hr_out_features)
@@ -346,8 +371,11 @@ class ForwardPass:
                 st = stats.numpy().reshape(len(cids), 64, n_out, 3)
                 mn, mx = st[..., 0].min(1), st[..., 1].max(1)
                 nn = st[..., 2].sum(1)
+                skip, allowed = self._const_ok(self.allowed_const)
                 for k, idx in enumerate(cids):
-                    bad = nn[k].any() or (mn[k] == mx[k]).any()
+                    const = [v for v, w in zip(mn[k], mx[k]) if v == w]
+                    bad = not skip and (
+                        nn[k].any() or any(v not in allowed for v in const))
                     if self.output_check and bad:
                         raise MemoryError('Forward pass output check failed '
                                           f'on chunk {idx}')
@@ -362,15 +390,22 @@ class ForwardPass:
             for shp, gids in groups.items():
                 for b0 in range(0, len(gids), batch):
                     cids = gids[b0:b0 + batch]
-                    xs = []
-                    for idx in cids:
+                    # the chunks' padded windows, cut out of the resident
+                    # domain into one (chunks, s1, s2, t, f) batch
+                    x = dev.empty((len(cids),) + tuple(shp) + (n_in,))
+                    dd1, dd2 = int(dom_d.shape[1]), int(dom_d.shape[2])
+                    for k, idx in enumerate(cids):
                         c = sl.chunks[idx]
-                        win = tuple(slice(s_.start - lo + p, s_.stop + hi + p)
-                                    for s_, (lo, hi), p in zip(
-                                        c['lr_pad_slice'], c['pad_width'],
-                                        (ps, ps, pt)))
-                        xs.append(dom_d[win])
-                    x = torch.stack(xs).contiguous()
+                        o = [s_.start - lo + p for s_, (lo, hi), p in zip(
+                            c['lr_pad_slice'], c['pad_width'], (ps, ps, pt))]
+                        src = dom_d.data_ptr() + 4 * n_in * (
+                            (o[0] * dd1 + o[1]) * dd2 + o[2])
+                        rc = L.s3_copy_block(
+                            dev.ctx, C.c_void_p(src),
+                            C.c_void_p(x[k].data_ptr()), shp[0], shp[1],
+                            shp[2] * n_in, dd1 * dd2 * n_in, dd2 * n_in,
+                            shp[1] * shp[2] * n_in, shp[2] * n_in)
+                        _lib.check(rc, dev.ctx, 's3_copy_block')
                     ph = gen.plan(tuple(x.shape), training=False)
                     y = ph.forward(x)
                     if self.slicer.s_enhance * shp[0] != y.shape[1] or \
@@ -387,8 +422,24 @@ class ForwardPass:
                             y.numel() // n_out, scale.ctypes.data_as(pf),
                             shift.ctypes.data_as(pf))
                         _lib.check(rc, dev.ctx, 's3_affine_channels')
+                    # halo crop (the same for every chunk of a shape group)
                     crop = sl.chunks[cids[0]]['hr_crop']
-                    yc = y[(slice(None),) + tuple(crop)].contiguous()
+                    y1, y2, y3 = (int(v) for v in y.shape[1:4])
+                    cr = [(s_.start or 0, y_ if s_.stop is None else s_.stop)
+                          for s_, y_ in zip(crop, (y1, y2, y3))]
+                    cr = [(a, b if b >= 0 else y_ + b)
+                          for (a, b), y_ in zip(cr, (y1, y2, y3))]
+                    c1, c2, c3 = (b - a for a, b in cr)
+                    yc = dev.empty((len(cids), c1, c2, c3, n_out))
+                    for k in range(len(cids)):
+                        src = y[k].data_ptr() + 4 * n_out * (
+                            (cr[0][0] * y2 + cr[1][0]) * y3 + cr[2][0])
+                        rc = L.s3_copy_block(
+                            dev.ctx, C.c_void_p(src),
+                            C.c_void_p(yc[k].data_ptr()), c1, c2, c3 * n_out,
+                            y2 * y3 * n_out, y3 * n_out, c2 * c3 * n_out,
+                            c3 * n_out)
+                        _lib.check(rc, dev.ctx, 's3_copy_block')
                     stats_d = dev.empty((len(cids), 64, n_out, 3))
                     rc = L.s3_chunk_stats(
                         dev.ctx, C.c_void_p(yc.data_ptr()), len(cids),

@@ -1,10 +1,9 @@
-"""``MultiStepGan`` — serial chain of single-step models.
-
-Mirrors ``sup3r/models/multi_step.py:23-330`` of the reference: the same
-constructor / ``load`` / ``generate`` surface, the 4-D <-> 5-D transposition
-between spatial-only and spatiotemporal steps (:128-170), the feature matching
-between steps (:172-196) and the per-step normalisation flags (:236-238).
-Every step's conv stack runs on the MI355X through ``Sup3rGan.generate``.
+"""``MultiStepGan`` — several trained single-step models run back to back
+(what ``sup3r/models/multi_step.py:23-330`` provides: the
+constructor / ``load`` / ``generate`` surface, the re-interpretation of the
+array between spatial-only (4-D) and spatiotemporal (5-D) steps, the feature
+selection between steps and the normalise-first / un-normalise-last rule).
+Each step's conv stack runs on the MI355X through that model's ``generate``.
 """
 import json
 import logging
@@ -17,8 +16,26 @@ from .utilities import ExoData
 logger = logging.getLogger(__name__)
 
 
+def _as_model_rank(model, arr):
+    """Present ``arr`` in the rank ``model`` consumes.  A stack of spatial
+    fields ``(n, s1, s2, f)`` handed to a 5-D model is ONE sample whose time
+    axis is the stack; a one-sample 5-D array handed to a 4-D model is a stack
+    of its time steps."""
+    if arr.ndim == model.input_dims:
+        return arr
+    if model.is_5d and arr.ndim == 4:
+        return np.moveaxis(arr, 0, 2)[None]
+    if model.is_4d and arr.ndim == 5:
+        if arr.shape[0] != 1:
+            raise AssertionError(
+                f'a 4-D step can only take ONE 5-D sample, got {arr.shape}')
+        return np.moveaxis(arr[0], 2, 0)
+    raise AssertionError(f'{arr.shape} does not fit a {model.input_dims}-D '
+                         'model')
+
+
 class MultiStepGan:
-    """Ordered tuple of trained single-step models run back to back."""
+    """Ordered tuple of trained single-step models."""
 
     def __init__(self, models):
         self._models = tuple(models)
@@ -28,152 +45,97 @@ class MultiStepGan:
 
     @classmethod
     def load(cls, model_dirs, model_kwargs=None, verbose=True):
-        """multi_step.py:42-84: one saved model directory per step; the class
-        of each step is read from its ``model_params.json`` ``meta.class``."""
+        """One saved model directory per step; each step's class is the
+        ``meta.class`` of its ``model_params.json`` (``Sup3rGan`` if absent)."""
         import sup3r_amd
-        if isinstance(model_dirs, str):
-            model_dirs = [model_dirs]
-        model_kwargs = model_kwargs or [{}] * len(model_dirs)
-        if isinstance(model_kwargs, dict):
+        dirs = [model_dirs] if isinstance(model_dirs, str) else list(model_dirs)
+        if model_kwargs is None:
+            model_kwargs = [{}] * len(dirs)
+        elif isinstance(model_kwargs, dict):
             model_kwargs = [model_kwargs]
-        models = []
-        for model_dir, kwargs in zip(model_dirs, model_kwargs):
-            fp_params = os.path.join(model_dir, 'model_params.json')
-            assert os.path.exists(fp_params), f'Could not find: {fp_params}'
-            with open(fp_params) as f:
-                params = json.load(f)
-            meta = params.get('meta', {'class': 'Sup3rGan'})
-            class_name = meta.get('class', 'Sup3rGan')
-            Sup3rClass = getattr(sup3r_amd, class_name)
-            models.append(Sup3rClass.load(model_dir, verbose=verbose, **kwargs))
-        return cls(models)
+        steps = []
+        for d, kw in zip(dirs, model_kwargs):
+            fp = os.path.join(d, 'model_params.json')
+            if not os.path.exists(fp):
+                raise AssertionError(f'{fp} does not exist')
+            with open(fp) as f:
+                meta = json.load(f).get('meta') or {}
+            klass = getattr(sup3r_amd, meta.get('class', 'Sup3rGan'))
+            steps.append(klass.load(d, verbose=verbose, **kw))
+        return cls(steps)
+
+    models = property(lambda self: self._models)
+    means = property(lambda self: tuple(m.means for m in self._models))
+    stdevs = property(lambda self: tuple(m.stdevs for m in self._models))
+    meta = property(lambda self: tuple(m.meta for m in self._models))
+    model_params = property(
+        lambda self: tuple(m.model_params for m in self._models))
+    lr_features = property(lambda self: self._models[0].lr_features)
+    hr_out_features = property(lambda self: self._models[-1].hr_out_features)
+    hr_exo_features = property(
+        lambda self: [m.hr_exo_features for m in self._models])
+    input_dims = property(lambda self: self._models[0].input_dims)
+    is_5d = property(lambda self: self.input_dims == 5)
+    is_4d = property(lambda self: self.input_dims == 4)
 
     @property
-    def models(self):
-        return self._models
+    def s_enhancements(self):
+        return [e for m in self._models for e in m.s_enhancements]
 
     @property
-    def means(self):
-        return tuple(model.means for model in self.models)
+    def t_enhancements(self):
+        return [e for m in self._models for e in m.t_enhancements]
 
-    @property
-    def stdevs(self):
-        return tuple(model.stdevs for model in self.models)
+    s_enhance = property(lambda self: int(np.prod(self.s_enhancements)))
+    t_enhance = property(lambda self: int(np.prod(self.t_enhancements)))
 
     @staticmethod
     def seed(s=0):
         from .gan import Sup3rGan
         Sup3rGan.seed(s=s)
 
+    # kept under the reference's names for callers that reach for them
     @staticmethod
     def _transpose_model_input(model, hi_res):
-        """multi_step.py:128-170: a (n_obs, s1, s2, f) stack fed to a 5-D
-        model becomes (1, s1, s2, n_obs-as-time, f) and vice versa."""
-        if model.is_5d and len(hi_res.shape) == 4:
-            hi_res = np.transpose(hi_res, axes=(1, 2, 0, 3))[np.newaxis]
-        elif model.is_4d and len(hi_res.shape) == 5:
-            msg = ('Recieved 5D input data with shape '
-                   f'({hi_res.shape}) to a 4D model.')
-            assert hi_res.shape[0] == 1, msg
-            hi_res = np.transpose(hi_res[0], axes=(2, 0, 1, 3))
-        else:
-            msg = ('Recieved input data with shape '
-                   f'{hi_res.shape} to a {model.input_dims}D model.')
-            assert model.input_dims == len(hi_res.shape), msg
-        return hi_res
+        return _as_model_rank(model, hi_res)
 
     def _match_model_input(self, model_step, hi_res, exo_data):
-        """multi_step.py:172-196: a step may use a subset of the previous
-        step's output features."""
-        if model_step > 0:
-            current_model = self.models[model_step]
-            previous_model = self.models[model_step - 1]
-            output_feats = previous_model.hr_out_features
-            input_feats = current_model.lr_features
-            exo_data = exo_data or {}
-            input_feats = [f for f in input_feats if f not in exo_data]
-            if not set(input_feats).issubset(set(output_feats)):
-                msg = ('Model step {} input features {} do not match '
-                       'previous model step {} output features {}'.format(
-                           model_step, input_feats, model_step - 1,
-                           output_feats))
-                logger.error(msg)
-                raise ValueError(msg)
-            lr_inds = [output_feats.index(fn) for fn in input_feats]
-            hi_res = hi_res[..., lr_inds]
-        return hi_res
+        """Channels step ``model_step`` reads out of the previous step's
+        output (its lo-res features minus what arrives as exogenous data), in
+        the order it lists them."""
+        if model_step == 0:
+            return hi_res
+        produced = self._models[model_step - 1].hr_out_features
+        wanted = [f for f in self._models[model_step].lr_features
+                  if f not in (exo_data or {})]
+        missing = [f for f in wanted if f not in produced]
+        if missing:
+            raise ValueError(
+                f'step {model_step} needs {missing}, step {model_step - 1} '
+                f'only produces {produced}')
+        return hi_res[..., [produced.index(f) for f in wanted]]
 
     def generate(self, low_res, norm_in=True, un_norm_out=True,
                  exogenous_data=None):
-        """multi_step.py:198-276."""
+        """Run the chain.  Only the first step may skip normalising its input
+        and only the last may skip un-normalising its output; every hand-over
+        in between is in physical units."""
         if isinstance(exogenous_data, dict) and \
                 not isinstance(exogenous_data, ExoData):
             exogenous_data = ExoData(exogenous_data)
-        hi_res = np.array(low_res, copy=True)
-        for i, model in enumerate(self.models):
-            i_norm_in = not (i == 0 and not norm_in)
-            i_un_norm_out = not (i + 1 == len(self.models) and not un_norm_out)
-            i_exo_data = (None if exogenous_data is None
-                          else exogenous_data.get_model_step_exo(i))
+        last = len(self._models) - 1
+        arr = np.array(low_res, copy=True)
+        for i, model in enumerate(self._models):
+            step_exo = None if exogenous_data is None else \
+                exogenous_data.get_model_step_exo(i)
             try:
-                hi_res = self._transpose_model_input(model, hi_res)
-                hi_res = self._match_model_input(i, hi_res, i_exo_data)
-                hi_res = model.generate(hi_res, norm_in=i_norm_in,
-                                        un_norm_out=i_un_norm_out,
-                                        exogenous_data=i_exo_data)
+                arr = self._match_model_input(
+                    i, _as_model_rank(model, arr), step_exo)
+                arr = model.generate(arr, norm_in=norm_in or i > 0,
+                                     un_norm_out=un_norm_out or i < last,
+                                     exogenous_data=step_exo)
             except Exception as e:
-                msg = ('Could not run model #{} of {} "{}" on tensor of '
-                       'shape {}'.format(i + 1, len(self.models), model,
-                                         hi_res.shape))
-                logger.exception(msg)
-                raise RuntimeError(msg) from e
-        return hi_res
-
-    # ---- aggregate views (multi_step.py:278-372)
-    @property
-    def meta(self):
-        return tuple(model.meta for model in self.models)
-
-    @property
-    def lr_features(self):
-        return self.models[0].lr_features
-
-    @property
-    def hr_out_features(self):
-        return self.models[-1].hr_out_features
-
-    @property
-    def hr_exo_features(self):
-        return [model.hr_exo_features for model in self.models]
-
-    @property
-    def model_params(self):
-        return tuple(model.model_params for model in self.models)
-
-    @property
-    def s_enhancements(self):
-        return [e for model in self.models for e in model.s_enhancements]
-
-    @property
-    def t_enhancements(self):
-        return [e for model in self.models for e in model.t_enhancements]
-
-    @property
-    def s_enhance(self):
-        return int(np.prod(self.s_enhancements))
-
-    @property
-    def t_enhance(self):
-        return int(np.prod(self.t_enhancements))
-
-    @property
-    def input_dims(self):
-        return self.models[0].input_dims
-
-    @property
-    def is_5d(self):
-        return self.input_dims == 5
-
-    @property
-    def is_4d(self):
-        return self.input_dims == 4
+                raise RuntimeError(
+                    f'step {i + 1} of {last + 1} ({type(model).__name__}) '
+                    f'failed on an array of shape {arr.shape}') from e
+        return arr

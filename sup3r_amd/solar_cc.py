@@ -31,6 +31,8 @@ logger = logging.getLogger(__name__)
 class SolarCompute(HipGanCompute):
     """``HipGanCompute`` with SolarCC's windowed ``calc_loss``."""
 
+    supports_defer = False   # its loss_and_grads reads the scalars back itself
+
     # (STARTING_HOUR, DAYLIGHT_HOURS, POINT_LOSS_HOURS), set by the model
     hours = (8, 8, 2)
     # fixed window starts for tests; None = a fresh uniform draw per call

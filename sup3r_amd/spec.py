@@ -120,6 +120,49 @@ SUPPORTED = ('FlexiblePadding', 'Conv2D', 'Conv3D', 'Conv2DTranspose',
              'Flatten', 'Dense', 'Sup3rConcat', 'Sup3rAdder')
 
 
+# keras kwargs a layer may carry: the ones the lowering reads, and the ones
+# that do not change the forward arithmetic.  Anything else (dilation_rate,
+# groups, a non-default data_format ...) would silently compute something
+# different from keras, so it raises like any other unsupported feature.
+_BENIGN = {'name', 'dtype', 'trainable', 'kernel_initializer',
+           'bias_initializer', 'kernel_regularizer', 'bias_regularizer',
+           'activity_regularizer', 'kernel_constraint', 'bias_constraint',
+           'input_shape', 'batch_input_shape'}
+_NEUTRAL = {'data_format': ('channels_last', None), 'dilation_rate': (1,),
+            'groups': (1,), 'output_padding': (None,)}
+_CONV_KW = {'filters', 'kernel_size', 'strides', 'padding', 'activation',
+            'use_bias'}
+_READ_KW = {
+    'Conv2D': _CONV_KW, 'Conv3D': _CONV_KW, 'Conv2DTranspose': _CONV_KW,
+    'Conv3DTranspose': _CONV_KW,
+    'Dense': {'units', 'activation', 'use_bias'},
+    'LeakyReLU': {'alpha', 'negative_slope'},
+    'Activation': {'activation'}, 'ReLU': set(),
+    'Cropping2D': {'cropping'}, 'Cropping3D': {'cropping'},
+    'FlexiblePadding': {'paddings', 'mode'},
+}
+
+
+def _check_kwargs(cls, kw, index):
+    known = _READ_KW.get(cls)
+    if known is None:
+        return
+    for k, v in kw.items():
+        if k in known or k in _BENIGN:
+            continue
+        if k in _NEUTRAL:
+            vals = v if isinstance(v, (list, tuple)) else [v]
+            if all(x in _NEUTRAL[k] for x in vals):
+                continue
+        raise KeyError(f'{cls} (hidden layer #{index}): keyword "{k}"={v!r} '
+                       'changes the arithmetic and has no MI355X kernel '
+                       'mapping')
+    if cls == 'ReLU' and any(kw.get(k) not in (None, 0, 0.0) for k in (
+            'max_value', 'negative_slope', 'threshold')):
+        raise KeyError(f'ReLU (hidden layer #{index}) with {kw} has no '
+                       'MI355X kernel mapping')
+
+
 def parse_layers(hidden_layers):
     """hidden_layers -> list[LayerSpec] with phygnn HiddenLayers semantics."""
     layers, skips = [], {}
@@ -131,6 +174,7 @@ def parse_layers(hidden_layers):
                 raise KeyError(
                     f'Layer class "{cls}" (hidden layer #{i}) has no '
                     'MI355X kernel mapping in sup3r_amd')
+            _check_kwargs(cls, spec, i)
             if cls == 'SkipConnection':
                 nm = spec['name']
                 if nm not in skips:
@@ -179,6 +223,9 @@ class Plan:
         self.output = None
         self.out_rank = None   # 2 (dense logits), 4 or 5
         self.layer_out_shapes = []   # keras-view shape after each layer
+        # (tensor id, op index | -1) holding the result after each layer; the
+        # layers of one fused group all point at the group's op
+        self.layer_out = []
 
     def new_tensor(self, shape5):
         self.tensors.append([int(v) for v in shape5])
@@ -269,6 +316,7 @@ def build_plan(layers, in_shape, param_table=None, fuse=True):
         L = layers[i]
         cls, kw = L.cls, L.kwargs
         consumed = 1
+        n_ops_before = len(plan.ops)
         if cls == 'FlexiblePadding':
             pads = [tuple(int(v) for v in p) for p in kw['paddings']]
             if len(pads) != nd + 2:
@@ -548,8 +596,10 @@ def build_plan(layers, in_shape, param_table=None, fuse=True):
             consumed = j - i
         else:
             raise KeyError(f'Layer class "{cls}" has no kernel mapping')
+        consumed_op = len(plan.ops) > n_ops_before
         for _ in range(consumed):
             plan.layer_out_shapes.append(keras_view(cur_dims(), flat))
+            plan.layer_out.append((cur, len(plan.ops) - 1 if consumed_op else -1))
         i += consumed
     flush_pad()
     if skip_cache:
@@ -585,7 +635,8 @@ def _crop_list(cropping, nd):
 def _layer_act(L):
     if L.cls == 'LeakyReLU':
         # keras-2.15 LeakyReLU default alpha = 0.3
-        return ACT_LEAKY, float(L.kwargs.get('alpha', 0.3))
+        return ACT_LEAKY, float(L.kwargs.get(
+            'alpha', L.kwargs.get('negative_slope', 0.3)))
     if L.cls == 'ReLU':
         return ACT_RELU, 0.0
     if L.cls == 'Activation':

@@ -17,6 +17,24 @@ def pytest_configure(config):
         'markers', 'gpu: test needs a real MI355X (run with -m gpu)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """``-m gpu`` tests need a device: on a box without one they are skipped
+    (with the reason), not failed, so a plain ``pytest tests`` is green on CPU
+    and the GPU parity is simply not claimed there."""
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason='needs an MI355X (torch.cuda.is_available() '
+                                   'is False); HIP parity not verified here')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope='session')
 def config_dir():
     return CONFIG_DIR

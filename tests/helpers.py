@@ -107,3 +107,84 @@ class SyntheticMomBatchHandler(SyntheticBatchHandler):
             return MomBatch(b.low_res, b.high_res, b.high_res.copy(), mask)
         self.batches = [to_mom(b) for b in self.batches]
         self.val_data = ValData([to_mom(b) for b in self.val_data.batches])
+
+
+# --------------------------------------------------------------------------
+# bf16 emulation: make the numpy oracle do the roundings a HIP plan does
+# --------------------------------------------------------------------------
+_BF16_WGRAD = ('bf16_trunk', 'bf16_gen', 'bf16_2d', 'c2', 'tail')
+_BF16_DGRAD = ('mfma_frame', 'mfma_valid', 'mfma_chunked', 'fewch_frame', 's2',
+               'c2', 'gconv')
+
+
+def emulate_plan(ref, ph, masks=False, rounding=True):
+    """Configure the oracle network ``ref`` (oracle.network.Network over the
+    same ``hidden_layers``) to reproduce the numerics of the HIP plan handle
+    ``ph`` (sup3r_amd.engine.PlanHandle):
+
+    * ``rounding``: a conv whose device kernel rounds its operands to bf16
+      (``s3_plan_op_info``: forward, weight gradient, data gradient) does the
+      same in the oracle, and a tensor the plan STORES as bf16 is rounded
+      after the last layer of its fused group;
+    * ``masks``: the sign pattern of every activation in the backward pass is
+      the one the device used (read from the training plan's saved
+      activations), so a pre-activation within round-off of zero cannot flip
+      a whole unit between the two backward passes.  Call after the device
+      forward.
+
+    Returns the number of (convs with bf16 operands, tensors stored as bf16,
+    masks installed)."""
+    from sup3r_amd import spec as S
+    plan = ph.plan
+    assert len(plan.layer_out) == len(ref.layers), \
+        (len(plan.layer_out), len(ref.layers))
+    groups = {}
+    for li, (_, oi) in enumerate(plan.layer_out):
+        if oi >= 0:
+            groups.setdefault(oi, []).append(li)
+    n_ops = n_store = n_mask = 0
+    is_bf16_plan = ph.precision == 1          # S3_PREC_BF16
+    for oi, lis in groups.items():
+        op = plan.ops[oi]
+        last = lis[-1]
+        if rounding and ph.tensor_is_bf16(op['out']):
+            ref.emu_store_round.add(last)
+            n_store += 1
+        wl = [ref.layers[li] for li in lis
+              if hasattr(ref.layers[li], 'kernel')]
+        if op['kind'] == S.OP_CONV and rounding:
+            info = ph.op_info(oi)
+            assert len(wl) == 1, (oi, lis)
+            wl[0].emu_fwd_round = bool(info['fwd_bf16_ops'])
+            wl[0].emu_wgrad_round = is_bf16_plan and info['wgrad'] in _BF16_WGRAD
+            wl[0].emu_dgrad_round = is_bf16_plan and info['dgrad'] in _BF16_DGRAD
+            n_ops += int(info['fwd_bf16_ops'])
+        if masks and op.get('act', 0):
+            y = ph.tensor(op['out'])
+            acts = [ref.layers[li] for li in lis
+                    if type(ref.layers[li]).__name__ in ('LeakyReLU',
+                                                         'Activation')]
+            tgt = acts[0] if acts else (wl[0] if wl else None)
+            assert tgt is not None, (oi, lis)
+            want = tgt._x.shape if hasattr(tgt, '_x') else tgt._pre.shape
+            tgt.emu_mask = (y > 0).reshape(want)
+            n_mask += 1
+    return n_ops, n_store, n_mask
+
+
+def rel_linf(a, b):
+    """max |a - b| / max(1, max |b|)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def rel_max(a, b):
+    """max |a - b| / max |b|"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+def rel_rms(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).mean())
+                 / max(1e-30, np.sqrt((b ** 2).mean())))
