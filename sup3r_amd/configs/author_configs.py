@@ -90,8 +90,29 @@ def disc(nd, padding, dense=(2048, 1024), widths=(32, 64, 128, 256)):
     return {'hidden_layers': hl}
 
 
+def toy_wind():
+    """The layer list of the reference's sup3rcc/gen_wind_3x_4x_2f.json (a
+    placeholder config: every hidden conv has ONE filter, 1 447 parameters,
+    Sup3rConcat topography) — BASELINE config C4 names it."""
+    hl = [{'n': 2, 'repeat': pcc(3, 1) + [
+        {'class': 'SpatioTemporalExpansion', 'temporal_mult': 2,
+         'temporal_method': 'nearest'}]}]
+    hl.append({'class': 'SkipConnection', 'name': 'a'})
+    hl.append({'n': 1, 'repeat': (
+        [{'class': 'SkipConnection', 'name': 'b'}] + pcc(3, 1)
+        + pcc(3, 1, act=False) + [{'class': 'SkipConnection', 'name': 'b'}])})
+    hl += pcc(3, 1, act=False) + [{'class': 'SkipConnection', 'name': 'a'}]
+    hl += pcc(3, 36, act=False) + [
+        {'class': 'SpatioTemporalExpansion', 'spatial_mult': 3},
+        {'alpha': 0.2, 'class': 'LeakyReLU'},
+        {'class': 'Sup3rConcat', 'name': 'topography'}]
+    hl += pcc(3, 2, act=False)
+    return {'hidden_layers': hl}
+
+
 def main():
     files = {
+        'gen_wind_3x_4x_2f_toy.json': toy_wind(),
         'gen_5x_12x_2f.json': st_gen(5, [2, 2, 3], 2),
         # C4/C5 body: the 3x/4x 2-feature topology (16 blocks x 64 ch)
         'gen_3x_4x_2f.json': st_gen(3, [2, 2], 2),

@@ -1,0 +1,481 @@
+"""GPU parity tests (``-m gpu``) added in round 2: what ``bench.py`` measures is
+what is checked here, at its size.
+
+* the full-size C2 generator in the bf16 throughput mode (batch 8: the
+  persistent trunk kernel is selected — asserted through ``s3_plan_op_info``)
+  against (i) the oracle doing the SAME roundings (bf16 operands where the
+  device kernel rounds them, bf16 storage where the plan stores bf16; fp32
+  accumulation) — bound 5e-3 of the output scale, it isolates kernel errors
+  from the precision of the mode — and (ii) the exact fp32 oracle — the
+  stated accuracy of the bf16 mode, 3e-2;
+* the same generator in the BF16X3 mode (hi*hi + hi*lo + lo*hi on the bf16
+  MFMA): L-inf < 1e-3 against the exact fp32 oracle, north_star's tolerance;
+* the production discriminators as whole networks, forward and backward;
+* gradients against the oracle under the device's own LeakyReLU masks: the
+  backward pass is then linear in its inputs and the bounds are those of the
+  arithmetic (1e-3 fp32, 1e-2 bf16-emulated), not of mask flips;
+* one full C2 ``_train_batch`` against ``GanOracle.train_batch``;
+* the sharded gradient (two shards accumulated on one GPU) against the
+  oracle's per-shard SUM;
+* the configs the round-1 verdict found unexercised: C3 (a 20x20x48 chunk
+  through ``run_batched`` with the C2 generator), C4 (the reference's
+  ``filters: 1`` toy and the 3x/4x body), C5 (CondMom on the 3x/4x body).
+
+Every tolerance is stated where it is asserted.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import emulate_plan, rel_linf, rel_max, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+CFG = os.path.join(os.path.dirname(__file__), '..', 'sup3r_amd', 'configs')
+
+
+def _load(name):
+    with open(os.path.join(CFG, name)) as f:
+        return json.load(f)
+
+
+def _oracle(spec, x, exo=None, seed=3, bias_scale=0.1):
+    from oracle.network import Network
+    net = Network(spec)
+    net.init_weights(x, exo, seed=seed, bias_scale=bias_scale)
+    return net
+
+
+def _hip(spec, weights, precision):
+    from sup3r_amd.engine import Network
+    net = Network(spec, precision=precision)
+    net.set_weights(weights)
+    return net
+
+
+def _kernels(ph, field='fwd'):
+    from sup3r_amd import spec as S
+    return [ph.op_info(i)[field] for i, op in enumerate(ph.plan.ops)
+            if op['kind'] == S.OP_CONV]
+
+
+# ---------------------------------------------------------------- C2 forward
+@pytest.fixture(scope='module')
+def c2():
+    """one C2 sample, oracle weights, exact fp32 oracle output (~40 s)"""
+    rng = np.random.default_rng(42)
+    spec = _load('gen_5x_12x_2f.json')
+    x = rng.standard_normal((8, 16, 16, 24, 4)).astype(np.float32)
+    # (fully convolutional: the lazy build runs on a tiny input)
+    ref = _oracle(spec, x[:1, :6, :6, :6], seed=0, bias_scale=0.0)
+    y_ref = ref.forward(x[:1])
+    return spec, x, ref, y_ref
+
+
+def test_c2_bf16_full_size_persistent_kernel_vs_oracle(c2):
+    spec, x, ref, y_ref = c2
+    net = _hip(spec, ref.weights, 'bf16')
+    ph = net.plan(x.shape, training=False)
+    fwd = _kernels(ph)
+    # the benchmarked kernel is the one under test: 33 body convs, the head
+    # convs at T >= 48 and the 64 -> 200 conv all run on the persistent kernel
+    assert fwd.count('mfma_persist') >= 34, fwd
+    assert fwd[0] == 'gconv_fewch' and fwd[-1] == 'tail_mfma', fwd
+    y = ph.forward(net.dev.to_device(x)).cpu().numpy()
+    assert y.shape == (8, 80, 80, 288, 2) and np.isfinite(y).all()
+    # (ii) the accuracy of the bf16 mode itself
+    err_mode = rel_linf(y[0], y_ref[0])
+    assert err_mode < 3e-2, err_mode
+    # (i) the same roundings in the oracle: kernel error only
+    emu = _oracle(spec, x[:1, :6, :6, :6], seed=0, bias_scale=0.0)
+    n_ops, n_store, _ = emulate_plan(emu, ph)
+    assert n_ops == 38 and n_store >= 30, (n_ops, n_store)
+    y_emu = emu.forward(x[:1])
+    err_kernel = rel_linf(y[0], y_emu[0])
+    rms_kernel = rel_rms(y[0], y_emu[0])
+    print(f'C2 bf16 batch 8: vs fp32 oracle {err_mode:.2e}, vs bf16-emulating '
+          f'oracle L-inf {err_kernel:.2e} rms {rms_kernel:.2e}')
+    assert err_kernel < 5e-3, err_kernel
+    assert rms_kernel < 1e-3, rms_kernel
+    # samples are independent: every copy of sample 0 in the batch is
+    # bit-identical to it, whatever tile / workgroup computed it
+    xx = np.repeat(x[:1], 8, axis=0)
+    yy = ph.forward(net.dev.to_device(xx)).cpu().numpy()
+    for k in range(8):
+        np.testing.assert_array_equal(yy[k], y[0])
+
+
+def test_c2_bf16x3_meets_the_fp32_tolerance(c2):
+    """S3_PREC_BF16X3: north_star's L-inf < 1e-3 at full C2 size"""
+    spec, x, ref, y_ref = c2
+    net = _hip(spec, ref.weights, 'bf16x3')
+    ph = net.plan((2,) + x.shape[1:], training=False)
+    assert _kernels(ph).count('mfma_tile') >= 34
+    y = ph.forward(net.dev.to_device(x[:2])).cpu().numpy()
+    err = float(np.abs(y[0] - y_ref[0]).max())
+    print(f'C2 bf16x3: L-inf {err:.2e} vs the fp32 oracle '
+          f'(output scale {np.abs(y_ref).max():.2f})')
+    assert err < 1e-3, err
+    # and against the exact-fp32 MFMA mode of the device
+    net32 = _hip(spec, ref.weights, 'f32')
+    y32 = net32(x[:1]).cpu().numpy()
+    assert float(np.abs(y[0] - y32[0]).max()) < 1e-3
+    assert float(np.abs(y32[0] - y_ref[0]).max()) < 1e-3
+
+
+def test_bf16x3_edge_shapes_and_backward():
+    """ragged tiles, both tile shapes, d2s / residual epilogues, and the data
+    gradient (the same kernel over the padded frame) in BF16X3"""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(5)
+    spec = pcc(3, 64) + [{'class': 'SkipConnection', 'name': 'a'}] + \
+        pcc(3, 64) + pcc(3, 64, act=False) + \
+        [{'class': 'SkipConnection', 'name': 'a'}] + \
+        pcc(3, 200, act=False) + \
+        [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
+         {'alpha': 0.2, 'class': 'LeakyReLU'}] + pcc(3, 2, act=False)
+    for shape in ((2, 5, 7, 19, 4), (12, 12, 17, 40, 4)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        ref = _oracle(spec, x)
+        y_ref = ref.forward(x)
+        net = _hip(spec, ref.weights, 'bf16x3')
+        ph = net.plan(shape, training=True)
+        y = ph.forward(net.dev.to_device(x)).cpu().numpy()
+        assert rel_linf(y, y_ref) < 2e-5, (shape, rel_linf(y, y_ref))
+        dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+        emulate_plan(ref, ph, masks=True, rounding=False)
+        dx_ref = ref.backward(dy)
+        dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
+        assert rel_max(dx.reshape(dx_ref.shape), dx_ref) < 1e-4
+        for g, g_ref in zip(net.grads, ref.grads):
+            assert rel_max(g, g_ref) < 1e-4
+
+
+# ------------------------------------------------- production discriminators
+def test_disc_st_production_forward_full_size():
+    """disc_st.json at the C2 hi-res shape (37 M parameters, 15360 x 2048
+    Dense): exact-fp32 mode vs the oracle, and the bf16 mode vs the oracle
+    doing the same roundings"""
+    rng = np.random.default_rng(8)
+    spec = _load('disc_st.json')
+    x = rng.standard_normal((1, 80, 80, 288, 2)).astype(np.float32)
+    ref = _oracle(spec, x, seed=1)
+    y_ref = ref.forward(x)
+    assert y_ref.shape == (1, 1)
+    n_par = sum(w.size for w in ref.weights)
+    assert n_par == 37072513
+    net = _hip(spec, ref.weights, 'f32')
+    y = net(x).cpu().numpy()
+    assert abs(float(y[0, 0] - y_ref[0, 0])) < 1e-4 * max(1, abs(y_ref[0, 0]))
+    net16 = _hip(spec, ref.weights, 'bf16')
+    ph = net16.plan(x.shape, training=True)
+    y16 = ph.forward(net16.dev.to_device(x)).cpu().numpy()
+    emulate_plan(ref, ph)                 # (ref now rounds like the device)
+    y_emu = ref.forward(x)
+    print('disc_st full size: f32', float(y[0, 0]), 'oracle',
+          float(y_ref[0, 0]), 'bf16', float(y16[0, 0]), 'emulated',
+          float(y_emu[0, 0]))
+    scale = max(1.0, abs(float(y_ref[0, 0])))
+    assert abs(float(y16[0, 0] - y_emu[0, 0])) < 2e-3 * scale
+    assert abs(float(y16[0, 0] - y_ref[0, 0])) < 3e-2 * scale
+
+
+def _fwd_bwd_vs_oracle(spec, shape, precision, seed, tol_y, tol_g,
+                       exo_name=None, exo_shape=None):
+    """forward + backward of one network on the device vs the oracle that
+    does the device's roundings and uses the device's masks"""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(shape).astype(np.float32)
+    exo = None
+    if exo_name:
+        exo = {exo_name: rng.standard_normal(exo_shape).astype(np.float32)}
+    ref = _oracle(spec, x, exo, seed=seed)
+    net = _hip(spec, ref.weights, precision)
+    dev = net.dev
+    ph = net.plan(shape, training=True)
+    exod = {k: dev.to_device(v) for k, v in (exo or {}).items()}
+    y = ph.forward(dev.to_device(x), exod).cpu().numpy()
+    emulate_plan(ref, ph, masks=False)
+    y_ref = ref.forward(x, exo)
+    emulate_plan(ref, ph, masks=True, rounding=False)
+    assert rel_linf(y, y_ref) < tol_y, (precision, rel_linf(y, y_ref))
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = ref.backward(dy)
+    dx = ph.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
+    errs = {'dx': rel_max(dx.reshape(dx_ref.shape), dx_ref)}
+    gmax = max(float(np.abs(g).max()) for g in ref.grads)
+    for i, (g, g_ref) in enumerate(zip(net.grads, ref.grads)):
+        # tensors whose gradient is numerically nothing compare at the
+        # round-off of the large ones
+        errs[i] = float(np.abs(g - g_ref).max()
+                        / max(np.abs(g_ref).max(), 1e-3 * gmax))
+    worst = max(errs.values())
+    print(f'{precision} {shape}: y {rel_linf(y, y_ref):.2e}, worst gradient '
+          f'error {worst:.2e}')
+    assert worst < tol_g, (precision, errs)
+    return ph
+
+
+@pytest.mark.parametrize('cfg,shape', [
+    ('disc_st_same.json', (2, 12, 12, 16, 2)),   # the reference's test disc
+    ('disc_s_same.json', (4, 20, 20, 2)),        # tests/data/config_disc_s_test
+    ('disc_s.json', (2, 64, 64, 2)),
+])
+def test_production_discriminators_fwd_bwd(cfg, shape):
+    """6.1 M / 2.2 M-parameter test discriminators of the reference and the
+    2-D production one: fp32 1e-4 / 1e-3, bf16 (emulated roundings, device
+    masks) 5e-3 / 2e-2"""
+    spec = _load(cfg)
+    _fwd_bwd_vs_oracle(spec, shape, 'f32', 31, 1e-4, 1e-3)
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 31, 5e-3, 2e-2)
+
+
+def test_disc_st_production_kernels_at_reduced_shape():
+    """disc_st.json forward / backward at the smallest shape that still runs
+    on the kernels of the C2 training step (selection asserted against the
+    plan of the full-size batch-8 discriminator)"""
+    spec = _load('disc_st.json')
+    from sup3r_amd.engine import Network
+    full = Network(spec, precision='bf16')
+    full.build((8, 80, 80, 288, 2), seed=0)
+    ph_full = full.plan((8, 80, 80, 288, 2), training=True)
+    want = {f: set(_kernels(ph_full, f)) for f in ('fwd', 'wgrad', 'dgrad')}
+    print('production kernels:', want)
+    del ph_full
+    full.clear_plans()
+    chosen = None
+    # (8 valid convs, strides 1 2 1 2 ...: 62 is the smallest extent)
+    for shape in ((2, 64, 64, 112, 2), (4, 64, 64, 112, 2),
+                  (4, 64, 64, 160, 2), (8, 64, 64, 160, 2)):
+        probe = Network(spec, precision='bf16')
+        probe.build(shape, seed=0)
+        ph = probe.plan(shape, training=True)
+        got = {f: set(_kernels(ph, f)) for f in want}
+        del ph
+        probe.clear_plans()
+        if all(want[f] <= got[f] for f in want):
+            chosen = shape
+            break
+        print('shape', shape, 'misses',
+              {f: want[f] - got[f] for f in want if want[f] - got[f]})
+    assert chosen is not None, 'no reduced shape selects every kernel'
+    _fwd_bwd_vs_oracle(spec, chosen, 'bf16', 17, 5e-3, 2e-2)
+    _fwd_bwd_vs_oracle(spec, chosen, 'f32', 17, 1e-4, 1e-3)
+
+
+# --------------------------------------------------- generators, masks fixed
+@pytest.mark.parametrize('cfg,shape', [
+    ('gen_2x_2f.json', (3, 9, 8, 2)),             # C1: 36 Conv2DTranspose
+    ('gen_3x_4x_2f.json', (1, 5, 6, 4, 2)),       # C4 / C5 body
+    ('gen_3x_4x_2f.json', (8, 16, 16, 24, 2)),    # ... on the bf16 kernels
+])
+def test_production_generators_gradients_under_device_masks(cfg, shape):
+    """round 1 asserted 5e-2 (f32) / 3e-1 (bf16) relative rms on these and
+    blamed LeakyReLU mask flips; with the device's masks given to the oracle
+    the bounds are 1e-3 (f32) and 2e-2 (bf16 with emulated roundings)"""
+    spec = _load(cfg)
+    big = shape[0] >= 8
+    if not big:
+        _fwd_bwd_vs_oracle(spec, shape, 'f32', 21, 1e-4, 1e-3)
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 21, 5e-3, 2e-2)
+
+
+def test_c4_toy_generator_filters_1():
+    """sup3rcc/gen_wind_3x_4x_2f.json of the reference: every hidden conv has
+    ONE filter (C_in = C_out = 1 geometries) + Sup3rConcat topography"""
+    spec = _load('gen_wind_3x_4x_2f_toy.json')
+    n_par = 0
+    ph = _fwd_bwd_vs_oracle(spec, (4, 4, 4, 4, 2), 'f32', 3, 1e-5, 1e-3,
+                            exo_name='topography',
+                            exo_shape=(4, 12, 12, 16, 1))
+    n_par = sum(int(np.prod(p['shape'])) for p in ph.plan.params)
+    assert n_par == 1447
+    _fwd_bwd_vs_oracle(spec, (4, 4, 4, 4, 2), 'bf16', 3, 5e-3, 2e-2,
+                       exo_name='topography', exo_shape=(4, 12, 12, 16, 1))
+
+
+# ----------------------------------------------------------- training steps
+def test_c2_train_batch_vs_oracle():
+    """one full ``Sup3rGan._train_batch`` of the C2 GAN (gen_5x_12x_2f +
+    disc_st, batch 1, exact-fp32 mode): generator step, then discriminator
+    step with the UPDATED generator — gradients of both steps and the weights
+    after them against ``GanOracle.train_batch`` (~4 min of numpy)"""
+    from oracle.gan import GanOracle
+    from oracle.network import Network as ONet
+    from sup3r_amd import Sup3rGan
+    rng = np.random.default_rng(77)
+    gspec, dspec = _load('gen_5x_12x_2f.json'), _load('disc_st.json')
+    lr = rng.standard_normal((1, 16, 16, 24, 4)).astype(np.float32)
+    hr = rng.standard_normal((1, 80, 80, 288, 2)).astype(np.float32)
+    og, od = ONet(gspec), ONet(dspec)
+    og.init_weights(lr, seed=5, bias_scale=0.05)
+    od.init_weights(hr, seed=6, bias_scale=0.05)
+    step = 1e-4
+    m = Sup3rGan(os.path.join(CFG, 'gen_5x_12x_2f.json'),
+                 os.path.join(CFG, 'disc_st.json'), loss='MeanAbsoluteError',
+                 learning_rate=step, precision='f32')
+    m.init_weights(lr.shape, hr.shape)
+    m.generator.set_weights(og.weights)
+    m.discriminator.set_weights(od.weights)
+    orc = GanOracle(og, od, loss='MeanAbsoluteError', learning_rate=step)
+
+    class B:
+        low_res, high_res = lr, hr
+    # the oracle's gradients of both steps, captured on their way into Adam
+    seen = {}
+    for name, opt in (('gen', orc.opt), ('disc', orc.opt_disc)):
+        def spy(grads, weights, _n=name, _f=opt.apply_gradients):
+            seen[_n] = [np.array(g) for g in grads]
+            return _f(grads, weights)
+        opt.apply_gradients = spy
+    ref_details = orc.train_batch(lr, hr, 1e-2, True, True)
+    got = m._train_batch(B, True, False, False, True, False, False, 1e-2)
+    # (the generator's gradient buffer still holds the generator step's
+    # gradients: the discriminator step runs the generator without a tape)
+    for name, net in (('gen', m.generator), ('disc', m.discriminator)):
+        worst = max(rel_rms(a_, b_) for a_, b_ in zip(net.grads, seen[name])
+                    if np.abs(b_).max() > 0)
+        print(f'C2 {name}-step gradients: worst rel. rms {worst:.2e}')
+        # own masks on both sides, 38 stacked LeakyReLU convs (generator) /
+        # 8 + 3 (discriminator), exact-fp32 arithmetic
+        assert worst < 2e-2, (name, worst)
+    for k in ('loss_gen', 'loss_gen_content', 'loss_gen_advers'):
+        assert abs(got[k] - ref_details[k]) < 1e-4 * max(1, abs(ref_details[k]))
+    # the disc step saw the UPDATED generator on both sides
+    assert abs(got['loss_disc'] - ref_details['loss_disc']) < 1e-3
+    # weights after one Adam step each: |delta| <= lr; a weight moves the
+    # other way only if its gradient's sign differs, i.e. it is ~0
+    for net, onet in ((m.generator, og), (m.discriminator, od)):
+        far, n = 0, 0
+        for w, w_ref in zip(net.weights, onet.weights):
+            d = np.abs(w - w_ref)
+            assert d.max() <= 2.01 * step
+            far += int((d > 0.05 * step).sum())
+            n += d.size
+        print('weights further than 5 % of a step from the oracle:', far,
+              'of', n)
+        assert far < 2e-2 * n
+
+
+def test_sharded_gradient_is_the_per_shard_sum():
+    """abstract.py:785-805 on one GPU: shard 0 then shard 1 with
+    ``accumulate_wgrad`` — the buffer holds the SUM of the two shards'
+    gradients (not the gradient of the whole batch's mean loss)"""
+    from oracle.gan import GanOracle
+    from oracle.network import Network as ONet
+    from sup3r_amd import Sup3rGan
+    rng = np.random.default_rng(3)
+    gspec, dspec = _load('test_gen_st_2x_4x_2f.json'), \
+        _load('test_disc_st_same.json')
+    lr = rng.standard_normal((4, 4, 4, 4, 2)).astype(np.float32)
+    hr = rng.standard_normal((4, 8, 8, 16, 2)).astype(np.float32)
+    og, od = ONet(gspec), ONet(dspec)
+    og.init_weights(lr, seed=1, bias_scale=0.1)
+    od.init_weights(hr, seed=2, bias_scale=0.1)
+    m = Sup3rGan(os.path.join(CFG, 'test_gen_st_2x_4x_2f.json'),
+                 os.path.join(CFG, 'test_disc_st_same.json'),
+                 loss='MeanAbsoluteError', precision='f32')
+    m.init_weights(lr.shape, hr.shape)
+    m.generator.set_weights(og.weights)
+    m.discriminator.set_weights(od.weights)
+    orc = GanOracle(og, od, loss='MeanAbsoluteError')
+    for which, kw in (('gen', dict(train_gen=True, train_disc=False)),
+                      ('disc', dict(train_gen=False, train_disc=True))):
+        total, losses = None, []
+        for r in range(2):
+            sl = slice(2 * r, 2 * r + 2)
+            loss, _, g = orc.loss_and_grads(lr[sl], hr[sl], 1e-2, **kw)
+            g = [np.array(x, np.float64) for x in g]
+            total = g if total is None else [a + b for a, b in zip(total, g)]
+            losses.append(float(loss))
+        m.virtual_gpus = 2
+        w_before = [w.copy() for w in m.weights]
+        det = m.run_gradient_descent(lr, hr, weight_gen_advers=1e-2,
+                                     multi_gpu=True, **kw)
+        net = m.generator if which == 'gen' else m.discriminator
+        for g, g_ref in zip(net.grads, total):
+            assert rel_max(g, g_ref) < 2e-3, which
+        key = 'loss_gen' if which == 'gen' else 'loss_disc'
+        assert abs(float(det[key]) - np.mean(losses)) < 1e-5
+        # put the weights back so the next case starts from the oracle's
+        m.generator.set_weights(w_before[:len(m.generator_weights)])
+        m.discriminator.set_weights(w_before[len(m.generator_weights):])
+
+
+def test_condmom_on_the_3x_4x_body():
+    """C5: Sup3rCondMom over gen_3x_4x_2f (the production body, 3.9 M
+    parameters): masked-MSE value and gradients vs the oracle"""
+    from oracle.network import Network as ONet
+    from sup3r_amd import Sup3rCondMom
+    rng = np.random.default_rng(12)
+    spec = _load('gen_3x_4x_2f.json')
+    lr = rng.standard_normal((2, 4, 4, 4, 2)).astype(np.float32)
+    out = rng.standard_normal((2, 12, 12, 16, 2)).astype(np.float32)
+    mask = (rng.uniform(size=out.shape) > 0.3).astype(np.float32)
+    og = ONet(spec)
+    og.init_weights(lr, seed=4, bias_scale=0.1)
+    m = Sup3rCondMom(os.path.join(CFG, 'gen_3x_4x_2f.json'), precision='f32')
+    m.init_weights(lr.shape, out.shape)
+    m.generator.set_weights(og.weights)
+    y = og.forward(lr)
+    d = y * mask - out * mask
+    loss_ref = float((d * d).mean())
+    _, det = m.get_single_grad(lr, out, mask=mask)
+    assert abs(float(det['loss_gen']) - loss_ref) < 1e-5 * max(1, loss_ref)
+    ph = m.generator.plan(lr.shape, training=True)
+    emulate_plan(og, ph, masks=True, rounding=False)
+    og.backward((2.0 * d * mask / d.size).astype(np.float32))
+    worst = max(rel_max(a, b) if np.abs(b).max() > 0 else 0.0
+                for a, b in zip(m.generator.grads, og.grads))
+    print(f'CondMom on gen_3x_4x_2f: worst gradient error {worst:.2e}')
+    assert worst < 2e-3, worst
+
+
+# ------------------------------------------------------------- C3 executor
+def test_c3_chunk_through_run_batched_with_the_c2_generator():
+    """a 20x20x48 lo-res chunk (+ halo) through ``ForwardPass.run_batched``
+    with the C2 generator in bf16 (the bench configuration): equals the
+    chunk-by-chunk ``run`` bit for bit and the oracle within the bf16 bound"""
+    from sup3r_amd import ChunkSlicer, ForwardPass, Sup3rGan
+    feats = ['u_100m', 'v_100m', 'temperature_100m', 'pressure_0m']
+    outs = ['u_100m', 'v_100m']
+    Sup3rGan.seed(11)
+    means = {f: np.float32(0.1 * (i + 1)) for i, f in enumerate(feats)}
+    stds = {f: np.float32(1.0 + 0.25 * i) for i, f in enumerate(feats)}
+    m = Sup3rGan(os.path.join(CFG, 'gen_5x_12x_2f.json'),
+                 os.path.join(CFG, 'test_disc_st_same.json'), means=means,
+                 stdevs=stds, precision='bf16')
+    m.set_model_params(lr_features=feats, hr_out_features=outs, s_enhance=5,
+                       t_enhance=12)
+    rng = np.random.default_rng(0)
+    domain = rng.standard_normal((24, 22, 52, 4)).astype(np.float32)
+    slicer = ChunkSlicer((24, 22), 52, 5, 12, (20, 20, 48), spatial_pad=1,
+                         temporal_pad=2)
+    assert slicer.n_chunks == 8
+    m.init_weights((1, 22, 22, 52, 4), (1, 110, 110, 624, 2))
+    fwp = ForwardPass(m, slicer)
+    got = np.full(slicer.hr_shape + (2,), np.nan, np.float32)
+    n = fwp.run_batched(domain, out=got, batch=4)
+    assert n == 8 and np.isfinite(got).all()
+    # chunk 0 (the full 20x20x48 one) again through the reference-shaped path
+    c0 = fwp.run_chunk(domain, 0)
+    hs = slicer.chunks[0]['hr_slice']
+    assert c0.shape == (100, 100, 576, 2)
+    np.testing.assert_array_equal(got[hs], c0)
+    # ... and against the fp32 oracle on that chunk's padded input
+    from oracle.gan import norm_input, un_norm_output
+    from oracle.network import Network as ONet
+    og = ONet(_load('gen_5x_12x_2f.json'))
+    xin = fwp.chunk_input(domain, 0)[None]
+    xin = norm_input(xin, [means[f] for f in feats],
+                     [stds[f] for f in feats]).astype(np.float32)
+    og.forward(xin[:, :6, :6, :6])
+    og.set_weights(m.generator_weights)
+    y = og.forward(xin)
+    y = un_norm_output(y, [means[f] for f in outs], [stds[f] for f in outs])
+    y = y[0][tuple(slicer.chunks[0]['hr_crop'])]
+    err = rel_linf(c0, y)
+    print(f'C3 chunk through run_batched (bf16) vs oracle: {err:.2e}')
+    assert err < 3e-2, err
