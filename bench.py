@@ -232,6 +232,32 @@ def inner_pmc(args):
     torch.cuda.synchronize()
 
 
+def hbm_class_ops(ph, ms):
+    """the HBM-bound ops of the forward (the C_in <= 8 convs
+    and the index ops): algorithmic bytes = read the input once + write the
+    output once in their storage dtypes, over the op's HIP-event time"""
+    out = []
+    for i, op in enumerate(ph.plan.ops):
+        info = ph.op_info(i)
+        conv = 'cout' in op
+        if conv and info['fwd'] in ('mfma_tile', 'mfma_persist'):
+            continue
+        nb = 0
+        for tid in (op['in0'], op['out']):
+            n = int(np.prod(ph.plan.tensors[tid]))
+            nb += n * (2 if ph.tensor_is_bf16(tid) else 4)
+        if ms[i] <= 0:
+            continue
+        gbs = nb / (ms[i] * 1e-3) / 1e9
+        out.append({'op': i, 'what': (f'conv {op["cin"]}->{op["cout"]} '
+                                      f'({info["fwd"]})' if conv
+                                      else f'index op kind {op["kind"]}'),
+                    'out_shape': ph.plan.tensors[op['out']],
+                    'algorithmic_bytes': nb, 'ms': ms[i],
+                    'achieved_GBps': gbs, 'frac_of_8TBps': gbs / PEAK_HBM_GBS})
+    return out
+
+
 def measure_traffic(batch, timeout=240):
     """HBM bytes per launch of the dominant kernel from the PMC counters, as
     MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
@@ -257,13 +283,17 @@ def measure_traffic(batch, timeout=240):
         except Exception as e:
             shutil.rmtree(d, ignore_errors=True)
             return None, f'rocprofv3 --pmc {counter} failed: {e!r}'[:300]
-        rows = []
+        rows, tail = [], []
         for fp in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
             with open(fp) as f:
-                rows += [r for r in csv.DictReader(f)
-                         if r.get('Counter_Name') == counter
-                         and 'conv3_mfma_persist_kernel<4>' in
-                         r.get('Kernel_Name', '')]
+                for r in csv.DictReader(f):
+                    if r.get('Counter_Name') != counter:
+                        continue
+                    name = r.get('Kernel_Name', '')
+                    if 'conv3_mfma_persist_kernel<4>' in name:
+                        rows.append(r)
+                    elif 'conv_tail_mfma_kernel' in name:
+                        tail.append(float(r['Counter_Value']))
         shutil.rmtree(d, ignore_errors=True)
         if not rows or len(rows) % 38:
             return None, (f'{len(rows)} dispatches of the persistent kernel '
@@ -272,7 +302,12 @@ def measure_traffic(batch, timeout=240):
         body = [float(r['Counter_Value']) for i, r in enumerate(rows)
                 if 2 <= i % 38 <= 34]
         vals[counter] = float(np.mean(body))
+        if tail:
+            vals['tail_' + counter] = float(np.mean(tail))
     total = (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
+    if 'tail_FETCH_SIZE' in vals and 'tail_WRITE_SIZE' in vals:
+        measure_traffic.tail = (2.0 * vals['tail_FETCH_SIZE']
+                                + vals['tail_WRITE_SIZE']) * 1024.0
     return total, (f'PMC, this run: FETCH_SIZE {vals["FETCH_SIZE"]:.0f} KB x 2 '
                    f'(gfx950 correction) + WRITE_SIZE {vals["WRITE_SIZE"]:.0f} '
                    'KB per body-conv launch, separate rocprofv3 --pmc passes')
@@ -546,6 +581,7 @@ def main():
             'hbm_frac': body_bytes / (body_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             'conv_ms_per_step': conv_ms, 'all_ops_ms_per_step': sum(ms),
             'forwards_profiled': n_prof,
+            'hbm_bound_ops': hbm_class_ops(ph, ms),
             'peak_note': 'dense bf16 MFMA peak (MI355X_MICROARCH.md); the '
                          "guide's best plain-HIP GEMM sustains 1330-1470 "
                          'TFLOP/s on random operands (the chip is power-'
@@ -616,6 +652,11 @@ def main():
         if traffic:
             result['roofline']['traffic_over_algorithmic'] = \
                 traffic / body_bytes
+        tail = getattr(measure_traffic, 'tail', None)
+        for o in result['roofline']['hbm_bound_ops']:
+            if tail and 'tail_mfma' in o['what']:
+                o['traffic_pmc_bytes'] = tail
+                o['traffic_over_algorithmic'] = tail / o['algorithmic_bytes']
     if not args.no_cpu_baseline:
         cpu, parity = cpu_legs(spec, dev)
         cpu['parity'] = parity

@@ -44,7 +44,8 @@ enum {
   S3_OP_PAD = 8,      /* FlexiblePadding not consumed by a conv              */
   S3_OP_CROP = 9,
   S3_OP_VIEW = 10,    /* Flatten / depth_to_time reshape (alias, no copy)    */
-  S3_OP_ROLL_T = 11   /* tf.roll along t (depth_to_time t_roll)              */
+  S3_OP_ROLL_T = 11,  /* tf.roll along t (depth_to_time t_roll)              */
+  S3_OP_DILATE = 12   /* zero insertion by stride[] (strided ConvNDTranspose) */
 };
 enum { S3_ACT_NONE = 0, S3_ACT_RELU = 1, S3_ACT_LEAKY = 2 };
 enum { S3_PAD_ZERO = 0, S3_PAD_REFLECT = 1 };

@@ -167,6 +167,10 @@ class HipGanCompute:
         call; the shards of a split mini-batch accumulate into one)"""
         return self._zero(self.dev.empty((4 + SLOTS_PER_TERM * MAX_TERMS,)))
 
+    def add_scalars(self, dst, src):
+        """dst += src on the device (shards of a split mini-batch)"""
+        self._copy_channels(src, 0, dst, 0, 1, accumulate=True)
+
     def allreduce_scalars(self, scal):
         """SUM of a loss-scalar buffer over the data-parallel ranks"""
         rc = _lib.lib().s3_allreduce_sum(self.dev.ctx, self._ptr(scal),
@@ -177,6 +181,8 @@ class HipGanCompute:
         return C.c_void_p(t.data_ptr() + 4 * offset)
 
     def _copy_channels(self, src, c0_src, dst, c0_dst, nc, accumulate=False):
+        if src.dim() == 1:           # flat buffers: one "channel" per element
+            src, dst = src.view(-1, 1), dst.view(-1, 1)
         n_pos = src.numel() // src.shape[-1]
         rc = _lib.lib().s3_copy_channels(
             self.dev.ctx, self._ptr(src), src.shape[-1], c0_src,

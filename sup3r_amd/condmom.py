@@ -39,6 +39,14 @@ class _Reported(LossFuture):
     def _scale(self, v):
         self._inner._scale = v
 
+    @property
+    def _scal(self):
+        return self._inner._scal
+
+    @_scal.setter
+    def _scal(self, v):
+        self._inner._scal = v
+
 
 class Sup3rCondMom(Sup3rGan):
     """Basic Sup3r conditional moments model."""

@@ -73,6 +73,15 @@ __host__ __device__ inline int s3_reflect(int i, int n) {
   return i;
 }
 
+// XCD-aware tile order for one-tile-per-workgroup kernels: the dispatcher puts
+// block b on XCD b % 8 and every XCD has a private L2, so hand each XCD a
+// contiguous run of tiles (bijective on [0, nblk)): neighbouring tiles share
+// halo cells, which then hit in that XCD's L2 instead of going to memory twice.
+__device__ inline int s3_xcd_tile(int b, int nblk) {
+  const int q = nblk / 8, r = nblk % 8, xcd = b % 8, k = b / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // ---- launchers (defined in the .hip files) ------------------------------
 // element types of a fused conv's activations (0 = fp32, 1 = bf16)
 struct ConvIO {

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) char halo[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kg = lane >> 4;
-  int tr = blockIdx.x;
+  int tr = s3_xcd_tile(blockIdx.x, gridDim.x);
   const int t2i = tr % tiles2; tr /= tiles2;
   const int t1i = tr % tiles1; tr /= tiles1;
   const int t0i = tr % tiles0; tr /= tiles0;

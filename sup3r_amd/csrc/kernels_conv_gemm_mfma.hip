@@ -458,7 +458,7 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p16 = lane & 15, kq = lane >> 4;
   const int R = g.Cout, ct = blockIdx.y;
-  int tr = blockIdx.x;
+  int tr = s3_xcd_tile(blockIdx.x, gridDim.x);
   const int t2i = tr % tiles2; tr /= tiles2;
   const int t1i = tr % tiles1; tr /= tiles1;
   const int t0i = tr % tiles0; tr /= tiles0;

@@ -110,6 +110,24 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
     }
   };
 
+  // ---- this workgroup's tiles.  Block b runs on XCD b % 8 and every XCD has
+  // its own L2: an XCD owns a CONTIGUOUS range of tiles and its workgroups walk
+  // it interleaved, so the tiles in flight on one XCD are neighbours and the
+  // halo cells they share (1.9x of the input is read per tile) are L2 hits
+  // instead of a second trip to memory.
+  int t_first, t_step, t_end;
+  {
+    const int G = gridDim.x, b = blockIdx.x, xcd = b % 8;
+    int before = 0;                       // workgroups on lower XCDs
+    for (int q = 0; q < xcd; ++q) before += (G - q + 7) / 8;
+    const int mine = (G - xcd + 7) / 8;   // workgroups on this XCD
+    const long long lo = (long long)n_tiles * before / G;
+    const long long hi = (long long)n_tiles * (before + mine) / G;
+    t_first = (int)lo + b / 8;
+    t_step = mine;
+    t_end = (int)hi;
+  }
+
   // ---- filter fragments (plain): lane (row = co = lane & 15, k-group kq) of
   // k-step s holds w[tap 4s+kq][ci 0..7][co] as bf16 (zero beyond 27 taps / C_out)
   constexpr int NWF = BAND ? 27 : KS;
@@ -173,12 +191,12 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
         *reinterpret_cast<uint4*>(smem + (st & 1) * BUF_BYTES + (HP + (st >> 1)) * 16) =
             make_uint4(0, 0, 0, 0);
     }
-    if ((int)blockIdx.x < n_tiles) stage(blockIdx.x, 0);
+    if (t_first < t_end) stage(t_first, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     TAIL_BARRIER();
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-      const int next = tile + gridDim.x;
-      if (next < n_tiles) stage(next, cur ^ 1);
+    for (int tile = t_first; tile < t_end; tile += t_step) {
+      const int next = tile + t_step;
+      if (next < t_end) stage(next, cur ^ 1);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       TAIL_BARRIER();   // next halo landed, this one free
       cur ^= 1;
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
   }
   // ------------------------------------------------------ compute waves
   TAIL_BARRIER();
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int tile = t_first; tile < t_end; tile += t_step) {
     int n, org0, org1, org2;
     tile_org(tile, n, org0, org1, org2);
     const char* halo = smem + cur * BUF_BYTES;

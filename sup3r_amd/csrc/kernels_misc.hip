@@ -48,6 +48,10 @@ __global__ void gather_kernel(const T* __restrict__ in, T* __restrict__ out,
         ci = ((o0 % b) * b + (o1 % b)) * g.Co + c;
       } break;
       case S3_OP_CROP: i0 = o0 + g.lo[0]; i1 = o1 + g.lo[1]; i2 = o2 + g.lo[2]; break;
+      case S3_OP_DILATE:   // lo[] = stride: out[i s] = in[i], zeros in between
+        zero = (o0 % g.lo[0]) || (o1 % g.lo[1]) || (o2 % g.lo[2]);
+        i0 = o0 / g.lo[0]; i1 = o1 / g.lo[1]; i2 = o2 / g.lo[2];
+        break;
       case S3_OP_PAD: {
         i0 = o0 - g.lo[0]; i1 = o1 - g.lo[1]; i2 = o2 - g.lo[2];
         if (g.pad_mode == S3_PAD_REFLECT) {
@@ -138,6 +142,9 @@ __global__ void gather_bwd_kernel(const float* __restrict__ dout,
             for (int e = 0; e < cnt[2]; ++e)
               acc += at(cand[0][a], cand[1][b], cand[2][e], c, g.Co);
       } break;
+      case S3_OP_DILATE:
+        acc = at(i0 * g.lo[0], i1 * g.lo[1], i2 * g.lo[2], c, g.Co);
+        break;
       case S3_OP_CONCAT:
         acc = at(i0, i1, i2, c + g.c_off, g.rep);
         break;

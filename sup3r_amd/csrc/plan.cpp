@@ -468,8 +468,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
         max_dpre = std::max(max_dpre, (size_t)ot.numel * sizeof(float));
       } break;
       case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
-      case S3_OP_ROLL_T:
+      case S3_OP_ROLL_T: case S3_OP_DILATE:
         fill_gather_geom(pl, d, o.gg);
+        if (d.kind == S3_OP_DILATE)
+          for (int q = 0; q < 3; ++q) o.gg.lo[q] = d.stride[q] < 1 ? 1 : d.stride[q];
         break;
       case S3_OP_CONCAT:
         if (d.in1 < 0) return bad("plan: concat without second input");
@@ -564,7 +566,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             }
             break;
           case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
-          case S3_OP_ROLL_T:
+          case S3_OP_ROLL_T: case S3_OP_DILATE:
             if (dt[root_of(pl, d.in0)] != dt[root_of(pl, d.out)]) {
               demote(d.in0, changed);
               demote(d.out, changed);
@@ -824,7 +826,7 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
       return launch_dense_fwd(ctx, tptr(pl, d.in0), w, b, tptr(pl, d.out), rows, (int)it.dims[4], (int)ot.dims[4], d.act, d.alpha);
     }
     case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
-    case S3_OP_ROLL_T:
+    case S3_OP_ROLL_T: case S3_OP_DILATE:
       return launch_gather(ctx, o.gg, tptr(pl, d.in0), tptr(pl, d.out), tdtype(pl, d.out) ? 2 : 4);
     case S3_OP_CONCAT: {
       // two channel-range copies: x -> out[..., :Cx], exo -> out[..., Cx:]
@@ -1380,7 +1382,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
         }
       } break;
       case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
-      case S3_OP_ROLL_T:
+      case S3_OP_ROLL_T: case S3_OP_DILATE:
         if (wants_grad(d.in0)) {
           float* dst = grad_dest(pl, d.in0);
           rc = launch_gather_bwd(ctx, o.gg, dy, dst);

@@ -512,17 +512,25 @@ class Sup3rGan:
                 raise RuntimeError(
                     f'{type(self).__name__} has no sharded gradient path')
             from .distributed import shard_batch
-            scal = self._compute.new_scalars()
+            scal = None
             extra = {k: calc_loss_kwargs.pop(k) for k in ('mask',)
                      if k in calc_loss_kwargs}
             for j, r in enumerate(mine):
                 kw = dict(calc_loss_kwargs)
                 for k, v in extra.items():
                     kw[k] = None if v is None else shard_batch(v, r, n_shards)
+                # (the loss kernels WRITE their scalar slots: one buffer per
+                # shard, summed on the device)
+                part = self._compute.new_scalars()
                 which, details = self.get_single_grad(
                     shard_batch(low_res, r, n_shards),
                     shard_batch(hi_res_true, r, n_shards), defer=True,
-                    scal=scal, accumulate_wgrad=j > 0, **kw)
+                    scal=part, accumulate_wgrad=j > 0, **kw)
+                if scal is None:
+                    scal = part
+                else:
+                    self._compute.add_scalars(scal, part)
+                    details._scal = scal
             if len(mine) < n_shards:       # the other shards live elsewhere
                 self._compute.allreduce_grads(which)
                 self._compute.allreduce_scalars(scal)

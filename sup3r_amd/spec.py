@@ -40,6 +40,7 @@ OP_PAD = 8
 OP_CROP = 9
 OP_VIEW = 10
 OP_ROLL_T = 11
+OP_DILATE = 12
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -361,9 +362,25 @@ def build_plan(layers, in_shape, param_table=None, fuse=True):
             pmode = pend['mode'] if pend else PAD_ZERO
             ext = [sh[1 + d] + plo[d] + phi[d] for d in range(3)]
             if is_t:
-                if any(v != 1 for v in s) or padding != 'valid':
-                    raise KeyError(f'{cls} with strides != 1 or '
-                                   'padding != valid has no kernel mapping')
+                if padding != 'valid':
+                    raise KeyError(f'{cls} with padding != valid has no '
+                                   'kernel mapping')
+                if any(v != 1 for v in s):
+                    # strided transpose: y[i s + k] += x[i] w[k] is the
+                    # stride-1 transpose of x with s - 1 zeros inserted
+                    # between its cells (the padding before it is real data
+                    # for the transpose, so it is materialised first)
+                    flush_pad()
+                    sh = cur_dims()
+                    dil = [sh[0]] + [(sh[1 + d] - 1) * s[d] + 1
+                                     for d in range(3)] + [sh[4]]
+                    t_d = plan.new_tensor(dil)
+                    plan.ops.append(dict(kind=OP_DILATE, in0=cur, out=t_d,
+                                         stride=list(s)))
+                    cur, sh = t_d, dil
+                    plo, phi, pmode = [0] * 3, [0] * 3, PAD_ZERO
+                    ext = [sh[1 + d] for d in range(3)]
+                    s = [1, 1, 1]
                 full = [ext[d] + k[d] - 1 for d in range(3)]
                 # look ahead for the crop that removes the zero-tail region
                 crop_lo, crop_hi = [0, 0, 0], [0, 0, 0]
@@ -373,8 +390,11 @@ def build_plan(layers, in_shape, param_table=None, fuse=True):
                         crop_lo[d], crop_hi[d] = c[d]
                     consumed = 2
                 need = [k[d] - 1 for d in range(3)]
-                if any(crop_lo[d] < need[d] or crop_hi[d] < need[d]
-                       for d in range(3)):
+                if pmode == PAD_REFLECT and any(
+                        crop_lo[d] < need[d] or crop_hi[d] < need[d]
+                        for d in range(3)):
+                    # (behind a fused REFLECT pad the zero tails of the
+                    # transpose would mix with mirrored data)
                     raise KeyError(
                         f'{cls} whose zero tails are not cropped '
                         '(cropping < kernel_size - 1) has no kernel mapping')

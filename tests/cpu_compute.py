@@ -124,6 +124,9 @@ class CpuGanCompute:
     def new_scalars(self):
         return _Scal()
 
+    def add_scalars(self, dst, src):
+        dst.a += src.a
+
     def tf_generate(self, low_res, hi_res_exo=None, training=False):
         self.gen.build(tuple(np.shape(low_res)))
         return self.gen.oracle.forward(np.asarray(low_res, np.float32),
@@ -151,6 +154,7 @@ class CpuGanCompute:
         if scal is None:
             scal = _Scal()
         a = scal.a
+        a[:] = 0.0                   # the device loss kernels WRITE their slots
         if 'loss_disc' in det:
             a[0] += det['loss_disc']
         if train_gen:

@@ -103,6 +103,11 @@ def run_plan(plan, params, inputs, dtype=np.float64):
             lo = op['lo']
             T[op['out']] = x[:, lo[0]:lo[0] + osh[1], lo[1]:lo[1] + osh[2],
                              lo[2]:lo[2] + osh[3]]
+        elif kind == S.OP_DILATE:
+            st = op['stride']
+            y = np.zeros(osh, dtype=x.dtype)
+            y[:, ::st[0], ::st[1], ::st[2]] = x
+            T[op['out']] = y
         elif kind == S.OP_VIEW:
             T[op['out']] = x.reshape(osh)
         else:

@@ -3,11 +3,13 @@ what is checked here, at its size.
 
 * the full-size C2 generator in the bf16 throughput mode (batch 8: the
   persistent trunk kernel is selected — asserted through ``s3_plan_op_info``)
-  against (i) the oracle doing the SAME roundings (bf16 operands where the
-  device kernel rounds them, bf16 storage where the plan stores bf16; fp32
-  accumulation) — bound 5e-3 of the output scale, it isolates kernel errors
-  from the precision of the mode — and (ii) the exact fp32 oracle — the
-  stated accuracy of the bf16 mode, 3e-2;
+  (i) PER OP against the oracle doing the same roundings, every op fed the
+  device's own input (``helpers.teacher_forced_check``): at most one bf16
+  spacing on at most 1 % of an op's elements, everything else identical —
+  this isolates kernel errors from the precision of the mode, which an
+  end-to-end bound cannot do for a deep bf16 stack (see that helper) — and
+  (ii) end to end against the exact fp32 oracle — the stated accuracy of the
+  bf16 mode, 3e-2;
 * the same generator in the BF16X3 mode (hi*hi + hi*lo + lo*hi on the bf16
   MFMA): L-inf < 1e-3 against the exact fp32 oracle, north_star's tolerance;
 * the production discriminators as whole networks, forward and backward;
@@ -29,7 +31,8 @@ import os
 import numpy as np
 import pytest
 
-from tests.helpers import emulate_plan, rel_linf, rel_max, rel_rms
+from tests.helpers import (emulate_plan, rel_linf, rel_max, rel_rms,
+                           teacher_forced_check)
 
 pytestmark = pytest.mark.gpu
 
@@ -74,37 +77,56 @@ def c2():
     return spec, x, ref, y_ref
 
 
+def _assert_per_op(stats, what, frac16=1e-2, frac32=1e-3):
+    """every op agrees with the oracle on the device's own input"""
+    worst = max(stats, key=lambda d: d['frac'])
+    print(f'{what}: {len(stats)} ops, worst mismatch fraction '
+          f'{worst["frac"]:.2e} (op {worst["op"]}), largest difference '
+          f'{max(d["max_ulp"] for d in stats if d["bf16"]) if any(d["bf16"] for d in stats) else 0:.2f} '
+          'bf16 spacings')
+    for d in stats:
+        if d['bf16']:
+            # a flipped rounding is exactly one spacing; two can only meet
+            # at a power of two
+            assert d['max_ulp'] <= 2.0 and d['frac'] < frac16, d
+        else:
+            assert d['max_ulp'] <= 100 and d['frac'] < frac32, d
+
+
 def test_c2_bf16_full_size_persistent_kernel_vs_oracle(c2):
     spec, x, ref, y_ref = c2
     net = _hip(spec, ref.weights, 'bf16')
     ph = net.plan(x.shape, training=False)
     fwd = _kernels(ph)
     # the benchmarked kernel is the one under test: 33 body convs, the head
-    # convs at T >= 48 and the 64 -> 200 conv all run on the persistent kernel
+    # conv at T = 96 and the 64 -> 200 conv all run on the persistent kernel
     assert fwd.count('mfma_persist') >= 34, fwd
     assert fwd[0] == 'gconv_fewch' and fwd[-1] == 'tail_mfma', fwd
     y = ph.forward(net.dev.to_device(x)).cpu().numpy()
     assert y.shape == (8, 80, 80, 288, 2) and np.isfinite(y).all()
-    # (ii) the accuracy of the bf16 mode itself
+    # (ii) the accuracy of the bf16 mode itself, end to end
     err_mode = rel_linf(y[0], y_ref[0])
+    print(f'C2 bf16 batch 8, end to end vs the fp32 oracle: {err_mode:.2e}')
     assert err_mode < 3e-2, err_mode
-    # (i) the same roundings in the oracle: kernel error only
-    emu = _oracle(spec, x[:1, :6, :6, :6], seed=0, bias_scale=0.0)
-    n_ops, n_store, _ = emulate_plan(emu, ph)
-    assert n_ops == 38 and n_store >= 30, (n_ops, n_store)
-    y_emu = emu.forward(x[:1])
-    err_kernel = rel_linf(y[0], y_emu[0])
-    rms_kernel = rel_rms(y[0], y_emu[0])
-    print(f'C2 bf16 batch 8: vs fp32 oracle {err_mode:.2e}, vs bf16-emulating '
-          f'oracle L-inf {err_kernel:.2e} rms {rms_kernel:.2e}')
-    assert err_kernel < 5e-3, err_kernel
-    assert rms_kernel < 1e-3, rms_kernel
     # samples are independent: every copy of sample 0 in the batch is
     # bit-identical to it, whatever tile / workgroup computed it
     xx = np.repeat(x[:1], 8, axis=0)
     yy = ph.forward(net.dev.to_device(xx)).cpu().numpy()
     for k in range(8):
         np.testing.assert_array_equal(yy[k], y[0])
+    # (i) per op, on the plan that keeps its activations; it runs the trunk
+    # on the same kernels as the inference plan
+    pht = net.plan(x.shape, training=True)
+    fwd_t = _kernels(pht)
+    assert fwd_t.count('mfma_persist') >= 34, fwd_t
+    yt = pht.forward(net.dev.to_device(x)).cpu().numpy()
+    assert rel_linf(yt[0], y_ref[0]) < 3e-2
+    emu = _oracle(spec, x[:1, :6, :6, :6], seed=0, bias_scale=0.0)
+    n_ops, n_store, _ = emulate_plan(emu, pht)
+    assert n_ops == 38 and n_store >= 30, (n_ops, n_store)
+    stats = teacher_forced_check(emu, pht, x, sample=slice(0, 1))
+    assert len(stats) == len(pht.plan.ops)
+    _assert_per_op(stats, 'C2 bf16 batch 8, per op')
 
 
 def test_c2_bf16x3_meets_the_fp32_tolerance(c2):
@@ -185,7 +207,11 @@ def test_disc_st_production_forward_full_size():
 def _fwd_bwd_vs_oracle(spec, shape, precision, seed, tol_y, tol_g,
                        exo_name=None, exo_shape=None):
     """forward + backward of one network on the device vs the oracle that
-    does the device's roundings and uses the device's masks"""
+    does the device's roundings and uses the device's masks.  bf16: the
+    forward is checked per op on the device's own inputs (teacher forcing,
+    see ``helpers.teacher_forced_check``) plus ``tol_y`` end to end against
+    the exact oracle; the backward pass then runs over the device's
+    activations, so its bound is that of the arithmetic."""
     rng = np.random.default_rng(seed)
     x = rng.standard_normal(shape).astype(np.float32)
     exo = None
@@ -197,10 +223,14 @@ def _fwd_bwd_vs_oracle(spec, shape, precision, seed, tol_y, tol_g,
     ph = net.plan(shape, training=True)
     exod = {k: dev.to_device(v) for k, v in (exo or {}).items()}
     y = ph.forward(dev.to_device(x), exod).cpu().numpy()
-    emulate_plan(ref, ph, masks=False)
     y_ref = ref.forward(x, exo)
+    err_y = rel_linf(y, y_ref)
+    assert err_y < tol_y, (precision, err_y)
+    if precision == 'bf16':
+        emulate_plan(ref, ph, masks=False)
+        stats = teacher_forced_check(ref, ph, x, exo)
+        _assert_per_op(stats, f'bf16 {shape} per op')
     emulate_plan(ref, ph, masks=True, rounding=False)
-    assert rel_linf(y, y_ref) < tol_y, (precision, rel_linf(y, y_ref))
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
     dx_ref = ref.backward(dy)
     dx = ph.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
@@ -212,7 +242,7 @@ def _fwd_bwd_vs_oracle(spec, shape, precision, seed, tol_y, tol_g,
         errs[i] = float(np.abs(g - g_ref).max()
                         / max(np.abs(g_ref).max(), 1e-3 * gmax))
     worst = max(errs.values())
-    print(f'{precision} {shape}: y {rel_linf(y, y_ref):.2e}, worst gradient '
+    print(f'{precision} {shape}: y {err_y:.2e} end to end, worst gradient '
           f'error {worst:.2e}')
     assert worst < tol_g, (precision, errs)
     return ph
@@ -225,11 +255,12 @@ def _fwd_bwd_vs_oracle(spec, shape, precision, seed, tol_y, tol_g,
 ])
 def test_production_discriminators_fwd_bwd(cfg, shape):
     """6.1 M / 2.2 M-parameter test discriminators of the reference and the
-    2-D production one: fp32 1e-4 / 1e-3, bf16 (emulated roundings, device
-    masks) 5e-3 / 2e-2"""
+    2-D production one: fp32 1e-4 end to end / 1e-3 gradients; bf16 per op
+    (teacher forced) + 3e-2 end to end / 2e-2 gradients on the device's
+    activations and masks"""
     spec = _load(cfg)
     _fwd_bwd_vs_oracle(spec, shape, 'f32', 31, 1e-4, 1e-3)
-    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 31, 5e-3, 2e-2)
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 31, 3e-2, 2e-2)
 
 
 def test_disc_st_production_kernels_at_reduced_shape():
@@ -261,7 +292,7 @@ def test_disc_st_production_kernels_at_reduced_shape():
         print('shape', shape, 'misses',
               {f: want[f] - got[f] for f in want if want[f] - got[f]})
     assert chosen is not None, 'no reduced shape selects every kernel'
-    _fwd_bwd_vs_oracle(spec, chosen, 'bf16', 17, 5e-3, 2e-2)
+    _fwd_bwd_vs_oracle(spec, chosen, 'bf16', 17, 3e-2, 2e-2)
     _fwd_bwd_vs_oracle(spec, chosen, 'f32', 17, 1e-4, 1e-3)
 
 
@@ -274,12 +305,13 @@ def test_disc_st_production_kernels_at_reduced_shape():
 def test_production_generators_gradients_under_device_masks(cfg, shape):
     """round 1 asserted 5e-2 (f32) / 3e-1 (bf16) relative rms on these and
     blamed LeakyReLU mask flips; with the device's masks given to the oracle
-    the bounds are 1e-3 (f32) and 2e-2 (bf16 with emulated roundings)"""
+    and — in bf16 — the device's activations (teacher forcing) the bounds are
+    1e-3 (f32) and 2e-2 (bf16)"""
     spec = _load(cfg)
     big = shape[0] >= 8
     if not big:
         _fwd_bwd_vs_oracle(spec, shape, 'f32', 21, 1e-4, 1e-3)
-    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 21, 5e-3, 2e-2)
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 21, 3e-2, 2e-2)
 
 
 def test_c4_toy_generator_filters_1():
@@ -292,7 +324,7 @@ def test_c4_toy_generator_filters_1():
                             exo_shape=(4, 12, 12, 16, 1))
     n_par = sum(int(np.prod(p['shape'])) for p in ph.plan.params)
     assert n_par == 1447
-    _fwd_bwd_vs_oracle(spec, (4, 4, 4, 4, 2), 'bf16', 3, 5e-3, 2e-2,
+    _fwd_bwd_vs_oracle(spec, (4, 4, 4, 4, 2), 'bf16', 3, 3e-2, 2e-2,
                        exo_name='topography', exo_shape=(4, 12, 12, 16, 1))
 
 
@@ -479,3 +511,23 @@ def test_c3_chunk_through_run_batched_with_the_c2_generator():
     err = rel_linf(c0, y)
     print(f'C3 chunk through run_batched (bf16) vs oracle: {err:.2e}')
     assert err < 3e-2, err
+
+
+# ----------------------------------------------- strided ConvNDTranspose (X1)
+@pytest.mark.parametrize('spec,shape', [
+    ([{'class': 'Conv3DTranspose', 'filters': 16, 'kernel_size': 3,
+       'strides': 2},
+      {'class': 'Cropping3D', 'cropping': 1},
+      {'alpha': 0.2, 'class': 'LeakyReLU'},
+      {'class': 'Conv3D', 'filters': 2, 'kernel_size': 3}], (2, 5, 6, 7, 3)),
+    ([{'class': 'FlexiblePadding', 'mode': 'REFLECT',
+       'paddings': [[0, 0], [1, 1], [1, 1], [0, 0]]},
+      {'class': 'Conv2DTranspose', 'filters': 8, 'kernel_size': 3,
+       'strides': [2, 3], 'activation': 'relu'},
+      {'class': 'Cropping2D', 'cropping': 2},
+      {'class': 'Conv2D', 'filters': 2, 'kernel_size': 3}], (3, 6, 5, 2)),
+])
+def test_strided_transpose_conv_vs_oracle(spec, shape):
+    """Conv3DTranspose / Conv2DTranspose with strides > 1 (zero insertion +
+    flipped-kernel conv on the device), forward and backward, fp32"""
+    _fwd_bwd_vs_oracle(spec, shape, 'f32', 9, 1e-5, 1e-3)

@@ -137,3 +137,43 @@ def test_bad_expansion_raises():
         S.parse_layers([{'class': 'NotALayer'}])
     with pytest.raises(KeyError):
         S.parse_layers([{'repeat': [{'class': 'Flatten'}]}])
+
+
+STRIDED_T = [
+    # strided Conv3DTranspose / Conv2DTranspose (named in north_star; 0
+    # occurrences in the reference's configs): with and without cropping of
+    # the zero tails, behind a REFLECT pad, anisotropic strides
+    ([{'class': 'Conv3DTranspose', 'filters': 5, 'kernel_size': 3,
+       'strides': 2}], (2, 3, 4, 3, 2), (2, 7, 9, 7, 5)),
+    ([{'class': 'Conv3DTranspose', 'filters': 4, 'kernel_size': 3,
+       'strides': [2, 1, 3]},
+      {'class': 'Cropping3D', 'cropping': [[1, 2], [0, 1], [2, 0]]},
+      {'alpha': 0.2, 'class': 'LeakyReLU'}], (1, 4, 3, 3, 3),
+     (1, 6, 4, 7, 4)),
+    ([{'class': 'FlexiblePadding', 'mode': 'REFLECT',
+       'paddings': [[0, 0], [1, 1], [1, 1], [0, 0]]},
+      {'class': 'Conv2DTranspose', 'filters': 3, 'kernel_size': 3,
+       'strides': 2, 'activation': 'relu'},
+      {'class': 'Cropping2D', 'cropping': 2}], (2, 4, 5, 2), (2, 9, 11, 3)),
+]
+
+
+@pytest.mark.parametrize('spec,shape,out_shape', STRIDED_T)
+def test_strided_transpose_lowering(spec, shape, out_shape):
+    """zero insertion (S3_OP_DILATE) + the stride-1 flipped-kernel conv ==
+    keras ConvNDTranspose(strides=s) as the oracle (pinned against
+    torch.conv_transpose in tests/test_oracle_vs_torch.py) computes it"""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(shape)
+    net = Network(spec)
+    net.init_weights(x, seed=2, bias_scale=0.1)
+    net.cast(np.float64)
+    y_ref = net.forward(x)
+    assert y_ref.shape == out_shape
+    plan = S.build_plan(S.parse_layers(spec), shape)
+    assert plan.out_shape == out_shape
+    assert any(op['kind'] == S.OP_DILATE for op in plan.ops)
+    params = [S.keras_to_canonical(w, p['layout']).astype(np.float64)
+              for w, p in zip(net.weights, plan.params)]
+    y = run_plan(plan, params, {'x': x})
+    np.testing.assert_allclose(y, y_ref, rtol=0, atol=2e-6)
