@@ -110,6 +110,11 @@ int s3_params_set(s3_params* p, int which, int idx, const float* host);
 int s3_params_get(s3_params* p, int which, int idx, float* host);
 void* s3_params_dptr(s3_params* p, int which, int idx);
 int s3_params_zero_grad(s3_params* p);
+/* counter that changes whenever the weights change (set, Adam step,
+ * broadcast): lets a caller reuse a forward result — Sup3rGan._train_batch
+ * runs D(hi_res_true) in the generator step and again, with the SAME
+ * discriminator weights, in the discriminator step (base.py:1001-1025) */
+uint64_t s3_params_version(const s3_params* p);
 /* mean(|x|) of one Adam slot / weight tensor (history columns
  * OptmGen/Adam/m/..., abstract.py:582-586) */
 int s3_params_mean_abs(s3_params* p, int which, int idx, float* host_out);

@@ -22,7 +22,8 @@ EXPORTS = [
     's3_ctx_create', 's3_ctx_destroy', 's3_last_error', 's3_ctx_sync',
     's3_ctx_stream', 's3_params_create', 's3_params_destroy',
     's3_params_total', 's3_params_set', 's3_params_get', 's3_params_dptr',
-    's3_params_zero_grad', 's3_params_mean_abs', 's3_adam_step',
+    's3_params_zero_grad', 's3_params_version', 's3_params_mean_abs',
+    's3_adam_step',
     's3_plan_create', 's3_plan_destroy', 's3_plan_forward',
     's3_plan_backward', 's3_plan_tensor', 's3_plan_workspace_bytes',
     's3_plan_profile_begin', 's3_plan_profile_end',
@@ -97,6 +98,7 @@ def lib():
         's3_params_get': (i32, [vp, i32, i32, pf]),
         's3_params_dptr': (vp, [vp, i32, i32]),
         's3_params_zero_grad': (i32, [vp]),
+        's3_params_version': (u64, [vp]),
         's3_params_mean_abs': (i32, [vp, i32, i32, pf]),
         's3_adam_step': (i32, [vp, f32, f32, f32, f32, i64]),
         's3_plan_create': (i32, [vp, vp, C.POINTER(TensorDesc), i32,

@@ -214,6 +214,26 @@ class HipGanCompute:
         ph = self.disc.plan(tuple(x.shape), training=training, slot=slot)
         return ph.forward(x)
 
+    def _disc_true(self, dph, hr_true, training):
+        """D(hi_res_true).  Within one ``_train_batch`` the generator step and
+        the discriminator step evaluate it on the same tensor with the same
+        discriminator weights (only the generator is updated in between,
+        base.py:1001-1025): the second evaluation — and, in a training plan,
+        its saved activations — is the first one, bit for bit, so it is
+        reused.  Keyed on the tensor's storage, torch's in-place version
+        counter, the weights' version and the plan; anything else recomputes."""
+        key = (hr_true.data_ptr(), getattr(hr_true, '_version', None),
+               tuple(hr_true.shape), self.disc.weights_version, id(dph),
+               bool(training))
+        hit = getattr(self, '_dtrue', None)
+        if hit is not None and hit[0] == key and \
+                not os.environ.get('SUP3R_AMD_NO_DTRUE_REUSE'):
+            return hit[1]
+        out = dph.forward(hr_true)
+        # (the input tensor is kept alive so its address cannot be recycled)
+        self._dtrue = (key, out, hr_true)
+        return out
+
     # --------------------------------------------------- loss (+ gradients)
     def loss_and_grads(self, low_res, hi_res_true, loss_terms,
                        weight_gen_advers=0.001, train_gen=True,
@@ -278,7 +298,7 @@ class HipGanCompute:
             tr = gen_train or disc_train
             dph_t = self.disc.plan(tuple(hr_true.shape), training=tr, slot=0)
             dph_g = self.disc.plan(tuple(hr_true.shape), training=tr, slot=1)
-            d_true = dph_t.forward(hr_true)
+            d_true = self._disc_true(dph_t, hr_true, tr)
             d_gen = dph_g.forward(gen_full)
             nb = d_true.numel()
         if need_disc and (compute_disc or train_disc):

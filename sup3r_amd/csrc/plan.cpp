@@ -257,6 +257,8 @@ extern "C" void* s3_params_dptr(s3_params* p, int which, int idx) {
 
 void s3_params_touch(s3_params* p) { if (p) p->version++; }
 
+extern "C" uint64_t s3_params_version(const s3_params* p) { return p ? p->version : 0; }
+
 extern "C" int s3_params_zero_grad(s3_params* p) {
   if (!p) return S3_EINVAL;
   s3_ctx* ctx = p->ctx;

@@ -373,6 +373,12 @@ class Network:
         _lib.check(rc, self.dev.ctx, 's3_params_mean_abs')
         return float(v.value)
 
+    @property
+    def weights_version(self):
+        """changes whenever the device weights change"""
+        return int(_lib.lib().s3_params_version(self.params)) \
+            if self.built else -1
+
     def zero_grad(self):
         _lib.check(_lib.lib().s3_params_zero_grad(self.params), self.dev.ctx,
                    'zero_grad')

@@ -786,6 +786,9 @@ class Sup3rGan:
         steps = []
         do_gen = only_gen or (train_gen and not gen_too_good)
         do_disc = only_disc or (train_disc and not disc_too_good)
+        # one upload per mini-batch: both steps read the same device tensors
+        # (and the discriminator's pass over the true field is shared)
+        batch = self._resident(batch)
         if do_gen:
             steps.append(self.run_gradient_descent(
                 batch.low_res, batch.high_res, None, optimizer=self.optimizer,
@@ -799,6 +802,16 @@ class Sup3rGan:
                 weight_gen_advers=weight_gen_advers, train_gen=False,
                 train_disc=True, multi_gpu=multi_gpu, defer=True))
         return steps, do_gen, do_disc
+
+    def _resident(self, batch):
+        dev = getattr(self._gen, 'dev', None)
+        if dev is None or not hasattr(dev, 'to_device'):
+            return batch
+
+        class Resident:
+            low_res = dev.to_device(batch.low_res)
+            high_res = dev.to_device(batch.high_res)
+        return Resident
 
     @staticmethod
     def _settle(steps, trained_gen, trained_disc):

@@ -78,19 +78,18 @@ def c2():
 
 
 def _assert_per_op(stats, what, frac16=1e-2, frac32=1e-3):
-    """every op agrees with the oracle on the device's own input"""
+    """every op agrees with the oracle on the device's own input: bf16-stored
+    outputs differ on < 1 % of their elements and there by one bf16 spacing
+    (+ fp32 accumulation noise, 2e-5 of the tensor's scale); fp32-stored ones
+    agree to that noise"""
     worst = max(stats, key=lambda d: d['frac'])
     print(f'{what}: {len(stats)} ops, worst mismatch fraction '
-          f'{worst["frac"]:.2e} (op {worst["op"]}), largest difference '
-          f'{max(d["max_ulp"] for d in stats if d["bf16"]) if any(d["bf16"] for d in stats) else 0:.2f} '
-          'bf16 spacings')
+          f'{worst["frac"]:.2e} (op {worst["op"]}), largest difference beyond '
+          f'one bf16 spacing {max(d["excess"] for d in stats):.2e} of the '
+          'tensor scale')
     for d in stats:
-        if d['bf16']:
-            # a flipped rounding is exactly one spacing; two can only meet
-            # at a power of two
-            assert d['max_ulp'] <= 2.0 and d['frac'] < frac16, d
-        else:
-            assert d['max_ulp'] <= 100 and d['frac'] < frac32, d
+        assert d['excess'] <= (d['noise'] if d['bf16'] else 5 * d['noise']), d
+        assert d['frac'] < (frac16 if d['bf16'] else frac32), d
 
 
 def test_c2_bf16_full_size_persistent_kernel_vs_oracle(c2):
@@ -427,8 +426,12 @@ def test_sharded_gradient_is_the_per_shard_sum():
         det = m.run_gradient_descent(lr, hr, weight_gen_advers=1e-2,
                                      multi_gpu=True, **kw)
         net = m.generator if which == 'gen' else m.discriminator
+        gmax = max(float(np.abs(g).max()) for g in total)
         for g, g_ref in zip(net.grads, total):
-            assert rel_max(g, g_ref) < 2e-3, which
+            # (tensors whose gradient is numerically nothing compare at the
+            # round-off of the large ones)
+            assert np.abs(g - g_ref).max() < 2e-3 * max(
+                float(np.abs(g_ref).max()), 1e-3 * gmax), which
         key = 'loss_gen' if which == 'gen' else 'loss_disc'
         assert abs(float(det[key]) - np.mean(losses)) < 1e-5
         # put the weights back so the next case starts from the oracle's
@@ -531,3 +534,68 @@ def test_strided_transpose_conv_vs_oracle(spec, shape):
     """Conv3DTranspose / Conv2DTranspose with strides > 1 (zero insertion +
     flipped-kernel conv on the device), forward and backward, fp32"""
     _fwd_bwd_vs_oracle(spec, shape, 'f32', 9, 1e-5, 1e-3)
+
+
+def test_pipelined_trunk_wgrad_is_bit_identical(monkeypatch):
+    """conv3_wgrad_bf16_pipe_kernel (next tile prefetched into registers under
+    the MFMAs) walks the same tiles in the same order as the synchronous
+    kernel: identical sums, bit for bit, on ragged tiles and several tiles
+    per workgroup"""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(6)
+    spec = pcc(3, 64) + pcc(3, 64) + pcc(3, 64) + pcc(3, 72) + pcc(3, 2,
+                                                                   act=False)
+    shape = (9, 9, 10, 37, 4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle(spec, x)
+    net = _hip(spec, ref.weights, 'bf16')
+    ph = net.plan(shape, training=True)
+    assert 'bf16_trunk' in _kernels(ph, 'wgrad')
+    y = ph.forward(net.dev.to_device(x))
+    dy = net.dev.to_device(rng.standard_normal(tuple(y.shape)).astype(
+        np.float32))
+    ph.backward(dy)
+    g_pipe = net.grads
+    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_PIPE', '1')
+    ph.backward(dy)
+    g_sync = net.grads
+    monkeypatch.delenv('SUP3R_AMD_NO_WGRAD_PIPE')
+    for a, b in zip(g_pipe, g_sync):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_shared_disc_pass_over_the_true_field_changes_nothing(monkeypatch):
+    """``_train_batch`` evaluates D(hi_res_true) once for the generator step
+    and the discriminator step (same tensor, same discriminator weights in
+    between): weights after the batch are bit-identical to recomputing it, and
+    a changed batch or changed weights are never served from the cache"""
+    from sup3r_amd import Sup3rGan
+    rng = np.random.default_rng(2)
+    lr = rng.standard_normal((4, 4, 4, 4, 2)).astype(np.float32)
+    hr = rng.standard_normal((4, 8, 8, 16, 2)).astype(np.float32)
+
+    def run(reuse):
+        if not reuse:
+            monkeypatch.setenv('SUP3R_AMD_NO_DTRUE_REUSE', '1')
+        Sup3rGan.seed(3)
+        m = Sup3rGan(os.path.join(CFG, 'test_gen_st_2x_4x_2f.json'),
+                     os.path.join(CFG, 'test_disc_st_same.json'),
+                     loss='MeanAbsoluteError', learning_rate=1e-3)
+        m.init_weights(lr.shape, hr.shape)
+
+        class B:
+            low_res, high_res = lr, hr
+        out = [m._train_batch(B, True, False, False, True, False, False, 1e-2)
+               for _ in range(3)]
+        # a different batch through the same model
+        B.high_res = hr[::-1].copy()
+        out.append(m._train_batch(B, True, False, False, True, False, False,
+                                  1e-2))
+        monkeypatch.delenv('SUP3R_AMD_NO_DTRUE_REUSE', raising=False)
+        return out, m.weights
+    d1, w1 = run(True)
+    d0, w0 = run(False)
+    for a, b in zip(d1, d0):
+        assert a == b
+    for a, b in zip(w1, w0):
+        np.testing.assert_array_equal(a, b)
