@@ -327,6 +327,173 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
 #undef TAIL_BARRIER
 }
 
+
+// ---------------------------------------------------------------------------
+// Sliding-window variant for C_out = 2 (the banded form above): the kernel is
+// bound by what one CU can pull in (~10 B / clk / CU, MI355X_MICROARCH.md),
+// not by HBM — with 4 x 8 x 64 tiles every input cell is fetched 1.93 times
+// (6 x 10 x 66 halo cells per 2048 positions; the XCD-contiguous tile order
+// makes the repeats L2 hits, FETCH_SIZE = 1.00x algorithmic, but they still
+// cross the L2 -> CU path).  Here a workgroup owns a COLUMN of 16 x 64
+// positions and walks it along s0: per output row it brings in ONE new input
+// plane (18 x 66 cells) into a 4-slot ring — planes s0 - 1, s0, s0 + 1 are the
+// taps a = 0, 1, 2 of row s0 — so a cell is fetched 1.16 x (in-plane halo)
+// x 22 / 20 (two extra planes per 20-row segment) = 1.28 times.  Same wave
+// roles as above: 8 compute waves (one 2 x 64 position set per row each, 27
+// banded MFMAs in the same order as the tile kernel: bit-identical results),
+// 4 staging waves (LDS-DMA of the next plane under the current row's MFMAs),
+// one raw barrier per row.
+constexpr int S1 = 16, S2 = 64, SEG0 = 20;
+constexpr int P1 = S1 + 2, P2 = S2 + 2;
+constexpr int PLANE_CELLS = P1 * P2;                    // 1188
+constexpr int PLANE_BYTES = ((PLANE_CELLS + 63) / 64) * 64 * 16;   // 19,456 incl. pad
+constexpr int NSLOT = 4;
+constexpr int SLIDE_LDS = NSLOT * PLANE_BYTES;          // 77,824
+
+__global__ __launch_bounds__(NTH) void conv_tail_slide_kernel(
+    const unsigned short* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ bias, float* __restrict__ y, ConvGeom g,
+    int segs0, int tiles1, int tiles2, int n_units) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, kq = lane >> 4;
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+  auto clampi = [](int i, int d) { return i < 0 ? 0 : (i > d - 1 ? d - 1 : i); };
+
+  // XCD-contiguous unit ranges (see conv_tail_mfma_kernel)
+  int u_first, u_step, u_end;
+  {
+    const int G = gridDim.x, b = blockIdx.x, xcd = b % 8;
+    int before = 0;
+    for (int q = 0; q < xcd; ++q) before += (G - q + 7) / 8;
+    const int mine = (G - xcd + 7) / 8;
+    u_first = (int)((long long)n_units * before / G) + b / 8;
+    u_step = mine;
+    u_end = (int)((long long)n_units * (before + mine) / G);
+  }
+  // unit -> (n, s0 segment, s1 tile, t tile); t fastest so neighbours share L2
+  auto unit_org = [&](int u, int& n, int& r0, int& o1, int& o2) __attribute__((always_inline)) {
+    int tr = u;
+    o2 = (tr % tiles2) * S2; tr /= tiles2;
+    o1 = (tr % tiles1) * S1; tr /= tiles1;
+    r0 = (tr % segs0) * SEG0; tr /= segs0;
+    n = tr;
+  };
+  // input plane of padded row index hr (= output row hr - lo0 ... reflect) -> ring slot
+  auto stage_plane = [&](int n, int hr, int o1, int o2, int slot) __attribute__((always_inline)) {
+    const unsigned short* xn = x + (size_t)n * D0 * D1 * D2 * 8;
+    const int i0 = clampi(s3_reflect(hr - g.lo[0], D0), D0);
+    const int i2 = clampi(s3_reflect(o2 + lane - g.lo[2], D2), D2);
+    char* bufp = smem + slot * PLANE_BYTES;
+    const int sw = wave - NCW;
+    for (int row = sw; row < P1; row += NDW) {
+      const int i1 = clampi(s3_reflect(o1 + row - g.lo[1], D1), D1);
+      const unsigned short* src = xn + (((size_t)i0 * D1 + i1) * D2 + i2) * 8;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(bufp + row * (P2 * 16)), 16, 0, 0);
+    }
+    const int st = tid - NCW * 64;                 // 0 .. 255
+    if (st < 2 * P1) {
+      const int row = st >> 1, c2 = 64 + (st & 1);
+      const int i1 = clampi(s3_reflect(o1 + row - g.lo[1], D1), D1);
+      const int j2 = clampi(s3_reflect(o2 + c2 - g.lo[2], D2), D2);
+      const uint4 v = *reinterpret_cast<const uint4*>(xn + (((size_t)i0 * D1 + i1) * D2 + j2) * 8);
+      *reinterpret_cast<uint4*>(bufp + (row * P2 + c2) * 16) = v;
+    }
+  };
+
+  // banded filter fragments, as in conv_tail_mfma_kernel<true>
+  bf16x8 wf[27];
+  {
+    const int delta = p >> 1, co = p & 1;
+#pragma unroll
+    for (int f = 0; f < 27; ++f) {
+      const int ab = f / 3, s = f % 3;
+      const int c = 4 * s + kq - delta;
+      unsigned u[4] = {0u, 0u, 0u, 0u};
+      if (c >= 0 && c <= 2) {
+        const float* wp = w + (size_t)(ab * 3 + c) * 8 * 2 + co;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = pk2(wp[(2 * e) * 2], wp[(2 * e + 1) * 2]);
+      }
+      uint4 uv = make_uint4(u[0], u[1], u[2], u[3]);
+      wf[f] = __builtin_bit_cast(bf16x8, uv);
+    }
+  }
+  const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+  const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
+#define SLIDE_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+  if (wave >= NCW) {
+    // ---------------------------------------------------- staging waves
+    {
+      // pad cells behind each plane are read against zero filter taps: finite
+      const int st = tid - NCW * 64;
+      const int npad = PLANE_BYTES / 16 - PLANE_CELLS;
+      for (int q = st; q < NSLOT * npad; q += NDW * 64)
+        *reinterpret_cast<uint4*>(smem + (q / npad) * PLANE_BYTES + (PLANE_CELLS + q % npad) * 16) =
+            make_uint4(0, 0, 0, 0);
+    }
+    for (int u = u_first; u < u_end; u += u_step) {
+      int n, r0, o1, o2;
+      unit_org(u, n, r0, o1, o2);
+      const int rows = (r0 + SEG0 <= g.O[0] ? SEG0 : g.O[0] - r0);
+      // padded rows r0 .. r0 + rows + 1 feed output rows r0 .. r0 + rows - 1
+      stage_plane(n, r0, o1, o2, 0);
+      stage_plane(n, r0 + 1, o1, o2, 1);
+      stage_plane(n, r0 + 2, o1, o2, 2);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      SLIDE_BARRIER();                       // planes 0..2 of this unit are in
+      for (int r = 0; r < rows; ++r) {
+        if (r + 1 < rows) stage_plane(n, r0 + r + 3, o1, o2, (r + 3) % NSLOT);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        SLIDE_BARRIER();                     // row r computed, next plane landed
+      }
+    }
+    return;
+  }
+  // ------------------------------------------------------ compute waves
+  // set `wave`: s1 rows 2 wave, 2 wave + 1 of the column; column j = lane & 15:
+  // s1 row j >> 3, base t = (j & 7) * 8; k-group kq reads cell e = 4 s + kq
+  const unsigned lane_base = (unsigned)((((2 * wave + (p >> 3)) * P2) + (p & 7) * 8 + kq) * 16);
+  for (int u = u_first; u < u_end; u += u_step) {
+    int n, r0, o1, o2;
+    unit_org(u, n, r0, o1, o2);
+    const int rows = (r0 + SEG0 <= g.O[0] ? SEG0 : g.O[0] - r0);
+    SLIDE_BARRIER();
+    for (int r = 0; r < rows; ++r) {
+      f32x4 acc0 = (f32x4){b0, b1, b0, b1}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int f = 0; f < 27; ++f) {
+        const int ab = f / 3, s = f % 3;
+        const int a = ab / 3, b = ab % 3;
+        const unsigned off = (unsigned)(((r + a) % NSLOT) * PLANE_BYTES) + (unsigned)((b * P2 + 4 * s) * 16);
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(smem + lane_base + off);
+        if (f & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], xf, acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f], xf, acc0, 0, 0, 0);
+      }
+      const int o0 = r0 + r, oo1 = o1 + 2 * wave + (p >> 3);
+      const int oo2 = o2 + (p & 7) * 8 + 2 * kq;
+      if (oo1 < g.O[1] && oo2 < g.O[2]) {
+        float* yp = y + ((((size_t)n * g.O[0] + o0) * g.O[1] + oo1) * g.O[2] + oo2) * 2;
+        const f32x4 t = acc0 + acc1;
+        const float v0 = act_sel(t[0], slope), v1 = act_sel(t[1], slope),
+                    v2 = act_sel(t[2], slope), v3 = act_sel(t[3], slope);
+        if (oo2 + 1 < g.O[2]) {
+          __builtin_nontemporal_store((f32x4){v0, v1, v2, v3}, reinterpret_cast<f32x4*>(yp));
+        } else {
+          yp[0] = v0; yp[1] = v1;
+        }
+      }
+      SLIDE_BARRIER();
+    }
+  }
+#undef SLIDE_BARRIER
+}
+
 }  // namespace
 
 bool conv_tail_mfma_supported(const ConvGeom& g) {
@@ -351,9 +518,27 @@ int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES));
     attr_set = true;
   }
+  const bool band = g.Cout == 2 && !getenv("SUP3R_AMD_NO_TAIL_BAND");
+  // read per call: the parity tests flip it between two forwards
+  const char* noslide = getenv("SUP3R_AMD_NO_TAIL_SLIDE");
+  if (band && g.O[0] >= 4 && !(noslide && atoi(noslide))) {
+    static bool slide_attr = false;
+    if (!slide_attr) {
+      S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail_slide_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SLIDE_LDS));
+      slide_attr = true;
+    }
+    const int segs0 = (g.O[0] + SEG0 - 1) / SEG0, st1 = (g.O[1] + S1 - 1) / S1, st2 = (g.O[2] + S2 - 1) / S2;
+    const int n_units = g.N * segs0 * st1 * st2;
+    int sgrid = ctx->num_cu;
+    if (sgrid > n_units) sgrid = n_units;
+    hipLaunchKernelGGL(conv_tail_slide_kernel, dim3(sgrid), dim3(NTH), SLIDE_LDS, ctx->stream,
+                       (const unsigned short*)x, w, bias, y, g, segs0, st1, st2, n_units);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   int grid = ctx->num_cu;
   if (grid > n_tiles) grid = n_tiles;
-  const bool band = g.Cout == 2 && !getenv("SUP3R_AMD_NO_TAIL_BAND");
   auto kern = band ? conv_tail_mfma_kernel<true> : conv_tail_mfma_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), 2 * BUF_BYTES, ctx->stream,
                      (const unsigned short*)x, w, bias, y, g, tiles0, tiles1, tiles2, n_tiles);

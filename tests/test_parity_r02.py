@@ -599,3 +599,29 @@ def test_shared_disc_pass_over_the_true_field_changes_nothing(monkeypatch):
         assert a == b
     for a, b in zip(w1, w0):
         np.testing.assert_array_equal(a, b)
+
+
+def test_sliding_window_tail_conv_is_bit_identical(monkeypatch):
+    """conv_tail_slide_kernel (a workgroup walks a 16 x 64 column along s0 with
+    a 4-plane ring) issues the same banded MFMAs per position as the tile
+    kernel: identical output bits on ragged columns / segments, and the
+    oracle's values within the bf16-mode bound"""
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(7)
+    spec = pcc(3, 64) + pcc(3, 200, act=False) + \
+        [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
+         {'alpha': 0.2, 'class': 'LeakyReLU'}] + pcc(3, 2, act=False)
+    for shape in ((2, 5, 7, 40, 4), (3, 9, 4, 70, 4)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        ref = _oracle(spec, x)
+        y_ref = ref.forward(x)
+        net = _hip(spec, ref.weights, 'bf16')
+        ph = net.plan(shape, training=False)
+        assert _kernels(ph)[-1] == 'tail_mfma'
+        xd = net.dev.to_device(x)
+        y_slide = ph.forward(xd).cpu().numpy()
+        monkeypatch.setenv('SUP3R_AMD_NO_TAIL_SLIDE', '1')
+        y_tile = ph.forward(xd).cpu().numpy()
+        monkeypatch.delenv('SUP3R_AMD_NO_TAIL_SLIDE')
+        np.testing.assert_array_equal(y_slide, y_tile)
+        assert rel_linf(y_slide, y_ref) < 3e-2
