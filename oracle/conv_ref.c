@@ -44,7 +44,7 @@ int s3ref_conv_valid(const float* x, int64_t N, int64_t D0, int64_t D1, int64_t 
   const int64_t O0 = (D0 - k0) / s0 + 1, O1 = (D1 - k1) / s1 + 1, O2 = (D2 - k2) / s2 + 1;
   if (O0 < 1 || O1 < 1 || O2 < 1) return -1;
   const int64_t rows = N * O0 * O1;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 1)
   for (int64_t r = 0; r < rows; ++r) {
     const int64_t o1 = r % O1, o0 = (r / O1) % O0, n = r / (O1 * O0);
     float acc[TB][1024];

@@ -260,4 +260,17 @@ int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
 int launch_fill(s3_ctx* ctx, float* p, int64_t n, float v);
 int launch_mean_abs(s3_ctx* ctx, const float* p, int64_t n, float* out_dev);
 int ensure_scratch(s3_ctx* ctx, size_t bytes);
+
+// whole-network kernel for small 2-D conv stacks (kernels_fused2d.hip)
+struct Fused2dLayer {
+  ConvGeom g;
+  int in_t, out_t, res_t;   // tensor ids (res_t < 0: none)
+  int64_t w_off, b_off;     // float offsets into the weight buffer (b_off < 0: no bias)
+};
+struct Fused2dPlan;
+Fused2dPlan* fused2d_build(s3_ctx* ctx, const std::vector<Fused2dLayer>& layers, int n_tensors,
+                           int in_tensor, int out_tensor);
+int fused2d_run(s3_ctx* ctx, Fused2dPlan* p, const float* W, uint64_t wversion, const float* x,
+                float* y);
+void fused2d_free(Fused2dPlan* p);
 void s3_params_touch(s3_params* p);   // weights changed behind the store's back: bump the version

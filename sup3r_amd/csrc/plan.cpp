@@ -111,6 +111,7 @@ struct s3_plan {
   uint64_t graph_version = 0;
   int eager_forwards = 0;
   bool graph_off = false;
+  Fused2dPlan* fused2d = nullptr;   // whole-network kernel (small 2-D inference plans)
 };
 
 static int plan_alloc(s3_plan* pl, void** out, size_t bytes) {
@@ -744,6 +745,26 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     }
   }
   pl->gwritten.assign(n_tensors, 0);
+  // small 2-D conv stacks (the spatial generators at test / C1 sizes): one launch
+  // for the whole op list, activations in LDS
+  if (!training && precision == S3_PREC_BF16 && n_inputs == 1) {
+    std::vector<Fused2dLayer> fl;
+    bool ok = true;
+    for (auto& o : pl->ops) {
+      if (o.d.kind != S3_OP_CONV) { ok = false; break; }
+      Fused2dLayer f;
+      f.g = o.cg;
+      f.in_t = root_of(pl, o.d.in0);
+      f.out_t = root_of(pl, o.d.out);
+      f.res_t = o.d.res >= 0 ? root_of(pl, o.d.res) : -1;
+      f.w_off = params->p[o.d.w].offset;
+      f.b_off = o.d.b >= 0 ? params->p[o.d.b].offset : -1;
+      fl.push_back(f);
+    }
+    if (ok) pl->fused2d = fused2d_build(ctx, fl, n_tensors, root_of(pl, pl->inputs[0]), root_of(pl, output));
+    if (getenv("SUP3R_AMD_TRACE"))
+      fprintf(stderr, "[plan] fused 2-D whole-network kernel: %s\n", pl->fused2d ? "yes" : "no");
+  }
   *out = pl;
   return S3_OK;
 }
@@ -762,6 +783,7 @@ extern "C" void s3_plan_destroy(s3_plan* pl) {
   if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
   for (auto& e : pl->prof_ev) (void)hipEventDestroy(e);
   for (void* p : pl->owned) (void)hipFree(p);
+  fused2d_free(pl->fused2d);
   delete pl;
 }
 
@@ -936,6 +958,16 @@ extern "C" int s3_plan_forward(s3_plan* pl, const void* const* inputs, void* out
   if (pl->prof_cap > 0 && pl->prof_n < pl->prof_cap)
     ev = pl->prof_ev.data() + (size_t)pl->prof_n * (n_ops + 1);
   int rc;
+  if (!ev && pl->fused2d && !getenv("SUP3R_AMD_NO_FUSED2D")) {
+    rc = bind_inputs(pl, inputs);
+    if (rc) return rc;
+    float* dst = output ? (float*)output : tptr(pl, pl->output);
+    rc = fused2d_run(ctx, pl->fused2d, pl->params->buf[S3_BUF_W], pl->params->version,
+                     (const float*)inputs[0], dst);
+    if (rc) return rc;
+    pl->forward_done = true;
+    return S3_OK;
+  }
   if (!ev && graph_wanted(pl)) {
     for (size_t i = 0; i < pl->inputs.size(); ++i) {
       if (!inputs || !inputs[i]) S3_FAIL(ctx, S3_EINVAL, "forward: null input pointer");
@@ -1013,6 +1045,12 @@ extern "C" int s3_plan_tensor_dtype(const s3_plan* pl, int32_t id) {
   if (!pl || id < 0 || id >= (int)pl->t.size()) return S3_EINVAL;
   int r = id;
   while (pl->t[r].alias_root >= 0) r = pl->t[r].alias_root;
+  // the whole-network kernel keeps every intermediate tensor in LDS as bf16
+  if (pl->fused2d && !getenv("SUP3R_AMD_NO_FUSED2D")) {
+    int out_r = pl->output;
+    while (pl->t[out_r].alias_root >= 0) out_r = pl->t[out_r].alias_root;
+    return (pl->t[r].is_input || r == out_r) ? 0 : 1;
+  }
   return pl->t[r].dtype;
 }
 
@@ -1053,11 +1091,13 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
     } else if (!o.io.out_bf16 && !res && conv_small_supported(o.cg, o.io.in_bf16)) {
       fwd = S3_FWD_SMALL;
     }
+    const bool fused = pl->fused2d && !pl->training && !getenv("SUP3R_AMD_NO_FUSED2D");
+    if (fused) fwd = S3_FWD_FUSED2D;
     v[S3_OPINFO_FWD] = fwd;
     v[S3_OPINFO_IN16] = o.io.in_bf16; v[S3_OPINFO_OUT16] = o.io.out_bf16; v[S3_OPINFO_RES16] = o.io.res_bf16;
     // operands rounded to bf16 by the forward kernel
     v[S3_OPINFO_FWD_BF16_OPS] = (pl->precision == S3_PREC_BF16 &&
-                                 (fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 ||
+                                 (fwd == S3_FWD_FUSED2D || fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 ||
                                   fwd == S3_FWD_GCONV || fwd == S3_FWD_GCONV_FEWCH || fwd == S3_FWD_TAIL_MFMA)) ? 1 : 0;
     if (pl->training) {
       int wg = S3_WGRAD_DIRECT;

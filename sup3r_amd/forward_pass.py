@@ -311,7 +311,7 @@ class ForwardPass:
                   and not getattr(model, 'hr_exo_features', [])
                   and domain.shape[-1] == len(model.lr_features))
         if not simple:
-            return self.run(domain, out=out, writer=writer)
+            return self.run_chunks(domain, out=out, writer=writer)
         dev, L = gen.dev, _lib.lib()
         ids = self.my_chunks()
         if max_chunks is not None:
@@ -530,14 +530,11 @@ class ForwardPass:
                 L.s3_host_unregister(dev.ctx, C.c_void_p(out.ctypes.data))
         return done
 
-    def run(self, domain, out=None, writer=None):
-        """Process this rank's chunks of ``domain`` (s1, s2, t, features).
-
-        ``out``: optional pre-allocated hi-res array (s1*s, s2*s, t*te, f_out)
-        each cropped chunk is placed into (ranks write disjoint windows).
-        ``writer(chunk_index, hr_slice, data)`` is called per chunk instead when
-        given (file output lives in sup3r's writers).  Returns the number of
-        chunks run."""
+    def run_chunks(self, domain, out=None, writer=None):
+        """The reference-shaped loop (``ForwardPass._run_serial``,
+        forward_pass.py:451-500): one ``run_chunk`` → ``model.generate`` per
+        chunk through host numpy.  Works for every model (exogenous inputs,
+        4-D and multi-step models); host-bound at ~10 chunks/s."""
         done = 0
         for idx in self.my_chunks():
             hr = self.run_chunk(domain, idx)
@@ -548,3 +545,26 @@ class ForwardPass:
                 out[sl] = hr
             done += 1
         return done
+
+    def run(self, domain, out=None, writer=None, batch=8):
+        """Process this rank's chunks of ``domain`` (s1, s2, t, features) —
+        what ``ForwardPass.run`` (forward_pass.py:427-449) is to a strategy.
+
+        ``out``: optional pre-allocated hi-res array (s1*s, s2*s, t*te, f_out)
+        each cropped chunk is placed into (ranks write disjoint windows).
+        ``writer(chunk_index, hr_slice, data)`` is called per chunk instead when
+        given (file output lives in sup3r's writers).  Returns the number of
+        chunks run.
+
+        Single-step 5-D models without exogenous inputs go through the
+        device-resident executor (:meth:`run_batched`, ~300 chunks/s, the same
+        bits — ``tests/test_forward_pass_gpu.py``); everything else through
+        the chunk-by-chunk loop (:meth:`run_chunks`)."""
+        model = self.model
+        if getattr(model, '_gen', None) is not None and \
+                getattr(model, 'is_5d', False) and \
+                not getattr(model, 'hr_exo_features', []) and \
+                domain.shape[-1] == len(getattr(model, 'lr_features', [])):
+            return self.run_batched(domain, out=out, writer=writer,
+                                    batch=batch)
+        return self.run_chunks(domain, out=out, writer=writer)

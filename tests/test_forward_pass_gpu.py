@@ -39,7 +39,7 @@ def test_run_batched_equals_run(batch):
     fwp = ForwardPass(model, slicer)
     ref = np.zeros(slicer.hr_shape + (2,), np.float32)
     got = np.full(slicer.hr_shape + (2,), np.nan, np.float32)
-    n_ref = fwp.run(domain, out=ref)
+    n_ref = fwp.run_chunks(domain, out=ref)
     n = fwp.run_batched(domain, out=got, batch=batch)
     assert n == n_ref == slicer.n_chunks
     np.testing.assert_array_equal(got, ref)
@@ -74,7 +74,7 @@ def test_run_batched_errors():
     # MemoryError from the output check, in both executors
     model.generator.set_weights(
         [np.zeros_like(w) for w in model.generator.weights])
-    for runner in (fwp.run, fwp.run_batched):
+    for runner in (fwp.run_chunks, fwp.run_batched, fwp.run):
         with pytest.raises(MemoryError):
             runner(domain, out=np.zeros(slicer.hr_shape + (2,), np.float32))
 

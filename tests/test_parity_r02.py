@@ -625,3 +625,79 @@ def test_sliding_window_tail_conv_is_bit_identical(monkeypatch):
         monkeypatch.delenv('SUP3R_AMD_NO_TAIL_SLIDE')
         np.testing.assert_array_equal(y_slide, y_tile)
         assert rel_linf(y_slide, y_ref) < 3e-2
+
+
+# ------------------------------------------------ whole-network 2-D kernel (C1)
+def _t2(filters, act='relu'):
+    return [{'class': 'FlexiblePadding', 'mode': 'REFLECT',
+             'paddings': [[0, 0], [3, 3], [3, 3], [0, 0]]},
+            {'class': 'Conv2DTranspose', 'filters': filters, 'kernel_size': 3,
+             'strides': 1, 'activation': act},
+            {'class': 'Cropping2D', 'cropping': 4}]
+
+
+FUSED_CHAINS = {
+    'one conv to the output': _t2(2, None),
+    'two convs': _t2(64) + _t2(2, None),
+    'residual': _t2(64) + [{'class': 'SkipConnection', 'name': 'a'}] + _t2(64)
+    + _t2(64, None) + [{'class': 'SkipConnection', 'name': 'a'}] + _t2(2, None),
+    'depth to space': _t2(64) + _t2(256, None) + [
+        {'class': 'SpatialExpansion', 'spatial_mult': 2},
+        {'class': 'Activation', 'activation': 'relu'}] + _t2(2, None),
+    'zero padding': [
+        {'class': 'Conv2D', 'filters': 32, 'kernel_size': 3, 'padding': 'same'},
+        {'alpha': 0.2, 'class': 'LeakyReLU'},
+        {'class': 'Conv2D', 'filters': 3, 'kernel_size': 3, 'padding': 'same'}],
+}
+
+
+@pytest.mark.parametrize('name', sorted(FUSED_CHAINS))
+@pytest.mark.parametrize('shape', [(3, 10, 10, 2), (2, 5, 7, 2)])
+def test_fused_2d_kernel_short_chains(name, shape, monkeypatch):
+    """fused2d_kernel on chains short enough for the bf16 roundings not to
+    cascade: against the oracle doing the same roundings (bf16 operands, bf16
+    intermediate tensors) 2e-3 of the output scale — conv, multi-fragment
+    C_out, residual, depth-to-space, reflect and zero borders, ragged
+    fragments — and against the op-by-op plan of the same precision"""
+    spec = FUSED_CHAINS[name]
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle(spec, x)
+    y_exact = ref.forward(x)
+    net = _hip(spec, ref.weights, 'bf16')
+    ph = net.plan(shape, training=False)
+    assert set(_kernels(ph)) == {'fused2d'}, _kernels(ph)
+    y = ph.forward(net.dev.to_device(x)).cpu().numpy()
+    assert y.shape == y_exact.shape
+    emulate_plan(ref, ph)
+    y_emu = ref.forward(x)
+    err = rel_linf(y, y_emu)
+    print(f'fused2d {name} {shape}: vs emulating oracle {err:.2e}, vs exact '
+          f'{rel_linf(y, y_exact):.2e}')
+    assert err < 2e-3, err
+    monkeypatch.setenv('SUP3R_AMD_NO_FUSED2D', '1')
+    y_ops = ph.forward(net.dev.to_device(x)).cpu().numpy()
+    monkeypatch.delenv('SUP3R_AMD_NO_FUSED2D')
+    assert rel_linf(y, y_ops) < 2e-2
+
+
+def test_fused_2d_kernel_c1_generator():
+    """BASELINE config C1: gen_2x_2f (36 Conv2DTranspose layers, 1 368 706
+    parameters) at the reference's test shapes through ONE launch; the bf16
+    mode's end-to-end bound against the exact oracle, samples independent"""
+    spec = _load('gen_2x_2f.json')
+    rng = np.random.default_rng(42)
+    for shape in ((15, 5, 5, 2), (3, 10, 10, 2)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        ref = _oracle(spec, x, seed=0)
+        y_ref = ref.forward(x)
+        net = _hip(spec, ref.weights, 'bf16')
+        ph = net.plan(shape, training=False)
+        assert set(_kernels(ph)) == {'fused2d'}
+        y = ph.forward(net.dev.to_device(x)).cpu().numpy()
+        assert y.shape == (shape[0], 2 * shape[1], 2 * shape[2], 2)
+        err = rel_linf(y, y_ref)
+        print(f'C1 fused forward {shape}: {err:.2e} vs the exact oracle')
+        assert err < 3e-2, err
+        y1 = net(x[1:2]).cpu().numpy()
+        np.testing.assert_array_equal(y1[0], y[1])
