@@ -23,6 +23,9 @@ Other modes (``value`` is then that mode's rate):
                 SUM, ``scaling = strong``); --config c2 | c4 | c4toy
   --mode c3     the per-chunk executor over a 400x400x720 domain tiled into
                 20x20x48 chunks, chunks sharded over the ranks
+  --mode c1     BASELINE configs[0]: the spatial 2x generator (gen_2x_2f, 36
+                Conv2DTranspose layers) on (--batch, 10, 10, 2) observations —
+                one whole-network launch per forward (kernels_fused2d.hip)
 """
 import argparse
 import csv
@@ -394,7 +397,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mode', default='infer',
-                    choices=['infer', 'train', 'c3'])
+                    choices=['infer', 'train', 'c3', 'c1'])
     ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c4toy'],
                     help='--mode train: which GAN')
     ap.add_argument('--batch', type=int, default=None,
@@ -471,6 +474,44 @@ def main():
                                        'reduce (SUM) of the flat gradient '
                                        'buffer per step'},
                 train=out)))
+        return
+
+    if args.mode == 'c1':
+        from sup3r_amd.engine import Device, Network
+        with open(os.path.join(CFGDIR, 'gen_2x_2f.json')) as f:
+            spec1 = json.load(f)
+        dev = Device.get(local_rank)
+        B = args.batch or 256
+        shape = (B, 10, 10, 2)
+        net = Network(spec1, name='generator', device=dev, precision='bf16')
+        net.build(shape, seed=0)
+        ph = net.plan(shape, training=False)
+        fused = ph.op_info(0)['fwd'] == 'fused2d'
+        x = dev.to_device(np.random.default_rng(42 + rank).standard_normal(
+            shape).astype(np.float32))
+        out = dev.empty((B, 20, 20, 2))
+        for _ in range(max(args.warmup, 3)):
+            ph.forward(x, out=out)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ph.forward(x, out=out)
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t0)
+        assert torch.isfinite(out).all().item()
+        if rank == 0:
+            print(json.dumps(dict(
+                base, metric='samples/sec (observations), generator forward, '
+                             'spatial 2x GAN (C1)',
+                value=world * B * args.steps / el, unit='samples/s',
+                ms_per_step=el / args.steps * 1e3, scaling='weak',
+                dtype='bf16',
+                config={'workload': f'C1: gen_2x_2f forward, lo-res ({B},10,10,2)'
+                                    f' -> hi-res ({B},20,20,2) per GPU per '
+                                    'step, 0.274 GFLOP per observation',
+                        'kernel': 'fused2d_kernel (whole network, one launch)'
+                        if fused else 'op-by-op launches',
+                        'parallelism': f'observations sharded x{world}'})))
         return
 
     if args.mode == 'c3':

@@ -33,9 +33,7 @@ typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
 typedef float hf32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int GT_N = 64;       // output-channel tile (4 fragments)
-constexpr int GT_MF = 2;       // position fragments per wave
 constexpr int GT_WAVES = 4;
-constexpr int GT_POS = GT_WAVES * GT_MF * 16;   // 128 positions per workgroup
 
 __device__ inline unsigned pk2(float a, float b) {
   hf32x2 v = {a, b};
@@ -71,7 +69,12 @@ __global__ void gconv_pack_kernel(const float* __restrict__ w, unsigned short* _
 
 // ADJ = false: forward gather  i = o*s + tap - lo   (reflect / zero boundary)
 // ADJ = true : adjoint gather  o = (i + lo - tap)/s  where exact and in range
-template <bool ADJ>
+// MF: position fragments per wave.  The four filter fragments of a (tap, k-chunk)
+// come from L1 / L2 for every wave: with MF = 2 they are two thirds of a
+// wave's vector-memory bytes (4 KB of filter + 2 KB of gathered cells per 8
+// MFMAs), with MF = 4 half (4 + 4 KB per 16 MFMAs) — used whenever the grid
+// still fills the chip.
+template <bool ADJ, int MF>
 __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, const float* __restrict__ res,
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
             G2 = ADJ ? g.D[2] + 2 * f2 : g.O[2];
   const int S0 = ADJ ? g.O[0] : g.D[0], S1 = ADJ ? g.O[1] : g.D[1], S2 = ADJ ? g.O[2] : g.D[2];
   const int ct = blockIdx.y;
-  const int64_t pbase = (int64_t)blockIdx.x * GT_POS + wave * (GT_MF * 16);
+  const int64_t pbase = (int64_t)blockIdx.x * (GT_WAVES * MF * 16) + wave * (MF * 16);
 
   // strided data gradient: positions are enumerated per residue class
   // (c mod s per axis, blockIdx.z) — all lanes of a workgroup then share the
@@ -108,17 +111,17 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
     E0 = (G0 - r0 + g.s[0] - 1) / g.s[0]; E1 = (G1 - r1 + g.s[1] - 1) / g.s[1];
     E2 = (G2 - r2 + g.s[2] - 1) / g.s[2];
     Pc = (int64_t)g.N * E0 * E1 * E2;
-    if ((int64_t)blockIdx.x * GT_POS >= Pc) return;
+    if ((int64_t)blockIdx.x * (GT_WAVES * MF * 16) >= Pc) return;
   }
   const int st0 = strided ? g.s[0] : 1, st1 = strided ? g.s[1] : 1, st2 = strided ? g.s[2] : 1;
   const int ta0 = strided ? (r0 + g.lo[0]) % g.s[0] : 0, tb0 = strided ? (r1 + g.lo[1]) % g.s[1] : 0,
             tc0 = strided ? (r2 + g.lo[2]) % g.s[2] : 0;
 
-  int pn[GT_MF], c0[GT_MF], c1[GT_MF], c2[GT_MF];
-  int64_t plin[GT_MF];
-  bool pok[GT_MF];
+  int pn[MF], c0[MF], c1[MF], c2[MF];
+  int64_t plin[MF];
+  bool pok[MF];
 #pragma unroll
-  for (int m = 0; m < GT_MF; ++m) {
+  for (int m = 0; m < MF; ++m) {
     int64_t p = pbase + m * 16 + p16;
     pok[m] = p < Pc;
     if (!pok[m]) p = Pc - 1;
@@ -132,22 +135,22 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
       plin[m] = (((int64_t)pn[m] * G0 + c0[m]) * G1 + c1[m]) * G2 + c2[m];
     }
   }
-  f32x4 acc[GT_MF][4];
+  f32x4 acc[MF][4];
 #pragma unroll
-  for (int m = 0; m < GT_MF; ++m)
+  for (int m = 0; m < MF; ++m)
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) acc[m][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // forward, no padding: the gather address is base(position) + offset(tap)
   bool inrange = !ADJ && g.pad_mode != S3_PAD_REFLECT;
-  int64_t fbase[GT_MF];
+  int64_t fbase[MF];
 #pragma unroll
-  for (int m = 0; m < GT_MF; ++m) fbase[m] = 0;
+  for (int m = 0; m < MF; ++m) fbase[m] = 0;
   if (!ADJ) {
     for (int d = 0; d < 3; ++d)
       inrange = inrange && g.lo[d] == 0 && (g.O[d] - 1) * g.s[d] + g.k[d] <= g.D[d];
     if (inrange) {
 #pragma unroll
-      for (int m = 0; m < GT_MF; ++m)
+      for (int m = 0; m < MF; ++m)
         fbase[m] = ((((int64_t)pn[m] * S0 + c0[m] * g.s[0]) * S1 + c1[m] * g.s[1]) * S2 +
                     c2[m] * g.s[2]) * K;
     }
@@ -161,10 +164,10 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
       for (int tc = tc0; tc < k2n; tc += st2) {
         const int tap = (ta * k1n + tb) * k2n + tc;
         // source cell of each position under this tap
-        const float* src[GT_MF];
-        bool sok[GT_MF];
+        const float* src[MF];
+        bool sok[MF];
 #pragma unroll
-        for (int m = 0; m < GT_MF; ++m) {
+        for (int m = 0; m < MF; ++m) {
           int i0, i1, i2;
           bool ok = true;
           if (!ADJ && inrange) {
@@ -196,12 +199,12 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
         }
         const unsigned short* wt = wpk + ((int64_t)tap * rows_pad + ct * GT_N + p16) * Kp + kq * 8;
         for (int kc = 0; kc < kchunks; ++kc) {
-          bf16x8 wf[4], xf[GT_MF];
+          bf16x8 wf[4], xf[MF];
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf)
             if (nf < nfv) wf[nf] = *reinterpret_cast<const bf16x8*>(wt + (int64_t)nf * 16 * Kp + kc * 32);
 #pragma unroll
-          for (int m = 0; m < GT_MF; ++m) {
+          for (int m = 0; m < MF; ++m) {
             if (x16) {
               // bf16 cells (bf16 saved activations, K % 8 == 0): the lane's 8
               // channels are one 16-B load; src[] was computed in fp32 elements
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
           for (int nf = 0; nf < 4; ++nf)
             if (nf < nfv) {       // wave-uniform: fragments past the last channel are skipped
 #pragma unroll
-              for (int m = 0; m < GT_MF; ++m)
+              for (int m = 0; m < MF; ++m)
                 acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[m], acc[m][nf], 0, 0, 0);
             }
         }
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
   // epilogue: lane (position, kq) owns channels ct*64 + nf*16 + kq*4 .. +3
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
 #pragma unroll
-  for (int m = 0; m < GT_MF; ++m) {
+  for (int m = 0; m < MF; ++m) {
     if (!pok[m]) continue;
     const int64_t p = plin[m];
 #pragma unroll
@@ -696,9 +699,17 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }
-  dim3 grid((unsigned)((P + GT_POS - 1) / GT_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
-  hipLaunchKernelGGL(gconv_mfma_kernel<false>, grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
-                     (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16, in_bf16);
+  const int n_ct = (g.Cout + GT_N - 1) / GT_N;
+  // four position fragments per wave when that still gives >= 2 workgroups per CU
+  const bool wide = (P / (GT_WAVES * 4 * 16)) * n_ct >= 2 * (int64_t)ctx->num_cu && !getenv("SUP3R_AMD_GCONV_MF2");
+  const int pos = GT_WAVES * (wide ? 4 : 2) * 16;
+  dim3 grid((unsigned)((P + pos - 1) / pos), (unsigned)n_ct);
+  if (wide)
+    hipLaunchKernelGGL((gconv_mfma_kernel<false, 4>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
+                       (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16, in_bf16);
+  else
+    hipLaunchKernelGGL((gconv_mfma_kernel<false, 2>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
+                       (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16, in_bf16);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -708,17 +719,26 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
   const int64_t P = frame ? (int64_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
                                 (g.D[2] + 2 * g.lo[2])
                           : (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
-  dim3 grid((unsigned)((P + GT_POS - 1) / GT_POS), (unsigned)((g.Cin + GT_N - 1) / GT_N));
+  const int n_ct = (g.Cin + GT_N - 1) / GT_N;
+  int64_t pw = P;        // positions one grid slice walks
+  int nz = 1;
   if (g.s[0] > 1 || g.s[1] > 1 || g.s[2] > 1) {
     // one grid slice per residue class, sized for the largest class (residue 0)
-    int64_t pc = g.N;
-    for (int d = 0; d < 3; ++d) pc *= (g.D[d] + g.s[d] - 1) / g.s[d];
-    grid.x = (unsigned)((pc + GT_POS - 1) / GT_POS);
-    grid.z = (unsigned)(g.s[0] * g.s[1] * g.s[2]);
+    pw = g.N;
+    for (int d = 0; d < 3; ++d) pw *= (g.D[d] + g.s[d] - 1) / g.s[d];
+    nz = g.s[0] * g.s[1] * g.s[2];
   }
-  hipLaunchKernelGGL(gconv_mfma_kernel<true>, grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
-                     (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
-                     rows_padded(g.Cin), accumulate, frame, 0, 0);
+  const bool wide = (pw / (GT_WAVES * 4 * 16)) * n_ct * nz >= 2 * (int64_t)ctx->num_cu && !getenv("SUP3R_AMD_GCONV_MF2");
+  const int pos = GT_WAVES * (wide ? 4 : 2) * 16;
+  dim3 grid((unsigned)((pw + pos - 1) / pos), (unsigned)n_ct, (unsigned)nz);
+  if (wide)
+    hipLaunchKernelGGL((gconv_mfma_kernel<true, 4>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
+                       (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
+                       rows_padded(g.Cin), accumulate, frame, 0, 0);
+  else
+    hipLaunchKernelGGL((gconv_mfma_kernel<true, 2>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
+                       (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
+                       rows_padded(g.Cin), accumulate, frame, 0, 0);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

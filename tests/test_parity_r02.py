@@ -701,3 +701,38 @@ def test_fused_2d_kernel_c1_generator():
         assert err < 3e-2, err
         y1 = net(x[1:2]).cpu().numpy()
         np.testing.assert_array_equal(y1[0], y[1])
+
+
+def test_gather_mfma_four_fragments_per_wave_is_bit_identical(monkeypatch):
+    """gconv_mfma_kernel<*, 4> (the filter fragments of a tap shared by four
+    position fragments per wave) vs <*, 2>: same MFMAs per position — forward
+    and data gradient, strided and valid layers"""
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(32, 2) + conv(64, 1) + conv(64, 2) + \
+        [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (8, 40, 40, 72, 2)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+    net = Network(spec, precision='bf16')
+    net.build(shape, seed=0)
+    ph = net.plan(shape, training=True)
+    assert 'gconv' in _kernels(ph) and 'gconv' in _kernels(ph, 'dgrad')
+    xd = net.dev.to_device(x)
+
+    def run():
+        y = ph.forward(xd)
+        dy = net.dev.to_device(np.ones(tuple(y.shape), np.float32))
+        dx = ph.backward(dy, need_dx=True).cpu().numpy()
+        return y.cpu().numpy(), dx, net.grads
+    y4, dx4, g4 = run()
+    monkeypatch.setenv('SUP3R_AMD_GCONV_MF2', '1')
+    y2, dx2, g2 = run()
+    monkeypatch.delenv('SUP3R_AMD_GCONV_MF2')
+    np.testing.assert_array_equal(y4, y2)
+    np.testing.assert_array_equal(dx4, dx2)
+    for a, b in zip(g4, g2):
+        np.testing.assert_array_equal(a, b)
