@@ -195,168 +195,6 @@ __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
   }
 }
 
-// Software-pipelined variant for bf16 activations (the training plans keep the
-// trunk in bf16): the global loads of tile i + 1 (7 x 16 B of halo + 3 x 16 B
-// of dPre per thread) are issued right after tile i's LDS images are complete
-// and stay in flight, in registers, under tile i's 144 MFMAs per wave; they
-// land in LDS after the barrier that ends tile i.  The synchronous kernel
-// above alternates an L2-bound staging phase with an MFMA phase (its MFMA
-// phase alone runs at 1 230 TFLOP/s, the whole kernel at 520).
-constexpr int PXI = (BHP * 8 + BNT - 1) / BNT;          // 7 halo chunks per thread
-constexpr int PDI = (BNP * (BCT / 4) + BNT - 1) / BNT;  // 3 dPre float4 per thread
-
-__global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_pipe_kernel(
-    const unsigned short* __restrict__ x, const float* __restrict__ dy,
-    float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
-    int tiles2, int n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* xs = smem;
-  char* ds = smem + XS_BYTES;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int q = lane & 15, kg = lane >> 4;
-  const int cb = wave & 3, ta = wave >> 2;
-  const int ct = blockIdx.y;
-  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
-
-  f32x4 acc[9][2];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  int a_off[3][2];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int th = 8 * (kg & 1) + 4 * h + (q >> 2) + c;
-      a_off[c][h] = ((ta * BH1 + (kg >> 1)) * BH2 + th) * 128 +
-                    ((cb ^ xs_key(th)) << 5) + ((q & 3) << 3);
-    }
-  int b_off[2][2];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int pl = 8 * kg + 4 * h + (q >> 2);
-      b_off[nb][h] = pl * 64 + ((nb ^ ((pl >> 3) & 1)) << 5) + ((q & 3) << 3);
-    }
-
-  uint4 xv[PXI];
-  float4 dv[PDI];
-  auto fetch = [&](int tile) __attribute__((always_inline)) {
-    int tr = tile;
-    const int t2i = tr % tiles2; tr /= tiles2;
-    const int t1i = tr % tiles1; tr /= tiles1;
-    const int t0i = tr % tiles0; tr /= tiles0;
-    const int n = tr;
-    const int org0 = t0i * BT0, org1 = t1i * BT1, org2 = t2i * BT2;
-#pragma unroll
-    for (int u = 0; u < PXI; ++u) {
-      const int item = tid + u * BNT;
-      xv[u] = make_uint4(0, 0, 0, 0);
-      if (item < BHP * 8) {
-        const int hp = item >> 3, ch = item & 7;
-        int h = hp;
-        const int c2 = h % BH2; h /= BH2;
-        const int c1 = h % BH1; h /= BH1;
-        const int c0 = h;
-        int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
-        bool valid = true;
-        if (g.pad_mode == S3_PAD_REFLECT) {
-          i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
-        } else {
-          valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
-        }
-        // cells feeding only out-of-range outputs are multiplied by zero dPre
-        i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
-        i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
-        i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
-        const size_t cell = (((size_t)n * D0 + i0) * D1 + i1) * D2 + i2;
-        if (valid) xv[u] = *reinterpret_cast<const uint4*>(x + cell * 64 + ch * 8);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < PDI; ++u) {
-      const int item = tid + u * BNT;
-      dv[u] = make_float4(0, 0, 0, 0);
-      if (item < BNP * (BCT / 4)) {
-        const int pl = item >> 3, ch = item & 7;
-        const int row = pl / BT2, tt = pl % BT2;
-        const int o0 = org0 + row / BT1, o1 = org1 + row % BT1, o2 = org2 + tt;
-        const int co = ct * BCT + ch * 4;
-        if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && co < g.Cout)
-          dv[u] = *reinterpret_cast<const float4*>(
-              dy + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co);
-      }
-    }
-  };
-  auto commit = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < PXI; ++u) {
-      const int item = tid + u * BNT;
-      if (item < BHP * 8) {
-        const int hp = item >> 3, ch = item & 7;
-        const int c2 = hp % BH2;
-        *reinterpret_cast<uint4*>(xs + hp * 128 + (((ch >> 1) ^ xs_key(c2)) << 5) + ((ch & 1) << 4)) = xv[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < PDI; ++u) {
-      const int item = tid + u * BNT;
-      if (item < BNP * (BCT / 4)) {
-        const int pl = item >> 3, ch = item & 7;
-        const uint2 pk = make_uint2(pk2(dv[u].x, dv[u].y), pk2(dv[u].z, dv[u].w));
-        *reinterpret_cast<uint2*>(ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3)) = pk;
-      }
-    }
-  };
-
-  int tile = blockIdx.x;
-  if (tile < n_tiles) fetch(tile);
-  for (; tile < n_tiles; tile += gridDim.x) {
-    __syncthreads();                 // every wave is done reading the previous images
-    commit();
-    __syncthreads();
-    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);   // in flight under the MFMAs
-    // (not unrolled: the prefetched tile lives in 40 VGPRs across this loop)
-#pragma unroll 1
-    for (int ks = 0; ks < BNP / 32; ++ks) {
-      const int rowb = (((ks >> 1) * BH1) + 2 * (ks & 1)) * BH2 * 128;
-      bf16x8 bfr[2];
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const s16x4 lo = lds_tr(ds + b_off[nb][0] + ks * 32 * 64);
-        const s16x4 hi = lds_tr(ds + b_off[nb][1] + ks * 32 * 64);
-        bfr[nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
-#pragma unroll
-      for (int b = 0; b < 3; ++b)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const s16x4 lo = lds_tr(xs + a_off[c][0] + rowb + b * BH2 * 128);
-          const s16x4 hi = lds_tr(xs + a_off[c][1] + rowb + b * BH2 * 128);
-          const bf16x8 afr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          acc[b * 3 + c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[0], acc[b * 3 + c][0], 0, 0, 0);
-          acc[b * 3 + c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[1], acc[b * 3 + c][1], 0, 0, 0);
-        }
-    }
-  }
-  float* out = partial + (size_t)blockIdx.x * 27 * 64 * g.Cout;
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int co = ct * BCT + nb * 16 + q;
-    if (co < g.Cout) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          out[((size_t)(ta * 9 + t) * 64 + cb * 16 + kg * 4 + r) * g.Cout + co] = acc[t][nb][r];
-    }
-  }
-}
-
 __global__ void wgrad_bf16_partial_reduce(const float* __restrict__ partial,
                                           int n_part, int64_t wsize,
                                           float* __restrict__ dw, int accumulate) {
@@ -817,18 +655,11 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_pipe_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
     attr_set = true;
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
   static const int dbg = getenv("SUP3R_AMD_WGRAD_DBG") ? atoi(getenv("SUP3R_AMD_WGRAD_DBG")) : 0;
-  // (read per call: the parity tests flip it between two backward passes)
-  const char* nopipe = getenv("SUP3R_AMD_NO_WGRAD_PIPE");
-  if (x_bf16 && !dbg && !(nopipe && atoi(nopipe)))
-    hipLaunchKernelGGL(conv3_wgrad_bf16_pipe_kernel, dim3(grid, n_ct), dim3(BNT), BF_LDS,
-                       ctx->stream, (const unsigned short*)x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles);
-  else if (x_bf16)
+  if (x_bf16)
     hipLaunchKernelGGL(conv3_wgrad_bf16_kernel<true>, dim3(grid, n_ct), dim3(BNT), BF_LDS,
                        ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles, dbg);
   else

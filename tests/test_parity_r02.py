@@ -536,34 +536,6 @@ def test_strided_transpose_conv_vs_oracle(spec, shape):
     _fwd_bwd_vs_oracle(spec, shape, 'f32', 9, 1e-5, 1e-3)
 
 
-def test_pipelined_trunk_wgrad_is_bit_identical(monkeypatch):
-    """conv3_wgrad_bf16_pipe_kernel (next tile prefetched into registers under
-    the MFMAs) walks the same tiles in the same order as the synchronous
-    kernel: identical sums, bit for bit, on ragged tiles and several tiles
-    per workgroup"""
-    from sup3r_amd.configs.author_configs import pcc
-    rng = np.random.default_rng(6)
-    spec = pcc(3, 64) + pcc(3, 64) + pcc(3, 64) + pcc(3, 72) + pcc(3, 2,
-                                                                   act=False)
-    shape = (9, 9, 10, 37, 4)
-    x = rng.standard_normal(shape).astype(np.float32)
-    ref = _oracle(spec, x)
-    net = _hip(spec, ref.weights, 'bf16')
-    ph = net.plan(shape, training=True)
-    assert 'bf16_trunk' in _kernels(ph, 'wgrad')
-    y = ph.forward(net.dev.to_device(x))
-    dy = net.dev.to_device(rng.standard_normal(tuple(y.shape)).astype(
-        np.float32))
-    ph.backward(dy)
-    g_pipe = net.grads
-    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_PIPE', '1')
-    ph.backward(dy)
-    g_sync = net.grads
-    monkeypatch.delenv('SUP3R_AMD_NO_WGRAD_PIPE')
-    for a, b in zip(g_pipe, g_sync):
-        np.testing.assert_array_equal(a, b)
-
-
 def test_shared_disc_pass_over_the_true_field_changes_nothing(monkeypatch):
     """``_train_batch`` evaluates D(hi_res_true) once for the generator step
     and the discriminator step (same tensor, same discriminator weights in

@@ -8,7 +8,9 @@ CMD="python $ROOTD/tools/train_probe.py $@"
 i=0
 for grp in \
  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
- "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS" ; do
+ "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS" \
+ "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
+ "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$ROOTD/$OUT/pass$i" -- $CMD > "$ROOTD/$OUT/pass$i.log" 2>&1
 done
@@ -24,7 +26,7 @@ for f in glob.glob(out + '/pass*/**/*counter_collection.csv', recursive=True):
         agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
 with open(out + '/pmc_summary.txt', 'w') as fo:
     for k, d in sorted(agg.items()):
-        if not any(s in k for s in ('wgrad_bf16', 'dgrad_c2', 'wgrad_c2', 'fewch', 'conv3_mfma', 'gconv')):
+        if not any(s in k for s in ('wgrad_bf16', 'dgrad_c2', 'dgrad_s2', 'wgrad_c2', 'fewch', 'conv3_mfma', 'gconv', 'halo32', 'conv_tail', 'gather_bwd')):
             continue
         fo.write(k + '\n')
         for c, v in sorted(d.items()):
