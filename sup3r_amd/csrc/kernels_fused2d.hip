@@ -280,9 +280,12 @@ Fused2dPlan* fused2d_build(s3_ctx* ctx, const std::vector<Fused2dLayer>& L, int 
       if (q == 1 && (th[t] != L[i].g.D[0] || tw[t] != L[i].g.D[1])) return nullptr;
     }
   }
-  // ---- LDS slots by liveness (greedy first fit); a slot = padded cells + slack
-  // for the fragments that run past the last row
-  auto cells_of = [&](int t) { return (th[t] + 2) * (tw[t] + 2) + FMG * 16 + 32; };
+  // ---- LDS slots by liveness (greedy first fit); a slot = the padded cells.
+  // The fragments that run past a tensor's last row read into whatever follows
+  // (another slot, or the slack after the last one): garbage that only reaches
+  // positions dropped at the store.
+  constexpr int kSlackCells = FMG * 16 + 32;
+  auto cells_of = [&](int t) { return (th[t] + 2) * (tw[t] + 2); };
   std::vector<int> slot_off(n_tensors, -1);
   struct Slot { int off, bytes, free_at; };
   std::vector<Slot> slots;
@@ -301,6 +304,7 @@ Fused2dPlan* fused2d_build(s3_ctx* ctx, const std::vector<Fused2dLayer>& L, int 
       if (last_use[L[i].out_t] < 0) return nullptr;   // dead tensor: not worth handling
       place(L[i].out_t, i);
     }
+  total += kSlackCells * 128;
   if (total > 158 * 1024) return nullptr;
   Fused2dPlan* P = new Fused2dPlan();
   P->in = L;

@@ -117,7 +117,7 @@ _BF16_DGRAD = ('mfma_frame', 'mfma_valid', 'mfma_chunked', 'fewch_frame', 's2',
                'c2', 'gconv')
 
 
-def emulate_plan(ref, ph, masks=False, rounding=True):
+def emulate_plan(ref, ph, masks=False, rounding=True, sample=slice(None)):
     """Configure the oracle network ``ref`` (oracle.network.Network over the
     same ``hidden_layers``) to reproduce the numerics of the HIP plan handle
     ``ph`` (sup3r_amd.engine.PlanHandle):
@@ -130,7 +130,7 @@ def emulate_plan(ref, ph, masks=False, rounding=True):
       the one the device used (read from the training plan's saved
       activations), so a pre-activation within round-off of zero cannot flip
       a whole unit between the two backward passes.  Call after the device
-      forward.
+      forward; ``sample`` selects the batch entries the oracle ran.
 
     Returns the number of (convs with bf16 operands, tensors stored as bf16,
     masks installed)."""
@@ -160,7 +160,7 @@ def emulate_plan(ref, ph, masks=False, rounding=True):
             wl[0].emu_dgrad_round = is_bf16_plan and info['dgrad'] in _BF16_DGRAD
             n_ops += int(info['fwd_bf16_ops'])
         if masks and op.get('act', 0):
-            y = ph.tensor(op['out'])
+            y = ph.tensor(op['out'])[sample]
             acts = [ref.layers[li] for li in lis
                     if type(ref.layers[li]).__name__ in ('LeakyReLU',
                                                          'Activation')]

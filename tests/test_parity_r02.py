@@ -204,15 +204,22 @@ def test_disc_st_production_forward_full_size():
 
 
 def _fwd_bwd_vs_oracle(spec, shape, precision, seed, tol_y, tol_g,
-                       exo_name=None, exo_shape=None):
+                       exo_name=None, exo_shape=None, replicate=False):
     """forward + backward of one network on the device vs the oracle that
     does the device's roundings and uses the device's masks.  bf16: the
     forward is checked per op on the device's own inputs (teacher forcing,
     see ``helpers.teacher_forced_check``) plus ``tol_y`` end to end against
     the exact oracle; the backward pass then runs over the device's
-    activations, so its bound is that of the arithmetic."""
+    activations, so its bound is that of the arithmetic.
+
+    ``replicate``: the device batch is ``shape[0]`` copies of ONE sample (and
+    of one output gradient), the oracle runs that sample once — the kernels
+    see the production batch size, the numpy side a 1 / N of the work; weight
+    gradients are then N times the oracle's."""
     rng = np.random.default_rng(seed)
-    x = rng.standard_normal(shape).astype(np.float32)
+    n_rep = shape[0] if replicate else 1
+    oshape = ((1,) + tuple(shape[1:])) if replicate else tuple(shape)
+    x = rng.standard_normal(oshape).astype(np.float32)
     exo = None
     if exo_name:
         exo = {exo_name: rng.standard_normal(exo_shape).astype(np.float32)}
@@ -221,23 +228,32 @@ def _fwd_bwd_vs_oracle(spec, shape, precision, seed, tol_y, tol_g,
     dev = net.dev
     ph = net.plan(shape, training=True)
     exod = {k: dev.to_device(v) for k, v in (exo or {}).items()}
-    y = ph.forward(dev.to_device(x), exod).cpu().numpy()
+    xd = np.repeat(x, n_rep, axis=0) if replicate else x
+    y = ph.forward(dev.to_device(xd), exod).cpu().numpy()
     y_ref = ref.forward(x, exo)
-    err_y = rel_linf(y, y_ref)
+    err_y = rel_linf(y[:oshape[0]], y_ref)
     assert err_y < tol_y, (precision, err_y)
+    if replicate:
+        for k in range(1, n_rep):
+            np.testing.assert_array_equal(y[k], y[0])
     if precision == 'bf16':
         emulate_plan(ref, ph, masks=False)
-        stats = teacher_forced_check(ref, ph, x, exo)
+        stats = teacher_forced_check(ref, ph, x, exo,
+                                     sample=slice(0, oshape[0]))
         _assert_per_op(stats, f'bf16 {shape} per op')
-    emulate_plan(ref, ph, masks=True, rounding=False)
+    emulate_plan(ref, ph, masks=True, rounding=False, sample=slice(
+        0, oshape[0]))
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
     dx_ref = ref.backward(dy)
-    dx = ph.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
-    errs = {'dx': rel_max(dx.reshape(dx_ref.shape), dx_ref)}
-    gmax = max(float(np.abs(g).max()) for g in ref.grads)
+    dyd = np.repeat(dy, n_rep, axis=0) if replicate else dy
+    dx = ph.backward(dev.to_device(dyd), need_dx=True).cpu().numpy()
+    dx = dx.reshape((-1,) + dx_ref.shape[1:])[:oshape[0]]
+    errs = {'dx': rel_max(dx, dx_ref)}
+    gmax = max(float(np.abs(g).max()) for g in ref.grads) * n_rep
     for i, (g, g_ref) in enumerate(zip(net.grads, ref.grads)):
         # tensors whose gradient is numerically nothing compare at the
         # round-off of the large ones
+        g_ref = g_ref * n_rep
         errs[i] = float(np.abs(g - g_ref).max()
                         / max(np.abs(g_ref).max(), 1e-3 * gmax))
     worst = max(errs.values())
@@ -291,8 +307,8 @@ def test_disc_st_production_kernels_at_reduced_shape():
         print('shape', shape, 'misses',
               {f: want[f] - got[f] for f in want if want[f] - got[f]})
     assert chosen is not None, 'no reduced shape selects every kernel'
-    _fwd_bwd_vs_oracle(spec, chosen, 'bf16', 17, 3e-2, 2e-2)
-    _fwd_bwd_vs_oracle(spec, chosen, 'f32', 17, 1e-4, 1e-3)
+    _fwd_bwd_vs_oracle(spec, chosen, 'bf16', 17, 3e-2, 2e-2, replicate=True)
+    _fwd_bwd_vs_oracle(spec, chosen, 'f32', 17, 1e-4, 1e-3, replicate=True)
 
 
 # --------------------------------------------------- generators, masks fixed
@@ -310,7 +326,7 @@ def test_production_generators_gradients_under_device_masks(cfg, shape):
     big = shape[0] >= 8
     if not big:
         _fwd_bwd_vs_oracle(spec, shape, 'f32', 21, 1e-4, 1e-3)
-    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 21, 3e-2, 2e-2)
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 21, 3e-2, 2e-2, replicate=big)
 
 
 def test_c4_toy_generator_filters_1():
