@@ -268,7 +268,7 @@ def measure_traffic(batch, timeout=240):
     combined with --pmc), both in KB, FETCH_SIZE doubled (gfx950 tallies the
     128-B requests of a wide coalesced stream at 64 B).  Only the 33 body-conv
     dispatches of each forward are averaged (positions 2..34 of the 38
-    conv3_mfma_persist_kernel<4> dispatches per forward at this batch: two head
+    conv3_mfma_persist_kernel<4, *> dispatches per forward at this batch: two head
     convs first, three 64-channel passes of the 64 -> 200 conv last)."""
     rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(rocprof):
@@ -293,9 +293,9 @@ def measure_traffic(batch, timeout=240):
                     if r.get('Counter_Name') != counter:
                         continue
                     name = r.get('Kernel_Name', '')
-                    if 'conv3_mfma_persist_kernel<4>' in name:
+                    if 'conv3_mfma_persist_kernel<4' in name:
                         rows.append(r)
-                    elif 'conv_tail_mfma_kernel' in name:
+                    elif 'conv_tail_' in name:
                         tail.append(float(r['Counter_Value']))
         shutil.rmtree(d, ignore_errors=True)
         if not rows or len(rows) % 38:
