@@ -79,8 +79,12 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, const float* __restrict__ res,
     void* __restrict__ yv, ConvGeom g, int64_t P, int rows_pad, int accumulate, int frame,
-    int out_bf16, int x16) {
+    int out_bf16, int x16, int nsplit, float* __restrict__ part) {
   float* __restrict__ y = reinterpret_cast<float*>(yv);
+  // nsplit > 1 (few positions, long contraction): blockIdx.z also enumerates
+  // slices of the (tap, k-chunk) sequence; a slice leaves its raw fp32 sums in
+  // part[slice][position][channel] and gconv_splitk_epilogue finishes the job
+  const int split = nsplit > 1 ? (int)(blockIdx.z % nsplit) : 0;
   // in ADJ mode: g is the FORWARD conv's geometry; positions run over its
   // input grid D, the gathered tensor x is dY on its output grid O, K = C_out
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
   int r0 = 0, r1 = 0, r2 = 0, E0 = G0, E1 = G1, E2 = G2;
   int64_t Pc = P;
   if (strided) {
-    const int cls = blockIdx.z;
+    const int cls = nsplit > 1 ? (int)(blockIdx.z / nsplit) : (int)blockIdx.z;
     r2 = cls % g.s[2]; r1 = (cls / g.s[2]) % g.s[1]; r0 = cls / (g.s[2] * g.s[1]);
     E0 = (G0 - r0 + g.s[0] - 1) / g.s[0]; E1 = (G1 - r1 + g.s[1] - 1) / g.s[1];
     E2 = (G2 - r2 + g.s[2] - 1) / g.s[2];
@@ -159,9 +163,19 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
   const int nfv = (R - ct * GT_N + 15) / 16 < 4 ? (R - ct * GT_N + 15) / 16 : 4;
   const int k0n = g.k[0], k1n = g.k[1], k2n = g.k[2];
   const int kchunks = (K + 31) / 32;      // K % 8 == 0: a lane's 8-channel group is whole or absent
+  // this slice's range of the flattened (visited tap, k-chunk) sequence
+  int it_lo = 0, it_hi = 0x7fffffff;
+  if (nsplit > 1) {
+    const int ntap = ((k0n - ta0 + st0 - 1) / st0) * ((k1n - tb0 + st1 - 1) / st1) * ((k2n - tc0 + st2 - 1) / st2);
+    const int iters = ntap * kchunks;
+    it_lo = (int)((int64_t)iters * split / nsplit);
+    it_hi = (int)((int64_t)iters * (split + 1) / nsplit);
+  }
+  int it_tap = 0;                         // first flattened index of the current tap
   for (int ta = ta0; ta < k0n; ta += st0)
     for (int tb = tb0; tb < k1n; tb += st1)
-      for (int tc = tc0; tc < k2n; tc += st2) {
+      for (int tc = tc0; tc < k2n; tc += st2, it_tap += kchunks) {
+        if (it_tap + kchunks <= it_lo || it_tap >= it_hi) continue;
         const int tap = (ta * k1n + tb) * k2n + tc;
         // source cell of each position under this tap
         const float* src[MF];
@@ -199,6 +213,7 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
         }
         const unsigned short* wt = wpk + ((int64_t)tap * rows_pad + ct * GT_N + p16) * Kp + kq * 8;
         for (int kc = 0; kc < kchunks; ++kc) {
+          if (it_tap + kc < it_lo || it_tap + kc >= it_hi) continue;
           bf16x8 wf[4], xf[MF];
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf)
@@ -238,6 +253,23 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
       }
 
   // epilogue: lane (position, kq) owns channels ct*64 + nf*16 + kq*4 .. +3
+  if (nsplit > 1) {
+    const int64_t Pall = ADJ ? (int64_t)g.N * G0 * G1 * G2 : P;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      if (!pok[m]) continue;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const int ch = ct * GT_N + nf * 16 + kq * 4;
+        if (ch >= R) continue;
+        float* pp = part + ((int64_t)split * Pall + plin[m]) * R + ch;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ch + r < R) pp[r] = acc[m][nf][r];
+      }
+    }
+    return;
+  }
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
 #pragma unroll
   for (int m = 0; m < MF; ++m) {
@@ -290,6 +322,44 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
   }
 }
 
+
+// sums the slices of a split contraction in fixed order, then the forward
+// epilogue (bias, activation, residual, fp32 or bf16 store) or the data
+// gradient's plain / accumulating store
+__global__ void gconv_splitk_epilogue(const float* __restrict__ part, int nsplit, int64_t P, int R,
+                                      const float* __restrict__ bias, const float* __restrict__ res,
+                                      void* __restrict__ yv, int fwd, float slope, int out_bf16,
+                                      int accumulate) {
+  const int64_t total = P * R;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int s = 0; s < nsplit; ++s) v += part[(int64_t)s * total + i];
+    if (fwd) {
+      if (bias) v += bias[i % R];
+      v = v > 0.f ? v : slope * v;
+      if (res) v += res[i];
+    }
+    if (out_bf16) {
+      reinterpret_cast<unsigned short*>(yv)[i] = (unsigned short)(pk2(v, 0.f) & 0xFFFFu);
+    } else {
+      float* y = reinterpret_cast<float*>(yv);
+      y[i] = accumulate ? y[i] + v : v;
+    }
+  }
+}
+
+// Slices of the contraction for a launch of `wgs` workgroups walking `iters`
+// (tap, k-chunk) steps each: only when the grid leaves most CUs idle and the
+// walk is long (the 128 / 256-channel discriminator layers on a few thousand
+// positions: 16 workgroups x 216 dependent steps = 0.34 ms for 1.7 GFLOP)
+int gconv_splits(const s3_ctx* ctx, int64_t wgs, int iters) {
+  if (getenv("SUP3R_AMD_NO_GCONV_SPLITK") || wgs >= ctx->num_cu || iters < 32) return 1;
+  int64_t n = (2 * (int64_t)ctx->num_cu + wgs - 1) / wgs;
+  if (n > iters / 6) n = iters / 6;
+  if (n > 32) n = 32;
+  return n < 2 ? 1 : (int)n;
+}
 
 // ---------------------------------------------------------------------------
 // Few input channels (C_in = 2: hi-res fields into the discriminator, C_in = 4:
@@ -703,14 +773,29 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
   // four position fragments per wave when that still gives >= 2 workgroups per CU
   const bool wide = (P / (GT_WAVES * 4 * 16)) * n_ct >= 2 * (int64_t)ctx->num_cu && !getenv("SUP3R_AMD_GCONV_MF2");
   const int pos = GT_WAVES * (wide ? 4 : 2) * 16;
-  dim3 grid((unsigned)((P + pos - 1) / pos), (unsigned)n_ct);
+  const int nblk = (int)((P + pos - 1) / pos);
+  const int iters = g.k[0] * g.k[1] * g.k[2] * ((g.Cin + 31) / 32);
+  int ns = gconv_splits(ctx, (int64_t)nblk * n_ct, iters);
+  if (ns > 1 && ensure_scratch(ctx, (size_t)ns * P * g.Cout * sizeof(float)) != S3_OK) ns = 1;
+  dim3 grid((unsigned)nblk, (unsigned)n_ct, (unsigned)ns);
   if (wide)
     hipLaunchKernelGGL((gconv_mfma_kernel<false, 4>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
-                       (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16, in_bf16);
+                       (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16, in_bf16,
+                       ns, ctx->scratch);
   else
     hipLaunchKernelGGL((gconv_mfma_kernel<false, 2>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
-                       (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16, in_bf16);
+                       (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16, in_bf16,
+                       ns, ctx->scratch);
   S3_HIP(ctx, hipGetLastError());
+  if (ns > 1) {
+    const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+    const int64_t total = P * g.Cout;
+    int eg = (int)((total + 255) / 256);
+    if (eg > 2048) eg = 2048;
+    hipLaunchKernelGGL(gconv_splitk_epilogue, dim3(eg), dim3(256), 0, ctx->stream, (const float*)ctx->scratch, ns,
+                       P, g.Cout, bias, res, y, 1, slope, out_bf16, 0);
+    S3_HIP(ctx, hipGetLastError());
+  }
   return S3_OK;
 }
 
@@ -730,15 +815,27 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
   }
   const bool wide = (pw / (GT_WAVES * 4 * 16)) * n_ct * nz >= 2 * (int64_t)ctx->num_cu && !getenv("SUP3R_AMD_GCONV_MF2");
   const int pos = GT_WAVES * (wide ? 4 : 2) * 16;
-  dim3 grid((unsigned)((pw + pos - 1) / pos), (unsigned)n_ct, (unsigned)nz);
+  const int nblk = (int)((pw + pos - 1) / pos);
+  // (stride-1 only: a residue class of a strided conv sees 1 - 8 taps)
+  int ns = nz == 1 ? gconv_splits(ctx, (int64_t)nblk * n_ct, g.k[0] * g.k[1] * g.k[2] * ((g.Cout + 31) / 32)) : 1;
+  if (ns > 1 && ensure_scratch(ctx, (size_t)ns * P * g.Cin * sizeof(float)) != S3_OK) ns = 1;
+  dim3 grid((unsigned)nblk, (unsigned)n_ct, (unsigned)(nz * ns));
   if (wide)
     hipLaunchKernelGGL((gconv_mfma_kernel<true, 4>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
                        (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
-                       rows_padded(g.Cin), accumulate, frame, 0, 0);
+                       rows_padded(g.Cin), accumulate, frame, 0, 0, ns, ctx->scratch);
   else
     hipLaunchKernelGGL((gconv_mfma_kernel<true, 2>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
                        (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
-                       rows_padded(g.Cin), accumulate, frame, 0, 0);
+                       rows_padded(g.Cin), accumulate, frame, 0, 0, ns, ctx->scratch);
   S3_HIP(ctx, hipGetLastError());
+  if (ns > 1) {
+    const int64_t total = P * g.Cin;
+    int eg = (int)((total + 255) / 256);
+    if (eg > 2048) eg = 2048;
+    hipLaunchKernelGGL(gconv_splitk_epilogue, dim3(eg), dim3(256), 0, ctx->stream, (const float*)ctx->scratch, ns,
+                       P, g.Cin, nullptr, nullptr, dx, 0, 1.f, 0, accumulate);
+    S3_HIP(ctx, hipGetLastError());
+  }
   return S3_OK;
 }

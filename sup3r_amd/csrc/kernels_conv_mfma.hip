@@ -627,7 +627,11 @@ bool conv_mfma_supported(const ConvGeom& g, int precision) {
     // dgrad frame: full correlation over the padded extent, zero boundary
     const bool full = g.k[d] == 3 && g.lo[d] == 2 && g.O[d] == g.D[d] + 2 &&
                       g.pad_mode == S3_PAD_ZERO;
-    if (!same && !full) return false;
+    // valid padding (the discriminator's 64 -> 128 conv): the halo never
+    // leaves the tensor except under the masked overhang of ragged tiles
+    const bool valid = g.k[d] == 3 && g.lo[d] == 0 && g.O[d] == g.D[d] - 2 &&
+                       g.pad_mode != S3_PAD_REFLECT;
+    if (!same && !full && !valid) return false;
   }
   if (g.d2s > 1 && (g.Cout / (g.d2s * g.d2s)) % 4 != 0) return false;
   if (g.k[2] == 1) return false;   // 2-D nets stay on the direct kernel for now
@@ -683,8 +687,11 @@ bool conv_dgrad_mfma_supported(const ConvGeom& g, int precision) {
 // 64 -> C_out 'same' conv with C_out > 64 (the 64 -> 200 expansion conv): its
 // data gradient contracts over C_out; run it as ceil(C_out / 64) passes of the
 // 64 -> 64 halo-tile kernel over 64-channel slices of dPre, accumulating in place
+ConvGeom conv_dgrad_valid_geom(const ConvGeom& g);
+
+// (a valid-padded conv's gradient lands on x's own grid: no frame, no fold)
 ConvGeom conv_dgrad_chunk_geom(const ConvGeom& g, int k) {
-  ConvGeom d = conv_dgrad_geom(g);
+  ConvGeom d = g.lo[0] == 0 ? conv_dgrad_valid_geom(g) : conv_dgrad_geom(g);
   d.Cin = 64; d.Cout = 64;
   d.in_cstride = g.Cout;
   d.in_cvalid = g.Cout - 64 * k < 64 ? g.Cout - 64 * k : 64;
@@ -694,11 +701,16 @@ ConvGeom conv_dgrad_chunk_geom(const ConvGeom& g, int k) {
 bool conv_dgrad_chunked_supported(const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_DGRAD_CHUNKED")) return false;
   if (g.Cin != 64 || g.Cout <= 64 || g.Cout % 8 != 0 || g.Cout > 512) return false;
-  for (int q = 0; q < 3; ++q)
-    if (g.k[q] != 3 || g.s[q] != 1 || g.lo[q] != 1 || g.O[q] != g.D[q]) return false;
+  bool same = true, valid = g.pad_mode != S3_PAD_REFLECT && g.d2s == 1;
+  for (int q = 0; q < 3; ++q) {
+    if (g.k[q] != 3 || g.s[q] != 1) return false;
+    same = same && g.lo[q] == 1 && g.O[q] == g.D[q];
+    valid = valid && g.lo[q] == 0 && g.O[q] == g.D[q] - 2;
+  }
+  if (!same && !valid) return false;
   ConvGeom base = g;
   base.Cout = 64; base.d2s = 1;
-  return conv_mfma_supported(conv_dgrad_geom(base), precision);
+  return conv_mfma_supported(valid ? conv_dgrad_valid_geom(base) : conv_dgrad_geom(base), precision);
 }
 
 int launch_conv_dgrad_chunk_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, float* wt, int k) {

@@ -448,8 +448,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             if (same && conv_gconv_supported(conv_dgrad_geom(g), precision))
               o.dgrad_mfma = o.dgrad_fewch = true;
           }
-          if (!o.dgrad_mfma && !o.fewpos && conv_dgrad_chunked_supported(g, precision))
+          if (!o.dgrad_mfma && !o.fewpos && conv_dgrad_chunked_supported(g, precision)) {
             o.dgrad_mfma = o.dgrad_chunked = true;
+            o.dgrad_valid = g.lo[0] == 0;
+          }
           o.dgrad_c2 = !o.dgrad_mfma && !o.fewpos && conv_dgrad_c2_supported(g, precision);
           o.dgrad_s2 = !o.dgrad_mfma && !o.dgrad_c2 && !o.fewpos && conv_dgrad_s2_supported(ctx, g, precision);
           o.gconv_dgrad = !o.dgrad_mfma && !o.dgrad_c2 && !o.dgrad_s2 && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
@@ -457,8 +459,8 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             max_dxp = std::max(max_dxp, (size_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
                                             (g.D[2] + 2 * g.lo[2]) * g.Cin * sizeof(float));
           if (o.dgrad_mfma) {
-            o.dg = o.dgrad_valid ? conv_dgrad_valid_geom(g)
-                                 : (o.dgrad_chunked ? conv_dgrad_chunk_geom(g, 0) : conv_dgrad_geom(g));
+            o.dg = o.dgrad_chunked ? conv_dgrad_chunk_geom(g, 0)
+                                   : (o.dgrad_valid ? conv_dgrad_valid_geom(g) : conv_dgrad_geom(g));
             max_dxp = std::max(max_dxp, (size_t)o.dg.N * o.dg.O[0] * o.dg.O[1] * o.dg.O[2] * o.dg.Cout * sizeof(float));
           }
         }
@@ -536,7 +538,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
             if (training && d.res >= 0 && fewch_out[root_of(pl, d.res)]) demote(d.res, changed);
             if (o.mfma) {
               if (!conv_mfma_bf16_out_ok(o.cg)) demote(d.out, changed);
-              if (training && !o.wgrad_bf16) demote(d.in0, changed);
+              // (a saved bf16 input is re-read by the weight gradient: the
+              // transpose-read kernels stage bf16 directly)
+              if (training && !o.wgrad_bf16 && !(o.wgrad_bf16_gen && !getenv("SUP3R_AMD_NO_DISC_BF16")))
+                demote(d.in0, changed);
             } else if (training) {
               // every other conv reads / writes fp32 in training plans — except
               // the hi-res tail conv, whose MFMA forward takes bf16 cells and
@@ -1292,10 +1297,16 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               }
               o.dg_version = P->version;
             }
+            float* acc_to = o.dgrad_valid ? dst : pl->dxp;   // valid padding: x's own grid
             for (int k = 0; k < nk; ++k) {
               rc = launch_conv_mfma_fwd(ctx, conv_dgrad_chunk_geom(g, k), pl->precision, dpre + 64 * k, o.dgc_wbf[k],
-                                        nullptr, k ? pl->dxp : nullptr, pl->dxp, ConvIO());
+                                        nullptr, k ? acc_to : nullptr, acc_to, ConvIO());
               if (rc) return rc;
+            }
+            if (o.dgrad_valid) {
+              rc = grad_deliver(pl, d.in0, dst);
+              if (rc) return rc;
+              break;
             }
             GatherGeom fg;
             fg.kind = S3_OP_PAD; fg.N = g.N;

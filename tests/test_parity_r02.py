@@ -724,3 +724,70 @@ def test_gather_mfma_four_fragments_per_wave_is_bit_identical(monkeypatch):
     np.testing.assert_array_equal(dx4, dx2)
     for a, b in zip(g4, g2):
         np.testing.assert_array_equal(a, b)
+
+
+def test_gather_mfma_split_contraction_matches_the_unsplit_walk(monkeypatch):
+    """The 128 / 256-channel discriminator layers sit on a few thousand
+    positions: gconv_mfma_kernel then splits the (tap, k-chunk) walk over
+    blockIdx.z and gconv_splitk_epilogue sums the slices in fixed order.  Same
+    bf16 products, different fp32 summation order: forward, data gradient and
+    weight gradients agree with the unsplit launch to fp32 round-off amplified
+    by the bf16 stores in between (a last-bit change of a pre-activation can
+    move its bf16 rounding) — and the stack passes the per-op oracle check"""
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(128, 1) + conv(128, 2) + conv(256, 1) + conv(256, 2) + \
+        [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (2, 15, 15, 35, 64)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+    net = Network(spec, precision='bf16')
+    net.build(shape, seed=0)
+    ph = net.plan(shape, training=True)
+    assert 'gconv' in _kernels(ph) and 'gconv' in _kernels(ph, 'dgrad')
+    xd = net.dev.to_device(x)
+
+    def run():
+        y = ph.forward(xd)
+        dy = net.dev.to_device(np.ones(tuple(y.shape), np.float32))
+        dx = ph.backward(dy, need_dx=True).cpu().numpy()
+        return y.cpu().numpy(), dx, [g.copy() for g in net.grads]
+    ys, dxs, gs = run()
+    monkeypatch.setenv('SUP3R_AMD_NO_GCONV_SPLITK', '1')
+    yu, dxu, gu = run()
+    monkeypatch.delenv('SUP3R_AMD_NO_GCONV_SPLITK')
+    assert not np.array_equal(dxs, dxu) or not np.array_equal(ys, yu), \
+        'the split path was not taken at this shape'
+    assert rel_linf(ys, yu) < 1e-3
+    assert rel_linf(dxs, dxu) < 1e-3
+    for a, b in zip(gs, gu):
+        assert rel_linf(a, b) < 1e-3
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 5, 3e-2, 2e-2)
+
+
+def test_valid_conv_on_the_halo_tile_kernel_with_chunked_data_gradient():
+    """64 -> 128 valid stride-1 conv (the discriminator's fifth layer): forward
+    on conv3_mfma_kernel (two C_out tiles, no padding), data gradient as two
+    64-channel slices of dPre through the same kernel accumulated in place on
+    x's own grid (no frame, no fold)"""
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(64, 2) + conv(128, 1) + conv(128, 2) + \
+        [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (2, 23, 21, 43, 32)
+    from sup3r_amd.engine import Network
+    net = Network(spec, precision='bf16')
+    net.build(shape, seed=0)
+    ph = net.plan(shape, training=True)
+    fwd, dg = _kernels(ph), _kernels(ph, 'dgrad')
+    assert 'mfma_tile' in fwd, fwd
+    assert 'mfma_chunked' in dg, dg
+    del ph
+    net.clear_plans()
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 9, 3e-2, 2e-2)
+    _fwd_bwd_vs_oracle(spec, shape, 'f32', 9, 1e-4, 1e-3)
