@@ -182,7 +182,8 @@ enum {
   S3_FWD_DIRECT = 0, S3_FWD_MFMA_TILE = 1, S3_FWD_MFMA_PERSIST = 2, S3_FWD_GCONV = 3,
   S3_FWD_GCONV_FEWCH = 4, S3_FWD_HALO32 = 5, S3_FWD_FEWPOS = 6, S3_FWD_TAIL_MFMA = 7,
   S3_FWD_SMALL = 8,
-  S3_FWD_FUSED2D = 9 /* the whole op list in one launch (small 2-D stacks) */
+  S3_FWD_FUSED2D = 9, /* the whole op list in one launch (small 2-D stacks) */
+  S3_FWD_HALO_S2 = 10 /* C_in = 32 stride-2 valid conv on an LDS halo          */
 };
 enum {
   S3_WGRAD_DIRECT = 0, S3_WGRAD_F32_TRUNK = 1, S3_WGRAD_BF16_TRUNK = 2, S3_WGRAD_F32_GEN = 3,

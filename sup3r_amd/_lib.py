@@ -170,7 +170,7 @@ def lib():
 OPINFO_FIELDS = ('kind', 'fwd', 'in16', 'out16', 'res16', 'fwd_bf16_ops',
                  'wgrad', 'dgrad', 'mask_fused_from')
 FWD_KERNELS = ('direct', 'mfma_tile', 'mfma_persist', 'gconv', 'gconv_fewch',
-               'halo32', 'fewpos', 'tail_mfma', 'small', 'fused2d')
+               'halo32', 'fewpos', 'tail_mfma', 'small', 'fused2d', 'halo_s2')
 WGRAD_KERNELS = ('direct', 'f32_trunk', 'bf16_trunk', 'f32_gen', 'bf16_gen',
                  'bf16_2d', 'c2', 'tail', 'fewpos')
 DGRAD_KERNELS = ('direct', 'mfma_frame', 'mfma_valid', 'mfma_chunked',

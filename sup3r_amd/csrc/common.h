@@ -146,6 +146,12 @@ size_t conv_wgrad_bf16_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
                                float* dw, float* partial, size_t partial_bytes, int accumulate,
                                int x_bf16 = 0);
+// stride-2 valid conv with C_in = 32 on an LDS halo (kernels_conv_halo_s2.hip)
+bool conv_halo_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision);
+size_t conv_halo_s2_packed_bytes(const ConvGeom& g);
+int launch_conv_halo_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
+int launch_conv_halo_s2_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* img,
+                            const float* bias, void* y, int out_bf16);
 // forward conv with C_in = 32 on an LDS halo (kernels_conv_halo32.hip)
 bool conv_halo32_supported(const s3_ctx* ctx, const ConvGeom& g, int precision);
 size_t conv_halo32_packed_bytes(const ConvGeom& g);

@@ -813,7 +813,11 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
     for (int d = 0; d < 3; ++d) pw *= (g.D[d] + g.s[d] - 1) / g.s[d];
     nz = g.s[0] * g.s[1] * g.s[2];
   }
-  const bool wide = (pw / (GT_WAVES * 4 * 16)) * n_ct * nz >= 2 * (int64_t)ctx->num_cu && !getenv("SUP3R_AMD_GCONV_MF2");
+  // (measured per layer at C2 batch 8: four fragments per wave pay off in the
+  // forward gathers only — the 64 -> 64 stride-2 data gradient ran 312 vs
+  // 288 us — so the adjoint takes them on request, SUP3R_AMD_GCONV_MF4=1)
+  const bool wide = (pw / (GT_WAVES * 4 * 16)) * n_ct * nz >= 2 * (int64_t)ctx->num_cu && !getenv("SUP3R_AMD_GCONV_MF2") &&
+                    getenv("SUP3R_AMD_GCONV_MF4");
   const int pos = GT_WAVES * (wide ? 4 : 2) * 16;
   const int nblk = (int)((pw + pos - 1) / pos);
   // (stride-1 only: a residue class of a strided conv sees 1 - 8 taps)

@@ -1,0 +1,262 @@
+// Stride-2 valid conv with 32 input channels on bf16 MFMA with an LDS halo —
+// the discriminator's second layer (32 -> 32, stride 2, over the 13.9 M
+// positions x 32 channels of the first activation; S3_PREC_BF16 plans, bf16
+// cells in, fp32 or bf16 out).
+//
+// The gather kernel re-reads every input cell 27 / 8 times through L1 with
+// per-tap index math (0.63 ms at C2 batch 8; the layer's input is 0.89 GB).
+// Here ONE persistent 4-wave workgroup per CU walks a contiguous range of
+// 2 x 4 x 16 output tiles:
+//
+//   * the tile's 5 x 9 x 33 input halo (64-B bf16 cells, 95 KB) sits in LDS
+//     with the t axis DE-INTERLEAVED per row — 17 even cells, then 16 odd —
+//     so the 16 positions t = 0..15 of a fragment read 16 CONTIGUOUS cells
+//     for each of the three t-taps (c = 0: even j, c = 1: odd j, c = 2: even
+//     j + 1): the stride-1 swizzle of conv_halo32_kernel stays conflict-free;
+//   * the whole 27 x 32 x 32 filter (55 KB bf16) is staged ONCE per workgroup
+//     into LDS, 64-B rows: a wave's A fragment is one contiguous KB;
+//   * the next tile's halo is fetched into registers (24 x 16 B per lane)
+//     before the 27-tap loop and dropped into LDS after it: the per-CU L2 -> CU
+//     path (~10 B / clk) that bounds this layer runs under the MFMAs.
+//
+// Roles as in conv_halo32_kernel: A = filter rows, B = positions; lane
+// (t, kg) of the C/D fragment owns 4 consecutive output channels.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int ST0 = 2, ST1 = 4, ST2 = 16;                 // output tile
+constexpr int SH0 = 2 * ST0 + 1, SH1 = 2 * ST1 + 1, SH2 = 2 * ST2 + 1;   // 5 x 9 x 33
+constexpr int SHP = SH0 * SH1 * SH2;                      // 1485 halo cells
+constexpr int SNW = 4, SNT = SNW * 64;
+constexpr int S_HALO = SHP * 64;                          // 95,040 B
+constexpr int S_FILT = 27 * 32 * 64;                      // 55,296 B
+constexpr int S_LDS = S_HALO + S_FILT;                    // 150,336 B
+constexpr int SNCH = (SHP * 4 + SNT - 1) / SNT;           // 24 chunks per lane
+constexpr int NEVEN = ST2 + 1;                            // even cells of a row
+
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+  hf32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
+}
+
+// in-row slot of input cell c2 (de-interleaved) and the chunk swizzle key
+__device__ __forceinline__ int row_slot(int c2) { return (c2 & 1) ? NEVEN + (c2 >> 1) : (c2 >> 1); }
+__device__ __forceinline__ int slot_key(int e) { return (e >> 1) & 3; }
+
+// fp32 w[tap][32][cout] -> bf16 img[tap][32 rows (cout, zero past it)][32 ci]
+__global__ void halo_s2_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ img,
+                                    int cout) {
+  const int total = 27 * 32 * 32;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int ci = idx & 31, row = (idx >> 5) & 31, tp = idx >> 10;
+    const float v = row < cout ? w[((size_t)tp * 32 + ci) * cout + row] : 0.f;
+    img[idx] = (unsigned short)(pk2(v, 0.f) & 0xFFFFu);
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(SNT) void conv_halo_s2_kernel(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ img,
+    const float* __restrict__ bias, void* __restrict__ yv, ConvGeom g,
+    int tiles0, int tiles1, int tiles2, int n_tiles, int out16) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* filt = smem + S_HALO;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+
+  // this workgroup's contiguous tile range (XCD-major ranks: neighbouring
+  // tiles share halo cells through the XCD's L2)
+  const int rank = s3_xcd_tile(blockIdx.x, gridDim.x);
+  const int t_first = (int)((int64_t)rank * n_tiles / gridDim.x);
+  const int t_end = (int)((int64_t)(rank + 1) * n_tiles / gridDim.x);
+  if (t_first >= t_end) return;
+
+  // ---- filter image -> LDS (once)
+  for (int i = tid; i < S_FILT / 16; i += SNT)
+    reinterpret_cast<uint4*>(filt)[i] = reinterpret_cast<const uint4*>(img)[i];
+
+  // ---- per-lane halo chunk table (tile-invariant): chunk u of this lane is
+  // item tid + u * SNT = (cell hp, 16-B chunk ch)
+  int c_pack[SNCH];              // c0 | c1 << 8 | c2 << 16 | ch << 24, -1 past the end
+  unsigned l_off[SNCH];          // LDS byte offset
+#pragma unroll
+  for (int u = 0; u < SNCH; ++u) {
+    const int item = tid + u * SNT;
+    c_pack[u] = -1; l_off[u] = 0;
+    if (item < SHP * 4) {
+      const int hp = item >> 2, ch = item & 3;
+      int h = hp;
+      const int c2 = h % SH2; h /= SH2;
+      const int c1 = h % SH1; h /= SH1;
+      const int c0 = h;
+      const int e = row_slot(c2);
+      c_pack[u] = c0 | (c1 << 8) | (c2 << 16) | (ch << 24);
+      l_off[u] = (unsigned)((((c0 * SH1 + c1) * SH2) + e) * 64 + ((ch ^ slot_key(e)) << 4));
+    }
+  }
+  auto tile_org = [&](int tile, int& n, int& o0, int& o1, int& o2) {
+    int tr = tile;
+    o2 = (tr % tiles2) * ST2; tr /= tiles2;
+    o1 = (tr % tiles1) * ST1; tr /= tiles1;
+    o0 = (tr % tiles0) * ST0; tr /= tiles0;
+    n = tr;
+  };
+  uint4 pre[SNCH];
+  auto halo_fetch = [&](int tile) {
+    int n, o0, o1, o2;
+    tile_org(tile, n, o0, o1, o2);
+    const unsigned short* xb = x + (size_t)n * D0 * D1 * D2 * 32;
+#pragma unroll
+    for (int u = 0; u < SNCH; ++u) {
+      pre[u] = make_uint4(0u, 0u, 0u, 0u);
+      const int cp = c_pack[u];
+      const int i0 = 2 * o0 + (cp & 255), i1 = 2 * o1 + ((cp >> 8) & 255), i2 = 2 * o2 + ((cp >> 16) & 255);
+      // (cells past the tensor feed only the masked overhang of ragged tiles)
+      if (cp >= 0 && i0 < D0 && i1 < D1 && i2 < D2)
+        pre[u] = *reinterpret_cast<const uint4*>(xb + (((size_t)i0 * D1 + i1) * D2 + i2) * 32 + (cp >> 24) * 8);
+    }
+  };
+  auto halo_put = [&]() {
+#pragma unroll
+    for (int u = 0; u < SNCH; ++u)
+      if (c_pack[u] >= 0) *reinterpret_cast<uint4*>(halo + l_off[u]) = pre[u];
+  };
+
+  halo_fetch(t_first);
+  halo_put();
+  __syncthreads();
+
+  // B (position) fragment addresses: t-tap c reads slots e0(c) + j
+  int off_c[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int e = (c == 1 ? NEVEN : (c >> 1)) + j;
+    off_c[c] = e * 64 + ((kg ^ slot_key(e)) << 4);
+  }
+  // this wave's two (s0, s1) output rows
+  const int r0 = 2 * wave, r1 = 2 * wave + 1;
+  const int rowb[2] = {((2 * (r0 / ST1)) * SH1 + 2 * (r0 % ST1)) * SH2 * 64,
+                       ((2 * (r1 / ST1)) * SH1 + 2 * (r1 % ST1)) * SH2 * 64};
+  const char* fa = filt + j * 64 + kg * 16;
+  const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+  const int R = g.Cout;
+
+  for (int tile = t_first; tile < t_end; ++tile) {
+    const bool has_next = tile + 1 < t_end;
+    if (has_next) halo_fetch(tile + 1);
+    f32x4 acc[2][NF];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) acc[m][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) {
+      const int a = tp / 9, b = (tp / 3) % 3, c = tp % 3;
+      bf16x8 afr[NF], bfr[2];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+        afr[nf] = *reinterpret_cast<const bf16x8*>(fa + (tp * 32 + nf * 16) * 64);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        bfr[m] = *reinterpret_cast<const bf16x8*>(halo + rowb[m] + (a * SH1 + b) * SH2 * 64 + off_c[c]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[nf], bfr[m], acc[m][nf], 0, 0, 0);
+    }
+
+    // ---- C/D: col = t, row = 4 kg + r (channel 16 nf + 4 kg + r)
+    int n, o0b, o1b, o2b;
+    tile_org(tile, n, o0b, o1b, o2b);
+    const int o2 = o2b + j;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int rr = 2 * wave + m;
+      const int o0 = o0b + rr / ST1, o1 = o1b + rr % ST1;
+      if (o0 >= g.O[0] || o1 >= g.O[1] || o2 >= g.O[2]) continue;
+      const size_t oi = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * R;
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int ch = nf * 16 + kg * 4;
+        if (ch >= R) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[m][nf][r] + ((bias && ch + r < R) ? bias[ch + r] : 0.f);
+          v[r] = v[r] > 0.f ? v[r] : slope * v[r];
+        }
+        if (out16)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(yv) + oi + ch) =
+              make_uint2(pk2(v[0], v[1]), pk2(v[2], v[3]));
+        else
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + oi + ch) =
+              make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __syncthreads();          // every wave is past its last halo read
+    if (has_next) halo_put();
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+bool conv_halo_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision) {
+  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_HALO_S2")) return false;
+  if (g.Cin != 32 || g.Cout % 4 != 0 || g.Cout < 16 || g.Cout > 32 || g.d2s != 1) return false;
+  if (g.pad_mode == S3_PAD_REFLECT) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g.k[d] != 3 || g.s[d] != 2 || g.lo[d] != 0 || (g.O[d] - 1) * 2 + 3 > g.D[d]) return false;
+  if ((int64_t)g.D[0] * g.D[1] * g.D[2] * 32 >= ((int64_t)1 << 31)) return false;
+  const int64_t min_tiles = getenv("SUP3R_AMD_HALO_S2_MIN_TILES") ? atoll(getenv("SUP3R_AMD_HALO_S2_MIN_TILES"))
+                                                                  : 4 * (int64_t)ctx->num_cu;
+  return g.O[2] >= 8 &&
+         (int64_t)g.N * ((g.O[0] + ST0 - 1) / ST0) * ((g.O[1] + ST1 - 1) / ST1) *
+                 ((g.O[2] + ST2 - 1) / ST2) >= min_tiles;
+}
+
+size_t conv_halo_s2_packed_bytes(const ConvGeom&) { return (size_t)S_FILT; }
+
+int launch_conv_halo_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img) {
+  hipLaunchKernelGGL(halo_s2_pack_kernel, dim3(108), dim3(256), 0, ctx->stream, w, (unsigned short*)img, g.Cout);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_conv_halo_s2_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* img,
+                            const float* bias, void* y, int out_bf16) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_s2_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_s2_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS));
+    attr_set = true;
+  }
+  const int tiles0 = (g.O[0] + ST0 - 1) / ST0, tiles1 = (g.O[1] + ST1 - 1) / ST1,
+            tiles2 = (g.O[2] + ST2 - 1) / ST2;
+  const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
+  int grid = ctx->num_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  if (g.Cout <= 16)
+    hipLaunchKernelGGL(conv_halo_s2_kernel<1>, dim3(grid), dim3(SNT), S_LDS, ctx->stream,
+                       (const unsigned short*)x, (const unsigned short*)img, bias, y, g, tiles0, tiles1,
+                       tiles2, n_tiles, out_bf16);
+  else
+    hipLaunchKernelGGL(conv_halo_s2_kernel<2>, dim3(grid), dim3(SNT), S_LDS, ctx->stream,
+                       (const unsigned short*)x, (const unsigned short*)img, bias, y, g, tiles0, tiles1,
+                       tiles2, n_tiles, out_bf16);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}

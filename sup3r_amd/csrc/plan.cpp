@@ -54,6 +54,7 @@ struct OpRec {
   bool dgrad_chunked = false;  // 64 -> C_out > 64 'same' conv: 64-channel slices of dPre through the tile kernel
   void* dgc_wbf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool halo32 = false;         // C_in = 32 stride-1 conv: LDS-halo forward
+  bool halo_s2 = false;        // C_in = 32 stride-2 valid conv: LDS-halo forward (bf16 cells in)
   void* h32_w = nullptr;
   uint64_t h32_version = 0;
   void* dc2_w = nullptr;
@@ -392,6 +393,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
           o.fewpos = false;
         o.gconv = !o.mfma && !o.fewpos && conv_gconv_supported(g, precision);
         o.halo32 = o.gconv && d.res < 0 && conv_halo32_supported(ctx, g, precision);
+        o.halo_s2 = o.gconv && d.res < 0 && conv_halo_s2_supported(ctx, g, precision);
         if (o.fewpos) {
           max_fp = std::max(max_fp, conv_fewpos_partial_bytes(g));
           if (training) {
@@ -723,8 +725,8 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       int rc = plan_alloc(pl, &o.gc_w, conv_gconv_packed_bytes(o.cg, 0));
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
-    if (o.halo32) {
-      int rc = plan_alloc(pl, &o.h32_w, conv_halo32_packed_bytes(o.cg));
+    if (o.halo32 || o.halo_s2) {
+      int rc = plan_alloc(pl, &o.h32_w, o.halo32 ? conv_halo32_packed_bytes(o.cg) : conv_halo_s2_packed_bytes(o.cg));
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
     if (o.dgrad_s2) {
@@ -833,6 +835,14 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
         }
         return launch_conv_halo32_fwd(ctx, o.cg, tptr(pl, d.in0), o.h32_w, b, tptr(pl, d.out), o.io.in_bf16,
                                       o.io.out_bf16);
+      }
+      if (o.halo_s2 && !res && o.io.in_bf16) {
+        if (o.h32_version != P->version) {
+          int rc = launch_conv_halo_s2_pack(ctx, o.cg, w, o.h32_w);
+          if (rc) return rc;
+          o.h32_version = P->version;
+        }
+        return launch_conv_halo_s2_fwd(ctx, o.cg, tptr(pl, d.in0), o.h32_w, b, tptr(pl, d.out), o.io.out_bf16);
       }
       if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
           (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
@@ -1085,6 +1095,8 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
       fwd = bfp && conv_mfma_persist_supported(pl->ctx, o.cg, o.io, res) ? S3_FWD_MFMA_PERSIST : S3_FWD_MFMA_TILE;
     } else if (o.halo32 && !res) {
       fwd = S3_FWD_HALO32;
+    } else if (o.halo_s2 && !res && o.io.in_bf16) {
+      fwd = S3_FWD_HALO_S2;
     } else if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
                (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
       fwd = o.cg.Cin <= 4 ? S3_FWD_GCONV_FEWCH : S3_FWD_GCONV;
@@ -1102,7 +1114,7 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
     v[S3_OPINFO_IN16] = o.io.in_bf16; v[S3_OPINFO_OUT16] = o.io.out_bf16; v[S3_OPINFO_RES16] = o.io.res_bf16;
     // operands rounded to bf16 by the forward kernel
     v[S3_OPINFO_FWD_BF16_OPS] = (pl->precision == S3_PREC_BF16 &&
-                                 (fwd == S3_FWD_FUSED2D || fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 ||
+                                 (fwd == S3_FWD_FUSED2D || fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 || fwd == S3_FWD_HALO_S2 ||
                                   fwd == S3_FWD_GCONV || fwd == S3_FWD_GCONV_FEWCH || fwd == S3_FWD_TAIL_MFMA)) ? 1 : 0;
     if (pl->training) {
       int wg = S3_WGRAD_DIRECT;

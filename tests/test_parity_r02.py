@@ -716,7 +716,9 @@ def test_gather_mfma_four_fragments_per_wave_is_bit_identical(monkeypatch):
         dy = net.dev.to_device(np.ones(tuple(y.shape), np.float32))
         dx = ph.backward(dy, need_dx=True).cpu().numpy()
         return y.cpu().numpy(), dx, net.grads
+    monkeypatch.setenv('SUP3R_AMD_GCONV_MF4', '1')   # the adjoint too
     y4, dx4, g4 = run()
+    monkeypatch.delenv('SUP3R_AMD_GCONV_MF4')
     monkeypatch.setenv('SUP3R_AMD_GCONV_MF2', '1')
     y2, dx2, g2 = run()
     monkeypatch.delenv('SUP3R_AMD_GCONV_MF2')
@@ -791,3 +793,38 @@ def test_valid_conv_on_the_halo_tile_kernel_with_chunked_data_gradient():
     net.clear_plans()
     _fwd_bwd_vs_oracle(spec, shape, 'bf16', 9, 3e-2, 2e-2)
     _fwd_bwd_vs_oracle(spec, shape, 'f32', 9, 1e-4, 1e-3)
+
+
+def test_stride2_lds_halo_conv_matches_the_gather_kernel(monkeypatch):
+    """conv_halo_s2_kernel (32 -> 32 stride-2 valid conv: de-interleaved LDS
+    halo, filter in LDS, persistent workgroups) vs gconv_mfma_kernel on the
+    same bf16 cells: same products per output, fp32 sums in the same tap order
+    — bit-identical, ragged tiles included; and vs the oracle per op"""
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(32, 2) + conv(64, 1) + \
+        [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (2, 25, 31, 75, 2)
+    monkeypatch.setenv('SUP3R_AMD_HALO_S2_MIN_TILES', '1')
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+    net = Network(spec, precision='bf16')
+    net.build(shape, seed=0)
+    ph = net.plan(shape, training=True)
+    assert 'halo_s2' in _kernels(ph), _kernels(ph)
+    xd = net.dev.to_device(x)
+    y1 = ph.forward(xd).cpu().numpy()
+    monkeypatch.setenv('SUP3R_AMD_NO_HALO_S2', '1')
+    net2 = Network(spec, precision='bf16')
+    net2.build(shape, seed=0)
+    ph2 = net2.plan(shape, training=True)
+    assert 'halo_s2' not in _kernels(ph2)
+    y2 = ph2.forward(net2.dev.to_device(x)).cpu().numpy()
+    monkeypatch.delenv('SUP3R_AMD_NO_HALO_S2')
+    np.testing.assert_array_equal(y1, y2)
+    del ph, ph2
+    net.clear_plans(); net2.clear_plans()
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 13, 3e-2, 2e-2)
