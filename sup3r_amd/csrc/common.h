@@ -231,11 +231,13 @@ int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
 
 int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
                   int esize);
+// (d16, nullable: bf16 copy of the stored gradient, 4-channel pad folds only)
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
-                      float* din);
+                      float* din, void* d16 = nullptr);
 bool gather_bwd_mask_ok(const GatherGeom& g);
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
-                             const void* mask_y, int y_bf16, float slope, float* bsum = nullptr);
+                             const void* mask_y, int y_bf16, float slope, float* bsum = nullptr,
+                             void* d16 = nullptr);
 int launch_act(s3_ctx* ctx, const float* x, float* y, int64_t n, int act,
                float alpha);
 // dx = dy * act'(y)  (y is the activation OUTPUT; sign-preserving acts only)
@@ -243,12 +245,16 @@ int launch_act_bwd(s3_ctx* ctx, const float* y, const float* dy, float* dx,
                    int64_t n, int act, float alpha);
 // dpre[pos][c] = dy[d2s-permuted] * act'(y[d2s-permuted]) (conv epilogue adj.)
 int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
-                             const float* dy, float* dpre, int y_bf16);
+                             const float* dy, float* dpre, int y_bf16, void* d16 = nullptr,
+                             float* bsum = nullptr);
+bool conv_epilogue_bwd_d16_ok(const ConvGeom& g);
+bool conv_epilogue_bwd_bsum_ok(const ConvGeom& g);
+int conv_epilogue_bwd_blocks(const s3_ctx* ctx, const ConvGeom& g, bool with_bsum);
 int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
                int c, int bcast_c);
 int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n);  // y += x
 int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add,
-                          float* bsum = nullptr);
+                          float* bsum = nullptr, void* d16 = nullptr);
 bool gather_bwd_bsum_ok(const GatherGeom& g);
 int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g);
 int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, int c, float* db, int accumulate);

@@ -163,7 +163,11 @@ template <int MASK>
 __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
                                        float* __restrict__ din, GatherGeom g,
                                        const void* __restrict__ mask_y, float slope,
-                                       float* __restrict__ bsum) {
+                                       float* __restrict__ bsum,
+                                       unsigned short* __restrict__ d16) {
+  // d16 (nullable): a bf16 copy of the stored tensor — the operand the data /
+  // weight gradient kernels of the producer conv would round to anyway, at
+  // half the bytes on their staging path
   // bsum (nullable, needs c4n | 256): per-workgroup channel sums of the stored
   // values, partial[block][Ci] — the bias gradient of the conv that produced
   // the folded tensor, for bias_grad_stage2 (a lane keeps one channel group:
@@ -228,6 +232,14 @@ __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
       acc.x += y.x; acc.y += y.y; acc.z += y.z; acc.w += y.w;
     }
     *reinterpret_cast<float4*>(din + idx * 4) = acc;
+    if (d16) {
+      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 lo2 = {acc.x, acc.y}, hi2 = {acc.z, acc.w};
+      *reinterpret_cast<uint2*>(d16 + idx * 4) =
+          make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf2)),
+                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf2)));
+    }
     bs.x += acc.x; bs.y += acc.y; bs.z += acc.z; bs.w += acc.w;
   }
   if (bsum) {
@@ -317,7 +329,13 @@ __global__ void conv_epilogue_bwd_kernel(const float* __restrict__ y,
 // the same without a store permutation, four channels per lane
 template <bool Y16>
 __global__ void conv_epilogue_bwd4_kernel(const void* __restrict__ y, const float4* __restrict__ dy,
-                                          float4* __restrict__ dpre, int64_t n4, float slope) {
+                                          float4* __restrict__ dpre, int64_t n4, float slope,
+                                          unsigned short* __restrict__ d16, float* __restrict__ bsum,
+                                          int c4n) {
+  // bsum (nullable, needs c4n | 256): per-workgroup channel sums of dpre — the
+  // conv's bias gradient — for bias_grad_stage2 (a lane keeps one channel
+  // group: the grid stride is a multiple of c4n), as in gather_bwd_pad4_kernel
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 d = dy[i];
     if (Y16) {
@@ -331,6 +349,28 @@ __global__ void conv_epilogue_bwd4_kernel(const void* __restrict__ y, const floa
       d.z *= v.z > 0.f ? 1.f : slope; d.w *= v.w > 0.f ? 1.f : slope;
     }
     dpre[i] = d;
+    bs.x += d.x; bs.y += d.y; bs.z += d.z; bs.w += d.w;
+    if (d16) {   // bf16 copy for the MFMA gradient kernels (see gather_bwd_pad4_kernel)
+      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 lo2 = {d.x, d.y}, hi2 = {d.z, d.w};
+      reinterpret_cast<uint2*>(d16)[i] =
+          make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf2)),
+                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf2)));
+    }
+  }
+  if (bsum) {
+    __shared__ float4 bred[256];
+    bred[threadIdx.x] = bs;
+    __syncthreads();
+    if ((int)threadIdx.x < c4n) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = threadIdx.x; q < 256; q += c4n) {
+        const float4 v = bred[q];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      reinterpret_cast<float4*>(bsum)[(int64_t)blockIdx.x * c4n + threadIdx.x] = t;
+    }
   }
 }
 
@@ -737,14 +777,16 @@ int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g) {
 }
 
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
-                             const void* mask_y, int y_bf16, float slope, float* bsum) {
+                             const void* mask_y, int y_bf16, float slope, float* bsum, void* d16) {
   if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_masked: unsupported geometry");
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
   const dim3 grid(grid_for(n / 4, ctx->num_cu));
   if (y_bf16)
-    hipLaunchKernelGGL(gather_bwd_pad4_kernel<2>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum);
+    hipLaunchKernelGGL(gather_bwd_pad4_kernel<2>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum,
+                       (unsigned short*)d16);
   else
-    hipLaunchKernelGGL(gather_bwd_pad4_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum);
+    hipLaunchKernelGGL(gather_bwd_pad4_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum,
+                       (unsigned short*)d16);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -758,24 +800,25 @@ int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, i
 
 // fold of a padded frame plus an earlier contribution: din = fold(dout) + add
 int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add,
-                          float* bsum) {
+                          float* bsum, void* d16) {
   if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_add: unsupported geometry");
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
   hipLaunchKernelGGL(gather_bwd_pad4_kernel<3>, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0, ctx->stream,
-                     dout, din, g, (const void*)add, 0.f, bsum);
+                     dout, din, g, (const void*)add, 0.f, bsum, (unsigned short*)d16);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
 
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
-                      float* din) {
+                      float* din, void* d16) {
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
   if (g.kind == S3_OP_PAD && g.Ci == g.Co && (g.Ci & 3) == 0) {
     hipLaunchKernelGGL(gather_bwd_pad4_kernel<0>, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,
-                       ctx->stream, dout, din, g, (const void*)nullptr, 0.f, (float*)nullptr);
+                       ctx->stream, dout, din, g, (const void*)nullptr, 0.f, (float*)nullptr, (unsigned short*)d16);
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }
+  if (d16) S3_FAIL(ctx, S3_EINVAL, "gather_bwd: bf16 side copy needs the 4-channel pad fold");
   hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, dout, din, g);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
@@ -795,23 +838,42 @@ int launch_act_bwd(s3_ctx* ctx, const float* y, const float* dy, float* dx,
   return S3_OK;
 }
 
+bool conv_epilogue_bwd_d16_ok(const ConvGeom& g) {
+  const int64_t n = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout;
+  return g.d2s <= 1 && (n & 3) == 0 && (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU);
+}
+
+// channel sums can ride along the mask pass (bias gradient): C_out / 4 | 256
+bool conv_epilogue_bwd_bsum_ok(const ConvGeom& g) {
+  const int c4n = g.Cout >> 2;
+  return conv_epilogue_bwd_d16_ok(g) && (g.Cout & 3) == 0 && c4n >= 1 && c4n <= 64 && (256 % c4n) == 0 &&
+         kBlock == 256;
+}
+int conv_epilogue_bwd_blocks(const s3_ctx* ctx, const ConvGeom& g, bool with_bsum) {
+  const int64_t n4 = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout / 4;
+  const int64_t want = (n4 + kBlock - 1) / kBlock;
+  const int64_t cap = with_bsum ? 16 * ctx->num_cu : 32 * ctx->num_cu;   // (bsum rows: <= 4096)
+  return (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+}
+
 int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
-                             const float* dy, float* dpre, int y_bf16) {
+                             const float* dy, float* dpre, int y_bf16, void* d16, float* bsum) {
   int64_t n = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout;
   if (g.d2s <= 1 && (n & 3) == 0 && (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU)) {
     const float slope = g.act == S3_ACT_LEAKY ? g.alpha : 0.f;
     const int64_t n4 = n / 4;
-    const int64_t want = (n4 + kBlock - 1) / kBlock;
-    const dim3 grid((unsigned)(want < 32 * ctx->num_cu ? (want < 1 ? 1 : want) : 32 * ctx->num_cu));
+    if (bsum && !conv_epilogue_bwd_bsum_ok(g)) S3_FAIL(ctx, S3_EINVAL, "conv_epilogue_bwd: channel sums need C_out / 4 | 256");
+    const dim3 grid((unsigned)conv_epilogue_bwd_blocks(ctx, g, bsum != nullptr));
     if (y_bf16)
       hipLaunchKernelGGL(conv_epilogue_bwd4_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, (const void*)y,
-                         (const float4*)dy, (float4*)dpre, n4, slope);
+                         (const float4*)dy, (float4*)dpre, n4, slope, (unsigned short*)d16, bsum, g.Cout >> 2);
     else
       hipLaunchKernelGGL(conv_epilogue_bwd4_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, (const void*)y,
-                         (const float4*)dy, (float4*)dpre, n4, slope);
+                         (const float4*)dy, (float4*)dpre, n4, slope, (unsigned short*)d16, bsum, g.Cout >> 2);
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }
+  if (d16 || bsum) S3_FAIL(ctx, S3_EINVAL, "conv_epilogue_bwd: side outputs need the 4-channel path");
   if (y_bf16)
     hipLaunchKernelGGL(conv_epilogue_bwd_kernel<true>, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, y, dy, dpre, g);
   else

@@ -31,6 +31,7 @@ struct TensorRec {
   int alias_root = -1;  // tensor id this one aliases (VIEW)
   float* ptr = nullptr;
   float* gptr = nullptr;  // gradient buffer (training plans)
+  void* g16 = nullptr;    // bf16 copy of the gradient, written by the fold that completes it (see OpRec::use16)
   bool is_input = false;
   int dtype = 0;        // 0 = fp32, 1 = bf16 (inference plans, bf16 mode)
   size_t bytes() const { return (size_t)numel * (dtype ? 2 : 4); }
@@ -47,6 +48,7 @@ struct OpRec {
   // MFMA backward (training plans)
   bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false, wgrad_bf16_2d = false, wgrad_tail = false;
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
+  bool use16 = false;          // data gradient stages a bf16 copy of dPre (left by the fold / mask pass that produced it)
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
   bool dgrad_s2 = false;       // stride-2 valid conv, C_out = 32: residue classes on an LDS halo
   int mask_prod = -1;          // producer conv of in0 whose activation adjoint is fused into this conv's dgrad store / fold
@@ -87,6 +89,8 @@ struct s3_plan {
   std::vector<size_t> buffer_bytes;
   std::vector<void*> owned;  // every hipMalloc of this plan
   float* dpre = nullptr;      // conv/dense epilogue-adjoint workspace
+  void* dpre16 = nullptr;     // its bf16 copy (mask pass of a conv with use16)
+  std::vector<char> g16valid; // TensorRec::g16 holds the tensor's finished gradient
   float* gtmp = nullptr;      // gradient staging when a tensor has >1 consumer
   float* wg_partial = nullptr;
   size_t wg_partial_bytes = 0;
@@ -101,6 +105,7 @@ struct s3_plan {
   std::vector<const float*> gsrc;      // the aliased first contribution (a finished gradient buffer)
   float* bsum = nullptr;               // channel sums left by a frame fold (bias gradient of the producer)
   int bsum_for = -1, bsum_nblk = 0;    // tensor root they belong to (-1: none), slabs
+  float* bsum2 = nullptr;              // channel sums left by a conv's own mask pass (consumed at once)
   std::vector<char> premasked;   // tensor gradient already carries its producer's activation adjoint
   // hipGraph replay of the forward op list (inference plans): inputs are
   // copied into plan-owned staging buffers so every pointer inside the
@@ -679,8 +684,25 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
     int rc = plan_alloc(pl, (void**)&pl->dpre, max_dpre);
+    // bf16 side copies of dPre for the halo-tile data gradients (the kernel
+    // rounds its operand to bf16 anyway; a bf16 source halves the bytes on its
+    // staging path, which is what bounds it with fp32 dPre)
+    if (precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_NO_DPRE16")) {
+      size_t max16 = 0;
+      for (auto& o : pl->ops) {
+        if (rc || o.d.kind != S3_OP_CONV) continue;
+        if (!o.dgrad_mfma || o.dgrad_fewch || o.dgrad_chunked || (o.cg.Cout & 3)) continue;
+        o.use16 = true;
+        TensorRec& ot = pl->t[root_of(pl, o.d.out)];
+        if (!ot.g16 && getenv("SUP3R_AMD_FOLD16") && atoi(getenv("SUP3R_AMD_FOLD16")))
+          rc = plan_alloc(pl, &ot.g16, (size_t)ot.numel * 2);
+        max16 = std::max(max16, (size_t)ot.numel * 2);
+      }
+      if (!rc && max16) rc = plan_alloc(pl, &pl->dpre16, max16);
+    }
     if (!rc) rc = plan_alloc(pl, (void**)&pl->gtmp, max_t);
     if (!rc) rc = plan_alloc(pl, (void**)&pl->bsum, (size_t)4096 * 256 * sizeof(float));
+    if (!rc) rc = plan_alloc(pl, (void**)&pl->bsum2, (size_t)4096 * 256 * sizeof(float));
     if (!rc && max_partial) {
       rc = plan_alloc(pl, (void**)&pl->wg_partial, max_partial);
       pl->wg_partial_bytes = max_partial;
@@ -1161,6 +1183,7 @@ static int grad_deliver(s3_plan* pl, int id, const float* src) {
   }
   if (pl->gwritten[r] == 2) {
     if (pl->bsum_for == r) pl->bsum_for = -1;   // the tensor changes: its channel sums are stale
+    if (!pl->g16valid.empty()) pl->g16valid[r] = 0;
     const float* first = pl->gsrc[r];
     pl->gsrc[r] = nullptr;
     pl->gwritten[r] = 1;
@@ -1169,6 +1192,7 @@ static int grad_deliver(s3_plan* pl, int id, const float* src) {
   }
   if (src == t.gptr) return S3_OK;  // accumulated in place by the producer
   if (pl->bsum_for == r) pl->bsum_for = -1;
+  if (!pl->g16valid.empty()) pl->g16valid[r] = 0;
   return launch_axpy(ctx, src, t.gptr, t.numel);
 }
 
@@ -1195,6 +1219,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
   std::fill(pl->gwritten.begin(), pl->gwritten.end(), 0);
   pl->premasked.assign(pl->gwritten.size(), 0);
   pl->gsrc.assign(pl->gwritten.size(), nullptr);
+  pl->g16valid.assign(pl->gwritten.size(), 0);
   pl->bsum_for = -1;
   {
     // the caller's buffer is read-only for the duration of the call: alias it
@@ -1225,15 +1250,28 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           if (rc) return rc;
         }
         const float* dpre = dy;
+        const void* dpre16 = nullptr;     // bf16 copy of dpre, if one was left behind
+        bool mask_sums = false;           // pl->bsum2 holds the channel sums of dpre
         if ((g.act != S3_ACT_NONE || g.d2s > 1) && !pl->premasked[ro]) {
-          rc = launch_conv_epilogue_bwd(ctx, g, tptr(pl, d.out), dy, pl->dpre, o.io.out_bf16);
+          void* side = (o.use16 && pl->dpre16 && conv_epilogue_bwd_d16_ok(g)) ? pl->dpre16 : nullptr;
+          // the bias gradient = channel sums of dpre: they ride along this pass
+          mask_sums = need_wgrad && d.b >= 0 && pl->bsum2 && conv_epilogue_bwd_bsum_ok(g) &&
+                      !getenv("SUP3R_AMD_NO_BIAS_FUSE");
+          rc = launch_conv_epilogue_bwd(ctx, g, tptr(pl, d.out), dy, pl->dpre, o.io.out_bf16, side,
+                                        mask_sums ? pl->bsum2 : nullptr);
           if (rc) return rc;
           dpre = pl->dpre;
+          dpre16 = side;
+        } else if (o.use16 && dy == pl->t[ro].gptr && pl->g16valid[ro]) {
+          dpre16 = pl->t[ro].g16;
         }
         const int64_t npos = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
         if (need_wgrad) {
           if (d.b >= 0) {
-            if (pl->bsum_for == ro && dpre == pl->t[ro].gptr && pl->gwritten[ro] == 1)
+            if (mask_sums)
+              rc = launch_bias_grad_from_partial(ctx, pl->bsum2, conv_epilogue_bwd_blocks(ctx, g, true), g.Cout,
+                                                 G + P->p[d.b].offset, accumulate_wgrad);
+            else if (pl->bsum_for == ro && dpre == pl->t[ro].gptr && pl->gwritten[ro] == 1)
               rc = launch_bias_grad_from_partial(ctx, pl->bsum, pl->bsum_nblk, g.Cout, G + P->p[d.b].offset,
                                                  accumulate_wgrad);
             else
@@ -1279,22 +1317,33 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               pl->bsum_for = rin;
               pl->bsum_nblk = gather_bwd_bsum_blocks(ctx, fg);
             }
+            // a bf16 copy of the stored gradient for the producer's data gradient
+            // (valid until another contribution lands: grad_deliver drops it)
+            // (opt-in, SUP3R_AMD_FOLD16=1: on MI355X the extra store stream costs
+            // the fold 42 us per 75 MB and saves the data gradient 30)
+            static const bool fold16 = getenv("SUP3R_AMD_FOLD16") && atoi(getenv("SUP3R_AMD_FOLD16"));
+            void* side = (fold16 && out == pl->t[rin].gptr && gather_bwd_mask_ok(fg)) ? pl->t[rin].g16 : nullptr;
             if (!fuse && pl->gwritten[rin] == 2 && out == pl->t[rin].gptr && gather_bwd_mask_ok(fg)) {
               // second contribution to a skip tensor: fold + the aliased first
               // one in a single store (no staging buffer, no axpy)
               const float* first = pl->gsrc[rin];
               pl->gsrc[rin] = nullptr;
               pl->gwritten[rin] = 1;
-              return launch_gather_bwd_add(ctx, fg, pl->dxp, out, first, bs);
+              int arc = launch_gather_bwd_add(ctx, fg, pl->dxp, out, first, bs, side);
+              if (!arc && side) pl->g16valid[rin] = 1;
+              return arc;
             }
             if (!fuse) {
               if (bs) pl->bsum_for = -1;   // plain fold: no side output
-              return launch_gather_bwd(ctx, fg, pl->dxp, out);
+              int prc = launch_gather_bwd(ctx, fg, pl->dxp, out, side);
+              if (!prc && side) pl->g16valid[rin] = 1;
+              return prc;
             }
             const ConvGeom& pg = pl->ops[o.mask_prod].cg;
             int frc = launch_gather_bwd_masked(ctx, fg, pl->dxp, out, tptr(pl, d.in0), pl->t[rin].dtype,
-                                               pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, bs);
+                                               pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, bs, side);
             if (!frc) pl->premasked[rin] = 1;
+            if (!frc && side) pl->g16valid[rin] = 1;
             return frc;
           };
           if (o.dgrad_chunked) {
@@ -1341,9 +1390,12 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             const void* wp = pl->precision != S3_PREC_F32 ? (const void*)o.dg_wbf : (const void*)o.dg_w32;
             if (o.dgrad_fewch)
               rc = launch_gconv_fwd(ctx, o.dg, dpre, o.dg_wbf, nullptr, nullptr, pl->dxp, 0);
-            else
-              rc = launch_conv_mfma_fwd(ctx, o.dg, pl->precision, dpre, wp, nullptr, nullptr,
-                                        o.dgrad_valid ? dst : pl->dxp, ConvIO());
+            else {
+              ConvIO dio;
+              dio.in_bf16 = (o.use16 && dpre16) ? 1 : 0;
+              rc = launch_conv_mfma_fwd(ctx, o.dg, pl->precision, dio.in_bf16 ? dpre16 : (const void*)dpre, wp, nullptr,
+                                        nullptr, o.dgrad_valid ? dst : pl->dxp, dio);
+            }
             if (rc) return rc;
             if (o.dgrad_valid) {
               rc = grad_deliver(pl, d.in0, dst);
