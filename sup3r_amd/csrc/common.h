@@ -231,13 +231,11 @@ int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
 
 int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
                   int esize);
-// (d16, nullable: bf16 copy of the stored gradient, 4-channel pad folds only)
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
-                      float* din, void* d16 = nullptr);
+                      float* din);
 bool gather_bwd_mask_ok(const GatherGeom& g);
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
-                             const void* mask_y, int y_bf16, float slope, float* bsum = nullptr,
-                             void* d16 = nullptr);
+                             const void* mask_y, int y_bf16, float slope, float* bsum = nullptr);
 int launch_act(s3_ctx* ctx, const float* x, float* y, int64_t n, int act,
                float alpha);
 // dx = dy * act'(y)  (y is the activation OUTPUT; sign-preserving acts only)
@@ -254,7 +252,7 @@ int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
                int c, int bcast_c);
 int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n);  // y += x
 int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add,
-                          float* bsum = nullptr, void* d16 = nullptr);
+                          float* bsum = nullptr);
 bool gather_bwd_bsum_ok(const GatherGeom& g);
 int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g);
 int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, int c, float* db, int accumulate);

@@ -517,7 +517,16 @@ constexpr int FG0 = FH0 + 2, FG1 = FH1 + 2, FG2 = FH2 + 2;
 constexpr int FHP = FG0 * FG1 * FG2;          // 2040 halo cells
 constexpr int FHW = 4;                        // waves; 16 fragments each
 
-template <int CIN>
+// bf16 output in whole 32-channel halves with a [0, 1] activation slope: the
+// permuted-row / lean-walk variant of gconv_fewch_halo_kernel (PERM)
+bool fewch_halo_perm(const ConvGeom& g, int out_bf16) {
+  const int r = g.Cout > GT_N ? GT_N : g.Cout;   // (every cout tile must qualify)
+  return out_bf16 && (g.Cout == 32 || (g.Cout & 63) == 0) && (r & 31) == 0 &&
+         !(g.act == S3_ACT_LEAKY && !(g.alpha >= 0.f && g.alpha <= 1.f));
+}
+
+// (NFP: N fragments per tile in the PERM variant — 2 for C_out = 32)
+template <int CIN, bool PERM, int NFP = 4>
 __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, void* __restrict__ yv, ConvGeom g, int tiles0, int tiles1,
@@ -538,7 +547,14 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
   const int n = tr;
   const int org0 = t0i * FH0, org1 = t1i * FH1, org2 = t2i * FH2;
   const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
-  const int nfv = (R - ct * GT_N + 15) / 16 < 4 ? (R - ct * GT_N + 15) / 16 : 4;
+  const int nfv = PERM ? NFP : ((R - ct * GT_N + 15) / 16 < 4 ? (R - ct * GT_N + 15) / 16 : 4);
+  // bf16 output with whole 32-channel halves: filter rows are taken in the
+  // order (half h, kq, nf & 1, r) so that a lane's C/D values of a fragment
+  // pair are 8 CONSECUTIVE channels h*32 + kq*8 .. +7 — one 16-B store per
+  // lane, a whole 64-B row per position across the four k-groups (with the
+  // natural order a lane stored 8 B and a wave store was sixteen 32-B pieces:
+  // the 0.89 GB first discriminator activation went out at 2 TB/s)
+  constexpr bool perm = PERM;
 
   // ---- stage the halo: cell (c0, c1, c2) = x[org + c - lo] under the padding rule
   for (int hp = tid; hp < FHP + 1; hp += FHW * 64) {
@@ -573,25 +589,100 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
       const int ta = tap / 9, tb = (tap / 3) % 3, tc = tap % 3;
       toff[kc][q] = tap < 27 ? ((ta * FG1 + tb) * FG2 + tc) * CELLB : -1;
     }
-  bf16x8 wf[KC][4];
+  constexpr int NFA = PERM ? NFP : 4;
+  bf16x8 wf[KC][NFA];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
-      if (nf < nfv)
+    for (int nf = 0; nf < NFA; ++nf)
+      if (nf < nfv) {
+        const int row = perm ? (nf >> 1) * 32 + (p16 >> 2) * 8 + (nf & 1) * 4 + (p16 & 3) : nf * 16 + p16;
         wf[kc][nf] = *reinterpret_cast<const bf16x8*>(
-            wpk + ((int64_t)ct * GT_N + nf * 16 + p16) * KP + kc * 32 + kq * 8);
+            wpk + ((int64_t)ct * GT_N + row) * KP + kc * 32 + kq * 8);
+      }
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
-  float bv[4][4];
+  float bv[NFA][4];
 #pragma unroll
-  for (int nf = 0; nf < 4; ++nf)
+  for (int nf = 0; nf < NFA; ++nf)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ch = ct * GT_N + nf * 16 + kq * 4 + r;
+      const int ch = ct * GT_N + (perm ? (nf >> 1) * 32 + kq * 8 + (nf & 1) * 4 : nf * 16 + kq * 4) + r;
       bv[nf][r] = (bias && ch < R) ? bias[ch] : 0.f;
     }
   __syncthreads();
 
+  if constexpr (PERM) {
+    // ---- lean walk for the bf16 / permuted-row case (the 13.9 M-position first
+    // discriminator layer: the generic loop below spent 80 % of the SIMD
+    // cycles on VALU index math, 211 instructions per fragment).  A wave owns
+    // the tile row r0 = wave; fragment f = (r1 = f >> 1, half = f & 1): every
+    // LDS address is (per-lane register) + (immediate), the accumulators start
+    // from the bias, the output offset is 32-bit relative to the wave's row.
+    // K-padding slots (taps 27 ..) read tap 26's cell: finite data x zero weight.
+    unsigned la[KC][TPL];
+    const int pos0 = ((wave * FG1) * FG2 + p16) * CELLB;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int q = 0; q < TPL; ++q)
+        la[kc][q] = (unsigned)(pos0 + (toff[kc][q] >= 0 ? toff[kc][q] : ((2 * FG1 + 2) * FG2 + 2) * CELLB));
+    const int o0 = org0 + wave;
+    if (o0 >= g.O[0]) return;                       // (no barrier below)
+    unsigned short* yrow = reinterpret_cast<unsigned short*>(yv) +
+                           ((((int64_t)n * g.O[0] + o0) * g.O[1] + org1) * g.O[2] + org2) * R + ct * GT_N;
+    const unsigned lane_off = (unsigned)(p16 * R + kq * 8);
+    const bool ok_half[2] = {org2 + p16 < g.O[2], org2 + 16 + p16 < g.O[2]};
+    const int rows_ok = g.O[1] - org1;               // rows r1 < rows_ok exist
+#pragma unroll 1
+    for (int r1 = 0; r1 < FH1; ++r1) {
+      if (r1 >= rows_ok) break;                      // wave-uniform
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int foff = half * 16 * CELLB;           // immediate
+        f32x4 acc[NFP];
+#pragma unroll
+        for (int nf = 0; nf < NFP; ++nf)
+          acc[nf] = (f32x4){bv[nf][0], bv[nf][1], bv[nf][2], bv[nf][3]};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          unsigned u[4];
+#pragma unroll
+          for (int q = 0; q < TPL; ++q) {
+            if (CIN == 2) {
+              u[q] = *reinterpret_cast<const unsigned*>(halo + la[kc][q] + foff);
+            } else {
+              const uint2 t = *reinterpret_cast<const uint2*>(halo + la[kc][q] + foff);
+              u[2 * q] = t.x; u[2 * q + 1] = t.y;
+            }
+          }
+          const bf16x8 xf = __builtin_bit_cast(bf16x8, make_uint4(u[0], u[1], u[2], u[3]));
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+            if (nf < nfv)
+              acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kc][nf], xf, acc[nf], 0, 0, 0);
+        }
+        if (!ok_half[half]) continue;
+        const unsigned off = lane_off + (unsigned)((r1 * g.O[2] + half * 16) * R);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (2 * h >= nfv) continue;
+          float o[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float a = acc[2 * h + (q >> 2)][q & 3];
+            o[q] = fmaxf(a, slope * a);              // slope in [0, 1]: identity / ReLU / LeakyReLU
+          }
+          *reinterpret_cast<uint4*>(yrow + off + h * 32) =
+              make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7]));
+        }
+      }
+      // next tile row: every halo address moves one row of cells
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int q = 0; q < TPL; ++q) la[kc][q] += FG2 * CELLB;
+    }
+  } else {
   // ---- 64 fragments per tile (32 rows x 2 halves of t), 16 per wave
 #pragma unroll 2
   for (int f = 0; f < 16; ++f) {
@@ -625,6 +716,21 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
     const int o0 = org0 + r0, o1 = org1 + r1, o2 = org2 + half * 16 + p16;
     if (o0 >= g.O[0] || o1 >= g.O[1] || o2 >= g.O[2]) continue;
     const int64_t pp = (((int64_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2;
+    if (perm) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (2 * h >= nfv) continue;
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          o[q] = acc[2 * h + (q >> 2)][q & 3] + bv[2 * h + (q >> 2)][q & 3];
+          o[q] = o[q] > 0.f ? o[q] : slope * o[q];
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(yv) + pp * R + ct * GT_N + h * 32 + kq * 8) =
+            make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7]));
+      }
+      continue;
+    }
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
       const int ch = ct * GT_N + nf * 16 + kq * 4;
@@ -647,6 +753,7 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
           if (ch + r < R) y[pp * R + ch + r] = o[r];
       }
     }
+  }
   }
 }
 
@@ -751,12 +858,13 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
     if (fewch_halo_ok(ctx, g, res, out_bf16)) {
       const int t0 = (g.O[0] + FH0 - 1) / FH0, t1 = (g.O[1] + FH1 - 1) / FH1, t2 = (g.O[2] + FH2 - 1) / FH2;
       dim3 hgrid((unsigned)(g.N * t0 * t1 * t2), (unsigned)((g.Cout + GT_N - 1) / GT_N));
-      if (g.Cin == 2)
-        hipLaunchKernelGGL(gconv_fewch_halo_kernel<2>, hgrid, dim3(FHW * 64), 0, ctx->stream, x, img, bias,
-                           y, g, t0, t1, t2, out_bf16);
-      else
-        hipLaunchKernelGGL(gconv_fewch_halo_kernel<4>, hgrid, dim3(FHW * 64), 0, ctx->stream, x, img, bias,
-                           y, g, t0, t1, t2, out_bf16);
+      const bool pm = fewch_halo_perm(g, out_bf16);
+      const bool two = g.Cout == 32;
+      auto kern = g.Cin == 2 ? (pm ? (two ? gconv_fewch_halo_kernel<2, true, 2> : gconv_fewch_halo_kernel<2, true, 4>)
+                                   : gconv_fewch_halo_kernel<2, false>)
+                             : (pm ? (two ? gconv_fewch_halo_kernel<4, true, 2> : gconv_fewch_halo_kernel<4, true, 4>)
+                                   : gconv_fewch_halo_kernel<4, false>);
+      hipLaunchKernelGGL(kern, hgrid, dim3(FHW * 64), 0, ctx->stream, x, img, bias, y, g, t0, t1, t2, out_bf16);
       S3_HIP(ctx, hipGetLastError());
       return S3_OK;
     }

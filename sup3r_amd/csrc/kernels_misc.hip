@@ -163,11 +163,7 @@ template <int MASK>
 __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
                                        float* __restrict__ din, GatherGeom g,
                                        const void* __restrict__ mask_y, float slope,
-                                       float* __restrict__ bsum,
-                                       unsigned short* __restrict__ d16) {
-  // d16 (nullable): a bf16 copy of the stored tensor — the operand the data /
-  // weight gradient kernels of the producer conv would round to anyway, at
-  // half the bytes on their staging path
+                                       float* __restrict__ bsum) {
   // bsum (nullable, needs c4n | 256): per-workgroup channel sums of the stored
   // values, partial[block][Ci] — the bias gradient of the conv that produced
   // the folded tensor, for bias_grad_stage2 (a lane keeps one channel group:
@@ -232,14 +228,6 @@ __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
       acc.x += y.x; acc.y += y.y; acc.z += y.z; acc.w += y.w;
     }
     *reinterpret_cast<float4*>(din + idx * 4) = acc;
-    if (d16) {
-      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-      typedef float f2 __attribute__((ext_vector_type(2)));
-      const f2 lo2 = {acc.x, acc.y}, hi2 = {acc.z, acc.w};
-      *reinterpret_cast<uint2*>(d16 + idx * 4) =
-          make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf2)),
-                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf2)));
-    }
     bs.x += acc.x; bs.y += acc.y; bs.z += acc.z; bs.w += acc.w;
   }
   if (bsum) {
@@ -777,16 +765,14 @@ int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g) {
 }
 
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
-                             const void* mask_y, int y_bf16, float slope, float* bsum, void* d16) {
+                             const void* mask_y, int y_bf16, float slope, float* bsum) {
   if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_masked: unsupported geometry");
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
   const dim3 grid(grid_for(n / 4, ctx->num_cu));
   if (y_bf16)
-    hipLaunchKernelGGL(gather_bwd_pad4_kernel<2>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum,
-                       (unsigned short*)d16);
+    hipLaunchKernelGGL(gather_bwd_pad4_kernel<2>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum);
   else
-    hipLaunchKernelGGL(gather_bwd_pad4_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum,
-                       (unsigned short*)d16);
+    hipLaunchKernelGGL(gather_bwd_pad4_kernel<1>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -800,25 +786,24 @@ int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, i
 
 // fold of a padded frame plus an earlier contribution: din = fold(dout) + add
 int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add,
-                          float* bsum, void* d16) {
+                          float* bsum) {
   if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_add: unsupported geometry");
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
   hipLaunchKernelGGL(gather_bwd_pad4_kernel<3>, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0, ctx->stream,
-                     dout, din, g, (const void*)add, 0.f, bsum, (unsigned short*)d16);
+                     dout, din, g, (const void*)add, 0.f, bsum);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
 
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
-                      float* din, void* d16) {
+                      float* din) {
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
   if (g.kind == S3_OP_PAD && g.Ci == g.Co && (g.Ci & 3) == 0) {
     hipLaunchKernelGGL(gather_bwd_pad4_kernel<0>, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,
-                       ctx->stream, dout, din, g, (const void*)nullptr, 0.f, (float*)nullptr, (unsigned short*)d16);
+                       ctx->stream, dout, din, g, (const void*)nullptr, 0.f, (float*)nullptr);
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }
-  if (d16) S3_FAIL(ctx, S3_EINVAL, "gather_bwd: bf16 side copy needs the 4-channel pad fold");
   hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, dout, din, g);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;

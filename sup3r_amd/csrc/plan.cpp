@@ -31,7 +31,6 @@ struct TensorRec {
   int alias_root = -1;  // tensor id this one aliases (VIEW)
   float* ptr = nullptr;
   float* gptr = nullptr;  // gradient buffer (training plans)
-  void* g16 = nullptr;    // bf16 copy of the gradient, written by the fold that completes it (see OpRec::use16)
   bool is_input = false;
   int dtype = 0;        // 0 = fp32, 1 = bf16 (inference plans, bf16 mode)
   size_t bytes() const { return (size_t)numel * (dtype ? 2 : 4); }
@@ -48,7 +47,7 @@ struct OpRec {
   // MFMA backward (training plans)
   bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false, wgrad_bf16_2d = false, wgrad_tail = false;
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
-  bool use16 = false;          // data gradient stages a bf16 copy of dPre (left by the fold / mask pass that produced it)
+  bool use16 = false;          // data gradient stages the bf16 copy of dPre its mask pass leaves behind
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
   bool dgrad_s2 = false;       // stride-2 valid conv, C_out = 32: residue classes on an LDS halo
   int mask_prod = -1;          // producer conv of in0 whose activation adjoint is fused into this conv's dgrad store / fold
@@ -90,7 +89,6 @@ struct s3_plan {
   std::vector<void*> owned;  // every hipMalloc of this plan
   float* dpre = nullptr;      // conv/dense epilogue-adjoint workspace
   void* dpre16 = nullptr;     // its bf16 copy (mask pass of a conv with use16)
-  std::vector<char> g16valid; // TensorRec::g16 holds the tensor's finished gradient
   float* gtmp = nullptr;      // gradient staging when a tensor has >1 consumer
   float* wg_partial = nullptr;
   size_t wg_partial_bytes = 0;
@@ -684,19 +682,18 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
     int rc = plan_alloc(pl, (void**)&pl->dpre, max_dpre);
-    // bf16 side copies of dPre for the halo-tile data gradients (the kernel
+    // bf16 side copy of dPre for the halo-tile data gradients (the kernel
     // rounds its operand to bf16 anyway; a bf16 source halves the bytes on its
-    // staging path, which is what bounds it with fp32 dPre)
+    // staging path).  Only the separate mask pass writes one: the same side
+    // store in the frame folds cost them 42 us per 75 MB and saved the data
+    // gradient 30 (measured, dropped).
     if (precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_NO_DPRE16")) {
       size_t max16 = 0;
       for (auto& o : pl->ops) {
         if (rc || o.d.kind != S3_OP_CONV) continue;
         if (!o.dgrad_mfma || o.dgrad_fewch || o.dgrad_chunked || (o.cg.Cout & 3)) continue;
         o.use16 = true;
-        TensorRec& ot = pl->t[root_of(pl, o.d.out)];
-        if (!ot.g16 && getenv("SUP3R_AMD_FOLD16") && atoi(getenv("SUP3R_AMD_FOLD16")))
-          rc = plan_alloc(pl, &ot.g16, (size_t)ot.numel * 2);
-        max16 = std::max(max16, (size_t)ot.numel * 2);
+        max16 = std::max(max16, (size_t)pl->t[root_of(pl, o.d.out)].numel * 2);
       }
       if (!rc && max16) rc = plan_alloc(pl, &pl->dpre16, max16);
     }
@@ -1183,7 +1180,6 @@ static int grad_deliver(s3_plan* pl, int id, const float* src) {
   }
   if (pl->gwritten[r] == 2) {
     if (pl->bsum_for == r) pl->bsum_for = -1;   // the tensor changes: its channel sums are stale
-    if (!pl->g16valid.empty()) pl->g16valid[r] = 0;
     const float* first = pl->gsrc[r];
     pl->gsrc[r] = nullptr;
     pl->gwritten[r] = 1;
@@ -1192,7 +1188,6 @@ static int grad_deliver(s3_plan* pl, int id, const float* src) {
   }
   if (src == t.gptr) return S3_OK;  // accumulated in place by the producer
   if (pl->bsum_for == r) pl->bsum_for = -1;
-  if (!pl->g16valid.empty()) pl->g16valid[r] = 0;
   return launch_axpy(ctx, src, t.gptr, t.numel);
 }
 
@@ -1219,7 +1214,6 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
   std::fill(pl->gwritten.begin(), pl->gwritten.end(), 0);
   pl->premasked.assign(pl->gwritten.size(), 0);
   pl->gsrc.assign(pl->gwritten.size(), nullptr);
-  pl->g16valid.assign(pl->gwritten.size(), 0);
   pl->bsum_for = -1;
   {
     // the caller's buffer is read-only for the duration of the call: alias it
@@ -1262,8 +1256,6 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           if (rc) return rc;
           dpre = pl->dpre;
           dpre16 = side;
-        } else if (o.use16 && dy == pl->t[ro].gptr && pl->g16valid[ro]) {
-          dpre16 = pl->t[ro].g16;
         }
         const int64_t npos = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
         if (need_wgrad) {
@@ -1317,33 +1309,22 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               pl->bsum_for = rin;
               pl->bsum_nblk = gather_bwd_bsum_blocks(ctx, fg);
             }
-            // a bf16 copy of the stored gradient for the producer's data gradient
-            // (valid until another contribution lands: grad_deliver drops it)
-            // (opt-in, SUP3R_AMD_FOLD16=1: on MI355X the extra store stream costs
-            // the fold 42 us per 75 MB and saves the data gradient 30)
-            static const bool fold16 = getenv("SUP3R_AMD_FOLD16") && atoi(getenv("SUP3R_AMD_FOLD16"));
-            void* side = (fold16 && out == pl->t[rin].gptr && gather_bwd_mask_ok(fg)) ? pl->t[rin].g16 : nullptr;
             if (!fuse && pl->gwritten[rin] == 2 && out == pl->t[rin].gptr && gather_bwd_mask_ok(fg)) {
               // second contribution to a skip tensor: fold + the aliased first
               // one in a single store (no staging buffer, no axpy)
               const float* first = pl->gsrc[rin];
               pl->gsrc[rin] = nullptr;
               pl->gwritten[rin] = 1;
-              int arc = launch_gather_bwd_add(ctx, fg, pl->dxp, out, first, bs, side);
-              if (!arc && side) pl->g16valid[rin] = 1;
-              return arc;
+              return launch_gather_bwd_add(ctx, fg, pl->dxp, out, first, bs);
             }
             if (!fuse) {
               if (bs) pl->bsum_for = -1;   // plain fold: no side output
-              int prc = launch_gather_bwd(ctx, fg, pl->dxp, out, side);
-              if (!prc && side) pl->g16valid[rin] = 1;
-              return prc;
+              return launch_gather_bwd(ctx, fg, pl->dxp, out);
             }
             const ConvGeom& pg = pl->ops[o.mask_prod].cg;
             int frc = launch_gather_bwd_masked(ctx, fg, pl->dxp, out, tptr(pl, d.in0), pl->t[rin].dtype,
-                                               pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, bs, side);
+                                               pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, bs);
             if (!frc) pl->premasked[rin] = 1;
-            if (!frc && side) pl->g16valid[rin] = 1;
             return frc;
           };
           if (o.dgrad_chunked) {
