@@ -525,8 +525,11 @@ bool fewch_halo_perm(const ConvGeom& g, int out_bf16) {
          !(g.act == S3_ACT_LEAKY && !(g.alpha >= 0.f && g.alpha <= 1.f));
 }
 
-// (NFP: N fragments per tile in the PERM variant — 2 for C_out = 32)
-template <int CIN, bool PERM, int NFP = 4>
+// MODE 0: generic walk (any C_out, fp32 or bf16 out).  MODE 1: lean walk,
+// permuted filter rows, bf16 out (C_out = 32 or a multiple of 64).  MODE 2:
+// lean walk, natural rows, fp32 out (C_out % 4 == 0; the 2 -> 8 data gradient of
+// the hi-res tail conv over its padded frame).  NFP: N fragments of the lean walks.
+template <int CIN, int MODE, int NFP = 4>
 __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, void* __restrict__ yv, ConvGeom g, int tiles0, int tiles1,
@@ -547,7 +550,8 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
   const int n = tr;
   const int org0 = t0i * FH0, org1 = t1i * FH1, org2 = t2i * FH2;
   const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
-  const int nfv = PERM ? NFP : ((R - ct * GT_N + 15) / 16 < 4 ? (R - ct * GT_N + 15) / 16 : 4);
+  constexpr bool PERM = MODE == 1, LEAN = MODE != 0;
+  const int nfv = LEAN ? NFP : ((R - ct * GT_N + 15) / 16 < 4 ? (R - ct * GT_N + 15) / 16 : 4);
   // bf16 output with whole 32-channel halves: filter rows are taken in the
   // order (half h, kq, nf & 1, r) so that a lane's C/D values of a fragment
   // pair are 8 CONSECUTIVE channels h*32 + kq*8 .. +7 — one 16-B store per
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
       const int ta = tap / 9, tb = (tap / 3) % 3, tc = tap % 3;
       toff[kc][q] = tap < 27 ? ((ta * FG1 + tb) * FG2 + tc) * CELLB : -1;
     }
-  constexpr int NFA = PERM ? NFP : 4;
+  constexpr int NFA = LEAN ? NFP : 4;
   bf16x8 wf[KC][NFA];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc)
@@ -611,8 +615,8 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
     }
   __syncthreads();
 
-  if constexpr (PERM) {
-    // ---- lean walk for the bf16 / permuted-row case (the 13.9 M-position first
+  if constexpr (LEAN) {
+    // ---- lean walk (MODE 1: the 13.9 M-position first
     // discriminator layer: the generic loop below spent 80 % of the SIMD
     // cycles on VALU index math, 211 instructions per fragment).  A wave owns
     // the tile row r0 = wave; fragment f = (r1 = f >> 1, half = f & 1): every
@@ -628,9 +632,11 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
         la[kc][q] = (unsigned)(pos0 + (toff[kc][q] >= 0 ? toff[kc][q] : ((2 * FG1 + 2) * FG2 + 2) * CELLB));
     const int o0 = org0 + wave;
     if (o0 >= g.O[0]) return;                       // (no barrier below)
-    unsigned short* yrow = reinterpret_cast<unsigned short*>(yv) +
-                           ((((int64_t)n * g.O[0] + o0) * g.O[1] + org1) * g.O[2] + org2) * R + ct * GT_N;
-    const unsigned lane_off = (unsigned)(p16 * R + kq * 8);
+    // (element offsets; the element is 2 B in MODE 1, 4 B in MODE 2)
+    const int64_t row_el = ((((int64_t)n * g.O[0] + o0) * g.O[1] + org1) * g.O[2] + org2) * R + ct * GT_N;
+    unsigned short* yrow = reinterpret_cast<unsigned short*>(yv) + row_el;
+    float* yrow32 = reinterpret_cast<float*>(yv) + row_el;
+    const unsigned lane_off = (unsigned)(p16 * R + (PERM ? kq * 8 : kq * 4));
     const bool ok_half[2] = {org2 + p16 < g.O[2], org2 + 16 + p16 < g.O[2]};
     const int rows_ok = g.O[1] - org1;               // rows r1 < rows_ok exist
 #pragma unroll 1
@@ -657,19 +663,32 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
           }
           const bf16x8 xf = __builtin_bit_cast(bf16x8, make_uint4(u[0], u[1], u[2], u[3]));
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf)
-            if (nf < nfv)
-              acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kc][nf], xf, acc[nf], 0, 0, 0);
+          for (int nf = 0; nf < NFP; ++nf)
+            acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kc][nf], xf, acc[nf], 0, 0, 0);
         }
         if (!ok_half[half]) continue;
         const unsigned off = lane_off + (unsigned)((r1 * g.O[2] + half * 16) * R);
+        if constexpr (!PERM) {
+#pragma unroll
+          for (int nf = 0; nf < NFP; ++nf) {
+            if (ct * GT_N + nf * 16 + kq * 4 >= R) continue;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a = acc[nf][r];
+              o[r] = a > 0.f ? a : slope * a;
+            }
+            *reinterpret_cast<float4*>(yrow32 + off + nf * 16) = make_float4(o[0], o[1], o[2], o[3]);
+          }
+          continue;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          if (2 * h >= nfv) continue;
+          if (2 * h >= NFP) continue;
           float o[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            const float a = acc[2 * h + (q >> 2)][q & 3];
+            const float a = acc[(2 * h + (q >> 2)) % NFP][q & 3];
             o[q] = fmaxf(a, slope * a);              // slope in [0, 1]: identity / ReLU / LeakyReLU
           }
           *reinterpret_cast<uint4*>(yrow + off + h * 32) =
@@ -860,10 +879,15 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
       dim3 hgrid((unsigned)(g.N * t0 * t1 * t2), (unsigned)((g.Cout + GT_N - 1) / GT_N));
       const bool pm = fewch_halo_perm(g, out_bf16);
       const bool two = g.Cout == 32;
-      auto kern = g.Cin == 2 ? (pm ? (two ? gconv_fewch_halo_kernel<2, true, 2> : gconv_fewch_halo_kernel<2, true, 4>)
-                                   : gconv_fewch_halo_kernel<2, false>)
-                             : (pm ? (two ? gconv_fewch_halo_kernel<4, true, 2> : gconv_fewch_halo_kernel<4, true, 4>)
-                                   : gconv_fewch_halo_kernel<4, false>);
+      // fp32 out, C_out % 4 == 0 and one cout tile: the lean natural-row walk
+      const int nf32 = (!out_bf16 && (g.Cout & 3) == 0 && g.Cout <= GT_N) ? (g.Cout + 15) / 16 : 0;
+      auto kern = g.Cin == 2 ? (pm ? (two ? gconv_fewch_halo_kernel<2, 1, 2> : gconv_fewch_halo_kernel<2, 1, 4>)
+                                   : gconv_fewch_halo_kernel<2, 0>)
+                             : (pm ? (two ? gconv_fewch_halo_kernel<4, 1, 2> : gconv_fewch_halo_kernel<4, 1, 4>)
+                                   : gconv_fewch_halo_kernel<4, 0>);
+      if (!pm && nf32 == 1) kern = g.Cin == 2 ? gconv_fewch_halo_kernel<2, 2, 1> : gconv_fewch_halo_kernel<4, 2, 1>;
+      else if (!pm && nf32 == 2) kern = g.Cin == 2 ? gconv_fewch_halo_kernel<2, 2, 2> : gconv_fewch_halo_kernel<4, 2, 2>;
+      else if (!pm && nf32 >= 3) kern = g.Cin == 2 ? gconv_fewch_halo_kernel<2, 2, 4> : gconv_fewch_halo_kernel<4, 2, 4>;
       hipLaunchKernelGGL(kern, hgrid, dim3(FHW * 64), 0, ctx->stream, x, img, bias, y, g, t0, t1, t2, out_bf16);
       S3_HIP(ctx, hipGetLastError());
       return S3_OK;
