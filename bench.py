@@ -405,7 +405,8 @@ def main():
                          'throughput vs batch on one MI355X: 4: 1600, 8: 1890, '
                          '16: 1910, 32: 1970, 64: 2000 samples/s); train: '
                          'GLOBAL batch (default 8 x GPUs for c2, 32 for c4); '
-                         'c3: chunks per launch sequence (default 4)')
+                         'c3: chunks per launch sequence (default 8; one MI355X: 2: '
+                         '283, 4: 327, 8: 358 chunks/s)')
     ap.add_argument('--precision', default='bf16',
                     choices=['bf16', 'f32', 'bf16x3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -515,7 +516,7 @@ def main():
         return
 
     if args.mode == 'c3':
-        b = args.batch or 4
+        b = args.batch or 8
         barrier()
         n, el = c3_leg(b, args.steps, args.warmup, world, rank)
         barrier()
