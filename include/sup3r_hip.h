@@ -92,6 +92,13 @@ void s3_ctx_destroy(s3_ctx* ctx);
 const char* s3_last_error(const s3_ctx* ctx);
 int s3_ctx_sync(s3_ctx* ctx);
 void* s3_ctx_stream(s3_ctx* ctx);
+/* launch counters of run-time kernel choices the plan cannot report up front
+ * (tests assert the path they mean to exercise was taken); -1 for an unknown
+ * counter */
+enum { S3_STAT_PERSIST_DGRAD = 0, /* trunk data gradients on the persistent kernel */
+       S3_STAT_GCONV_SPLITK = 1,  /* gather-MFMA launches with a split contraction  */
+       S3_STAT_COUNT = 2 };
+int64_t s3_ctx_stat(const s3_ctx* ctx, int which);
 
 /* ---- parameter store ---------------------------------------------------
  * replaces: phygnn.CustomNetwork.weights (list of tf.Variable: kernel, bias

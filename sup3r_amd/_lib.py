@@ -20,7 +20,7 @@ PRECISIONS = {'f32': PREC_F32, 'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
 
 EXPORTS = [
     's3_ctx_create', 's3_ctx_destroy', 's3_last_error', 's3_ctx_sync',
-    's3_ctx_stream', 's3_params_create', 's3_params_destroy',
+    's3_ctx_stream', 's3_ctx_stat', 's3_params_create', 's3_params_destroy',
     's3_params_total', 's3_params_set', 's3_params_get', 's3_params_dptr',
     's3_params_zero_grad', 's3_params_version', 's3_params_mean_abs',
     's3_adam_step',
@@ -91,6 +91,7 @@ def lib():
         's3_last_error': (C.c_char_p, [vp]),
         's3_ctx_sync': (i32, [vp]),
         's3_ctx_stream': (vp, [vp]),
+        's3_ctx_stat': (i64, [vp, i32]),
         's3_params_create': (i32, [vp, i32, C.POINTER(i64), C.POINTER(vp)]),
         's3_params_destroy': (None, [vp]),
         's3_params_total': (i64, [vp]),
@@ -165,6 +166,8 @@ def lib():
     _lib = L
     return L
 
+
+STATS = {'persist_dgrad': 0, 'gconv_splitk': 1}
 
 # s3_plan_op_info fields / codes (include/sup3r_hip.h)
 OPINFO_FIELDS = ('kind', 'fwd', 'in16', 'out16', 'res16', 'fwd_bf16_ops',

@@ -19,6 +19,7 @@ struct s3_ctx {
   float* scratch = nullptr;  // small device scratch (reductions)
   size_t scratch_bytes = 0;
   int num_cu = 256;
+  int64_t stat[4] = {0, 0, 0, 0};   // S3_STAT_* launch counters
 };
 
 #define S3_HIP(ctx, call)                                                    \
@@ -118,6 +119,11 @@ bool conv_mfma_persist_geom_ok(const ConvGeom& g);
 bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
                                  bool has_res);
 size_t conv_mfma_persist_image_bytes(const ConvGeom& g);
+// the trunk's data gradient on the persistent kernel (bf16 dPre in, fp32 frame out)
+bool conv_mfma_persist_dgrad_geom_ok(const ConvGeom& g);
+bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g);
+int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* dpre16, const void* image,
+                                   float* dxp);
 int launch_conv_mfma_persist_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
 int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                              const void* image, const float* bias,
@@ -191,7 +197,7 @@ bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                            const float* dy, float* dw, float* partial,
-                           size_t partial_bytes, int accumulate, int x_bf16);
+                           size_t partial_bytes, int accumulate, int x_bf16, int dy_bf16 = 0);
 // wgrad: persistent-workgroup kernel (kernels_conv_wgrad_mfma.hip)
 bool conv_wgrad_mfma_supported(const ConvGeom& g);
 size_t conv_wgrad_mfma_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
@@ -235,7 +241,8 @@ int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
                       float* din);
 bool gather_bwd_mask_ok(const GatherGeom& g);
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
-                             const void* mask_y, int y_bf16, float slope, float* bsum = nullptr);
+                             const void* mask_y, int y_bf16, float slope, float* bsum = nullptr,
+                             int out_bf16 = 0);
 int launch_act(s3_ctx* ctx, const float* x, float* y, int64_t n, int act,
                float alpha);
 // dx = dy * act'(y)  (y is the activation OUTPUT; sign-preserving acts only)

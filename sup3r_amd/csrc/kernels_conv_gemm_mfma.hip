@@ -920,6 +920,7 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
                        ns, ctx->scratch);
   S3_HIP(ctx, hipGetLastError());
   if (ns > 1) {
+    ++ctx->stat[S3_STAT_GCONV_SPLITK];
     const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
     const int64_t total = P * g.Cout;
     int eg = (int)((total + 255) / 256);
@@ -966,6 +967,7 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
                        rows_padded(g.Cin), accumulate, frame, 0, 0, ns, ctx->scratch);
   S3_HIP(ctx, hipGetLastError());
   if (ns > 1) {
+    ++ctx->stat[S3_STAT_GCONV_SPLITK];
     const int64_t total = P * g.Cin;
     int eg = (int)((total + 255) / 256);
     if (eg > 2048) eg = 2048;

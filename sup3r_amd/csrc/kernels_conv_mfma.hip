@@ -754,7 +754,7 @@ size_t conv_mfma_packed_bytes(const ConvGeom& g, int precision) {
   if (precision == S3_PREC_BF16) {
     const int n_ct = (g.Cout + CT - 1) / CT;
     size_t b = (size_t)n_ct * g.k[0] * g.k[1] * g.k[2] * CT * CIN * 2;
-    if (conv_mfma_persist_geom_ok(g)) b += conv_mfma_persist_image_bytes(g);
+    if (conv_mfma_persist_geom_ok(g) || conv_mfma_persist_dgrad_geom_ok(g)) b += conv_mfma_persist_image_bytes(g);
     return b;
   }
   if (precision == S3_PREC_BF16X3)   // hi | lo images of both channel halves
@@ -782,7 +782,7 @@ int launch_conv_mfma_pack(s3_ctx* ctx, const ConvGeom& g, int precision,
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, (unsigned short*)packed, taps, g.Cout, n_ct);
   S3_HIP(ctx, hipGetLastError());
-  if (conv_mfma_persist_geom_ok(g))
+  if (conv_mfma_persist_geom_ok(g) || conv_mfma_persist_dgrad_geom_ok(g))
     return launch_conv_mfma_persist_pack(ctx, g, w, (char*)packed + total * 2);
   return S3_OK;
 }

@@ -135,12 +135,25 @@ __global__ void pack_persist_kernel(const float* __restrict__ w,
 
 // NFV: N fragments computed (4 = all 64 channels of the tile; 2 = the first
 // 32, for a last tile holding <= 32 valid channels)
-template <int NFV>
+//
+// DG: the DATA GRADIENT of a reflect-padded 64 -> 64 trunk conv — the full
+// correlation of bf16 dPre (g.D) with the flipped filter over the padded frame
+// g.O = g.D + 2, zero boundary, fp32 out, no bias / activation / skip.  The
+// frames of the N samples are STACKED into one gs0 x gs1 grid of frames along
+// s0 and s1 (stacked coordinate S = q E + u, E = frame extent): with E = 18 no
+// multiple of the 4 x 8 tile fits one frame, but 2 x 4 frames are 36 x 72 =
+// 9 x 9 tiles exactly.  In stacked coordinates the gradient is a 'same' conv
+// over Z[q E + j] = dPre_q[j - 1] for 1 <= j <= E - 2, zero for j = 0, E - 1:
+// the zero separator rows stand for both neighbours' zero boundaries, so
+// a tile may straddle frames.  The halo tables carry a "zero row" flag (bit 30
+// of the element offset; a chunk is zeroed before it lands in LDS if any of
+// its three axes is flagged) instead of the reflect rule.
+template <int NFV, bool DG>
 __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg,
     const float* __restrict__ bias, const unsigned short* __restrict__ res,
     unsigned short* __restrict__ y, ConvGeom g, int tiles0, int tiles1,
-    int tiles2, int n_tiles, int ct) {
+    int tiles2, int n_tiles, int ct, int gs0, int gs1) {
   // ct: which 64-wide output-channel tile this launch computes (C_out > 64:
   // one launch per tile; wimg / bias already point at the tile's image)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -233,11 +246,24 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       const int org = ax == 0 ? o0_ : (ax == 1 ? o1_ : o2_);                           \
       const int D = ax == 0 ? D0 : (ax == 1 ? D1 : D2);                                \
       const int stride = ax == 0 ? D1 * D2 * 64 : (ax == 1 ? D2 * 64 : 64);            \
+      if (DG) {                                                                        \
+        /* stacked frames on axes 0 / 1 (extent E = D + 2, gs frames), plain zero */  \
+        /* boundary on axis 2; flagged rows load a legal address and are zeroed */    \
+        const int E = D + 2, gsx = ax == 0 ? gs0 : (ax == 1 ? gs1 : 1);                \
+        const int R = org + c - 1;                                                     \
+        const int q = R >= 0 ? R / E : 0, j = R - q * E;                               \
+        const bool zero = R < 0 || R >= gsx * E || j == 0 || j == E - 1;               \
+        const int sstr = D0 * D1 * D2 * 64;                                            \
+        const int qoff = ax == 0 ? q * gs1 * sstr : (ax == 1 ? q * sstr : 0);          \
+        htab = zero ? 0x40000000 : qoff + (j - 1) * stride;                            \
+        hx = x;                                                                        \
+      } else {                                                                         \
       int i = s3_reflect(org + c - g.lo[ax], D);                                       \
       /* ragged tiles: keep addresses legal (results are masked at the store) */      \
       i = i < 0 ? 0 : (i > D - 1 ? D - 1 : i);                                         \
       htab = i * stride;                                                               \
       hx = x + (size_t)n_ * D0 * D1 * D2 * 64;                                         \
+      }                                                                                \
       _Pragma("unroll") for (int j = 0; j < JR; ++j) {                                 \
         int cell = pcell + 32 * j;                                                     \
         if (cell > ROWC - 1) cell = ROWC - 1;                                          \
@@ -252,11 +278,19 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     // >= 2 taps before its halo_put has landed without a wait of its own
     auto halo_load = [&](int r, int j) __attribute__((always_inline)) {
       const unsigned row = (unsigned)__builtin_amdgcn_readlane(htab, r);
-      return ld16_async(hx, (row + in_off[j]) * 2);
+      // (DG: bits 30.. of the sum count the flagged axes; the rest is legal)
+      const unsigned eo = DG ? ((row + in_off[j]) & 0x3FFFFFFFu) : row + in_off[j];
+      return ld16_async(hx, eo * 2);
     };
     auto halo_put = [&](int r, int j, const u32x4& v) __attribute__((always_inline)) {
-      if (pcell + 32 * j < ROWC)
-        *reinterpret_cast<u32x4*>(smem + r * (ROWC * 128) + lds_off[j]) = v;
+      if (pcell + 32 * j < ROWC) {
+        u32x4 w = v;
+        if (DG) {
+          const unsigned row = (unsigned)__builtin_amdgcn_readlane(htab, r);
+          if ((row + in_off[j]) >> 30) w = (u32x4){0u, 0u, 0u, 0u};
+        }
+        *reinterpret_cast<u32x4*>(smem + r * (ROWC * 128) + lds_off[j]) = w;
+      }
     };
 
     // ---- prologue: biases (rho order), first halo, slabs of taps 0 and 1
@@ -429,6 +463,30 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       }
     }
 
+    if constexpr (DG) {
+      // ---- fp32 store over the stacked frames: S = q E + u per axis
+      int n_, org0, org1, org2;
+      tile_org(tile, n_, org0, org1, org2);
+      float* yf = reinterpret_cast<float*>(y);
+      const int E0 = g.O[0], E1 = g.O[1];
+#pragma unroll
+      for (int m = 0; m < MFW; ++m) {
+        const int mf = mf0 + m;
+        const int S0 = org0 + mf / TS1, S1 = org1 + mf % TS1, o2 = org2 + frow;
+        if (S0 >= gs0 * E0 || S1 >= gs1 * E1 || o2 >= g.O[2]) continue;
+        const int q0 = S0 / E0, u0 = S0 - q0 * E0, q1 = S1 / E1, u1 = S1 - q1 * E1;
+        float* yp = yf + ((((size_t)(q0 * gs1 + q1) * E0 + u0) * E1 + u1) * g.O[2] + o2) * 64 + kq * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (2 * h >= NFV) continue;
+          const f32x4 a0 = acc[m][(2 * h) % NFV], a1 = acc[m][(2 * h + 1) % NFV];
+          *reinterpret_cast<float4*>(yp + h * 32) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+          *reinterpret_cast<float4*>(yp + h * 32 + 4) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        }
+      }
+      WG_BARRIER();   // next halo visible
+      continue;
+    }
     // ---- epilogue straight from the accumulators.  A lane owns two
     // 8-channel chunks per position.  With a depth-to-space store (block b,
     // C_out / b^2 channels per hi-res cell, a multiple of 8) a chunk is one
@@ -510,6 +568,66 @@ bool conv_mfma_persist_geom_ok(const ConvGeom& g) {
          (int64_t)g.O[0] * g.O[1] * g.O[2] * g.Cout < (int64_t)1 << 31;
 }
 
+// data-gradient geometry of a 64 -> 64 'same' k3 conv (conv_dgrad_geom): full
+// correlation over the padded frame, zero boundary
+bool conv_mfma_persist_dgrad_geom_ok(const ConvGeom& g) {
+  if (g.Cin != 64 || g.Cout != 64 || g.d2s != 1 || g.pad_mode != S3_PAD_ZERO || g.act != S3_ACT_NONE) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] != 2 || g.O[d] != g.D[d] + 2) return false;
+  // 30-bit element offsets over the whole batch (the zero flag is bit 30)
+  return (int64_t)g.N * g.D[0] * g.D[1] * g.D[2] * 64 < (int64_t)1 << 28;
+}
+
+// frames per stacked axis: N = gs0 * gs1 with the least tile overhang
+static void persist_dgrad_grid(const ConvGeom& g, int* gs0, int* gs1) {
+  int64_t best = -1;
+  for (int a = 1; a <= g.N; ++a) {
+    if (g.N % a) continue;
+    const int b = g.N / a;
+    const int64_t t = (int64_t)((a * g.O[0] + TS0 - 1) / TS0) * ((b * g.O[1] + TS1 - 1) / TS1);
+    if (best < 0 || t < best) { best = t; *gs0 = a; *gs1 = b; }
+  }
+}
+
+bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g) {
+  const char* off = getenv("SUP3R_AMD_NO_PERSIST_DGRAD");
+  if (off && atoi(off)) return false;
+  if (!conv_mfma_persist_dgrad_geom_ok(g)) return false;
+  int gs0 = 1, gs1 = 1;
+  persist_dgrad_grid(g, &gs0, &gs1);
+  const int64_t tiles = (int64_t)((gs0 * g.O[0] + TS0 - 1) / TS0) * ((gs1 * g.O[1] + TS1 - 1) / TS1) *
+                        ((g.O[2] + TS2 - 1) / TS2);
+  // worth it only with little overhang (the halo-tile kernel's 6 x 6 x 16 tiles waste 5 %)
+  const int64_t covered = tiles * TS0 * TS1 * TS2, real = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  const int64_t min_tiles = getenv("SUP3R_AMD_PERSIST_DGRAD_MIN_TILES")
+                                ? atoll(getenv("SUP3R_AMD_PERSIST_DGRAD_MIN_TILES")) : ctx->num_cu;
+  return tiles >= min_tiles && covered * 10 <= real * 12;
+}
+
+int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* dpre16, const void* image,
+                                   float* dxp) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  int gs0 = 1, gs1 = 1;
+  persist_dgrad_grid(g, &gs0, &gs1);
+  const int tiles0 = (gs0 * g.O[0] + TS0 - 1) / TS0, tiles1 = (gs1 * g.O[1] + TS1 - 1) / TS1,
+            tiles2 = (g.O[2] + TS2 - 1) / TS2;
+  const int n_tiles = tiles0 * tiles1 * tiles2;
+  int grid = ctx->num_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  hipLaunchKernelGGL((conv3_mfma_persist_kernel<4, true>), dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
+                     (const unsigned short*)dpre16, (const char*)image, (const float*)nullptr,
+                     (const unsigned short*)nullptr, (unsigned short*)dxp, g, tiles0, tiles1, tiles2, n_tiles, 0,
+                     gs0, gs1);
+  S3_HIP(ctx, hipGetLastError());
+  ++ctx->stat[S3_STAT_PERSIST_DGRAD];
+  return S3_OK;
+}
+
 bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
                                  bool has_res) {
   // read per call: the parity tests flip it between two forwards
@@ -540,9 +658,9 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                              const void* res, void* y) {
   static bool attr_set = false;
   if (!attr_set) {
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4>),
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2>),
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
@@ -554,11 +672,11 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
   const int n_ct = (g.Cout + 63) / 64;
   for (int ct = 0; ct < n_ct; ++ct) {
     // a last tile with <= 32 valid channels computes two N fragments only
-    auto kern = g.Cout - ct * 64 <= 32 ? conv3_mfma_persist_kernel<2> : conv3_mfma_persist_kernel<4>;
+    auto kern = g.Cout - ct * 64 <= 32 ? conv3_mfma_persist_kernel<2, false> : conv3_mfma_persist_kernel<4, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
                        (const unsigned short*)x, (const char*)image + (size_t)ct * 27 * 8192, bias,
                        (const unsigned short*)res, (unsigned short*)y, g, tiles0,
-                       tiles1, tiles2, n_tiles, ct);
+                       tiles1, tiles2, n_tiles, ct, 1, 1);
   }
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;

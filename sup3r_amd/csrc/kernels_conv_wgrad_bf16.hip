@@ -55,7 +55,8 @@ __device__ __forceinline__ s16x4 lds_tr(const char* p) {
       (s16x4 __attribute__((address_space(3)))*)(p));
 }
 
-template <bool IN16>
+// DY16: dPre arrives as bf16 (the frame fold's bf16-only store): 8-B loads, no convert
+template <bool IN16, bool DY16 = false>
 __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
@@ -147,11 +148,16 @@ __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
       const int row = pl / BT2, tt = pl % BT2;
       const int o0 = org0 + row / BT1, o1 = org1 + row % BT1, o2 = org2 + tt;
       const int co = ct * BCT + ch * 4;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && co < g.Cout)
-        v = *reinterpret_cast<const float4*>(
-            dy + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co);
-      uint2 pk = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+      uint2 pk = make_uint2(0u, 0u);
+      const bool in = o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && co < g.Cout;
+      const size_t de = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co;
+      if constexpr (DY16) {
+        if (in) pk = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dy) + de);
+      } else {
+        float4 v = make_float4(0, 0, 0, 0);
+        if (in) v = *reinterpret_cast<const float4*>(dy + de);
+        pk = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+      }
       *reinterpret_cast<uint2*>(ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3)) = pk;
     }
     __syncthreads();
@@ -644,22 +650,28 @@ size_t conv_wgrad_bf16_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
 
 int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                            const float* dy, float* dw, float* partial,
-                           size_t partial_bytes, int accumulate, int x_bf16) {
+                           size_t partial_bytes, int accumulate, int x_bf16, int dy_bf16) {
   int n_tiles, tiles0, tiles1, tiles2;
   const int grid = bf_grid(ctx, g, &n_tiles, &tiles0, &tiles1, &tiles2);
   if (partial_bytes < conv_wgrad_bf16_partial_bytes(ctx, g))
     S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16: partial buffer too small");
+  if (dy_bf16 && (!x_bf16 || (g.Cout & 3))) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16: bf16 dPre needs bf16 x and C_out % 4 == 0");
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel<true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
     attr_set = true;
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
   static const int dbg = getenv("SUP3R_AMD_WGRAD_DBG") ? atoi(getenv("SUP3R_AMD_WGRAD_DBG")) : 0;
-  if (x_bf16)
+  if (dy_bf16)
+    hipLaunchKernelGGL((conv3_wgrad_bf16_kernel<true, true>), dim3(grid, n_ct), dim3(BNT), BF_LDS,
+                       ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles, dbg);
+  else if (x_bf16)
     hipLaunchKernelGGL(conv3_wgrad_bf16_kernel<true>, dim3(grid, n_ct), dim3(BNT), BF_LDS,
                        ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles, dbg);
   else

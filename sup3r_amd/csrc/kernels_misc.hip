@@ -159,7 +159,10 @@ __global__ void gather_bwd_kernel(const float* __restrict__ dout,
 // MASK: 0 none, 1 fp32 y, 2 bf16 y — multiplies by the activation adjoint of the
 // conv that produced the folded tensor (y = act(pre): 1 where y > 0, else slope);
 // 3: mask_y is an fp32 tensor ADDED to the fold (an earlier gradient contribution)
-template <int MASK>
+// OUT16: the folded tensor is stored as bf16 ONLY (din is then an unsigned
+// short buffer): dPre of a conv whose data / weight gradient kernels take bf16
+// and whose bias gradient rides along in bsum — nothing reads it as fp32
+template <int MASK, bool OUT16 = false>
 __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
                                        float* __restrict__ din, GatherGeom g,
                                        const void* __restrict__ mask_y, float slope,
@@ -227,7 +230,16 @@ __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
       const float4 y = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(mask_y) + idx * 4);
       acc.x += y.x; acc.y += y.y; acc.z += y.z; acc.w += y.w;
     }
-    *reinterpret_cast<float4*>(din + idx * 4) = acc;
+    if constexpr (OUT16) {
+      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 lo2 = {acc.x, acc.y}, hi2 = {acc.z, acc.w};
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(din) + idx * 4) =
+          make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf2)),
+                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf2)));
+    } else {
+      *reinterpret_cast<float4*>(din + idx * 4) = acc;
+    }
     bs.x += acc.x; bs.y += acc.y; bs.z += acc.z; bs.w += acc.w;
   }
   if (bsum) {
@@ -765,9 +777,20 @@ int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g) {
 }
 
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
-                             const void* mask_y, int y_bf16, float slope, float* bsum) {
+                             const void* mask_y, int y_bf16, float slope, float* bsum, int out_bf16) {
   if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_masked: unsupported geometry");
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  if (out_bf16) {   // (din: bf16 buffer)
+    const dim3 grid16(grid_for(n / 4, ctx->num_cu));
+    if (y_bf16)
+      hipLaunchKernelGGL((gather_bwd_pad4_kernel<2, true>), grid16, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y,
+                         slope, bsum);
+    else
+      hipLaunchKernelGGL((gather_bwd_pad4_kernel<1, true>), grid16, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y,
+                         slope, bsum);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   const dim3 grid(grid_for(n / 4, ctx->num_cu));
   if (y_bf16)
     hipLaunchKernelGGL(gather_bwd_pad4_kernel<2>, grid, dim3(kBlock), 0, ctx->stream, dout, din, g, mask_y, slope, bsum);

@@ -89,6 +89,7 @@ struct s3_plan {
   std::vector<void*> owned;  // every hipMalloc of this plan
   float* dpre = nullptr;      // conv/dense epilogue-adjoint workspace
   void* dpre16 = nullptr;     // its bf16 copy (mask pass of a conv with use16)
+  int dpre16_for = -1;        // tensor root whose dPre lives ONLY in dpre16 (bf16-only frame fold), -1: none
   float* gtmp = nullptr;      // gradient staging when a tensor has >1 consumer
   float* wg_partial = nullptr;
   size_t wg_partial_bytes = 0;
@@ -169,6 +170,11 @@ extern "C" void s3_ctx_destroy(s3_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+extern "C" int64_t s3_ctx_stat(const s3_ctx* ctx, int which) {
+  if (!ctx || which < 0 || which >= S3_STAT_COUNT) return -1;
+  return ctx->stat[which];
 }
 
 extern "C" const char* s3_last_error(const s3_ctx* ctx) {
@@ -1215,6 +1221,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
   pl->premasked.assign(pl->gwritten.size(), 0);
   pl->gsrc.assign(pl->gwritten.size(), nullptr);
   pl->bsum_for = -1;
+  pl->dpre16_for = -1;
   {
     // the caller's buffer is read-only for the duration of the call: alias it
     int r = root_of(pl, pl->output);
@@ -1246,8 +1253,19 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
         const float* dpre = dy;
         const void* dpre16 = nullptr;     // bf16 copy of dpre, if one was left behind
         bool mask_sums = false;           // pl->bsum2 holds the channel sums of dpre
+        // dPre written as bf16 ONLY by the consumer's frame fold (see fold_frame):
+        // the fp32 buffer behind `dpre` holds nothing — every reader below takes
+        // dpre16 (the fold made sure they all can)
+        const bool only16 = pl->dpre16_for == ro && pl->premasked[ro];
+        if (only16) {
+          dpre16 = pl->dpre16;
+          pl->dpre16_for = -1;
+          if (!o.use16 || !o.wgrad_bf16 || d.res >= 0)
+            S3_FAIL(ctx, S3_ESTATE, "backward: bf16-only dPre reached a conv that needs fp32");
+        }
         if ((g.act != S3_ACT_NONE || g.d2s > 1) && !pl->premasked[ro]) {
-          void* side = (o.use16 && pl->dpre16 && conv_epilogue_bwd_d16_ok(g)) ? pl->dpre16 : nullptr;
+          // (never over a pending bf16-only dPre of another tensor)
+          void* side = (o.use16 && pl->dpre16 && pl->dpre16_for < 0 && conv_epilogue_bwd_d16_ok(g)) ? pl->dpre16 : nullptr;
           // the bias gradient = channel sums of dpre: they ride along this pass
           mask_sums = need_wgrad && d.b >= 0 && pl->bsum2 && conv_epilogue_bwd_bsum_ok(g) &&
                       !getenv("SUP3R_AMD_NO_BIAS_FUSE");
@@ -1266,6 +1284,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             else if (pl->bsum_for == ro && dpre == pl->t[ro].gptr && pl->gwritten[ro] == 1)
               rc = launch_bias_grad_from_partial(ctx, pl->bsum, pl->bsum_nblk, g.Cout, G + P->p[d.b].offset,
                                                  accumulate_wgrad);
+            else if (only16)
+              S3_FAIL(ctx, S3_ESTATE, "backward: bf16-only dPre without its channel sums");
             else
               rc = launch_bias_grad(ctx, dpre, npos, g.Cout, G + P->p[d.b].offset, accumulate_wgrad);
             if (rc) return rc;
@@ -1283,7 +1303,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           else if (o.wgrad_gen)
             rc = launch_conv_wgrad_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16)
-            rc = launch_conv_wgrad_bf16(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16);
+            rc = launch_conv_wgrad_bf16(ctx, g, tptr(pl, d.in0), only16 ? (const float*)dpre16 : dpre, G + P->p[d.w].offset,
+                                        pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16, only16 ? 1 : 0);
           else if (o.wgrad_mfma)
             rc = launch_conv_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else
@@ -1321,10 +1342,23 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               if (bs) pl->bsum_for = -1;   // plain fold: no side output
               return launch_gather_bwd(ctx, fg, pl->dxp, out);
             }
-            const ConvGeom& pg = pl->ops[o.mask_prod].cg;
-            int frc = launch_gather_bwd_masked(ctx, fg, pl->dxp, out, tptr(pl, d.in0), pl->t[rin].dtype,
-                                               pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, bs);
+            const OpRec& po = pl->ops[o.mask_prod];
+            const ConvGeom& pg = po.cg;
+            // The folded tensor is dPre of the producer conv and nothing else
+            // (single consumer, mask applied here).  When every reader of it
+            // takes bf16 — halo-tile / persistent data gradient, transpose-read
+            // weight gradient, bias gradient from the channel sums riding
+            // along — it is stored as bf16 ONLY: the fold writes 75 instead of
+            // 151 MB and the readers stage half the bytes; they would round to
+            // bf16 (the same round-to-nearest-even) anyway.
+            const bool to16 = out == pl->t[rin].gptr && po.use16 && po.wgrad_bf16 && po.io.in_bf16 && po.d.res < 0 &&
+                              (po.cg.Cout & 3) == 0 && pl->dpre16 && pl->dpre16_for < 0 &&
+                              (!need_wgrad || po.d.b < 0 || bs != nullptr) && pl->precision == S3_PREC_BF16;
+            int frc = launch_gather_bwd_masked(ctx, fg, pl->dxp, to16 ? (float*)pl->dpre16 : out, tptr(pl, d.in0),
+                                               pl->t[rin].dtype, pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, bs,
+                                               to16 ? 1 : 0);
             if (!frc) pl->premasked[rin] = 1;
+            if (!frc && to16) pl->dpre16_for = rin;
             return frc;
           };
           if (o.dgrad_chunked) {
@@ -1371,7 +1405,12 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             const void* wp = pl->precision != S3_PREC_F32 ? (const void*)o.dg_wbf : (const void*)o.dg_w32;
             if (o.dgrad_fewch)
               rc = launch_gconv_fwd(ctx, o.dg, dpre, o.dg_wbf, nullptr, nullptr, pl->dxp, 0);
-            else {
+            else if (o.use16 && dpre16 && !o.dgrad_valid && pl->precision == S3_PREC_BF16 &&
+                     conv_mfma_persist_dgrad_supported(ctx, o.dg)) {
+              // the persistent trunk kernel over the stacked padded frames
+              const size_t tile_img = (size_t)((o.dg.Cout + 63) / 64) * 27 * 64 * 64 * 2;
+              rc = launch_conv_mfma_persist_dgrad(ctx, o.dg, dpre16, (const char*)o.dg_wbf + tile_img, pl->dxp);
+            } else {
               ConvIO dio;
               dio.in_bf16 = (o.use16 && dpre16) ? 1 : 0;
               rc = launch_conv_mfma_fwd(ctx, o.dg, pl->precision, dio.in_bf16 ? dpre16 : (const void*)dpre, wp, nullptr,

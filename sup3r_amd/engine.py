@@ -57,6 +57,10 @@ class Device:
     def sync(self):
         _lib.check(_lib.lib().s3_ctx_sync(self.ctx), self.ctx, 'sync')
 
+    def stat(self, name):
+        """launch counter of a run-time kernel choice (``_lib.STATS``)"""
+        return int(_lib.lib().s3_ctx_stat(self.ctx, _lib.STATS[name]))
+
     def empty(self, shape):
         torch = _torch()
         return torch.empty(tuple(int(v) for v in shape), dtype=torch.float32,

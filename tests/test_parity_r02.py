@@ -864,3 +864,43 @@ def test_bf16_side_copy_of_dpre_changes_nothing(monkeypatch):
     np.testing.assert_array_equal(dx1, dx0)
     for a, b in zip(g1, g0):
         np.testing.assert_array_equal(a, b)
+
+
+def test_trunk_data_gradient_on_the_persistent_kernel_is_bit_identical(monkeypatch):
+    """conv3_mfma_persist_kernel<4, DG> — the padded frames of the samples
+    stacked into a grid so that 4 x 8 tiles fit them exactly, zero-flagged
+    separator rows, fp32 store — vs the halo-tile kernel over the same bf16
+    dPre: same MFMA sequence per output, so dx and every weight gradient are
+    bit-identical; the stat counter proves the path ran"""
+    # (the C2 generator: trunk frames 18 x 18 x 62 = 9 x 9 x 4 tiles for the
+    # 2 x 4 grid of 8 samples, 3 % overhang)
+    spec = _load('gen_5x_12x_2f.json')
+    shape = (8, 16, 16, 5, 4)
+    monkeypatch.setenv('SUP3R_AMD_PERSIST_DGRAD_MIN_TILES', '1')
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+
+    def run():
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=0)
+        ph = net.plan(shape, training=True)
+        n0 = net.dev.stat('persist_dgrad')
+        y = ph.forward(net.dev.to_device(x))
+        dy = net.dev.to_device(
+            np.random.default_rng(9).standard_normal(tuple(y.shape)).astype(np.float32))
+        dx = ph.backward(dy, need_dx=True).cpu().numpy()
+        g = [a.copy() for a in net.grads]
+        used = net.dev.stat('persist_dgrad') - n0
+        del ph
+        net.clear_plans()
+        return dx, g, used
+    dx1, g1, used1 = run()
+    assert used1 > 0, 'no data gradient ran on the persistent kernel'
+    monkeypatch.setenv('SUP3R_AMD_NO_PERSIST_DGRAD', '1')
+    dx0, g0, used0 = run()
+    monkeypatch.delenv('SUP3R_AMD_NO_PERSIST_DGRAD')
+    assert used0 == 0
+    np.testing.assert_array_equal(dx1, dx0)
+    for a, b in zip(g1, g0):
+        np.testing.assert_array_equal(a, b)
