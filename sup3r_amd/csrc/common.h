@@ -259,7 +259,7 @@ int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
                int c, int bcast_c);
 int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n);  // y += x
 int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add,
-                          float* bsum = nullptr);
+                          float* bsum = nullptr, void* side16 = nullptr);
 bool gather_bwd_bsum_ok(const GatherGeom& g);
 int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g);
 int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, int c, float* db, int accumulate);

@@ -162,11 +162,14 @@ __global__ void gather_bwd_kernel(const float* __restrict__ dout,
 // OUT16: the folded tensor is stored as bf16 ONLY (din is then an unsigned
 // short buffer): dPre of a conv whose data / weight gradient kernels take bf16
 // and whose bias gradient rides along in bsum — nothing reads it as fp32
-template <int MASK, bool OUT16 = false>
+// SIDE16: fp32 store to din AND a bf16 copy to side16 (a tensor that stays
+// fp32 for the skip path but whose producer conv stages bf16)
+template <int MASK, bool OUT16 = false, bool SIDE16 = false>
 __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
                                        float* __restrict__ din, GatherGeom g,
                                        const void* __restrict__ mask_y, float slope,
-                                       float* __restrict__ bsum) {
+                                       float* __restrict__ bsum,
+                                       unsigned short* __restrict__ side16 = nullptr) {
   // bsum (nullable, needs c4n | 256): per-workgroup channel sums of the stored
   // values, partial[block][Ci] — the bias gradient of the conv that produced
   // the folded tensor, for bias_grad_stage2 (a lane keeps one channel group:
@@ -239,6 +242,14 @@ __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
                      __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf2)));
     } else {
       *reinterpret_cast<float4*>(din + idx * 4) = acc;
+      if constexpr (SIDE16) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 lo2 = {acc.x, acc.y}, hi2 = {acc.z, acc.w};
+        *reinterpret_cast<uint2*>(side16 + idx * 4) =
+            make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf2)),
+                       __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf2)));
+      }
     }
     bs.x += acc.x; bs.y += acc.y; bs.z += acc.z; bs.w += acc.w;
   }
@@ -809,9 +820,15 @@ int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, i
 
 // fold of a padded frame plus an earlier contribution: din = fold(dout) + add
 int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add,
-                          float* bsum) {
+                          float* bsum, void* side16) {
   if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_add: unsupported geometry");
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  if (side16) {
+    hipLaunchKernelGGL((gather_bwd_pad4_kernel<3, false, true>), dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,
+                       ctx->stream, dout, din, g, (const void*)add, 0.f, bsum, (unsigned short*)side16);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   hipLaunchKernelGGL(gather_bwd_pad4_kernel<3>, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0, ctx->stream,
                      dout, din, g, (const void*)add, 0.f, bsum);
   S3_HIP(ctx, hipGetLastError());

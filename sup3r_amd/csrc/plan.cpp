@@ -51,6 +51,7 @@ struct OpRec {
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
   bool dgrad_s2 = false;       // stride-2 valid conv, C_out = 32: residue classes on an LDS halo
   int mask_prod = -1;          // producer conv of in0 whose activation adjoint is fused into this conv's dgrad store / fold
+  int in_prod = -1;            // producer conv of in0 (any number of consumers), -1: not a conv
   bool dgrad_fewch = false;    // C_out <= 4 'same' conv: dgrad = few-channel forward conv over the frame
   bool dgrad_chunked = false;  // 64 -> C_out > 64 'same' conv: 64-channel slices of dPre through the tile kernel
   void* dgc_wbf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -89,7 +90,8 @@ struct s3_plan {
   std::vector<void*> owned;  // every hipMalloc of this plan
   float* dpre = nullptr;      // conv/dense epilogue-adjoint workspace
   void* dpre16 = nullptr;     // its bf16 copy (mask pass of a conv with use16)
-  int dpre16_for = -1;        // tensor root whose dPre lives ONLY in dpre16 (bf16-only frame fold), -1: none
+  int dpre16_for = -1;        // tensor root whose finished gradient = dPre of its producer is in dpre16, -1: none
+  bool dpre16_only = false;   // ... and ONLY there (bf16-only frame fold); false: the fp32 tensor is valid too
   float* gtmp = nullptr;      // gradient staging when a tensor has >1 consumer
   float* wg_partial = nullptr;
   size_t wg_partial_bytes = 0;
@@ -628,6 +630,10 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       if (d.kind != S3_OP_VIEW) prod[root_of(pl, d.out)] = i;
     }
     for (auto& o : pl->ops) {
+      if (o.d.kind == S3_OP_CONV) {
+        const int pr = prod[root_of(pl, o.d.in0)];
+        if (pr >= 0 && pl->ops[pr].d.kind == S3_OP_CONV) o.in_prod = pr;
+      }
       // (the stride-2 dgrad kernel masks from an fp32 y; the frame fold of the
       // halo-tile dgrad from fp32 or bf16)
       const bool fold = o.dgrad_mfma && !o.dgrad_valid;
@@ -1184,6 +1190,11 @@ static int grad_deliver(s3_plan* pl, int id, const float* src) {
     pl->gwritten[r] = 2;
     return S3_OK;
   }
+  if (pl->gwritten[r] && pl->dpre16_for == r && src != t.gptr) {
+    // the tensor changes: its bf16 copy is stale (a bf16-only tensor has no fp32 to add to)
+    if (pl->dpre16_only) S3_FAIL(ctx, S3_ESTATE, "backward: second contribution to a bf16-only gradient");
+    pl->dpre16_for = -1;
+  }
   if (pl->gwritten[r] == 2) {
     if (pl->bsum_for == r) pl->bsum_for = -1;   // the tensor changes: its channel sums are stale
     const float* first = pl->gsrc[r];
@@ -1256,12 +1267,17 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
         // dPre written as bf16 ONLY by the consumer's frame fold (see fold_frame):
         // the fp32 buffer behind `dpre` holds nothing — every reader below takes
         // dpre16 (the fold made sure they all can)
-        const bool only16 = pl->dpre16_for == ro && pl->premasked[ro];
+        const bool only16 = pl->dpre16_for == ro && pl->dpre16_only && pl->premasked[ro];
         if (only16) {
           dpre16 = pl->dpre16;
           pl->dpre16_for = -1;
           if (!o.use16 || !o.wgrad_bf16 || d.res >= 0)
             S3_FAIL(ctx, S3_ESTATE, "backward: bf16-only dPre reached a conv that needs fp32");
+        } else if (pl->dpre16_for == ro && !pl->dpre16_only) {
+          // fp32 tensor + bf16 copy (fold + earlier contribution of a skip tensor):
+          // dPre = dy for a conv without activation
+          if (o.use16 && g.act == S3_ACT_NONE && g.d2s <= 1 && dy == pl->t[ro].gptr) dpre16 = pl->dpre16;
+          pl->dpre16_for = -1;
         }
         if ((g.act != S3_ACT_NONE || g.d2s > 1) && !pl->premasked[ro]) {
           // (never over a pending bf16-only dPre of another tensor)
@@ -1303,8 +1319,11 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           else if (o.wgrad_gen)
             rc = launch_conv_wgrad_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16)
-            rc = launch_conv_wgrad_bf16(ctx, g, tptr(pl, d.in0), only16 ? (const float*)dpre16 : dpre, G + P->p[d.w].offset,
-                                        pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16, only16 ? 1 : 0);
+          {
+            const bool dy16 = only16 || (dpre16 && o.io.in_bf16 && (g.Cout & 3) == 0);
+            rc = launch_conv_wgrad_bf16(ctx, g, tptr(pl, d.in0), dy16 ? (const float*)dpre16 : dpre, G + P->p[d.w].offset,
+                                        pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16, dy16 ? 1 : 0);
+          }
           else if (o.wgrad_mfma)
             rc = launch_conv_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else
@@ -1336,7 +1355,16 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               const float* first = pl->gsrc[rin];
               pl->gsrc[rin] = nullptr;
               pl->gwritten[rin] = 1;
-              return launch_gather_bwd_add(ctx, fg, pl->dxp, out, first, bs);
+              // the producer of this (now finished) skip tensor is a conv without
+              // activation whose gradient kernels stage bf16: leave a bf16 copy
+              void* side = nullptr;
+              if (o.in_prod >= 0 && pl->dpre16 && pl->dpre16_for < 0 && !getenv("SUP3R_AMD_NO_FOLD16")) {
+                const OpRec& po = pl->ops[o.in_prod];
+                if (po.use16 && po.cg.act == S3_ACT_NONE && po.cg.d2s <= 1 && (po.cg.Cout & 3) == 0) side = pl->dpre16;
+              }
+              int arc = launch_gather_bwd_add(ctx, fg, pl->dxp, out, first, bs, side);
+              if (!arc && side) { pl->dpre16_for = rin; pl->dpre16_only = false; }
+              return arc;
             }
             if (!fuse) {
               if (bs) pl->bsum_for = -1;   // plain fold: no side output
@@ -1358,7 +1386,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
                                                pl->t[rin].dtype, pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, bs,
                                                to16 ? 1 : 0);
             if (!frc) pl->premasked[rin] = 1;
-            if (!frc && to16) pl->dpre16_for = rin;
+            if (!frc && to16) { pl->dpre16_for = rin; pl->dpre16_only = true; }
             return frc;
           };
           if (o.dgrad_chunked) {
