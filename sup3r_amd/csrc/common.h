@@ -119,6 +119,17 @@ bool conv_mfma_persist_geom_ok(const ConvGeom& g);
 bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
                                  bool has_res);
 size_t conv_mfma_persist_image_bytes(const ConvGeom& g);
+// one job of the batched filter re-pack (pack_jobs_kernel): a 64-input-channel
+// k3 conv's bf16 images from its fp32 filter
+struct S3PackJob {
+  const float* w;              // forward filter [27][cin_f][cout_f] in the parameter store
+  unsigned short* tile;        // halo-tile image [n_ct][27][64][64]
+  unsigned short* persist;     // persistent-kernel image, or nullptr
+  int cout;                    // output channels of the PACKED conv (forward: cout_f; dgrad: cin_f)
+  int n_ct;                    // ceil(cout / 64)
+  int dgrad;                   // 1: packed conv = data gradient (cin' = cout_f = 64), flip + transpose
+};
+int launch_pack_jobs(s3_ctx* ctx, const S3PackJob* jobs_dev, int n_jobs, int max_ct);
 // the trunk's data gradient on the persistent kernel (bf16 dPre in, fp32 frame out)
 bool conv_mfma_persist_dgrad_geom_ok(const ConvGeom& g);
 bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g);

@@ -133,6 +133,37 @@ __global__ void pack_persist_kernel(const float* __restrict__ w,
   }
 }
 
+// ---- batched re-pack: after an optimizer step every bf16 conv of a training
+// plan needs its filter images again — three launches of ~5 us per conv and
+// direction (tile image, persistent image, flipped fp32 filter of the data
+// gradient: 220+ launches per C2 step).  One launch walks a table of jobs:
+// blockIdx.y = job, a thread computes one filter element once and writes it to
+// the halo-tile image (kernels_conv_mfma.hip: rows = cout, 16-B chunks
+// swizzled by (row >> 1) & 7) and, when the job has one, to the persistent
+// image (rows in rho order).  dgrad jobs read the forward filter through the
+// flip / transpose map  v'(tap', ci', co') = w[26 - tap'][co'][ci'].
+__global__ void pack_jobs_kernel(const S3PackJob* __restrict__ jobs) {
+  const S3PackJob jb = jobs[blockIdx.y];
+  const int total = jb.n_ct * 27 * 64 * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int ci = idx & 63, row = (idx >> 6) & 63, tap = (idx >> 12) % 27, ct = (idx >> 12) / 27;
+    const int co = ct * 64 + row;
+    float v = 0.f;
+    if (co < jb.cout)
+      v = jb.dgrad ? jb.w[((size_t)(26 - tap) * jb.cout + co) * 64 + ci]      // forward w[tap][ci_f = co'][co_f = ci']
+                   : jb.w[((size_t)tap * 64 + ci) * jb.cout + co];
+    const unsigned short h = (unsigned short)(pk_bf16(v, 0.f) & 0xFFFFu);
+    const size_t base = (((size_t)ct * 27 + tap) * 64) * 64;
+    const int sw = (ci >> 3);
+    jb.tile[base + (size_t)row * 64 + ((sw ^ ((row >> 1) & 7)) << 3) + (ci & 7)] = h;
+    if (jb.persist) {
+      const int nf = ((row >> 5) << 1) | ((row >> 2) & 1), kq = (row >> 3) & 3, r = row & 3;
+      const int rho = nf * 16 + kq * 4 + r;      // slab_row_cout(rho) == row
+      jb.persist[base + (size_t)rho * 64 + ((sw ^ ((rho >> 1) & 7)) << 3) + (ci & 7)] = h;
+    }
+  }
+}
+
 // NFV: N fragments computed (4 = all 64 channels of the tile; 2 = the first
 // 32, for a last tile holding <= 32 valid channels)
 //
@@ -639,6 +670,13 @@ bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io
   const int64_t tiles = (int64_t)g.N * ((g.O[0] + TS0 - 1) / TS0) *
                         ((g.O[1] + TS1 - 1) / TS1) * ((g.O[2] + TS2 - 1) / TS2);
   return tiles >= ctx->num_cu;
+}
+
+int launch_pack_jobs(s3_ctx* ctx, const S3PackJob* jobs_dev, int n_jobs, int max_ct) {
+  if (n_jobs <= 0) return S3_OK;
+  hipLaunchKernelGGL(pack_jobs_kernel, dim3(108 * max_ct, n_jobs), dim3(256), 0, ctx->stream, jobs_dev);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
 }
 
 size_t conv_mfma_persist_image_bytes(const ConvGeom& g) {

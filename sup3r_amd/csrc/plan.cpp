@@ -119,6 +119,12 @@ struct s3_plan {
   int eager_forwards = 0;
   bool graph_off = false;
   Fused2dPlan* fused2d = nullptr;   // whole-network kernel (small 2-D inference plans)
+  // batched filter re-pack (bf16 plans): job tables on the device, built once
+  S3PackJob* pack_fwd = nullptr;
+  S3PackJob* pack_bwd = nullptr;
+  std::vector<int> pack_fwd_ops, pack_bwd_ops;
+  int pack_fwd_ct = 1, pack_bwd_ct = 1;
+  bool pack_built = false;
 };
 
 static int plan_alloc(s3_plan* pl, void** out, size_t bytes) {
@@ -838,6 +844,82 @@ static float* tptr(s3_plan* pl, int id) { return pl->t[root_of(pl, id)].ptr; }
 static int tdtype(s3_plan* pl, int id) { return pl->t[root_of(pl, id)].dtype; }
 static float* gptr(s3_plan* pl, int id) { return pl->t[root_of(pl, id)].gptr; }
 
+// ---- batched filter re-pack.  After an optimizer step every bf16 conv of the
+// plan needs its images again; instead of 1 - 3 launches of ~5 us per conv and
+// direction (lazily, in front of each conv) one launch per direction walks a
+// device table of jobs.  Convs outside the table (other precisions, chunked /
+// few-channel data gradients, gather-MFMA convs) keep their lazy packs.
+static int pack_tables_build(s3_plan* pl) {
+  s3_ctx* ctx = pl->ctx;
+  pl->pack_built = true;
+  if (pl->precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_BATCHED_PACK")) return S3_OK;
+  s3_params* P = pl->params;
+  float* W = P->buf[S3_BUF_W];
+  std::vector<S3PackJob> fwd, bwd;
+  for (int i = 0; i < (int)pl->ops.size(); ++i) {
+    OpRec& o = pl->ops[i];
+    if (o.d.kind != S3_OP_CONV) continue;
+    const ConvGeom& g = o.cg;
+    const bool k3 = g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3;
+    if (o.mfma && o.packed && g.Cin == 64 && k3) {
+      S3PackJob j;
+      j.w = W + P->p[o.d.w].offset;
+      j.cout = g.Cout; j.n_ct = (g.Cout + 63) / 64; j.dgrad = 0;
+      j.tile = (unsigned short*)o.packed;
+      j.persist = conv_mfma_persist_geom_ok(g) ? j.tile + (size_t)j.n_ct * 27 * 64 * 64 : nullptr;
+      fwd.push_back(j); pl->pack_fwd_ops.push_back(i);
+      pl->pack_fwd_ct = std::max(pl->pack_fwd_ct, j.n_ct);
+    }
+    if (pl->training && o.dgrad_mfma && !o.dgrad_fewch && !o.dgrad_chunked && o.dg_wbf && g.Cout == 64 && k3 &&
+        o.dg.Cin == 64) {
+      S3PackJob j;
+      j.w = W + P->p[o.d.w].offset;
+      j.cout = g.Cin; j.n_ct = (g.Cin + 63) / 64; j.dgrad = 1;
+      j.tile = (unsigned short*)o.dg_wbf;
+      j.persist = conv_mfma_persist_dgrad_geom_ok(o.dg) ? j.tile + (size_t)j.n_ct * 27 * 64 * 64 : nullptr;
+      bwd.push_back(j); pl->pack_bwd_ops.push_back(i);
+      pl->pack_bwd_ct = std::max(pl->pack_bwd_ct, j.n_ct);
+    }
+  }
+  if (fwd.size() >= 2) {
+    int rc = plan_alloc(pl, (void**)&pl->pack_fwd, fwd.size() * sizeof(S3PackJob));
+    if (rc) return rc;
+    S3_HIP(ctx, hipMemcpyAsync(pl->pack_fwd, fwd.data(), fwd.size() * sizeof(S3PackJob), hipMemcpyHostToDevice, ctx->stream));
+    S3_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the host vector goes away)
+  } else {
+    pl->pack_fwd_ops.clear();
+  }
+  if (bwd.size() >= 2) {
+    int rc = plan_alloc(pl, (void**)&pl->pack_bwd, bwd.size() * sizeof(S3PackJob));
+    if (rc) return rc;
+    S3_HIP(ctx, hipMemcpyAsync(pl->pack_bwd, bwd.data(), bwd.size() * sizeof(S3PackJob), hipMemcpyHostToDevice, ctx->stream));
+    S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    pl->pack_bwd_ops.clear();
+  }
+  return S3_OK;
+}
+
+// re-pack every listed conv whose images are stale (all or none: the weights
+// of a net change together)
+static int pack_stale(s3_plan* pl, bool bwd) {
+  if (!pl->pack_built) {
+    int rc = pack_tables_build(pl);
+    if (rc) return rc;
+  }
+  const std::vector<int>& ops = bwd ? pl->pack_bwd_ops : pl->pack_fwd_ops;
+  if (ops.empty()) return S3_OK;
+  const uint64_t ver = pl->params->version;
+  bool stale = false;
+  for (int i : ops) stale = stale || (bwd ? pl->ops[i].dg_version : pl->ops[i].packed_version) != ver;
+  if (!stale) return S3_OK;
+  int rc = launch_pack_jobs(pl->ctx, bwd ? pl->pack_bwd : pl->pack_fwd, (int)ops.size(),
+                            bwd ? pl->pack_bwd_ct : pl->pack_fwd_ct);
+  if (rc) return rc;
+  for (int i : ops) (bwd ? pl->ops[i].dg_version : pl->ops[i].packed_version) = ver;
+  return S3_OK;
+}
+
 static int run_op_forward(s3_plan* pl, OpRec& o) {
   s3_ctx* ctx = pl->ctx;
   s3_params* P = pl->params;
@@ -929,6 +1011,10 @@ static int bind_inputs(s3_plan* pl, const void* const* inputs) {
 static int forward_ops(s3_plan* pl, hipEvent_t* ev) {
   s3_ctx* ctx = pl->ctx;
   const int n_ops = (int)pl->ops.size();
+  {
+    int prc = pack_stale(pl, false);
+    if (prc) return prc;
+  }
   if (ev) S3_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
   for (int i = 0; i < n_ops; ++i) {
     int rc = run_op_forward(pl, pl->ops[i]);
@@ -1238,6 +1324,10 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
     int r = root_of(pl, pl->output);
     pl->gsrc[r] = (const float*)d_output;
     pl->gwritten[r] = 2;
+  }
+  {
+    int prc = pack_stale(pl, true);
+    if (prc) return prc;
   }
   const int x_id = pl->inputs.empty() ? -1 : root_of(pl, pl->inputs[0]);
   auto wants_grad = [&](int id) {
