@@ -628,11 +628,13 @@ bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g) {
   persist_dgrad_grid(g, &gs0, &gs1);
   const int64_t tiles = (int64_t)((gs0 * g.O[0] + TS0 - 1) / TS0) * ((gs1 * g.O[1] + TS1 - 1) / TS1) *
                         ((g.O[2] + TS2 - 1) / TS2);
-  // worth it only with little overhang (the halo-tile kernel's 6 x 6 x 16 tiles waste 5 %)
-  const int64_t covered = tiles * TS0 * TS1 * TS2, real = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  // worth it unless the stacked 4 x 8 x 16 tiles cover clearly more than the
+  // halo-tile kernel's 6 x 6 x 16 ones would (both share the overhang along t)
+  const int64_t covered = tiles * TS0 * TS1 * TS2;
+  const int64_t six = (int64_t)g.N * ((g.O[0] + 5) / 6) * ((g.O[1] + 5) / 6) * ((g.O[2] + 15) / 16) * 576;
   const int64_t min_tiles = getenv("SUP3R_AMD_PERSIST_DGRAD_MIN_TILES")
                                 ? atoll(getenv("SUP3R_AMD_PERSIST_DGRAD_MIN_TILES")) : ctx->num_cu;
-  return tiles >= min_tiles && covered * 10 <= real * 12;
+  return tiles >= min_tiles && covered * 10 <= six * 11;
 }
 
 int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* dpre16, const void* image,

@@ -866,16 +866,18 @@ def test_bf16_side_copy_of_dpre_changes_nothing(monkeypatch):
         np.testing.assert_array_equal(a, b)
 
 
-def test_trunk_data_gradient_on_the_persistent_kernel_is_bit_identical(monkeypatch):
+@pytest.mark.parametrize('n_samples', [8, 6, 16])
+def test_trunk_data_gradient_on_the_persistent_kernel_is_bit_identical(monkeypatch, n_samples):
     """conv3_mfma_persist_kernel<4, DG> — the padded frames of the samples
     stacked into a grid so that 4 x 8 tiles fit them exactly, zero-flagged
     separator rows, fp32 store — vs the halo-tile kernel over the same bf16
     dPre: same MFMA sequence per output, so dx and every weight gradient are
     bit-identical; the stat counter proves the path ran"""
     # (the C2 generator: trunk frames 18 x 18 x 62 = 9 x 9 x 4 tiles for the
-    # 2 x 4 grid of 8 samples, 3 % overhang)
+    # 2 x 4 grid of 8 samples, 3 % overhang; 6 samples = 2 x 3 frames = 36 x 54
+    # positions, tiles straddle frames and overhang; 16 = 4 x 4)
     spec = _load('gen_5x_12x_2f.json')
-    shape = (8, 16, 16, 5, 4)
+    shape = (n_samples, 16, 16, 5, 4)
     monkeypatch.setenv('SUP3R_AMD_PERSIST_DGRAD_MIN_TILES', '1')
     rng = np.random.default_rng(8)
     x = rng.standard_normal(shape).astype(np.float32)
