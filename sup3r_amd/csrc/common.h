@@ -181,13 +181,16 @@ bool conv_dgrad_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision
 size_t conv_dgrad_s2_packed_bytes(const ConvGeom& g);
 int launch_conv_dgrad_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
 int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx,
-                         const void* mask_y, float mask_slope, int mask_bf16 = 0);
+                         const void* mask_y, float mask_slope, int mask_bf16 = 0, int out_bf16 = 0,
+                         float* bsum = nullptr);
+bool conv_dgrad_s2_out16_ok(const ConvGeom& g);
+int conv_dgrad_s2_blocks(const ConvGeom& g);
 // dgrad of the few-channel hi-res conv with an LDS halo (kernels_conv_dgrad_fewch.hip)
 bool conv_dgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_dgrad_c2_packed_bytes();
 int launch_conv_dgrad_c2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
 int launch_conv_dgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img,
-                         float* dx);
+                         float* dx, int dy_bf16 = 0);
 bool conv_wgrad_bf16_2d_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_2d_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_bf16_2d(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
@@ -196,7 +199,7 @@ int launch_conv_wgrad_bf16_2d(s3_ctx* ctx, const ConvGeom& g, const float* x, co
 bool conv_wgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_c2_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                         float* dw, float* partial, size_t partial_bytes, int accumulate);
+                         float* dw, float* partial, size_t partial_bytes, int accumulate, int dy_bf16 = 0);
 // LDS-halo wgrad of the hi-res tail conv (C_in = 8), kernels_conv_wgrad_fewch.hip
 bool conv_wgrad_tail_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_tail_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);

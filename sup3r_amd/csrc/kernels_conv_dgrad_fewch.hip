@@ -51,7 +51,7 @@ __global__ void dgrad_c2_pack_kernel(const float* __restrict__ w, unsigned short
 
 __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad_c2_kernel(
     const float* __restrict__ dy, const unsigned short* __restrict__ img,
-    float* __restrict__ dx, ConvGeom g, int tiles0, int tiles1, int tiles2) {
+    float* __restrict__ dx, ConvGeom g, int tiles0, int tiles1, int tiles2, int dy16) {
   extern __shared__ __attribute__((aligned(16))) char halo[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kg = lane >> 4;
@@ -64,6 +64,39 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int O0 = g.O[0], O1 = g.O[1], O2 = g.O[2];
 
   // ---- stage the dPre halo: cell (c0, c1, c2) = dPre[org + c + lo - 2], zero outside
+  // (dy16: dPre is a bf16 tensor — the stride-2 layer above stored it that way —
+  // one 16-B chunk per item, no convert)
+  if (dy16) {
+    const unsigned short* d16 = reinterpret_cast<const unsigned short*>(dy);
+    for (int base = tid; base < DHP * 4; base += DNT * 3) {
+      uint4 v[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int item = base + u * DNT;
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (item < DHP * 4) {
+          const int hp = item >> 2, ch = item & 3;
+          int h = hp;
+          const int c2 = h % DH2; h /= DH2;
+          const int c1 = h % DH1; h /= DH1;
+          const int c0 = h;
+          const int i0 = org0 + c0 + g.lo[0] - 2, i1 = org1 + c1 + g.lo[1] - 2,
+                    i2 = org2 + c2 + g.lo[2] - 2;
+          if (i0 >= 0 && i0 < O0 && i1 >= 0 && i1 < O1 && i2 >= 0 && i2 < O2)
+            v[u] = *reinterpret_cast<const uint4*>(d16 + ((((size_t)n * O0 + i0) * O1 + i1) * O2 + i2) * 32 + ch * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int item = base + u * DNT;
+        if (item < DHP * 4) {
+          const int hp = item >> 2, ch = item & 3;
+          const int key = ((hp % DH2) >> 1) & 3;
+          *reinterpret_cast<uint4*>(halo + hp * 64 + ((ch ^ key) << 4)) = v[u];
+        }
+      }
+    }
+  } else
   for (int base = tid; base < DHP * 4; base += DNT * 3) {
     float4 va[3], vb[3];
 #pragma unroll
@@ -174,7 +207,7 @@ int launch_conv_dgrad_c2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, vo
 }
 
 int launch_conv_dgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img,
-                         float* dx) {
+                         float* dx, int dy_bf16) {
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_c2_kernel),
@@ -185,7 +218,7 @@ int launch_conv_dgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const 
             tiles2 = (g.D[2] + DT2 - 1) / DT2;
   hipLaunchKernelGGL(conv_dgrad_c2_kernel, dim3((unsigned)(g.N * tiles0 * tiles1 * tiles2)),
                      dim3(DNT), DLDS, ctx->stream, dy, (const unsigned short*)img, dx, g, tiles0,
-                     tiles1, tiles2);
+                     tiles1, tiles2, dy_bf16);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -49,11 +49,19 @@ __global__ void dgrad_s2_pack_kernel(const float* __restrict__ w, unsigned short
   }
 }
 
-template <int NF>
+// O16 (NF = 2, C_in = 32): dx is stored as bf16 ONLY — it is dPre of the conv
+// below (mask fused, single consumer) whose gradient kernels take bf16.  The
+// filter rows are taken in the order (kg, nf, r) so that a lane's two C/D
+// fragments are 8 CONSECUTIVE channels 8 kg .. 8 kg + 7: one 16-B store (and
+// one 16-B mask read) per position and lane, a whole 64-B row per position
+// across the k-groups.  A lane owns the same 8 channels throughout, so their
+// sums — the bias gradient of that conv — accumulate in registers and leave as
+// one partial row per workgroup (bsum[block][32], for bias_grad_stage2).
+template <int NF, bool O16 = false>
 __global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
     const float* __restrict__ dy, const unsigned short* __restrict__ img,
     float* __restrict__ dx, ConvGeom g, int rows_pad, int tiles0, int tiles1, int tiles2,
-    const void* __restrict__ mask_y, float mask_slope, int mask_bf16) {
+    const void* __restrict__ mask_y, float mask_slope, int mask_bf16, float* __restrict__ bsum) {
   extern __shared__ __attribute__((aligned(16))) char halo[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kg = lane >> 4;
@@ -108,8 +116,10 @@ __global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
     const int th = j + 1 - d;
     off_d[d] = th * 64 + ((kg ^ ((th >> 1) & 3)) << 4);
   }
-  const unsigned short* wrow = img + ((size_t)ct * 64 + j) * 32 + kg * 8;
+  // (O16: row (nf, j) of the A operand = channel 8 (j >> 2) + 4 nf + (j & 3))
+  const unsigned short* wrow = img + ((size_t)ct * 64 + (O16 ? (j >> 2) * 8 + (j & 3) : j)) * 32 + kg * 8;
   const int R = g.Cin;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // O16: channel sums of what this lane stores
   // wave w owns the u rows (r0 = w, r1 = 0..7)
 #pragma unroll 1
   for (int cls = 0; cls < 8; ++cls) {
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
           bf16x8 afr[NF];
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf)
-            afr[nf] = *reinterpret_cast<const bf16x8*>(wrow + ((size_t)tp * rows_pad + nf * 16) * 32);
+            afr[nf] = *reinterpret_cast<const bf16x8*>(wrow + ((size_t)tp * rows_pad + (O16 ? nf * 4 : nf * 16)) * 32);
           const char* hb = halo + (((wave + 1 - d0) * SG1 + (1 - d1)) * SG2) * 64 + off_d[d2];
 #pragma unroll
           for (int m = 0; m < 8; ++m) {
@@ -142,6 +152,40 @@ __global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
         }
     // ---- store the class: x position i = 2 u + p
     const int i0 = 2 * (u0 + wave) + p0, i2 = 2 * (u2 + j) + p2;
+    if constexpr (O16) {
+      unsigned short* dx16 = reinterpret_cast<unsigned short*>(dx);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int i1 = 2 * (u1 + m) + p1;
+        if (i0 >= g.D[0] || i1 >= g.D[1] || i2 >= g.D[2]) continue;
+        const size_t e = ((((size_t)n * g.D[0] + i0) * g.D[1] + i1) * g.D[2] + i2) * 32 + kg * 8;
+        float v[8];
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) v[q8] = acc[m][q8 >> 2][q8 & 3];
+        if (mask_y) {
+          float yv[8];
+          if (mask_bf16) {
+            const uint4 h = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(mask_y) + e);
+            yv[0] = __uint_as_float(h.x << 16); yv[1] = __uint_as_float(h.x & 0xFFFF0000u);
+            yv[2] = __uint_as_float(h.y << 16); yv[3] = __uint_as_float(h.y & 0xFFFF0000u);
+            yv[4] = __uint_as_float(h.z << 16); yv[5] = __uint_as_float(h.z & 0xFFFF0000u);
+            yv[6] = __uint_as_float(h.w << 16); yv[7] = __uint_as_float(h.w & 0xFFFF0000u);
+          } else {
+            const float4 a4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(mask_y) + e);
+            const float4 b4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(mask_y) + e + 4);
+            yv[0] = a4.x; yv[1] = a4.y; yv[2] = a4.z; yv[3] = a4.w;
+            yv[4] = b4.x; yv[5] = b4.y; yv[6] = b4.z; yv[7] = b4.w;
+          }
+#pragma unroll
+          for (int q8 = 0; q8 < 8; ++q8) v[q8] *= yv[q8] > 0.f ? 1.f : mask_slope;
+        }
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) csum[q8] += v[q8];
+        *reinterpret_cast<uint4*>(dx16 + e) =
+            make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+      }
+      continue;
+    }
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       const int ch = ct * 64 + nf * 16 + kg * 4;
@@ -166,6 +210,23 @@ __global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
           v.z *= yv.z > 0.f ? 1.f : mask_slope; v.w *= yv.w > 0.f ? 1.f : mask_slope;
         }
         *reinterpret_cast<float4*>(dx + e) = v;
+      }
+    }
+  }
+  if constexpr (O16) {
+    if (bsum) {
+      // lanes (j, kg) of all four waves -> channel 8 kg + q8: fixed-order sum in LDS
+      __syncthreads();                       // every wave is done with the halo
+      float* red = reinterpret_cast<float*>(halo);      // [256 threads][8]
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8) red[tid * 8 + q8] = csum[q8];
+      __syncthreads();
+      if (tid < 32) {
+        const int kq = tid >> 3, q8 = tid & 7;
+        float t = 0.f;
+        for (int w = 0; w < SNW; ++w)
+          for (int jj = 0; jj < 16; ++jj) t += red[((w * 64) + kq * 16 + jj) * 8 + q8];
+        bsum[(size_t)blockIdx.x * 32 + tid] = t;
       }
     }
   }
@@ -201,19 +262,33 @@ int launch_conv_dgrad_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, vo
   return S3_OK;
 }
 
+// dx as bf16 only (+ per-workgroup channel sums): C_in = 32, one cout tile
+bool conv_dgrad_s2_out16_ok(const ConvGeom& g) { return g.Cin == 32; }
+int conv_dgrad_s2_blocks(const ConvGeom& g) {
+  const int U0 = (g.D[0] + 1) / 2, U1 = (g.D[1] + 1) / 2, U2 = (g.D[2] + 1) / 2;
+  return g.N * ((U0 + ST0 - 1) / ST0) * ((U1 + ST1 - 1) / ST1) * ((U2 + ST2 - 1) / ST2);
+}
+
 int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx,
-                         const void* mask_y, float mask_slope, int mask_bf16) {
+                         const void* mask_y, float mask_slope, int mask_bf16, int out_bf16, float* bsum) {
   const int U0 = (g.D[0] + 1) / 2, U1 = (g.D[1] + 1) / 2, U2 = (g.D[2] + 1) / 2;
   const int tiles0 = (U0 + ST0 - 1) / ST0, tiles1 = (U1 + ST1 - 1) / ST1, tiles2 = (U2 + ST2 - 1) / ST2;
   const int n_ct = (g.Cin + 63) / 64;
   dim3 grid((unsigned)(g.N * tiles0 * tiles1 * tiles2), (unsigned)n_ct);
   const int rp = s2_rows_pad(g.Cin);
-  if (g.Cin <= 32)
+  if (out_bf16) {
+    if (!conv_dgrad_s2_out16_ok(g)) S3_FAIL(ctx, S3_EINVAL, "dgrad_s2: bf16 output needs C_in = 32");
+    hipLaunchKernelGGL((conv_dgrad_s2_kernel<2, true>), grid, dim3(SNT), SLDS, ctx->stream, dy,
+                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_y, mask_slope, mask_bf16,
+                       bsum);
+  } else if (g.Cin <= 32)
     hipLaunchKernelGGL(conv_dgrad_s2_kernel<2>, grid, dim3(SNT), SLDS, ctx->stream, dy,
-                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_y, mask_slope, mask_bf16);
+                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_y, mask_slope, mask_bf16,
+                       (float*)nullptr);
   else
     hipLaunchKernelGGL(conv_dgrad_s2_kernel<4>, grid, dim3(SNT), SLDS, ctx->stream, dy,
-                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_y, mask_slope, mask_bf16);
+                       (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_y, mask_slope, mask_bf16,
+                       (float*)nullptr);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

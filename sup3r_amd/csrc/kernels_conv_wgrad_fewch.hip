@@ -32,7 +32,11 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
 
 constexpr int C2_WAVES = 4;
 
-template <int CIN, int NB>
+// DY16: dPre is a bf16 tensor (C_out even).  Lane (co, kg) still issues 8 four-
+// byte loads per channel block — the dword holding channels (co & ~1, co | 1)
+// of t = 8 kg + e — and keeps its own half: the same instruction count as the
+// fp32 path, half the bytes from memory (2-B loads were measured slower).
+template <int CIN, int NB, bool DY16 = false>
 __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int chunks, int64_t n_steps) {
@@ -75,6 +79,22 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
     bf16x8 bfr[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
+      if constexpr (DY16) {
+        const unsigned* dr32 = reinterpret_cast<const unsigned*>(
+            reinterpret_cast<const unsigned short*>(dy) +
+            ((((int64_t)n * O0 + o0) * O1 + o1) * O2 + tl) * Cout);
+        const int co = nb * 16 + i;
+        unsigned h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned w2 = co < Cout ? dr32[((int64_t)e * Cout + (co & ~1)) >> 1] : 0u;
+          const unsigned hv = (co & 1) ? (w2 >> 16) : (w2 & 0xFFFFu);
+          h[e] = (e >= shift && tl + e < O2) ? hv : 0u;
+        }
+        const uint4 u = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        bfr[nb] = __builtin_bit_cast(bf16x8, u);
+        continue;
+      }
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -192,7 +212,7 @@ size_t conv_wgrad_c2_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
 }
 
 int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                         float* dw, float* partial, size_t partial_bytes, int accumulate) {
+                         float* dw, float* partial, size_t partial_bytes, int accumulate, int dy_bf16) {
   int chunks;
   const int64_t n_steps = c2_steps(g, &chunks);
   const int grid = c2_grid(ctx, n_steps);
@@ -202,7 +222,11 @@ int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const f
 #define S3_C2(C, B)                                                                          \
   hipLaunchKernelGGL((conv_wgrad_c2_kernel<C, B>), dim3(grid), dim3(C2_WAVES * 64), 0, ctx->stream, \
                      x, dy, partial, g, chunks, n_steps)
-  if (g.Cin == 8) S3_C2(8, 1);
+  if (dy_bf16) {
+    if (g.Cin != 2 || nb != 2 || (g.Cout & 1)) S3_FAIL(ctx, S3_EINVAL, "wgrad_c2: bf16 dPre needs C_in = 2, C_out = 32");
+    hipLaunchKernelGGL((conv_wgrad_c2_kernel<2, 2, true>), dim3(grid), dim3(C2_WAVES * 64), 0, ctx->stream,
+                       x, dy, partial, g, chunks, n_steps);
+  } else if (g.Cin == 8) S3_C2(8, 1);
   else if (nb == 1) S3_C2(2, 1);
   else if (nb == 2) S3_C2(2, 2);
   else S3_C2(2, 4);

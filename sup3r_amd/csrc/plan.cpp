@@ -90,6 +90,7 @@ struct s3_plan {
   std::vector<void*> owned;  // every hipMalloc of this plan
   float* dpre = nullptr;      // conv/dense epilogue-adjoint workspace
   void* dpre16 = nullptr;     // its bf16 copy (mask pass of a conv with use16)
+  size_t dpre16_bytes = 0;
   int dpre16_for = -1;        // tensor root whose finished gradient = dPre of its producer is in dpre16, -1: none
   bool dpre16_only = false;   // ... and ONLY there (bf16-only frame fold); false: the fp32 tensor is valid too
   float* gtmp = nullptr;      // gradient staging when a tensor has >1 consumer
@@ -713,7 +714,14 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
         o.use16 = true;
         max16 = std::max(max16, (size_t)pl->t[root_of(pl, o.d.out)].numel * 2);
       }
+      // ... and for the stride-2 data gradient that stores dPre of the
+      // few-channel conv below it as bf16 only (see the dgrad_s2 branch)
+      for (auto& o : pl->ops)
+        if (o.d.kind == S3_OP_CONV && o.dgrad_s2 && o.mask_prod >= 0 && pl->ops[o.mask_prod].wgrad_c2 &&
+            conv_dgrad_s2_out16_ok(o.cg))
+          max16 = std::max(max16, (size_t)pl->t[root_of(pl, o.d.in0)].numel * 2);
       if (!rc && max16) rc = plan_alloc(pl, &pl->dpre16, max16);
+      pl->dpre16_bytes = max16;
     }
     if (!rc) rc = plan_alloc(pl, (void**)&pl->gtmp, max_t);
     if (!rc) rc = plan_alloc(pl, (void**)&pl->bsum, (size_t)4096 * 256 * sizeof(float));
@@ -1361,7 +1369,9 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
         if (only16) {
           dpre16 = pl->dpre16;
           pl->dpre16_for = -1;
-          if (!o.use16 || !o.wgrad_bf16 || d.res >= 0)
+          const bool trunk16 = o.use16 && o.wgrad_bf16;
+          const bool fewch16 = o.wgrad_c2 && (o.dgrad_c2 || !wants_grad(d.in0));
+          if ((!trunk16 && !fewch16) || d.res >= 0)
             S3_FAIL(ctx, S3_ESTATE, "backward: bf16-only dPre reached a conv that needs fp32");
         } else if (pl->dpre16_for == ro && !pl->dpre16_only) {
           // fp32 tensor + bf16 copy (fold + earlier contribution of a skip tensor):
@@ -1401,7 +1411,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           else if (o.wgrad_tail)
             rc = launch_conv_wgrad_tail(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16);
           else if (o.wgrad_c2)
-            rc = launch_conv_wgrad_c2(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+            rc = launch_conv_wgrad_c2(ctx, g, tptr(pl, d.in0), only16 ? (const float*)dpre16 : dpre, G + P->p[d.w].offset,
+                                      pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, only16 ? 1 : 0);
           else if (o.wgrad_bf16_2d)
             rc = launch_conv_wgrad_bf16_2d(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16_gen)
@@ -1554,18 +1565,39 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             }
             // single consumer of an activated conv output: its LeakyReLU / ReLU
             // adjoint is applied in the store (the producer then skips its mask pass)
-            const bool fuse = o.mask_prod >= 0 && !pl->gwritten[root_of(pl, d.in0)] && !getenv("SUP3R_AMD_NO_MASK_FUSE");
-            const ConvGeom& pg = pl->ops[fuse ? o.mask_prod : i].cg;
-            rc = launch_conv_dgrad_s2(ctx, g, dpre, o.dc2_w, dst, fuse ? tptr(pl, d.in0) : nullptr,
-                                      pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, o.io.in_bf16);
-            if (!rc && fuse) pl->premasked[root_of(pl, d.in0)] = 1;
+            const int rin = root_of(pl, d.in0);
+            const bool fuse = o.mask_prod >= 0 && !pl->gwritten[rin] && !getenv("SUP3R_AMD_NO_MASK_FUSE");
+            const OpRec& po = pl->ops[fuse ? o.mask_prod : i];
+            const ConvGeom& pg = po.cg;
+            // dx is dPre of the few-channel conv below (mask fused, single
+            // consumer).  Its weight gradient (conv_wgrad_c2_kernel), its data
+            // gradient (conv_dgrad_c2_kernel, generator step only) and its bias
+            // gradient (channel sums riding along here) all take bf16: store it
+            // as bf16 ONLY — 0.89 instead of 1.78 GB written here and read there,
+            // and no separate bias pass over it.
+            const int nblk = conv_dgrad_s2_blocks(g);
+            const bool sums = need_wgrad && po.d.b >= 0;
+            const bool to16 = fuse && dst == pl->t[rin].gptr && pl->precision == S3_PREC_BF16 && po.wgrad_c2 &&
+                              po.cg.Cin == 2 && po.cg.Cout == 32 && po.d.res < 0 &&
+                              (po.dgrad_c2 || !wants_grad(po.d.in0)) && conv_dgrad_s2_out16_ok(g) && pl->dpre16 &&
+                              pl->dpre16_bytes >= (size_t)pl->t[rin].numel * 2 && pl->dpre16_for < 0 &&
+                              (!sums || (pl->bsum && nblk <= 4096 && !getenv("SUP3R_AMD_NO_BIAS_FUSE"))) &&
+                              !getenv("SUP3R_AMD_NO_DPRE16");
+            rc = launch_conv_dgrad_s2(ctx, g, dpre, o.dc2_w, to16 ? (float*)pl->dpre16 : dst,
+                                      fuse ? tptr(pl, d.in0) : nullptr, pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f,
+                                      o.io.in_bf16, to16 ? 1 : 0, (to16 && sums) ? pl->bsum : nullptr);
+            if (!rc && fuse) pl->premasked[rin] = 1;
+            if (!rc && to16) {
+              pl->dpre16_for = rin; pl->dpre16_only = true;
+              if (sums) { pl->bsum_for = rin; pl->bsum_nblk = nblk; }
+            }
           } else if (o.dgrad_c2) {
             if (o.dc2_version != (int64_t)P->version) {
               rc = launch_conv_dgrad_c2_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);
               if (rc) return rc;
               o.dc2_version = (int64_t)P->version;
             }
-            rc = launch_conv_dgrad_c2(ctx, g, dpre, o.dc2_w, dst);
+            rc = launch_conv_dgrad_c2(ctx, g, only16 ? (const float*)dpre16 : dpre, o.dc2_w, dst, only16 ? 1 : 0);
           } else if (o.gconv_dgrad) {
             if (o.gct_version != P->version) {
               rc = launch_gconv_pack(ctx, g, W + P->p[d.w].offset, o.gc_wt, 1);

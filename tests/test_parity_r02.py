@@ -906,3 +906,47 @@ def test_trunk_data_gradient_on_the_persistent_kernel_is_bit_identical(monkeypat
     np.testing.assert_array_equal(dx1, dx0)
     for a, b in zip(g1, g0):
         np.testing.assert_array_equal(a, b)
+
+
+def test_first_disc_layer_bf16_only_dpre_changes_only_the_bias_sum_order(monkeypatch):
+    """conv_dgrad_s2_kernel<2, O16> stores the gradient of the first
+    discriminator activation — dPre of the 2 -> 32 conv, mask fused — as bf16
+    only; conv_wgrad_c2_kernel<.., DY16> / conv_dgrad_c2_kernel read it that
+    way and the bias gradient comes from the channel sums of the store.  The
+    fp32 route rounds the same values to bf16 in those kernels: dx and the
+    filter gradients are bit-identical, the bias gradient differs by the
+    order of its fp32 sum"""
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(32, 2) + conv(64, 1) + \
+        [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (2, 27, 33, 77, 2)
+    monkeypatch.setenv('SUP3R_AMD_DGRAD_S2_MIN_TILES', '1')
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+
+    def run():
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=0)
+        ph = net.plan(shape, training=True)
+        assert _kernels(ph, 'dgrad')[1] == 's2' and _kernels(ph, 'wgrad')[0] == 'c2'
+        y = ph.forward(net.dev.to_device(x))
+        dy = net.dev.to_device(np.ones(tuple(y.shape), np.float32))
+        dx = ph.backward(dy, need_dx=True).cpu().numpy()
+        g = [a.copy() for a in net.grads]
+        del ph
+        net.clear_plans()
+        return dx, g
+    dx1, g1 = run()
+    monkeypatch.setenv('SUP3R_AMD_NO_DPRE16', '1')
+    dx0, g0 = run()
+    monkeypatch.delenv('SUP3R_AMD_NO_DPRE16')
+    np.testing.assert_array_equal(dx1, dx0)
+    for k, (a, b) in enumerate(zip(g1, g0)):
+        if a.ndim > 1:
+            np.testing.assert_array_equal(a, b)
+        else:
+            assert rel_linf(a, b) < 1e-5, k
