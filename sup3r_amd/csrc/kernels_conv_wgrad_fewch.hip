@@ -32,10 +32,13 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
 
 constexpr int C2_WAVES = 4;
 
-// DY16: dPre is a bf16 tensor (C_out even).  Lane (co, kg) still issues 8 four-
-// byte loads per channel block — the dword holding channels (co & ~1, co | 1)
-// of t = 8 kg + e — and keeps its own half: the same instruction count as the
-// fp32 path, half the bytes from memory (2-B loads were measured slower).
+// DY16: dPre is a bf16 tensor with C_out = 32.  The 32 t-rows of a k-step are
+// 2 KB: every lane fetches 32 B of them (two 16-B loads instead of sixteen 4-B
+// ones), drops them into a wave-private LDS block in the natural [t][co]
+// order, and the K-major B fragments come back through ds_read_b64_tr_b16
+// exactly as in conv3_wgrad_bf16_kernel (same 32-B segment swizzle).  No
+// workgroup barrier: a wave's LDS operations complete in issue order.  (Per-
+// lane 4-B pair loads + unpacking were measured 1.6x SLOWER than the fp32 path.)
 template <int CIN, int NB, bool DY16 = false>
 __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
@@ -43,6 +46,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
   constexpr int MT = 27 * CIN;                  // rows of the gradient
   constexpr int MB = (MT + 15) / 16;
   __shared__ float red[C2_WAVES][MB * NB][64][4];
+  __shared__ __attribute__((aligned(16))) char dst[DY16 ? C2_WAVES * 2048 : 16];   // DY16: [wave][32 t][64 B]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kg = lane >> 4;
   const int S1 = g.D[1], S2 = g.D[2];
@@ -72,7 +76,9 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
     const int n = (int)row;
     // clamp the lane's first t so that the 8 loads stay inside the row; the
     // shifted-out positions are masked through dPre
-    const int tl = t0 + 8 <= O2 ? t0 : (O2 - 8 > 0 ? O2 - 8 : 0);
+    // (DY16: no shift — the staged dPre rows carry the t >= O2 mask, the x
+    // loads past the row end take the per-element path below)
+    const int tl = DY16 ? t0 : (t0 + 8 <= O2 ? t0 : (O2 - 8 > 0 ? O2 - 8 : 0));
     const int shift = t0 - tl;                 // 0, or how many of the 8 slots repeat earlier t
     const float* dr = dy + ((((int64_t)n * O0 + o0) * O1 + o1) * O2 + tl) * Cout;
     const int xstep = CIN * g.s[2];
@@ -80,19 +86,39 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       if constexpr (DY16) {
-        const unsigned* dr32 = reinterpret_cast<const unsigned*>(
-            reinterpret_cast<const unsigned short*>(dy) +
-            ((((int64_t)n * O0 + o0) * O1 + o1) * O2 + tl) * Cout);
-        const int co = nb * 16 + i;
-        unsigned h[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const unsigned w2 = co < Cout ? dr32[((int64_t)e * Cout + (co & ~1)) >> 1] : 0u;
-          const unsigned hv = (co & 1) ? (w2 >> 16) : (w2 & 0xFFFFu);
-          h[e] = (e >= shift && tl + e < O2) ? hv : 0u;
+        if (nb == 0) {
+          // stage rows t = 32 chunk + r, r = lane >> 1; this lane's 32-B half
+          const int r = lane >> 1, hf = lane & 1;
+          const int tr = (int)(step % chunks) * 32 + r;
+          uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0;
+          if (tr < O2) {
+            const uint4* src = reinterpret_cast<const uint4*>(
+                reinterpret_cast<const unsigned short*>(dy) +
+                ((((int64_t)n * O0 + o0) * O1 + o1) * O2 + tr) * 32 + hf * 16);
+            q0 = src[0]; q1 = src[1];
+          }
+          char* d = dst + wave * 2048 + r * 64 + ((hf ^ ((r >> 3) & 1)) << 5);
+          // (other lanes read what this lane writes: keep the compiler from
+          // moving LDS accesses across these points; the hardware runs a
+          // wave's LDS operations in order)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          *reinterpret_cast<uint4*>(d) = q0;
+          *reinterpret_cast<uint4*>(d + 16) = q1;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        const uint4 u = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-        bfr[nb] = __builtin_bit_cast(bf16x8, u);
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const char* wb = dst + wave * 2048;
+        s16x4 lh[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pl = 8 * kg + 4 * h + (i >> 2);
+          lh[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(wb + pl * 64 + ((nb ^ ((pl >> 3) & 1)) << 5) + ((i & 3) << 3)));
+        }
+        bfr[nb] = __builtin_shufflevector(lh[0], lh[1], 0, 1, 2, 3, 4, 5, 6, 7);
         continue;
       }
       float v[8];
@@ -223,7 +249,7 @@ int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const f
   hipLaunchKernelGGL((conv_wgrad_c2_kernel<C, B>), dim3(grid), dim3(C2_WAVES * 64), 0, ctx->stream, \
                      x, dy, partial, g, chunks, n_steps)
   if (dy_bf16) {
-    if (g.Cin != 2 || nb != 2 || (g.Cout & 1)) S3_FAIL(ctx, S3_EINVAL, "wgrad_c2: bf16 dPre needs C_in = 2, C_out = 32");
+    if (g.Cin != 2 || g.Cout != 32) S3_FAIL(ctx, S3_EINVAL, "wgrad_c2: bf16 dPre needs C_in = 2, C_out = 32");
     hipLaunchKernelGGL((conv_wgrad_c2_kernel<2, 2, true>), dim3(grid), dim3(C2_WAVES * 64), 0, ctx->stream,
                        x, dy, partial, g, chunks, n_steps);
   } else if (g.Cin == 8) S3_C2(8, 1);
