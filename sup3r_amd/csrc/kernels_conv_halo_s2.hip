@@ -5,7 +5,8 @@
 //
 // The gather kernel re-reads every input cell 27 / 8 times through L1 with
 // per-tap index math (0.63 ms at C2 batch 8; the layer's input is 0.89 GB).
-// Here ONE persistent 4-wave workgroup per CU walks a contiguous range of
+// Here ONE persistent 8-wave workgroup per CU (a wave per output row: two
+// waves per SIMD hide each other's LDS latency) walks a contiguous range of
 // 2 x 4 x 16 output tiles:
 //
 //   * the tile's 5 x 9 x 33 input halo (64-B bf16 cells, 95 KB) sits in LDS
@@ -15,7 +16,7 @@
 //     j + 1): the stride-1 swizzle of conv_halo32_kernel stays conflict-free;
 //   * the whole 27 x 32 x 32 filter (55 KB bf16) is staged ONCE per workgroup
 //     into LDS, 64-B rows: a wave's A fragment is one contiguous KB;
-//   * the next tile's halo is fetched into registers (24 x 16 B per lane)
+//   * the next tile's halo is fetched into registers (12 x 16 B per lane)
 //     before the 27-tap loop and dropped into LDS after it: the per-CU L2 -> CU
 //     path (~10 B / clk) that bounds this layer runs under the MFMAs.
 //
@@ -35,11 +36,11 @@ typedef float hf32x2 __attribute__((ext_vector_type(2)));
 constexpr int ST0 = 2, ST1 = 4, ST2 = 16;                 // output tile
 constexpr int SH0 = 2 * ST0 + 1, SH1 = 2 * ST1 + 1, SH2 = 2 * ST2 + 1;   // 5 x 9 x 33
 constexpr int SHP = SH0 * SH1 * SH2;                      // 1485 halo cells
-constexpr int SNW = 4, SNT = SNW * 64;
+constexpr int SNW = 8, SNT = SNW * 64;      // one (s0, s1) output row per wave, two waves per SIMD
 constexpr int S_HALO = SHP * 64;                          // 95,040 B
 constexpr int S_FILT = 27 * 32 * 64;                      // 55,296 B
 constexpr int S_LDS = S_HALO + S_FILT;                    // 150,336 B
-constexpr int SNCH = (SHP * 4 + SNT - 1) / SNT;           // 24 chunks per lane
+constexpr int SNCH = (SHP * 4 + SNT - 1) / SNT;           // 12 chunks per lane
 constexpr int NEVEN = ST2 + 1;                            // even cells of a row
 
 __device__ __forceinline__ unsigned pk2(float a, float b) {
@@ -143,10 +144,8 @@ __global__ __launch_bounds__(SNT) void conv_halo_s2_kernel(
     const int e = (c == 1 ? NEVEN : (c >> 1)) + j;
     off_c[c] = e * 64 + ((kg ^ slot_key(e)) << 4);
   }
-  // this wave's two (s0, s1) output rows
-  const int r0 = 2 * wave, r1 = 2 * wave + 1;
-  const int rowb[2] = {((2 * (r0 / ST1)) * SH1 + 2 * (r0 % ST1)) * SH2 * 64,
-                       ((2 * (r1 / ST1)) * SH1 + 2 * (r1 % ST1)) * SH2 * 64};
+  // this wave's (s0, s1) output row
+  const int rowb = ((2 * (wave / ST1)) * SH1 + 2 * (wave % ST1)) * SH2 * 64;
   const char* fa = filt + j * 64 + kg * 16;
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
   const int R = g.Cout;
@@ -154,46 +153,38 @@ __global__ __launch_bounds__(SNT) void conv_halo_s2_kernel(
   for (int tile = t_first; tile < t_end; ++tile) {
     const bool has_next = tile + 1 < t_end;
     if (has_next) halo_fetch(tile + 1);
-    f32x4 acc[2][NF];
+    f32x4 acc[NF];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) acc[m][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < NF; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tp = 0; tp < 27; ++tp) {
       const int a = tp / 9, b = (tp / 3) % 3, c = tp % 3;
-      bf16x8 afr[NF], bfr[2];
+      bf16x8 afr[NF];
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf)
         afr[nf] = *reinterpret_cast<const bf16x8*>(fa + (tp * 32 + nf * 16) * 64);
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(halo + rowb + (a * SH1 + b) * SH2 * 64 + off_c[c]);
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-        bfr[m] = *reinterpret_cast<const bf16x8*>(halo + rowb[m] + (a * SH1 + b) * SH2 * 64 + off_c[c]);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-          acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[nf], bfr[m], acc[m][nf], 0, 0, 0);
+      for (int nf = 0; nf < NF; ++nf)
+        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[nf], bfr, acc[nf], 0, 0, 0);
     }
 
     // ---- C/D: col = t, row = 4 kg + r (channel 16 nf + 4 kg + r)
     int n, o0b, o1b, o2b;
     tile_org(tile, n, o0b, o1b, o2b);
     const int o2 = o2b + j;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int rr = 2 * wave + m;
-      const int o0 = o0b + rr / ST1, o1 = o1b + rr % ST1;
-      if (o0 >= g.O[0] || o1 >= g.O[1] || o2 >= g.O[2]) continue;
+    {
+      const int o0 = o0b + wave / ST1, o1 = o1b + wave % ST1;
+      const bool ok = o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2];
       const size_t oi = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * R;
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
         const int ch = nf * 16 + kg * 4;
-        if (ch >= R) continue;
+        if (ch >= R || !ok) continue;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = acc[m][nf][r] + ((bias && ch + r < R) ? bias[ch + r] : 0.f);
+          v[r] = acc[nf][r] + ((bias && ch + r < R) ? bias[ch + r] : 0.f);
           v[r] = v[r] > 0.f ? v[r] : slope * v[r];
         }
         if (out16)

@@ -337,6 +337,56 @@ __global__ void conv_epilogue_bwd_kernel(const float* __restrict__ y,
   }
 }
 
+// depth-to-space variant, four channels per lane, walking dPre (the
+// DESTINATION) in order: the generic kernel above spends 89 % of the SIMD
+// cycles on five 64-bit divisions per ELEMENT (PMC, 64 -> 200 + d2s 5 conv of
+// C2: 0.59 ms).  Here a lane owns 4 consecutive channels of one (cell, block):
+// 32-bit index math when the tensor allows, one division chain per four
+// elements, fully coalesced 16-B stores (whole 128-B lines per wave) and 16-B /
+// 8-B gathers of dy / y from the hi-res layout (32-B sectors, nothing wasted).
+// (Walking the hi-res layout instead scatters 16-B pieces of every dPre line
+// over 25 far-apart moments: 0.52 ms.)
+template <bool Y16>
+__global__ void conv_epilogue_bwd_d2s4_kernel(const void* __restrict__ y, const float4* __restrict__ dy,
+                                              float4* __restrict__ dpre, ConvGeom g, float slope) {
+  const unsigned b = (unsigned)g.d2s, co4 = ((unsigned)g.Cout / (b * b)) >> 2, C4 = (unsigned)g.Cout >> 2;
+  const unsigned O0 = (unsigned)g.O[0], O1 = (unsigned)g.O[1], O2 = (unsigned)g.O[2];
+  const int64_t total = (int64_t)g.N * O0 * O1 * O2 * C4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    unsigned c4, o2, o1, o0, n;
+    if (total <= 0xffffffffLL) {
+      unsigned r = (unsigned)idx, q;
+      q = r / C4; c4 = r - q * C4; r = q;
+      q = r / O2; o2 = r - q * O2; r = q;
+      q = r / O1; o1 = r - q * O1; r = q;
+      q = r / O0; o0 = r - q * O0; n = q;
+    } else {
+      int64_t r = idx;
+      c4 = (unsigned)(r % C4); r /= C4;
+      o2 = (unsigned)(r % O2); r /= O2;
+      o1 = (unsigned)(r % O1); r /= O1;
+      o0 = (unsigned)(r % O0); r /= O0;
+      n = (unsigned)r;
+    }
+    const unsigned blk = c4 / co4, cc4 = c4 - blk * co4, p0 = blk / b, p1 = blk - p0 * b;
+    // float4 index of the hi-res cell (n, o0 b + p0, o1 b + p1, o2), channels 4 cc4 ..
+    const int64_t src = ((((int64_t)n * O0 * b + o0 * b + p0) * (O1 * b) + o1 * b + p1) * O2 + o2) * co4 + cc4;
+    float4 d = dy[src];
+    if (Y16) {
+      const uint2 h = reinterpret_cast<const uint2*>(y)[src];
+      auto pos = [](unsigned v) { return (v & 0x8000u) == 0 && (v & 0x7FFFu) != 0; };
+      d.x *= pos(h.x & 0xFFFFu) ? 1.f : slope; d.y *= pos(h.x >> 16) ? 1.f : slope;
+      d.z *= pos(h.y & 0xFFFFu) ? 1.f : slope; d.w *= pos(h.y >> 16) ? 1.f : slope;
+    } else {
+      const float4 v = reinterpret_cast<const float4*>(y)[src];
+      d.x *= v.x > 0.f ? 1.f : slope; d.y *= v.y > 0.f ? 1.f : slope;
+      d.z *= v.z > 0.f ? 1.f : slope; d.w *= v.w > 0.f ? 1.f : slope;
+    }
+    dpre[idx] = d;
+  }
+}
+
 // the same without a store permutation, four channels per lane
 template <bool Y16>
 __global__ void conv_epilogue_bwd4_kernel(const void* __restrict__ y, const float4* __restrict__ dy,
@@ -899,6 +949,19 @@ int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
     return S3_OK;
   }
   if (d16 || bsum) S3_FAIL(ctx, S3_EINVAL, "conv_epilogue_bwd: side outputs need the 4-channel path");
+  if (g.d2s > 1 && ((g.Cout / (g.d2s * g.d2s)) & 3) == 0 && (g.Cout & 3) == 0 &&
+      (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU || g.act == S3_ACT_NONE)) {
+    const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+    const dim3 grid(grid_for(n / 4, ctx->num_cu));
+    if (y_bf16)
+      hipLaunchKernelGGL(conv_epilogue_bwd_d2s4_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, (const void*)y,
+                         (const float4*)dy, (float4*)dpre, g, slope);
+    else
+      hipLaunchKernelGGL(conv_epilogue_bwd_d2s4_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, (const void*)y,
+                         (const float4*)dy, (float4*)dpre, g, slope);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   if (y_bf16)
     hipLaunchKernelGGL(conv_epilogue_bwd_kernel<true>, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, y, dy, dpre, g);
   else
