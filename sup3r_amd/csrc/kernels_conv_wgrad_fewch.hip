@@ -47,6 +47,13 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
   constexpr int MB = (MT + 15) / 16;
   __shared__ float red[C2_WAVES][MB * NB][64][4];
   __shared__ __attribute__((aligned(16))) char dst[DY16 ? C2_WAVES * 2048 : 16];   // DY16: [wave][32 t][64 B]
+  // DY16, stride 1, no padding: the x window of a k-step — 9 (ta, tb) rows of 34
+  // cells — is fetched once per wave (5 coalesced 8-B loads per lane instead of
+  // 32 gathered 4-B ones) and the A fragments are read back from here
+  constexpr int XW_CELLS = 9 * 34;
+  __shared__ __attribute__((aligned(16))) float2 xw[(DY16 && CIN == 2) ? C2_WAVES * XW_CELLS : 1];
+  const bool xwin = DY16 && CIN == 2 && !(g.pad_mode == S3_PAD_REFLECT) && g.s[0] == 1 && g.s[1] == 1 &&
+                    g.s[2] == 1 && g.lo[0] == 0 && g.lo[1] == 0 && g.lo[2] == 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kg = lane >> 4;
   const int S1 = g.D[1], S2 = g.D[2];
@@ -132,9 +139,43 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
       const uint4 u = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
       bfr[nb] = __builtin_bit_cast(bf16x8, u);
     }
+    if constexpr (DY16 && CIN == 2) {
+      if (xwin) {
+        const int tch = (int)(step % chunks) * 32;
+        float2* xb = xw + wave * XW_CELLS;
+        float2 c5[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int item = lane + 64 * k;
+          const int rw = item / 34, cl = item - rw * 34;
+          int tt = tch + cl;
+          tt = tt > S2 - 1 ? S2 - 1 : tt;          // (past the row: feeds t >= O2 only, zero dPre)
+          c5[k] = make_float2(0.f, 0.f);
+          if (item < XW_CELLS)
+            c5[k] = *reinterpret_cast<const float2*>(
+                x + ((((int64_t)n * D0 + o0 + rw / 3) * S1 + o1 + rw % 3) * S2 + tt) * 2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (lane + 64 * k < XW_CELLS) xb[lane + 64 * k] = c5[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       float v[8];
+      if (DY16 && CIN == 2 && xwin) {
+        const int ti = tinfo[mb];
+        const int ta = ti & 15, tb = (ti >> 4) & 15, tc = (ti >> 8) & 15, ci = (ti >> 12) & 15;
+        const float* xr = reinterpret_cast<const float*>(xw + wave * XW_CELLS) +
+                          ((ta * 3 + tb) * 34 + kg * 8 + tc) * 2 + ci;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ti >= 0 ? xr[e * 2] : 0.f;
+      } else
       {
         // this lane's tap: source row (i0, i1) under the (virtual) padding,
         // then 8 cells along t — linear when they are all inside the row
