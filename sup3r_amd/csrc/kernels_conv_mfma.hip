@@ -143,7 +143,10 @@ __global__ void pack_bf16x3_kernel(const float* __restrict__ w,
   }
 }
 
-template <int PREC, int TS0, int TS1, int NW, bool IN16, bool OUT16>
+// NFV: N fragments of the 64-wide cout tile that are computed (bf16 mode; 2 when
+// C_out <= 32 — the data gradient of the discriminator's 32 -> 64 conv — so that
+// half of the MFMAs and filter-fragment reads are not spent on zero rows)
+template <int PREC, int TS0, int TS1, int NW, bool IN16, bool OUT16, int NFV = 4>
 __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
     const void* __restrict__ xv, const void* __restrict__ wpk,
     const float* __restrict__ bias, const void* __restrict__ resv,
@@ -455,16 +458,16 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
             } else {
 #pragma unroll
               for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 bfr[4];
+                bf16x8 bfr[NFV];
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf)
+                for (int nf = 0; nf < NFV; ++nf)
                   bfr[nf] = *reinterpret_cast<const bf16x8*>(smem + b_addr[nf][ks] + slot * 8192);
 #pragma unroll
                 for (int m = 0; m < MFW; ++m) {
                   const int roff = ((m / TS1) * H1 + (m % TS1) + ta * H1 + tb) * H2 * 128;
                   const bf16x8 afr = *reinterpret_cast<const bf16x8*>(smem + a_addr[tc][ks] + roff);
 #pragma unroll
-                  for (int nf = 0; nf < 4; ++nf)
+                  for (int nf = 0; nf < NFV; ++nf)
                     acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nf], acc[m][nf], 0, 0, 0);
                 }
               }
@@ -580,12 +583,12 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
   }
 }
 
-template <int PREC, int TS0, int TS1, int NW, bool IN16, bool OUT16>
+template <int PREC, int TS0, int TS1, int NW, bool IN16, bool OUT16, int NFV = 4>
 int launch_io(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* wpk,
               const float* bias, const void* res, void* y, int res16) {
   using T = Tile<TS0, TS1, NW>;
   const size_t lds = PREC == S3_PREC_F32 ? T::lds_f32 : T::lds_bf16;
-  auto kern = conv3_mfma_kernel<PREC, TS0, TS1, NW, IN16, OUT16>;
+  auto kern = conv3_mfma_kernel<PREC, TS0, TS1, NW, IN16, OUT16, NFV>;
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -606,6 +609,12 @@ int launch_bf16(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* wpk,
                 const float* bias, const void* res, void* y, ConvIO io) {
   if (io.in_bf16 && io.out_bf16)
     return launch_io<S3_PREC_BF16, TS0, TS1, NW, true, true>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
+  // (fp32-out data gradients with <= 32 output channels: two N fragments)
+  if (g.Cout <= 32 && !io.out_bf16 && TS0 == 4 && TS1 == 8 && NW == 16 && !getenv("SUP3R_AMD_NO_TILE_NF2")) {
+    if (io.in_bf16)
+      return launch_io<S3_PREC_BF16, TS0, TS1, NW, true, false, 2>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
+    return launch_io<S3_PREC_BF16, TS0, TS1, NW, false, false, 2>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
+  }
   if (io.in_bf16)
     return launch_io<S3_PREC_BF16, TS0, TS1, NW, true, false>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
   if (io.out_bf16)

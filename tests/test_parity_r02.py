@@ -950,3 +950,37 @@ def test_first_disc_layer_bf16_only_dpre_changes_only_the_bias_sum_order(monkeyp
             np.testing.assert_array_equal(a, b)
         else:
             assert rel_linf(a, b) < 1e-5, k
+
+
+def test_halo_tile_kernel_with_two_n_fragments_is_bit_identical(monkeypatch):
+    """data gradient of a valid 32 -> 64 conv = a 64 -> 32 conv on the
+    halo-tile kernel: with C_out <= 32 only two of the four N fragments of the
+    cout tile are computed (conv3_mfma_kernel<.., NFV = 2>); the other two
+    were zero rows"""
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(64, 1) + [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (4, 16, 32, 64, 32)
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+
+    def run():
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=0)
+        ph = net.plan(shape, training=True)
+        assert _kernels(ph, 'dgrad')[0] == 'mfma_valid', _kernels(ph, 'dgrad')
+        y = ph.forward(net.dev.to_device(x))
+        dy = net.dev.to_device(np.ones(tuple(y.shape), np.float32))
+        dx = ph.backward(dy, need_dx=True).cpu().numpy()
+        del ph
+        net.clear_plans()
+        return dx
+    dx2 = run()
+    monkeypatch.setenv('SUP3R_AMD_NO_TILE_NF2', '1')
+    dx4 = run()
+    monkeypatch.delenv('SUP3R_AMD_NO_TILE_NF2')
+    assert np.abs(dx2).max() > 0
+    np.testing.assert_array_equal(dx2, dx4)
