@@ -4,6 +4,8 @@
 // HBM, so: lanes run along `out` (coalesced 256-B rows of W), x / dy values
 // are wave-uniform (scalar loads), the batch lives in registers (NB = 8 rows
 // per pass), and K is split over the grid with a deterministic two-stage sum.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -130,7 +132,10 @@ int launch_dense_fwd(s3_ctx* ctx, const float* x, const float* w,
                      const float* bias, float* y, int n, int cin, int cout,
                      int act, float alpha) {
   const int col_tiles = (cout + 63) / 64;
-  int n_slabs = (512 + col_tiles - 1) / col_tiles;
+  // ~8 waves per SIMD in flight: the pass is one stream over W and needs the
+  // memory parallelism (512 workgroups ran it at 1.1 TB/s)
+  static const int wg_target = getenv("SUP3R_AMD_DENSE_WGS") ? atoi(getenv("SUP3R_AMD_DENSE_WGS")) : 2048;
+  int n_slabs = (wg_target + col_tiles - 1) / col_tiles;
   int max_slabs = (cin + 63) / 64;
   if (n_slabs > max_slabs) n_slabs = max_slabs;
   if (n_slabs < 1) n_slabs = 1;
