@@ -13,7 +13,9 @@
 //     with the t axis DE-INTERLEAVED per row — 17 even cells, then 16 odd —
 //     so the 16 positions t = 0..15 of a fragment read 16 CONTIGUOUS cells
 //     for each of the three t-taps (c = 0: even j, c = 1: odd j, c = 2: even
-//     j + 1): the stride-1 swizzle of conv_halo32_kernel stays conflict-free;
+//     j + 1) under the stride-1 chunk swizzle of conv_halo32_kernel (PMC: a
+//     third of the LDS-active cycles are still bank conflicts — the odd row
+//     pitch of 33 cells — at 25 % LDS utilisation: not what bounds the layer);
 //   * the whole 27 x 32 x 32 filter (55 KB bf16) is staged ONCE per workgroup
 //     into LDS, 64-B rows: a wave's A fragment is one contiguous KB;
 //   * the next tile's halo is fetched into registers (12 x 16 B per lane)
