@@ -215,6 +215,73 @@ def c3_leg(batch, steps, warmup, world, rank):
     return n, el
 
 
+# ---------------------------------------------------- power / clock evidence
+def _smi_poll(stop, out):
+    import re as _re
+    while not stop.is_set():
+        try:
+            t = subprocess.run(['rocm-smi', '--showclocks', '--showpower'],
+                               capture_output=True, text=True, timeout=5).stdout
+            m = _re.search(r'sclk clock level: \S+ \((\d+)Mhz\)', t)
+            p_ = _re.search(r'Power \(W\): ([\d.]+)', t)
+            if m and p_:
+                out.append((int(m.group(1)), float(p_.group(1))))
+        except Exception:
+            return
+        time.sleep(0.1)
+
+
+def power_leg(spec, weights, dev, x, out, seconds=2.0):
+    """The same forward on the benchmark's random operands and on all-zero
+    operands (zero weights, zero input: the identical instruction stream with
+    no toggling in the MFMA datapath), rocm-smi polled alongside.  A kernel
+    bound by its schedule takes the same time on both; one bound by the
+    board's power cap speeds up with the shader clock."""
+    import threading
+
+    import torch
+    from sup3r_amd.engine import Network
+    res = {}
+    for what in ('random', 'zeros'):
+        net = Network(spec, name='generator', device=dev, precision='bf16')
+        net.set_weights(weights if what == 'random'
+                        else [np.zeros_like(w) for w in weights])
+        ph = net.plan(tuple(x.shape), training=False)
+        xd = x if what == 'random' else torch.zeros_like(x)
+        for _ in range(3):
+            ph.forward(xd, out=out)
+        torch.cuda.synchronize()
+        stop, samples = threading.Event(), []
+        th = threading.Thread(target=_smi_poll, args=(stop, samples))
+        th.start()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(10):
+                ph.forward(xd, out=out)
+            torch.cuda.synchronize()
+            n += 10
+        el = time.perf_counter() - t0
+        stop.set()
+        th.join()
+        busy = [s_ for s_ in samples if s_[1] > 600] or samples
+        res[what] = {'samples_per_s': int(x.shape[0]) * n / el,
+                     'sclk_MHz': (float(np.mean([s_[0] for s_ in busy]))
+                                  if busy else None),
+                     'power_W': (float(np.mean([s_[1] for s_ in busy]))
+                                 if busy else None)}
+        del ph
+        net.clear_plans()
+    res['zeros_over_random'] = (res['zeros']['samples_per_s'] /
+                                res['random']['samples_per_s'])
+    res['note'] = ('same kernels, same launches; only the operand values '
+                   'differ.  zeros_over_random > 1 with a higher sclk and a '
+                   'lower power = the random-operand run sits at the power '
+                   'cap (1400 W), not at a scheduling limit: frac x '
+                   'zeros_over_random is what the schedule delivers at the '
+                   'unthrottled clock')
+    return res
+
+
 # ------------------------------------------------------- HBM traffic (PMC)
 def inner_pmc(args):
     """child process under ``rocprofv3 --pmc``: a few forwards, nothing else"""
@@ -679,6 +746,11 @@ def main():
                      frac=modes['f32']['achieved_tflops_fp32_equivalent']
                      / PEAK_TFLOPS['f32']),
             speedup_vs_f32=modes['bf16x3']['value'] / modes['f32']['value'])
+    if single and not args.no_parity_mode:
+        try:
+            result['roofline']['power'] = power_leg(spec, weights, dev, x, out)
+        except Exception as e:              # evidence, never fatal
+            result['roofline']['power'] = {'error': repr(e)[:200]}
     del ph, net
     torch.cuda.empty_cache()
     if single and not args.no_train:
