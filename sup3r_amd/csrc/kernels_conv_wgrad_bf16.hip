@@ -201,6 +201,167 @@ __global__ __launch_bounds__(BNT) void conv3_wgrad_bf16_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Wave-specialised variant for the all-bf16, reflect-padded, exact-fit case (the
+// trunk convs of a training step).  PMC of conv3_wgrad_bf16_kernel: MFMA busy
+// 27 % of the SIMD cycles, waves waiting 58 % — all 12 waves stand in front of
+// every tile's staging loads, and next to 72 accumulators there is no register
+// room to prefetch (three attempts).  Here the 4 x 4 x 16 tile
+// is walked as two 2 x 4 x 16 halves (same k-step order: bit-identical sums),
+// a half's images are 62 KB (x halo 4 x 6 x 18 cells + 128 dPre rows), so TWO
+// fit in LDS, and 4 extra producer waves fill the other buffer by LDS-DMA
+// (global_load_lds_dwordx4: bf16 in HBM = bf16 in LDS, the swizzles are applied
+// by choosing each lane's SOURCE chunk) while the 12 consumer waves run the
+// 4 k-steps of the current half.  One workgroup barrier per half hands over.
+constexpr int WH0 = 2;                                   // s0 rows of a half tile
+constexpr int WHP = (WH0 + 2) * BH1 * BH2;               // 432 halo cells
+constexpr int WNP = WH0 * BT1 * BT2;                     // 128 positions
+constexpr int WXS = WHP * 128;                           // 55,296 B
+constexpr int WBUF = WXS + WNP * 64;                     // 63,488 B per buffer
+constexpr int WS_LDS = 2 * WBUF;                         // 126,976 B
+constexpr int WS_NT = 1024;                              // 12 consumer + 4 producer waves
+constexpr int WS_NXI = WXS / 1024;                       // 54 wave-DMAs per x halo
+constexpr int WS_NDI = WNP * 64 / 1024;                  // 8 wave-DMAs per dPre block
+
+__global__ __launch_bounds__(WS_NT) void conv3_wgrad_bf16_ws_kernel(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+    float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
+    int tiles2, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = blockIdx.y;
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+  // this workgroup's half tiles: item it = (tile blockIdx.x + (it >> 1) gridDim.x, half it & 1)
+  const int my_tiles = (int)blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int n_items = 2 * my_tiles;
+  auto item_org = [&](int it, int& n, int& o0, int& o1, int& o2) __attribute__((always_inline)) {
+    int tr = blockIdx.x + (it >> 1) * gridDim.x;
+    o2 = (tr % tiles2) * BT2; tr /= tiles2;
+    o1 = (tr % tiles1) * BT1; tr /= tiles1;
+    o0 = (tr % tiles0) * BT0 + (it & 1) * WH0; tr /= tiles0;
+    n = tr;
+  };
+
+  if (wave >= 12) {
+    // ================================================= producer waves
+    const int pw = wave - 12;
+    auto load_item = [&](int it, char* buf) __attribute__((always_inline)) {
+      int n, o0, o1, o2;
+      item_org(it, n, o0, o1, o2);
+      const unsigned short* xn = x + (size_t)n * D0 * D1 * D2 * 64;
+      // x halo: wave-DMA j fills cells 8 j .. 8 j + 7; lane -> (cell, 16-B slot)
+#pragma unroll 2
+      for (int j = pw; j < WS_NXI; j += 4) {
+        const int cell = 8 * j + (lane >> 3), slot = lane & 7;
+        int h = cell;
+        const int c2 = h % BH2; h /= BH2;
+        const int c1 = h % BH1; h /= BH1;
+        const int c0 = h;
+        // slot = (((ch >> 1) ^ key) << 1) | (ch & 1)  <=>  ch = (((slot >> 1) ^ key) << 1) | (slot & 1)
+        const int ch = ((((slot >> 1) ^ xs_key(c2)) << 1) | (slot & 1));
+        const int i0 = s3_reflect(o0 + c0 - 1, D0), i1 = s3_reflect(o1 + c1 - 1, D1),
+                  i2 = s3_reflect(o2 + c2 - 1, D2);
+        const unsigned short* src = xn + ((size_t)(i0 * D1 + i1) * D2 + i2) * 64 + ch * 8;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)src,
+            (__attribute__((address_space(3))) void*)(buf + j * 1024), 16, 0, 0);
+      }
+      // dPre rows: wave-DMA j fills positions 16 j .. 16 j + 15; lane -> (position, 16-B slot)
+      const unsigned short* dn = dy + (size_t)n * g.O[0] * g.O[1] * g.O[2] * g.Cout + ct * BCT;
+#pragma unroll
+      for (int j = pw; j < WS_NDI; j += 4) {
+        const int pl = 16 * j + (lane >> 2), s16 = lane & 3;
+        const int row = pl / BT2, tt = pl % BT2;
+        const int p0 = o0 + row / BT1, p1 = o1 + row % BT1, p2 = o2 + tt;
+        // LDS: 32-B segment seg ^ ((pl >> 3) & 1) holds channels 16 seg ..; slot s16 = its 16-B half
+        const int seg = (s16 >> 1) ^ ((pl >> 3) & 1);
+        const unsigned short* src = dn + ((size_t)(p0 * g.O[1] + p1) * g.O[2] + p2) * g.Cout + seg * 16 + (s16 & 1) * 8;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)src,
+            (__attribute__((address_space(3))) void*)(buf + WXS + j * 1024), 16, 0, 0);
+      }
+    };
+    if (n_items > 0) load_item(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA landed before the hand-over
+    __syncthreads();
+    for (int it = 0; it < n_items; ++it) {
+      if (it + 1 < n_items) load_item(it + 1, smem + ((it + 1) & 1) * WBUF);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    return;
+  }
+
+  // =================================================== consumer waves
+  const int q = lane & 15, kg = lane >> 4;
+  const int cb = wave & 3, ta = wave >> 2;
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  int a_off[3][2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int th = 8 * (kg & 1) + 4 * h + (q >> 2) + c;
+      a_off[c][h] = ((ta * BH1 + (kg >> 1)) * BH2 + th) * 128 +
+                    ((cb ^ xs_key(th)) << 5) + ((q & 3) << 3);
+    }
+  int b_off[2][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pl = 8 * kg + 4 * h + (q >> 2);
+      b_off[nb][h] = pl * 64 + ((nb ^ ((pl >> 3) & 1)) << 5) + ((q & 3) << 3);
+    }
+  __syncthreads();            // first half landed
+  for (int it = 0; it < n_items; ++it) {
+    const char* xs = smem + (it & 1) * WBUF;
+    const char* ds = xs + WXS;
+#pragma unroll
+    for (int ks = 0; ks < WNP / 32; ++ks) {
+      // rows 2 ks, 2 ks + 1 of the half: r0 = ks >> 1, r1 = 2 (ks & 1) + (kg >> 1)
+      const int rowb = (((ks >> 1) * BH1) + 2 * (ks & 1)) * BH2 * 128;
+      bf16x8 bfr[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const s16x4 lo = lds_tr(ds + b_off[nb][0] + ks * 32 * 64);
+        const s16x4 hi = lds_tr(ds + b_off[nb][1] + ks * 32 * 64);
+        bfr[nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const s16x4 lo = lds_tr(xs + a_off[c][0] + rowb + b * BH2 * 128);
+          const s16x4 hi = lds_tr(xs + a_off[c][1] + rowb + b * BH2 * 128);
+          const bf16x8 afr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[b * 3 + c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[0], acc[b * 3 + c][0], 0, 0, 0);
+          acc[b * 3 + c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[1], acc[b * 3 + c][1], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  float* out = partial + (size_t)blockIdx.x * 27 * 64 * g.Cout;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int co = ct * BCT + nb * 16 + q;
+    if (co < g.Cout) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[((size_t)(ta * 9 + t) * 64 + cb * 16 + kg * 4 + r) * g.Cout + co] = acc[t][nb][r];
+    }
+  }
+}
+
 __global__ void wgrad_bf16_partial_reduce(const float* __restrict__ partial,
                                           int n_part, int64_t wsize,
                                           float* __restrict__ dw, int accumulate) {
@@ -664,11 +825,21 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel<true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_ws_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
     attr_set = true;
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
   static const int dbg = getenv("SUP3R_AMD_WGRAD_DBG") ? atoi(getenv("SUP3R_AMD_WGRAD_DBG")) : 0;
-  if (dy_bf16)
+  // wave-specialised variant: reflect padding, tiles and cout tiles that fit exactly
+  const bool ws = dy_bf16 && !dbg && !getenv("SUP3R_AMD_NO_WGRAD_WS") && g.pad_mode == S3_PAD_REFLECT &&
+                  g.O[0] % BT0 == 0 && g.O[1] % BT1 == 0 && g.O[2] % BT2 == 0 && g.Cout % BCT == 0 &&
+                  (int64_t)g.D[0] * g.D[1] * g.D[2] * 64 < ((int64_t)1 << 31);
+  if (ws)
+    hipLaunchKernelGGL(conv3_wgrad_bf16_ws_kernel, dim3(grid, n_ct), dim3(WS_NT), WS_LDS, ctx->stream,
+                       (const unsigned short*)x, (const unsigned short*)dy, partial, g, tiles0, tiles1, tiles2,
+                       n_tiles);
+  else if (dy_bf16)
     hipLaunchKernelGGL((conv3_wgrad_bf16_kernel<true, true>), dim3(grid, n_ct), dim3(BNT), BF_LDS,
                        ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles, dbg);
   else if (x_bf16)

@@ -984,3 +984,37 @@ def test_halo_tile_kernel_with_two_n_fragments_is_bit_identical(monkeypatch):
     monkeypatch.delenv('SUP3R_AMD_NO_TILE_NF2')
     assert np.abs(dx2).max() > 0
     np.testing.assert_array_equal(dx2, dx4)
+
+
+def test_wave_specialised_trunk_weight_gradient_is_bit_identical(monkeypatch):
+    """conv3_wgrad_bf16_ws_kernel — 4 producer waves fill the other of two
+    half-tile LDS buffers by LDS-DMA while 12 consumer waves run the k-steps
+    of the current half — walks the same positions in the same k-step order as
+    conv3_wgrad_bf16_kernel: every weight gradient bit-identical (three tiles
+    per workgroup at this shape, both halves, both buffers)"""
+    spec = _load('gen_5x_12x_2f.json')
+    shape = (8, 16, 16, 4, 4)
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+
+    def run():
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=0)
+        ph = net.plan(shape, training=True)
+        assert 'bf16_trunk' in _kernels(ph, 'wgrad')
+        y = ph.forward(net.dev.to_device(x))
+        dy = net.dev.to_device(
+            np.random.default_rng(14).standard_normal(tuple(y.shape)).astype(np.float32))
+        ph.backward(dy)
+        g = [a.copy() for a in net.grads]
+        del ph
+        net.clear_plans()
+        return g
+    g1 = run()
+    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_WS', '1')
+    g0 = run()
+    monkeypatch.delenv('SUP3R_AMD_NO_WGRAD_WS')
+    assert any(np.abs(a).max() > 0 for a in g1)
+    for a, b in zip(g1, g0):
+        np.testing.assert_array_equal(a, b)
