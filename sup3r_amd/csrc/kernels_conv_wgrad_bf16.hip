@@ -247,23 +247,44 @@ __global__ __launch_bounds__(WS_NT) void conv3_wgrad_bf16_ws_kernel(
   if (wave >= 12) {
     // ================================================= producer waves
     const int pw = wave - 12;
+    // tile-invariant part of this lane's DMA sources: halo cell coordinates and
+    // the swizzle-resolved source chunk of every wave-DMA it takes part in
+    constexpr int NXJ = (WS_NXI + 3) / 4, NDJ = (WS_NDI + 3) / 4;
+    int xt[NXJ];          // c0 | c1 << 4 | c2 << 8 | ch << 16
+#pragma unroll
+    for (int k = 0; k < NXJ; ++k) {
+      const int j = pw + 4 * k;
+      const int cell = 8 * j + (lane >> 3), slot = lane & 7;
+      int h = cell;
+      const int c2 = h % BH2; h /= BH2;
+      const int c1 = h % BH1; h /= BH1;
+      // slot = (((ch >> 1) ^ key) << 1) | (ch & 1)  <=>  ch = (((slot >> 1) ^ key) << 1) | (slot & 1)
+      const int ch = ((((slot >> 1) ^ xs_key(c2)) << 1) | (slot & 1));
+      xt[k] = h | (c1 << 4) | (c2 << 8) | (ch << 16);
+    }
+    int dt[NDJ];          // s0 row | s1 row << 4 | t << 8 | source channel << 16
+#pragma unroll
+    for (int k = 0; k < NDJ; ++k) {
+      const int j = pw + 4 * k;
+      const int pl = 16 * j + (lane >> 2), s16 = lane & 3;
+      const int row = pl / BT2, tt = pl % BT2;
+      // LDS: 32-B segment seg ^ ((pl >> 3) & 1) holds channels 16 seg ..; slot s16 = its 16-B half
+      const int seg = (s16 >> 1) ^ ((pl >> 3) & 1);
+      dt[k] = (row / BT1) | ((row % BT1) << 4) | (tt << 8) | ((seg * 16 + (s16 & 1) * 8) << 16);
+    }
     auto load_item = [&](int it, char* buf) __attribute__((always_inline)) {
       int n, o0, o1, o2;
       item_org(it, n, o0, o1, o2);
       const unsigned short* xn = x + (size_t)n * D0 * D1 * D2 * 64;
       // x halo: wave-DMA j fills cells 8 j .. 8 j + 7; lane -> (cell, 16-B slot)
-#pragma unroll 2
-      for (int j = pw; j < WS_NXI; j += 4) {
-        const int cell = 8 * j + (lane >> 3), slot = lane & 7;
-        int h = cell;
-        const int c2 = h % BH2; h /= BH2;
-        const int c1 = h % BH1; h /= BH1;
-        const int c0 = h;
-        // slot = (((ch >> 1) ^ key) << 1) | (ch & 1)  <=>  ch = (((slot >> 1) ^ key) << 1) | (slot & 1)
-        const int ch = ((((slot >> 1) ^ xs_key(c2)) << 1) | (slot & 1));
-        const int i0 = s3_reflect(o0 + c0 - 1, D0), i1 = s3_reflect(o1 + c1 - 1, D1),
-                  i2 = s3_reflect(o2 + c2 - 1, D2);
-        const unsigned short* src = xn + ((size_t)(i0 * D1 + i1) * D2 + i2) * 64 + ch * 8;
+#pragma unroll
+      for (int k = 0; k < NXJ; ++k) {
+        const int j = pw + 4 * k;
+        if (j >= WS_NXI) break;
+        const int t = xt[k];
+        const int i0 = s3_reflect(o0 + (t & 15) - 1, D0), i1 = s3_reflect(o1 + ((t >> 4) & 15) - 1, D1),
+                  i2 = s3_reflect(o2 + ((t >> 8) & 255) - 1, D2);
+        const unsigned short* src = xn + (unsigned)(((i0 * D1 + i1) * D2 + i2) * 64 + (t >> 16) * 8);
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)src,
             (__attribute__((address_space(3))) void*)(buf + j * 1024), 16, 0, 0);
@@ -271,13 +292,12 @@ __global__ __launch_bounds__(WS_NT) void conv3_wgrad_bf16_ws_kernel(
       // dPre rows: wave-DMA j fills positions 16 j .. 16 j + 15; lane -> (position, 16-B slot)
       const unsigned short* dn = dy + (size_t)n * g.O[0] * g.O[1] * g.O[2] * g.Cout + ct * BCT;
 #pragma unroll
-      for (int j = pw; j < WS_NDI; j += 4) {
-        const int pl = 16 * j + (lane >> 2), s16 = lane & 3;
-        const int row = pl / BT2, tt = pl % BT2;
-        const int p0 = o0 + row / BT1, p1 = o1 + row % BT1, p2 = o2 + tt;
-        // LDS: 32-B segment seg ^ ((pl >> 3) & 1) holds channels 16 seg ..; slot s16 = its 16-B half
-        const int seg = (s16 >> 1) ^ ((pl >> 3) & 1);
-        const unsigned short* src = dn + ((size_t)(p0 * g.O[1] + p1) * g.O[2] + p2) * g.Cout + seg * 16 + (s16 & 1) * 8;
+      for (int k = 0; k < NDJ; ++k) {
+        const int j = pw + 4 * k;
+        if (j >= WS_NDI) break;
+        const int t = dt[k];
+        const int p0 = o0 + (t & 15), p1 = o1 + ((t >> 4) & 15), p2 = o2 + ((t >> 8) & 255);
+        const unsigned short* src = dn + (unsigned)(((p0 * g.O[1] + p1) * g.O[2] + p2) * g.Cout + (t >> 16));
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)src,
             (__attribute__((address_space(3))) void*)(buf + WXS + j * 1024), 16, 0, 0);
@@ -834,7 +854,8 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
   // wave-specialised variant: reflect padding, tiles and cout tiles that fit exactly
   const bool ws = dy_bf16 && !dbg && !getenv("SUP3R_AMD_NO_WGRAD_WS") && g.pad_mode == S3_PAD_REFLECT &&
                   g.O[0] % BT0 == 0 && g.O[1] % BT1 == 0 && g.O[2] % BT2 == 0 && g.Cout % BCT == 0 &&
-                  (int64_t)g.D[0] * g.D[1] * g.D[2] * 64 < ((int64_t)1 << 31);
+                  (int64_t)g.D[0] * g.D[1] * g.D[2] * 64 < ((int64_t)1 << 31) &&
+                  (int64_t)g.O[0] * g.O[1] * g.O[2] * g.Cout < ((int64_t)1 << 31);
   if (ws)
     hipLaunchKernelGGL(conv3_wgrad_bf16_ws_kernel, dim3(grid, n_ct), dim3(WS_NT), WS_LDS, ctx->stream,
                        (const unsigned short*)x, (const unsigned short*)dy, partial, g, tiles0, tiles1, tiles2,
