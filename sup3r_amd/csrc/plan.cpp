@@ -1338,6 +1338,15 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
     if (prc) return prc;
   }
   const int x_id = pl->inputs.empty() ? -1 : root_of(pl, pl->inputs[0]);
+  // conv `prod` is processed right after conv `cons` in this reverse walk
+  // (nothing but views in between): a bf16-ONLY dPre handed from one to the
+  // other, with its channel sums in pl->bsum, cannot be clobbered on the way
+  auto back_to_back = [&](int prod, int cons) {
+    if (prod < 0 || prod >= cons) return false;
+    for (int k = prod + 1; k < cons; ++k)
+      if (pl->ops[k].d.kind != S3_OP_VIEW) return false;
+    return true;
+  };
   auto wants_grad = [&](int id) {
     int r = root_of(pl, id);
     if (!pl->t[r].is_input) return true;
@@ -1480,7 +1489,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             // along — it is stored as bf16 ONLY: the fold writes 75 instead of
             // 151 MB and the readers stage half the bytes; they would round to
             // bf16 (the same round-to-nearest-even) anyway.
-            const bool to16 = out == pl->t[rin].gptr && po.use16 && po.wgrad_bf16 && po.io.in_bf16 && po.d.res < 0 &&
+            const bool to16 = out == pl->t[rin].gptr && back_to_back(o.mask_prod, i) && po.use16 && po.wgrad_bf16 &&
+                              po.io.in_bf16 && po.d.res < 0 &&
                               (po.cg.Cout & 3) == 0 && pl->dpre16 && pl->dpre16_for < 0 &&
                               (!need_wgrad || po.d.b < 0 || bs != nullptr) && pl->precision == S3_PREC_BF16;
             int frc = launch_gather_bwd_masked(ctx, fg, pl->dxp, to16 ? (float*)pl->dpre16 : out, tptr(pl, d.in0),
@@ -1577,7 +1587,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             // and no separate bias pass over it.
             const int nblk = conv_dgrad_s2_blocks(g);
             const bool sums = need_wgrad && po.d.b >= 0;
-            const bool to16 = fuse && dst == pl->t[rin].gptr && pl->precision == S3_PREC_BF16 && po.wgrad_c2 &&
+            const bool to16 = fuse && back_to_back(o.mask_prod, i) && dst == pl->t[rin].gptr &&
+                              pl->precision == S3_PREC_BF16 && po.wgrad_c2 &&
                               po.cg.Cin == 2 && po.cg.Cout == 32 && po.d.res < 0 &&
                               (po.dgrad_c2 || !wants_grad(po.d.in0)) && conv_dgrad_s2_out16_ok(g) && pl->dpre16 &&
                               pl->dpre16_bytes >= (size_t)pl->t[rin].numel * 2 && pl->dpre16_for < 0 &&
