@@ -446,7 +446,12 @@ struct BfGen {
   }
 };
 
-template <int CIB, int STR, bool IN16>
+// PF (C_in = 32 blocks, bf16 x): with one cout block per wave (36 accumulator
+// registers) there IS room to prefetch — the next tile's x chunks and dPre rows
+// are fetched into registers before the k-steps of the current tile and dropped
+// into LDS after them (zero padding / ragged tiles: per-chunk zero masks), so
+// the staging traffic runs under the MFMAs.  Same operands, same order.
+template <int CIB, int STR, bool IN16, bool PF = false>
 __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
@@ -492,6 +497,113 @@ __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
       b_off[nb][h] = pl * 64 + (((nb0 + nb) ^ ((pl >> 3) & 1)) << 5) + ((q & 3) << 3);
     }
 
+  if constexpr (PF) {
+    static_assert(IN16, "the prefetching variant stages bf16 cells");
+    constexpr int CHP = CIB * 2;                               // 16-B chunks per cell
+    constexpr int NXI = (HP * CHP + BNT - 1) / BNT, NDI = (NP * (BCT / 4) + BNT - 1) / BNT;
+    uint4 xr[NXI];
+    float4 dr[NDI];
+    unsigned xz = 0, dz = 0;                                   // chunks stored as zero
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+      int tr = tile;
+      const int t2i = tr % tiles2; tr /= tiles2;
+      const int t1i = tr % tiles1; tr /= tiles1;
+      const int t0i = tr % tiles0; tr /= tiles0;
+      const int n = tr;
+      const int org0 = t0i * W::T0, org1 = t1i * T1, org2 = t2i * T2;
+      xz = 0; dz = 0;
+#pragma unroll
+      for (int k = 0; k < NXI; ++k) {
+        const int item = tid + k * BNT;
+        const int hp = item / CHP, ch = item % CHP;
+        int h = hp;
+        const int c2 = h % G2; h /= G2;
+        const int c1 = h % G1; h /= G1;
+        int i0 = org0 * STR + h - g.lo[0], i1 = org1 * STR + c1 - g.lo[1], i2 = org2 * STR + c2 - g.lo[2];
+        if (g.pad_mode == S3_PAD_REFLECT) {
+          i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
+        }
+        const bool valid = item < HP * CHP && i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2 &&
+                           ci0 + ch * 8 < Cin;
+        if (!valid) xz |= 1u << k;
+        else
+          xr[k] = *reinterpret_cast<const uint4*>(
+              reinterpret_cast<const unsigned short*>(x) +
+              ((((size_t)n * D0 + i0) * D1 + i1) * D2 + i2) * Cin + ci0 + ch * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < NDI; ++k) {
+        const int item = tid + k * BNT;
+        const int pl = item >> 3, ch = item & 7;
+        const int row = pl / T2, tt = pl % T2;
+        const int o0 = org0 + row / T1, o1 = org1 + row % T1, o2 = org2 + tt;
+        const int co = ct * BCT + ch * 4;
+        const bool in = item < NP * (BCT / 4) && o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && co < Cout;
+        if (!in) dz |= 1u << k;
+        else
+          dr[k] = *reinterpret_cast<const float4*>(
+              dy + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * Cout + co);
+      }
+    };
+    auto put = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < NXI; ++k) {
+        const int item = tid + k * BNT;
+        if (item >= HP * CHP) continue;
+        const int hp = item / CHP, ch = item % CHP;
+        int h = hp;
+        const int c2 = h % G2; h /= G2;
+        const int c1 = h % G1; h /= G1;
+        const int u = W::tau(c2);
+        char* cell = xs + ((h * G1 + c1) * G2 + u) * CB;
+        *reinterpret_cast<uint4*>(cell + (((ch >> 1) ^ W::key(u)) << 5) + ((ch & 1) << 4)) =
+            (xz >> k) & 1u ? make_uint4(0u, 0u, 0u, 0u) : xr[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NDI; ++k) {
+        const int item = tid + k * BNT;
+        if (item >= NP * (BCT / 4)) continue;
+        const int pl = item >> 3, ch = item & 7;
+        const float4 v = (dz >> k) & 1u ? make_float4(0.f, 0.f, 0.f, 0.f) : dr[k];
+        *reinterpret_cast<uint2*>(ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3)) =
+            make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+      }
+    };
+    if ((int)blockIdx.x < n_tiles) {
+      fetch(blockIdx.x);
+      put();
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      const int next = tile + gridDim.x;
+      if (next < n_tiles) fetch(next);
+#pragma unroll
+      for (int ks = 0; ks < NP / 32; ++ks) {
+        const int rowb = ((((2 * ks) / T1) * STR * G1) + ((2 * ks) % T1) * STR) * G2 * CB;
+        bf16x8 bfr[NBW];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          const s16x4 lo = lds_tr(ds + b_off[nb][0] + ks * 32 * 64);
+          const s16x4 hi = lds_tr(ds + b_off[nb][1] + ks * 32 * 64);
+          bfr[nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const s16x4 lo = lds_tr(xs + a_off[c][0] + rowb + b * G2 * CB);
+            const s16x4 hi = lds_tr(xs + a_off[c][1] + rowb + b * G2 * CB);
+            const bf16x8 afr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+              acc[b * 3 + c][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nb], acc[b * 3 + c][nb], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+      if (next < n_tiles) put();
+      __syncthreads();
+    }
+  } else
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     int tr = tile;
     const int t2i = tr % tiles2; tr /= tiles2;
@@ -609,11 +721,17 @@ int bf_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* d
   const int grid = bf_gen_grid<CIB, STR>(ctx, g, &n_tiles, &t0, &t1, &t2);
   const size_t need = (size_t)grid * 27 * g.Cin * g.Cout * sizeof(float);
   if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_gen: partial buffer too small");
+  constexpr bool CAN_PF = CIB == 2 && IN16;
   auto kern = conv_wgrad_bf16_gen_kernel<CIB, STR, IN16>;
+  if constexpr (CAN_PF)
+    if (!getenv("SUP3R_AMD_NO_WGRAD_GEN_PF")) kern = conv_wgrad_bf16_gen_kernel<CIB, STR, IN16, true>;
   static bool attr_set = false;
   if (!attr_set) {
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_gen_kernel<CIB, STR, IN16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS));
+    if constexpr (CAN_PF)
+      S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_gen_kernel<CIB, STR, IN16, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS));
     attr_set = true;
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
