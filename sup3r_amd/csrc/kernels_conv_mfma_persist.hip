@@ -506,7 +506,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
         const int S0 = org0 + mf / TS1, S1 = org1 + mf % TS1, o2 = org2 + frow;
         if (S0 >= gs0 * E0 || S1 >= gs1 * E1 || o2 >= g.O[2]) continue;
         const int q0 = S0 / E0, u0 = S0 - q0 * E0, q1 = S1 / E1, u1 = S1 - q1 * E1;
-        float* yp = yf + ((((size_t)(q0 * gs1 + q1) * E0 + u0) * E1 + u1) * g.O[2] + o2) * 64 + kq * 8;
+        float* yp = yf + ((((size_t)(q0 * gs1 + q1) * E0 + u0) * E1 + u1) * g.O[2] + o2) * g.Cout + kq * 8;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           if (2 * h >= NFV) continue;
@@ -602,7 +602,10 @@ bool conv_mfma_persist_geom_ok(const ConvGeom& g) {
 // data-gradient geometry of a 64 -> 64 'same' k3 conv (conv_dgrad_geom): full
 // correlation over the padded frame, zero boundary
 bool conv_mfma_persist_dgrad_geom_ok(const ConvGeom& g) {
-  if (g.Cin != 64 || g.Cout != 64 || g.d2s != 1 || g.pad_mode != S3_PAD_ZERO || g.act != S3_ACT_NONE) return false;
+  // (C_out = 32: the data gradient of a valid 32 -> 64 conv, two N fragments)
+  if (g.Cin != 64 || (g.Cout != 64 && g.Cout != 32) || g.d2s != 1 || g.pad_mode != S3_PAD_ZERO ||
+      g.act != S3_ACT_NONE)
+    return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] != 2 || g.O[d] != g.D[d] + 2) return false;
   // 30-bit element offsets over the whole batch (the zero flag is bit 30)
@@ -643,6 +646,8 @@ int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* d
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
   int gs0 = 1, gs1 = 1;
@@ -652,7 +657,8 @@ int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* d
   const int n_tiles = tiles0 * tiles1 * tiles2;
   int grid = ctx->num_cu;
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL((conv3_mfma_persist_kernel<4, true>), dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
+  auto kern = g.Cout <= 32 ? conv3_mfma_persist_kernel<2, true> : conv3_mfma_persist_kernel<4, true>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
                      (const unsigned short*)dpre16, (const char*)image, (const float*)nullptr,
                      (const unsigned short*)nullptr, (unsigned short*)dxp, g, tiles0, tiles1, tiles2, n_tiles, 0,
                      gs0, gs1);

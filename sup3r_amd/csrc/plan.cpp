@@ -1544,11 +1544,13 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             const void* wp = pl->precision != S3_PREC_F32 ? (const void*)o.dg_wbf : (const void*)o.dg_w32;
             if (o.dgrad_fewch)
               rc = launch_gconv_fwd(ctx, o.dg, dpre, o.dg_wbf, nullptr, nullptr, pl->dxp, 0);
-            else if (o.use16 && dpre16 && !o.dgrad_valid && pl->precision == S3_PREC_BF16 &&
+            else if (o.use16 && dpre16 && pl->precision == S3_PREC_BF16 &&
                      conv_mfma_persist_dgrad_supported(ctx, o.dg)) {
-              // the persistent trunk kernel over the stacked padded frames
+              // the persistent trunk kernel over the stacked frames (a valid conv's
+              // full correlation lands on x's own grid: straight into dst)
               const size_t tile_img = (size_t)((o.dg.Cout + 63) / 64) * 27 * 64 * 64 * 2;
-              rc = launch_conv_mfma_persist_dgrad(ctx, o.dg, dpre16, (const char*)o.dg_wbf + tile_img, pl->dxp);
+              rc = launch_conv_mfma_persist_dgrad(ctx, o.dg, dpre16, (const char*)o.dg_wbf + tile_img,
+                                                  o.dgrad_valid ? dst : pl->dxp);
             } else {
               ConvIO dio;
               dio.in_bf16 = (o.use16 && dpre16) ? 1 : 0;

@@ -986,6 +986,47 @@ def test_halo_tile_kernel_with_two_n_fragments_is_bit_identical(monkeypatch):
     np.testing.assert_array_equal(dx2, dx4)
 
 
+@pytest.mark.parametrize('shape', [(8, 14, 14, 30, 32), (6, 10, 13, 21, 32)])
+def test_valid_conv_data_gradient_on_the_persistent_kernel_is_bit_identical(monkeypatch, shape):
+    """data gradient of a valid 32 -> 64 conv: the full correlation of dPre
+    with the flipped filter lands on x's own grid, so the samples' frames stack
+    like the trunk's padded ones and conv3_mfma_persist_kernel<2, DG> (two N
+    fragments) writes dx directly — bit-identical to the halo-tile kernel"""
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(64, 1) + [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    monkeypatch.setenv('SUP3R_AMD_PERSIST_DGRAD_MIN_TILES', '1')
+    rng = np.random.default_rng(15)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+
+    def run():
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=0)
+        ph = net.plan(shape, training=True)
+        n0 = net.dev.stat('persist_dgrad')
+        y = ph.forward(net.dev.to_device(x))
+        dy = net.dev.to_device(
+            np.random.default_rng(16).standard_normal(tuple(y.shape)).astype(np.float32))
+        dx = ph.backward(dy, need_dx=True).cpu().numpy()
+        g = [a.copy() for a in net.grads]
+        used = net.dev.stat('persist_dgrad') - n0
+        del ph
+        net.clear_plans()
+        return dx, g, used
+    dx1, g1, used1 = run()
+    assert used1 > 0, 'the data gradient did not run on the persistent kernel'
+    monkeypatch.setenv('SUP3R_AMD_NO_PERSIST_DGRAD', '1')
+    dx0, g0, used0 = run()
+    monkeypatch.delenv('SUP3R_AMD_NO_PERSIST_DGRAD')
+    assert used0 == 0 and np.abs(dx1).max() > 0
+    np.testing.assert_array_equal(dx1, dx0)
+    for a, b in zip(g1, g0):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_wave_specialised_trunk_weight_gradient_is_bit_identical(monkeypatch):
     """conv3_wgrad_bf16_ws_kernel — 4 producer waves fill the other of two
     half-tile LDS buffers by LDS-DMA while 12 consumer waves run the k-steps
