@@ -252,7 +252,7 @@ int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
 int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
                   int esize);
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
-                      float* din);
+                      float* din, void* side16 = nullptr);
 bool gather_bwd_mask_ok(const GatherGeom& g);
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
                              const void* mask_y, int y_bf16, float slope, float* bsum = nullptr,

@@ -886,8 +886,16 @@ int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, f
 }
 
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
-                      float* din) {
+                      float* din, void* side16) {
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  if (side16) {   // (callers check gather_bwd_mask_ok: the float4 fold)
+    if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd: bf16 side copy needs the float4 fold");
+    hipLaunchKernelGGL((gather_bwd_pad4_kernel<0, false, true>), dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,
+                       ctx->stream, dout, din, g, (const void*)nullptr, 0.f, (float*)nullptr,
+                       (unsigned short*)side16);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   if (g.kind == S3_OP_PAD && g.Ci == g.Co && (g.Ci & 3) == 0) {
     hipLaunchKernelGGL(gather_bwd_pad4_kernel<0>, dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,
                        ctx->stream, dout, din, g, (const void*)nullptr, 0.f, (float*)nullptr);

@@ -1477,8 +1477,22 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               return arc;
             }
             if (!fuse) {
-              if (bs) pl->bsum_for = -1;   // plain fold: no side output
-              return launch_gather_bwd(ctx, fg, pl->dxp, out);
+              if (bs) pl->bsum_for = -1;   // plain fold: no channel sums
+              // (so far) the whole gradient of a tensor whose producer is a conv
+              // without activation that stages bf16: leave it a bf16 copy
+              // (grad_deliver drops the copy if a second contribution arrives)
+              void* side = nullptr;
+              if (o.in_prod >= 0 && out == pl->t[rin].gptr && !pl->gwritten[rin] && pl->dpre16 &&
+                  pl->dpre16_for < 0 && gather_bwd_mask_ok(fg) && !getenv("SUP3R_AMD_NO_FOLD16") &&
+                  !getenv("SUP3R_AMD_NO_PLAIN_FOLD16")) {
+                const OpRec& po = pl->ops[o.in_prod];
+                if (po.use16 && po.cg.act == S3_ACT_NONE && po.cg.d2s <= 1 && (po.cg.Cout & 3) == 0 &&
+                    pl->dpre16_bytes >= (size_t)pl->t[rin].numel * 2)
+                  side = pl->dpre16;
+              }
+              int prc = launch_gather_bwd(ctx, fg, pl->dxp, out, side);
+              if (!prc && side) { pl->dpre16_for = rin; pl->dpre16_only = false; }
+              return prc;
             }
             const OpRec& po = pl->ops[o.mask_prod];
             const ConvGeom& pg = po.cg;
