@@ -50,12 +50,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--n', type=int, default=12)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--poison', action='store_true',
+                    help='plan buffers start as NaN patterns in the specialised run')
     args = ap.parse_args()
     from sup3r_amd.configs.author_configs import pcc
     rng = np.random.default_rng(args.seed)
     force = {'SUP3R_AMD_HALO32_MIN_TILES': '1', 'SUP3R_AMD_FEWCH_HALO_MIN_TILES': '1',
              'SUP3R_AMD_DGRAD_S2_MIN_TILES': '1', 'SUP3R_AMD_PERSIST_DGRAD_MIN_TILES': '1',
              'SUP3R_AMD_HALO_S2_MIN_TILES': '1'}
+    if args.poison:
+        force['SUP3R_AMD_POISON_ALLOC'] = '1'
     off = dict(force, SUP3R_AMD_NO_HALO32='1', SUP3R_AMD_NO_FEWCH_HALO='1',
                SUP3R_AMD_NO_DGRAD_S2='1', SUP3R_AMD_NO_DGRAD_C2='1',
                SUP3R_AMD_NO_WGRAD_TAIL='1', SUP3R_AMD_NO_WGRAD_C2='1',
@@ -65,6 +69,7 @@ def main():
                SUP3R_AMD_NO_PERSIST_DGRAD='1', SUP3R_AMD_NO_HALO_S2='1', SUP3R_AMD_NO_WGRAD_WS='1',
                SUP3R_AMD_NO_DPRE16='1', SUP3R_AMD_NO_GCONV_SPLITK='1', SUP3R_AMD_NO_TILE_NF2='1',
                SUP3R_AMD_NO_FOLD16='1', SUP3R_AMD_NO_WGRAD_GEN_PF='1', SUP3R_AMD_NO_BATCHED_PACK='1')
+    off.pop('SUP3R_AMD_POISON_ALLOC', None)
     worst = 0.0
     for it in range(args.n):
         kind = it % 4
