@@ -155,7 +155,7 @@ int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* pack
 int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
                      const float* bias, const float* res, void* y, int out_bf16, int in_bf16 = 0);
 int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* packed_t,
-                       float* dx, int accumulate, int frame);
+                       float* dx, int accumulate, int frame, int dy_bf16 = 0);
 
 // MFMA backward of the 3x3x3 stride-1 trunk convs.
 bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision);

@@ -933,7 +933,8 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
 }
 
 int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* packed_t,
-                       float* dx, int accumulate, int frame) {
+                       float* dx, int accumulate, int frame, int dy_bf16) {
+  // dy_bf16: dy is the bf16 copy of dPre (C_out % 8 == 0)
   const int64_t P = frame ? (int64_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
                                 (g.D[2] + 2 * g.lo[2])
                           : (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
@@ -960,11 +961,11 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
   if (wide)
     hipLaunchKernelGGL((gconv_mfma_kernel<true, 4>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
                        (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
-                       rows_padded(g.Cin), accumulate, frame, 0, 0, ns, ctx->scratch);
+                       rows_padded(g.Cin), accumulate, frame, 0, dy_bf16, ns, ctx->scratch);
   else
     hipLaunchKernelGGL((gconv_mfma_kernel<true, 2>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
                        (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
-                       rows_padded(g.Cin), accumulate, frame, 0, 0, ns, ctx->scratch);
+                       rows_padded(g.Cin), accumulate, frame, 0, dy_bf16, ns, ctx->scratch);
   S3_HIP(ctx, hipGetLastError());
   if (ns > 1) {
     ++ctx->stat[S3_STAT_GCONV_SPLITK];

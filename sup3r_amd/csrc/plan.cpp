@@ -710,7 +710,11 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       size_t max16 = 0;
       for (auto& o : pl->ops) {
         if (rc || o.d.kind != S3_OP_CONV) continue;
-        if (!o.dgrad_mfma || o.dgrad_fewch || o.dgrad_chunked || (o.cg.Cout & 3)) continue;
+        // (... and the gather-MFMA adjoint of the strided / valid discriminator
+        // convs: a lane's 8 channels of a dPre cell are one 16-B load)
+        const bool gadj = o.gconv_dgrad && (o.cg.Cout & 7) == 0 && o.cg.pad_mode != S3_PAD_REFLECT &&
+                          !getenv("SUP3R_AMD_NO_GCONV_DY16");
+        if (!gadj && (!o.dgrad_mfma || o.dgrad_fewch || o.dgrad_chunked || (o.cg.Cout & 3))) continue;
         o.use16 = true;
         max16 = std::max(max16, (size_t)pl->t[root_of(pl, o.d.out)].numel * 2);
       }
@@ -1642,7 +1646,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
               rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
             } else {
-              rc = launch_gconv_dgrad(ctx, g, dpre, o.gc_wt, dst, 0, 0);
+              const bool dy16 = o.use16 && dpre16 != nullptr;
+              rc = launch_gconv_dgrad(ctx, g, dy16 ? (const float*)dpre16 : dpre, o.gc_wt, dst, 0, 0, dy16 ? 1 : 0);
             }
           } else if (o.fewpos && o.fp_wt) {
             if (o.fp_version != P->version) {
