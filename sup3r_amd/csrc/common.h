@@ -134,7 +134,7 @@ int launch_pack_jobs(s3_ctx* ctx, const S3PackJob* jobs_dev, int n_jobs, int max
 bool conv_mfma_persist_dgrad_geom_ok(const ConvGeom& g);
 bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* dpre16, const void* image,
-                                   float* dxp);
+                                   float* dxp, int accumulate = 0);
 int launch_conv_mfma_persist_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
 int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                              const void* image, const float* bias,

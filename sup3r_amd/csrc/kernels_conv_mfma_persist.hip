@@ -254,6 +254,9 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     // is a scalar (readlane), the in-row offset of chunk j two ds_bpermute
     // lookups per tile, so a chunk's address is one add.
     const int pcell = pt >> 3, pch = pt & 7;
+    // (DG over a channel slice: 16-B chunks past the slice's valid channels
+    // load the cell's first chunk — a legal address — and land as zeros)
+    const bool cdead = DG && g.in_cstride && pch * 8 >= g.in_cvalid;
     u32x4 hlate[NLATE], hrow[JR];
     unsigned in_off[JR];      // element offset of chunk j inside a halo row
     unsigned lds_off[JR];     // byte offset of chunk j inside a halo row (swizzled)
@@ -276,7 +279,8 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       const int c = lane - (ax == 0 ? 0 : (ax == 1 ? H0 : H0 + H1));                   \
       const int org = ax == 0 ? o0_ : (ax == 1 ? o1_ : o2_);                           \
       const int D = ax == 0 ? D0 : (ax == 1 ? D1 : D2);                                \
-      const int stride = ax == 0 ? D1 * D2 * 64 : (ax == 1 ? D2 * 64 : 64);            \
+      const int cs = (DG && g.in_cstride) ? g.in_cstride : 64;  /* channel slice of a wider dPre */ \
+      const int stride = ax == 0 ? D1 * D2 * cs : (ax == 1 ? D2 * cs : cs);            \
       if (DG) {                                                                        \
         /* stacked frames on axes 0 / 1 (extent E = D + 2, gs frames), plain zero */  \
         /* boundary on axis 2; flagged rows load a legal address and are zeroed */    \
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
         const int R = org + c - 1;                                                     \
         const int q = R >= 0 ? R / E : 0, j = R - q * E;                               \
         const bool zero = R < 0 || R >= gsx * E || j == 0 || j == E - 1;               \
-        const int sstr = D0 * D1 * D2 * 64;                                            \
+        const int sstr = D0 * D1 * D2 * cs;                                            \
         const int qoff = ax == 0 ? q * gs1 * sstr : (ax == 1 ? q * sstr : 0);          \
         htab = zero ? 0x40000000 : qoff + (j - 1) * stride;                            \
         hx = x;                                                                        \
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
         const int c1 = cell / H2, c2 = cell - c1 * H2;                                 \
         in_off[j] = (unsigned)__builtin_amdgcn_ds_bpermute((H0 + c1) << 2, htab) +     \
                     (unsigned)__builtin_amdgcn_ds_bpermute((H0 + H1 + c2) << 2, htab) + \
-                    pch * 8;                                                           \
+                    (cdead ? 0 : pch * 8);                                             \
       }                                                                                \
     }
     // in-loop loads are hand-ordered (ld16_async): every tap's counted wait
@@ -317,8 +321,13 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       if (pcell + 32 * j < ROWC) {
         u32x4 w = v;
         if (DG) {
+          // v may still be in flight when this lambda is inlined: nothing may
+          // touch it before the counted wait that precedes the call.  The
+          // zeroing select below is plain C — an empty volatile asm (ordered
+          // after that wait, like every volatile asm) pins it behind the wait
+          asm volatile("" : "+v"(w));
           const unsigned row = (unsigned)__builtin_amdgcn_readlane(htab, r);
-          if ((row + in_off[j]) >> 30) w = (u32x4){0u, 0u, 0u, 0u};
+          if (((row + in_off[j]) >> 30) || cdead) w = (u32x4){0u, 0u, 0u, 0u};
         }
         *reinterpret_cast<u32x4*>(smem + r * (ROWC * 128) + lds_off[j]) = w;
       }
@@ -510,7 +519,13 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           if (2 * h >= NFV) continue;
-          const f32x4 a0 = acc[m][(2 * h) % NFV], a1 = acc[m][(2 * h + 1) % NFV];
+          f32x4 a0 = acc[m][(2 * h) % NFV], a1 = acc[m][(2 * h + 1) % NFV];
+          if (res) {   // a later channel slice of the contraction: add to the earlier ones
+            const float4 p0 = *reinterpret_cast<const float4*>(yp + h * 32);
+            const float4 p1 = *reinterpret_cast<const float4*>(yp + h * 32 + 4);
+            a0[0] += p0.x; a0[1] += p0.y; a0[2] += p0.z; a0[3] += p0.w;
+            a1[0] += p1.x; a1[1] += p1.y; a1[2] += p1.z; a1[3] += p1.w;
+          }
           *reinterpret_cast<float4*>(yp + h * 32) = make_float4(a0[0], a0[1], a0[2], a0[3]);
           *reinterpret_cast<float4*>(yp + h * 32 + 4) = make_float4(a1[0], a1[1], a1[2], a1[3]);
         }
@@ -608,8 +623,10 @@ bool conv_mfma_persist_dgrad_geom_ok(const ConvGeom& g) {
     return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] != 2 || g.O[d] != g.D[d] + 2) return false;
+  // a 64-channel slice of a wider dPre (the 64 -> 200 conv): whole 16-B chunks
+  if (g.in_cstride && ((g.in_cstride & 7) || (g.in_cvalid & 7) || g.in_cvalid < 8 || g.in_cvalid > 64)) return false;
   // 30-bit element offsets over the whole batch (the zero flag is bit 30)
-  return (int64_t)g.N * g.D[0] * g.D[1] * g.D[2] * 64 < (int64_t)1 << 28;
+  return (int64_t)g.N * g.D[0] * g.D[1] * g.D[2] * (g.in_cstride ? g.in_cstride : 64) < (int64_t)1 << 28;
 }
 
 // frames per stacked axis: N = gs0 * gs1 with the least tile overhang
@@ -641,7 +658,7 @@ bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g) {
 }
 
 int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* dpre16, const void* image,
-                                   float* dxp) {
+                                   float* dxp, int accumulate) {
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, true>),
@@ -660,8 +677,8 @@ int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* d
   auto kern = g.Cout <= 32 ? conv3_mfma_persist_kernel<2, true> : conv3_mfma_persist_kernel<4, true>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
                      (const unsigned short*)dpre16, (const char*)image, (const float*)nullptr,
-                     (const unsigned short*)nullptr, (unsigned short*)dxp, g, tiles0, tiles1, tiles2, n_tiles, 0,
-                     gs0, gs1);
+                     (const unsigned short*)(accumulate ? dxp : nullptr), (unsigned short*)dxp, g, tiles0, tiles1,
+                     tiles2, n_tiles, 0, gs0, gs1);
   S3_HIP(ctx, hipGetLastError());
   ++ctx->stat[S3_STAT_PERSIST_DGRAD];
   return S3_OK;

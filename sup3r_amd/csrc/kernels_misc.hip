@@ -346,9 +346,10 @@ __global__ void conv_epilogue_bwd_kernel(const float* __restrict__ y,
 // 8-B gathers of dy / y from the hi-res layout (32-B sectors, nothing wasted).
 // (Walking the hi-res layout instead scatters 16-B pieces of every dPre line
 // over 25 far-apart moments: 0.52 ms.)
-template <bool Y16>
+template <bool Y16, bool D16 = false>
 __global__ void conv_epilogue_bwd_d2s4_kernel(const void* __restrict__ y, const float4* __restrict__ dy,
-                                              float4* __restrict__ dpre, ConvGeom g, float slope) {
+                                              float4* __restrict__ dpre, ConvGeom g, float slope,
+                                              unsigned short* __restrict__ d16 = nullptr) {
   const unsigned b = (unsigned)g.d2s, co4 = ((unsigned)g.Cout / (b * b)) >> 2, C4 = (unsigned)g.Cout >> 2;
   const unsigned O0 = (unsigned)g.O[0], O1 = (unsigned)g.O[1], O2 = (unsigned)g.O[2];
   const int64_t total = (int64_t)g.N * O0 * O1 * O2 * C4;
@@ -384,6 +385,14 @@ __global__ void conv_epilogue_bwd_d2s4_kernel(const void* __restrict__ y, const 
       d.z *= v.z > 0.f ? 1.f : slope; d.w *= v.w > 0.f ? 1.f : slope;
     }
     dpre[idx] = d;
+    if constexpr (D16) {   // bf16 copy for the MFMA gradient kernels
+      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 lo2 = {d.x, d.y}, hi2 = {d.z, d.w};
+      reinterpret_cast<uint2*>(d16)[idx] =
+          make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf2)),
+                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf2)));
+    }
   }
 }
 
@@ -921,15 +930,20 @@ int launch_act_bwd(s3_ctx* ctx, const float* y, const float* dy, float* dx,
   return S3_OK;
 }
 
+static bool conv_epilogue_bwd_d2s4_geom(const ConvGeom& g) {
+  return g.d2s > 1 && ((g.Cout / (g.d2s * g.d2s)) & 3) == 0 && (g.Cout & 3) == 0 &&
+         (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU || g.act == S3_ACT_NONE);
+}
 bool conv_epilogue_bwd_d16_ok(const ConvGeom& g) {
   const int64_t n = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout;
+  if (conv_epilogue_bwd_d2s4_geom(g)) return true;    // (the depth-to-space walk, bf16 y)
   return g.d2s <= 1 && (n & 3) == 0 && (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU);
 }
 
 // channel sums can ride along the mask pass (bias gradient): C_out / 4 | 256
 bool conv_epilogue_bwd_bsum_ok(const ConvGeom& g) {
   const int c4n = g.Cout >> 2;
-  return conv_epilogue_bwd_d16_ok(g) && (g.Cout & 3) == 0 && c4n >= 1 && c4n <= 64 && (256 % c4n) == 0 &&
+  return g.d2s <= 1 && conv_epilogue_bwd_d16_ok(g) && (g.Cout & 3) == 0 && c4n >= 1 && c4n <= 64 && (256 % c4n) == 0 &&
          kBlock == 256;
 }
 int conv_epilogue_bwd_blocks(const s3_ctx* ctx, const ConvGeom& g, bool with_bsum) {
@@ -956,12 +970,15 @@ int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }
-  if (d16 || bsum) S3_FAIL(ctx, S3_EINVAL, "conv_epilogue_bwd: side outputs need the 4-channel path");
-  if (g.d2s > 1 && ((g.Cout / (g.d2s * g.d2s)) & 3) == 0 && (g.Cout & 3) == 0 &&
-      (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU || g.act == S3_ACT_NONE)) {
+  if (bsum || (d16 && !(conv_epilogue_bwd_d2s4_geom(g) && y_bf16)))
+    S3_FAIL(ctx, S3_EINVAL, "conv_epilogue_bwd: side outputs need the 4-channel path");
+  if (conv_epilogue_bwd_d2s4_geom(g)) {
     const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
     const dim3 grid(grid_for(n / 4, ctx->num_cu));
-    if (y_bf16)
+    if (y_bf16 && d16)
+      hipLaunchKernelGGL((conv_epilogue_bwd_d2s4_kernel<true, true>), grid, dim3(kBlock), 0, ctx->stream,
+                         (const void*)y, (const float4*)dy, (float4*)dpre, g, slope, (unsigned short*)d16);
+    else if (y_bf16)
       hipLaunchKernelGGL(conv_epilogue_bwd_d2s4_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, (const void*)y,
                          (const float4*)dy, (float4*)dpre, g, slope);
     else

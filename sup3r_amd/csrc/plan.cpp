@@ -714,7 +714,8 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
         // convs: a lane's 8 channels of a dPre cell are one 16-B load)
         const bool gadj = o.gconv_dgrad && (o.cg.Cout & 7) == 0 && o.cg.pad_mode != S3_PAD_REFLECT &&
                           !getenv("SUP3R_AMD_NO_GCONV_DY16");
-        if (!gadj && (!o.dgrad_mfma || o.dgrad_fewch || o.dgrad_chunked || (o.cg.Cout & 3))) continue;
+        if (!gadj && (!o.dgrad_mfma || o.dgrad_fewch || (o.cg.Cout & 3))) continue;
+        if (o.dgrad_chunked && ((o.cg.Cout & 7) || getenv("SUP3R_AMD_NO_CHUNKED_DY16"))) continue;
         o.use16 = true;
         max16 = std::max(max16, (size_t)pl->t[root_of(pl, o.d.out)].numel * 2);
       }
@@ -1394,7 +1395,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
         }
         if ((g.act != S3_ACT_NONE || g.d2s > 1) && !pl->premasked[ro]) {
           // (never over a pending bf16-only dPre of another tensor)
-          void* side = (o.use16 && pl->dpre16 && pl->dpre16_for < 0 && conv_epilogue_bwd_d16_ok(g)) ? pl->dpre16 : nullptr;
+          void* side = (o.use16 && pl->dpre16 && pl->dpre16_for < 0 && conv_epilogue_bwd_d16_ok(g) &&
+                        (g.d2s <= 1 || o.io.out_bf16)) ? pl->dpre16 : nullptr;
           // the bias gradient = channel sums of dpre: they ride along this pass
           mask_sums = need_wgrad && d.b >= 0 && pl->bsum2 && conv_epilogue_bwd_bsum_ok(g) &&
                       !getenv("SUP3R_AMD_NO_BIAS_FUSE");
@@ -1531,9 +1533,18 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               o.dg_version = P->version;
             }
             float* acc_to = o.dgrad_valid ? dst : pl->dxp;   // valid padding: x's own grid
+            // with the bf16 copy of dPre: the slices go through the persistent
+            // kernel (stacked frames, the later slices add in its store)
+            const bool p16 = o.use16 && dpre16 && conv_mfma_persist_dgrad_supported(ctx, conv_dgrad_chunk_geom(g, 0)) &&
+                             conv_mfma_persist_dgrad_geom_ok(conv_dgrad_chunk_geom(g, nk - 1));
             for (int k = 0; k < nk; ++k) {
-              rc = launch_conv_mfma_fwd(ctx, conv_dgrad_chunk_geom(g, k), pl->precision, dpre + 64 * k, o.dgc_wbf[k],
-                                        nullptr, k ? acc_to : nullptr, acc_to, ConvIO());
+              const ConvGeom cgk = conv_dgrad_chunk_geom(g, k);
+              if (p16)
+                rc = launch_conv_mfma_persist_dgrad(ctx, cgk, (const unsigned short*)dpre16 + 64 * k,
+                                                    (const char*)o.dgc_wbf[k] + (size_t)27 * 64 * 64 * 2, acc_to, k ? 1 : 0);
+              else
+                rc = launch_conv_mfma_fwd(ctx, cgk, pl->precision, dpre + 64 * k, o.dgc_wbf[k],
+                                          nullptr, k ? acc_to : nullptr, acc_to, ConvIO());
               if (rc) return rc;
             }
             if (o.dgrad_valid) {

@@ -1027,6 +1027,50 @@ def test_valid_conv_data_gradient_on_the_persistent_kernel_is_bit_identical(monk
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('n_samples', [8, 3])
+def test_wide_conv_data_gradient_slices_on_the_persistent_kernel(monkeypatch, n_samples):
+    """data gradient of the 64 -> 200 expansion conv: the four 64-channel
+    slices of its dPre (the last one 8 channels wide) go through
+    conv3_mfma_persist_kernel<4, DG> reading the bf16 copy the depth-to-space
+    mask pass leaves behind (cell stride 200, dead 16-B chunks zeroed), the
+    later slices adding to the frame in the store — against the halo-tile
+    kernel over fp32 slices: same bf16 operands, same order, bit-identical"""
+    from sup3r_amd.configs.author_configs import pcc
+    spec = pcc(3, 64) + pcc(3, 64) + pcc(3, 200, act=False) + \
+        [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
+         {'alpha': 0.2, 'class': 'LeakyReLU'}] + pcc(3, 2, act=False)
+    shape = (n_samples, 6, 6, 30, 4)
+    monkeypatch.setenv('SUP3R_AMD_PERSIST_DGRAD_MIN_TILES', '1')
+    rng = np.random.default_rng(18)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+
+    def run():
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=0)
+        ph = net.plan(shape, training=True)
+        assert 'mfma_chunked' in _kernels(ph, 'dgrad')
+        n0 = net.dev.stat('persist_dgrad')
+        y = ph.forward(net.dev.to_device(x))
+        dy = net.dev.to_device(
+            np.random.default_rng(19).standard_normal(tuple(y.shape)).astype(np.float32))
+        dx = ph.backward(dy, need_dx=True).cpu().numpy()
+        g = [a.copy() for a in net.grads]
+        used = net.dev.stat('persist_dgrad') - n0
+        del ph
+        net.clear_plans()
+        return dx, g, used
+    dx1, g1, used1 = run()
+    monkeypatch.setenv('SUP3R_AMD_NO_CHUNKED_DY16', '1')
+    dx0, g0, used0 = run()
+    monkeypatch.delenv('SUP3R_AMD_NO_CHUNKED_DY16')
+    assert used1 >= used0 + 4, (used1, used0)
+    assert np.abs(dx1).max() > 0
+    np.testing.assert_array_equal(dx1, dx0)
+    for a, b in zip(g1, g0):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_wave_specialised_trunk_weight_gradient_is_bit_identical(monkeypatch):
     """conv3_wgrad_bf16_ws_kernel — 4 producer waves fill the other of two
     half-tile LDS buffers by LDS-DMA while 12 consumer waves run the k-steps
