@@ -283,3 +283,43 @@ def test_condmom_masked_mse_and_train():
         with open(os.path.join(out_dir, 'model_params.json')) as f:
             assert json.load(f)['num_par'] == sum(
                 w.size for w in model.generator_weights)
+
+
+def test_c2_training_steps_are_deterministic():
+    """Race screen (tools/determinism_soak.py in short): the same four
+    ``_train_batch`` steps of the C2 GAN (production generator + discriminator,
+    batch 8: every production training kernel) twice from the same seed.
+    Every reduction runs in a fixed order, so the weights must come out
+    bit-identical; an operand consumed before its wait or an LDS hand-over
+    without its barrier shows up as a difference."""
+    import torch
+    from sup3r_amd import Sup3rGan
+    from sup3r_amd.engine import Device
+
+    def run():
+        Sup3rGan.seed(7)
+        m = Sup3rGan(_cfg('gen_5x_12x_2f.json'), _cfg('disc_st.json'),
+                     loss='MeanAbsoluteError', precision='bf16')
+        dev = Device.get()
+        rng = np.random.default_rng(3)
+        lr_s, hr_s = (8, 16, 16, 24, 4), (8, 80, 80, 288, 2)
+        m.init_weights(lr_s, hr_s)
+        losses = []
+        for _ in range(4):
+            class Batch:
+                low_res = dev.to_device(rng.standard_normal(lr_s).astype(np.float32))
+                high_res = dev.to_device(rng.standard_normal(hr_s).astype(np.float32))
+            d = m._train_batch(Batch, True, False, False, True, False, False, 1e-3)
+            losses.append((d['loss_gen'], d['loss_disc']))
+        torch.cuda.synchronize()
+        w = [np.array(a) for a in m.generator.weights] + \
+            [np.array(a) for a in m.discriminator.weights]
+        del m
+        torch.cuda.empty_cache()
+        return w, losses
+    w0, l0 = run()
+    w1, l1 = run()
+    assert all(np.isfinite(a).all() for a in w0)
+    assert l0 == l1
+    for a, b in zip(w0, w1):
+        np.testing.assert_array_equal(a, b)
