@@ -347,8 +347,15 @@ constexpr int S1 = 16, S2 = 64, SEG0 = 20;
 constexpr int P1 = S1 + 2, P2 = S2 + 2;
 constexpr int PLANE_CELLS = P1 * P2;                    // 1188
 constexpr int PLANE_BYTES = ((PLANE_CELLS + 63) / 64) * 64 * 16;   // 19,456 incl. pad
-constexpr int NSLOT = 4;
-constexpr int SLIDE_LDS = NSLOT * PLANE_BYTES;          // 77,824
+// PD planes are in flight ahead of the row being computed (the round trip of a
+// plane's LDS-DMA under load is longer than one row's 27 MFMAs: with PD = 1
+// every row barrier waited for it).  Measured at C2 x 32 chunks: PD 1 / 2 / 3 /
+// 4 = 0.369 / 0.338 / 0.342 / 0.352 ms; a conflict-free swizzle of the plane
+// rows (the banded B reads are 4-way bank conflicts in column order) changed
+// nothing at PD 1 — the rows wait on the fetch path, not on LDS.
+constexpr int PD = 2;
+constexpr int NSLOT = 3 + PD;
+constexpr int SLIDE_LDS = NSLOT * PLANE_BYTES;          // 97,280
 
 __global__ __launch_bounds__(NTH) void conv_tail_slide_kernel(
     const unsigned short* __restrict__ x, const float* __restrict__ w,
@@ -388,20 +395,34 @@ __global__ __launch_bounds__(NTH) void conv_tail_slide_kernel(
     const int i2 = clampi(s3_reflect(o2 + lane - g.lo[2], D2), D2);
     char* bufp = smem + slot * PLANE_BYTES;
     const int sw = wave - NCW;
+    // (columns 64 / 65: a second DMA piece per row with two active lanes — no
+    // register-path load, so every wait below is a counted vmcnt on DMA pieces)
+    const int j2 = clampi(s3_reflect(o2 + 64 + (lane & 1) - g.lo[2], D2), D2);
     for (int row = sw; row < P1; row += NDW) {
       const int i1 = clampi(s3_reflect(o1 + row - g.lo[1], D1), D1);
-      const unsigned short* src = xn + (((size_t)i0 * D1 + i1) * D2 + i2) * 8;
+      const unsigned short* rowp = xn + ((size_t)i0 * D1 + i1) * D2 * 8;
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)src,
+          (const __attribute__((address_space(1))) void*)(rowp + (size_t)i2 * 8),
           (__attribute__((address_space(3))) void*)(bufp + row * (P2 * 16)), 16, 0, 0);
+      if (lane < 2)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(rowp + (size_t)j2 * 8),
+            (__attribute__((address_space(3))) void*)(bufp + (row * P2 + 64) * 16), 16, 0, 0);
     }
-    const int st = tid - NCW * 64;                 // 0 .. 255
-    if (st < 2 * P1) {
-      const int row = st >> 1, c2 = 64 + (st & 1);
-      const int i1 = clampi(s3_reflect(o1 + row - g.lo[1], D1), D1);
-      const int j2 = clampi(s3_reflect(o2 + c2 - g.lo[2], D2), D2);
-      const uint4 v = *reinterpret_cast<const uint4*>(xn + (((size_t)i0 * D1 + i1) * D2 + j2) * 8);
-      *reinterpret_cast<uint4*>(bufp + (row * P2 + c2) * 16) = v;
+  };
+  // vector-memory instructions stage_plane issues in this wave
+  const int plane_ops = 2 * ((P1 - (wave - NCW) + NDW - 1) / NDW);
+  auto wait_planes = [&](int in_flight) __attribute__((always_inline)) {
+    // all but the youngest `in_flight` planes of this wave have landed
+    switch (in_flight * plane_ops) {
+      case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
+      case 16: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;
+      case 20: asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory"); break;
+      case 24: asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); break;
+      case 30: asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
     }
   };
 
@@ -441,16 +462,19 @@ __global__ __launch_bounds__(NTH) void conv_tail_slide_kernel(
       int n, r0, o1, o2;
       unit_org(u, n, r0, o1, o2);
       const int rows = (r0 + SEG0 <= g.O[0] ? SEG0 : g.O[0] - r0);
-      // padded rows r0 .. r0 + rows + 1 feed output rows r0 .. r0 + rows - 1
-      stage_plane(n, r0, o1, o2, 0);
-      stage_plane(n, r0 + 1, o1, o2, 1);
-      stage_plane(n, r0 + 2, o1, o2, 2);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      SLIDE_BARRIER();                       // planes 0..2 of this unit are in
+      // padded rows r0 .. r0 + rows + 1 feed output rows r0 .. r0 + rows - 1;
+      // plane q (slot q % NSLOT) is needed from row q - 2 on
+      int issued = 0;                        // planes staged so far
+      for (; issued < 2 + PD && issued < rows + 2; ++issued) stage_plane(n, r0 + issued, o1, o2, issued % NSLOT);
+      wait_planes(issued - 3);               // planes 0 .. 2 are in
+      SLIDE_BARRIER();
       for (int r = 0; r < rows; ++r) {
-        if (r + 1 < rows) stage_plane(n, r0 + r + 3, o1, o2, (r + 3) % NSLOT);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        SLIDE_BARRIER();                     // row r computed, next plane landed
+        // slot (r + 2 + PD) % NSLOT held plane r - 1: free since the last barrier
+        if (issued < rows + 2) { stage_plane(n, r0 + issued, o1, o2, issued % NSLOT); ++issued; }
+        // row r + 1 reads planes up to r + 3
+        const int need = r + 4 < rows + 2 ? r + 4 : rows + 2;
+        wait_planes(issued - need);
+        SLIDE_BARRIER();                     // row r computed, plane r + 3 landed
       }
     }
     return;
