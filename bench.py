@@ -106,6 +106,13 @@ def train_models(config, precision='bf16'):
                      loss='MeanAbsoluteError', precision=precision)
         return m, (16, 16, 24, 2), (48, 48, 96, 2), \
             'gen_3x_4x_2f + disc_st_same (C4 body)', None
+    if config == 'c1':
+        # tests/training/test_train_gan.py (S): batch 15, lr 5 x 5 -> hr 10 x 10
+        m = Sup3rGan(os.path.join(CFGDIR, 'gen_2x_2f.json'),
+                     os.path.join(CFGDIR, 'disc_s_same.json'),
+                     loss='MeanAbsoluteError', precision=precision)
+        return m, (5, 5, 2), (10, 10, 2), \
+            'gen_2x_2f + disc_s_same (C1, the reference test shape)', None
     if config == 'c4toy':
         m = Sup3rGan(os.path.join(CFGDIR, 'gen_wind_3x_4x_2f_toy.json'),
                      os.path.join(CFGDIR, 'disc_st_same.json'),
@@ -465,7 +472,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mode', default='infer',
                     choices=['infer', 'train', 'c3', 'c1'])
-    ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c4toy'],
+    ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c4toy', 'c1'],
                     help='--mode train: which GAN')
     ap.add_argument('--batch', type=int, default=None,
                     help='infer: lo-res chunks per GPU per step (default 32; '
@@ -523,7 +530,8 @@ def main():
             'higher_is_better': True, 'vs_baseline': None, 'data': 'synthetic'}
 
     if args.mode == 'train':
-        gb = args.batch or (8 * world if args.config == 'c2' else 32)
+        gb = args.batch or (8 * world if args.config == 'c2' else
+                            15 if args.config == 'c1' else 32)
         if gb % world:
             raise SystemExit(f'global batch {gb} does not divide over {world}')
         barrier()
