@@ -242,6 +242,7 @@ int launch_conv_fewpos_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,
                              const float* wt, float* dx, float* partial,
                              size_t partial_bytes);
 size_t conv_fewpos_wgrad_partial_bytes(const ConvGeom& g);
+bool conv_fewpos_wgrad_ok(const ConvGeom& g);
 ConvGeom conv_fewpos_frame_geom(const ConvGeom& g);
 int launch_conv_fewpos_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,
                              const float* dy, float* dw, float* partial, size_t partial_bytes,

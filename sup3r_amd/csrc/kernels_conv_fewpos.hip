@@ -219,6 +219,13 @@ bool conv_fewpos_supported(const ConvGeom& g) {
   return P <= 4096 && Pin <= 32768 && wsize >= 16384 && g.Cin >= 16 && g.Cout >= 16;
 }
 
+// the weight-gradient kernel alone has no lower bounds on the filter size
+bool conv_fewpos_wgrad_ok(const ConvGeom& g) {
+  const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  const int64_t Pin = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
+  return P <= 4096 && Pin <= 32768;
+}
+
 size_t conv_fewpos_partial_bytes(const ConvGeom& g) {
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];

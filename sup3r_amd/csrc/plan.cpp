@@ -72,6 +72,7 @@ struct OpRec {
   uint64_t gc_version = 0, gct_version = 0;
   // few-positions GEMM path
   bool fewpos = false;
+  bool fewpos_wgrad = false;   // few positions, small filter: only the weight gradient takes the fewpos kernel
   float* fp_wt = nullptr;      // [tap][co][ci] transposed filter (dgrad)
   uint64_t fp_version = 0;
 };
@@ -451,6 +452,15 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               conv_wgrad_gen_supported(g)) {
             o.wgrad_gen = true;
             max_partial = std::max(max_partial, conv_wgrad_gen_partial_bytes(ctx, g));
+          }
+          // what is left would take the generic kernel (one thread per filter
+          // element walking every position: 204 us for the 1 500 positions of
+          // the C1 discriminator's first layers); with few positions the slab
+          // kernel of the fewpos family does any C_in / C_out
+          if (!o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_tail && !o.wgrad_bf16_gen && !o.wgrad_bf16_2d &&
+              !o.wgrad_gen && conv_fewpos_wgrad_ok(g) && !getenv("SUP3R_AMD_NO_FEWPOS")) {
+            o.fewpos_wgrad = true;
+            max_partial = std::max(max_partial, conv_fewpos_wgrad_partial_bytes(g));
           }
           o.dgrad_mfma = conv_dgrad_mfma_supported(g, precision);
           if (!o.dgrad_mfma && !o.fewpos && precision == S3_PREC_BF16 &&
@@ -1248,7 +1258,7 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
                                   fwd == S3_FWD_GCONV || fwd == S3_FWD_GCONV_FEWCH || fwd == S3_FWD_TAIL_MFMA)) ? 1 : 0;
     if (pl->training) {
       int wg = S3_WGRAD_DIRECT;
-      if (o.fewpos) wg = S3_WGRAD_FEWPOS;
+      if (o.fewpos || (o.fewpos_wgrad && !o.io.in_bf16)) wg = S3_WGRAD_FEWPOS;
       else if (o.wgrad_tail) wg = S3_WGRAD_TAIL;
       else if (o.wgrad_c2) wg = S3_WGRAD_C2;
       else if (o.wgrad_bf16_2d) wg = S3_WGRAD_BF16_2D;
@@ -1442,6 +1452,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           }
           else if (o.wgrad_mfma)
             rc = launch_conv_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+          else if (o.fewpos_wgrad && !o.io.in_bf16)
+            rc = launch_conv_fewpos_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else
             rc = launch_conv_generic_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           if (rc) return rc;
