@@ -36,7 +36,9 @@ __device__ inline int64_t fewpos_src(const ConvGeom& g, int mode, int64_t row,
                                      int tap) {
   const int a = tap / (g.k[1] * g.k[2]), b = (tap / g.k[2]) % g.k[1], c = tap % g.k[2];
   const int kk[3] = {a, b, c};
-  int64_t r = row;
+  // (fewpos geometries have < 2^16 positions: 32-bit divisions — the 64-bit
+  // ones were most of the weight-gradient kernel's time)
+  unsigned r = (unsigned)row;
   int p[3], n;
   if (mode == 0) {
     p[2] = (int)(r % g.O[2]); r /= g.O[2];
@@ -167,14 +169,49 @@ __global__ __launch_bounds__(256) void fewpos_wgrad_kernel(
 #pragma unroll
   for (int j = 0; j < CI_T; ++j) acc[j] = 0.f;
   const int64_t p0 = rows * slab / slabs, p1 = rows * (slab + 1) / slabs;
-  for (int64_t p = p0; p < p1; ++p) {
-    const int64_t s = fewpos_src(g, 0, p, tap);   // wave-uniform
-    if (s < 0) continue;
-    const float d = live ? dy[p * g.Cout + co] : 0.f;
-    const float* xp = x + s * g.Cin + ci0;
+  // four positions per trip, every load issued before the first fma (one
+  // position per trip was a chain of exposed memory latencies: 28 us for 47
+  // positions); same summation order, padding taps add an exact zero
+  constexpr int UP = 4;
+  // output coordinates of the walk: one set of divisions per slab, then carries
+  const int ka = tap / (g.k[1] * g.k[2]), kb = (tap / g.k[2]) % g.k[1], kc = tap % g.k[2];
+  int wn, w0, w1, w2;
+  {
+    unsigned r = (unsigned)p0;
+    w2 = (int)(r % (unsigned)g.O[2]); r /= (unsigned)g.O[2];
+    w1 = (int)(r % (unsigned)g.O[1]); r /= (unsigned)g.O[1];
+    w0 = (int)(r % (unsigned)g.O[0]); wn = (int)(r / (unsigned)g.O[0]);
+  }
+  auto src_here = [&]() -> int64_t {
+    int i0 = w0 * g.s[0] + ka - g.lo[0], i1 = w1 * g.s[1] + kb - g.lo[1], i2 = w2 * g.s[2] + kc - g.lo[2];
+    if (g.pad_mode == S3_PAD_REFLECT) {
+      i0 = s3_reflect(i0, g.D[0]); i1 = s3_reflect(i1, g.D[1]); i2 = s3_reflect(i2, g.D[2]);
+    }
+    if (i0 < 0 || i0 >= g.D[0] || i1 < 0 || i1 >= g.D[1] || i2 < 0 || i2 >= g.D[2]) return -1;
+    return (((int64_t)wn * g.D[0] + i0) * g.D[1] + i1) * g.D[2] + i2;
+  };
+  auto step = [&]() {
+    if (++w2 == g.O[2]) { w2 = 0; if (++w1 == g.O[1]) { w1 = 0; if (++w0 == g.O[0]) { w0 = 0; ++wn; } } }
+  };
+  for (int64_t p = p0; p < p1; p += UP) {
+    int64_t s[UP];
+    float d[UP], xv[UP][CI_T];
 #pragma unroll
-    for (int j = 0; j < CI_T; ++j)
-      acc[j] = fmaf((ci0 + j < g.Cin) ? xp[j] : 0.f, d, acc[j]);
+    for (int u = 0; u < UP; ++u) {          // wave-uniform
+      s[u] = p + u < p1 ? src_here() : -1;
+      step();
+    }
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+      d[u] = (s[u] >= 0 && live) ? dy[(p + u) * g.Cout + co] : 0.f;
+#pragma unroll
+      for (int j = 0; j < CI_T; ++j)
+        xv[u][j] = (s[u] >= 0 && ci0 + j < g.Cin) ? x[s[u] * g.Cin + ci0 + j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UP; ++u)
+#pragma unroll
+      for (int j = 0; j < CI_T; ++j) acc[j] = fmaf(xv[u][j], d[u], acc[j]);
   }
   if (!live) return;
   const int64_t wsize = (int64_t)gridDim.z * g.Cin * g.Cout;
