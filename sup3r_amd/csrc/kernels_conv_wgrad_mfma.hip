@@ -139,6 +139,42 @@ __global__ void wgrad_partial_reduce(const float* __restrict__ partial,
   }
 }
 
+// many partials of a small filter (the hi-res few-channel convs: up to 2 048
+// partials of a few thousand elements): one thread per element walking all of
+// them is a 130 us chain on a handful of workgroups.  Segments of the partials
+// are summed side by side (blockIdx.y), then the segment sums in order — a
+// fixed order either way
+__global__ void wgrad_partial_reduce_seg(const float* __restrict__ partial, int n_part, int64_t wsize,
+                                         float* __restrict__ seg_out, int n_seg) {
+  const int seg = blockIdx.y;
+  const int s0 = (int)((int64_t)n_part * seg / n_seg), s1 = (int)((int64_t)n_part * (seg + 1) / n_seg);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < wsize;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int s = s0; s < s1; ++s) t += partial[(int64_t)s * wsize + i];
+    seg_out[(int64_t)seg * wsize + i] = t;
+  }
+}
+
+int launch_wgrad_partial_reduce(s3_ctx* ctx, const float* partial, int n_part, int64_t wsize, float* dw,
+                                int accumulate) {
+  int rg = (int)((wsize + 255) / 256);
+  if (rg > 2048) rg = 2048;
+  // (only where it pays: enough partials, too few workgroups to hide the walk)
+  const int n_seg = (n_part >= 128 && rg * 4 <= ctx->num_cu && !getenv("SUP3R_AMD_NO_SEG_REDUCE")) ? 16 : 1;
+  if (n_seg > 1 && ensure_scratch(ctx, (size_t)n_seg * wsize * sizeof(float)) == S3_OK) {
+    hipLaunchKernelGGL(wgrad_partial_reduce_seg, dim3(rg, n_seg), dim3(256), 0, ctx->stream, partial, n_part, wsize,
+                       ctx->scratch, n_seg);
+    hipLaunchKernelGGL(wgrad_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, (const float*)ctx->scratch, n_seg,
+                       wsize, dw, accumulate);
+  } else {
+    hipLaunchKernelGGL(wgrad_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial, n_part, wsize, dw,
+                       accumulate);
+  }
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 int wgrad_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles_out, int* t0,
                int* t1, int* t2) {
   const int tiles0 = (g.O[0] + WT0 - 1) / WT0, tiles1 = (g.O[1] + WT1 - 1) / WT1,
@@ -184,12 +220,7 @@ int launch_conv_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x,
   hipLaunchKernelGGL(conv3_wgrad_mfma_kernel, dim3(grid, n_ct), dim3(WNT), WG_LDS,
                      ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles);
   const int64_t wsize = (int64_t)27 * 64 * g.Cout;
-  int rg = (int)((wsize + 255) / 256);
-  if (rg > 2048) rg = 2048;
-  hipLaunchKernelGGL(wgrad_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream,
-                     partial, grid, wsize, dw, accumulate);
-  S3_HIP(ctx, hipGetLastError());
-  return S3_OK;
+  return launch_wgrad_partial_reduce(ctx, partial, grid, wsize, dw, accumulate);
 }
 
 // ===========================================================================
@@ -383,12 +414,7 @@ int wgrad_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float
   hipLaunchKernelGGL(kern, dim3(grid, n_ct, n_cit), dim3(512), W::LDS, ctx->stream, x, dy,
                      partial, g, t0, t1, t2, n_tiles);
   const int64_t wsize = (int64_t)27 * g.Cin * g.Cout;
-  int rg = (int)((wsize + 255) / 256);
-  if (rg > 2048) rg = 2048;
-  hipLaunchKernelGGL(wgrad_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial,
-                     grid * W::PS, wsize, dw, accumulate);
-  S3_HIP(ctx, hipGetLastError());
-  return S3_OK;
+  return launch_wgrad_partial_reduce(ctx, partial, grid * W::PS, wsize, dw, accumulate);
 }
 
 int wgrad_gen_cib(const ConvGeom& g) { return g.Cin <= 16 ? 1 : (g.Cin <= 32 ? 2 : 4); }   // C_in > 64: tiles of 64
