@@ -231,7 +231,11 @@ __global__ __launch_bounds__(WS_NT) void conv3_wgrad_bf16_ws_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct = blockIdx.y;
+  // first channel of this workgroup's 32-wide cout tile.  C_out need not be a
+  // multiple of 32 (the 64 -> 200 conv): the last tile is moved back to end at
+  // C_out, its overlap with the tile before is computed twice — the same sums
+  // in the same order, so both workgroups store identical values there
+  const int cbase = (int)(blockIdx.y * BCT + BCT) <= g.Cout ? (int)(blockIdx.y * BCT) : g.Cout - BCT;
   const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
   // this workgroup's half tiles: item it = (tile blockIdx.x + (it >> 1) gridDim.x, half it & 1)
   const int my_tiles = (int)blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(WS_NT) void conv3_wgrad_bf16_ws_kernel(
             (__attribute__((address_space(3))) void*)(buf + j * 1024), 16, 0, 0);
       }
       // dPre rows: wave-DMA j fills positions 16 j .. 16 j + 15; lane -> (position, 16-B slot)
-      const unsigned short* dn = dy + (size_t)n * g.O[0] * g.O[1] * g.O[2] * g.Cout + ct * BCT;
+      const unsigned short* dn = dy + (size_t)n * g.O[0] * g.O[1] * g.O[2] * g.Cout + cbase;
 #pragma unroll
       for (int k = 0; k < NDJ; ++k) {
         const int j = pw + 4 * k;
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(WS_NT) void conv3_wgrad_bf16_ws_kernel(
   float* out = partial + (size_t)blockIdx.x * 27 * 64 * g.Cout;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
-    const int co = ct * BCT + nb * 16 + q;
+    const int co = cbase + nb * 16 + q;
     if (co < g.Cout) {
 #pragma unroll
       for (int t = 0; t < 9; ++t)
@@ -969,9 +973,9 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
   static const int dbg = getenv("SUP3R_AMD_WGRAD_DBG") ? atoi(getenv("SUP3R_AMD_WGRAD_DBG")) : 0;
-  // wave-specialised variant: reflect padding, tiles and cout tiles that fit exactly
+  // wave-specialised variant: reflect padding, tiles that fit exactly, whole 16-B channel chunks
   const bool ws = dy_bf16 && !dbg && !getenv("SUP3R_AMD_NO_WGRAD_WS") && g.pad_mode == S3_PAD_REFLECT &&
-                  g.O[0] % BT0 == 0 && g.O[1] % BT1 == 0 && g.O[2] % BT2 == 0 && g.Cout % BCT == 0 &&
+                  g.O[0] % BT0 == 0 && g.O[1] % BT1 == 0 && g.O[2] % BT2 == 0 && g.Cout >= BCT && g.Cout % 8 == 0 &&
                   (int64_t)g.D[0] * g.D[1] * g.D[2] * 64 < ((int64_t)1 << 31) &&
                   (int64_t)g.O[0] * g.O[1] * g.O[2] * g.Cout < ((int64_t)1 << 31);
   if (ws)

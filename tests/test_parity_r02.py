@@ -1027,8 +1027,8 @@ def test_valid_conv_data_gradient_on_the_persistent_kernel_is_bit_identical(monk
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize('n_samples', [8, 3])
-def test_wide_conv_data_gradient_slices_on_the_persistent_kernel(monkeypatch, n_samples):
+@pytest.mark.parametrize('n_samples,extent', [(8, (6, 6, 30)), (3, (6, 6, 30)), (4, (8, 8, 32))])
+def test_wide_conv_data_gradient_slices_on_the_persistent_kernel(monkeypatch, n_samples, extent):
     """data gradient of the 64 -> 200 expansion conv: the four 64-channel
     slices of its dPre (the last one 8 channels wide) go through
     conv3_mfma_persist_kernel<4, DG> reading the bf16 copy the depth-to-space
@@ -1039,7 +1039,10 @@ def test_wide_conv_data_gradient_slices_on_the_persistent_kernel(monkeypatch, n_
     spec = pcc(3, 64) + pcc(3, 64) + pcc(3, 200, act=False) + \
         [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
          {'alpha': 0.2, 'class': 'LeakyReLU'}] + pcc(3, 2, act=False)
-    shape = (n_samples, 6, 6, 30, 4)
+    # (8 x 8 x 32: tiles fit exactly — the expansion conv's weight gradient then
+    # also runs on the wave-specialised kernel, its seventh cout tile moved
+    # back to channels 168 .. 199)
+    shape = (n_samples,) + extent + (4,)
     monkeypatch.setenv('SUP3R_AMD_PERSIST_DGRAD_MIN_TILES', '1')
     rng = np.random.default_rng(18)
     x = rng.standard_normal(shape).astype(np.float32)
