@@ -711,11 +711,13 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
     int rc = plan_alloc(pl, (void**)&pl->dpre, max_dpre);
-    // bf16 side copy of dPre for the halo-tile data gradients (the kernel
-    // rounds its operand to bf16 anyway; a bf16 source halves the bytes on its
-    // staging path).  Only the separate mask pass writes one: the same side
-    // store in the frame folds cost them 42 us per 75 MB and saved the data
-    // gradient 30 (measured, dropped).
+    // bf16 copy of dPre for the MFMA gradient kernels (they round their
+    // operand to bf16 anyway; a bf16 source halves the bytes they stage, and
+    // the persistent data gradient / the wave-specialised weight gradient take
+    // nothing else).  Whichever pass finishes a conv's dPre leaves it: the mask
+    // pass (d2s walk included), the frame folds (compile-time variants: a
+    // run-time side store cost them 42 us per 75 MB), the stride-2 data
+    // gradient.  One buffer, handed from producer to consumer (dpre16_for).
     if (precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_NO_DPRE16")) {
       size_t max16 = 0;
       for (auto& o : pl->ops) {
