@@ -390,6 +390,20 @@ int s3_invert_uv(s3_ctx* ctx, float* data, int64_t n_sp, int64_t t, int c,
                  const float* sin_theta);
 int s3_clip_channels(s3_ctx* ctx, float* data, int c, int64_t n_pos,
                      const float* min_host, const float* max_host);
+/*   s3_range_mask / s3_fill_indexed = enforce_limits(nn_fill=True) (same lines)
+ *                      + nn_fill_array (utilities.py:55-75): channel ch of the
+ *                      (n_pos, c) chunk — mask[p] = 1 where the value is
+ *                      outside [lo, hi] or NaN (the reference writes NaN there);
+ *                      then data[p, ch] = data[src[p], ch] on the masked
+ *                      positions.  src is the flattened index map of
+ *                      scipy.ndimage.distance_transform_edt(mask,
+ *                      return_indices=True) — the reference's own call, made by
+ *                      the host on the boolean mask only; the field stays on
+ *                      the device. */
+int s3_range_mask(s3_ctx* ctx, const float* data, int c, int ch, int64_t n_pos,
+                  float lo, float hi, unsigned char* mask);
+int s3_fill_indexed(s3_ctx* ctx, float* data, int c, int ch, int64_t n_pos,
+                    const unsigned char* mask, const int* src);
 
 /* ---- data-parallel gradient sync (RCCL over xGMI) -----------------------
  * replaces: the host-side python sum of per-GPU gradient lists,

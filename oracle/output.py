@@ -94,21 +94,39 @@ def get_renamed_features(features):
     return out
 
 
-def enforce_limits(features, data):
-    """utilities.py:155-220 with nn_fill=False"""
+def nn_fill_array(array):
+    """utilities.py:55-75: NaNs take the value of the nearest non-NaN cell
+    (scipy's Euclidean distance transform over ALL axes of the array)."""
+    from scipy import ndimage as nd
+    nan_mask = np.isnan(array)
+    indices = nd.distance_transform_edt(nan_mask, return_distances=False,
+                                        return_indices=True)
+    return array[tuple(indices)]
+
+
+def enforce_limits(features, data, nn_fill=False):
+    """utilities.py:155-220"""
     data = np.array(data, copy=True)
     for fidx, fn in enumerate(features):
         name = get_feature_basename(fn)
         if name not in OUTPUT_LIMITS:
             raise KeyError(f'Could not find "{name}" in OUTPUT_ATTRS dict!')
         lo, hi = OUTPUT_LIMITS[name]
-        data[..., fidx] = np.maximum(data[..., fidx], lo)
-        data[..., fidx] = np.minimum(data[..., fidx], hi)
+        if nn_fill:
+            data[..., fidx] = np.where(data[..., fidx] > hi, np.nan,
+                                       data[..., fidx])
+            data[..., fidx] = np.where(data[..., fidx] < lo, np.nan,
+                                       data[..., fidx])
+            data[..., fidx] = nn_fill_array(data[..., fidx])
+        else:
+            data[..., fidx] = np.maximum(data[..., fidx], lo)
+            data[..., fidx] = np.minimum(data[..., fidx], hi)
     return data.astype(np.float32)
 
 
-def transform_output(data, features, lat_lon, invert_uv_flag=False):
-    """writers/base.py:304-345 (nn_fill=False); returns (data, features)"""
+def transform_output(data, features, lat_lon, invert_uv_flag=False,
+                     nn_fill=False):
+    """writers/base.py:304-345; returns (data, features)"""
     data = np.array(data, copy=True)
     features = list(features)
     if invert_uv_flag and any(re.match(r'[uv]_(.*?)m$', f.lower())
@@ -121,4 +139,4 @@ def transform_output(data, features, lat_lon, invert_uv_flag=False):
                 ws, wd = invert_uv(data[..., ui], data[..., vi], lat_lon)
                 data[..., ui], data[..., vi] = ws, wd
         features = get_renamed_features(features)
-    return enforce_limits(features, data), features
+    return enforce_limits(features, data, nn_fill=nn_fill), features

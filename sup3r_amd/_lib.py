@@ -36,7 +36,7 @@ EXPORTS = [
     's3_copy_channels', 's3_affine_channels', 's3_fill', 's3_copy_block',
     's3_coarsen', 's3_gaussian_smooth', 's3_chunk_stats',
     's3_host_register', 's3_host_unregister', 's3_d2h_window',
-    's3_invert_uv', 's3_clip_channels',
+    's3_invert_uv', 's3_clip_channels', 's3_range_mask', 's3_fill_indexed',
     's3_comm_unique_id', 's3_comm_init', 's3_params_allreduce_grads',
     's3_allreduce_sum', 's3_params_broadcast', 's3_broadcast',
     's3_comm_destroy', 's3_version',
@@ -144,6 +144,8 @@ def lib():
         's3_chunk_stats': (i32, [vp, vp, i32, i64, i32, vp]),
         's3_invert_uv': (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp]),
         's3_clip_channels': (i32, [vp, vp, i32, i64, pf, pf]),
+        's3_range_mask': (i32, [vp, vp, i32, i32, i64, f32, f32, vp]),
+        's3_fill_indexed': (i32, [vp, vp, i32, i32, i64, vp, vp]),
         's3_host_register': (i32, [vp, vp, C.c_size_t]),
         's3_host_unregister': (i32, [vp, vp]),
         's3_d2h_window': (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),

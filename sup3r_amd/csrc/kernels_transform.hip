@@ -177,6 +177,46 @@ extern "C" int s3_invert_uv(s3_ctx* ctx, float* data, int64_t n_sp, int64_t t, i
   return S3_OK;
 }
 
+// enforce_limits(nn_fill=True): mask of one channel's out-of-range (or NaN)
+// values, and the refill of the masked positions from an index map
+__global__ void range_mask_kernel(const float* __restrict__ data, int c, int ch, int64_t n_pos,
+                                  float lo, float hi, unsigned char* __restrict__ mask) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pos;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const float v = data[p * c + ch];
+    mask[p] = (v >= lo && v <= hi) ? 0 : 1;          // NaN compares false: masked
+  }
+}
+
+__global__ void fill_indexed_kernel(float* __restrict__ data, int c, int ch, int64_t n_pos,
+                                    const unsigned char* __restrict__ mask,
+                                    const int* __restrict__ src) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pos;
+       p += (int64_t)gridDim.x * blockDim.x)
+    if (mask[p]) data[p * c + ch] = data[(int64_t)src[p] * c + ch];   // sources are never masked
+}
+
+extern "C" int s3_range_mask(s3_ctx* ctx, const float* data, int c, int ch, int64_t n_pos,
+                             float lo, float hi, unsigned char* mask) {
+  if (!ctx || !data || !mask) return S3_EINVAL;
+  if (ch < 0 || ch >= c) S3_FAIL(ctx, S3_EINVAL, "range_mask: bad channel index");
+  hipLaunchKernelGGL(range_mask_kernel, dim3(grid_of(n_pos, ctx->num_cu)), dim3(kBlk), 0, ctx->stream,
+                     data, c, ch, n_pos, lo, hi, mask);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_fill_indexed(s3_ctx* ctx, float* data, int c, int ch, int64_t n_pos,
+                               const unsigned char* mask, const int* src) {
+  if (!ctx || !data || !mask || !src) return S3_EINVAL;
+  if (ch < 0 || ch >= c) S3_FAIL(ctx, S3_EINVAL, "fill_indexed: bad channel index");
+  if (n_pos >= ((int64_t)1 << 31)) S3_FAIL(ctx, S3_EINVAL, "fill_indexed: 32-bit position indices");
+  hipLaunchKernelGGL(fill_indexed_kernel, dim3(grid_of(n_pos, ctx->num_cu)), dim3(kBlk), 0, ctx->stream,
+                     data, c, ch, n_pos, mask, src);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 extern "C" int s3_clip_channels(s3_ctx* ctx, float* data, int c, int64_t n_pos,
                                 const float* min_host, const float* max_host) {
   if (!ctx || !data) return S3_EINVAL;

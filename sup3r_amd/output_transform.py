@@ -9,8 +9,12 @@ with clipping (sup3r/utilities/utilities.py:155-220) run on the hi-res chunk
 while it is still on the device, so only final values cross PCIe.  The grid
 angle theta(s1, s2) is computed on the host from ``lat_lon`` exactly as the
 reference does (a small 2-D array) and uploaded as cos / sin tables.
-``nn_fill=True`` (nearest-neighbour refill of out-of-range values) stays a
-host operation of the writers and is not offered here.
+``nn_fill=True`` (utilities.py:208-215 + ``nn_fill_array`` :55-75): the
+out-of-range / NaN mask of a feature is built on the device, the index map of
+the nearest valid cell comes from the reference's own
+``scipy.ndimage.distance_transform_edt(mask, return_indices=True)`` call on
+that boolean mask (host, only for features that leave their range), and the
+refill is a device gather — the field itself never leaves the device.
 """
 import ctypes as C
 import logging
@@ -85,10 +89,6 @@ class DeviceOutputTransform:
 
     def transform_output(self, data, features, lat_lon, invert_uv=False,
                          nn_fill=False):
-        if nn_fill:
-            raise NotImplementedError(
-                'nn_fill=True is a host operation of the writers; the device '
-                'epilogue clips (nn_fill=False)')
         L, dev = _lib.lib(), self.dev
         x = dev.to_device(data)
         if x.dim() != 4:
@@ -132,15 +132,50 @@ class DeviceOutputTransform:
         sth = st.cpu().numpy()[0]
         for i, fn in enumerate(features):
             f_min, f_max = sth[:, i, 0].min(), sth[:, i, 1].max()
-            if f_max > hi[i] or f_min < lo[i]:
+            bad = f_max > hi[i] or f_min < lo[i]
+            if bad:
                 msg = (f'{fn} has a range of ({f_min}, {f_max}) outside '
                        f'({lo[i]}, {hi[i]}). Enforcing the range with '
-                       'clipping.')
+                       + ('nearest neighbor interpolation.' if nn_fill
+                          else 'clipping.'))
                 logger.warning(msg)
                 warn(msg)
+            if nn_fill and (bad or not np.isfinite([f_min, f_max]).all()):
+                self._nn_fill_channel(x, i, float(lo[i]), float(hi[i]))
+        if nn_fill:
+            return x, features
         pf = C.POINTER(C.c_float)
         rc = L.s3_clip_channels(dev.ctx, C.c_void_p(x.data_ptr()), c,
                                 s1 * s2 * t, lo.ctypes.data_as(pf),
                                 hi.ctypes.data_as(pf))
         _lib.check(rc, dev.ctx, 's3_clip_channels')
         return x, features
+
+
+    def _nn_fill_channel(self, x, ch, lo, hi):
+        """``data[..., ch] = nn_fill_array(where(out of range, nan, data[..., ch]))``
+        (utilities.py:208-215, :55-75) on the device tensor ``x``."""
+        import torch
+        from scipy import ndimage as nd
+        L, dev = _lib.lib(), self.dev
+        s1, s2, t, c = (int(v) for v in x.shape)
+        n_pos = s1 * s2 * t
+        mask = torch.empty(n_pos, dtype=torch.uint8, device=x.device)
+        rc = L.s3_range_mask(dev.ctx, C.c_void_p(x.data_ptr()), c, ch, n_pos,
+                             lo, hi, C.c_void_p(mask.data_ptr()))
+        _lib.check(rc, dev.ctx, 's3_range_mask')
+        m = mask.cpu().numpy().astype(bool).reshape(s1, s2, t)
+        if not m.any():
+            return
+        if m.all():
+            raise ValueError('nn_fill: no value of the feature is inside its '
+                             'range')
+        # the reference's own call (utilities.py:70-72) on the boolean mask
+        idx = nd.distance_transform_edt(m, return_distances=False,
+                                        return_indices=True)
+        flat = np.ravel_multi_index(tuple(idx), (s1, s2, t)).astype(np.int32)
+        src = torch.from_numpy(np.ascontiguousarray(flat.ravel())).to(x.device)
+        rc = L.s3_fill_indexed(dev.ctx, C.c_void_p(x.data_ptr()), c, ch, n_pos,
+                               C.c_void_p(mask.data_ptr()),
+                               C.c_void_p(src.data_ptr()))
+        _lib.check(rc, dev.ctx, 's3_fill_indexed')

@@ -82,6 +82,71 @@ def test_device_output_transform_vs_oracle(ascending):
         DeviceOutputTransform().transform_output(data, ['a'] * 5, ll)
 
 
+def _spiked(rng, s1=14, s2=11, t=9):
+    """(s1, s2, t, 3) field with isolated and clustered out-of-range values
+    and a few NaNs in the temperature / humidity channels"""
+    data = np.stack([rng.uniform(-60, 60, (s1, s2, t)),
+                     rng.uniform(-150, 90, (s1, s2, t)),
+                     rng.uniform(5, 95, (s1, s2, t))], -1).astype(np.float32)
+    for ch, bad in ((1, 300.0), (1, -900.0), (2, 180.0), (2, -3.0)):
+        idx = rng.integers(0, [s1, s2, t], size=(12, 3))
+        data[idx[:, 0], idx[:, 1], idx[:, 2], ch] = bad
+    data[2:5, 3:6, 4:6, 1] = 555.0          # a cluster: nearest valid cell is 2+ away
+    data[0, 0, 0, 2] = np.nan
+    return data
+
+
+def test_oracle_nn_fill_takes_the_nearest_valid_value():
+    """enforce_limits(nn_fill=True) (utilities.py:208-215): every out-of-range
+    / NaN value is replaced by an in-range value of the same feature whose
+    index distance is minimal; in-range values are untouched"""
+    from oracle.output import enforce_limits
+    rng = np.random.default_rng(5)
+    data = _spiked(rng)
+    feats = ['u_10m', 'temperature_2m', 'relativehumidity_2m']
+    out = enforce_limits(feats, data.astype(np.float64), nn_fill=True)
+    lims = [(-120, 120), (-200, 100), (0, 100)]
+    for ch, (lo, hi) in enumerate(lims):
+        v = data[..., ch]
+        ok = (v >= lo) & (v <= hi)
+        np.testing.assert_array_equal(out[..., ch][ok], v[ok])
+        assert np.isfinite(out[..., ch]).all()
+        assert out[..., ch].min() >= lo and out[..., ch].max() <= hi
+        good = np.argwhere(ok)
+        for p in np.argwhere(~ok)[:40]:
+            d2 = ((good - p) ** 2).sum(1)
+            nearest_vals = v[tuple(good[d2 == d2.min()].T)]
+            assert out[tuple(p) + (ch,)] in nearest_vals.astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_device_nn_fill_vs_oracle():
+    """transform_output(nn_fill=True): device mask + the reference's own EDT
+    call on it + device gather = the oracle's enforce_limits(nn_fill=True),
+    bit for bit (no arithmetic is involved)"""
+    from oracle.output import transform_output
+    from sup3r_amd.output_transform import DeviceOutputTransform
+    rng = np.random.default_rng(5)
+    data = _spiked(rng, 20, 17, 24)
+    feats = ['u_10m', 'temperature_2m', 'relativehumidity_2m']
+    ll = _lat_lon(20, 17, rng)
+    ref, names_ref = transform_output(data.astype(np.float64), feats, ll, False,
+                                      nn_fill=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        out, names = DeviceOutputTransform().transform_output(
+            data, feats, ll, invert_uv=False, nn_fill=True)
+    assert names == names_ref == feats
+    assert any('nearest neighbor' in str(x.message) for x in w)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    # nothing out of range: nothing changes
+    clean = np.clip(data, [-100, -150, 5], [100, 90, 95])
+    clean[0, 0, 0, 2] = 50.0
+    out2, _ = DeviceOutputTransform().transform_output(clean, feats, ll,
+                                                       nn_fill=True)
+    np.testing.assert_array_equal(out2.cpu().numpy(), clean)
+
+
 # --- the reference's own known-answer tests for the wind rotation pair
 # (/root/reference/tests/utilities/test_utilities.py:360-452 test_transform_rotate,
 # /root/reference/tests/output/test_output_handling.py:60-91 test_invert_uv),
