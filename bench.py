@@ -183,13 +183,19 @@ def train_leg(config, global_batch, world, rank, min_seconds, max_steps,
     return out
 
 
-def c3_leg(batch, steps, warmup, world, rank):
-    """chunks/s of ``ForwardPass.run_batched`` over this rank's share of the C3
-    chunk list (domain 400x400x720, chunks 20x20x48 + halo 1 / 2), cropped
-    hi-res chunks delivered to a host callback (checksummed, not stored: the
-    whole output is 276 GB)."""
+def c3_leg(batch, steps, warmup, world, rank, entry='strategy'):
+    """chunks/s over this rank's share of the C3 chunk list (domain
+    400x400x720, chunks 20x20x48 + halo 1 / 2), cropped hi-res chunks
+    delivered to the host (checksummed, not stored: the whole output is
+    276 GB).  ``entry='strategy'``: the reference's entry — ``ForwardPassChunk``
+    structures from a strategy's ``init_chunk`` through
+    ``ForwardPass.get_input_chunk`` / ``iter_chunks`` (what ``ForwardPass.run
+    (strategy, node_index)`` executes; node = rank).  ``entry='domain'``: the
+    in-memory ``run_batched`` over a resident domain."""
     import torch
     from sup3r_amd import ChunkSlicer, ForwardPass, Sup3rGan
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
     feats = ['u_100m', 'v_100m', 'temperature_100m', 'pressure_0m']
     m = Sup3rGan(CFG, os.path.join(CFGDIR, 'test_disc_st_same.json'),
                  precision='bf16')
@@ -197,28 +203,53 @@ def c3_leg(batch, steps, warmup, world, rank):
                        s_enhance=5, t_enhance=12)
     Sup3rGan.seed(0)
     m.init_weights((1, 22, 22, 52, 4), (1, 110, 110, 624, 2))
-    slicer = ChunkSlicer((400, 400), 720, 5, 12, (20, 20, 48), spatial_pad=1,
-                         temporal_pad=2)
-    assert slicer.n_chunks == 6000
     rng = np.random.default_rng(7)
     # only the first rows of the domain are visited by the bounded run
     domain = rng.standard_normal((400, 400, 720, 4), dtype=np.float32)
-    fwp = ForwardPass(m, slicer, rank=rank, nranks=world, shard='block')
     seen = [0, 0.0]
 
     def writer(idx, hr_slice, data):
         seen[0] += 1
         seen[1] += float(data[::17, ::17, ::17].sum())
-    fwp.run_batched(domain, writer=writer, batch=batch,
-                    max_chunks=warmup * batch)
-    torch.cuda.synchronize()
-    seen[0] = 0
-    t0 = time.perf_counter()
-    n = fwp.run_batched(domain, writer=writer, batch=batch,
-                        max_chunks=steps * batch)
+    if entry == 'strategy':
+        register_model('Sup3rGan', {'model_dir': 'bench-c3'}, m)
+        st = ArrayStrategy(domain, {'model_dir': 'bench-c3'}, (20, 20, 48),
+                           spatial_pad=1, temporal_pad=2, max_nodes=world,
+                           model=m)
+        assert st.n_chunks == 6000
+        fwp = ForwardPass(st, rank)
+        mine = [int(i) for i in st.node_chunks[rank]]
+
+        def run(ids):
+            n = 0
+            for chunk, failed, data in ForwardPass.iter_chunks(
+                    (fwp.get_input_chunk(i) for i in ids), m,
+                    allowed_const=st.allowed_const, batch=batch):
+                assert not failed
+                writer(chunk.index, None, data)
+                n += 1
+            return n
+        run(mine[:warmup * batch])
+        torch.cuda.synchronize()
+        seen[0] = 0
+        t0 = time.perf_counter()
+        n = run(mine[warmup * batch:(warmup + steps) * batch])
+    else:
+        slicer = ChunkSlicer((400, 400), 720, 5, 12, (20, 20, 48),
+                             spatial_pad=1, temporal_pad=2)
+        assert slicer.n_chunks == 6000
+        fwp = ForwardPass(m, slicer, rank=rank, nranks=world, shard='block')
+        resident = fwp.upload_domain(domain)
+        fwp.run_batched(resident, writer=writer, batch=batch,
+                        max_chunks=warmup * batch)
+        torch.cuda.synchronize()
+        seen[0] = 0
+        t0 = time.perf_counter()
+        n = fwp.run_batched(resident, writer=writer, batch=batch,
+                            max_chunks=steps * batch)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    assert n == seen[0] == steps * batch
+    assert n == seen[0] == steps * batch, (n, seen[0], steps * batch)
     return n, el
 
 
@@ -491,6 +522,12 @@ def main():
     ap.add_argument('--no-traffic', action='store_true',
                     help='skip the rocprofv3 --pmc passes (roofline.traffic '
                          'is then null)')
+    ap.add_argument('--c3-entry', default='strategy',
+                    choices=['strategy', 'domain'],
+                    help="c3: 'strategy' = ForwardPassChunk structures through "
+                         "the reference's entry (get_input_chunk / "
+                         "iter_chunks); 'domain' = run_batched over a "
+                         'resident in-memory domain')
     ap.add_argument('--train-seconds', type=float, default=5.0)
     ap.add_argument('--dump-ops', default=None,
                     help='write per-op mean ms of the timed region here')
@@ -593,7 +630,8 @@ def main():
     if args.mode == 'c3':
         b = args.batch or 8
         barrier()
-        n, el = c3_leg(b, args.steps, args.warmup, world, rank)
+        n, el = c3_leg(b, args.steps, args.warmup, world, rank,
+                       entry=args.c3_entry)
         barrier()
         el = max_over_ranks(el)
         if rank == 0:
@@ -604,10 +642,15 @@ def main():
                 ms_per_step=el / args.steps * 1e3, scaling='weak',
                 dtype='bf16',
                 px_per_sec=world * n / el * 100 * 100 * 576,
-                config={'workload': 'C3: gen_5x_12x_2f through ForwardPass.'
-                                    f'run_batched, {b} chunks (22,22,52,4) per '
-                                    'launch sequence, cropped (100,100,576,2) '
-                                    'chunks delivered to a host callback',
+                config={'workload': 'C3: gen_5x_12x_2f through ' + (
+                    'ForwardPassChunk structures (ArrayStrategy.init_chunk '
+                    '-> ForwardPass.get_input_chunk -> iter_chunks, the '
+                    "reference's run(strategy, node) path)"
+                    if args.c3_entry == 'strategy' else
+                    'ForwardPass.run_batched (resident domain)')
+                    + f', {b} chunks (22,22,52,4) per '
+                    'launch sequence, cropped (100,100,576,2) '
+                    'chunks delivered to the host',
                         'parallelism': f'chunk list sharded x{world}, no '
                                        'collective'})))
         return

@@ -126,6 +126,13 @@ class GanOracle:
         self.opt = Adam(learning_rate)
         self.opt_disc = Adam(learning_rate_disc or learning_rate)
         self.n_exo = n_exo
+        # test hooks (tests/test_parity_r03.py): replacements of the two
+        # forward passes — a teacher-forced walk that leaves the DEVICE's
+        # activations in the layers' caches — and a callable run between the
+        # forward and the backward pass (installs the device's masks)
+        self.gen_forward = None
+        self.disc_forward = None
+        self.pre_backward = None
 
     def _exo_from_true(self, hi_res_true, exo_names):
         """get_hr_exo_input (abstract.py:415-436)."""
@@ -142,7 +149,7 @@ class GanOracle:
         """calc_loss + tape.gradient w.r.t. the trained network's weights.
         Returns (loss, details, grads list in keras order)."""
         exo = self._exo_from_true(hi_res_true, list(exo_names))
-        hr_gen = self.gen.forward(low_res, exo)
+        hr_gen = (self.gen_forward or self.gen.forward)(low_res, exo)
         n_exo = len(exo_names)
         if n_exo:
             gen_full = np.concatenate(
@@ -153,9 +160,11 @@ class GanOracle:
             raise RuntimeError('shape mismatch {} vs {}'.format(
                 gen_full.shape, hi_res_true.shape))
         nb = hi_res_true.shape[0]
-        d_both = self.disc.forward(
+        d_both = (self.disc_forward or self.disc.forward)(
             np.concatenate((hi_res_true, gen_full), axis=0))
         d_true, d_gen = d_both[:nb], d_both[nb:]
+        if self.pre_backward is not None:
+            self.pre_backward()
         details = {}
         if compute_disc or train_disc:
             ld, g_dt, g_dg = rel_bce(d_true, d_gen)

@@ -220,19 +220,31 @@ class HipGanCompute:
         discriminator weights (only the generator is updated in between,
         base.py:1001-1025): the second evaluation — and, in a training plan,
         its saved activations — is the first one, bit for bit, so it is
-        reused.  Keyed on the tensor's storage, torch's in-place version
-        counter, the weights' version and the plan; anything else recomputes."""
+        reused.  Only inside one ``Sup3rGan._launch_batch`` (``share_dtrue``;
+        the entry is dropped when the mini-batch ends, so a producer that
+        refills a pre-allocated hi-res tensor through raw pointers between
+        batches can never be served stale activations), and there keyed on
+        the tensor's storage, torch's in-place version counter, the weights'
+        version and the plan; anything else recomputes."""
         key = (hr_true.data_ptr(), getattr(hr_true, '_version', None),
                tuple(hr_true.shape), self.disc.weights_version, id(dph),
                bool(training))
+        share = getattr(self, 'share_dtrue', False) and \
+            not os.environ.get('SUP3R_AMD_NO_DTRUE_REUSE')
         hit = getattr(self, '_dtrue', None)
-        if hit is not None and hit[0] == key and \
-                not os.environ.get('SUP3R_AMD_NO_DTRUE_REUSE'):
+        if share and hit is not None and hit[0] == key:
             return hit[1]
         out = dph.forward(hr_true)
         # (the input tensor is kept alive so its address cannot be recycled)
-        self._dtrue = (key, out, hr_true)
+        self._dtrue = (key, out, hr_true) if share else None
         return out
+
+    def batch_scope(self, active):
+        """``True`` at the start, ``False`` at the end of one mini-batch: the
+        window inside which D(hi_res_true) may be shared between the
+        generator step and the discriminator step"""
+        self.share_dtrue = bool(active)
+        self._dtrue = None
 
     # --------------------------------------------------- loss (+ gradients)
     def loss_and_grads(self, low_res, hi_res_true, loss_terms,

@@ -18,109 +18,149 @@ MI355X design points:
   * every chunk is padded to the SAME padded shape (interior overlap +
     reflect at domain edges) so one plan serves the whole domain.
 """
+import json
 import logging
-from dataclasses import dataclass, field
+import os
 
 import numpy as np
 
+from .strategy import (ArrayStrategy, ChunkSlicer,  # noqa: F401
+                       ForwardPassChunk, chunk_slices)
+
 logger = logging.getLogger(__name__)
 
-
-def chunk_slices(size, chunk):
-    """[slice(0, chunk), slice(chunk, 2*chunk), ...] covering ``size``
-    (sup3r.pipeline.utilities.get_chunk_slices semantics, step 1)."""
-    out, start = [], 0
-    while start < size:
-        stop = min(start + chunk, size)
-        out.append(slice(start, stop))
-        start = stop
-    return out
+_MODELS = {}
 
 
-@dataclass
-class ChunkSlicer:
-    """Index algebra for tiling a lo-res domain (s1, s2, t) into generator
-    chunks with overlap, and placing the cropped hi-res output.
+def get_model(model_class, kwargs):
+    """sup3r.pipeline.utilities.get_model (utilities.py:11-24): the class by
+    name from this package, ``Model.load(**kwargs)``.  The model is loaded
+    ONCE per process and GPU (the reference re-loads it for every chunk,
+    forward_pass.py:638): the loaded object, its device weights and its
+    shape-specialised plans are cached on (class, kwargs)."""
+    import sup3r_amd
+    if isinstance(kwargs, str):
+        kwargs = {'model_dir': kwargs}
+    if _model_key(model_class, kwargs) in _MODELS:
+        return _MODELS[_model_key(model_class, kwargs)]
+    cls = getattr(sup3r_amd, str(model_class), None)
+    if cls is None or not hasattr(cls, 'load'):
+        msg = ('Could not load requested model class "{}" from '
+               'sup3r_amd, Make sure you typed in the model class '
+               'name correctly.'.format(model_class))
+        logger.error(msg)
+        raise KeyError(msg)
+    key = _model_key(model_class, kwargs)
+    if key not in _MODELS:
+        _MODELS[key] = cls.load(**kwargs, verbose=True)
+    return _MODELS[key]
 
-    For chunk ``i``: ``lr_pad_slice`` is the in-domain padded window read from
-    the source, ``pad_width`` the extra reflect padding applied at domain edges
-    so every chunk sees ``spatial_pad`` / ``temporal_pad`` cells of context on
-    all sides, ``hr_crop`` removes the enhanced padding from the generator
-    output and ``hr_slice`` is where the result lands in the hi-res domain."""
 
-    coarse_shape: tuple
-    time_steps: int
-    s_enhance: int
-    t_enhance: int
-    chunk_shape: tuple
-    spatial_pad: int = 0
-    temporal_pad: int = 0
-    chunks: list = field(default_factory=list, init=False)
+def _model_key(model_class, kwargs):
+    if isinstance(kwargs, str):
+        kwargs = {'model_dir': kwargs}
+    return (str(model_class), json.dumps(kwargs, sort_keys=True, default=str))
 
-    def __post_init__(self):
-        s1 = chunk_slices(self.coarse_shape[0], self.chunk_shape[0])
-        s2 = chunk_slices(self.coarse_shape[1], self.chunk_shape[1])
-        tt = chunk_slices(self.time_steps, self.chunk_shape[2])
-        self.n_spatial_chunks = len(s1) * len(s2)
-        self.n_time_chunks = len(tt)
-        dims = (self.coarse_shape[0], self.coarse_shape[1], self.time_steps)
-        pads = (self.spatial_pad, self.spatial_pad, self.temporal_pad)
-        enh = (self.s_enhance, self.s_enhance, self.t_enhance)
-        # chunk index = t_idx * n_spatial + (s1_idx * n_s2 + s2_idx), the
-        # ordering of ForwardPassSlicer.chunk_lookup (slicer.py:473-483)
-        for t_sl in tt:
-            for a in s1:
-                for b in s2:
-                    lr = (a, b, t_sl)
-                    lr_pad, pad_width, hr_crop, hr_slice = [], [], [], []
-                    for sl, n, p, e in zip(lr, dims, pads, enh):
-                        start, stop = max(0, sl.start - p), min(n, sl.stop + p)
-                        lr_pad.append(slice(start, stop))
-                        lo = max(0, p - sl.start)
-                        hi = max(0, sl.stop + p - n)
-                        pad_width.append((lo, hi))
-                        hr_crop.append(slice(
-                            p * e, p * e + (sl.stop - sl.start) * e))
-                        hr_slice.append(slice(sl.start * e, sl.stop * e))
-                    self.chunks.append(dict(
-                        lr_slice=lr, lr_pad_slice=tuple(lr_pad),
-                        pad_width=tuple(pad_width), hr_crop=tuple(hr_crop),
-                        hr_slice=tuple(hr_slice)))
 
-    @property
-    def n_chunks(self):
-        return len(self.chunks)
+def register_model(model_class, kwargs, model):
+    """Make an already loaded / freshly trained model the one ``get_model``
+    returns for (model_class, kwargs) in this process."""
+    _MODELS[_model_key(model_class, kwargs)] = model
+    return model
 
-    @property
-    def hr_shape(self):
-        return (self.coarse_shape[0] * self.s_enhance,
-                self.coarse_shape[1] * self.s_enhance,
-                self.time_steps * self.t_enhance)
 
-    def get_chunk_indices(self, chunk_index):
-        return (chunk_index % self.n_spatial_chunks,
-                chunk_index // self.n_spatial_chunks)
+def get_source_type(file_paths):
+    """'h5' | 'nc' | 'npz' | None from a path (or the first of a list), the
+    role of sup3r.preprocessing.utilities.get_source_type"""
+    if file_paths is None:
+        return None
+    if isinstance(file_paths, (list, tuple)):
+        file_paths = file_paths[0]
+    ext = os.path.splitext(str(file_paths))[1].lower()
+    if ext == '.h5':
+        return 'h5'
+    if ext == '.npz':
+        return 'npz'
+    return 'nc'
 
-    def rank_chunks(self, rank, nranks, mode='interleave'):
-        """Chunk ids of one rank.  'interleave' balances ragged edge chunks;
-        'block' mirrors ForwardPassStrategy.node_chunks (np.array_split,
-        strategy.py:363-372)."""
-        ids = np.arange(self.n_chunks)
-        if mode == 'block':
-            return list(np.array_split(ids, nranks)[rank])
-        return list(ids[rank::nranks])
+
+class NpzOutputHandler:
+    """Minimal chunk writer with the ``_write_output`` call of sup3r's
+    ``OutputHandlerH5`` / ``OutputHandlerNC`` (sup3r/writers/base.py): the
+    H5 / NetCDF writers themselves are out of scope (SURVEY.md §2 #18, h5py
+    is not in this image).  ``data`` arrives already transformed by
+    ``DeviceOutputTransform`` (u/v inversion, limits) on the device."""
+
+    @classmethod
+    def _write_output(cls, data, features, lat_lon, times, out_file,
+                      meta_data=None, invert_uv=False, nn_fill=False,
+                      max_workers=None, gids=None):
+        tmp = out_file + '.tmp.npz'
+        np.savez(tmp, data=np.asarray(data), features=np.array(features),
+                 lat_lon=np.zeros(0) if lat_lon is None else
+                 np.asarray(lat_lon),
+                 times=np.zeros(0) if times is None else
+                 np.asarray(times).astype('int64'),
+                 gids=np.zeros(0) if gids is None else np.asarray(gids),
+                 meta=json.dumps(meta_data or {}, default=str))
+        os.replace(tmp, out_file)
+
+
+class ResidentDomain:
+    """A lo-res domain uploaded once (NaN-checked, reflect-padded by the
+    slicer's halo, normalised with the model's statistics at upload time):
+    the explicit handle ``ForwardPass.upload_domain`` returns and
+    ``run_batched`` accepts in place of the array.  Nothing is cached behind
+    the caller's back — a new or modified array needs a new upload."""
+
+    def __init__(self, tensor, shape, stats_key):
+        self.tensor, self.shape, self.stats_key = tensor, tuple(shape), \
+            stats_key
 
 
 class ForwardPass:
-    """Run a generator over the chunks of an in-memory lo-res domain."""
+    """Per-chunk executor of the generator.
 
-    def __init__(self, model, slicer, rank=0, nranks=1, shard='interleave',
-                 output_check=True, allowed_const=False):
-        """``allowed_const`` (ForwardPassStrategy.allowed_const,
+    Two faces.  The reference's (``sup3r.pipeline.forward_pass.ForwardPass``):
+    ``ForwardPass(strategy, node_index)``, ``ForwardPass.run(strategy,
+    node_index)``, ``fwp.get_input_chunk(chunk_index)`` and the classmethod
+    ``run_chunk(chunk, model_kwargs, model_class, allowed_const, invert_uv,
+    meta, nn_fill, output_workers)`` over ``ForwardPassChunk`` structures
+    (exo data included) — ``strategy`` is duck-typed (``init_chunk``,
+    ``node_chunks``, ``chunk_finished``, ``model_kwargs``, ...), so sup3r's
+    ``ForwardPassStrategy`` or ``strategy.ArrayStrategy`` both drive it.  And
+    the in-memory one: ``ForwardPass(model, slicer)`` with ``run_domain`` /
+    ``run_batched`` over a lo-res array resident on the device."""
+
+    OUTPUT_HANDLER_CLASS = {'npz': NpzOutputHandler}
+
+    def __init__(self, model, slicer=0, rank=0, nranks=1, shard='interleave',
+                 output_check=True, allowed_const=False, node_index=None):
+        """``ForwardPass(strategy, node_index=0)`` (forward_pass.py:44-64) or
+        ``ForwardPass(model, slicer, rank, nranks, ...)``.
+
+        ``allowed_const`` (ForwardPassStrategy.allowed_const,
         strategy.py:186-196): False = a constant output channel fails the
         chunk, True = any constant is fine, a value / list = only these
         constants are (0 for night-time clearsky ratio).  ``output_check=False``
         switches the whole check off."""
+        self.strategy = None
+        if hasattr(model, 'init_chunk'):
+            strategy = model
+            self.strategy = strategy
+            self.node_index = int(slicer if node_index is None
+                                  else node_index)
+            model = get_model(strategy.model_class, strategy.model_kwargs)
+            slicer = strategy.fwp_slicer
+            allowed_const = getattr(strategy, 'allowed_const', allowed_const)
+            rank, nranks = self.node_index, len(strategy.node_chunks)
+            shard = 'block'
+            output_type = get_source_type(
+                getattr(strategy, 'out_pattern', None))
+            assert output_type is None or \
+                output_type in self.OUTPUT_HANDLER_CLASS or \
+                output_type in ('h5', 'nc'), \
+                f'Received bad output type {output_type}'
         self.model = model
         self.slicer = slicer
         self.rank, self.nranks = rank, nranks
@@ -133,6 +173,45 @@ class ForwardPass:
                 'model enhancement ({}, {}) does not match the slicer ({}, {})'
                 .format(model.s_enhance, model.t_enhance, slicer.s_enhance,
                         slicer.t_enhance))
+
+    @property
+    def meta(self):
+        """forward_pass.py:74-86: what goes into the output files' attrs"""
+        import datetime
+        return {'node_index': getattr(self, 'node_index', self.rank),
+                'creation_date': datetime.datetime.now().strftime(
+                    '%d/%m/%Y %H:%M:%S'),
+                'model_meta': self.model.meta,
+                'gan_params': self.model.model_params,
+                'strategy_meta': getattr(self.strategy, 'meta', {})}
+
+    def _get_step_enhance(self, step):
+        """forward_pass.py:88-120: enhancement of an exo step's field
+        relative to the lo-res input."""
+        combine_type, model_step = step['combine_type'], step['model']
+        assert combine_type.lower() in ('input', 'output', 'layer'), \
+            f'Received weird combine_type {combine_type} for step: {step}'
+        s_all = list(getattr(self.model, 's_enhancements',
+                             [self.model.s_enhance]))
+        t_all = list(getattr(self.model, 't_enhancements',
+                             [self.model.t_enhance]))
+        n = model_step if combine_type.lower() == 'input' else model_step + 1
+        return (int(np.prod(s_all[:n], dtype=np.int64)),
+                int(np.prod(t_all[:n], dtype=np.int64)))
+
+    def get_input_chunk(self, chunk_index=0, mode='reflect'):
+        """forward_pass.py:66-72: ``strategy.init_chunk`` + edge padding of
+        the lo-res window and of its exo fields."""
+        chunk = self.strategy.init_chunk(chunk_index)
+        enh = None
+        if chunk.exo_data is not None:
+            enh = {f: [self._get_step_enhance(st)
+                       for st in chunk.exo_data[f]['steps']]
+                   for f in chunk.exo_data}
+        chunk.input_data, chunk.exo_data = self.pad_source_data(
+            chunk.input_data, chunk.pad_width, chunk.exo_data, mode=mode,
+            enhancements=enh)
+        return chunk
 
     # -- reference-compatible helpers ------------------------------------
     @staticmethod
@@ -216,8 +295,8 @@ class ForwardPass:
         return False, (allowed_const,)
 
     @classmethod
-    def _output_check(cls, out_data, features=None, chunk_index=None,
-                      allowed_const=False):
+    def _output_check(cls, out_data, allowed_const=False, features=None,
+                      chunk_index=None):
         """forward_pass.py:384-425: NaNs, or an output channel that is one
         constant not listed in ``allowed_const``, mean the chunk failed."""
         skip, allowed = cls._const_ok(allowed_const)
@@ -245,9 +324,9 @@ class ForwardPass:
             data, _ = self.pad_source_data(data, c['pad_width'])
         return data
 
-    def run_chunk(self, domain, chunk_index):
-        """One chunk: pad -> NaN check -> generate -> enhancement check ->
-        crop (-> output check)."""
+    def run_domain_chunk(self, domain, chunk_index):
+        """One chunk of an in-memory domain: pad -> NaN check -> generate ->
+        enhancement check -> crop (-> output check)."""
         c = self.slicer.chunks[chunk_index]
         data = self.chunk_input(domain, chunk_index)
         if np.isnan(data).any():
@@ -257,14 +336,42 @@ class ForwardPass:
                                  s_enhance=self.slicer.s_enhance,
                                  t_enhance=self.slicer.t_enhance)
         if self.output_check and self._output_check(
-                out, self.model.hr_out_features, chunk_index,
-                allowed_const=self.allowed_const):
+                out, self.allowed_const, self.model.hr_out_features,
+                chunk_index):
             raise MemoryError(
                 f'Forward pass output check failed on chunk {chunk_index}')
         return out
 
     def my_chunks(self):
         return self.slicer.rank_chunks(self.rank, self.nranks, self.shard)
+
+    def _stats_key(self):
+        m = self.model
+        if getattr(m, 'means', None) is None:
+            return None
+        mu, sd = m._stats_for(m.lr_features)
+        return (tuple(m.lr_features), mu.tobytes(), sd.tobytes())
+
+    def upload_domain(self, domain):
+        """NaN-check, reflect-pad by the slicer's halo, normalise and upload
+        a lo-res ``(s1, s2, t, features)`` domain once; every chunk's padded
+        input is then a plain window of the resident tensor (a chunk's edge
+        padding mirrors the same cells the domain padding mirrors)."""
+        sl, model = self.slicer, self.model
+        ps, pt = sl.spatial_pad, sl.temporal_pad
+        domain = np.asarray(domain)
+        if np.isnan(domain).any():
+            for idx in self.my_chunks():
+                if np.isnan(domain[sl.chunks[idx]['lr_pad_slice']]).any():
+                    raise ValueError(f'Forward pass chunk {idx} input '
+                                     'data has NaN values')
+        padded = np.pad(np.asarray(domain, dtype=np.float32),
+                        ((ps, ps), (ps, ps), (pt, pt), (0, 0)),
+                        mode='reflect')
+        if model.means is not None:
+            padded = np.asarray(model.norm_input(padded), dtype=np.float32)
+        return ResidentDomain(model._gen.dev.to_device(padded), domain.shape,
+                              self._stats_key())
 
     # -- MI355X-native executor ---------------------------------------------
     def run_batched(self, domain, out=None, writer=None, batch=8,
@@ -294,8 +401,10 @@ class ForwardPass:
           slower on this platform (4.6 KB rows: 9 GB/s), kept as an option.
 
         ``max_chunks`` bounds the run to the first chunks of this rank's list
-        (benchmarks); the uploaded domain stays resident between calls on the
-        same array.
+        (benchmarks).  ``domain`` is the lo-res array — checked, padded,
+        normalised and uploaded by this call — or the ``ResidentDomain`` of an
+        earlier :meth:`upload_domain` (repeated runs over one domain);
+        residency is never implicit.
 
         Supports single-step 5-D models without exogenous inputs; anything
         else falls back to :meth:`run`."""
@@ -319,25 +428,14 @@ class ForwardPass:
         if not ids:
             return 0
         ps, pt = sl.spatial_pad, sl.temporal_pad
-        key = (id(domain), tuple(domain.shape))
-        cached = getattr(self, '_resident', None)
-        if cached is not None and cached[0] == key:
-            dom_d = cached[1]
+        if isinstance(domain, ResidentDomain):
+            if domain.stats_key != self._stats_key():
+                raise RuntimeError(
+                    'the resident domain was normalised with other statistics '
+                    'than the model holds now; upload it again')
+            dom_d = domain.tensor
         else:
-            if np.isnan(domain).any():
-                for idx in self.my_chunks():
-                    if np.isnan(domain[sl.chunks[idx]['lr_pad_slice']]).any():
-                        raise ValueError(f'Forward pass chunk {idx} input '
-                                         'data has NaN values')
-            padded = np.pad(np.asarray(domain, dtype=np.float32),
-                            ((ps, ps), (ps, ps), (pt, pt), (0, 0)),
-                            mode='reflect')
-            if model.means is not None:
-                padded = np.asarray(model.norm_input(padded),
-                                    dtype=np.float32)
-            dom_d = dev.to_device(padded)
-            del padded
-            self._resident = (key, dom_d)
+            dom_d = self.upload_domain(domain).tensor
         n_in = int(dom_d.shape[-1])
         n_out = len(model.hr_out_features)
         if model.means is not None:
@@ -530,14 +628,369 @@ class ForwardPass:
                 L.s3_host_unregister(dev.ctx, C.c_void_p(out.ctypes.data))
         return done
 
+    # -- the reference's entry points over ForwardPassChunk structures -----
+    @classmethod
+    def _device_path(cls, model, chunk):
+        """single-step 5-D generator on this package's engine, no exo field
+        combined at the output: the chunk batches go through one plan on the
+        device; anything else (4-D models, ``MultiStepGan``, 'output' exo)
+        takes ``run_generator`` -> ``model.generate`` chunk by chunk"""
+        if getattr(model, '_gen', None) is None or \
+                not getattr(model, 'is_5d', False) or \
+                not getattr(model, 'supports_device_chunks', False):
+            return False
+        for entry in (chunk.exo_data or {}).values():
+            if any(st['combine_type'].lower() == 'output'
+                   for st in entry['steps']):
+                return False
+        return True
+
+    @classmethod
+    def _crop_bounds(cls, crop, shape):
+        """hr_crop_slice (None / negative stops, slicer.py:216-293) as
+        (start, stop) per axis of a tensor of ``shape``"""
+        out = []
+        for s_, n in zip(crop, shape):
+            a, b, _ = s_.indices(n)
+            out.append((a, b))
+        return out
+
+    @classmethod
+    def iter_chunks(cls, chunks, model, allowed_const=False, batch=8,
+                    invert_uv=False, nn_fill=True, meta=None,
+                    output_workers=None, return_data=True, write=True):
+        """Run ``ForwardPassChunk`` structures (already edge-padded:
+        ``get_input_chunk``) through the generator, ``batch`` equal-shaped
+        chunks per launch sequence, and yield ``(chunk, failed, output_data)``
+        in input order.
+
+        Per batch: the chunks' lo-res windows (+ 'input' exo channels) are
+        normalised and stacked on the host (75 KB each), their 'layer' exo
+        fields (topography ...) are normalised, stacked and uploaded next to
+        them, one plan forward runs the batch; un-normalisation, the halo crop
+        (``chunk.hr_crop_slice``), the output check (NaN / constant channel,
+        forward_pass.py:384-425) run on the device; the cropped hi-res window
+        crosses PCIe through pinned buffers on a copy stream while the next
+        batch computes.  With ``write`` and a chunk's ``out_file`` set, the
+        output epilogue (u/v inversion, limits: ``DeviceOutputTransform``)
+        runs on the device and the registered ``OUTPUT_HANDLER_CLASS`` entry
+        writes the result.  ``return_data=False`` skips the raw download when
+        only the files are wanted (``run``)."""
+        import collections
+
+        pending = collections.deque()
+
+        def flush(keep):
+            while len(pending) > keep:
+                yield from pending.popleft()()
+
+        group, shape = [], None
+        for chunk in chunks:
+            if not cls._device_path(model, chunk):
+                yield from flush(0)
+                if group:
+                    pending.append(cls._launch_chunk_batch(
+                        group, model, allowed_const, invert_uv, nn_fill, meta,
+                        output_workers, return_data, write))
+                    group, shape = [], None
+                    yield from flush(0)
+                yield cls._run_chunk_host(chunk, model, allowed_const,
+                                          invert_uv, nn_fill, meta,
+                                          output_workers, write)
+                continue
+            key = (tuple(chunk.input_data.shape),
+                   tuple((f, tuple(tuple(st['data'].shape)
+                                   for st in e['steps']))
+                         for f, e in sorted((chunk.exo_data or {}).items())),
+                   tuple((s_.start, s_.stop) for s_ in chunk.hr_crop_slice))
+            if group and (key != shape or len(group) >= batch):
+                pending.append(cls._launch_chunk_batch(
+                    group, model, allowed_const, invert_uv, nn_fill, meta,
+                    output_workers, return_data, write))
+                group = []
+                yield from flush(1)
+            group.append(chunk)
+            shape = key
+        if group:
+            pending.append(cls._launch_chunk_batch(
+                group, model, allowed_const, invert_uv, nn_fill, meta,
+                output_workers, return_data, write))
+        yield from flush(0)
+
+    @classmethod
+    def _run_chunk_host(cls, chunk, model, allowed_const, invert_uv, nn_fill,
+                        meta, output_workers, write):
+        """forward_pass.py:640-672 through ``model.generate``"""
+        output_data = cls.run_generator(
+            data_chunk=chunk.input_data, hr_crop_slices=chunk.hr_crop_slice,
+            s_enhance=model.s_enhance, t_enhance=model.t_enhance,
+            exo_data=chunk.exo_data, model=model)
+        failed = cls._output_check(output_data, allowed_const=allowed_const)
+        if write and chunk.out_file is not None and not failed:
+            cls._write_chunk(chunk, model, output_data, invert_uv, nn_fill,
+                             meta, output_workers)
+        return chunk, failed, output_data
+
+    @classmethod
+    def _write_chunk(cls, chunk, model, data, invert_uv, nn_fill, meta,
+                     output_workers):
+        """the output epilogue on the device (writers/base.py:304-345), then
+        the registered writer for the file type"""
+        from .output_transform import DeviceOutputTransform
+        logger.info(f'Saving forward pass output to {chunk.out_file}.')
+        features = [f.lower() for f in model.hr_out_features]
+        tr = DeviceOutputTransform(model._gen.dev if getattr(
+            model, '_gen', None) is not None else None)
+        x, features = tr.transform_output(
+            data, features, chunk.hr_lat_lon, invert_uv=invert_uv,
+            nn_fill=nn_fill)
+        output_type = get_source_type(chunk.out_file)
+        handler = cls.OUTPUT_HANDLER_CLASS.get(output_type)
+        if handler is None:
+            raise KeyError(
+                f'no output handler registered for "{output_type}" files '
+                f'({chunk.out_file}): the H5 / NetCDF writers live in sup3r '
+                '(sup3r.writers.OutputHandlerH5 / OutputHandlerNC); register '
+                'one in ForwardPass.OUTPUT_HANDLER_CLASS')
+        # (already transformed: the handler must not invert / fill again)
+        handler._write_output(
+            data=x.cpu().numpy(), features=features,
+            lat_lon=chunk.hr_lat_lon, times=chunk.hr_times,
+            out_file=chunk.out_file, meta_data=meta, invert_uv=False,
+            nn_fill=False, max_workers=output_workers, gids=chunk.gids)
+
+    @classmethod
+    def _launch_chunk_batch(cls, group, model, allowed_const, invert_uv,
+                            nn_fill, meta, output_workers, return_data,
+                            write):
+        """Enqueue one batch of equal-shaped chunks; returns the closure that
+        waits for it and yields its ``(chunk, failed, output_data)``."""
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+        from .utilities import ExoData
+        gen = model._gen
+        dev, L = gen.dev, _lib.lib()
+        n = len(group)
+        xs, exos = [], []
+        for chunk in group:
+            mask = np.isnan(chunk.input_data).any(axis=(0, 1, 2))
+            if np.any(mask):
+                feats = np.array(model.lr_features[:len(mask)])[mask]
+                msg = f'Input data for {feats} contains NaN values!'
+                logger.error(msg)
+                raise RuntimeError(msg)
+            exo = chunk.exo_data
+            if exo is not None and not isinstance(exo, ExoData):
+                exo = ExoData(exo)
+            exos.append(exo)
+            x = model._combine_fwp_input(
+                np.asarray(chunk.input_data)[None], cls._batch_axis(exo))
+            xs.append(np.asarray(model.norm_input(x), dtype=np.float32))
+        x = np.concatenate(xs, axis=0) if n > 1 else xs[0]
+        try:
+            ph = gen.plan(x.shape, training=False)
+            layer_exo = {}
+            for name in ph.input_names:
+                if name == 'x':
+                    continue
+                sh = list(ph.in_shapes[name])
+                parts = []
+                for exo in exos:
+                    assert exo is not None and name in exo, \
+                        f'the generator needs exogenous feature "{name}"'
+                    arr = model._reshape_norm_exo(
+                        tuple([1] + sh[1:]),
+                        np.asarray(exo.get_combine_type_data(
+                            name, 'layer'))[None], name)
+                    parts.append(arr.astype(np.float32, copy=False))
+                layer_exo[name] = dev.to_device(
+                    np.concatenate(parts, axis=0) if n > 1 else parts[0])
+            y = ph.forward(dev.to_device(x), layer_exo)
+        except AssertionError:
+            raise
+        except Exception as e:
+            msg = 'Forward pass failed on chunk with shape {}.'.format(
+                x.shape)
+            logger.exception(msg)
+            raise RuntimeError(msg) from e
+        if model.s_enhance * x.shape[1] != y.shape[1]:
+            msg = ('The stated spatial enhancement of {}x did not match the '
+                   'low res / high res shapes of {} -> {}'.format(
+                       model.s_enhance, x.shape, tuple(y.shape)))
+            logger.error(msg)
+            raise RuntimeError(msg)
+        if model.t_enhance * x.shape[3] != y.shape[3]:
+            msg = ('The stated temporal enhancement of {}x did not match the '
+                   'low res / high res shapes of {} -> {}'.format(
+                       model.t_enhance, x.shape, tuple(y.shape)))
+            logger.error(msg)
+            raise RuntimeError(msg)
+        n_out = int(y.shape[-1])
+        pf = C.POINTER(C.c_float)
+        if model.means is not None:
+            mu, sd = model._stats_for(model.hr_out_features)
+            scale = np.ascontiguousarray(sd, dtype=np.float32)
+            shift = np.ascontiguousarray(mu, dtype=np.float32)
+            rc = L.s3_affine_channels(
+                dev.ctx, C.c_void_p(y.data_ptr()), C.c_void_p(y.data_ptr()),
+                n_out, y.numel() // n_out, scale.ctypes.data_as(pf),
+                shift.ctypes.data_as(pf))
+            _lib.check(rc, dev.ctx, 's3_affine_channels')
+        y1, y2, y3 = (int(v) for v in y.shape[1:4])
+        cr = cls._crop_bounds(group[0].hr_crop_slice, (y1, y2, y3))
+        c1, c2, c3 = (b - a for a, b in cr)
+        yc = dev.empty((n, c1, c2, c3, n_out))
+        for k in range(n):
+            src = y[k].data_ptr() + 4 * n_out * (
+                (cr[0][0] * y2 + cr[1][0]) * y3 + cr[2][0])
+            rc = L.s3_copy_block(
+                dev.ctx, C.c_void_p(src), C.c_void_p(yc[k].data_ptr()), c1,
+                c2, c3 * n_out, y2 * y3 * n_out, y3 * n_out, c2 * c3 * n_out,
+                c3 * n_out)
+            _lib.check(rc, dev.ctx, 's3_copy_block')
+        del y
+        stats_d = dev.empty((n, 64, n_out, 3))
+        rc = L.s3_chunk_stats(dev.ctx, C.c_void_p(yc.data_ptr()), n,
+                              yc.numel() // (n * n_out), n_out,
+                              C.c_void_p(stats_d.data_ptr()))
+        _lib.check(rc, dev.ctx, 's3_chunk_stats')
+        copy_stream = cls._copy_stream(dev)
+        stats_h = torch.empty(tuple(stats_d.shape), dtype=torch.float32,
+                              pin_memory=True)
+        host = torch.empty(tuple(yc.shape), dtype=torch.float32,
+                           pin_memory=True) if return_data else None
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ready)
+            stats_h.copy_(stats_d, non_blocking=True)
+            if host is not None:
+                host.copy_(yc, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        yc.record_stream(copy_stream)
+        stats_d.record_stream(copy_stream)
+
+        def finish():
+            ev.synchronize()
+            st = stats_h.numpy().reshape(n, 64, n_out, 3)
+            mn, mx = st[..., 0].min(1), st[..., 1].max(1)
+            nn = st[..., 2].sum(1)
+            skip, allowed = cls._const_ok(allowed_const)
+            for k, chunk in enumerate(group):
+                failed = False
+                if not skip:
+                    if nn[k].any():
+                        logger.error('Forward pass output contains NaN '
+                                     'values!')
+                        failed = True
+                    else:
+                        for i in range(n_out):
+                            if mn[k, i] == mx[k, i] and \
+                                    mn[k, i] not in allowed:
+                                logger.error('All values are the same for '
+                                             f'feature channel {i}!')
+                                failed = True
+                                break
+                if write and chunk.out_file is not None and not failed:
+                    cls._write_chunk(chunk, model, yc[k], invert_uv, nn_fill,
+                                     meta, output_workers)
+                # (a view of this batch's own pinned buffer, alive as long as
+                # the caller keeps the array: no extra host copy of 46 MB)
+                yield (chunk, failed,
+                       host[k].numpy() if host is not None else None)
+        return finish
+
+    @staticmethod
+    def _batch_axis(exo):
+        """the exo structure of ONE chunk with a leading batch axis on every
+        field (``_reshape_data_chunk`` for 5-D models, forward_pass.py:
+        303-337), without touching the caller's arrays"""
+        if exo is None:
+            return None
+        from .utilities import ExoData
+        return ExoData({f: {'steps': [dict(st, data=np.asarray(st['data'])[
+            None]) for st in e['steps']]} for f, e in exo.items()})
+
+    _copy_streams = {}
+
+    @classmethod
+    def _copy_stream(cls, dev):
+        import torch
+        if dev.index not in cls._copy_streams:
+            cls._copy_streams[dev.index] = torch.cuda.Stream(
+                device=dev.torch_device)
+        return cls._copy_streams[dev.index]
+
+    @classmethod
+    def run_chunk(cls, chunk, model_kwargs, model_class, allowed_const,
+                  invert_uv=False, meta=None, nn_fill=True,
+                  output_workers=None):
+        """Run a forward pass on a single spatiotemporal chunk
+        (forward_pass.py:582-673): same arguments, same return value
+        ``(failed, output_data)`` — ``output_data`` the cropped, un-normalised
+        hi-res array ``(s1, s2, t, features)``; when ``chunk.out_file`` is set
+        and the chunk did not fail the (device-)transformed output is written
+        through ``OUTPUT_HANDLER_CLASS``.  The model is loaded once per
+        process (``get_model``), not per chunk."""
+        logger.info(f'Running forward pass for chunk_index={chunk.index}.')
+        model = get_model(model_class, model_kwargs)
+        (_, failed, output_data), = cls.iter_chunks(
+            [chunk], model, allowed_const=allowed_const, batch=1,
+            invert_uv=invert_uv, nn_fill=nn_fill, meta=meta,
+            output_workers=output_workers)
+        return failed, output_data
+
+    @classmethod
+    def run(cls, strategy, node_index, batch=8, return_data=False):
+        """Forward passes on all chunks of one node (forward_pass.py:427-449,
+        ``_run_serial`` :451-500) — one node = one process = one GPU; the
+        node's chunks are the rank's share of the data-parallel work, there
+        is no collective.  Chunks are stacked ``batch`` at a time on the
+        device (``iter_chunks``).  Raises ``MemoryError`` on a failed chunk
+        like the reference.  Returns the number of chunks run (and, with
+        ``return_data``, the list of ``(chunk_index, output_data)``)."""
+        if strategy.node_finished(node_index):
+            return (0, []) if return_data else 0
+        fwp = cls(strategy, node_index=node_index)
+        todo = [int(i) for i in strategy.node_chunks[node_index]
+                if not strategy.chunk_finished(int(i))]
+
+        def chunks():
+            for i in todo:
+                yield fwp.get_input_chunk(chunk_index=i)
+        done, kept = 0, []
+        meta = fwp.meta
+        for chunk, failed, data in cls.iter_chunks(
+                chunks(), fwp.model, allowed_const=strategy.allowed_const,
+                batch=batch, invert_uv=getattr(strategy, 'invert_uv', False),
+                nn_fill=getattr(strategy, 'nn_fill', True), meta=meta,
+                output_workers=getattr(strategy, 'output_workers', None),
+                return_data=return_data):
+            if failed:
+                raise MemoryError(
+                    f'Forward pass for chunk_index {chunk.index} failed '
+                    'with constant output or NaNs.')
+            if hasattr(strategy, 'mark_finished'):
+                strategy.mark_finished(chunk.index)
+            if return_data:
+                kept.append((chunk.index, data))
+            done += 1
+        logger.info('Finished forward passes on %d chunks', done)
+        return (done, kept) if return_data else done
+
+    _run_serial = run
+
     def run_chunks(self, domain, out=None, writer=None):
-        """The reference-shaped loop (``ForwardPass._run_serial``,
-        forward_pass.py:451-500): one ``run_chunk`` → ``model.generate`` per
-        chunk through host numpy.  Works for every model (exogenous inputs,
+        """The chunk-by-chunk loop over an in-memory domain: one
+        ``model.generate`` per chunk through host numpy.  Works for every model (exogenous inputs,
         4-D and multi-step models); host-bound at ~10 chunks/s."""
         done = 0
         for idx in self.my_chunks():
-            hr = self.run_chunk(domain, idx)
+            hr = self.run_domain_chunk(domain, idx)
             sl = self.slicer.chunks[idx]['hr_slice']
             if writer is not None:
                 writer(idx, sl, hr)
@@ -546,7 +999,7 @@ class ForwardPass:
             done += 1
         return done
 
-    def run(self, domain, out=None, writer=None, batch=8):
+    def run_domain(self, domain, out=None, writer=None, batch=8):
         """Process this rank's chunks of ``domain`` (s1, s2, t, features) —
         what ``ForwardPass.run`` (forward_pass.py:427-449) is to a strategy.
 

@@ -61,6 +61,10 @@ class Sup3rGan:
     # tests may install another factory with the same interface; the product
     # default is the HIP engine and nothing else
     _compute_factory = HipGanCompute
+    # ``generate`` is the plain normalise -> plan -> un-normalise composition:
+    # ``ForwardPass.iter_chunks`` may stack chunks and run the plan itself
+    # (subclasses that change ``generate`` switch this off)
+    supports_device_chunks = True
 
     def __init__(self, gen_layers, disc_layers, loss='MeanSquaredError',
                  optimizer=None, learning_rate=1e-4, optimizer_disc=None,
@@ -789,18 +793,26 @@ class Sup3rGan:
         # one upload per mini-batch: both steps read the same device tensors
         # (and the discriminator's pass over the true field is shared)
         batch = self._resident(batch)
-        if do_gen:
-            steps.append(self.run_gradient_descent(
-                batch.low_res, batch.high_res, None, optimizer=self.optimizer,
-                weight_gen_advers=weight_gen_advers, train_gen=True,
-                train_disc=False, compute_disc=train_disc,
-                multi_gpu=multi_gpu, defer=True))
-        if do_disc:
-            steps.append(self.run_gradient_descent(
-                batch.low_res, batch.high_res, None,
-                optimizer=self.optimizer_disc,
-                weight_gen_advers=weight_gen_advers, train_gen=False,
-                train_disc=True, multi_gpu=multi_gpu, defer=True))
+        scope = getattr(self._compute, 'batch_scope', None)
+        if scope is not None:
+            scope(True)
+        try:
+            if do_gen:
+                steps.append(self.run_gradient_descent(
+                    batch.low_res, batch.high_res, None,
+                    optimizer=self.optimizer,
+                    weight_gen_advers=weight_gen_advers, train_gen=True,
+                    train_disc=False, compute_disc=train_disc,
+                    multi_gpu=multi_gpu, defer=True))
+            if do_disc:
+                steps.append(self.run_gradient_descent(
+                    batch.low_res, batch.high_res, None,
+                    optimizer=self.optimizer_disc,
+                    weight_gen_advers=weight_gen_advers, train_gen=False,
+                    train_disc=True, multi_gpu=multi_gpu, defer=True))
+        finally:
+            if scope is not None:
+                scope(False)
         return steps, do_gen, do_disc
 
     def _resident(self, batch):

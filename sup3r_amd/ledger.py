@@ -78,10 +78,14 @@ class LossWindow:
     # ---- views
     def means(self):
         out = {}
+        # pandas ``mean`` semantics (skipna): only NaN is dropped — a
+        # diverged batch (inf) stays visible in the running mean that drives
+        # the train / skip gating (base.py:1161-1164)
         for k, ring in self._rows.items():
-            vals = ring[np.isfinite(ring)]
+            vals = ring[~np.isnan(ring)]
             if len(vals):
-                out[k] = float(vals.mean())
+                with np.errstate(invalid='ignore'):
+                    out[k] = float(vals.mean())
         return out
 
     def last(self, key, default=None):

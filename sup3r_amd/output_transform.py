@@ -140,7 +140,12 @@ class DeviceOutputTransform:
                           else 'clipping.'))
                 logger.warning(msg)
                 warn(msg)
-            if nn_fill and (bad or not np.isfinite([f_min, f_max]).all()):
+            # NaNs are excluded from the device extrema (counted in slot 2):
+            # the reference fills them whatever the range (utilities.py:
+            # 208-215 -> nn_fill_array)
+            n_nan = float(sth[:, i, 2].sum())
+            if nn_fill and (bad or n_nan > 0
+                            or not np.isfinite([f_min, f_max]).all()):
                 self._nn_fill_channel(x, i, float(lo[i]), float(hi[i]))
         if nn_fill:
             return x, features

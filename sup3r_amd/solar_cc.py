@@ -294,6 +294,8 @@ class SolarCC(Sup3rGan):
                      hi_res.shape)
         return hi_res
 
+    supports_device_chunks = False     # generate() is overridden below
+
     def generate(self, low_res, **kwargs):
         hi_res = self.temporal_pad(
             low_res, super().generate(low_res=low_res, **kwargs))

@@ -366,6 +366,13 @@ def build_plan(layers, in_shape, param_table=None, fuse=True):
                     raise KeyError(f'{cls} with padding != valid has no '
                                    'kernel mapping')
                 if any(v != 1 for v in s):
+                    if any(k[d] < s[d] for d in range(3)):
+                        # keras 'valid' gives in * s + max(k - s, 0) cells,
+                        # the zero-insertion lowering (in - 1) * s + k: they
+                        # agree only for k >= s
+                        raise KeyError(
+                            f'{cls} with kernel_size {k[:cnd]} < strides '
+                            f'{s[:cnd]} has no kernel mapping')
                     # strided transpose: y[i s + k] += x[i] w[k] is the
                     # stride-1 transpose of x with s - 1 zeros inserted
                     # between its cells (the padding before it is real data

@@ -76,13 +76,13 @@ def test_chunked_equals_unchunked():
     s = ChunkSlicer((20, 17), 25, 2, 3, (8, 8, 10), spatial_pad=1,
                     temporal_pad=1)
     out = np.zeros(s.hr_shape + (2,))
-    n = ForwardPass(model, s).run(domain, out=out)
+    n = ForwardPass(model, s).run_domain(domain, out=out)
     assert n == s.n_chunks
     np.testing.assert_allclose(out, full, atol=1e-12)
     # single chunk == direct generate (test_fwp_nochunking)
     s1 = ChunkSlicer((20, 17), 25, 2, 3, (20, 17, 25))
     out1 = np.zeros(s1.hr_shape + (2,))
-    ForwardPass(model, s1).run(domain, out=out1)
+    ForwardPass(model, s1).run_domain(domain, out=out1)
     np.testing.assert_array_equal(out1, full)
 
 
@@ -97,9 +97,9 @@ def test_output_check_and_errors():
     bad = np.zeros((8, 8, 8, 2))
     bad[0, 0, 0, 0] = np.nan
     with pytest.raises(ValueError):
-        fp.run_chunk(bad, 0)
+        fp.run_domain_chunk(bad, 0)
     with pytest.raises(MemoryError):
-        fp.run_chunk(np.ones((8, 8, 8, 2)), 0)
+        fp.run_domain_chunk(np.ones((8, 8, 8, 2)), 0)
     s_bad = ChunkSlicer((8, 8), 8, 3, 3, (4, 4, 4))
     with pytest.raises(RuntimeError):
         ForwardPass(model, s_bad)
@@ -120,7 +120,7 @@ model = LocalModel()
 s = ChunkSlicer((12, 10), 14, 2, 3, (5, 5, 6), spatial_pad=1, temporal_pad=1)
 out = np.zeros(s.hr_shape + (2,))
 fp = ForwardPass(model, s, rank=rank, nranks=world)
-n = fp.run(domain, out=out)
+n = fp.run_domain(domain, out=out)
 # ranks wrote disjoint windows: SUM over ranks assembles the domain
 total = sum_over_ranks_host([out])[0]
 full = model.generate(domain[None])[0]
@@ -156,3 +156,123 @@ def test_world_size_2_gloo(tmp_path):
     assert res.returncode == 0, res.stdout + res.stderr
     # both workers ran every assertion (their stdout lines may interleave)
     assert res.stdout.count('ok') >= 2, res.stdout
+
+
+# ------------------------------------------- the reference's entry points
+import dataclasses  # noqa: E402
+
+
+@dataclasses.dataclass
+class RefChunk:
+    """replica of sup3r.pipeline.strategy.ForwardPassChunk (strategy.py:
+    37-54): the executor only duck-types the structure"""
+    input_data: np.ndarray
+    exo_data: dict
+    hr_crop_slice: tuple
+    lr_pad_slice: tuple
+    hr_lat_lon: np.ndarray
+    hr_times: object
+    gids: np.ndarray
+    out_file: str
+    pad_width: tuple
+    index: int
+
+    def __post_init__(self):
+        self.shape = self.input_data.shape
+
+
+class ExoLocalModel(LocalModel):
+    """LocalModel + a hi-res 'layer' exo field added to both outputs"""
+    meta, model_params = {}, {}
+    s_enhancements, t_enhancements = [2], [3]
+    lr_features = ['a', 'b']
+
+    def generate(self, x, exogenous_data=None):
+        y = super().generate(x)
+        if exogenous_data is not None:
+            topo = exogenous_data['topography']['steps'][0]['data']
+            assert topo.shape[:4] == y.shape[:4], (topo.shape, y.shape)
+            y = y + topo
+        return y
+
+
+def _array_strategy(domain, topo, max_nodes=1, **kw):
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    model = register_model('ExoLocalModel', {'model_dir': 'mem'},
+                           ExoLocalModel())
+    exo = None if topo is None else {'topography': {'steps': [
+        {'model': 0, 'combine_type': 'layer', 'data': topo, 's_enhance': 2,
+         't_enhance': 3}]}}
+    return ArrayStrategy(domain, {'model_dir': 'mem'}, (8, 8, 10),
+                         spatial_pad=1, temporal_pad=1,
+                         model_class='ExoLocalModel', exo_data=exo,
+                         max_nodes=max_nodes, model=model, **kw), model
+
+
+def test_strategy_chunks_with_exo_through_the_reference_entry_points():
+    """``ForwardPass.run(strategy, node_index)`` over ``ForwardPassChunk``s
+    that carry hi-res exo data (strategy.py:520-581, forward_pass.py:66-72,
+    427-500): chunked == un-chunked, every node's share placed once, and the
+    classmethod ``run_chunk(chunk, model_kwargs, model_class, allowed_const,
+    ...)`` on a replica of the reference's chunk structure"""
+    rng = np.random.default_rng(1)
+    domain = rng.standard_normal((20, 17, 25, 2))
+    topo = rng.standard_normal((40, 34, 1))          # constant in time
+    strategy, model = _array_strategy(domain, topo, max_nodes=3)
+    sl = strategy.fwp_slicer
+    full = model.generate(domain[None])[0] + topo[:, :, None, :]
+    out = np.full(sl.hr_shape + (2,), np.nan)
+    n = 0
+    assert len(strategy.node_chunks) == 3
+    for node in range(3):
+        done, kept = ForwardPass.run(strategy, node, return_data=True)
+        n += done
+        for idx, data in kept:
+            assert np.isnan(out[sl.chunks[idx]['hr_slice']]).all()
+            out[sl.chunks[idx]['hr_slice']] = data
+    assert n == sl.n_chunks and strategy.node_finished(0)
+    # interior cells: exact; the un-chunked run reflect-pads the same way at
+    # the domain edges (LocalModel), so everything is
+    np.testing.assert_allclose(out, full, rtol=0, atol=1e-12)
+    # a finished node is skipped (forward_pass.py:441)
+    assert ForwardPass.run(strategy, 0) == 0
+    # --- run_chunk on a replica of the reference's structure
+    strategy2, _ = _array_strategy(domain, topo)
+    fwp = ForwardPass(strategy2, 0)
+    c = fwp.get_input_chunk(4)
+    rc = RefChunk(**{f.name: getattr(c, f.name)
+                     for f in dataclasses.fields(RefChunk)})
+    assert rc.shape == (10, 10, 12, 2)
+    # 'layer' exo arrives edge-padded, expanded in time, at hi-res
+    assert rc.exo_data['topography']['steps'][0]['data'].shape == \
+        (20, 20, 36, 1)
+    failed, data = ForwardPass.run_chunk(
+        rc, {'model_dir': 'mem'}, 'ExoLocalModel', False, invert_uv=False,
+        meta=fwp.meta, nn_fill=True, output_workers=None)
+    assert not failed
+    np.testing.assert_allclose(data, full[sl.chunks[4]['hr_slice']],
+                               rtol=0, atol=1e-12)
+    assert set(fwp.meta) == {'node_index', 'creation_date', 'model_meta',
+                             'gan_params', 'strategy_meta'}
+    # NaN in the input -> RuntimeError naming the feature (:640-645) on the
+    # device path; the host path reports through model.generate
+    with pytest.raises(KeyError):
+        ForwardPass.run_chunk(rc, 'nowhere', 'NoSuchModel', False)
+
+
+def test_failed_chunk_raises_memory_error():
+    class Flat(ExoLocalModel):
+        def generate(self, x, exogenous_data=None):
+            return np.zeros_like(super().generate(x))
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    m = register_model('Flat', {'model_dir': 'flat'}, Flat())
+    domain = np.random.default_rng(2).standard_normal((8, 8, 10, 2))
+    st = ArrayStrategy(domain, {'model_dir': 'flat'}, (8, 8, 10), 1, 1,
+                       model_class='Flat', model=m)
+    with pytest.raises(MemoryError):
+        ForwardPass.run(st, 0)
+    st = ArrayStrategy(domain, {'model_dir': 'flat'}, (8, 8, 10), 1, 1,
+                       model_class='Flat', model=m, allowed_const=[0])
+    assert ForwardPass.run(st, 0) == 1

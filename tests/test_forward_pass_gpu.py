@@ -74,7 +74,7 @@ def test_run_batched_errors():
     # MemoryError from the output check, in both executors
     model.generator.set_weights(
         [np.zeros_like(w) for w in model.generator.weights])
-    for runner in (fwp.run_chunks, fwp.run_batched, fwp.run):
+    for runner in (fwp.run_chunks, fwp.run_batched, fwp.run_domain):
         with pytest.raises(MemoryError):
             runner(domain, out=np.zeros(slicer.hr_shape + (2,), np.float32))
 
@@ -101,3 +101,162 @@ def test_chunk_stats_kernel():
     np.testing.assert_array_equal(mx, np.nanmax(x, axis=1))
     np.testing.assert_array_equal(nn, np.isnan(x).sum(1))
     assert mn[1, 1] == mx[1, 1] == np.float32(0.75)
+
+
+# ------------------------------------------- the reference's entry points
+def _topo_model(tmp_path=None):
+    """a topography-conditioned 3x / 4x generator (Sup3rConcat mid-network)"""
+    from sup3r_amd import Sup3rGan
+    feats, exo = ['u_10m', 'v_10m'], ['topography']
+    Sup3rGan.seed(7)
+    means = {'u_10m': np.float32(0.2), 'v_10m': np.float32(-0.4),
+             'topography': np.float32(300.0)}
+    stds = {'u_10m': np.float32(1.25), 'v_10m': np.float32(1.75),
+            'topography': np.float32(150.0)}
+    m = Sup3rGan(os.path.join(CFG, 'test_gen_st_3x_4x_2f_topo.json'),
+                 os.path.join(CFG, 'test_disc_st_same.json'), means=means,
+                 stdevs=stds)
+    m.set_model_params(lr_features=feats, hr_out_features=feats,
+                       hr_exo_features=exo, s_enhance=3, t_enhance=4)
+    m.init_weights((1, 7, 7, 6, 2), (1, 21, 21, 24, 3))
+    return m
+
+
+def _lat_lon(n1, n2):
+    lat = np.linspace(41, 40, n1)[:, None] + np.zeros((1, n2))
+    lon = np.linspace(-105, -104, n2)[None] + np.zeros((n1, 1))
+    return np.stack([lat, lon], -1)
+
+
+def test_strategy_chunks_with_exo_on_the_device(tmp_path):
+    """``ForwardPass.run(strategy, node_index)`` / ``run_chunk(chunk, ...)``
+    (forward_pass.py:427-500,582-673) over ``ForwardPassChunk`` structures
+    carrying hi-res topography (strategy.py:520-581) through a
+    ``Sup3rConcat`` generator: the batched device executor is bit-identical
+    to the chunk-by-chunk ``model.generate`` path for every batch size, the
+    oracle agrees on a chunk, and the file output is the device-transformed
+    field"""
+    from oracle.gan import norm_input, un_norm_output
+    from oracle.network import Network as ONet
+    from sup3r_amd.forward_pass import (ForwardPass, ForwardPassChunk,
+                                        register_model)
+    from sup3r_amd.strategy import ArrayStrategy
+    import json
+    model = _topo_model()
+    register_model('Sup3rGan', {'model_dir': 'topo-test'}, model)
+    rng = np.random.default_rng(4)
+    domain = (rng.standard_normal((13, 11, 14, 2)) * 2 + 0.3).astype(
+        np.float32)
+    topo = (300 + 150 * rng.standard_normal((39, 33, 1))).astype(np.float32)
+    exo = {'topography': {'steps': [
+        {'model': 0, 'combine_type': 'layer', 'data': topo, 's_enhance': 3,
+         't_enhance': 4}]}}
+
+    def strategy(**kw):
+        return ArrayStrategy(domain, {'model_dir': 'topo-test'}, (6, 5, 6),
+                             spatial_pad=1, temporal_pad=1, exo_data=exo,
+                             lat_lon=_lat_lon(39, 33), **kw)
+    st = strategy()
+    sl = st.fwp_slicer
+    # reference-shaped path, chunk by chunk through model.generate
+    fwp = ForwardPass(st, 0)
+    ref = np.full(sl.hr_shape + (2,), np.nan, np.float32)
+    for i in range(sl.n_chunks):
+        c = fwp.get_input_chunk(i)
+        assert isinstance(c, ForwardPassChunk)
+        ref[sl.chunks[i]['hr_slice']] = ForwardPass.run_generator(
+            c.input_data, c.hr_crop_slice, model, s_enhance=3, t_enhance=4,
+            exo_data=c.exo_data)
+    assert np.isfinite(ref).all()
+    # the device executor, ragged edge chunks in separate shape groups
+    for batch in (1, 4, 8):
+        got = np.full_like(ref, np.nan)
+        done, kept = ForwardPass.run(strategy(), 0, batch=batch,
+                                     return_data=True)
+        assert done == sl.n_chunks
+        for idx, data in kept:
+            got[sl.chunks[idx]['hr_slice']] = data
+        np.testing.assert_array_equal(got, ref)
+    # two nodes (= two GPUs) split the chunk list, nothing else is shared
+    got = np.full_like(ref, np.nan)
+    st2 = strategy(max_nodes=2)
+    for node in range(2):
+        for idx, data in ForwardPass.run(st2, node, return_data=True)[1]:
+            got[sl.chunks[idx]['hr_slice']] = data
+    np.testing.assert_array_equal(got, ref)
+    # run_chunk on one structure + the fp32 oracle on its padded input
+    c = fwp.get_input_chunk(3)
+    failed, data = ForwardPass.run_chunk(c, {'model_dir': 'topo-test'},
+                                         'Sup3rGan', False)
+    assert not failed
+    np.testing.assert_array_equal(data, ref[sl.chunks[3]['hr_slice']])
+    with open(os.path.join(CFG, 'test_gen_st_3x_4x_2f_topo.json')) as f:
+        og = ONet(json.load(f))
+    c = fwp.get_input_chunk(3)
+    x = norm_input(c.input_data[None], [0.2, -0.4], [1.25, 1.75]).astype(
+        np.float32)
+    t = ((c.exo_data['topography']['steps'][0]['data'][None] - np.float32(
+        300.0)) / np.float32(150.0)).astype(np.float32)
+    og.forward(x, {'topography': t})
+    og.set_weights(model.generator_weights)
+    y = un_norm_output(og.forward(x, {'topography': t}), [0.2, -0.4],
+                       [1.25, 1.75])
+    y = y[0][tuple(c.hr_crop_slice)]
+    err = np.abs(y - data).max() / max(1.0, np.abs(y).max())
+    print(f'topography chunk through run_chunk vs oracle: {err:.2e}')
+    assert err < 1e-4, err
+    # file output: u/v inverted on the device, written by the npz handler
+    from oracle.output import transform_output
+    pat = os.path.join(str(tmp_path), 'out_{file_id}.npz')
+    st3 = strategy(out_pattern=pat, invert_uv=True, nn_fill=False)
+    assert ForwardPass.run(st3, 0) == sl.n_chunks
+    assert st3.node_finished(0) and ForwardPass.run(st3, 0) == 0
+    f3 = np.load(st3.out_files[3], allow_pickle=False)
+    assert list(f3['features']) == ['windspeed_10m', 'winddirection_10m']
+    hs = sl.chunks[3]['hr_slice']
+    want, _ = transform_output(
+        ref[hs].astype(np.float64), ['u_10m', 'v_10m'],
+        _lat_lon(39, 33)[hs[0], hs[1]], True, nn_fill=False)
+    assert np.abs(f3['data'][..., 0] - want[..., 0]).max() < 1e-4
+    d = np.abs(f3['data'][..., 1] - want[..., 1])
+    assert np.minimum(d, 360 - d).max() < 5e-2
+    assert f3['gids'].shape == (hs[0].stop - hs[0].start,
+                                hs[1].stop - hs[1].start)
+
+
+def test_residency_is_explicit():
+    """``run_batched`` never serves a stale upload: a second array of the same
+    shape (CPython may even give it the same ``id``), or the same array
+    updated in place, is uploaded again; an explicit ``upload_domain`` handle
+    is reused only while the model's statistics are the ones it was
+    normalised with"""
+    from sup3r_amd import ChunkSlicer, ForwardPass
+    model = _model()
+    slicer = ChunkSlicer((8, 8), 8, 2, 4, (4, 4, 4), spatial_pad=1,
+                         temporal_pad=1)
+    fwp = ForwardPass(model, slicer)
+    rng = np.random.default_rng(0)
+
+    def run(d):
+        out = np.zeros(slicer.hr_shape + (2,), np.float32)
+        fwp.run_batched(d, out=out)
+        return out
+    outs = []
+    for i in range(3):
+        d = rng.standard_normal((8, 8, 8, 2)).astype(np.float32)
+        outs.append((d.copy(), run(d)))
+        del d
+    for d, o in outs:
+        np.testing.assert_array_equal(run(d), o)
+    assert not np.array_equal(outs[0][1], outs[1][1])
+    d = outs[0][0].copy()
+    o0 = run(d)
+    d[:] = outs[1][0]                       # in-place refill
+    np.testing.assert_array_equal(run(d), outs[1][1])
+    assert not np.array_equal(o0, outs[1][1])
+    h = fwp.upload_domain(outs[2][0])
+    np.testing.assert_array_equal(run(h), outs[2][1])
+    model.set_norm_stats({'u_10m': 0.0, 'v_10m': 0.0},
+                         {'u_10m': 1.0, 'v_10m': 1.0})
+    with pytest.raises(RuntimeError, match='statistics'):
+        run(h)

@@ -116,22 +116,22 @@ def test_forward_pass_executor_on_gpu():
     assert full.shape == (24, 24, 32, 2)
     s1 = ChunkSlicer((12, 12), 8, 2, 4, (12, 12, 8))
     out1 = np.zeros(s1.hr_shape + (2,), np.float32)
-    ForwardPass(model, s1).run(domain, out=out1)
+    ForwardPass(model, s1).run_domain(domain, out=out1)
     np.testing.assert_array_equal(out1, full)
     s = ChunkSlicer((12, 12), 8, 2, 4, (6, 6, 4), spatial_pad=3,
                     temporal_pad=2)
     a = np.zeros(s.hr_shape + (2,), np.float32)
-    ForwardPass(model, s).run(domain, out=a)
+    ForwardPass(model, s).run_domain(domain, out=a)
     b = np.zeros_like(a)
-    n0 = ForwardPass(model, s, rank=0, nranks=2).run(domain, out=b)
-    n1 = ForwardPass(model, s, rank=1, nranks=2).run(domain, out=b)
+    n0 = ForwardPass(model, s, rank=0, nranks=2).run_domain(domain, out=b)
+    n1 = ForwardPass(model, s, rank=1, nranks=2).run_domain(domain, out=b)
     assert n0 + n1 == s.n_chunks
     np.testing.assert_array_equal(a, b)
     # overlap reduces the chunk-edge error (the generator's receptive field,
     # ~10 lo-res cells, exceeds any overlap this tiny domain allows)
     s0 = ChunkSlicer((12, 12), 8, 2, 4, (6, 6, 4))
     c = np.zeros_like(a)
-    ForwardPass(model, s0).run(domain, out=c)
+    ForwardPass(model, s0).run_domain(domain, out=c)
     assert np.abs(a - full).mean() < np.abs(c - full).mean()
 
 

@@ -381,46 +381,6 @@ def test_losses_adam_utils():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize('cfg,shape', [
-    ('gen_2x_2f.json', (3, 9, 8, 2)),             # C1: 36 Conv2DTranspose, 64 ch
-    ('gen_3x_4x_2f.json', (1, 5, 6, 4, 2)),       # C4 body
-])
-def test_production_configs_bf16_forward_backward(cfg, shape):
-    """The production-size generators in bf16 mode (kernel selection differs
-    from the small-channel test nets: 2-D 64-channel convs on the gather-MFMA
-    kernels, 3-D ones on the halo-tile / general wgrad kernels).  Forward:
-    5e-2 of the largest value.  Backward through 36 - 37 stacked LeakyReLU
-    convs with random weights is ill-conditioned — a pre-activation within
-    round-off of zero flips its mask — so even the exact-fp32 mode is only
-    within ~1e-2 (rms) of the oracle there; the bounds are on the relative
-    rms error: 5e-2 (f32 mode), 3e-1 (bf16 mode)."""
-    rng = np.random.default_rng(21)
-    spec = _load(cfg)
-    x = rng.standard_normal(shape).astype(np.float32)
-    ref = _oracle_net(spec, x, None)
-    y_ref = ref.forward(x)
-    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
-    dx_ref = ref.backward(dy)
-
-    def rel_rms(a, b):
-        return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
-    for prec, tol_y, tol_g in (('f32', 1e-4, 5e-2), ('bf16', 5e-2, 3e-1)):
-        net = _hip_net(spec, ref.weights, precision=prec)
-        dev = net.dev
-        ph = net.plan(shape, training=True)
-        y = ph.forward(dev.to_device(x)).cpu().numpy()
-        assert y.shape == y_ref.shape
-        assert np.abs(y - y_ref).max() < tol_y * max(1.0, np.abs(y_ref).max()), prec
-        dx = ph.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
-        assert rel_rms(dx.reshape(dx_ref.shape), dx_ref) < tol_g, prec
-        for g, g_ref in zip(net.grads, ref.grads):
-            if np.abs(g_ref).max() > 0:
-                assert rel_rms(g, g_ref) < tol_g, prec
-        # the inference plan (bf16 trunk activations in bf16 mode) agrees too
-        y_inf = net(x).cpu().numpy()
-        assert np.abs(y_inf - y_ref).max() < tol_y * max(1.0, np.abs(y_ref).max())
-
-
 def test_hipgraph_replay_is_bit_identical(monkeypatch):
     """SUP3R_AMD_GRAPH=1: the forward op list is captured into a hipGraph
     (staged inputs, fixed pointers) and replayed; outputs must equal the eager

@@ -145,6 +145,18 @@ def test_device_nn_fill_vs_oracle():
     out2, _ = DeviceOutputTransform().transform_output(clean, feats, ll,
                                                        nn_fill=True)
     np.testing.assert_array_equal(out2.cpu().numpy(), clean)
+    # NaNs in a channel that is otherwise INSIDE its range are filled as well
+    # (nn_fill_array runs for every feature, utilities.py:208-215): the
+    # device extrema skip NaNs, so the range alone would not trigger it
+    holes = clean.copy()
+    holes[3, 4, 5, 1] = np.nan
+    holes[10:12, 7, 2, 1] = np.nan
+    ref3, _ = transform_output(holes.astype(np.float64), feats, ll, False,
+                               nn_fill=True)
+    out3, _ = DeviceOutputTransform().transform_output(holes, feats, ll,
+                                                       nn_fill=True)
+    assert np.isfinite(out3.cpu().numpy()).all()
+    np.testing.assert_array_equal(out3.cpu().numpy(), ref3)
 
 
 # --- the reference's own known-answer tests for the wind rotation pair

@@ -177,3 +177,19 @@ def test_strided_transpose_lowering(spec, shape, out_shape):
               for w, p in zip(net.weights, plan.params)]
     y = run_plan(plan, params, {'x': x})
     np.testing.assert_allclose(y, y_ref, rtol=0, atol=2e-6)
+
+
+def test_strided_transpose_with_kernel_smaller_than_stride_is_refused():
+    """keras 'valid' Conv*DTranspose output is in * s + max(k - s, 0); the
+    zero-insertion lowering gives (in - 1) * s + k — equal only for k >= s,
+    so k < s must not build a (shorter) plan silently"""
+    import pytest
+    from sup3r_amd import spec as S
+    layers = S.parse_layers([{'class': 'Conv2DTranspose', 'filters': 4,
+                              'kernel_size': 2, 'strides': 3}])
+    with pytest.raises(KeyError, match='kernel_size'):
+        S.build_plan(layers, (1, 5, 5, 2))
+    ok = S.parse_layers([{'class': 'Conv2DTranspose', 'filters': 4,
+                          'kernel_size': 3, 'strides': 2}])
+    plan = S.build_plan(ok, (1, 5, 5, 2))
+    assert tuple(plan.out_shape) == (1, 11, 11, 4)     # in * s + k - s

@@ -369,3 +369,16 @@ def test_world_size_2_training_over_gloo(tmp_path):
                          timeout=240)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert res.stdout.count('ok') >= 2, res.stdout
+
+
+def test_loss_window_keeps_inf_like_pandas():
+    """LossWindow.means drops NaN only (pandas skipna): a diverged batch with
+    an inf loss stays visible to the train / skip gating (base.py:1161-1164)"""
+    from sup3r_amd.ledger import LossWindow
+    w = LossWindow('train_')
+    w.resize(4)
+    w.push({'loss_disc': 0.5, 'loss_gen': 1.0})
+    w.push({'loss_disc': float('inf'), 'loss_gen': float('nan')})
+    m = w.means()
+    assert m['train_loss_disc'] == float('inf')
+    assert m['train_loss_gen'] == 1.0

@@ -43,7 +43,7 @@ def main():
     out = np.zeros(slicer.hr_shape + (2,), np.float32)
     fwp = ForwardPass(model, slicer)
     # warm-up (plans, weights)
-    fwp.run_chunk(domain, 0)
+    fwp.run_domain_chunk(domain, 0)
     for rep in range(args.repeat):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -52,7 +52,7 @@ def main():
                                 n_host_threads=args.threads,
                                 direct_placement=args.direct)
         else:
-            n = fwp.run(domain, out=out)
+            n = fwp.run_domain(domain, out=out)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f'run {rep}: domain {d}: {n} chunks in {dt:.3f} s = {n / dt:.1f} '
