@@ -131,6 +131,19 @@ int s3_params_mean_abs(s3_params* p, int which, int idx, float* host_out);
  * w -= m*alpha/(sqrt(v)+eps).  t is the 1-based step count. */
 int s3_adam_step(s3_params* p, float lr, float beta1, float beta2, float eps,
                  int64_t t);
+/* The other keras optimizers ``init_optimizer`` may be handed by name
+ * (abstract.py:321-350, models/utilities.py:150-158), keras-2.15
+ * ``update_step`` each, one fused pass over the store (slots: BUF_M / BUF_V).
+ * hp[]: Adam {lr, beta_1, beta_2, epsilon}; SGD {lr, momentum, nesterov};
+ * RMSprop {lr, rho, momentum, epsilon} (centered=False); Adagrad {lr,
+ * epsilon, initial_accumulator_value}; Adamax {lr, beta_1, beta_2, epsilon};
+ * AdamW {lr, beta_1, beta_2, epsilon, weight_decay}. */
+typedef enum {
+  S3_OPT_ADAM = 0, S3_OPT_SGD = 1, S3_OPT_RMSPROP = 2, S3_OPT_ADAGRAD = 3,
+  S3_OPT_ADAMAX = 4, S3_OPT_ADAMW = 5
+} s3_optimizer_kind;
+int s3_optimizer_step(s3_params* p, int kind, const float* hp, int n_hp,
+                      int64_t t);
 
 /* ---- plan (shape-specialised executor) ---------------------------------
  * replaces: the eager/graph layer loops AbstractSingleModel._tf_generate

@@ -114,6 +114,64 @@ class Adam:
         self.iterations = t
 
 
+class KerasOptimizer:
+    """keras-2.15 ``update_step`` of the other optimizers sup3r may be given
+    by name (abstract.py:321-350), restated from keras' published source
+    (keras is not installed here): SGD, RMSprop (not centered), Adagrad,
+    Adamax, AdamW.  Two slot lists ``m`` / ``v`` like the device store."""
+
+    def __init__(self, name, **kw):
+        self.name, self.kw = name, kw
+        self.iterations = 0
+        self.m = self.v = None
+
+    def apply_gradients(self, grads, weights):
+        k, name = self.kw, self.name
+        if self.m is None:
+            self.m = [np.zeros_like(w) for w in weights]
+            init = k.get('initial_accumulator_value', 0.1) \
+                if name == 'Adagrad' else 0.0
+            self.v = [np.full_like(w, init) for w in weights]
+        t = self.iterations + 1
+        lr = k.get('learning_rate')
+        for w, g, m, v in zip(weights, grads, self.m, self.v):
+            g = g.astype(w.dtype)
+            if name == 'SGD':
+                mom = k.get('momentum', 0.0)
+                if mom:
+                    m[...] = -g * lr + m * mom
+                    w += (-g * lr + m * mom) if k.get('nesterov') else m
+                else:
+                    w += -g * lr
+            elif name == 'RMSprop':
+                rho, eps = k.get('rho', 0.9), k.get('epsilon', 1e-7)
+                v[...] = rho * v + (1 - rho) * g * g
+                inc = lr * g / np.sqrt(v + eps)
+                if k.get('momentum', 0.0) > 0:
+                    m[...] = k['momentum'] * m + inc
+                    w -= m
+                else:
+                    w -= inc
+            elif name == 'Adagrad':
+                v += g * g
+                w -= lr * g / np.sqrt(v + k.get('epsilon', 1e-7))
+            elif name == 'Adamax':
+                b1, b2 = k.get('beta_1', 0.9), k.get('beta_2', 0.999)
+                m += (g - m) * (1 - b1)
+                v[...] = np.maximum(b2 * v, np.abs(g))
+                w -= (lr * m) / ((1 - b1 ** t) * (v + k.get('epsilon', 1e-7)))
+            elif name == 'AdamW':
+                b1, b2 = k.get('beta_1', 0.9), k.get('beta_2', 0.999)
+                w -= w * k.get('weight_decay', 0.004) * lr
+                alpha = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+                m += (g - m) * (1 - b1)
+                v += (g * g - v) * (1 - b2)
+                w -= (m * alpha) / (np.sqrt(v) + k.get('epsilon', 1e-7))
+            else:
+                raise KeyError(name)
+        self.iterations = t
+
+
 # ---------------------------------------------------------------- GAN step
 class GanOracle:
     """Sup3rGan compute core: generator + discriminator ``oracle.network``

@@ -249,7 +249,10 @@ class ConvND(Layer):
         cin = x.shape[-1]
         w = self.kernel.astype(dy.dtype, copy=False)
         dy2 = dy.reshape(-1, self.filters)
-        db = dy2.sum(axis=0)
+        # (float64 accumulation: numpy's float32 reduction along axis 0 is a
+        # sequential running sum — 1.8 M equal-magnitude terms of an MAE
+        # gradient bias it by ~1e-3)
+        db = dy2.sum(axis=0, dtype=np.float64).astype(dy2.dtype)
         # (device kernels: the weight gradient rounds x and dPre, the data
         # gradient dPre and w)
         dyw = dyd = dy2
@@ -336,7 +339,8 @@ class ConvTransposeND(Layer):
         in_sp = x.shape[1:1 + self.nd]
         w = self.kernel.astype(dy.dtype, copy=False)
         x2 = x.reshape(-1, x.shape[-1])
-        db = dy.reshape(-1, self.filters).sum(axis=0)
+        db = dy.reshape(-1, self.filters).sum(axis=0, dtype=np.float64).astype(
+            dy.dtype)
         dyw = dyd = dy
         if getattr(self, 'emu_wgrad_round', False):
             x2, dyw = round_bf16(x2), round_bf16(dy)
@@ -561,7 +565,8 @@ class Dense(Layer):
         x2 = self._x.reshape(-1, self._x.shape[-1])
         dy2 = dy.reshape(-1, self.units)
         dw = x2.T @ dy2
-        self.grads = [dw, dy2.sum(axis=0)] if self.use_bias else [dw]
+        self.grads = [dw, dy2.sum(axis=0, dtype=np.float64).astype(
+            dy2.dtype)] if self.use_bias else [dw]
         return (dy2 @ self.kernel.astype(dy.dtype, copy=False).T
                 ).reshape(self._x.shape)
 

@@ -14,11 +14,12 @@ from .gan import Sup3rGan  # noqa: E402,F401
 from .condmom import Sup3rCondMom  # noqa: E402,F401
 from .data_centric import Sup3rGanDC  # noqa: E402,F401
 from .solar_cc import SolarCC  # noqa: E402,F401
+from .with_obs import Sup3rGanWithObs  # noqa: E402,F401
 from .forward_pass import ChunkSlicer, ForwardPass  # noqa: E402,F401
 from .multi_step import MultiStepGan  # noqa: E402,F401
 from .batch_queue import (DeviceBatchHandler, DeviceBatchQueue,  # noqa: E402,F401
                           DsetTuple)
 
-__all__ = ['Sup3rGan', 'Sup3rCondMom', 'Sup3rGanDC', 'SolarCC', 'MultiStepGan', 'ForwardPass',
+__all__ = ['Sup3rGan', 'Sup3rCondMom', 'Sup3rGanDC', 'SolarCC', 'Sup3rGanWithObs', 'MultiStepGan', 'ForwardPass',
            'ChunkSlicer', 'DeviceBatchQueue', 'DeviceBatchHandler', 'DsetTuple',
            '__version__']

@@ -23,7 +23,7 @@ EXPORTS = [
     's3_ctx_stream', 's3_ctx_stat', 's3_params_create', 's3_params_destroy',
     's3_params_total', 's3_params_set', 's3_params_get', 's3_params_dptr',
     's3_params_zero_grad', 's3_params_version', 's3_params_mean_abs',
-    's3_adam_step',
+    's3_adam_step', 's3_optimizer_step',
     's3_plan_create', 's3_plan_destroy', 's3_plan_forward',
     's3_plan_backward', 's3_plan_tensor', 's3_plan_workspace_bytes',
     's3_plan_profile_begin', 's3_plan_profile_end',
@@ -102,6 +102,7 @@ def lib():
         's3_params_version': (u64, [vp]),
         's3_params_mean_abs': (i32, [vp, i32, i32, pf]),
         's3_adam_step': (i32, [vp, f32, f32, f32, f32, i64]),
+        's3_optimizer_step': (i32, [vp, i32, pf, i32, i64]),
         's3_plan_create': (i32, [vp, vp, C.POINTER(TensorDesc), i32,
                                  C.POINTER(OpDesc), i32, C.POINTER(i32), i32,
                                  i32, i32, i32, C.POINTER(vp)]),

@@ -251,8 +251,16 @@ class HipGanCompute:
                        weight_gen_advers=0.001, train_gen=True,
                        train_disc=False, compute_disc=False, exo_names=(),
                        backward=True, hi_res_gen=None, mask=None,
-                       accumulate_wgrad=False, scal=None, defer=False):
+                       accumulate_wgrad=False, scal=None, defer=False,
+                       extra_exo=None, obs=None):
         """One ``_get_hr_exo_and_loss`` + ``tape.gradient``.
+
+        ``extra_exo``: further named generator inputs (the sparse observation
+        fields of ``Sup3rGanWithObs``).  ``obs`` = (observed-cell mask as a
+        0 / 1 host array over the output features, kind of the observation
+        loss, its weight): adds ``loss_obs`` / ``loss_non_obs`` /
+        ``obs_frac`` and, weighted, the observation term to the generator loss
+        and its gradient (with_obs.py:248-279).
 
         ``backward=False`` evaluates ``calc_loss`` only (validation).  When
         ``hi_res_gen`` is given (public ``calc_loss(hi_res_true, hi_res_gen)``)
@@ -270,9 +278,12 @@ class HipGanCompute:
         c_true = hr_true.shape[-1]
         gen_train = bool(backward and train_gen)
         disc_train = bool(backward and train_disc and not train_gen)
+        obs_info = None
         if hi_res_gen is None:
             lr = dev.to_device(low_res)
             exo = self.exo_from_true(hr_true, list(exo_names))
+            for name, arr in (extra_exo or {}).items():
+                exo[name] = dev.to_device(arr)
             gph = self.gen.plan(tuple(lr.shape), training=gen_train)
             hr_gen = gph.forward(lr, exo)
         else:
@@ -356,6 +367,35 @@ class HipGanCompute:
                         self._ptr(scal, slot),
                         self._ptr(dg) if gen_train else None, 1)
                 _lib.check(rc, dev.ctx, 's3_loss_content')
+            obs_info = None
+            if obs is not None:
+                # loss over the observed / the un-observed cells of the output
+                # features (with_obs.py:88-99): the masked kernel averages
+                # |m (gen - true)| over ALL cells, the reference over the
+                # selected ones -> x n_total / n_selected; the weighted
+                # observed term joins the generator loss and its gradient
+                # (with_obs.py:271-275)
+                m_host, okind, w_obs = obs
+                m_host = np.asarray(m_host, np.float32)
+                m_obs = dev.to_device(m_host)
+                m_non = dev.to_device(1.0 - m_host)
+                n_tot = int(m_host.size)
+                n_obs = int(m_host.sum())
+                if len(loss_terms) + 2 > MAX_TERMS:
+                    raise ValueError('too many loss terms for the obs terms')
+                c_o = int(m_obs.shape[-1])
+                base = 4 + SLOTS_PER_TERM * len(loss_terms)
+                w_eff = float(w_obs) * n_tot / n_obs if (w_obs and n_obs) \
+                    else 0.0
+                for q, (mk, wq) in enumerate(((m_obs, w_eff), (m_non, 0.0))):
+                    dgq = d_gen_full if (gen_train and wq) else None
+                    rc = L.s3_loss_content_masked(
+                        dev.ctx, okind, self._ptr(gen_full), c_true,
+                        self._ptr(hr_true), c_true, self._ptr(mk), c_o, c_o,
+                        n_pos, wq, self._ptr(scal, base + SLOTS_PER_TERM * q),
+                        self._ptr(dgq) if dgq is not None else None, 1)
+                    _lib.check(rc, dev.ctx, 's3_loss_content_masked')
+                obs_info = (base, n_tot, n_obs, float(w_obs or 0.0))
             if need_disc:
                 # adversarial term: roles swapped (base.py:899-901); only
                 # D(gen) depends on the generator
@@ -387,10 +427,25 @@ class HipGanCompute:
         with_disc = need_disc and (compute_disc or train_disc)
         coefs = term_coefs if train_gen else None
 
+
         def recipe(vals):
-            return details_from_scalars(vals, loss_terms, coefs, with_disc,
-                                        train_gen, need_disc,
-                                        weight_gen_advers)
+            det = details_from_scalars(vals, loss_terms, coefs, with_disc,
+                                       train_gen, need_disc,
+                                       weight_gen_advers)
+            if obs_info is not None:
+                base, n_tot, n_obs, w_obs = obs_info
+                n_non = n_tot - n_obs
+                l_obs = float(vals[base]) * n_tot / n_obs if n_obs else \
+                    float('nan')
+                l_non = float(vals[base + SLOTS_PER_TERM]) * n_tot / n_non \
+                    if n_non else float('nan')
+                det['loss_obs'] = LossValue(l_obs)
+                det['loss_non_obs'] = LossValue(l_non)
+                det['obs_frac'] = LossValue(n_obs / n_tot)
+                if w_obs and n_obs:
+                    for k in ('loss_gen', 'loss_gen_content'):
+                        det[k] = LossValue(float(det[k]) + w_obs * l_obs)
+            return det
         if defer:
             return None, LossFuture(scal, recipe), hr_gen
         details = recipe(scal.cpu().numpy())   # one sync per mini-batch
@@ -606,14 +661,14 @@ class HipGanCompute:
 
     # ------------------------------------------------------------ optimizer
     def apply(self, which, optimizer):
-        """keras Adam ``apply_gradients`` on the whole store of one network."""
+        """keras ``apply_gradients`` on the whole store of one network: one
+        fused launch, whatever the optimizer (``optimizers.py``)."""
         net = self.gen if which == 'gen' else self.disc
-        cfg = optimizer.get_config()
-        if cfg['name'].lower() != 'adam':
-            raise KeyError(f'optimizer "{cfg["name"]}" has no MI355X kernel')
+        kind = getattr(optimizer, 'KIND', None)
+        if kind is None or not hasattr(optimizer, 'hyper'):
+            raise KeyError(f'optimizer "{optimizer}" has no MI355X kernel')
         optimizer.iterations += 1
-        net.adam_step(cfg['learning_rate'], cfg['beta_1'], cfg['beta_2'],
-                      cfg['epsilon'], optimizer.iterations)
+        net.optimizer_step(kind, optimizer.hyper(), optimizer.iterations)
 
     def allreduce_grads(self, which):
         net = self.gen if which == 'gen' else self.disc

@@ -289,6 +289,8 @@ int launch_dense_wgrad(s3_ctx* ctx, const float* x, const float* dy, float* dw,
                        int n, int cin, int cout, int accumulate);
 int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
                 int64_t n, float alpha, float b1, float b2, float eps);
+int launch_optimizer(s3_ctx* ctx, int kind, float* w, const float* g, float* m, float* v,
+                     int64_t n, const float* h);
 int launch_fill(s3_ctx* ctx, float* p, int64_t n, float v);
 int launch_mean_abs(s3_ctx* ctx, const float* p, int64_t n, float* out_dev);
 int ensure_scratch(s3_ctx* ctx, size_t bytes);

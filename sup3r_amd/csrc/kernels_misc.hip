@@ -1060,6 +1060,80 @@ int launch_mean_abs(s3_ctx* ctx, const float* p, int64_t n, float* out_dev) {
   return S3_OK;
 }
 
+// keras-2.15 update_step of the other optimizers sup3r may be given by name
+// (abstract.py:321-350); one fused pass over the flat store like Adam.
+// hp[]: SGD {lr, momentum, nesterov}; RMSprop {lr, rho, momentum, eps} (not
+// centered); Adagrad {lr, eps}; Adamax {lr / (1 - b1^t), 1 - b1, b2, eps};
+// AdamW = decoupled decay w -= w * wd * lr, then Adam: {alpha, 1-b1, 1-b2,
+// eps, wd * lr}.  m / v are the two slot buffers of the store.
+template <int KIND>
+__global__ void optimizer_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                 float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                 float h0, float h1, float h2, float h3, float h4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i];
+    float wi = w[i];
+    if (KIND == S3_OPT_SGD) {
+      if (h1 != 0.f) {
+        const float mi = -gi * h0 + m[i] * h1;
+        m[i] = mi;
+        wi += h2 != 0.f ? (-gi * h0 + mi * h1) : mi;
+      } else {
+        wi += -gi * h0;
+      }
+    } else if (KIND == S3_OPT_RMSPROP) {
+      const float vi = h1 * v[i] + (1.f - h1) * gi * gi;
+      v[i] = vi;
+      const float inc = h0 * gi * (1.f / sqrtf(vi + h3));
+      if (h2 > 0.f) {
+        const float mi = h2 * m[i] + inc;
+        m[i] = mi;
+        wi -= mi;
+      } else {
+        wi -= inc;
+      }
+    } else if (KIND == S3_OPT_ADAGRAD) {
+      const float vi = v[i] + gi * gi;
+      v[i] = vi;
+      wi -= h0 * gi / sqrtf(vi + h1);
+    } else if (KIND == S3_OPT_ADAMAX) {
+      const float mi = m[i] + (gi - m[i]) * h1;
+      const float ui = fmaxf(h2 * v[i], fabsf(gi));
+      m[i] = mi;
+      v[i] = ui;
+      wi -= (h0 * mi) / (ui + h3);
+    } else {   // S3_OPT_ADAMW
+      wi -= wi * h4;
+      const float mi = m[i] + (gi - m[i]) * h1;
+      const float vi = v[i] + (gi * gi - v[i]) * h2;
+      m[i] = mi;
+      v[i] = vi;
+      wi -= (mi * h0) / (sqrtf(vi) + h3);
+    }
+    w[i] = wi;
+  }
+}
+
+int launch_optimizer(s3_ctx* ctx, int kind, float* w, const float* g, float* m, float* v,
+                     int64_t n, const float* h) {
+  const dim3 grid(grid_for(n, ctx->num_cu)), blk(kBlock);
+#define S3_OPT_LAUNCH(K)                                                                   \
+  hipLaunchKernelGGL(optimizer_kernel<K>, grid, blk, 0, ctx->stream, w, g, m, v, n, h[0], \
+                     h[1], h[2], h[3], h[4])
+  switch (kind) {
+    case S3_OPT_SGD: S3_OPT_LAUNCH(S3_OPT_SGD); break;
+    case S3_OPT_RMSPROP: S3_OPT_LAUNCH(S3_OPT_RMSPROP); break;
+    case S3_OPT_ADAGRAD: S3_OPT_LAUNCH(S3_OPT_ADAGRAD); break;
+    case S3_OPT_ADAMAX: S3_OPT_LAUNCH(S3_OPT_ADAMAX); break;
+    case S3_OPT_ADAMW: S3_OPT_LAUNCH(S3_OPT_ADAMW); break;
+    default: S3_FAIL(ctx, S3_EINVAL, "optimizer_step: unknown optimizer kind");
+  }
+#undef S3_OPT_LAUNCH
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
                 int64_t n, float alpha, float b1, float b2, float eps) {
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, w, g, m, v, n, alpha, 1.f - b1, 1.f - b2, eps);

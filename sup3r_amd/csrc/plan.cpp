@@ -315,6 +315,53 @@ extern "C" int s3_adam_step(s3_params* p, float lr, float beta1, float beta2,
   return S3_OK;
 }
 
+extern "C" int s3_optimizer_step(s3_params* p, int kind, const float* hp, int n_hp, int64_t t) {
+  if (!p || !hp || t < 1) return S3_EINVAL;
+  s3_ctx* ctx = p->ctx;
+  float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  auto need = [&](int n) { return n_hp >= n; };
+  switch (kind) {
+    case S3_OPT_ADAM:
+      if (!need(4)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(Adam): {lr, beta_1, beta_2, epsilon}");
+      return s3_adam_step(p, hp[0], hp[1], hp[2], hp[3], t);
+    case S3_OPT_SGD:
+      if (!need(3)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(SGD): {lr, momentum, nesterov}");
+      h[0] = hp[0]; h[1] = hp[1]; h[2] = hp[2];
+      break;
+    case S3_OPT_RMSPROP:
+      if (!need(4)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(RMSprop): {lr, rho, momentum, epsilon}");
+      h[0] = hp[0]; h[1] = hp[1]; h[2] = hp[2]; h[3] = hp[3];
+      break;
+    case S3_OPT_ADAGRAD:
+      if (!need(3)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(Adagrad): {lr, epsilon, initial_accumulator_value}");
+      h[0] = hp[0]; h[1] = hp[1];
+      if (t == 1) {   // keras creates the accumulator filled with its initial value
+        int rc = launch_fill(ctx, p->buf[S3_BUF_V], p->total, hp[2]);
+        if (rc) return rc;
+      }
+      break;
+    case S3_OPT_ADAMAX: {
+      if (!need(4)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(Adamax): {lr, beta_1, beta_2, epsilon}");
+      const float b1p = powf(hp[1], (float)t);
+      h[0] = hp[0] / (1.f - b1p); h[1] = 1.f - hp[1]; h[2] = hp[2]; h[3] = hp[3];
+      break;
+    }
+    case S3_OPT_ADAMW: {
+      if (!need(5)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(AdamW): {lr, beta_1, beta_2, epsilon, weight_decay}");
+      const float b1p = powf(hp[1], (float)t), b2p = powf(hp[2], (float)t);
+      h[0] = hp[0] * sqrtf(1.f - b2p) / (1.f - b1p);
+      h[1] = 1.f - hp[1]; h[2] = 1.f - hp[2]; h[3] = hp[3]; h[4] = hp[4] * hp[0];
+      break;
+    }
+    default: S3_FAIL(ctx, S3_EINVAL, "optimizer_step: unknown optimizer kind");
+  }
+  int rc = launch_optimizer(ctx, kind, p->buf[S3_BUF_W], p->buf[S3_BUF_G], p->buf[S3_BUF_M],
+                            p->buf[S3_BUF_V], p->total, h);
+  if (rc) return rc;
+  p->version++;
+  return S3_OK;
+}
+
 // --------------------------------------------------------------------- plan
 static int64_t numel5(const int64_t* d) { return d[0] * d[1] * d[2] * d[3] * d[4]; }
 

@@ -392,6 +392,12 @@ class Network:
                                      int(t))
         _lib.check(rc, self.dev.ctx, 's3_adam_step')
 
+    def optimizer_step(self, kind, hyper, t):
+        hp = (C.c_float * len(hyper))(*[float(v) for v in hyper])
+        rc = _lib.lib().s3_optimizer_step(self.params, int(kind), hp,
+                                          len(hyper), int(t))
+        _lib.check(rc, self.dev.ctx, 's3_optimizer_step')
+
     def allreduce_grads(self):
         rc = _lib.lib().s3_params_allreduce_grads(self.params)
         _lib.check(rc, self.dev.ctx, 's3_params_allreduce_grads')
@@ -431,16 +437,49 @@ class Network:
 
     @classmethod
     def load(cls, fp, device=None, precision=None):
+        hidden, weights, name = read_network_file(fp)
+        net = cls(hidden, name=name, device=device, precision=precision)
+        net._from_file = True
+        if weights:
+            net._pending = weights
+        return net
+
+
+def read_network_file(fp):
+    """(hidden_layers, weights | None, name) of a saved network.
+
+    Two layouts: this package's ``sup3r_amd.network.v1`` (``Network.save`` and
+    ``tools/convert_phygnn_pkl.py``), and the ``model_params`` dict that
+    ``phygnn.CustomNetwork.save`` pickles — builtins and numpy arrays only:
+    ``hidden_layers`` (the layer list the network was built from) and
+    ``weight_dict`` (expanded layer index -> that layer's ``get_weights()``),
+    which flattens to the keras-order weight list.  The second layout is
+    restated from phygnn 0.0.33's published source and could not be checked
+    against a real file here (phygnn is not installable in this image): the
+    converter, run where phygnn is, remains the authoritative route, and a
+    pickle that needs phygnn / TF classes to unpickle raises a ``TypeError``
+    saying so."""
+    try:
         with open(fp, 'rb') as f:
             d = pickle.load(f)
-        if not isinstance(d, dict) or d.get('format') != \
-                'sup3r_amd.network.v1':
-            raise TypeError(
-                f'{fp} is not a sup3r_amd network file (phygnn .pkl files '
-                'need phygnn to be converted)')
-        net = cls(d['hidden_layers'], name=d['name'], device=device,
-                  precision=precision)
-        net._from_file = True
-        if d['weights']:
-            net._pending = d['weights']
-        return net
+    except (ModuleNotFoundError, AttributeError, ImportError) as e:
+        raise TypeError(
+            f'{fp} needs classes that are not importable here ({e}); convert '
+            'it with tools/convert_phygnn_pkl.py on a machine that has '
+            'phygnn') from e
+    if isinstance(d, dict) and d.get('format') == 'sup3r_amd.network.v1':
+        return d['hidden_layers'], (d['weights'] or None), d.get('name')
+    if isinstance(d, dict) and 'hidden_layers' in d and \
+            ('weight_dict' in d or 'weights' in d):
+        if 'weight_dict' in d:
+            wd = d['weight_dict']
+            keys = sorted(wd, key=lambda k: int(k))
+            flat = [np.asarray(a, np.float32) for k in keys
+                    for a in (wd[k] or [])]
+        else:
+            flat = [np.asarray(a, np.float32) for a in d['weights']]
+        return d['hidden_layers'], (flat or None), d.get('name')
+    raise TypeError(
+        f'{fp} is neither a sup3r_amd network file nor a phygnn '
+        'CustomNetwork model_params pickle (keys: '
+        f'{sorted(d) if isinstance(d, dict) else type(d).__name__})')

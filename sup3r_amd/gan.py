@@ -124,14 +124,9 @@ class Sup3rGan:
                 f'{model}: no "hidden_layers" (nor "meta/config_{role}/'
                 f'hidden_layers") among {sorted(cfg)}')
         if isinstance(model, str) and model.endswith('.pkl'):
-            import pickle
-            with open(model, 'rb') as f:
-                blob = pickle.load(f)
-            if isinstance(blob, dict) and \
-                    blob.get('format') == 'sup3r_amd.network.v1':
-                return blob['hidden_layers'], (blob['weights'] or None)
-            raise TypeError(f'"{model}" is not a sup3r_amd network file '
-                            '(a phygnn pickle needs phygnn to be converted)')
+            from .engine import read_network_file
+            hidden, weights, _ = read_network_file(model)
+            return hidden, weights
         raise TypeError(f'cannot build the {role} from a '
                         f'{type(model).__name__}')
 
@@ -346,6 +341,10 @@ class Sup3rGan:
             key = exo_name if exo_name in self._means else \
                 exo_name.replace('_obs', '')
             exo = (exo.copy() - self._means[key]) / self._stdevs[key]
+        if exo_name in self.obs_features:
+            # sparse observations: NaN = not observed (with_obs.py:24-29);
+            # carried as 0 in normalised units (spec.py, Sup3rConcatObs)
+            exo = np.nan_to_num(exo, nan=0.0)
         if exo.ndim == 3:                       # (s1, s2, 1): one per sample
             exo = np.broadcast_to(exo[None], (hr_shape[0],) + exo.shape)
         if exo.ndim == 4 and len(hr_shape) == 5:    # constant in time
@@ -374,6 +373,14 @@ class Sup3rGan:
             for name in ph.input_names:
                 if name == 'x':
                     continue
+                if name in self.obs_features and (
+                        exogenous_data is None or name not in exogenous_data):
+                    # the reference runs the obs layer without the field and
+                    # the next layer fails on the channel count
+                    # (abstract.py:1003-1013 -> :1093-1098)
+                    raise RuntimeError(
+                        f'exogenous_data is missing observation feature '
+                        f'"{name}": the generator cannot run without it')
                 assert exogenous_data is not None and \
                     name in exogenous_data, \
                     f'the generator needs exogenous feature "{name}"'
@@ -385,7 +392,7 @@ class Sup3rGan:
                     name, norm_in=norm_in)
                 layer_exo[name] = dev.to_device(arr.astype(np.float32))
             hi_res = ph.forward(dev.to_device(x), layer_exo)
-        except AssertionError:
+        except (AssertionError, RuntimeError):
             raise
         except Exception as e:
             raise RuntimeError(f'generator failed on input of shape '

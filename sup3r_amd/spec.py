@@ -118,7 +118,7 @@ SUPPORTED = ('FlexiblePadding', 'Conv2D', 'Conv3D', 'Conv2DTranspose',
              'Conv3DTranspose',
              'Cropping2D', 'Cropping3D', 'LeakyReLU', 'Activation', 'ReLU',
              'SkipConnection', 'SpatialExpansion', 'SpatioTemporalExpansion',
-             'Flatten', 'Dense', 'Sup3rConcat', 'Sup3rAdder')
+             'Flatten', 'Dense', 'Sup3rConcat', 'Sup3rAdder', 'Sup3rConcatObs')
 
 
 # keras kwargs a layer may carry: the ones the lowering reads, and the ones
@@ -576,10 +576,17 @@ def build_plan(layers, in_shape, param_table=None, fuse=True):
                                      sh[4] // (b * b)])
                 plan.ops.append(dict(kind=OP_D2S, in0=cur, out=t, d2s=b))
                 cur = t
-        elif cls in EXO_CLASSES:
+        elif cls in EXO_CLASSES or cls == 'Sup3rConcatObs':
+            # Sup3rConcatObs (phygnn, not vendored): a sparse observation
+            # field joins the tensor as one more channel.  Its NaN handling
+            # cannot be restated from anything under /root/reference; here an
+            # un-observed cell carries 0 in normalised units (the feature
+            # mean) — the fill is applied where the field is prepared
+            # (Sup3rGan._reshape_norm_exo / Sup3rGanWithObs), the device op is
+            # the plain concat.  UNVERIFIED against phygnn.
             flush_pad()
             sh = cur_dims()
-            if cls == 'Sup3rConcat':
+            if cls in ('Sup3rConcat', 'Sup3rConcatObs'):
                 e = plan.new_tensor(sh[:4] + [1])
                 plan.inputs[L.name] = e
                 t = plan.new_tensor(sh[:4] + [sh[4] + 1])

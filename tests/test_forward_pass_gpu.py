@@ -145,9 +145,9 @@ def test_strategy_chunks_with_exo_on_the_device(tmp_path):
     model = _topo_model()
     register_model('Sup3rGan', {'model_dir': 'topo-test'}, model)
     rng = np.random.default_rng(4)
-    domain = (rng.standard_normal((13, 11, 14, 2)) * 2 + 0.3).astype(
+    domain = (rng.standard_normal((14, 10, 14, 2)) * 2 + 0.3).astype(
         np.float32)
-    topo = (300 + 150 * rng.standard_normal((39, 33, 1))).astype(np.float32)
+    topo = (300 + 150 * rng.standard_normal((42, 30, 1))).astype(np.float32)
     exo = {'topography': {'steps': [
         {'model': 0, 'combine_type': 'layer', 'data': topo, 's_enhance': 3,
          't_enhance': 4}]}}
@@ -155,7 +155,7 @@ def test_strategy_chunks_with_exo_on_the_device(tmp_path):
     def strategy(**kw):
         return ArrayStrategy(domain, {'model_dir': 'topo-test'}, (6, 5, 6),
                              spatial_pad=1, temporal_pad=1, exo_data=exo,
-                             lat_lon=_lat_lon(39, 33), **kw)
+                             lat_lon=_lat_lon(42, 30), **kw)
     st = strategy()
     sl = st.fwp_slicer
     # reference-shaped path, chunk by chunk through model.generate
@@ -216,7 +216,7 @@ def test_strategy_chunks_with_exo_on_the_device(tmp_path):
     hs = sl.chunks[3]['hr_slice']
     want, _ = transform_output(
         ref[hs].astype(np.float64), ['u_10m', 'v_10m'],
-        _lat_lon(39, 33)[hs[0], hs[1]], True, nn_fill=False)
+        _lat_lon(42, 30)[hs[0], hs[1]], True, nn_fill=False)
     assert np.abs(f3['data'][..., 0] - want[..., 0]).max() < 1e-4
     d = np.abs(f3['data'][..., 1] - want[..., 1])
     assert np.minimum(d, 360 - d).max() < 5e-2
