@@ -495,6 +495,38 @@ def cpu_legs(spec, dev, seconds_budget=30.0):
     }, parity
 
 
+def child_leg(leg_args, world, k, limit):
+    """One more bench mode on the same GPUs in a fresh group of processes
+    (every rank spawns its own child with its RANK / LOCAL_RANK and a
+    rendezvous port of its own).  Returns rank 0's JSON line, or what went
+    wrong — a crash or a hang in there never reaches the caller."""
+    env = dict(os.environ)
+    env['MASTER_PORT'] = str(int(env.get('MASTER_PORT', '29500')) + 101
+                             + 7 * k)
+    for var in ('TORCHELASTIC_RUN_ID', 'TORCHELASTIC_RESTART_COUNT',
+                'TORCHELASTIC_MAX_RESTARTS', 'TORCHELASTIC_USE_AGENT_STORE'):
+        env.pop(var, None)
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world)] \
+        + list(leg_args)
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                           timeout=limit)
+    except subprocess.TimeoutExpired:
+        return {'error': f'timed out after {limit} s', 'cmd': leg_args}
+    except Exception as e:
+        return {'error': repr(e)[:300], 'cmd': leg_args}
+    for line in reversed(p.stdout.strip().splitlines()):
+        if line.startswith('{'):
+            try:
+                return json.loads(line)
+            except Exception:
+                break
+    if int(env.get('RANK', '0')) != 0 and p.returncode == 0:
+        return {}
+    return {'error': f'exit code {p.returncode}',
+            'stderr_tail': p.stderr[-600:], 'cmd': leg_args}
+
+
 # ----------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -532,6 +564,7 @@ def main():
     ap.add_argument('--dump-ops', default=None,
                     help='write per-op mean ms of the timed region here')
     ap.add_argument('--inner-pmc', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--force-legs', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.inner_pmc:
         args.batch = args.batch or 32
@@ -682,25 +715,12 @@ def main():
     elapsed = max_over_ranks(elapsed)
     assert torch.isfinite(out).all().item()
 
-    # a short data-parallel training leg in the multi-GPU run as well: the
-    # RCCL gradient SUM is then exercised (and timed) whenever the driver has
-    # an N-GPU node.  A watchdog prints the headline without it if a
-    # collective should hang.
-    train_multi = None
-    if world > 1 and args.precision == 'bf16' and not args.no_train:
-        done = threading.Event()
-        result_holder = {}
-
-        def watchdog():
-            if not done.wait(240.0):
-                if rank == 0 and 'line' in result_holder:
-                    r = dict(result_holder['line'])
-                    r['train'] = {'error': 'multi-GPU training leg timed out'}
-                    print(json.dumps(r), flush=True)
-                os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
-    else:
-        done, result_holder = None, {}
+    # Multi-GPU run: the data-parallel training step (RCCL gradient SUM) and
+    # the chunk-sharded C3 executor are measured as well, each in its OWN
+    # group of child processes (same ranks, another rendezvous port) after the
+    # headline is complete — a collective that hangs or a runtime that aborts
+    # there costs that leg, never the headline line.
+    result_holder = {}
 
     ms_per_step = elapsed / args.steps * 1e3
     samples_per_s = world * B * args.steps / elapsed
@@ -755,16 +775,18 @@ def main():
                                          ph.plan.tensors[op['out']]),
                                 int(ph.op_is_mfma(i)), ms[i]))
     result_holder['line'] = result
-    if world > 1:
-        if done is not None:
-            try:
-                train_multi = train_leg('c2', 8 * world, world, rank, 3.0, 40,
-                                        multi_gpu=True)
-            except Exception as e:          # the headline must survive
-                train_multi = {'error': repr(e)[:300]}
-            done.set()
-            if rank == 0:
-                result['train'] = train_multi
+    if world > 1 or args.force_legs:
+        if args.precision == 'bf16' and not args.no_train:
+            legs = (('train', ['--mode', 'train', '--config', 'c2', '--steps',
+                               '20'], 300),
+                    ('c3', ['--mode', 'c3', '--steps', '3', '--warmup', '1'],
+                     300),
+                    ('train_c4', ['--mode', 'train', '--config', 'c4',
+                                  '--steps', '20'], 240))
+            for k, (name, leg_args, limit) in enumerate(legs):
+                sub = child_leg(leg_args, world, k, limit)
+                if rank == 0:
+                    result[name] = sub
         if rank == 0:
             print(json.dumps(result), flush=True)
         return

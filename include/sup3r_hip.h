@@ -97,7 +97,8 @@ void* s3_ctx_stream(s3_ctx* ctx);
  * counter */
 enum { S3_STAT_PERSIST_DGRAD = 0, /* trunk data gradients on the persistent kernel */
        S3_STAT_GCONV_SPLITK = 1,  /* gather-MFMA launches with a split contraction  */
-       S3_STAT_COUNT = 2 };
+       S3_STAT_BUCKET_ELEMS = 2,  /* gradient elements all-reduced bucket by bucket  */
+       S3_STAT_COUNT = 3 };
 int64_t s3_ctx_stat(const s3_ctx* ctx, int which);
 
 /* ---- parameter store ---------------------------------------------------
@@ -134,7 +135,8 @@ int s3_adam_step(s3_params* p, float lr, float beta1, float beta2, float eps,
 /* The other keras optimizers ``init_optimizer`` may be handed by name
  * (abstract.py:321-350, models/utilities.py:150-158), keras-2.15
  * ``update_step`` each, one fused pass over the store (slots: BUF_M / BUF_V).
- * hp[]: Adam {lr, beta_1, beta_2, epsilon}; SGD {lr, momentum, nesterov};
+ * hp[] (doubles, cast like keras casts its Python scalars: 1 - beta in double,
+ * then fp32): Adam {lr, beta_1, beta_2, epsilon}; SGD {lr, momentum, nesterov};
  * RMSprop {lr, rho, momentum, epsilon} (centered=False); Adagrad {lr,
  * epsilon, initial_accumulator_value}; Adamax {lr, beta_1, beta_2, epsilon};
  * AdamW {lr, beta_1, beta_2, epsilon, weight_decay}. */
@@ -142,8 +144,31 @@ typedef enum {
   S3_OPT_ADAM = 0, S3_OPT_SGD = 1, S3_OPT_RMSPROP = 2, S3_OPT_ADAGRAD = 3,
   S3_OPT_ADAMAX = 4, S3_OPT_ADAMW = 5
 } s3_optimizer_kind;
-int s3_optimizer_step(s3_params* p, int kind, const float* hp, int n_hp,
+int s3_optimizer_step(s3_params* p, int kind, const double* hp, int n_hp,
                       int64_t t);
+
+/* ---- options ---------------------------------------------------------------
+ * Kernel-selection switches (the A/B comparisons of the parity tests, the
+ * profiling ablations) are options of a context and of the plans created from
+ * it, not process environment: `NO_PERSIST`, `NO_WGRAD_BF16`, `MFMA_TILE`,
+ * `HALO32_MIN_TILES`, ... (s3_option_name_at enumerates them; DESIGN.md §5.4
+ * says what each one does).  An option is unset (the default behaviour) or
+ * carries an int32.  s3_ctx_create reads the variables SUP3R_AMD_<NAME> ONCE
+ * as the initial defaults of that context; nothing reads the environment
+ * afterwards.  A plan snapshots the context's options when it is created,
+ * overridden by the `options` of s3_plan_create_opt; the snapshot governs
+ * that plan's forward / backward launches. */
+#define S3_OPTION_UNSET INT32_MIN
+typedef struct {
+  int32_t n;                  /* number of (name, value) pairs */
+  const char* const* names;   /* "NO_PERSIST" (or "SUP3R_AMD_NO_PERSIST") */
+  const int32_t* values;      /* S3_OPTION_UNSET removes the option */
+} s3_plan_options;
+int s3_ctx_set_option(s3_ctx* ctx, const char* name, int32_t value);
+/* returns 1 if the option is set (value written), 0 if unset, < 0 unknown */
+int s3_ctx_get_option(const s3_ctx* ctx, const char* name, int32_t* value);
+/* option names, index 0 .. until NULL */
+const char* s3_option_name_at(int index);
 
 /* ---- plan (shape-specialised executor) ---------------------------------
  * replaces: the eager/graph layer loops AbstractSingleModel._tf_generate
@@ -155,6 +180,12 @@ int s3_plan_create(s3_ctx* ctx, s3_params* params, const s3_tensor_desc* tensors
                    int n_tensors, const s3_op_desc* ops, int n_ops,
                    const int32_t* inputs, int n_inputs, int32_t output,
                    int precision, int training, s3_plan** out);
+/* the same with per-plan options on top of the context's (NULL = none) */
+int s3_plan_create_opt(s3_ctx* ctx, s3_params* params, const s3_tensor_desc* tensors,
+                       int n_tensors, const s3_op_desc* ops, int n_ops,
+                       const int32_t* inputs, int n_inputs, int32_t output,
+                       int precision, int training, const s3_plan_options* options,
+                       s3_plan** out);
 void s3_plan_destroy(s3_plan* plan);
 /* inputs: device pointers (fp32, NDHWC) in the order given at creation;
  * output: device pointer receiving the result, or NULL to leave it in the
@@ -426,6 +457,14 @@ int s3_comm_unique_id(void* out128); /* rank 0; 128 bytes                  */
 int s3_comm_init(s3_ctx* ctx, int rank, int nranks, const void* unique_id128);
 int s3_params_allreduce_grads(s3_params* p);
 int s3_allreduce_sum(s3_ctx* ctx, float* buf, int64_t n);
+/* Overlap with the backward pass: arm the store BEFORE the s3_plan_backward
+ * call that finalises its gradients (need_wgrad; the last one when several
+ * accumulate).  That call then hands the finished tail of the gradient buffer
+ * to RCCL bucket by bucket (>= bucket_bytes each; <= 0: one bucket) on a second
+ * stream behind an event, so the xGMI traffic runs under the remaining
+ * gradient kernels; the following s3_params_allreduce_grads only joins the two
+ * streams.  Every rank arms the same store with the same bucket size. */
+int s3_params_arm_allreduce(s3_params* p, int64_t bucket_bytes);
 /* replicas must start from identical weights (the reference's towers read ONE
  * set of tf.Variables, abstract.py:827-841): ncclBroadcast of a store buffer
  * (S3_BUF_*) / any fp32 buffer from rank `root` */

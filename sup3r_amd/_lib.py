@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get('SUP3R_AMD_LIB') or os.path.join(
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 LOSS_MAE, LOSS_MSE, LOSS_EXP = 0, 1, 2
 BUF_W, BUF_G, BUF_M, BUF_V = 0, 1, 2, 3
+OPT_ADAM = 0
 PRECISIONS = {'f32': PREC_F32, 'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
 
 EXPORTS = [
@@ -24,7 +25,8 @@ EXPORTS = [
     's3_params_total', 's3_params_set', 's3_params_get', 's3_params_dptr',
     's3_params_zero_grad', 's3_params_version', 's3_params_mean_abs',
     's3_adam_step', 's3_optimizer_step',
-    's3_plan_create', 's3_plan_destroy', 's3_plan_forward',
+    's3_ctx_set_option', 's3_ctx_get_option', 's3_option_name_at',
+    's3_plan_create', 's3_plan_create_opt', 's3_plan_destroy', 's3_plan_forward',
     's3_plan_backward', 's3_plan_tensor', 's3_plan_workspace_bytes',
     's3_plan_profile_begin', 's3_plan_profile_end',
     's3_plan_op_is_mfma', 's3_plan_op_info', 's3_plan_tensor_dtype', 's3_plan_tensor_read',
@@ -38,9 +40,18 @@ EXPORTS = [
     's3_host_register', 's3_host_unregister', 's3_d2h_window',
     's3_invert_uv', 's3_clip_channels', 's3_range_mask', 's3_fill_indexed',
     's3_comm_unique_id', 's3_comm_init', 's3_params_allreduce_grads',
+    's3_params_arm_allreduce',
     's3_allreduce_sum', 's3_params_broadcast', 's3_broadcast',
     's3_comm_destroy', 's3_version',
 ]
+
+
+OPTION_UNSET = -2 ** 31
+
+
+class PlanOptions(C.Structure):
+    _fields_ = [('n', C.c_int32), ('names', C.POINTER(C.c_char_p)),
+                ('values', C.POINTER(C.c_int32))]
 
 
 class TensorDesc(C.Structure):
@@ -102,10 +113,17 @@ def lib():
         's3_params_version': (u64, [vp]),
         's3_params_mean_abs': (i32, [vp, i32, i32, pf]),
         's3_adam_step': (i32, [vp, f32, f32, f32, f32, i64]),
-        's3_optimizer_step': (i32, [vp, i32, pf, i32, i64]),
+        's3_optimizer_step': (i32, [vp, i32, C.POINTER(C.c_double), i32, i64]),
         's3_plan_create': (i32, [vp, vp, C.POINTER(TensorDesc), i32,
                                  C.POINTER(OpDesc), i32, C.POINTER(i32), i32,
                                  i32, i32, i32, C.POINTER(vp)]),
+        's3_plan_create_opt': (i32, [vp, vp, C.POINTER(TensorDesc), i32,
+                                     C.POINTER(OpDesc), i32, C.POINTER(i32),
+                                     i32, i32, i32, i32,
+                                     C.POINTER(PlanOptions), C.POINTER(vp)]),
+        's3_ctx_set_option': (i32, [vp, C.c_char_p, i32]),
+        's3_ctx_get_option': (i32, [vp, C.c_char_p, C.POINTER(i32)]),
+        's3_option_name_at': (C.c_char_p, [i32]),
         's3_plan_destroy': (None, [vp]),
         's3_plan_forward': (i32, [vp, C.POINTER(vp), vp]),
         's3_plan_backward': (i32, [vp, vp, vp, i32, i32]),
@@ -157,6 +175,7 @@ def lib():
         's3_comm_unique_id': (i32, [vp]),
         's3_comm_init': (i32, [vp, i32, i32, vp]),
         's3_params_allreduce_grads': (i32, [vp]),
+        's3_params_arm_allreduce': (i32, [vp, i64]),
         's3_allreduce_sum': (i32, [vp, vp, i64]),
         's3_params_broadcast': (i32, [vp, i32, i32]),
         's3_broadcast': (i32, [vp, vp, i64, i32]),
@@ -170,7 +189,29 @@ def lib():
     return L
 
 
-STATS = {'persist_dgrad': 0, 'gconv_splitk': 1}
+STATS = {'persist_dgrad': 0, 'gconv_splitk': 1, 'bucket_elems': 2}
+
+
+def option_names():
+    """names of the context / plan options (include/sup3r_hip.h)"""
+    L, out, i = lib(), [], 0
+    while True:
+        name = L.s3_option_name_at(i)
+        if not name:
+            return out
+        out.append(name.decode())
+        i += 1
+
+
+def plan_options(options):
+    """dict name -> int | None (None = unset) as an ``s3_plan_options``
+    (+ the ctypes arrays it points into, to be kept alive by the caller)"""
+    items = sorted((options or {}).items())
+    n = len(items)
+    names = (C.c_char_p * max(n, 1))(*[k.encode() for k, _ in items])
+    values = (C.c_int32 * max(n, 1))(*[
+        OPTION_UNSET if v is None else int(v) for _, v in items])
+    return PlanOptions(n, names, values), (names, values)
 
 # s3_plan_op_info fields / codes (include/sup3r_hip.h)
 OPINFO_FIELDS = ('kind', 'fwd', 'in16', 'out16', 'res16', 'fwd_bf16_ops',

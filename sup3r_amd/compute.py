@@ -141,6 +141,9 @@ class HipGanCompute:
     """Generator / discriminator pair on one GPU."""
 
     supports_defer = True
+    # tests switch the sharing of D(hi_res_true) inside a mini-batch off to
+    # compare against recomputing it
+    share_dtrue_allowed = True
 
     def __init__(self, gen_layers, disc_layers, device=None, precision=None):
         self.dev = device or Device.get()
@@ -230,7 +233,7 @@ class HipGanCompute:
                tuple(hr_true.shape), self.disc.weights_version, id(dph),
                bool(training))
         share = getattr(self, 'share_dtrue', False) and \
-            not os.environ.get('SUP3R_AMD_NO_DTRUE_REUSE')
+            self.share_dtrue_allowed
         hit = getattr(self, '_dtrue', None)
         if share and hit is not None and hit[0] == key:
             return hit[1]
@@ -252,8 +255,13 @@ class HipGanCompute:
                        train_disc=False, compute_disc=False, exo_names=(),
                        backward=True, hi_res_gen=None, mask=None,
                        accumulate_wgrad=False, scal=None, defer=False,
-                       extra_exo=None, obs=None):
+                       extra_exo=None, obs=None, overlap_bucket=None):
         """One ``_get_hr_exo_and_loss`` + ``tape.gradient``.
+
+        ``overlap_bucket`` (bytes): the trained network's gradients are final
+        after this call — its last backward pass hands them to RCCL bucket by
+        bucket while it runs (``s3_params_arm_allreduce``); the caller's
+        ``allreduce_grads`` then only joins the streams.
 
         ``extra_exo``: further named generator inputs (the sparse observation
         fields of ``Sup3rGanWithObs``).  ``obs`` = (observed-cell mask as a
@@ -415,6 +423,8 @@ class HipGanCompute:
                     self._copy_channels(d_gen_full, 0, d_hr_gen, 0, c_gen)
                 else:
                     d_hr_gen = d_gen_full
+                if overlap_bucket:
+                    self.gen.arm_allreduce(overlap_bucket)
                 gph.backward(d_hr_gen, need_wgrad=True,
                              accumulate_wgrad=accumulate_wgrad)
             loss_key = 'loss_gen'
@@ -422,6 +432,8 @@ class HipGanCompute:
             if disc_train:
                 dph_t.backward(g_t, need_wgrad=True,
                                accumulate_wgrad=accumulate_wgrad)
+                if overlap_bucket:
+                    self.disc.arm_allreduce(overlap_bucket)
                 dph_g.backward(g_g, need_wgrad=True, accumulate_wgrad=True)
             loss_key = 'loss_disc'
         with_disc = need_disc and (compute_disc or train_disc)

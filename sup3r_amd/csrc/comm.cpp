@@ -91,6 +91,45 @@ extern "C" int s3_allreduce_sum(s3_ctx* ctx, float* buf, int64_t n) {
   return S3_OK;
 }
 
+// ---- bucketed all-reduce overlapped with the backward pass ----------------
+// s3_plan_backward hands over the finished tail of the gradient buffer bucket
+// by bucket (plan.cpp); each bucket is reduced on a second stream behind an
+// event on the compute stream, so RCCL's xGMI traffic runs under the
+// remaining weight / data gradient kernels.  Collectives are issued in the
+// same order on every rank (the op order of the plan).
+static int comm_stream_ready(s3_ctx* ctx) {
+  if (ctx->comm_stream) return S3_OK;
+  S3_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i)
+    S3_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_ev[i], hipEventDisableTiming));
+  return S3_OK;
+}
+
+extern "C" int s3_comm_reduce_range(s3_ctx* ctx, float* buf, int64_t n) {
+  if (!ctx || !buf || n <= 0) return S3_EINVAL;
+  if (!ctx->comm) return S3_OK;               // single rank: nothing to sum
+  int rc = comm_stream_ready(ctx);
+  if (rc) return rc;
+  S3_HIP(ctx, hipEventRecord(ctx->comm_ev[0], ctx->stream));
+  S3_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ev[0], 0));
+  const int nrc = g_rccl.allreduce(buf, buf, (size_t)n, kNcclFloat32, kNcclSum, ctx->comm,
+                                   ctx->comm_stream);
+  if (nrc != 0) {
+    ctx->err = std::string("ncclAllReduce (bucket): ") + (g_rccl.errstr ? g_rccl.errstr(nrc) : "error");
+    return S3_ERCCL;
+  }
+  ctx->stat[S3_STAT_BUCKET_ELEMS] += n;
+  return S3_OK;
+}
+
+// the compute stream continues only after every bucket has been reduced
+static int comm_join(s3_ctx* ctx) {
+  if (!ctx->comm || !ctx->comm_stream) return S3_OK;
+  S3_HIP(ctx, hipEventRecord(ctx->comm_ev[1], ctx->comm_stream));
+  S3_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_ev[1], 0));
+  return S3_OK;
+}
+
 extern "C" int s3_broadcast(s3_ctx* ctx, float* buf, int64_t n, int root) {
   if (!ctx || !buf || n < 0) return S3_EINVAL;
   if (ctx->nranks <= 1 && !ctx->comm) return S3_OK;
@@ -125,5 +164,9 @@ extern "C" int s3_params_broadcast(s3_params* p, int which, int root) {
 extern "C" int s3_params_allreduce_grads(s3_params* p) {
   if (!p) return S3_EINVAL;
   s3_ctx* ctx = reinterpret_cast<s3_params_view*>(p)->ctx;
+  int n_buckets = 0;
+  const int armed = s3_params_take_armed(p, &n_buckets);
+  if (armed == 1) return comm_join(ctx);       // reduced bucket by bucket under the backward pass
+  if (armed < 0) S3_FAIL(ctx, S3_ESTATE, "allreduce: the armed backward pass did not cover the gradient buffer");
   return s3_allreduce_sum(ctx, (float*)s3_params_dptr(p, S3_BUF_G, -1), s3_params_total(p));
 }

@@ -9,6 +9,92 @@
 
 #include "../../include/sup3r_hip.h"
 
+
+// ---- plan / context options -------------------------------------------------
+// Kernel-selection switches (A/B comparisons in the tests, profiling
+// ablations) are OPTIONS of a context and of the plans created from it — set
+// through s3_ctx_set_option / s3_plan_create_opt (include/sup3r_hip.h), not
+// read from the process environment while running.  The environment is read
+// ONCE, by s3_ctx_create, as the initial defaults of that context (variable
+// SUP3R_AMD_<NAME>; developer convenience for tools/ab.sh and the profilers).
+// A plan snapshots its options when it is created; its entry points make them
+// the calling thread's active set for the duration of the call.
+#define S3_OPTION_LIST(X) \
+  X(BF16_TRAIN_ACT) \
+  X(DENSE_WGS) \
+  X(DGRAD_S2_MIN_TILES) \
+  X(DISC_BF16) \
+  X(FEWCH_HALO_MIN_TILES) \
+  X(FP32_ACT) \
+  X(GCONV_MF2) \
+  X(GCONV_MF4) \
+  X(GRAPH) \
+  X(HALO32_MIN_TILES) \
+  X(HALO_S2_MIN_TILES) \
+  X(MFMA_DBG) \
+  X(MFMA_TILE) \
+  X(NO_BATCHED_PACK) \
+  X(NO_BIAS_FUSE) \
+  X(NO_CHUNKED_DY16) \
+  X(NO_DGRAD_C2) \
+  X(NO_DGRAD_CHUNKED) \
+  X(NO_DGRAD_FEWCH) \
+  X(NO_DGRAD_S2) \
+  X(NO_DISC_BF16) \
+  X(NO_DPRE16) \
+  X(NO_FEWCH) \
+  X(NO_FEWCH_HALO) \
+  X(NO_FEWPOS) \
+  X(NO_FOLD16) \
+  X(NO_FUSED2D) \
+  X(NO_GCONV) \
+  X(NO_GCONV_DY16) \
+  X(NO_GCONV_SPLITK) \
+  X(NO_HALO32) \
+  X(NO_HALO_S2) \
+  X(NO_MASK_FUSE) \
+  X(NO_MFMA_BWD) \
+  X(NO_PERSIST) \
+  X(NO_PERSIST_DGRAD) \
+  X(NO_PLAIN_FOLD16) \
+  X(NO_SEG_REDUCE) \
+  X(NO_TAIL_BAND) \
+  X(NO_TAIL_MFMA) \
+  X(NO_TAIL_SLIDE) \
+  X(NO_TILE66) \
+  X(NO_TILE_NF2) \
+  X(NO_WGRAD_BF16) \
+  X(NO_WGRAD_C2) \
+  X(NO_WGRAD_GEN_PF) \
+  X(NO_WGRAD_TAIL) \
+  X(NO_WGRAD_WS) \
+  X(PERSIST_DGRAD_MIN_TILES) \
+  X(POISON_ALLOC) \
+  X(TRACE) \
+  X(WGRAD_DBG)
+enum S3OptId {
+#define X(n) S3O_##n,
+  S3_OPTION_LIST(X)
+#undef X
+  S3O_COUNT
+};
+struct S3Options {
+  int32_t v[S3O_COUNT];
+  bool has[S3O_COUNT];
+  S3Options() { for (int i = 0; i < S3O_COUNT; ++i) { v[i] = 0; has[i] = false; } }
+};
+extern thread_local const S3Options* s3_active_options;
+const char* s3_option_name(int id);
+int s3_option_id(const char* name);      // accepts "NO_PERSIST" or "SUP3R_AMD_NO_PERSIST"; -1 if unknown
+inline bool s3_opt_has(int id) { return s3_active_options && s3_active_options->has[id]; }
+inline long long s3_opt_int(int id, long long dflt) { return s3_opt_has(id) ? s3_active_options->v[id] : dflt; }
+inline bool s3_opt_on(int id) { return s3_opt_int(id, 0) != 0; }
+struct S3OptScope {
+  const S3Options* prev;
+  explicit S3OptScope(const S3Options* o) : prev(s3_active_options) { s3_active_options = o; }
+  ~S3OptScope() { s3_active_options = prev; }
+};
+
 struct s3_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -20,6 +106,9 @@ struct s3_ctx {
   size_t scratch_bytes = 0;
   int num_cu = 256;
   int64_t stat[4] = {0, 0, 0, 0};   // S3_STAT_* launch counters
+  S3Options opt;                     // defaults of the plans created from this context
+  hipStream_t comm_stream = nullptr; // bucketed gradient all-reduce under the backward pass
+  hipEvent_t comm_ev[2] = {nullptr, nullptr};   // [0] compute -> comm, [1] comm -> compute
 };
 
 #define S3_HIP(ctx, call)                                                    \
@@ -288,10 +377,14 @@ int launch_dense_dgrad(s3_ctx* ctx, const float* dy, const float* w, float* dx,
 int launch_dense_wgrad(s3_ctx* ctx, const float* x, const float* dy, float* dw,
                        int n, int cin, int cout, int accumulate);
 int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
-                int64_t n, float alpha, float b1, float b2, float eps);
+                int64_t n, float alpha, float one_minus_b1, float one_minus_b2, float eps);
 int launch_optimizer(s3_ctx* ctx, int kind, float* w, const float* g, float* m, float* v,
                      int64_t n, const float* h);
 int launch_fill(s3_ctx* ctx, float* p, int64_t n, float v);
+// comm.cpp: SUM over the ranks of buf[0 .. n) on the context's comm stream,
+// after everything enqueued so far on its compute stream
+extern "C" int s3_comm_reduce_range(s3_ctx* ctx, float* buf, int64_t n);
+extern "C" int s3_params_take_armed(s3_params* p, int* n_buckets);
 int launch_mean_abs(s3_ctx* ctx, const float* p, int64_t n, float* out_dev);
 int ensure_scratch(s3_ctx* ctx, size_t bytes);
 

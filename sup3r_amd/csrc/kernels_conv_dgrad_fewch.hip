@@ -185,7 +185,7 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }  // namespace
 
 bool conv_dgrad_c2_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_DGRAD_C2")) return false;
+  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_DGRAD_C2)) return false;
   if (g.Cin < 1 || g.Cin > 4 || g.Cout != 32 || g.d2s != 1) return false;
   if (g.pad_mode == S3_PAD_REFLECT) return false;
   for (int d = 0; d < 3; ++d) {

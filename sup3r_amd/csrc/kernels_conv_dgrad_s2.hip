@@ -237,14 +237,14 @@ int s2_rows_pad(int cin) { return (cin + 63) / 64 * 64; }
 }  // namespace
 
 bool conv_dgrad_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_DGRAD_S2")) return false;
+  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_DGRAD_S2)) return false;
   if (g.Cout != 32 || g.Cin % 16 != 0 || g.Cin < 16 || g.d2s != 1) return false;
   for (int d = 0; d < 3; ++d) {
     if (g.k[d] != 3 || g.s[d] != 2 || g.lo[d] != 0) return false;
     // valid padding: every x position i < D has its sources inside or zero; u grid covers D
     if ((g.O[d] - 1) * 2 + 3 > g.D[d]) return false;
   }
-  const int64_t min_tiles = getenv("SUP3R_AMD_DGRAD_S2_MIN_TILES") ? atoll(getenv("SUP3R_AMD_DGRAD_S2_MIN_TILES"))
+  const int64_t min_tiles = s3_opt_has(S3O_DGRAD_S2_MIN_TILES) ? s3_opt_int(S3O_DGRAD_S2_MIN_TILES, 0)
                                                                    : ctx->num_cu;
   int64_t tiles = g.N;
   const int T[3] = {ST0, ST1, ST2};

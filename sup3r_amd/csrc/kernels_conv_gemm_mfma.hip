@@ -354,7 +354,7 @@ __global__ void gconv_splitk_epilogue(const float* __restrict__ part, int nsplit
 // walk is long (the 128 / 256-channel discriminator layers on a few thousand
 // positions: 16 workgroups x 216 dependent steps = 0.34 ms for 1.7 GFLOP)
 int gconv_splits(const s3_ctx* ctx, int64_t wgs, int iters) {
-  if (getenv("SUP3R_AMD_NO_GCONV_SPLITK") || wgs >= ctx->num_cu || iters < 32) return 1;
+  if (s3_opt_has(S3O_NO_GCONV_SPLITK) || wgs >= ctx->num_cu || iters < 32) return 1;
   int64_t n = (2 * (int64_t)ctx->num_cu + wgs - 1) / wgs;
   if (n > iters / 6) n = iters / 6;
   if (n > 32) n = 32;
@@ -778,14 +778,14 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
 
 // the halo variant needs stride 1, no residual and enough tiles to fill the chip
 bool fewch_halo_ok(const s3_ctx* ctx, const ConvGeom& g, const float* res, int out_bf16) {
-  if (res || getenv("SUP3R_AMD_NO_FEWCH_HALO")) return false;
+  if (res || s3_opt_has(S3O_NO_FEWCH_HALO)) return false;
   if (out_bf16 && (g.Cout & 3)) return false;
   for (int d = 0; d < 3; ++d)
     if (g.s[d] != 1 || g.lo[d] < 0 || g.lo[d] > 2) return false;
   const int64_t tiles = (int64_t)g.N * ((g.O[0] + FH0 - 1) / FH0) * ((g.O[1] + FH1 - 1) / FH1) *
                         ((g.O[2] + FH2 - 1) / FH2);
-  const int64_t min_tiles = getenv("SUP3R_AMD_FEWCH_HALO_MIN_TILES")
-                                ? atoll(getenv("SUP3R_AMD_FEWCH_HALO_MIN_TILES")) : 2 * ctx->num_cu;
+  const int64_t min_tiles = s3_opt_has(S3O_FEWCH_HALO_MIN_TILES)
+                                ? s3_opt_int(S3O_FEWCH_HALO_MIN_TILES, 0) : 2 * ctx->num_cu;
   return tiles >= min_tiles;
 }
 
@@ -803,14 +803,14 @@ __global__ void gconv_fewch_pack_kernel(const float* __restrict__ w, unsigned sh
 
 bool fewch_geom(const ConvGeom& g) {
   return (g.Cin == 2 || g.Cin == 4) && g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3 &&
-         !getenv("SUP3R_AMD_NO_FEWCH");
+         !s3_opt_has(S3O_NO_FEWCH);
 }
 
 }  // namespace
 
 bool conv_gconv_supported(const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16) return false;
-  if (getenv("SUP3R_AMD_NO_GCONV")) return false;
+  if (s3_opt_has(S3O_NO_GCONV)) return false;
   if (g.d2s != 1) return false;
   // C_in = 4: the generator's first conv (a cell is one float4)
   // C_in = 2: hi-res fields into the discriminator (a cell is one float2)
@@ -821,7 +821,7 @@ bool conv_gconv_supported(const ConvGeom& g, int precision) {
 // data gradient through the same kernel: contraction over C_out
 bool conv_gconv_dgrad_supported(const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16) return false;
-  if (getenv("SUP3R_AMD_NO_GCONV")) return false;
+  if (s3_opt_has(S3O_NO_GCONV)) return false;
   // (a depth-to-space store is undone by the epilogue adjoint: dPre arrives in
   // the conv's own output layout)
   // reflect padding: stride-1 'same' frame + fold only
@@ -903,7 +903,7 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
   }
   const int n_ct = (g.Cout + GT_N - 1) / GT_N;
   // four position fragments per wave when that still gives >= 2 workgroups per CU
-  const bool wide = (P / (GT_WAVES * 4 * 16)) * n_ct >= 2 * (int64_t)ctx->num_cu && !getenv("SUP3R_AMD_GCONV_MF2");
+  const bool wide = (P / (GT_WAVES * 4 * 16)) * n_ct >= 2 * (int64_t)ctx->num_cu && !s3_opt_has(S3O_GCONV_MF2);
   const int pos = GT_WAVES * (wide ? 4 : 2) * 16;
   const int nblk = (int)((P + pos - 1) / pos);
   const int iters = g.k[0] * g.k[1] * g.k[2] * ((g.Cin + 31) / 32);
@@ -950,8 +950,8 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
   // (measured per layer at C2 batch 8: four fragments per wave pay off in the
   // forward gathers only — the 64 -> 64 stride-2 data gradient ran 312 vs
   // 288 us — so the adjoint takes them on request, SUP3R_AMD_GCONV_MF4=1)
-  const bool wide = (pw / (GT_WAVES * 4 * 16)) * n_ct * nz >= 2 * (int64_t)ctx->num_cu && !getenv("SUP3R_AMD_GCONV_MF2") &&
-                    getenv("SUP3R_AMD_GCONV_MF4");
+  const bool wide = (pw / (GT_WAVES * 4 * 16)) * n_ct * nz >= 2 * (int64_t)ctx->num_cu && !s3_opt_has(S3O_GCONV_MF2) &&
+                    s3_opt_has(S3O_GCONV_MF4);
   const int pos = GT_WAVES * (wide ? 4 : 2) * 16;
   const int nblk = (int)((pw + pos - 1) / pos);
   // (stride-1 only: a residue class of a strided conv sees 1 - 8 taps)

@@ -423,7 +423,7 @@ int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x,
                             const float* res, void* y, int out_bf16,
                             int in_bf16) {
   if (in_bf16 && !out_bf16 && !res && conv_tail_mfma_supported(g) &&
-      !getenv("SUP3R_AMD_NO_TAIL_MFMA"))
+      !s3_opt_has(S3O_NO_TAIL_MFMA))
     return launch_conv_tail_mfma(ctx, g, x, w, bias, (float*)y);
   if (!out_bf16 && !res && conv_small_supported(g, in_bf16)) {
     constexpr int TT = 4;
@@ -468,7 +468,7 @@ int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x,
 int launch_conv_generic_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,
                               const float* w, float* dx) {
   const int64_t P = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
-  if (getenv("SUP3R_AMD_TRACE"))
+  if (s3_opt_has(S3O_TRACE))
     fprintf(stderr, "[dgrad] N=%d D=%dx%dx%d O=%dx%dx%d Cin=%d Cout=%d k=%d%d%d s=%d%d%d\n", g.N, g.D[0], g.D[1], g.D[2], g.O[0], g.O[1], g.O[2], g.Cin, g.Cout, g.k[0], g.k[1], g.k[2], g.s[0], g.s[1], g.s[2]);
   int ci_t = g.Cin >= 8 ? 8 : (g.Cin >= 4 ? 4 : (g.Cin >= 2 ? 2 : 1));
   int n_cg = (g.Cin + ci_t - 1) / ci_t;
@@ -492,7 +492,7 @@ int launch_conv_generic_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,
                               const float* dy, float* dw, float* partial,
                               size_t partial_bytes, int accumulate) {
   const int n_slabs = wgrad_slabs(g);
-  if (getenv("SUP3R_AMD_TRACE"))
+  if (s3_opt_has(S3O_TRACE))
     fprintf(stderr, "[wgrad] N=%d D=%dx%dx%d O=%dx%dx%d Cin=%d Cout=%d k=%d%d%d s=%d%d%d\n", g.N, g.D[0], g.D[1], g.D[2], g.O[0], g.O[1], g.O[2], g.Cin, g.Cout, g.k[0], g.k[1], g.k[2], g.s[0], g.s[1], g.s[2]);
   if (partial_bytes < conv_generic_wgrad_partial_bytes(g))
     S3_FAIL(ctx, S3_EINVAL, "wgrad: partial buffer too small");

@@ -191,13 +191,13 @@ int halo32_rows_pad(int cout) { return (cout + 63) / 64 * 64; }
 }  // namespace
 
 bool conv_halo32_supported(const s3_ctx* ctx, const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_HALO32")) return false;
+  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_HALO32)) return false;
   if (g.Cin != 32 || g.Cout % 4 != 0 || g.Cout < 16 || g.d2s != 1) return false;
   if (g.pad_mode == S3_PAD_REFLECT) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] < 0 || g.lo[d] > 2) return false;
   // enough tiles to fill the chip (SUP3R_AMD_HALO32_MIN_TILES overrides, for tests)
-  const int64_t min_tiles = getenv("SUP3R_AMD_HALO32_MIN_TILES") ? atoll(getenv("SUP3R_AMD_HALO32_MIN_TILES"))
+  const int64_t min_tiles = s3_opt_has(S3O_HALO32_MIN_TILES) ? s3_opt_int(S3O_HALO32_MIN_TILES, 0)
                                                                  : ctx->num_cu;
   return g.O[2] >= 8 &&
          (int64_t)g.N * ((g.O[0] + HT0 - 1) / HT0) * ((g.O[1] + HT1 - 1) / HT1) *

@@ -206,13 +206,13 @@ __global__ __launch_bounds__(SNT) void conv_halo_s2_kernel(
 }  // namespace
 
 bool conv_halo_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_HALO_S2")) return false;
+  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_HALO_S2)) return false;
   if (g.Cin != 32 || g.Cout % 4 != 0 || g.Cout < 16 || g.Cout > 32 || g.d2s != 1) return false;
   if (g.pad_mode == S3_PAD_REFLECT) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 2 || g.lo[d] != 0 || (g.O[d] - 1) * 2 + 3 > g.D[d]) return false;
   if ((int64_t)g.D[0] * g.D[1] * g.D[2] * 32 >= ((int64_t)1 << 31)) return false;
-  const int64_t min_tiles = getenv("SUP3R_AMD_HALO_S2_MIN_TILES") ? atoll(getenv("SUP3R_AMD_HALO_S2_MIN_TILES"))
+  const int64_t min_tiles = s3_opt_has(S3O_HALO_S2_MIN_TILES) ? s3_opt_int(S3O_HALO_S2_MIN_TILES, 0)
                                                                   : 4 * (int64_t)ctx->num_cu;
   return g.O[2] >= 8 &&
          (int64_t)g.N * ((g.O[0] + ST0 - 1) / ST0) * ((g.O[1] + ST1 - 1) / ST1) *

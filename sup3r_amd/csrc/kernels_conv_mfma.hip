@@ -598,7 +598,7 @@ int launch_io(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* wpk,
   const int tiles0 = (g.O[0] + TS0 - 1) / TS0, tiles1 = (g.O[1] + TS1 - 1) / TS1,
             tiles2 = (g.O[2] + TS2 - 1) / TS2;
   dim3 grid((unsigned)(g.N * tiles0 * tiles1 * tiles2), (unsigned)((g.Cout + CT - 1) / CT));
-  static const int dbg = getenv("SUP3R_AMD_MFMA_DBG") ? atoi(getenv("SUP3R_AMD_MFMA_DBG")) : 0;
+  const int dbg = (int)s3_opt_int(S3O_MFMA_DBG, 0);
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, ctx->stream, x, wpk, bias, res, y, g, tiles0, tiles1, tiles2, res16, dbg);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
@@ -610,7 +610,7 @@ int launch_bf16(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* wpk,
   if (io.in_bf16 && io.out_bf16)
     return launch_io<S3_PREC_BF16, TS0, TS1, NW, true, true>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
   // (fp32-out data gradients with <= 32 output channels: two N fragments)
-  if (g.Cout <= 32 && !io.out_bf16 && TS0 == 4 && TS1 == 8 && NW == 16 && !getenv("SUP3R_AMD_NO_TILE_NF2")) {
+  if (g.Cout <= 32 && !io.out_bf16 && TS0 == 4 && TS1 == 8 && NW == 16 && !s3_opt_has(S3O_NO_TILE_NF2)) {
     if (io.in_bf16)
       return launch_io<S3_PREC_BF16, TS0, TS1, NW, true, false, 2>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
     return launch_io<S3_PREC_BF16, TS0, TS1, NW, false, false, 2>(ctx, g, x, wpk, bias, res, y, io.res_bf16);
@@ -708,7 +708,7 @@ ConvGeom conv_dgrad_chunk_geom(const ConvGeom& g, int k) {
 }
 
 bool conv_dgrad_chunked_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_DGRAD_CHUNKED")) return false;
+  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_DGRAD_CHUNKED)) return false;
   if (g.Cin != 64 || g.Cout <= 64 || g.Cout % 8 != 0 || g.Cout > 512) return false;
   bool same = true, valid = g.pad_mode != S3_PAD_REFLECT && g.d2s == 1;
   for (int q = 0; q < 3; ++q) {
@@ -803,7 +803,7 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
     if (!g.in_cstride && conv_mfma_persist_supported(ctx, g, io, res != nullptr))
       return launch_conv_mfma_persist(ctx, g, x, (const char*)packed + (size_t)((g.Cout + CT - 1) / CT) * 27 * CT * CIN * 2, bias, res, y);
     // tile / wave configuration (SUP3R_AMD_MFMA_TILE overrides for A/B probes)
-    static const int tile_env = getenv("SUP3R_AMD_MFMA_TILE") ? atoi(getenv("SUP3R_AMD_MFMA_TILE")) : -1;
+    const int tile_env = (int)s3_opt_int(S3O_MFMA_TILE, -1);
     int tile = tile_env;
     if (tile < 0) {
       // 512-position workgroups (16 waves) amortise the filter slabs best;
@@ -816,7 +816,7 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
       const int64_t six = (int64_t)g.N * ((g.O[0] + 5) / 6) * ((g.O[1] + 5) / 6) * ((g.O[2] + 15) / 16);
       const int64_t ncu = ctx->num_cu;
       if (tile == 4 && six >= ncu && ((six + ncu - 1) / ncu) * 576 < ((big + ncu - 1) / ncu) * 512 &&
-          !getenv("SUP3R_AMD_NO_TILE66"))
+          !s3_opt_has(S3O_NO_TILE66))
         tile = 7;
     }
     if (tile == 1) return launch_bf16<2, 4, 4>(ctx, g, x, packed, bias, res, y, io);

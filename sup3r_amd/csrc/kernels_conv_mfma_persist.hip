@@ -641,8 +641,7 @@ static void persist_dgrad_grid(const ConvGeom& g, int* gs0, int* gs1) {
 }
 
 bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g) {
-  const char* off = getenv("SUP3R_AMD_NO_PERSIST_DGRAD");
-  if (off && atoi(off)) return false;
+  if (s3_opt_on(S3O_NO_PERSIST_DGRAD)) return false;
   if (!conv_mfma_persist_dgrad_geom_ok(g)) return false;
   int gs0 = 1, gs1 = 1;
   persist_dgrad_grid(g, &gs0, &gs1);
@@ -652,8 +651,8 @@ bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g) {
   // halo-tile kernel's 6 x 6 x 16 ones would (both share the overhang along t)
   const int64_t covered = tiles * TS0 * TS1 * TS2;
   const int64_t six = (int64_t)g.N * ((g.O[0] + 5) / 6) * ((g.O[1] + 5) / 6) * ((g.O[2] + 15) / 16) * 576;
-  const int64_t min_tiles = getenv("SUP3R_AMD_PERSIST_DGRAD_MIN_TILES")
-                                ? atoll(getenv("SUP3R_AMD_PERSIST_DGRAD_MIN_TILES")) : ctx->num_cu;
+  const int64_t min_tiles = s3_opt_has(S3O_PERSIST_DGRAD_MIN_TILES)
+                                ? s3_opt_int(S3O_PERSIST_DGRAD_MIN_TILES, 0) : ctx->num_cu;
   return tiles >= min_tiles && covered * 10 <= six * 11;
 }
 
@@ -687,8 +686,7 @@ int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* d
 bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
                                  bool has_res) {
   // read per call: the parity tests flip it between two forwards
-  const char* off = getenv("SUP3R_AMD_NO_PERSIST");
-  if (off && atoi(off)) return false;
+  if (s3_opt_on(S3O_NO_PERSIST)) return false;
   if (!io.in_bf16 || !io.out_bf16 || (has_res && !io.res_bf16)) return false;
   if (!conv_mfma_persist_geom_ok(g)) return false;
   if (has_res && g.d2s != 1) return false;

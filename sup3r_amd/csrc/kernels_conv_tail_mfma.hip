@@ -542,10 +542,10 @@ int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES));
     attr_set = true;
   }
-  const bool band = g.Cout == 2 && !getenv("SUP3R_AMD_NO_TAIL_BAND");
+  const bool band = g.Cout == 2 && !s3_opt_has(S3O_NO_TAIL_BAND);
   // read per call: the parity tests flip it between two forwards
-  const char* noslide = getenv("SUP3R_AMD_NO_TAIL_SLIDE");
-  if (band && g.O[0] >= 4 && !(noslide && atoi(noslide))) {
+  const bool noslide = s3_opt_on(S3O_NO_TAIL_SLIDE);
+  if (band && g.O[0] >= 4 && !noslide) {
     static bool slide_attr = false;
     if (!slide_attr) {
       S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail_slide_kernel),

@@ -728,7 +728,7 @@ int bf_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* d
   constexpr bool CAN_PF = CIB == 2 && IN16;
   auto kern = conv_wgrad_bf16_gen_kernel<CIB, STR, IN16>;
   if constexpr (CAN_PF)
-    if (!getenv("SUP3R_AMD_NO_WGRAD_GEN_PF")) kern = conv_wgrad_bf16_gen_kernel<CIB, STR, IN16, true>;
+    if (!s3_opt_has(S3O_NO_WGRAD_GEN_PF)) kern = conv_wgrad_bf16_gen_kernel<CIB, STR, IN16, true>;
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_gen_kernel<CIB, STR, IN16>),
@@ -937,7 +937,7 @@ int bf_2d_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy
 }  // namespace
 
 bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_WGRAD_BF16")) return false;
+  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_BF16)) return false;
   if (g.Cin != 64 || g.Cout % 4 != 0 || g.Cout < 16) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] != 1 || g.O[d] != g.D[d]) return false;
@@ -972,9 +972,9 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
     attr_set = true;
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
-  static const int dbg = getenv("SUP3R_AMD_WGRAD_DBG") ? atoi(getenv("SUP3R_AMD_WGRAD_DBG")) : 0;
+  const int dbg = (int)s3_opt_int(S3O_WGRAD_DBG, 0);
   // wave-specialised variant: reflect padding, tiles that fit exactly, whole 16-B channel chunks
-  const bool ws = dy_bf16 && !dbg && !getenv("SUP3R_AMD_NO_WGRAD_WS") && g.pad_mode == S3_PAD_REFLECT &&
+  const bool ws = dy_bf16 && !dbg && !s3_opt_has(S3O_NO_WGRAD_WS) && g.pad_mode == S3_PAD_REFLECT &&
                   g.O[0] % BT0 == 0 && g.O[1] % BT1 == 0 && g.O[2] % BT2 == 0 && g.Cout >= BCT && g.Cout % 8 == 0 &&
                   (int64_t)g.D[0] * g.D[1] * g.D[2] * 64 < ((int64_t)1 << 31) &&
                   (int64_t)g.O[0] * g.O[1] * g.O[2] * g.Cout < ((int64_t)1 << 31);
@@ -1001,7 +1001,7 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
 
 // ---- general variant (discriminator convs)
 bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_WGRAD_BF16")) return false;
+  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_BF16)) return false;
   if (g.d2s != 1 || g.Cin % 32 != 0 || g.Cin < 32 || g.Cout % 4 != 0 || g.Cout < 16) return false;
   if (g.Cin > 64 && g.Cin % 64 != 0) return false;
   for (int d = 0; d < 3; ++d)
@@ -1033,7 +1033,7 @@ int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, c
 
 // ---- 2-D variant (spatial models)
 bool conv_wgrad_bf16_2d_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_WGRAD_BF16")) return false;
+  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_BF16)) return false;
   if (g.d2s != 1 || g.Cin % 32 != 0 || g.Cin < 32 || g.Cout % 4 != 0 || g.Cout < 16) return false;
   if (g.Cin > 64 && g.Cin % 64 != 0) return false;
   if (g.k[0] != 3 || g.k[1] != 3 || g.k[2] != 1 || g.D[2] != 1 || g.O[2] != 1) return false;

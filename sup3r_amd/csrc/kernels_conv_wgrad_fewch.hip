@@ -260,7 +260,7 @@ int64_t c2_steps(const ConvGeom& g, int* chunks) {
 }  // namespace
 
 bool conv_wgrad_c2_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_WGRAD_C2")) return false;
+  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_C2)) return false;
   // 2 -> 16 / 32 / 64 (discriminator input layer) or 8 -> C_out <= 16 (hi-res tail)
   const bool a = g.Cin == 2 && (g.Cout == 16 || g.Cout == 32 || g.Cout == 64);
   const bool b = g.Cin == 8 && g.Cout <= 16;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
 }  // namespace
 
 bool conv_wgrad_tail_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_WGRAD_TAIL")) return false;
+  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_TAIL)) return false;
   if (g.Cin != 8 || g.Cout > 16 || g.Cout < 1 || g.d2s != 1) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] < 0 || g.lo[d] > 2) return false;

@@ -161,7 +161,7 @@ int launch_wgrad_partial_reduce(s3_ctx* ctx, const float* partial, int n_part, i
   int rg = (int)((wsize + 255) / 256);
   if (rg > 2048) rg = 2048;
   // (only where it pays: enough partials, too few workgroups to hide the walk)
-  const int n_seg = (n_part >= 128 && rg * 4 <= ctx->num_cu && !getenv("SUP3R_AMD_NO_SEG_REDUCE")) ? 16 : 1;
+  const int n_seg = (n_part >= 128 && rg * 4 <= ctx->num_cu && !s3_opt_has(S3O_NO_SEG_REDUCE)) ? 16 : 1;
   if (n_seg > 1 && ensure_scratch(ctx, (size_t)n_seg * wsize * sizeof(float)) == S3_OK) {
     hipLaunchKernelGGL(wgrad_partial_reduce_seg, dim3(rg, n_seg), dim3(256), 0, ctx->stream, partial, n_part, wsize,
                        ctx->scratch, n_seg);
@@ -422,7 +422,7 @@ int wgrad_gen_cib(const ConvGeom& g) { return g.Cin <= 16 ? 1 : (g.Cin <= 32 ? 2
 }  // namespace
 
 bool conv_wgrad_gen_supported(const ConvGeom& g) {
-  if (getenv("SUP3R_AMD_NO_GCONV")) return false;
+  if (s3_opt_has(S3O_NO_GCONV)) return false;
   if (g.d2s != 1) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != g.s[0] || (g.s[d] != 1 && g.s[d] != 2)) return false;

@@ -134,7 +134,7 @@ int launch_dense_fwd(s3_ctx* ctx, const float* x, const float* w,
   const int col_tiles = (cout + 63) / 64;
   // ~8 waves per SIMD in flight: the pass is one stream over W and needs the
   // memory parallelism (512 workgroups ran it at 1.1 TB/s)
-  static const int wg_target = getenv("SUP3R_AMD_DENSE_WGS") ? atoi(getenv("SUP3R_AMD_DENSE_WGS")) : 2048;
+  const int wg_target = (int)s3_opt_int(S3O_DENSE_WGS, 2048);
   int n_slabs = (wg_target + col_tiles - 1) / col_tiles;
   int max_slabs = (cin + 63) / 64;
   if (n_slabs > max_slabs) n_slabs = max_slabs;

@@ -238,7 +238,7 @@ struct Fused2dPlan {
 // 160 KB of LDS.
 Fused2dPlan* fused2d_build(s3_ctx* ctx, const std::vector<Fused2dLayer>& L, int n_tensors,
                            int in_tensor, int out_tensor) {
-  if (getenv("SUP3R_AMD_NO_FUSED2D") || L.empty() || (int)L.size() > FMAX_LAYERS) return nullptr;
+  if (s3_opt_has(S3O_NO_FUSED2D) || L.empty() || (int)L.size() > FMAX_LAYERS) return nullptr;
   std::vector<int> th(n_tensors, 0), tw(n_tensors, 0), tc(n_tensors, 0), border(n_tensors, -1),
       last_use(n_tensors, -1), prod(n_tensors, -1);
   const int nl = (int)L.size();

@@ -807,7 +807,7 @@ int ensure_scratch(s3_ctx* ctx, size_t bytes) {
   }
   size_t want = bytes < (size_t)(1 << 20) ? (size_t)(1 << 20) : bytes;
   S3_HIP(ctx, hipMalloc((void**)&ctx->scratch, want));
-  S3_HIP(ctx, hipMemsetAsync(ctx->scratch, getenv("SUP3R_AMD_POISON_ALLOC") ? 0xFF : 0, want, ctx->stream));
+  S3_HIP(ctx, hipMemsetAsync(ctx->scratch, ctx->opt.has[S3O_POISON_ALLOC] ? 0xFF : 0, want, ctx->stream));
   ctx->scratch_bytes = want;
   return S3_OK;
 }
@@ -1083,7 +1083,7 @@ __global__ void optimizer_kernel(float* __restrict__ w, const float* __restrict_
         wi += -gi * h0;
       }
     } else if (KIND == S3_OPT_RMSPROP) {
-      const float vi = h1 * v[i] + (1.f - h1) * gi * gi;
+      const float vi = h1 * v[i] + h4 * gi * gi;   // h4 = fp32(1 - rho)
       v[i] = vi;
       const float inc = h0 * gi * (1.f / sqrtf(vi + h3));
       if (h2 > 0.f) {
@@ -1135,8 +1135,8 @@ int launch_optimizer(s3_ctx* ctx, int kind, float* w, const float* g, float* m, 
 }
 
 int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
-                int64_t n, float alpha, float b1, float b2, float eps) {
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, w, g, m, v, n, alpha, 1.f - b1, 1.f - b2, eps);
+                int64_t n, float alpha, float omb1, float omb2, float eps) {
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, w, g, m, v, n, alpha, omb1, omb2, eps);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -22,6 +22,11 @@ struct s3_params {
   int64_t total = 0;
   float* buf[4] = {nullptr, nullptr, nullptr, nullptr};  // W, G, M, V
   uint64_t version = 1;  // bumped whenever W changes (re-pack trigger)
+  // bucketed gradient all-reduce under the backward pass (s3_params_arm_allreduce):
+  // [0, reduce_end) of the gradient buffer is not yet handed to RCCL
+  bool armed = false;
+  int64_t reduce_end = 0, bucket_elems = 0;
+  int buckets_issued = 0;
 };
 
 struct TensorRec {
@@ -79,6 +84,7 @@ struct OpRec {
 
 struct s3_plan {
   s3_ctx* ctx = nullptr;
+  S3Options opt;              // snapshot of the options this plan was created with
   s3_params* params = nullptr;
   std::vector<TensorRec> t;
   std::vector<OpRec> ops;
@@ -138,11 +144,69 @@ static int plan_alloc(s3_plan* pl, void** out, size_t bytes) {
   // on what ran before).  SUP3R_AMD_POISON_ALLOC=1 fills all-ones bytes instead
   // (NaN as fp32 and as bf16): a debugging aid that makes any read of a plan
   // buffer before its first write show up in the results.
-  S3_HIP(ctx, hipMemsetAsync(*out, getenv("SUP3R_AMD_POISON_ALLOC") ? 0xFF : 0, bytes, ctx->stream));
+  S3_HIP(ctx, hipMemsetAsync(*out, s3_opt_has(S3O_POISON_ALLOC) ? 0xFF : 0, bytes, ctx->stream));
   pl->owned.push_back(*out);
   pl->total_bytes += bytes;
   return S3_OK;
 }
+
+// ------------------------------------------------------------------ options
+thread_local const S3Options* s3_active_options = nullptr;
+
+static const char* const kOptionNames[S3O_COUNT] = {
+#define X(n) #n,
+    S3_OPTION_LIST(X)
+#undef X
+};
+
+const char* s3_option_name(int id) { return (id >= 0 && id < S3O_COUNT) ? kOptionNames[id] : nullptr; }
+
+int s3_option_id(const char* name) {
+  if (!name) return -1;
+  if (!strncmp(name, "SUP3R_AMD_", 10)) name += 10;
+  for (int i = 0; i < S3O_COUNT; ++i)
+    if (!strcmp(name, kOptionNames[i])) return i;
+  return -1;
+}
+
+// initial defaults of a context: the SUP3R_AMD_<NAME> variables as they are
+// when the context is created (never read again afterwards)
+static void options_from_env(S3Options& o) {
+  for (int i = 0; i < S3O_COUNT; ++i) {
+    const std::string var = std::string("SUP3R_AMD_") + kOptionNames[i];
+    const char* v = getenv(var.c_str());
+    if (v) { o.has[i] = true; o.v[i] = (int32_t)atoll(v); }
+  }
+}
+
+static int apply_options(s3_ctx* ctx, S3Options& o, const s3_plan_options* opt) {
+  if (!opt) return S3_OK;
+  for (int i = 0; i < opt->n; ++i) {
+    const int id = s3_option_id(opt->names ? opt->names[i] : nullptr);
+    if (id < 0) S3_FAIL(ctx, S3_EINVAL, std::string("unknown option \"") + (opt->names && opt->names[i] ? opt->names[i] : "(null)") + "\"");
+    if (opt->values[i] == S3_OPTION_UNSET) { o.has[id] = false; o.v[id] = 0; }
+    else { o.has[id] = true; o.v[id] = opt->values[i]; }
+  }
+  return S3_OK;
+}
+
+extern "C" int s3_ctx_set_option(s3_ctx* ctx, const char* name, int32_t value) {
+  if (!ctx) return S3_EINVAL;
+  const char* names[1] = {name};
+  const int32_t values[1] = {value};
+  s3_plan_options o = {1, names, values};
+  return apply_options(ctx, ctx->opt, &o);
+}
+
+extern "C" int s3_ctx_get_option(const s3_ctx* ctx, const char* name, int32_t* value) {
+  if (!ctx) return S3_EINVAL;
+  const int id = s3_option_id(name);
+  if (id < 0) return S3_EINVAL;
+  if (value) *value = ctx->opt.v[id];
+  return ctx->opt.has[id] ? 1 : 0;
+}
+
+extern "C" const char* s3_option_name_at(int index) { return s3_option_name(index); }
 
 // ------------------------------------------------------------------ context
 extern "C" int s3_ctx_create(int device_id, void* stream, int create_stream,
@@ -150,6 +214,7 @@ extern "C" int s3_ctx_create(int device_id, void* stream, int create_stream,
   if (!out) return S3_EINVAL;
   s3_ctx* ctx = new s3_ctx();
   ctx->device = device_id;
+  options_from_env(ctx->opt);
   hipError_t e = hipSetDevice(device_id);
   if (e != hipSuccess) {
     // keep the object so the caller can read the message
@@ -304,53 +369,81 @@ extern "C" int s3_params_mean_abs(s3_params* p, int which, int idx, float* host_
 
 extern "C" int s3_adam_step(s3_params* p, float lr, float beta1, float beta2,
                             float eps, int64_t t) {
-  if (!p || t < 1) return S3_EINVAL;
-  // keras-2.15 Adam.update_step, evaluated in fp32 like the reference
-  float b1p = powf(beta1, (float)t), b2p = powf(beta2, (float)t);
-  float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
-  int rc = launch_adam(p->ctx, p->buf[S3_BUF_W], p->buf[S3_BUF_G], p->buf[S3_BUF_M],
-                       p->buf[S3_BUF_V], p->total, alpha, beta1, beta2, eps);
-  if (rc) return rc;
-  p->version++;
+  const double hp[4] = {lr, beta1, beta2, eps};
+  return s3_optimizer_step(p, S3_OPT_ADAM, hp, 4, t);
+}
+
+extern "C" int s3_params_arm_allreduce(s3_params* p, int64_t bucket_bytes) {
+  if (!p) return S3_EINVAL;
+  p->armed = true;
+  p->reduce_end = p->total;
+  p->bucket_elems = bucket_bytes > 0 ? bucket_bytes / (int64_t)sizeof(float) : p->total;
+  p->buckets_issued = 0;
   return S3_OK;
 }
 
-extern "C" int s3_optimizer_step(s3_params* p, int kind, const float* hp, int n_hp, int64_t t) {
+// called by s3_params_allreduce_grads (comm.cpp): 1 = the armed, bucketed
+// reduction covered the whole buffer (the caller only joins the streams),
+// 0 = nothing was armed (reduce the whole buffer now), -1 = armed but the
+// backward pass did not reach the start of the buffer
+extern "C" int s3_params_take_armed(s3_params* p, int* n_buckets) {
+  if (!p || !p->armed) return 0;
+  const bool complete = p->reduce_end == 0;
+  if (n_buckets) *n_buckets = p->buckets_issued;
+  p->armed = false;
+  return complete ? 1 : -1;
+}
+
+// Hyper-parameters arrive as doubles (they are Python floats in the keras
+// configs) and are cast the way keras casts them: `1 - beta` is evaluated in
+// double and THEN rounded to fp32 (keras multiplies the fp32 tensor by the
+// Python scalar 1 - beta), the powers beta^t in fp32 (tf.pow of the cast
+// beta).  fp32(1) - fp32(0.999) would be off by 4.7e-5 of itself.
+extern "C" int s3_optimizer_step(s3_params* p, int kind, const double* hp, int n_hp, int64_t t) {
   if (!p || !hp || t < 1) return S3_EINVAL;
   s3_ctx* ctx = p->ctx;
   float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   auto need = [&](int n) { return n_hp >= n; };
   switch (kind) {
-    case S3_OPT_ADAM:
+    case S3_OPT_ADAM: {
       if (!need(4)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(Adam): {lr, beta_1, beta_2, epsilon}");
-      return s3_adam_step(p, hp[0], hp[1], hp[2], hp[3], t);
+      const float b1p = powf((float)hp[1], (float)t), b2p = powf((float)hp[2], (float)t);
+      const float alpha = (float)hp[0] * sqrtf(1.f - b2p) / (1.f - b1p);
+      int rc = launch_adam(ctx, p->buf[S3_BUF_W], p->buf[S3_BUF_G], p->buf[S3_BUF_M], p->buf[S3_BUF_V],
+                           p->total, alpha, (float)(1.0 - hp[1]), (float)(1.0 - hp[2]), (float)hp[3]);
+      if (rc) return rc;
+      p->version++;
+      return S3_OK;
+    }
     case S3_OPT_SGD:
       if (!need(3)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(SGD): {lr, momentum, nesterov}");
-      h[0] = hp[0]; h[1] = hp[1]; h[2] = hp[2];
+      h[0] = (float)hp[0]; h[1] = (float)hp[1]; h[2] = (float)hp[2];
       break;
     case S3_OPT_RMSPROP:
       if (!need(4)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(RMSprop): {lr, rho, momentum, epsilon}");
-      h[0] = hp[0]; h[1] = hp[1]; h[2] = hp[2]; h[3] = hp[3];
+      h[0] = (float)hp[0]; h[1] = (float)hp[1]; h[2] = (float)hp[2]; h[3] = (float)hp[3];
+      h[4] = (float)(1.0 - hp[1]);
       break;
     case S3_OPT_ADAGRAD:
       if (!need(3)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(Adagrad): {lr, epsilon, initial_accumulator_value}");
-      h[0] = hp[0]; h[1] = hp[1];
+      h[0] = (float)hp[0]; h[1] = (float)hp[1];
       if (t == 1) {   // keras creates the accumulator filled with its initial value
-        int rc = launch_fill(ctx, p->buf[S3_BUF_V], p->total, hp[2]);
+        int rc = launch_fill(ctx, p->buf[S3_BUF_V], p->total, (float)hp[2]);
         if (rc) return rc;
       }
       break;
     case S3_OPT_ADAMAX: {
       if (!need(4)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(Adamax): {lr, beta_1, beta_2, epsilon}");
-      const float b1p = powf(hp[1], (float)t);
-      h[0] = hp[0] / (1.f - b1p); h[1] = 1.f - hp[1]; h[2] = hp[2]; h[3] = hp[3];
+      const float b1p = powf((float)hp[1], (float)t);
+      h[0] = (float)hp[0] / (1.f - b1p); h[1] = (float)(1.0 - hp[1]); h[2] = (float)hp[2]; h[3] = (float)hp[3];
       break;
     }
     case S3_OPT_ADAMW: {
       if (!need(5)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(AdamW): {lr, beta_1, beta_2, epsilon, weight_decay}");
-      const float b1p = powf(hp[1], (float)t), b2p = powf(hp[2], (float)t);
-      h[0] = hp[0] * sqrtf(1.f - b2p) / (1.f - b1p);
-      h[1] = 1.f - hp[1]; h[2] = 1.f - hp[2]; h[3] = hp[3]; h[4] = hp[4] * hp[0];
+      const float b1p = powf((float)hp[1], (float)t), b2p = powf((float)hp[2], (float)t);
+      h[0] = (float)hp[0] * sqrtf(1.f - b2p) / (1.f - b1p);
+      h[1] = (float)(1.0 - hp[1]); h[2] = (float)(1.0 - hp[2]); h[3] = (float)hp[3];
+      h[4] = (float)hp[4] * (float)hp[0];
       break;
     }
     default: S3_FAIL(ctx, S3_EINVAL, "optimizer_step: unknown optimizer kind");
@@ -402,9 +495,23 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
                               const int32_t* inputs, int n_inputs,
                               int32_t output, int precision, int training,
                               s3_plan** out) {
+  return s3_plan_create_opt(ctx, params, tensors, n_tensors, ops, n_ops, inputs, n_inputs, output,
+                            precision, training, nullptr, out);
+}
+
+extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
+                                  const s3_tensor_desc* tensors, int n_tensors,
+                                  const s3_op_desc* ops, int n_ops,
+                                  const int32_t* inputs, int n_inputs,
+                                  int32_t output, int precision, int training,
+                                  const s3_plan_options* options, s3_plan** out) {
   if (!ctx || !params || !tensors || !ops || !out) return S3_EINVAL;
   if (output < 0 || output >= n_tensors) S3_FAIL(ctx, S3_EINVAL, "plan: bad output id");
+  S3Options plan_opt = ctx->opt;
+  if (int orc = apply_options(ctx, plan_opt, options)) return orc;
   s3_plan* pl = new s3_plan();
+  pl->opt = plan_opt;
+  S3OptScope opt_scope(&pl->opt);
   pl->ctx = ctx; pl->params = params; pl->precision = precision;
   pl->training = training; pl->output = output;
   pl->t.resize(n_tensors);
@@ -450,7 +557,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
         }
         if (d.res >= 0 && pl->t[d.res].numel != ot.numel) return bad("plan: residual shape mismatch");
         o.mfma = conv_mfma_supported(g, precision);
-        o.fewpos = !o.mfma && !getenv("SUP3R_AMD_NO_FEWPOS") && conv_fewpos_supported(g);
+        o.fewpos = !o.mfma && !s3_opt_has(S3O_NO_FEWPOS) && conv_fewpos_supported(g);
         // bf16 plans: the weight-streaming fp32 path only for really few
         // positions; mid-size layers go to the gather-MFMA kernels
         if (o.fewpos && (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 256 &&
@@ -474,7 +581,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
         size_t ysz = (size_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout * sizeof(float);
         max_dpre = std::max(max_dpre, ysz);
         max_partial = std::max(max_partial, conv_generic_wgrad_partial_bytes(g));
-        if (training && !getenv("SUP3R_AMD_NO_MFMA_BWD")) {
+        if (training && !s3_opt_has(S3O_NO_MFMA_BWD)) {
           o.wgrad_mfma = conv_wgrad_mfma_supported(g);
           o.wgrad_bf16 = o.wgrad_mfma && conv_wgrad_bf16_supported(g, precision);
           if (o.wgrad_bf16)
@@ -505,7 +612,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
           // the C1 discriminator's first layers); with few positions the slab
           // kernel of the fewpos family does any C_in / C_out
           if (!o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_tail && !o.wgrad_bf16_gen && !o.wgrad_bf16_2d &&
-              !o.wgrad_gen && conv_fewpos_wgrad_ok(g) && !getenv("SUP3R_AMD_NO_FEWPOS")) {
+              !o.wgrad_gen && conv_fewpos_wgrad_ok(g) && !s3_opt_has(S3O_NO_FEWPOS)) {
             o.fewpos_wgrad = true;
             max_partial = std::max(max_partial, conv_fewpos_wgrad_partial_bytes(g));
           }
@@ -514,7 +621,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               conv_dgrad_mfma_valid_supported(g, precision)) {
             o.dgrad_mfma = o.dgrad_valid = true;
           }
-          if (!o.dgrad_mfma && !o.fewpos && precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_NO_DGRAD_FEWCH") &&
+          if (!o.dgrad_mfma && !o.fewpos && precision == S3_PREC_BF16 && !s3_opt_has(S3O_NO_DGRAD_FEWCH) &&
               (g.Cout == 2 || g.Cout == 4) && g.Cin % 4 == 0 && g.d2s == 1 &&
               (int64_t)g.N * g.D[0] * g.D[1] * g.D[2] >= 4096) {
             // hi-res tail conv (8 -> 2): its data gradient is a conv with 2 input
@@ -580,9 +687,9 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
   // transpose-read bf16 kernel (which stages bf16 directly); the LeakyReLU
   // mask pass reads the sign of a bf16 output; gradients stay fp32.  The
   // forward is then bit-identical to the bf16 inference plan of the trunk.
-  const bool train16 = training && precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_FP32_ACT") &&
-                       !(getenv("SUP3R_AMD_BF16_TRAIN_ACT") && atoi(getenv("SUP3R_AMD_BF16_TRAIN_ACT")) == 0);
-  if ((!training || train16) && precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_FP32_ACT")) {
+  const bool train16 = training && precision == S3_PREC_BF16 && !s3_opt_has(S3O_FP32_ACT) &&
+                       !(s3_opt_has(S3O_BF16_TRAIN_ACT) && s3_opt_int(S3O_BF16_TRAIN_ACT, 0) == 0);
+  if ((!training || train16) && precision == S3_PREC_BF16 && !s3_opt_has(S3O_FP32_ACT)) {
     std::vector<int> dt(n_tensors, 1);
     auto demote = [&](int id, bool& changed) {
       if (id < 0) return;
@@ -617,7 +724,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               if (!conv_mfma_bf16_out_ok(o.cg)) demote(d.out, changed);
               // (a saved bf16 input is re-read by the weight gradient: the
               // transpose-read kernels stage bf16 directly)
-              if (training && !o.wgrad_bf16 && !(o.wgrad_bf16_gen && !getenv("SUP3R_AMD_NO_DISC_BF16")))
+              if (training && !o.wgrad_bf16 && !(o.wgrad_bf16_gen && !s3_opt_has(S3O_NO_DISC_BF16)))
                 demote(d.in0, changed);
             } else if (training) {
               // every other conv reads / writes fp32 in training plans — except
@@ -631,8 +738,8 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
               // ... and so on down the stack: every gather-MFMA / LDS-halo conv with
               // C_in % 8 == 0 takes and writes bf16 cells (SUP3R_AMD_DISC_BF16=1
               // keeps it to the first pair, SUP3R_AMD_NO_DISC_BF16 turns it off)
-              const bool disc16 = !getenv("SUP3R_AMD_NO_DISC_BF16");
-              const bool deep16 = disc16 && !(getenv("SUP3R_AMD_DISC_BF16") && atoi(getenv("SUP3R_AMD_DISC_BF16")) == 1);
+              const bool disc16 = !s3_opt_has(S3O_NO_DISC_BF16);
+              const bool deep16 = disc16 && !(s3_opt_has(S3O_DISC_BF16) && s3_opt_int(S3O_DISC_BF16, 0) == 1);
               const bool gc_in16 = disc16 && o.gconv && (!o.halo32 || deep16) && d.res < 0 && o.wgrad_bf16_gen &&
                                    o.cg.Cin % 8 == 0;
               const bool gc_out16 = disc16 && o.gconv && d.res < 0 && o.cg.Cout % 8 == 0 &&
@@ -673,7 +780,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     o.io.in_bf16 = pl->t[root_of(pl, o.d.in0)].dtype;
     o.io.out_bf16 = pl->t[root_of(pl, o.d.out)].dtype;
     o.io.res_bf16 = o.d.res >= 0 ? pl->t[root_of(pl, o.d.res)].dtype : 0;
-    if (getenv("SUP3R_AMD_TRACE"))
+    if (s3_opt_has(S3O_TRACE))
       fprintf(stderr, "[plan] conv %d->%d %s: mfma %d fewpos %d gconv %d halo32 %d | in16 %d out16 %d res16 %d | "
               "wgrad bf16 %d gen %d 2d %d c2 %d tail %d mfma %d | dgrad mfma %d c2 %d s2 %d gconv %d\n",
               o.cg.Cin, o.cg.Cout, training ? "train" : "infer", (int)o.mfma, (int)o.fewpos, (int)o.gconv,
@@ -765,16 +872,16 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
     // pass (d2s walk included), the frame folds (compile-time variants: a
     // run-time side store cost them 42 us per 75 MB), the stride-2 data
     // gradient.  One buffer, handed from producer to consumer (dpre16_for).
-    if (precision == S3_PREC_BF16 && !getenv("SUP3R_AMD_NO_DPRE16")) {
+    if (precision == S3_PREC_BF16 && !s3_opt_has(S3O_NO_DPRE16)) {
       size_t max16 = 0;
       for (auto& o : pl->ops) {
         if (rc || o.d.kind != S3_OP_CONV) continue;
         // (... and the gather-MFMA adjoint of the strided / valid discriminator
         // convs: a lane's 8 channels of a dPre cell are one 16-B load)
         const bool gadj = o.gconv_dgrad && (o.cg.Cout & 7) == 0 && o.cg.pad_mode != S3_PAD_REFLECT &&
-                          !getenv("SUP3R_AMD_NO_GCONV_DY16");
+                          !s3_opt_has(S3O_NO_GCONV_DY16);
         if (!gadj && (!o.dgrad_mfma || o.dgrad_fewch || (o.cg.Cout & 3))) continue;
-        if (o.dgrad_chunked && ((o.cg.Cout & 7) || getenv("SUP3R_AMD_NO_CHUNKED_DY16"))) continue;
+        if (o.dgrad_chunked && ((o.cg.Cout & 7) || s3_opt_has(S3O_NO_CHUNKED_DY16))) continue;
         o.use16 = true;
         max16 = std::max(max16, (size_t)pl->t[root_of(pl, o.d.out)].numel * 2);
       }
@@ -878,7 +985,7 @@ extern "C" int s3_plan_create(s3_ctx* ctx, s3_params* params,
       fl.push_back(f);
     }
     if (ok) pl->fused2d = fused2d_build(ctx, fl, n_tensors, root_of(pl, pl->inputs[0]), root_of(pl, output));
-    if (getenv("SUP3R_AMD_TRACE"))
+    if (s3_opt_has(S3O_TRACE))
       fprintf(stderr, "[plan] fused 2-D whole-network kernel: %s\n", pl->fused2d ? "yes" : "no");
   }
   *out = pl;
@@ -924,7 +1031,7 @@ static float* gptr(s3_plan* pl, int id) { return pl->t[root_of(pl, id)].gptr; }
 static int pack_tables_build(s3_plan* pl) {
   s3_ctx* ctx = pl->ctx;
   pl->pack_built = true;
-  if (pl->precision != S3_PREC_BF16 || getenv("SUP3R_AMD_NO_BATCHED_PACK")) return S3_OK;
+  if (pl->precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_BATCHED_PACK)) return S3_OK;
   s3_params* P = pl->params;
   float* W = P->buf[S3_BUF_W];
   std::vector<S3PackJob> fwd, bwd;
@@ -1105,8 +1212,7 @@ static bool graph_wanted(const s3_plan* pl) {
   // opt-in: measured on MI355X / ROCm 7.2 the replay is bit-identical but not
   // faster (C1: 0.524 ms eager vs 0.535 ms replayed — the 36 dependent
   // micro-kernels cost ~14 us each on the GPU side either way)
-  const char* on = getenv("SUP3R_AMD_GRAPH");
-  return on && atoi(on);
+  return s3_opt_on(S3O_GRAPH);
 }
 
 static int forward_graph(s3_plan* pl) {
@@ -1139,7 +1245,7 @@ static int forward_graph(s3_plan* pl) {
     ctx->stream = user;
     if (e == hipSuccess && rc == S3_OK)
       e = hipGraphInstantiate(&pl->graph_exec, pl->graph, nullptr, nullptr, 0);
-    if (getenv("SUP3R_AMD_TRACE"))
+    if (s3_opt_has(S3O_TRACE))
       fprintf(stderr, "[graph] capture of %d ops: %s\n", (int)pl->ops.size(),
               (e == hipSuccess && rc == S3_OK) ? "ok" : hipGetErrorString(e));
     if (e != hipSuccess || rc != S3_OK) {
@@ -1157,12 +1263,13 @@ static int forward_graph(s3_plan* pl) {
 extern "C" int s3_plan_forward(s3_plan* pl, const void* const* inputs, void* output) {
   if (!pl) return S3_EINVAL;
   s3_ctx* ctx = pl->ctx;
+  S3OptScope opt_scope(&pl->opt);
   const int n_ops = (int)pl->ops.size();
   hipEvent_t* ev = nullptr;
   if (pl->prof_cap > 0 && pl->prof_n < pl->prof_cap)
     ev = pl->prof_ev.data() + (size_t)pl->prof_n * (n_ops + 1);
   int rc;
-  if (!ev && pl->fused2d && !getenv("SUP3R_AMD_NO_FUSED2D")) {
+  if (!ev && pl->fused2d && !s3_opt_has(S3O_NO_FUSED2D)) {
     rc = bind_inputs(pl, inputs);
     if (rc) return rc;
     float* dst = output ? (float*)output : tptr(pl, pl->output);
@@ -1250,7 +1357,7 @@ extern "C" int s3_plan_tensor_dtype(const s3_plan* pl, int32_t id) {
   int r = id;
   while (pl->t[r].alias_root >= 0) r = pl->t[r].alias_root;
   // the whole-network kernel keeps every intermediate tensor in LDS as bf16
-  if (pl->fused2d && !getenv("SUP3R_AMD_NO_FUSED2D")) {
+  if (pl->fused2d && !s3_opt_has(S3O_NO_FUSED2D)) {
     int out_r = pl->output;
     while (pl->t[out_r].alias_root >= 0) out_r = pl->t[out_r].alias_root;
     return (pl->t[r].is_input || r == out_r) ? 0 : 1;
@@ -1292,12 +1399,12 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
     } else if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16) {
       fwd = S3_FWD_FEWPOS;
     } else if (o.io.in_bf16 && !o.io.out_bf16 && !res && conv_tail_mfma_supported(o.cg) &&
-               !getenv("SUP3R_AMD_NO_TAIL_MFMA")) {
+               !s3_opt_has(S3O_NO_TAIL_MFMA)) {
       fwd = S3_FWD_TAIL_MFMA;
     } else if (!o.io.out_bf16 && !res && conv_small_supported(o.cg, o.io.in_bf16)) {
       fwd = S3_FWD_SMALL;
     }
-    const bool fused = pl->fused2d && !pl->training && !getenv("SUP3R_AMD_NO_FUSED2D");
+    const bool fused = pl->fused2d && !pl->training && !s3_opt_has(S3O_NO_FUSED2D);
     if (fused) fwd = S3_FWD_FUSED2D;
     v[S3_OPINFO_FWD] = fwd;
     v[S3_OPINFO_IN16] = o.io.in_bf16; v[S3_OPINFO_OUT16] = o.io.out_bf16; v[S3_OPINFO_RES16] = o.io.res_bf16;
@@ -1381,6 +1488,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
                                 int need_wgrad, int accumulate_wgrad) {
   if (!pl || !d_output) return S3_EINVAL;
   s3_ctx* ctx = pl->ctx;
+  S3OptScope opt_scope(&pl->opt);
   if (!pl->training) S3_FAIL(ctx, S3_ESTATE, "backward on an inference plan");
   if (!pl->forward_done) S3_FAIL(ctx, S3_ESTATE, "backward before forward");
   s3_params* P = pl->params;
@@ -1458,7 +1566,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
                         (g.d2s <= 1 || o.io.out_bf16)) ? pl->dpre16 : nullptr;
           // the bias gradient = channel sums of dpre: they ride along this pass
           mask_sums = need_wgrad && d.b >= 0 && pl->bsum2 && conv_epilogue_bwd_bsum_ok(g) &&
-                      !getenv("SUP3R_AMD_NO_BIAS_FUSE");
+                      !s3_opt_has(S3O_NO_BIAS_FUSE);
           rc = launch_conv_epilogue_bwd(ctx, g, tptr(pl, d.out), dy, pl->dpre, o.io.out_bf16, side,
                                         mask_sums ? pl->bsum2 : nullptr);
           if (rc) return rc;
@@ -1515,13 +1623,13 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           auto fold_frame = [&](const GatherGeom& fg, float* out) -> int {
             const int rin = root_of(pl, d.in0);
             const bool fuse = o.mask_prod >= 0 && !pl->gwritten[rin] && gather_bwd_mask_ok(fg) &&
-                              !getenv("SUP3R_AMD_NO_MASK_FUSE");
+                              !s3_opt_has(S3O_NO_MASK_FUSE);
             // the stored tensor is (so far) the whole gradient of d.in0: its
             // channel sums = the bias gradient of the conv that produced it
             // ride along (grad_deliver drops them if the tensor changes later)
             float* bs = nullptr;
             if (need_wgrad && pl->bsum && out == pl->t[rin].gptr && gather_bwd_bsum_ok(fg) &&
-                gather_bwd_bsum_blocks(ctx, fg) <= 4096 && !getenv("SUP3R_AMD_NO_BIAS_FUSE")) {
+                gather_bwd_bsum_blocks(ctx, fg) <= 4096 && !s3_opt_has(S3O_NO_BIAS_FUSE)) {
               bs = pl->bsum;
               pl->bsum_for = rin;
               pl->bsum_nblk = gather_bwd_bsum_blocks(ctx, fg);
@@ -1535,7 +1643,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               // the producer of this (now finished) skip tensor is a conv without
               // activation whose gradient kernels stage bf16: leave a bf16 copy
               void* side = nullptr;
-              if (o.in_prod >= 0 && pl->dpre16 && pl->dpre16_for < 0 && !getenv("SUP3R_AMD_NO_FOLD16")) {
+              if (o.in_prod >= 0 && pl->dpre16 && pl->dpre16_for < 0 && !s3_opt_has(S3O_NO_FOLD16)) {
                 const OpRec& po = pl->ops[o.in_prod];
                 if (po.use16 && po.cg.act == S3_ACT_NONE && po.cg.d2s <= 1 && (po.cg.Cout & 3) == 0) side = pl->dpre16;
               }
@@ -1550,8 +1658,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               // (grad_deliver drops the copy if a second contribution arrives)
               void* side = nullptr;
               if (o.in_prod >= 0 && out == pl->t[rin].gptr && !pl->gwritten[rin] && pl->dpre16 &&
-                  pl->dpre16_for < 0 && gather_bwd_mask_ok(fg) && !getenv("SUP3R_AMD_NO_FOLD16") &&
-                  !getenv("SUP3R_AMD_NO_PLAIN_FOLD16")) {
+                  pl->dpre16_for < 0 && gather_bwd_mask_ok(fg) && !s3_opt_has(S3O_NO_FOLD16) &&
+                  !s3_opt_has(S3O_NO_PLAIN_FOLD16)) {
                 const OpRec& po = pl->ops[o.in_prod];
                 if (po.use16 && po.cg.act == S3_ACT_NONE && po.cg.d2s <= 1 && (po.cg.Cout & 3) == 0 &&
                     pl->dpre16_bytes >= (size_t)pl->t[rin].numel * 2)
@@ -1668,7 +1776,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             // single consumer of an activated conv output: its LeakyReLU / ReLU
             // adjoint is applied in the store (the producer then skips its mask pass)
             const int rin = root_of(pl, d.in0);
-            const bool fuse = o.mask_prod >= 0 && !pl->gwritten[rin] && !getenv("SUP3R_AMD_NO_MASK_FUSE");
+            const bool fuse = o.mask_prod >= 0 && !pl->gwritten[rin] && !s3_opt_has(S3O_NO_MASK_FUSE);
             const OpRec& po = pl->ops[fuse ? o.mask_prod : i];
             const ConvGeom& pg = po.cg;
             // dx is dPre of the few-channel conv below (mask fused, single
@@ -1684,8 +1792,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
                               po.cg.Cin == 2 && po.cg.Cout == 32 && po.d.res < 0 &&
                               (po.dgrad_c2 || !wants_grad(po.d.in0)) && conv_dgrad_s2_out16_ok(g) && pl->dpre16 &&
                               pl->dpre16_bytes >= (size_t)pl->t[rin].numel * 2 && pl->dpre16_for < 0 &&
-                              (!sums || (pl->bsum && nblk <= 4096 && !getenv("SUP3R_AMD_NO_BIAS_FUSE"))) &&
-                              !getenv("SUP3R_AMD_NO_DPRE16");
+                              (!sums || (pl->bsum && nblk <= 4096 && !s3_opt_has(S3O_NO_BIAS_FUSE))) &&
+                              !s3_opt_has(S3O_NO_DPRE16);
             rc = launch_conv_dgrad_s2(ctx, g, dpre, o.dc2_w, to16 ? (float*)pl->dpre16 : dst,
                                       fuse ? tptr(pl, d.in0) : nullptr, pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f,
                                       o.io.in_bf16, to16 ? 1 : 0, (to16 && sums) ? pl->bsum : nullptr);
@@ -1805,6 +1913,27 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
       default: break;
     }
     if (rc) return rc;
+    // bucketed all-reduce under the backward pass: the gradients of every
+    // parameter at or above this op's are final in stream order
+    if (need_wgrad && P->armed && (d.w >= 0 || d.b >= 0)) {
+      int64_t lowest = P->reduce_end;
+      if (d.w >= 0 && P->p[d.w].offset < lowest) lowest = P->p[d.w].offset;
+      if (d.b >= 0 && P->p[d.b].offset < lowest) lowest = P->p[d.b].offset;
+      if (P->reduce_end - lowest >= P->bucket_elems) {
+        rc = s3_comm_reduce_range(ctx, G + lowest, P->reduce_end - lowest);
+        if (rc) return rc;
+        P->reduce_end = lowest;
+        P->buckets_issued++;
+      }
+    }
+  }
+  if (need_wgrad && P->armed) {
+    if (P->reduce_end > 0) {
+      const int rc = s3_comm_reduce_range(ctx, G, P->reduce_end);
+      if (rc) return rc;
+      P->reduce_end = 0;
+      P->buckets_issued++;
+    }
   }
   if (d_input) {
     if (x_id < 0 || !pl->gwritten[x_id]) S3_FAIL(ctx, S3_ESTATE, "backward: no gradient reached the input");

@@ -28,6 +28,7 @@ class Device:
     current stream on that device."""
 
     _cache = {}
+    _option_names = None
 
     def __init__(self, index=0):
         torch = _torch()
@@ -45,6 +46,7 @@ class Device:
         _lib.check(rc, h, 's3_ctx_create')
         self.ctx = h
         self.rank, self.nranks = 0, 1
+        self._set, self.options_key = {}, ()   # options changed since creation
 
     @classmethod
     def get(cls, index=None):
@@ -56,6 +58,11 @@ class Device:
 
     def sync(self):
         _lib.check(_lib.lib().s3_ctx_sync(self.ctx), self.ctx, 'sync')
+
+    def option_names(self):
+        if Device._option_names is None:
+            Device._option_names = _lib.option_names()
+        return Device._option_names
 
     def stat(self, name):
         """launch counter of a run-time kernel choice (``_lib.STATS``)"""
@@ -79,6 +86,43 @@ class Device:
         arr = np.ascontiguousarray(np.asarray(arr, dtype=np.float32))
         return torch.from_numpy(arr).to(self.torch_device)
 
+    # -- options: kernel-selection switches of this context (defaults of the
+    # plans created from it; include/sup3r_hip.h).  The SUP3R_AMD_<NAME>
+    # environment is read once, when the context is created.
+    def set_option(self, name, value=1):
+        """value None removes the option (default behaviour)"""
+        rc = _lib.lib().s3_ctx_set_option(
+            self.ctx, name.encode(),
+            _lib.OPTION_UNSET if value is None else int(value))
+        _lib.check(rc, self.ctx, f's3_ctx_set_option({name})')
+        self._set[name] = None if value is None else int(value)
+        self.options_key = tuple(sorted(self._set.items()))
+
+    def get_option(self, name):
+        v = C.c_int32()
+        rc = _lib.lib().s3_ctx_get_option(self.ctx, name.encode(),
+                                          C.byref(v))
+        if rc < 0:
+            raise KeyError(f'unknown option "{name}"')
+        return int(v.value) if rc == 1 else None
+
+    def options(self, **values):
+        """``with dev.options(NO_PERSIST=1): ...`` — set for the block, the
+        previous values restored afterwards"""
+        dev = self
+
+        class _Scope:
+            def __enter__(self):
+                self.old = {k: dev.get_option(k) for k in values}
+                for k, v in values.items():
+                    dev.set_option(k, v)
+                return dev
+
+            def __exit__(self, *exc):
+                for k, v in self.old.items():
+                    dev.set_option(k, v)
+        return _Scope()
+
     def init_comm(self, rank, nranks, unique_id):
         rc = _lib.lib().s3_comm_init(self.ctx, rank, nranks, unique_id)
         _lib.check(rc, self.ctx, 's3_comm_init')
@@ -95,7 +139,7 @@ def precision_code(precision=None):
 class PlanHandle:
     """One s3_plan (fixed input shape, precision, training flag)."""
 
-    def __init__(self, net, plan, precision, training):
+    def __init__(self, net, plan, precision, training, options=None):
         L = _lib.lib()
         self.net, self.plan = net, plan
         self.dev = net.dev
@@ -127,9 +171,12 @@ class PlanHandle:
         inp = (C.c_int32 * len(self.input_names))(
             *[plan.inputs[k] for k in self.input_names])
         h = C.c_void_p()
-        rc = L.s3_plan_create(self.dev.ctx, net.params, tens, nt, ops, nops,
-                              inp, len(self.input_names), plan.output,
-                              precision, int(training), C.byref(h))
+        popt, keep = _lib.plan_options(options)
+        rc = L.s3_plan_create_opt(
+            self.dev.ctx, net.params, tens, nt, ops, nops, inp,
+            len(self.input_names), plan.output, precision, int(training),
+            C.byref(popt) if options else None, C.byref(h))
+        del keep
         _lib.check(rc, self.dev.ctx, 's3_plan_create')
         self.h = h
         self.out_shape = plan.out_shape
@@ -306,15 +353,25 @@ class Network:
                     ws.append(np.zeros(p['shape'], np.float32))
             self.set_weights(ws)
 
-    def plan(self, in_shape, training=False, precision=None, slot=0):
+    def plan(self, in_shape, training=False, precision=None, slot=0,
+             options=None):
+        """The shape-specialised plan (cached).  ``options``: kernel-selection
+        switches of THIS plan on top of the context's (``Device.set_option``),
+        e.g. ``{'NO_PERSIST': 1}``; a plan keeps the options it was created
+        with."""
         in_shape = tuple(int(v) for v in in_shape)
         prec = precision_code(precision or self.precision)
-        key = (in_shape, bool(training), prec, slot)
+        okey = tuple(sorted((options or {}).items()))
+        # (the context's options in force when the plan is built belong to
+        # its identity too)
+        ckey = self.dev.options_key
+        key = (in_shape, bool(training), prec, slot, okey, ckey)
         if key not in self._plans:
             self.build(in_shape)
             plan = S.build_plan(self.layers, in_shape,
                                 param_table=self.param_table)
-            self._plans[key] = PlanHandle(self, plan, prec, training)
+            self._plans[key] = PlanHandle(self, plan, prec, training,
+                                          options=options)
         return self._plans[key]
 
     def clear_plans(self):
@@ -388,15 +445,20 @@ class Network:
                    'zero_grad')
 
     def adam_step(self, lr, beta_1, beta_2, epsilon, t):
-        rc = _lib.lib().s3_adam_step(self.params, lr, beta_1, beta_2, epsilon,
-                                     int(t))
-        _lib.check(rc, self.dev.ctx, 's3_adam_step')
+        self.optimizer_step(_lib.OPT_ADAM, [lr, beta_1, beta_2, epsilon], t)
 
     def optimizer_step(self, kind, hyper, t):
-        hp = (C.c_float * len(hyper))(*[float(v) for v in hyper])
+        hp = (C.c_double * len(hyper))(*[float(v) for v in hyper])
         rc = _lib.lib().s3_optimizer_step(self.params, int(kind), hp,
                                           len(hyper), int(t))
         _lib.check(rc, self.dev.ctx, 's3_optimizer_step')
+
+    def arm_allreduce(self, bucket_bytes):
+        """the next backward pass that writes this store's gradients reduces
+        them over the ranks bucket by bucket while it runs"""
+        rc = _lib.lib().s3_params_arm_allreduce(self.params,
+                                                int(bucket_bytes))
+        _lib.check(rc, self.dev.ctx, 's3_params_arm_allreduce')
 
     def allreduce_grads(self):
         rc = _lib.lib().s3_params_allreduce_grads(self.params)

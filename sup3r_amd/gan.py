@@ -65,6 +65,12 @@ class Sup3rGan:
     # ``ForwardPass.iter_chunks`` may stack chunks and run the plan itself
     # (subclasses that change ``generate`` switch this off)
     supports_device_chunks = True
+    # data-parallel training: size of the gradient buckets handed to RCCL
+    # while the backward pass is still running (0 / None: one all-reduce of
+    # the whole buffer after it).  xGMI is point-to-point: few, large
+    # collectives — 16 MB keeps every link busy and still leaves 9 buckets of
+    # the 148 MB discriminator to hide under its backward pass.
+    allreduce_bucket_bytes = 16 << 20
 
     def __init__(self, gen_layers, disc_layers, loss='MeanSquaredError',
                  optimizer=None, learning_rate=1e-4, optimizer_disc=None,
@@ -533,6 +539,11 @@ class Sup3rGan:
                 # (the loss kernels WRITE their scalar slots: one buffer per
                 # shard, summed on the device)
                 part = self._compute.new_scalars()
+                if len(mine) < n_shards and j == len(mine) - 1 and \
+                        self.allreduce_bucket_bytes:
+                    # the other shards live on other GPUs: the RCCL SUM runs
+                    # bucket by bucket under this (last) backward pass
+                    kw['overlap_bucket'] = int(self.allreduce_bucket_bytes)
                 which, details = self.get_single_grad(
                     shard_batch(low_res, r, n_shards),
                     shard_batch(hi_res_true, r, n_shards), defer=True,

@@ -38,3 +38,20 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def config_dir():
     return CONFIG_DIR
+
+
+@pytest.fixture(autouse=True)
+def _reset_context_options():
+    """kernel-selection options a test set on the GPU context
+    (``helpers.switch``) do not leak into the next test"""
+    yield
+    try:
+        from sup3r_amd.engine import Device
+    except Exception:
+        return
+    for dev in list(Device._cache.values()):
+        for name, value in list(dev._set.items()):
+            if value is not None:
+                dev.set_option(name, None)
+        dev._set.clear()
+        dev.options_key = ()

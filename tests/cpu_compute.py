@@ -140,7 +140,8 @@ class CpuGanCompute:
                        weight_gen_advers=0.001, train_gen=True,
                        train_disc=False, compute_disc=False, exo_names=(),
                        backward=True, hi_res_gen=None, mask=None,
-                       accumulate_wgrad=False, scal=None, defer=False):
+                       accumulate_wgrad=False, scal=None, defer=False,
+                       overlap_bucket=None):
         assert hi_res_gen is None and mask is None
         spec = {n: {} for n, *_ in loss_terms}
         spec['term_weights'] = [t[2] for t in loss_terms]

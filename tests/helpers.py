@@ -6,6 +6,15 @@ import collections
 
 import numpy as np
 
+def switch(name, value=1):
+    """Set (``None``: remove) a kernel-selection option of the GPU context —
+    the default of every plan created afterwards (``include/sup3r_hip.h``
+    "options"; a plan keeps the options it was created with).  The autouse
+    fixture of ``tests/conftest.py`` removes whatever a test set."""
+    from sup3r_amd.engine import Device
+    Device.get().set_option(name, value)
+
+
 Batch = collections.namedtuple('Batch', ['low_res', 'high_res'])
 MomBatch = collections.namedtuple(
     'MomBatch', ['low_res', 'high_res', 'output', 'mask'])
@@ -168,6 +177,16 @@ def emulate_plan(ref, ph, masks=False, rounding=True, sample=slice(None)):
             assert tgt is not None, (oi, lis)
             want = tgt._pre.shape if hasattr(tgt, 'kernel') else tgt._x.shape
             m = y > 0
+            b = int(op.get('d2s', 1) or 1)
+            if b > 1 and hasattr(tgt, 'kernel'):
+                # the activation of a conv that also carries the
+                # depth-to-space store: the device tensor is the permuted one,
+                # out[n, h b + i, w b + j, t, c] = pre[n, h, w, t, (i b + j) Co
+                # + c] (DCR) — undo the permutation for the conv's own mask
+                n_, s1, s2, t_, co = m.shape
+                m = m.reshape(n_, s1 // b, b, s2 // b, b, t_, co)
+                m = m.transpose(0, 1, 3, 5, 2, 4, 6).reshape(
+                    n_, s1 // b, s2 // b, t_, b * b * co)
             if m.size != int(np.prod(want)):
                 # a conv with a fused activation kwarg followed by a crop
                 # (Conv2DTranspose(activation=relu) + Cropping2D): the oracle

@@ -156,3 +156,60 @@ def test_rccl_single_rank_allreduce():
     dev.sync()
     for a, b in zip(net.grads, gs):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_bucketed_allreduce_under_the_backward_pass_single_rank():
+    """``s3_params_arm_allreduce``: the backward pass hands the finished tail
+    of the gradient buffer to RCCL bucket by bucket on the comm stream.  With
+    a 1-rank communicator the SUM is the identity, so the armed step must
+    leave exactly the gradients (and, after Adam, the weights) of the plain
+    step — and the buckets must cover the buffer exactly once."""
+    import ctypes as C
+    import os
+    from sup3r_amd import Sup3rGan, _lib
+    from sup3r_amd.engine import Device
+    L = _lib.lib()
+    dev = Device.get()
+    uid = (C.c_char * 128)()
+    assert L.s3_comm_unique_id(uid) == 0
+    dev.init_comm(0, 1, uid)
+    cfg = os.path.join(os.path.dirname(__file__), '..', 'sup3r_amd',
+                       'configs')
+    rng = np.random.default_rng(3)
+    lr = rng.standard_normal((4, 4, 4, 4, 2)).astype(np.float32)
+    hr = rng.standard_normal((4, 8, 8, 16, 2)).astype(np.float32)
+
+    def run(bucket):
+        Sup3rGan.seed(4)
+        m = Sup3rGan(os.path.join(cfg, 'test_gen_st_2x_4x_2f.json'),
+                     os.path.join(cfg, 'test_disc_st_same.json'),
+                     loss='MeanAbsoluteError', learning_rate=1e-3)
+        m.init_weights(lr.shape, hr.shape)
+        out = {}
+        for which, kw in (('gen', dict(train_gen=True, train_disc=False)),
+                          ('disc', dict(train_gen=False, train_disc=True))):
+            net = m.generator if which == 'gen' else m.discriminator
+            total = sum(int(w.size) for w in net.weights)
+            before = dev.stat('bucket_elems')
+            m._compute.loss_and_grads(
+                lr, hr, m._loss_terms, weight_gen_advers=1e-2,
+                overlap_bucket=bucket, **kw)
+            m._compute.allreduce_grads(which)
+            dev.sync()
+            if bucket:
+                assert dev.stat('bucket_elems') - before == total, which
+            out[which] = net.grads
+            m._compute.apply(which, m.optimizer if which == 'gen'
+                             else m.optimizer_disc)
+        return out, m.weights
+    g0, w0 = run(None)
+    for bucket in (4096, 1 << 30):          # many small buckets / one
+        g1, w1 = run(bucket)
+        for which in g0:
+            for a, b in zip(g1[which], g0[which]):
+                np.testing.assert_array_equal(a, b)
+        for a, b in zip(w1, w0):
+            np.testing.assert_array_equal(a, b)
+    L.s3_comm_destroy(dev.ctx)
+    dev.rank, dev.nranks = 0, 1

@@ -11,6 +11,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.helpers import switch
+
 pytestmark = pytest.mark.gpu
 
 CFG = os.path.join(os.path.dirname(__file__), '..', 'sup3r_amd', 'configs')
@@ -188,11 +190,11 @@ def test_persistent_trunk_kernel_matches_tile_kernel_and_oracle():
     y = net(x).cpu().numpy()
     scale = max(1.0, np.abs(y_ref).max())
     assert np.abs(y - y_ref).max() / scale < 3e-2
-    os.environ['SUP3R_AMD_NO_PERSIST'] = '1'
+    switch('NO_PERSIST', 1)
     try:
         y_tile = net(x).cpu().numpy()
     finally:
-        del os.environ['SUP3R_AMD_NO_PERSIST']
+        switch('NO_PERSIST', None)
     assert np.abs(y - y_tile).max() / scale < 1e-2
 
 
@@ -218,11 +220,11 @@ def test_persistent_kernel_cout_tiles_and_depth_to_space():
     assert y.shape == (6, 75, 90, 52, 2)
     scale = max(1.0, np.abs(y_ref).max())
     assert np.abs(y - y_ref).max() / scale < 3e-2
-    os.environ['SUP3R_AMD_NO_PERSIST'] = '1'
+    switch('NO_PERSIST', 1)
     try:
         y_tile = net(x).cpu().numpy()
     finally:
-        del os.environ['SUP3R_AMD_NO_PERSIST']
+        switch('NO_PERSIST', None)
     assert np.abs(y - y_tile).max() / scale < 1e-2
 
 
@@ -282,11 +284,11 @@ def test_tail_conv_mfma_vs_oracle_and_direct_kernel(n_out):
     scale = max(1.0, np.abs(y_ref).max())
     assert np.abs(y - y_ref).max() / scale < 3e-2
     if n_out == 2:
-        os.environ['SUP3R_AMD_NO_TAIL_MFMA'] = '1'
+        switch('NO_TAIL_MFMA', 1)
         try:
             y_direct = net(x).cpu().numpy()
         finally:
-            del os.environ['SUP3R_AMD_NO_TAIL_MFMA']
+            switch('NO_TAIL_MFMA', None)
         assert np.abs(y - y_direct).max() / scale < 1e-2
 
 
@@ -392,20 +394,20 @@ def test_hipgraph_replay_is_bit_identical(monkeypatch):
     ref = _oracle_net(spec, x, None)
     net = _hip_net(spec, ref.weights)
     y_eager = net(x).cpu().numpy()
-    monkeypatch.setenv('SUP3R_AMD_GRAPH', '1')
+    switch('GRAPH', 1)
     for _ in range(4):                      # eager warm-up, capture, replays
         y = net(x).cpu().numpy()
         np.testing.assert_array_equal(y, y_eager)
     x2 = rng.standard_normal(shape).astype(np.float32)
     y2 = net(x2).cpu().numpy()
-    monkeypatch.delenv('SUP3R_AMD_GRAPH')
+    switch('GRAPH', None)
     np.testing.assert_array_equal(y2, net(x2).cpu().numpy())
-    monkeypatch.setenv('SUP3R_AMD_GRAPH', '1')
+    switch('GRAPH', 1)
     w = [v * 1.01 for v in net.weights]
     net.set_weights(w)
     y3 = net(x).cpu().numpy()
     y3b = net(x).cpu().numpy()
-    monkeypatch.delenv('SUP3R_AMD_GRAPH')
+    switch('GRAPH', None)
     np.testing.assert_array_equal(y3, net(x).cpu().numpy())
     np.testing.assert_array_equal(y3b, y3)
     assert np.abs(y3 - y_eager).max() > 0
@@ -435,7 +437,7 @@ def test_trunk_wgrad_bf16_transpose_read_kernel(monkeypatch):
         ph.backward(net.dev.to_device(dy), need_dx=False)
         return [np.array(g) for g in net.grads]
     g_bf = grads()
-    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_BF16', '1')
+    switch('NO_WGRAD_BF16', 1)
     g_32 = grads()
     for i, (a, b, r) in enumerate(zip(g_bf, g_32, ref.grads)):
         assert np.abs(a - r).max() < 1e-1 * np.abs(r).max(), i
@@ -474,8 +476,8 @@ def test_disc_wgrad_bf16_transpose_read_general_kernel(monkeypatch):
         ph.backward(net.dev.to_device(dy), need_dx=False)
         return [np.array(g) for g in net.grads]
     g_bf = grads()
-    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_BF16', '1')
-    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_C2', '1')
+    switch('NO_WGRAD_BF16', 1)
+    switch('NO_WGRAD_C2', 1)
     g_32 = grads()
     gmax = max(float(np.abs(g).max()) for g in ref.grads)
     for i, (a, b, r) in enumerate(zip(g_bf, g_32, ref.grads)):
@@ -514,8 +516,8 @@ def test_valid_conv_dgrad_on_halo_tile_kernel(monkeypatch):
         dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
         return dx, [np.array(g) for g in net.grads]
     dx, g = run()
-    monkeypatch.setenv('SUP3R_AMD_NO_MFMA_BWD', '1')
-    monkeypatch.setenv('SUP3R_AMD_NO_DGRAD_C2', '1')   # 32 -> 2: LDS-halo kernel off too
+    switch('NO_MFMA_BWD', 1)
+    switch('NO_DGRAD_C2', 1)   # 32 -> 2: LDS-halo kernel off too
     dx2, g2 = run()
     assert np.abs(dx - dx2).max() > 0
     assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
@@ -557,7 +559,7 @@ def test_2d_wgrad_bf16_transpose_read_kernel(monkeypatch):
         ph.backward(net.dev.to_device(dy), need_dx=False)
         return [np.array(g) for g in net.grads]
     g_bf = grads()
-    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_BF16', '1')
+    switch('NO_WGRAD_BF16', 1)
     g_32 = grads()
     ndiff = 0
     for i, (a, b, r) in enumerate(zip(g_bf, g_32, ref.grads)):
@@ -593,14 +595,14 @@ def test_tail_conv_wgrad_ldsfree_kernel_with_reflect_padding(monkeypatch):
         ph.backward(net.dev.to_device(dy), need_dx=False)
         return [np.array(g) for g in net.grads]
     g_bf = grads()
-    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_C2', '1')
+    switch('NO_WGRAD_C2', 1)
     g_32 = grads()
     a, b, r = g_bf[2], g_32[2], ref.grads[2]          # the 8 -> 2 kernel
     assert a.shape == (3, 3, 3, 8, 2)
     # its data gradient runs as a 2-channel forward conv over the padded frame
     # (SUP3R_AMD_NO_DGRAD_FEWCH=1: direct kernel, fp32): the first conv's
     # weight gradient sees it
-    monkeypatch.setenv('SUP3R_AMD_NO_DGRAD_FEWCH', '1')
+    switch('NO_DGRAD_FEWCH', 1)
     g_dd = grads()
     assert np.abs(g_32[0] - g_dd[0]).max() > 0
     rms0 = np.sqrt(((g_32[0] - g_dd[0]) ** 2).mean()) / np.sqrt((g_dd[0] ** 2).mean())
@@ -638,7 +640,7 @@ def test_training_plan_bf16_saved_activations(monkeypatch):
         dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
         return y, dx, [np.array(g) for g in net.grads]
     y16, dx16, g16 = run()
-    monkeypatch.setenv('SUP3R_AMD_BF16_TRAIN_ACT', '0')
+    switch('BF16_TRAIN_ACT', 0)
     y32, dx32, g32 = run()
 
     def rel_rms(a, b):
@@ -674,7 +676,7 @@ def test_training_plan_bf16_first_discriminator_activation(monkeypatch, capfd):
     y_ref = ref.forward(x)
     dy = rng.standard_normal(y_ref.shape).astype(np.float32)
     dx_ref = ref.backward(dy)
-    monkeypatch.setenv('SUP3R_AMD_TRACE', '1')
+    switch('TRACE', 1)
 
     def run():
         net = _hip_net(spec, ref.weights, precision='bf16')
@@ -691,7 +693,7 @@ def test_training_plan_bf16_first_discriminator_activation(monkeypatch, capfd):
     # ... and the stride-2 conv hands bf16 cells on to the third conv
     third = [ln for ln in trace.splitlines() if 'conv 32->16 train' in ln]
     assert 'out16 1' in second[0] and third and 'in16 1' in third[0], trace
-    monkeypatch.setenv('SUP3R_AMD_NO_DISC_BF16', '1')
+    switch('NO_DISC_BF16', 1)
     y32, dx32, g32 = run()
     trace = capfd.readouterr().err
     assert not [ln for ln in trace.splitlines()
@@ -725,8 +727,8 @@ def test_halo32_forward_conv_vs_oracle_and_gather_kernel(monkeypatch, capfd):
     x = rng.standard_normal(shape).astype(np.float32)
     ref = _oracle_net(spec, x, None)
     y_ref = ref.forward(x)
-    monkeypatch.setenv('SUP3R_AMD_HALO32_MIN_TILES', '1')
-    monkeypatch.setenv('SUP3R_AMD_TRACE', '1')
+    switch('HALO32_MIN_TILES', 1)
+    switch('TRACE', 1)
     net = _hip_net(spec, ref.weights, precision='bf16')
     y = net(x).cpu().numpy()
     ph = net.plan(shape, training=True)
@@ -734,7 +736,7 @@ def test_halo32_forward_conv_vs_oracle_and_gather_kernel(monkeypatch, capfd):
     trace = capfd.readouterr().err
     # 32 -> 64 (valid) and 32 -> 24 ('same'), inference and training plan
     assert trace.count('halo32 1') == 4, trace
-    monkeypatch.setenv('SUP3R_AMD_NO_HALO32', '1')
+    switch('NO_HALO32', 1)
     net2 = _hip_net(spec, ref.weights, precision='bf16')
     y2 = net2(x).cpu().numpy()
     assert 'halo32 1' not in capfd.readouterr().err
@@ -762,14 +764,14 @@ def test_fewch_halo_forward_conv_vs_oracle_and_gather_variant(monkeypatch):
     cases = [(conv(32, 'valid'), (2, 11, 13, 45, 2)),
              (conv(24, 'same'), (2, 9, 10, 37, 2)),
              (pcc(3, 64), (2, 9, 10, 37, 4))]
-    monkeypatch.setenv('SUP3R_AMD_FEWCH_HALO_MIN_TILES', '1')
+    switch('FEWCH_HALO_MIN_TILES', 1)
     for spec, shape in cases:
         x = rng.standard_normal(shape).astype(np.float32)
         ref = _oracle_net(spec, x, None)
         y_ref = ref.forward(x)
-        monkeypatch.delenv('SUP3R_AMD_NO_FEWCH_HALO', raising=False)
+        switch('NO_FEWCH_HALO', None)
         y = _hip_net(spec, ref.weights, precision='bf16')(x).cpu().numpy()
-        monkeypatch.setenv('SUP3R_AMD_NO_FEWCH_HALO', '1')
+        switch('NO_FEWCH_HALO', 1)
         y2 = _hip_net(spec, ref.weights, precision='bf16')(x).cpu().numpy()
         scale = max(1.0, np.abs(y_ref).max())
         assert y.shape == y_ref.shape
@@ -799,9 +801,9 @@ def test_tail_conv_wgrad_halo_transpose_read_kernel(monkeypatch):
             ph.forward(net.dev.to_device(x))
             ph.backward(net.dev.to_device(dy), need_dx=False)
             return np.array(net.grads[2])
-        monkeypatch.delenv('SUP3R_AMD_NO_WGRAD_TAIL', raising=False)
+        switch('NO_WGRAD_TAIL', None)
         a = grads()
-        monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_TAIL', '1')
+        switch('NO_WGRAD_TAIL', 1)
         b = grads()
         r = ref.grads[2]
         assert a.shape == (3, 3, 3, 8, n_out)
@@ -822,7 +824,7 @@ def test_stride2_dgrad_residue_class_halo_kernel(monkeypatch, capfd):
         return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
                  'strides': s, 'padding': pad},
                 {'alpha': 0.2, 'class': 'LeakyReLU'}]
-    monkeypatch.setenv('SUP3R_AMD_DGRAD_S2_MIN_TILES', '1')
+    switch('DGRAD_S2_MIN_TILES', 1)
     for cin, shape in ((32, (2, 21, 18, 39, 2)), (64, (2, 20, 19, 38, 2))):
         spec = conv(cin, 1) + conv(32, 2) + [{'class': 'Flatten'},
                                              {'class': 'Dense', 'units': 1}]
@@ -838,12 +840,12 @@ def test_stride2_dgrad_residue_class_halo_kernel(monkeypatch, capfd):
             ph.forward(net.dev.to_device(x))
             dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
             return dx, np.array(net.grads[0])
-        monkeypatch.setenv('SUP3R_AMD_TRACE', '1')
-        monkeypatch.delenv('SUP3R_AMD_NO_DGRAD_S2', raising=False)
+        switch('TRACE', 1)
+        switch('NO_DGRAD_S2', None)
         capfd.readouterr()
         dx, g0 = run()
         assert ' s2 1 ' in capfd.readouterr().err          # the halo kernel was planned ...
-        monkeypatch.setenv('SUP3R_AMD_NO_DGRAD_S2', '1')
+        switch('NO_DGRAD_S2', 1)
         dx2, g02 = run()
         assert ' s2 1 ' not in capfd.readouterr().err      # ... and the gather kernel here
         assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
@@ -876,7 +878,7 @@ def test_chunked_dgrad_of_wide_conv_on_tile_kernel(monkeypatch):
         dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
         return dx, np.array(net.grads[0])
     dx, g0 = run()
-    monkeypatch.setenv('SUP3R_AMD_NO_DGRAD_CHUNKED', '1')
+    switch('NO_DGRAD_CHUNKED', 1)
     dx2, g02 = run()
 
     def rel_rms(a, b):

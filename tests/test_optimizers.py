@@ -87,10 +87,13 @@ def test_gan_trains_with_a_named_optimizer(tmp_path):
             weight_gen_advers=1e-3, checkpoint_int=None,
             out_dir=os.path.join(str(tmp_path), 'gan_{epoch}'))
     w0 = [w.copy() for w in m.generator_weights]
-    assert m.optimizer.iterations == 2 and m.optimizer.name == 'SGD'
+    # (the generator sits a batch out when the discriminator is outside its
+    # loss bounds: 1 or 2 steps)
+    n_it = m.optimizer.iterations
+    assert n_it in (1, 2) and m.optimizer.name == 'SGD'
     assert any(c.startswith('OptmGen/SGD/m/') for c in m.history.columns)
     m.update_optimizer('gen', learning_rate=5e-4)
-    assert m.optimizer.learning_rate == 5e-4 and m.optimizer.iterations == 2
+    assert m.optimizer.learning_rate == 5e-4 and m.optimizer.iterations == n_it
     m.train(bh, {'spatial': '8km', 'temporal': '60min'}, 1,
             weight_gen_advers=1e-3, checkpoint_int=None,
             out_dir=os.path.join(str(tmp_path), 'gan_{epoch}'))

@@ -32,7 +32,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.helpers import (emulate_plan, rel_linf, rel_max, rel_rms,
+from tests.helpers import (emulate_plan, rel_linf, rel_max, rel_rms, switch,
                            teacher_forced_check)
 
 pytestmark = pytest.mark.gpu
@@ -504,13 +504,12 @@ def test_shared_disc_pass_over_the_true_field_changes_nothing(monkeypatch):
     hr = rng.standard_normal((4, 8, 8, 16, 2)).astype(np.float32)
 
     def run(reuse):
-        if not reuse:
-            monkeypatch.setenv('SUP3R_AMD_NO_DTRUE_REUSE', '1')
         Sup3rGan.seed(3)
         m = Sup3rGan(os.path.join(CFG, 'test_gen_st_2x_4x_2f.json'),
                      os.path.join(CFG, 'test_disc_st_same.json'),
                      loss='MeanAbsoluteError', learning_rate=1e-3)
         m.init_weights(lr.shape, hr.shape)
+        m._compute.share_dtrue_allowed = reuse
 
         class B:
             low_res, high_res = lr, hr
@@ -520,7 +519,6 @@ def test_shared_disc_pass_over_the_true_field_changes_nothing(monkeypatch):
         B.high_res = hr[::-1].copy()
         out.append(m._train_batch(B, True, False, False, True, False, False,
                                   1e-2))
-        monkeypatch.delenv('SUP3R_AMD_NO_DTRUE_REUSE', raising=False)
         return out, m.weights
     d1, w1 = run(True)
     d0, w0 = run(False)
@@ -549,9 +547,9 @@ def test_sliding_window_tail_conv_is_bit_identical(monkeypatch):
         assert _kernels(ph)[-1] == 'tail_mfma'
         xd = net.dev.to_device(x)
         y_slide = ph.forward(xd).cpu().numpy()
-        monkeypatch.setenv('SUP3R_AMD_NO_TAIL_SLIDE', '1')
+        switch('NO_TAIL_SLIDE', 1)
         y_tile = ph.forward(xd).cpu().numpy()
-        monkeypatch.delenv('SUP3R_AMD_NO_TAIL_SLIDE')
+        switch('NO_TAIL_SLIDE', None)
         np.testing.assert_array_equal(y_slide, y_tile)
         assert rel_linf(y_slide, y_ref) < 3e-2
 
@@ -604,9 +602,9 @@ def test_fused_2d_kernel_short_chains(name, shape, monkeypatch):
     print(f'fused2d {name} {shape}: vs emulating oracle {err:.2e}, vs exact '
           f'{rel_linf(y, y_exact):.2e}')
     assert err < 2e-3, err
-    monkeypatch.setenv('SUP3R_AMD_NO_FUSED2D', '1')
+    switch('NO_FUSED2D', 1)
     y_ops = ph.forward(net.dev.to_device(x)).cpu().numpy()
-    monkeypatch.delenv('SUP3R_AMD_NO_FUSED2D')
+    switch('NO_FUSED2D', None)
     assert rel_linf(y, y_ops) < 2e-2
 
 
@@ -657,12 +655,12 @@ def test_gather_mfma_four_fragments_per_wave_is_bit_identical(monkeypatch):
         dy = net.dev.to_device(np.ones(tuple(y.shape), np.float32))
         dx = ph.backward(dy, need_dx=True).cpu().numpy()
         return y.cpu().numpy(), dx, net.grads
-    monkeypatch.setenv('SUP3R_AMD_GCONV_MF4', '1')   # the adjoint too
+    switch('GCONV_MF4', 1)   # the adjoint too
     y4, dx4, g4 = run()
-    monkeypatch.delenv('SUP3R_AMD_GCONV_MF4')
-    monkeypatch.setenv('SUP3R_AMD_GCONV_MF2', '1')
+    switch('GCONV_MF4', None)
+    switch('GCONV_MF2', 1)
     y2, dx2, g2 = run()
-    monkeypatch.delenv('SUP3R_AMD_GCONV_MF2')
+    switch('GCONV_MF2', None)
     np.testing.assert_array_equal(y4, y2)
     np.testing.assert_array_equal(dx4, dx2)
     for a, b in zip(g4, g2):
@@ -693,15 +691,16 @@ def test_gather_mfma_split_contraction_matches_the_unsplit_walk(monkeypatch):
     assert 'gconv' in _kernels(ph) and 'gconv' in _kernels(ph, 'dgrad')
     xd = net.dev.to_device(x)
 
-    def run():
+    def run(ph):
         y = ph.forward(xd)
         dy = net.dev.to_device(np.ones(tuple(y.shape), np.float32))
         dx = ph.backward(dy, need_dx=True).cpu().numpy()
         return y.cpu().numpy(), dx, [g.copy() for g in net.grads]
-    ys, dxs, gs = run()
-    monkeypatch.setenv('SUP3R_AMD_NO_GCONV_SPLITK', '1')
-    yu, dxu, gu = run()
-    monkeypatch.delenv('SUP3R_AMD_NO_GCONV_SPLITK')
+    ys, dxs, gs = run(ph)
+    # (a plan keeps the options it was created with: the unsplit walk is a
+    # second plan over the same parameter store)
+    yu, dxu, gu = run(net.plan(shape, training=True,
+                               options={'NO_GCONV_SPLITK': 1}))
     assert not np.array_equal(dxs, dxu) or not np.array_equal(ys, yu), \
         'the split path was not taken at this shape'
     assert rel_linf(ys, yu) < 1e-3
@@ -750,7 +749,7 @@ def test_stride2_lds_halo_conv_matches_the_gather_kernel(monkeypatch):
     spec = conv(32, 1) + conv(32, 2) + conv(64, 1) + \
         [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
     shape = (2, 25, 31, 75, 2)
-    monkeypatch.setenv('SUP3R_AMD_HALO_S2_MIN_TILES', '1')
+    switch('HALO_S2_MIN_TILES', 1)
     rng = np.random.default_rng(3)
     x = rng.standard_normal(shape).astype(np.float32)
     from sup3r_amd.engine import Network
@@ -760,13 +759,13 @@ def test_stride2_lds_halo_conv_matches_the_gather_kernel(monkeypatch):
     assert 'halo_s2' in _kernels(ph), _kernels(ph)
     xd = net.dev.to_device(x)
     y1 = ph.forward(xd).cpu().numpy()
-    monkeypatch.setenv('SUP3R_AMD_NO_HALO_S2', '1')
+    switch('NO_HALO_S2', 1)
     net2 = Network(spec, precision='bf16')
     net2.build(shape, seed=0)
     ph2 = net2.plan(shape, training=True)
     assert 'halo_s2' not in _kernels(ph2)
     y2 = ph2.forward(net2.dev.to_device(x)).cpu().numpy()
-    monkeypatch.delenv('SUP3R_AMD_NO_HALO_S2')
+    switch('NO_HALO_S2', None)
     np.testing.assert_array_equal(y1, y2)
     del ph, ph2
     net.clear_plans(); net2.clear_plans()
@@ -799,9 +798,9 @@ def test_bf16_side_copy_of_dpre_changes_nothing(monkeypatch):
         net.clear_plans()
         return dx, g
     dx1, g1 = run()
-    monkeypatch.setenv('SUP3R_AMD_NO_DPRE16', '1')
+    switch('NO_DPRE16', 1)
     dx0, g0 = run()
-    monkeypatch.delenv('SUP3R_AMD_NO_DPRE16')
+    switch('NO_DPRE16', None)
     np.testing.assert_array_equal(dx1, dx0)
     for a, b in zip(g1, g0):
         np.testing.assert_array_equal(a, b)
@@ -819,7 +818,7 @@ def test_trunk_data_gradient_on_the_persistent_kernel_is_bit_identical(monkeypat
     # positions, tiles straddle frames and overhang; 16 = 4 x 4)
     spec = _load('gen_5x_12x_2f.json')
     shape = (n_samples, 16, 16, 5, 4)
-    monkeypatch.setenv('SUP3R_AMD_PERSIST_DGRAD_MIN_TILES', '1')
+    switch('PERSIST_DGRAD_MIN_TILES', 1)
     rng = np.random.default_rng(8)
     x = rng.standard_normal(shape).astype(np.float32)
     from sup3r_amd.engine import Network
@@ -840,9 +839,9 @@ def test_trunk_data_gradient_on_the_persistent_kernel_is_bit_identical(monkeypat
         return dx, g, used
     dx1, g1, used1 = run()
     assert used1 > 0, 'no data gradient ran on the persistent kernel'
-    monkeypatch.setenv('SUP3R_AMD_NO_PERSIST_DGRAD', '1')
+    switch('NO_PERSIST_DGRAD', 1)
     dx0, g0, used0 = run()
-    monkeypatch.delenv('SUP3R_AMD_NO_PERSIST_DGRAD')
+    switch('NO_PERSIST_DGRAD', None)
     assert used0 == 0
     np.testing.assert_array_equal(dx1, dx0)
     for a, b in zip(g1, g0):
@@ -864,7 +863,7 @@ def test_first_disc_layer_bf16_only_dpre_changes_only_the_bias_sum_order(monkeyp
     spec = conv(32, 1) + conv(32, 2) + conv(64, 1) + \
         [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
     shape = (2, 27, 33, 77, 2)
-    monkeypatch.setenv('SUP3R_AMD_DGRAD_S2_MIN_TILES', '1')
+    switch('DGRAD_S2_MIN_TILES', 1)
     rng = np.random.default_rng(11)
     x = rng.standard_normal(shape).astype(np.float32)
     from sup3r_amd.engine import Network
@@ -882,9 +881,9 @@ def test_first_disc_layer_bf16_only_dpre_changes_only_the_bias_sum_order(monkeyp
         net.clear_plans()
         return dx, g
     dx1, g1 = run()
-    monkeypatch.setenv('SUP3R_AMD_NO_DPRE16', '1')
+    switch('NO_DPRE16', 1)
     dx0, g0 = run()
-    monkeypatch.delenv('SUP3R_AMD_NO_DPRE16')
+    switch('NO_DPRE16', None)
     np.testing.assert_array_equal(dx1, dx0)
     for k, (a, b) in enumerate(zip(g1, g0)):
         if a.ndim > 1:
@@ -920,9 +919,9 @@ def test_halo_tile_kernel_with_two_n_fragments_is_bit_identical(monkeypatch):
         net.clear_plans()
         return dx
     dx2 = run()
-    monkeypatch.setenv('SUP3R_AMD_NO_TILE_NF2', '1')
+    switch('NO_TILE_NF2', 1)
     dx4 = run()
-    monkeypatch.delenv('SUP3R_AMD_NO_TILE_NF2')
+    switch('NO_TILE_NF2', None)
     assert np.abs(dx2).max() > 0
     np.testing.assert_array_equal(dx2, dx4)
 
@@ -938,7 +937,7 @@ def test_valid_conv_data_gradient_on_the_persistent_kernel_is_bit_identical(monk
                  'strides': s, 'padding': 'valid'},
                 {'alpha': 0.2, 'class': 'LeakyReLU'}]
     spec = conv(64, 1) + [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
-    monkeypatch.setenv('SUP3R_AMD_PERSIST_DGRAD_MIN_TILES', '1')
+    switch('PERSIST_DGRAD_MIN_TILES', 1)
     rng = np.random.default_rng(15)
     x = rng.standard_normal(shape).astype(np.float32)
     from sup3r_amd.engine import Network
@@ -959,9 +958,9 @@ def test_valid_conv_data_gradient_on_the_persistent_kernel_is_bit_identical(monk
         return dx, g, used
     dx1, g1, used1 = run()
     assert used1 > 0, 'the data gradient did not run on the persistent kernel'
-    monkeypatch.setenv('SUP3R_AMD_NO_PERSIST_DGRAD', '1')
+    switch('NO_PERSIST_DGRAD', 1)
     dx0, g0, used0 = run()
-    monkeypatch.delenv('SUP3R_AMD_NO_PERSIST_DGRAD')
+    switch('NO_PERSIST_DGRAD', None)
     assert used0 == 0 and np.abs(dx1).max() > 0
     np.testing.assert_array_equal(dx1, dx0)
     for a, b in zip(g1, g0):
@@ -984,7 +983,7 @@ def test_wide_conv_data_gradient_slices_on_the_persistent_kernel(monkeypatch, n_
     # also runs on the wave-specialised kernel, its seventh cout tile moved
     # back to channels 168 .. 199)
     shape = (n_samples,) + extent + (4,)
-    monkeypatch.setenv('SUP3R_AMD_PERSIST_DGRAD_MIN_TILES', '1')
+    switch('PERSIST_DGRAD_MIN_TILES', 1)
     rng = np.random.default_rng(18)
     x = rng.standard_normal(shape).astype(np.float32)
     from sup3r_amd.engine import Network
@@ -1005,9 +1004,9 @@ def test_wide_conv_data_gradient_slices_on_the_persistent_kernel(monkeypatch, n_
         net.clear_plans()
         return dx, g, used
     dx1, g1, used1 = run()
-    monkeypatch.setenv('SUP3R_AMD_NO_CHUNKED_DY16', '1')
+    switch('NO_CHUNKED_DY16', 1)
     dx0, g0, used0 = run()
-    monkeypatch.delenv('SUP3R_AMD_NO_CHUNKED_DY16')
+    switch('NO_CHUNKED_DY16', None)
     assert used1 >= used0 + 4, (used1, used0)
     assert np.abs(dx1).max() > 0
     np.testing.assert_array_equal(dx1, dx0)
@@ -1041,9 +1040,9 @@ def test_wave_specialised_trunk_weight_gradient_is_bit_identical(monkeypatch):
         net.clear_plans()
         return g
     g1 = run()
-    monkeypatch.setenv('SUP3R_AMD_NO_WGRAD_WS', '1')
+    switch('NO_WGRAD_WS', 1)
     g0 = run()
-    monkeypatch.delenv('SUP3R_AMD_NO_WGRAD_WS')
+    switch('NO_WGRAD_WS', None)
     assert any(np.abs(a).max() > 0 for a in g1)
     for a, b in zip(g1, g0):
         np.testing.assert_array_equal(a, b)

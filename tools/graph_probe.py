@@ -10,6 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from sup3r_amd.engine import Device  # noqa: E402
 import torch  # noqa: E402
 from sup3r_amd.engine import Network  # noqa: E402
 
@@ -23,13 +24,13 @@ for cfg, shape, prec in [('gen_2x_2f.json', (15, 5, 5, 2), 'f32'),
     rng = np.random.default_rng(0)
     x = net.dev.to_device(rng.standard_normal(shape).astype(np.float32))
     out = net.dev.empty(ph.out_shape)
-    os.environ.pop('SUP3R_AMD_GRAPH', None)
+    Device.get().set_option('GRAPH', None)
     ph.forward(x, out=out)
     ref = out.clone()
     res = {}
     for mode in ('eager', 'graph'):
         if mode == 'graph':
-            os.environ['SUP3R_AMD_GRAPH'] = '1'
+            Device.get().set_option('GRAPH', 1)
         for _ in range(4):
             ph.forward(x, out=out)
         torch.cuda.synchronize()

@@ -7,6 +7,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+from sup3r_amd.engine import Device  # noqa: E402
 from sup3r_amd.configs.author_configs import pcc  # noqa: E402
 from sup3r_amd.engine import Network  # noqa: E402
 
@@ -21,9 +22,9 @@ for shape in [(5, 18, 20, 72, 4), (8, 16, 16, 64, 4), (3, 16, 24, 112, 4),
     x = rng.standard_normal(shape).astype(np.float32)
     net = Network(spec, precision='bf16')
     net.build(shape, seed=0)
-    os.environ['SUP3R_AMD_NO_PERSIST'] = '1'
+    Device.get().set_option('NO_PERSIST', 1)
     y0 = net(x).cpu().numpy()
-    del os.environ['SUP3R_AMD_NO_PERSIST']
+    Device.get().set_option('NO_PERSIST', None)
     ph = net.plan(shape, training=False)
     k = [ph.op_kernel_class(i) for i in range(len(ph.plan.ops))]
     worst = 0.0

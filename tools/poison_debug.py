@@ -10,6 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from sup3r_amd.engine import Device  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
@@ -51,17 +52,17 @@ def main():
         if isinstance(spec, dict):
             spec = spec['hidden_layers']
         for training in (True, False):
-            os.environ.pop('SUP3R_AMD_POISON_ALLOC', None)
+            Device.get().set_option('POISON_ALLOC', None)
             clean = run(spec, shape, training)
-            os.environ['SUP3R_AMD_POISON_ALLOC'] = '1'
+            Device.get().set_option('POISON_ALLOC', 1)
             if name == 'chunked' and training:
-                os.environ['SUP3R_AMD_TRACE'] = '1'
+                Device.get().set_option('TRACE', 1)
             dirty = run(spec, shape, training)
-            os.environ.pop('SUP3R_AMD_TRACE', None)
+            Device.get().set_option('TRACE', None)
             if name == 'chunked' and training:
-                os.environ['SUP3R_AMD_NO_DGRAD_CHUNKED'] = '1'
+                Device.get().set_option('NO_DGRAD_CHUNKED', 1)
                 d2 = run(spec, shape, training)
-                os.environ.pop('SUP3R_AMD_NO_DGRAD_CHUNKED', None)
+                Device.get().set_option('NO_DGRAD_CHUNKED', None)
                 for k in d2:
                     if np.isnan(d2[k]).any():
                         print('chunked (gather dgrad)', k, 'nan at', np.argwhere(np.isnan(d2[k]))[:4].tolist())
