@@ -190,7 +190,8 @@ def test_bucketed_allreduce_under_the_backward_pass_single_rank():
         for which, kw in (('gen', dict(train_gen=True, train_disc=False)),
                           ('disc', dict(train_gen=False, train_disc=True))):
             net = m.generator if which == 'gen' else m.discriminator
-            total = sum(int(w.size) for w in net.weights)
+            # (the flat store pads every tensor to whole float4s)
+            total = int(L.s3_params_total(net.params))
             before = dev.stat('bucket_elems')
             m._compute.loss_and_grads(
                 lr, hr, m._loss_terms, weight_gen_advers=1e-2,

@@ -27,8 +27,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.helpers import (emulate_plan, rel_linf, rel_max,
-                           teacher_forced_check)
+from tests.helpers import emulate_plan, rel_linf, teacher_forced_check
 
 pytestmark = pytest.mark.gpu
 
@@ -334,23 +333,25 @@ def _check_adam(net, opt, opt_ref, dev_grads, w_before, tol, name):
 
 
 def test_c2_train_batch_fp32_under_device_masks():
-    """exact-fp32 mode, batch 1: gradients of both steps 1e-3 (round 2 had
-    2e-2 with own masks on each side), loss scalars 1e-4"""
-    _train_batch_vs_oracle('f32', 1, 1e-3, 1e-4)
+    """exact-fp32 mode, batch 1: gradients of both steps 1e-4 (measured
+    2e-6 / 5e-6; round 2 had 2e-2 with own masks on each side), loss scalars
+    1e-4"""
+    _train_batch_vs_oracle('f32', 1, 1e-4, 1e-4)
 
 
 def test_c2_train_batch_bf16_batch8_vs_emulating_oracle():
     """the benched training step (``bench.py --mode train``: bf16, batch 8):
     per-op forward of the generator and of the discriminator on both fields,
-    gradients of both steps 2e-2, loss scalars 1e-3, Adam slots"""
-    _train_batch_vs_oracle('bf16', 8, 2e-2, 1e-3)
+    gradients of both steps 1e-2 (measured 1.1e-3 / 3.6e-3), loss scalars
+    1e-3, Adam slots"""
+    _train_batch_vs_oracle('bf16', 8, 1e-2, 1e-3)
 
 
 # --------------------------------------------------------- (e) C5 in bf16
 def test_condmom_bf16_step_on_the_3x_4x_body():
     """C5 in the throughput mode: ``Sup3rCondMom`` over ``gen_3x_4x_2f`` at
     lo-res (8, 16, 16, 24, 2) (the bf16 MFMA kernels), masked MSE: loss value
-    against the teacher-forced oracle output 1e-3, gradients 2e-2
+    against the teacher-forced oracle output 1e-3, gradients 1e-2
     (conditional.py:221-283)"""
     from oracle.network import Network as ONet
     from sup3r_amd import Sup3rCondMom
@@ -386,5 +387,4 @@ def test_condmom_bf16_step_on_the_3x_4x_body():
     errs = _grad_errors(m.generator.grads, og.grads)
     print(f'CondMom bf16 on gen_3x_4x_2f: worst gradient error '
           f'{max(errs):.2e}')
-    assert max(errs) < 2e-2, errs
-    assert rel_max(np.zeros(1), np.zeros(1)) == 0.0
+    assert max(errs) < 1e-2, errs          # measured 1.6e-3
