@@ -1,5 +1,7 @@
-"""Brute-force check of the persistent conv's LDS read addresses
-(kernels_conv_mfma_persist.hip, 32x32x16 layout): for every ds_read_b128 the
+"""Brute-force check of the LDS read addresses of the 32x32x16 layout tried
+on the persistent conv in round 3 (profiles/r03/README.md; the layout is
+restated below — the variant itself is not kept in the tree): for every
+ds_read_b128 the
 16 lanes of each of the instruction's four lane groups (MI355X_MICROARCH.md
 §LDS) must touch 16 distinct 16-byte bank slots (byte address / 16 mod 16),
 for every tap shift, k-step, fragment and consumer wave."""
