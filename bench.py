@@ -462,22 +462,23 @@ def cpu_legs(spec, dev, seconds_budget=30.0):
     # ---- (ii) C + OpenMP
     lib, how = c_ref.load(native=True)
     threads_c = int(lib.s3ref_threads())
-    y_c, _, _ = c_ref.forward(net, x, lib=lib)             # warm-up
+    # BASELINE.md §3 / SURVEY.md §8d protocol: 3 warm-up + 5 timed, median
+    for _ in range(3):
+        y_c, _, _ = c_ref.forward(net, x, lib=lib)
     assert np.abs(y_c - y_np).max() < 1e-3
-    times_c, el = [], 0.0
-    while len(times_c) < 5 and el < seconds_budget / 2:
+    times_c = []
+    while len(times_c) < 5:
         _, dt, _ = c_ref.forward(net, x, lib=lib)
         times_c.append(dt)
-        el += dt
     # ---- (i) torch / oneDNN
     threads_t = torch.get_num_threads()
-    y_t, _ = torch_generator_forward(net, x)               # warm-up
+    for _ in range(3):
+        y_t, _ = torch_generator_forward(net, x)
     assert np.abs(y_t - y_np).max() < 1e-3
-    times_t, el = [], 0.0
-    while len(times_t) < 5 and el < seconds_budget / 2:
+    times_t = []
+    while len(times_t) < 5:
         _, dt = torch_generator_forward(net, x)
         times_t.append(dt)
-        el += dt
     med_c, med_t = float(np.median(times_c)), float(np.median(times_t))
     best = min(med_c, med_t)
     return {
@@ -485,7 +486,7 @@ def cpu_legs(spec, dev, seconds_budget=30.0):
         'cores': threads_c if med_c <= med_t else int(threads_t),
         'kind': 'port',
         'sample': 'one C2 chunk (1,16,16,24,4)->(1,80,80,288,2), as-TF-'
-                  'executes op sequence (474 GMAC/sample); 1 warm-up + median '
+                  'executes op sequence (474 GMAC/sample); 3 warm-up + median '
                   f'of {len(times_c)} (C/OpenMP, {how}, {threads_c} threads: '
                   f'{med_c:.2f} s/sample) and of {len(times_t)} (torch-CPU/'
                   f'oneDNN "TF-CPU proxy", {threads_t} threads: {med_t:.2f} '

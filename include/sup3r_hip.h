@@ -98,7 +98,8 @@ void* s3_ctx_stream(s3_ctx* ctx);
 enum { S3_STAT_PERSIST_DGRAD = 0, /* trunk data gradients on the persistent kernel */
        S3_STAT_GCONV_SPLITK = 1,  /* gather-MFMA launches with a split contraction  */
        S3_STAT_BUCKET_ELEMS = 2,  /* gradient elements all-reduced bucket by bucket  */
-       S3_STAT_COUNT = 3 };
+       S3_STAT_DGRAD_C2_SLIDE = 3, /* first-layer data gradients on the sliding kernel */
+       S3_STAT_COUNT = 4 };
 int64_t s3_ctx_stat(const s3_ctx* ctx, int which);
 
 /* ---- parameter store ---------------------------------------------------

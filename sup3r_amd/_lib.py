@@ -189,7 +189,8 @@ def lib():
     return L
 
 
-STATS = {'persist_dgrad': 0, 'gconv_splitk': 1, 'bucket_elems': 2}
+STATS = {'persist_dgrad': 0, 'gconv_splitk': 1, 'bucket_elems': 2,
+         'dgrad_c2_slide': 3}
 
 
 def option_names():

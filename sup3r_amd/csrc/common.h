@@ -37,6 +37,8 @@
   X(NO_BIAS_FUSE) \
   X(NO_CHUNKED_DY16) \
   X(NO_DGRAD_C2) \
+  X(NO_DGRAD_C2_SLIDE) \
+  X(DGRAD_C2_SLIDE_MIN_UNITS) \
   X(NO_DGRAD_CHUNKED) \
   X(NO_DGRAD_FEWCH) \
   X(NO_DGRAD_S2) \
@@ -105,7 +107,7 @@ struct s3_ctx {
   float* scratch = nullptr;  // small device scratch (reductions)
   size_t scratch_bytes = 0;
   int num_cu = 256;
-  int64_t stat[4] = {0, 0, 0, 0};   // S3_STAT_* launch counters
+  int64_t stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // S3_STAT_* launch counters
   S3Options opt;                     // defaults of the plans created from this context
   hipStream_t comm_stream = nullptr; // bucketed gradient all-reduce under the backward pass
   hipEvent_t comm_ev[2] = {nullptr, nullptr};   // [0] compute -> comm, [1] comm -> compute

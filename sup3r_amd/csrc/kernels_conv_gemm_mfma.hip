@@ -785,7 +785,9 @@ bool fewch_halo_ok(const s3_ctx* ctx, const ConvGeom& g, const float* res, int o
   const int64_t tiles = (int64_t)g.N * ((g.O[0] + FH0 - 1) / FH0) * ((g.O[1] + FH1 - 1) / FH1) *
                         ((g.O[2] + FH2 - 1) / FH2);
   const int64_t min_tiles = s3_opt_has(S3O_FEWCH_HALO_MIN_TILES)
-                                ? s3_opt_int(S3O_FEWCH_HALO_MIN_TILES, 0) : 2 * ctx->num_cu;
+                                ? s3_opt_int(S3O_FEWCH_HALO_MIN_TILES, 0) : ctx->num_cu;
+  // (one tile per CU already beats the gather variant: the generator's 4 -> 64
+  // head conv at C2 batch 32 is 256 tiles — 59 us on the gather walk)
   return tiles >= min_tiles;
 }
 

@@ -45,13 +45,22 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
     float* __restrict__ partial, ConvGeom g, int chunks, int64_t n_steps) {
   constexpr int MT = 27 * CIN;                  // rows of the gradient
   constexpr int MB = (MT + 15) / 16;
-  __shared__ float red[C2_WAVES][MB * NB][64][4];
-  __shared__ __attribute__((aligned(16))) char dst[DY16 ? C2_WAVES * 2048 : 16];   // DY16: [wave][32 t][64 B]
   // DY16, stride 1, no padding: the x window of a k-step — 9 (ta, tb) rows of 34
   // cells — is fetched once per wave (5 coalesced 8-B loads per lane instead of
   // 32 gathered 4-B ones) and the A fragments are read back from here
   constexpr int XW_CELLS = 9 * 34;
-  __shared__ __attribute__((aligned(16))) float2 xw[(DY16 && CIN == 2) ? C2_WAVES * XW_CELLS : 1];
+  // ONE LDS block: the staging areas of the k-step loop (dst: [wave][32 t][64 B],
+  // xw) and the end-of-kernel reduction buffer `red` are never live together.
+  // Separate arrays were 50 KB per workgroup = 3 workgroups per CU for a grid
+  // of 4 per CU: the fourth ran as a tail (round 3: 32 KB, all four resident).
+  constexpr int RED_BYTES = C2_WAVES * MB * NB * 64 * 4 * 4;
+  constexpr int DST_BYTES = DY16 ? C2_WAVES * 2048 : 16;
+  constexpr int XW_BYTES = (DY16 && CIN == 2) ? C2_WAVES * XW_CELLS * 8 : 8;
+  constexpr int STAGE_BYTES = DST_BYTES + XW_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds_all[RED_BYTES > STAGE_BYTES ? RED_BYTES : STAGE_BYTES];
+  float (*red)[MB * NB][64][4] = reinterpret_cast<float (*)[MB * NB][64][4]>(lds_all);
+  char* dst = lds_all;
+  float2* xw = reinterpret_cast<float2*>(lds_all + DST_BYTES);
   const bool xwin = DY16 && CIN == 2 && !(g.pad_mode == S3_PAD_REFLECT) && g.s[0] == 1 && g.s[1] == 1 &&
                     g.s[2] == 1 && g.lo[0] == 0 && g.lo[1] == 0 && g.lo[2] == 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -75,6 +84,95 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int64_t n_waves = (int64_t)gridDim.x * C2_WAVES;
+  if constexpr (DY16 && CIN == 2) {
+    if (xwin) {
+      // Round 3: the same k-steps, software-pipelined.  The generic loop
+      // below loads a step's dPre rows and x window and waits for them on the
+      // spot — waves sat in s_waitcnt 65 % of the time (profiles/r03/
+      // pmc_train_start.txt) — here the NEXT step's 18 registers of loads are
+      // in flight while this step goes through LDS and the MFMAs.
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      const int r = lane >> 1, hf = lane & 1;
+      uint4 q0, q1;
+      float2 c5[5];
+      auto fetch = [&](int64_t st) __attribute__((always_inline)) {
+        int64_t row = st / chunks;
+        const int tch = (int)(st % chunks) * 32;
+        const int o1 = (int)(row % O1); row /= O1;
+        const int o0 = (int)(row % O0); row /= O0;
+        const int n = (int)row;
+        const int tr = tch + r;
+        q0 = make_uint4(0u, 0u, 0u, 0u); q1 = q0;
+        if (tr < O2) {
+          const uint4* src = reinterpret_cast<const uint4*>(
+              reinterpret_cast<const unsigned short*>(dy) +
+              ((((int64_t)n * O0 + o0) * O1 + o1) * O2 + tr) * 32 + hf * 16);
+          q0 = src[0]; q1 = src[1];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int item = lane + 64 * k;
+          const int rw = item / 34, cl = item - rw * 34;
+          int tt = tch + cl;
+          tt = tt > S2 - 1 ? S2 - 1 : tt;          // (past the row: feeds t >= O2 only, zero dPre)
+          c5[k] = make_float2(0.f, 0.f);
+          if (item < XW_CELLS)
+            c5[k] = *reinterpret_cast<const float2*>(
+                x + ((((int64_t)n * D0 + o0 + rw / 3) * S1 + o1 + rw % 3) * S2 + tt) * 2);
+        }
+      };
+      int64_t step = (int64_t)blockIdx.x * C2_WAVES + wave;
+      if (step < n_steps) fetch(step);
+      for (; step < n_steps; step += n_waves) {
+        char* d = dst + wave * 2048 + r * 64 + ((hf ^ ((r >> 3) & 1)) << 5);
+        float2* xb = xw + wave * XW_CELLS;
+        // (other lanes read what this lane writes: keep the compiler from
+        // moving LDS accesses across these points; the hardware runs a wave's
+        // LDS operations in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<uint4*>(d) = q0;
+        *reinterpret_cast<uint4*>(d + 16) = q1;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (lane + 64 * k < XW_CELLS) xb[lane + 64 * k] = c5[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the next step's loads fly under this step's LDS reads and MFMAs
+        if (step + n_waves < n_steps) fetch(step + n_waves);
+        bf16x8 bfr[NB];
+        const char* wb = dst + wave * 2048;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          s16x4 lh[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int pl = 8 * kg + 4 * h + (i >> 2);
+            lh[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(wb + pl * 64 + ((nb ^ ((pl >> 3) & 1)) << 5) + ((i & 3) << 3)));
+          }
+          bfr[nb] = __builtin_shufflevector(lh[0], lh[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int ti = tinfo[mb];
+          const int ta = ti & 15, tb = (ti >> 4) & 15, tc = (ti >> 8) & 15, ci = (ti >> 12) & 15;
+          const float* xr = reinterpret_cast<const float*>(xw + wave * XW_CELLS) +
+                            ((ta * 3 + tb) * 34 + kg * 8 + tc) * 2 + ci;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ti >= 0 ? xr[e * 2] : 0.f;
+          const uint4 u = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+          const bf16x8 afr = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nb], acc[mb][nb], 0, 0, 0);
+        }
+      }
+      goto reduce;
+    }
+  }
   for (int64_t step = (int64_t)blockIdx.x * C2_WAVES + wave; step < n_steps; step += n_waves) {
     int64_t row = step / chunks;
     const int t0 = (int)(step % chunks) * 32 + kg * 8;
@@ -209,7 +307,9 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nb], acc[mb][nb], 0, 0, 0);
     }
   }
+reduce:
   // ---- sum the workgroup's waves, write partial[bid][m][co]
+  __syncthreads();          // (red aliases the staging areas of the slower waves)
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll

@@ -708,7 +708,7 @@ class ForwardPass:
                     group, model, allowed_const, invert_uv, nn_fill, meta,
                     output_workers, return_data, write))
                 group = []
-                yield from flush(1)
+                yield from flush(2)
             group.append(chunk)
             shape = key
         if group:
@@ -790,6 +790,7 @@ class ForwardPass:
                 np.asarray(chunk.input_data)[None], cls._batch_axis(exo))
             xs.append(np.asarray(model.norm_input(x), dtype=np.float32))
         x = np.concatenate(xs, axis=0) if n > 1 else xs[0]
+        staged = []               # pinned upload buffers, alive until finish()
         try:
             ph = gen.plan(x.shape, training=False)
             layer_exo = {}
@@ -806,9 +807,10 @@ class ForwardPass:
                         np.asarray(exo.get_combine_type_data(
                             name, 'layer'))[None], name)
                     parts.append(arr.astype(np.float32, copy=False))
-                layer_exo[name] = dev.to_device(
-                    np.concatenate(parts, axis=0) if n > 1 else parts[0])
-            y = ph.forward(dev.to_device(x), layer_exo)
+                layer_exo[name] = cls._upload_async(
+                    dev, np.concatenate(parts, axis=0) if n > 1 else parts[0],
+                    staged)
+            y = ph.forward(cls._upload_async(dev, x, staged), layer_exo)
         except AssertionError:
             raise
         except Exception as e:
@@ -876,6 +878,7 @@ class ForwardPass:
 
         def finish():
             ev.synchronize()
+            staged.clear()
             st = stats_h.numpy().reshape(n, 64, n_out, 3)
             mn, mx = st[..., 0].min(1), st[..., 1].max(1)
             nn = st[..., 2].sum(1)
@@ -903,6 +906,21 @@ class ForwardPass:
                 yield (chunk, failed,
                        host[k].numpy() if host is not None else None)
         return finish
+
+    @staticmethod
+    def _upload_async(dev, arr, keep):
+        """host array -> device tensor without blocking the host: a pageable
+        ``.to(device)`` on the compute stream returns only when the copy has
+        run, i.e. after every kernel enqueued before it — the host could not
+        prepare and enqueue the next batch under the current one.  The array
+        goes through a pinned staging tensor (kept alive in ``keep`` until the
+        batch is finished) and a stream-ordered non-blocking copy."""
+        import torch
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        stage = torch.empty(arr.shape, dtype=torch.float32, pin_memory=True)
+        stage.numpy()[...] = arr
+        keep.append(stage)
+        return stage.to(dev.torch_device, non_blocking=True)
 
     @staticmethod
     def _batch_axis(exo):

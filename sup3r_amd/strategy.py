@@ -174,6 +174,8 @@ class ArrayStrategy:
             self.fwp_chunk_shape, spatial_pad=spatial_pad,
             temporal_pad=temporal_pad)
         self._finished = set()
+        self._out_files = None
+        self._gids = None
 
     # -- what the executor reads -----------------------------------------
     @property
@@ -182,7 +184,12 @@ class ArrayStrategy:
 
     @property
     def out_files(self):
-        """strategy.py:455-472"""
+        """strategy.py:455-472 (a cached property there too)"""
+        if self._out_files is None:
+            self._out_files = self._make_out_files()
+        return self._out_files
+
+    def _make_out_files(self):
         sl = self.fwp_slicer
         if self.out_pattern is None:
             return [None] * sl.n_chunks
@@ -244,8 +251,10 @@ class ArrayStrategy:
             np.asarray(self.lat_lon)[hr[0], hr[1]]
         times = None if self.time_index is None else \
             self.time_index[hr[2]]
-        n1, n2 = sl.hr_shape[:2]
-        gids = np.arange(n1 * n2).reshape(n1, n2)[hr[0], hr[1]]
+        if self._gids is None:
+            n1, n2 = sl.hr_shape[:2]
+            self._gids = np.arange(n1 * n2).reshape(n1, n2)
+        gids = self._gids[hr[0], hr[1]]
         return ForwardPassChunk(
             input_data=data, exo_data=self._exo_chunk(c['lr_pad_slice']),
             lr_pad_slice=c['lr_pad_slice'], hr_crop_slice=c['hr_crop'],

@@ -892,6 +892,52 @@ def test_first_disc_layer_bf16_only_dpre_changes_only_the_bias_sum_order(monkeyp
             assert rel_linf(a, b) < 1e-5, k
 
 
+def test_first_layer_data_gradient_on_the_sliding_window_kernel():
+    """conv_dgrad_c2_slide_kernel (round 3): the data gradient of the 2 -> 32
+    conv as a column walk along s0 with the three t-taps packed into the
+    MFMA's M dimension — same bf16 operands as conv_dgrad_c2_kernel, another
+    fp32 summation order: dx agrees to round-off, nothing else changes, and
+    the stack passes the oracle check.  Ragged in s0 (2 segments would need
+    > 40 rows: one short segment), s1 (33 = 2 x 16 + 1) and t (77 = 5 x 14 +
+    7)."""
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(32, 2) + conv(64, 1) + \
+        [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (2, 47, 33, 77, 2)
+    switch('DGRAD_S2_MIN_TILES', 1)
+    switch('DGRAD_C2_SLIDE_MIN_UNITS', 1)
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+    net = Network(spec, precision='bf16')
+    net.build(shape, seed=0)
+    xd = net.dev.to_device(x)
+
+    def run(options):
+        ph = net.plan(shape, training=True, options=options)
+        assert _kernels(ph, 'dgrad')[0] == 'c2'
+        y = ph.forward(xd)
+        dy = net.dev.to_device(np.ones(tuple(y.shape), np.float32))
+        before = net.dev.stat('dgrad_c2_slide')
+        dx = ph.backward(dy, need_dx=True).cpu().numpy()
+        return dx, [a.copy() for a in net.grads], \
+            net.dev.stat('dgrad_c2_slide') - before
+    dx1, g1, used1 = run(None)
+    dx0, g0, used0 = run({'NO_DGRAD_C2_SLIDE': 1})
+    assert used1 == 1 and used0 == 0, (used1, used0)
+    assert np.abs(dx0).max() > 0
+    err = rel_max(dx1, dx0)
+    print(f'sliding-window first-layer data gradient vs the tile kernel: {err:.2e}')
+    assert err < 1e-5, err
+    for a, b in zip(g1, g0):
+        np.testing.assert_array_equal(a, b)
+    net.clear_plans()
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 13, 3e-2, 2e-2)
+
+
 def test_halo_tile_kernel_with_two_n_fragments_is_bit_identical(monkeypatch):
     """data gradient of a valid 32 -> 64 conv = a 64 -> 32 conv on the
     halo-tile kernel: with C_out <= 32 only two of the four N fragments of the
