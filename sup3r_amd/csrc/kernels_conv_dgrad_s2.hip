@@ -58,7 +58,7 @@ __global__ void dgrad_s2_pack_kernel(const float* __restrict__ w, unsigned short
 // sums — the bias gradient of that conv — accumulate in registers and leave as
 // one partial row per workgroup (bsum[block][32], for bias_grad_stage2).
 template <int NF, bool O16 = false>
-__global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
+__global__ __launch_bounds__(SNT) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_dgrad_s2_kernel(
     const float* __restrict__ dy, const unsigned short* __restrict__ img,
     float* __restrict__ dx, ConvGeom g, int rows_pad, int tiles0, int tiles1, int tiles2,
     const void* __restrict__ mask_y, float mask_slope, int mask_bf16, float* __restrict__ bsum) {
@@ -120,11 +120,32 @@ __global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
   const unsigned short* wrow = img + ((size_t)ct * 64 + (O16 ? (j >> 2) * 8 + (j & 3) : j)) * 32 + kg * 8;
   const int R = g.Cin;
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // O16: channel sums of what this lane stores
+  // O16 with a bf16 mask source (the C2 case): the eight 16-B mask reads of a
+  // class do not depend on its MFMAs but sat behind them — waves were parked
+  // in s_waitcnt 79 % of the time (profiles/r03/pmc_train_start.txt).  They
+  // are issued one class AHEAD now, under the tap loop of the class before.
+  const bool mpre = O16 && mask_y && mask_bf16;
+  uint4 mk[8], mk_next[8];
+  auto mask_fetch = [&](int cls_, uint4* dst8) __attribute__((always_inline)) {
+    const int q0 = cls_ >> 2, q1 = (cls_ >> 1) & 1, q2 = cls_ & 1;
+    const int i0 = 2 * (u0 + wave) + q0, i2 = 2 * (u2 + j) + q2;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int i1 = 2 * (u1 + m) + q1;
+      dst8[m] = make_uint4(0u, 0u, 0u, 0u);
+      if (i0 < g.D[0] && i1 < g.D[1] && i2 < g.D[2])
+        dst8[m] = *reinterpret_cast<const uint4*>(
+            reinterpret_cast<const unsigned short*>(mask_y) +
+            ((((size_t)n * g.D[0] + i0) * g.D[1] + i1) * g.D[2] + i2) * 32 + kg * 8);
+    }
+  };
+  if (mpre) mask_fetch(0, mk);
   // wave w owns the u rows (r0 = w, r1 = 0..7)
 #pragma unroll 1
   for (int cls = 0; cls < 8; ++cls) {
     const int p0 = cls >> 2, p1 = (cls >> 1) & 1, p2 = cls & 1;
     const int n0 = p0 ? 1 : 2, n1 = p1 ? 1 : 2, n2 = p2 ? 1 : 2;   // taps per axis
+    if (mpre && cls < 7) mask_fetch(cls + 1, mk_next);
     f32x4 acc[8][NF];
 #pragma unroll
     for (int m = 0; m < 8; ++m)
@@ -165,7 +186,7 @@ __global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
         if (mask_y) {
           float yv[8];
           if (mask_bf16) {
-            const uint4 h = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(mask_y) + e);
+            const uint4 h = mpre ? mk[m] : *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(mask_y) + e);
             yv[0] = __uint_as_float(h.x << 16); yv[1] = __uint_as_float(h.x & 0xFFFF0000u);
             yv[2] = __uint_as_float(h.y << 16); yv[3] = __uint_as_float(h.y & 0xFFFF0000u);
             yv[4] = __uint_as_float(h.z << 16); yv[5] = __uint_as_float(h.z & 0xFFFF0000u);
@@ -183,6 +204,10 @@ __global__ __launch_bounds__(SNT) void conv_dgrad_s2_kernel(
         for (int q8 = 0; q8 < 8; ++q8) csum[q8] += v[q8];
         *reinterpret_cast<uint4*>(dx16 + e) =
             make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+      }
+      if (mpre) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mk[m] = mk_next[m];
       }
       continue;
     }
