@@ -350,6 +350,10 @@ def hbm_class_ops(ph, ms):
         conv = 'cout' in op
         if conv and info['fwd'] in ('mfma_tile', 'mfma_persist'):
             continue
+        if not conv and info.get('in_rep'):
+            # a temporal repeat read through its consumers' halo index: no
+            # launch, no bytes (plan.cpp, the repeat-fusion pass)
+            continue
         nb = 0
         for tid in (op['in0'], op['out']):
             n = int(np.prod(ph.plan.tensors[tid]))

@@ -228,7 +228,11 @@ enum {
   S3_OPINFO_DGRAD = 7,         /* S3_DGRAD_*                                   */
   S3_OPINFO_MASK_FUSED_FROM = 8, /* op whose activation adjoint this conv's
                                   dgrad store applies, or -1                  */
-  S3_OPINFO_COUNT = 9
+  S3_OPINFO_IN_REP = 9,        /* conv reads its input through a fused temporal
+                                  repeat of this factor; a repeat op: 1 = absorbed
+                                  by its consumer (no launch)                   */
+  S3_OPINFO_RES_REP = 10,      /* ... and its residual operand                  */
+  S3_OPINFO_COUNT = 11
 };
 enum {
   S3_FWD_DIRECT = 0, S3_FWD_MFMA_TILE = 1, S3_FWD_MFMA_PERSIST = 2, S3_FWD_GCONV = 3,

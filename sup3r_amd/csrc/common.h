@@ -58,6 +58,7 @@
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \
+  X(NO_REPEAT_FUSE) \
   X(NO_PLAIN_FOLD16) \
   X(NO_SEG_REDUCE) \
   X(NO_TAIL_BAND) \
@@ -144,6 +145,16 @@ struct ConvGeom {
   // slice exist (0 = the tensor has exactly C_in channels).  Used by the
   // chunked data gradient of convs with C_out > 64.
   int in_cstride = 0, in_cvalid = 0;
+  // persistent trunk kernel, inference plans: the input is the temporal repeat
+  // (SpatioTemporalExpansion temporal_mult, out[.., j, :] = in[.., j / rep, :]) of
+  // a tensor with D[2] / in_rep time steps, read through the halo index instead
+  // of being materialised; 0 / 1 = plain input
+  int in_rep = 0;
+  // ... and the same for the residual operand (d2s == 1): res[.., j, :] is
+  // cell j / res_rep of a tensor with O[2] / res_rep steps.  res_rep_magic =
+  // ceil(2^16 / res_rep): (j * magic) >> 16 == j / res_rep for every j < O[2]
+  // (checked where the plan sets it)
+  int res_rep = 0, res_rep_magic = 0;
 };
 
 // generic gather op (pad / crop / repeat / roll / d2s / concat): out <- in

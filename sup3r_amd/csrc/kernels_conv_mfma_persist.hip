@@ -179,7 +179,7 @@ __global__ void pack_jobs_kernel(const S3PackJob* __restrict__ jobs) {
 // a tile may straddle frames.  The halo tables carry a "zero row" flag (bit 30
 // of the element offset; a chunk is zeroed before it lands in LDS if any of
 // its three axes is flagged) instead of the reflect rule.
-template <int NFV, bool DG>
+template <int NFV, bool DG, bool REP = false>
 __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg,
     const float* __restrict__ bias, const unsigned short* __restrict__ res,
@@ -280,7 +280,10 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       const int org = ax == 0 ? o0_ : (ax == 1 ? o1_ : o2_);                           \
       const int D = ax == 0 ? D0 : (ax == 1 ? D1 : D2);                                \
       const int cs = (DG && g.in_cstride) ? g.in_cstride : 64;  /* channel slice of a wider dPre */ \
-      const int stride = ax == 0 ? D1 * D2 * cs : (ax == 1 ? D2 * cs : cs);            \
+      /* a fused temporal repeat: D2 is the repeated extent, the tensor holds D2 / rp */ \
+      const int rp = (REP && !DG && g.in_rep > 1) ? g.in_rep : 1;                             \
+      const int D2s = D2 / rp;                                                         \
+      const int stride = ax == 0 ? D1 * D2s * cs : (ax == 1 ? D2s * cs : cs);          \
       if (DG) {                                                                        \
         /* stacked frames on axes 0 / 1 (extent E = D + 2, gs frames), plain zero */  \
         /* boundary on axis 2; flagged rows load a legal address and are zeroed */    \
@@ -296,8 +299,9 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       int i = s3_reflect(org + c - g.lo[ax], D);                                       \
       /* ragged tiles: keep addresses legal (results are masked at the store) */      \
       i = i < 0 ? 0 : (i > D - 1 ? D - 1 : i);                                         \
+      if (ax == 2 && rp > 1) i /= rp;                                                  \
       htab = i * stride;                                                               \
-      hx = x + (size_t)n_ * D0 * D1 * D2 * 64;                                         \
+      hx = x + (size_t)n_ * D0 * D1 * D2s * 64;                                        \
       }                                                                                \
       _Pragma("unroll") for (int j = 0; j < JR; ++j) {                                 \
         int cell = pcell + 32 * j;                                                     \
@@ -557,15 +561,27 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     // add + 16-B stores
     uint4 rres[MFW][2];
     if (res) {
+      // a residual read through a fused temporal repeat (d2s == 1, cpo = 64):
+      // cell o2 of the skip tensor is cell o2 / res_rep of what is stored
+      const bool rr = REP && !DG && g.res_rep > 1;
+      const int O2s = rr ? g.O[2] / g.res_rep : g.O[2];
+      const size_t r_base = rr ? (size_t)n * g.O[0] * g.O[1] * O2s * g.Cout : e_base;
 #pragma unroll
-      for (int m = 0; m < MFW; ++m)
+      for (int m = 0; m < MFW; ++m) {
+        unsigned r_pos = e_pos[m];
+        if (rr) {
+          const int mf = mf0 + m;
+          const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1, o2 = org2 + frow;
+          r_pos = (unsigned)(((o0 * g.O[1] + o1) * O2s + ((o2 * g.res_rep_magic) >> 16)) * cpo);
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           bool ok;
-          const unsigned off = chunk_off(m, h, ok);
+          chunk_off(m, h, ok);
           rres[m][h] = make_uint4(0, 0, 0, 0);
-          if (ok) rres[m][h] = *reinterpret_cast<const uint4*>(res + e_base + off);
+          if (ok) rres[m][h] = *reinterpret_cast<const uint4*>(res + r_base + r_pos + c_off[h]);
         }
+      }
     }
 #pragma unroll
     for (int m = 0; m < MFW; ++m) {
@@ -723,6 +739,10 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
   const int tiles0 = (g.O[0] + TS0 - 1) / TS0, tiles1 = (g.O[1] + TS1 - 1) / TS1,
@@ -731,9 +751,14 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
   int grid = ctx->num_cu;
   if (grid > n_tiles) grid = n_tiles;
   const int n_ct = (g.Cout + 63) / 64;
+  // (operands read through a fused temporal repeat: a variant of its own, the
+  // index arithmetic does not fit the 168-register budget of the plain one)
+  const bool rep = g.in_rep > 1 || g.res_rep > 1;
   for (int ct = 0; ct < n_ct; ++ct) {
     // a last tile with <= 32 valid channels computes two N fragments only
-    auto kern = g.Cout - ct * 64 <= 32 ? conv3_mfma_persist_kernel<2, false> : conv3_mfma_persist_kernel<4, false>;
+    const bool half = g.Cout - ct * 64 <= 32;
+    auto kern = rep ? (half ? conv3_mfma_persist_kernel<2, false, true> : conv3_mfma_persist_kernel<4, false, true>)
+                    : (half ? conv3_mfma_persist_kernel<2, false> : conv3_mfma_persist_kernel<4, false>);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
                        (const unsigned short*)x, (const char*)image + (size_t)ct * 27 * 8192, bias,
                        (const unsigned short*)res, (unsigned short*)y, g, tiles0,

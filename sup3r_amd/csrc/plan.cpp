@@ -67,6 +67,9 @@ struct OpRec {
   void* dc2_w = nullptr;
   int64_t dc2_version = -1;
   ConvGeom dg;                 // geometry of the dgrad-as-conv launch
+  int rep_src = -1;            // conv: tensor read through a fused temporal repeat (cg.in_rep)
+  int res_src = -1;            // ... and the residual (cg.res_rep)
+  bool fused_away = false;     // repeat op absorbed by its consumer conv: no launch
   float* dg_w32 = nullptr;     // flipped / transposed fp32 filter
   void* dg_wbf = nullptr;      // its bf16 slabs (bf16 mode)
   uint64_t dg_version = 0;
@@ -820,13 +823,56 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
     }
   }
 
+  // ---- inference plans: a temporal repeat whose only consumer is a conv on
+  // the persistent trunk kernel is read through that kernel's halo index
+  // (cell t of the repeated tensor = cell t / rep of the source) instead of
+  // being written out and read back (at C2 batch 32 the 96 -> 288
+  // repeat alone is a 400 MB store + load per forward)
+  if (!training && precision == S3_PREC_BF16 && !s3_opt_has(S3O_NO_REPEAT_FUSE)) {
+    for (int i = 0; i < n_ops; ++i) {
+      OpRec& r = pl->ops[i];
+      if (r.d.kind != S3_OP_REPEAT_T || r.d.rep < 2 || r.d.rep > 8) continue;
+      const int rt = root_of(pl, r.d.out);
+      if (rt == root_of(pl, output) || pl->t[root_of(pl, r.d.in0)].dtype != pl->t[rt].dtype) continue;
+      // every consumer is a persistent-kernel conv taking it as the input or
+      // (no depth-to-space store) as the residual — SkipConnection sources sit
+      // right behind the last temporal expansion in the reference's generators
+      bool ok = true;
+      int n_use = 0;
+      for (int k = 0; k < n_ops && ok; ++k) {
+        const OpRec& c = pl->ops[k];
+        const bool as_in = c.d.in0 >= 0 && root_of(pl, c.d.in0) == rt;
+        const bool as_in1 = c.d.in1 >= 0 && root_of(pl, c.d.in1) == rt;
+        const bool as_res = c.d.res >= 0 && root_of(pl, c.d.res) == rt;
+        if (!as_in && !as_in1 && !as_res) continue;
+        ++n_use;
+        ok = k > i && !as_in1 && c.d.kind == S3_OP_CONV && c.mfma &&
+             conv_mfma_persist_supported(ctx, c.cg, c.io, c.d.res >= 0) && (!as_res || c.cg.d2s == 1) &&
+             c.cg.O[2] <= 8192;
+      }
+      if (!ok || !n_use) continue;
+      const int magic = (65536 + r.d.rep - 1) / r.d.rep;
+      for (int k = i + 1; k < n_ops; ++k) {
+        OpRec& c = pl->ops[k];
+        if (c.d.kind != S3_OP_CONV) continue;
+        if (root_of(pl, c.d.in0) == rt) { c.cg.in_rep = r.d.rep; c.rep_src = r.d.in0; }
+        if (c.d.res >= 0 && root_of(pl, c.d.res) == rt) {
+          for (int q = 0; q < c.cg.O[2]; ++q)
+            if (((q * magic) >> 16) != q / r.d.rep) S3_FAIL(ctx, S3_ESTATE, "repeat fusion: division constant");
+          c.cg.res_rep = r.d.rep; c.cg.res_rep_magic = magic; c.res_src = r.d.in0;
+        }
+      }
+      r.fused_away = true;
+    }
+  }
+
   // ---- static arena planning.  Training keeps every tensor; inference
   // reuses buffers by liveness (greedy best-fit).
   std::vector<int> last_use(n_tensors, -1);
   for (int i = 0; i < n_ops; ++i) {
     const s3_op_desc& d = pl->ops[i].d;
-    int ids[4] = {d.in0, d.in1, d.res, d.out};
-    for (int q = 0; q < 4; ++q)
+    int ids[6] = {d.in0, d.in1, d.res, d.out, pl->ops[i].rep_src, pl->ops[i].res_src};
+    for (int q = 0; q < 6; ++q)
       if (ids[q] >= 0) last_use[root_of(pl, ids[q])] = i;
   }
   last_use[root_of(pl, output)] = n_ops + 1;
@@ -1109,7 +1155,7 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
     case S3_OP_CONV: {
       const float* w = W + P->p[d.w].offset;
       const float* b = d.b >= 0 ? W + P->p[d.b].offset : nullptr;
-      const float* res = d.res >= 0 ? tptr(pl, d.res) : nullptr;
+      const float* res = d.res >= 0 ? tptr(pl, o.res_src >= 0 ? o.res_src : d.res) : nullptr;
       if (o.mfma) {
         if (o.packed_version != P->version) {
           int rc = launch_conv_mfma_pack(ctx, o.cg, pl->precision, w, o.packed);
@@ -1117,7 +1163,8 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
           o.packed_version = P->version;
         }
         const void* wp = pl->precision != S3_PREC_F32 ? (const void*)o.packed : (const void*)w;
-        return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out), o.io);
+        return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, o.rep_src >= 0 ? o.rep_src : d.in0), wp, b,
+                                    res, tptr(pl, d.out), o.io);
       }
       if (o.halo32 && !res) {
         if (o.h32_version != P->version) {
@@ -1158,6 +1205,7 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
     }
     case S3_OP_REPEAT_T: case S3_OP_D2S: case S3_OP_PAD: case S3_OP_CROP:
     case S3_OP_ROLL_T: case S3_OP_DILATE:
+      if (o.fused_away) return S3_OK;        // read through its consumer's halo index
       return launch_gather(ctx, o.gg, tptr(pl, d.in0), tptr(pl, d.out), tdtype(pl, d.out) ? 2 : 4);
     case S3_OP_CONCAT: {
       // two channel-range copies: x -> out[..., :Cx], exo -> out[..., Cx:]
@@ -1408,6 +1456,8 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
     if (fused) fwd = S3_FWD_FUSED2D;
     v[S3_OPINFO_FWD] = fwd;
     v[S3_OPINFO_IN16] = o.io.in_bf16; v[S3_OPINFO_OUT16] = o.io.out_bf16; v[S3_OPINFO_RES16] = o.io.res_bf16;
+    v[S3_OPINFO_IN_REP] = o.cg.in_rep;
+    v[S3_OPINFO_RES_REP] = o.cg.res_rep;
     // operands rounded to bf16 by the forward kernel
     v[S3_OPINFO_FWD_BF16_OPS] = (pl->precision == S3_PREC_BF16 &&
                                  (fwd == S3_FWD_FUSED2D || fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 || fwd == S3_FWD_HALO_S2 ||
@@ -1436,6 +1486,7 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
       v[S3_OPINFO_MASK_FUSED_FROM] = o.mask_prod;
     }
   }
+  if (o.d.kind == S3_OP_REPEAT_T) v[S3_OPINFO_IN_REP] = o.fused_away ? 1 : 0;
   for (int q = 0; q < cap && q < S3_OPINFO_COUNT; ++q) out[q] = v[q];
   return S3_OPINFO_COUNT;
 }

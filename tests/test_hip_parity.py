@@ -228,6 +228,64 @@ def test_persistent_kernel_cout_tiles_and_depth_to_space():
     assert np.abs(y - y_tile).max() / scale < 1e-2
 
 
+def test_temporal_repeat_read_through_the_trunk_kernel():
+    """Inference plans: SpatioTemporalExpansion(temporal_mult=4, nearest)
+    followed by 64 -> 64 trunk convs (as input and as SkipConnection
+    residual, the gen_5x_12x_2f arrangement) is not materialised — the persistent
+    kernel's halo index reads cell t of the repeated tensor from cell t // 4
+    of the source (sup3r.models ... SpatioTemporalExpansion, phygnn
+    layers/custom_layers.py `_temporal_expand` nearest = tf.repeat on the
+    time axis).  Bit-identical to the plan that writes the repeat out, and
+    within the bf16 bound of the oracle; ragged in every axis, batch 9."""
+    from sup3r_amd import spec as S
+    from sup3r_amd.configs.author_configs import pcc
+    rng = np.random.default_rng(17)
+    spec = pcc(3, 64) + pcc(3, 64) + \
+        [{'class': 'SpatioTemporalExpansion', 'temporal_mult': 2,
+          'temporal_method': 'nearest'}] + pcc(3, 64) + \
+        [{'class': 'SpatioTemporalExpansion', 'temporal_mult': 3,
+          'temporal_method': 'nearest'},
+         {'class': 'SkipConnection', 'name': 'a'},
+         {'class': 'SkipConnection', 'name': 'b'}] + \
+        pcc(3, 64) + pcc(3, 64, act=False) + \
+        [{'class': 'SkipConnection', 'name': 'b'}] + \
+        pcc(3, 64, act=False) + \
+        [{'class': 'SkipConnection', 'name': 'a'}] + pcc(3, 64) + \
+        pcc(3, 2, act=False)
+    shape = (9, 18, 20, 13, 4)     # >= 256 tiles of 4 x 8 x 16 from T = 26 on
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle_net(spec, x, None)
+    y_ref = ref.forward(x)
+    net = _hip_net(spec, ref.weights, precision='bf16')
+    ph = net.plan(shape, training=False)
+    info = [ph.op_info(i) for i in range(len(ph.plan.ops))]
+    rep = [i for i, op in enumerate(ph.plan.ops)
+           if op['kind'] == S.OP_REPEAT_T]
+    brief = [(d['kind'], d['fwd'], d['in_rep'], d['res_rep']) for d in info]
+    assert len(rep) == 2 and all(info[i]['in_rep'] == 1 for i in rep), brief
+    convs = [d for d in info if d['kind'] == S.OP_CONV]
+    # the x2 repeat feeds one conv; the x3 repeat the first body conv and,
+    # as the residual, the closing convs of SkipConnection 'b' and 'a'
+    assert [d['in_rep'] for d in convs] == [0, 0, 2, 3, 0, 0, 0, 0], convs
+    assert [d['res_rep'] for d in convs] == [0, 0, 0, 0, 3, 3, 0, 0], convs
+    assert all(d['fwd'] == 'mfma_persist' for d in convs[2:6]), convs
+    y = net(x).cpu().numpy()
+    assert y.shape == (9, 18, 20, 78, 2)
+    scale = max(1.0, np.abs(y_ref).max())
+    assert np.abs(y - y_ref).max() / scale < 3e-2
+    switch('NO_REPEAT_FUSE', 1)
+    try:
+        ph2 = net.plan(shape, training=False)
+        assert ph2.op_info(rep[1])['in_rep'] == 0
+        y_plain = net(x).cpu().numpy()
+    finally:
+        switch('NO_REPEAT_FUSE', None)
+    assert np.array_equal(y, y_plain)
+    # a training plan keeps the repeat (its output is the conv's saved input)
+    pht = net.plan(shape, training=True)
+    assert pht.op_info(rep[0])['in_rep'] == 0
+
+
 def test_gather_mfma_conv_strided_valid_vs_oracle():
     """Discriminator-style stack (valid padding, strides 1 / 2, channels 32 /
     64 / 96) on the general gather-MFMA kernels in bf16 mode: forward, data
