@@ -59,6 +59,7 @@
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \
   X(NO_REPEAT_FUSE) \
+  X(NO_WGRAD_X3) \
   X(NO_PLAIN_FOLD16) \
   X(NO_SEG_REDUCE) \
   X(NO_TAIL_BAND) \
@@ -313,7 +314,7 @@ bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                            const float* dy, float* dw, float* partial,
-                           size_t partial_bytes, int accumulate, int x_bf16, int dy_bf16 = 0);
+                           size_t partial_bytes, int accumulate, int x_bf16, int dy_bf16 = 0, int x3 = 0);
 // wgrad: persistent-workgroup kernel (kernels_conv_wgrad_mfma.hip)
 bool conv_wgrad_mfma_supported(const ConvGeom& g);
 size_t conv_wgrad_mfma_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);

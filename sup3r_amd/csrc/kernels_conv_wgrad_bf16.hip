@@ -386,6 +386,169 @@ __global__ __launch_bounds__(WS_NT) void conv3_wgrad_bf16_ws_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// S3_PREC_BF16X3 training plans: the same contraction with both operands split
+// on the fly into bf16 pairs (hi = bf16(v), lo = bf16(v - hi)) and every
+// product taken as hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate —
+// fp32-class weight gradients (the dropped lo*lo term is ~2^-16 relative) at
+// three MFMAs per product instead of the exact-fp32 MFMA's eight-times-slower
+// rate.  x and dPre are fp32 in HBM.  The hi and lo images together are as
+// large as the fp32 data, so a workgroup walks HALF tiles (2 x 4 x 16
+// positions, x halo 4 x 6 x 18 cells) like the wave-specialised kernel:
+// x hi | x lo | dPre hi | dPre lo = 2 x 55,296 + 2 x 8,192 = 126,976 B.
+// Same lane maps, swizzles and k-step order as conv3_wgrad_bf16_kernel.
+__global__ __launch_bounds__(BNT) void conv3_wgrad_x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy,
+    float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
+    int tiles2, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int H0 = 2;                             // s0 rows of a half tile
+  constexpr int HP = (H0 + 2) * BH1 * BH2;          // 432 halo cells
+  constexpr int NP = H0 * BT1 * BT2;                // 128 positions
+  char* xh = smem;                                  // [HP][128 B] hi
+  char* xl = smem + HP * 128;                       // [HP][128 B] lo
+  char* dh = smem + 2 * HP * 128;                   // [NP][64 B] hi
+  char* dl = dh + NP * 64;                          // [NP][64 B] lo
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int q = lane & 15, kg = lane >> 4;
+  const int cb = wave & 3, ta = wave >> 2;
+  const int ct = blockIdx.y;
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  int a_off[3][2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int th = 8 * (kg & 1) + 4 * h + (q >> 2) + c;
+      a_off[c][h] = ((ta * BH1 + (kg >> 1)) * BH2 + th) * 128 +
+                    ((cb ^ xs_key(th)) << 5) + ((q & 3) << 3);
+    }
+  int b_off[2][2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pl = 8 * kg + 4 * h + (q >> 2);
+      b_off[nb][h] = pl * 64 + ((nb ^ ((pl >> 3) & 1)) << 5) + ((q & 3) << 3);
+    }
+  // split two fp32 pairs into packed bf16 hi / lo words
+  auto split = [](const float4& v, uint2& hi, uint2& lo) __attribute__((always_inline)) {
+    hi = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+    lo = make_uint2(pk2(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xFFFF0000u)),
+                    pk2(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xFFFF0000u)));
+  };
+
+  for (int item = 2 * blockIdx.x; item < 2 * n_tiles; item = (item & 1) ? item - 1 + 2 * (int)gridDim.x : item + 1) {
+    // item = (tile, half): both halves of a tile, then the tile gridDim.x further on
+    int tr = item >> 1;
+    const int t2i = tr % tiles2; tr /= tiles2;
+    const int t1i = tr % tiles1; tr /= tiles1;
+    const int t0i = tr % tiles0; tr /= tiles0;
+    const int n = tr;
+    const int org0 = t0i * BT0 + (item & 1) * H0, org1 = t1i * BT1, org2 = t2i * BT2;
+    __syncthreads();   // previous half fully consumed
+    for (int it = tid; it < HP * 16; it += BNT) {
+      const int hp = it >> 4, ch = it & 15;
+      int h = hp;
+      const int c2 = h % BH2; h /= BH2;
+      const int c1 = h % BH1; h /= BH1;
+      const int c0 = h;
+      int i0 = org0 + c0 - g.lo[0], i1 = org1 + c1 - g.lo[1], i2 = org2 + c2 - g.lo[2];
+      bool valid = true;
+      if (g.pad_mode == S3_PAD_REFLECT) {
+        i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); i2 = s3_reflect(i2, D2);
+      } else {
+        valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
+      }
+      // cells feeding only out-of-range outputs are multiplied by zero dPre
+      i0 = i0 < 0 ? 0 : (i0 > D0 - 1 ? D0 - 1 : i0);
+      i1 = i1 < 0 ? 0 : (i1 > D1 - 1 ? D1 - 1 : i1);
+      i2 = i2 < 0 ? 0 : (i2 > D2 - 1 ? D2 - 1 : i2);
+      const size_t cell = (((size_t)n * D0 + i0) * D1 + i1) * D2 + i2;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (valid) v = *reinterpret_cast<const float4*>(x + cell * 64 + ch * 4);
+      uint2 hi, lo;
+      split(v, hi, lo);
+      const int o = hp * 128 + (((ch >> 2) ^ xs_key(c2)) << 5) + ((ch & 3) << 3);
+      *reinterpret_cast<uint2*>(xh + o) = hi;
+      *reinterpret_cast<uint2*>(xl + o) = lo;
+    }
+    for (int it = tid; it < NP * (BCT / 4); it += BNT) {
+      const int pl = it >> 3, ch = it & 7;
+      const int row = pl / BT2, tt = pl % BT2;
+      const int o0 = org0 + row / BT1, o1 = org1 + row % BT1, o2 = org2 + tt;
+      const int co = ct * BCT + ch * 4;
+      const bool in = o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && co < g.Cout;
+      const size_t de = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * g.Cout + co;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (in) v = *reinterpret_cast<const float4*>(dy + de);
+      uint2 hi, lo;
+      split(v, hi, lo);
+      const int o = pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3);
+      *reinterpret_cast<uint2*>(dh + o) = hi;
+      *reinterpret_cast<uint2*>(dl + o) = lo;
+    }
+    __syncthreads();
+    // ---- 4 k-steps of 32 positions (2 s1 rows x 16 t)
+#pragma unroll
+    for (int ks = 0; ks < NP / 32; ++ks) {
+      const int rowb = (((ks >> 1) * BH1) + 2 * (ks & 1)) * BH2 * 128;
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const s16x4 h0 = lds_tr(dh + b_off[nb][0] + ks * 32 * 64);
+        const s16x4 h1 = lds_tr(dh + b_off[nb][1] + ks * 32 * 64);
+        bh[nb] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const s16x4 l0 = lds_tr(dl + b_off[nb][0] + ks * 32 * 64);
+        const s16x4 l1 = lds_tr(dl + b_off[nb][1] + ks * 32 * 64);
+        bl[nb] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int ao0 = a_off[c][0] + rowb + b * BH2 * 128, ao1 = a_off[c][1] + rowb + b * BH2 * 128;
+          const s16x4 h0 = lds_tr(xh + ao0);
+          const s16x4 h1 = lds_tr(xh + ao1);
+          const bf16x8 ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const s16x4 l0 = lds_tr(xl + ao0);
+          const s16x4 l1 = lds_tr(xl + ao1);
+          const bf16x8 al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            f32x4 a = acc[b * 3 + c][nb];
+            // small terms first
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nb], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nb], a, 0, 0, 0);
+            acc[b * 3 + c][nb] = a;
+          }
+        }
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * 27 * 64 * g.Cout;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int co = ct * BCT + nb * 16 + q;
+    if (co < g.Cout) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[((size_t)(ta * 9 + t) * 64 + cb * 16 + kg * 4 + r) * g.Cout + co] = acc[t][nb][r];
+    }
+  }
+}
+constexpr int X3_LDS = 2 * (4 * BH1 * BH2) * 128 + 2 * (2 * BT1 * BT2) * 64;   // 126,976 B
+
 __global__ void wgrad_bf16_partial_reduce(const float* __restrict__ partial,
                                           int n_part, int64_t wsize,
                                           float* __restrict__ dw, int accumulate) {
@@ -937,7 +1100,9 @@ int bf_2d_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy
 }  // namespace
 
 bool conv_wgrad_bf16_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_BF16)) return false;
+  // (BF16X3 plans: conv3_wgrad_x3_kernel, fp32 operands split in the staging)
+  if (precision == S3_PREC_BF16X3 ? s3_opt_has(S3O_NO_WGRAD_X3) : precision != S3_PREC_BF16) return false;
+  if (s3_opt_has(S3O_NO_WGRAD_BF16)) return false;
   if (g.Cin != 64 || g.Cout % 4 != 0 || g.Cout < 16) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] != 1 || g.O[d] != g.D[d]) return false;
@@ -953,11 +1118,12 @@ size_t conv_wgrad_bf16_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
 
 int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                            const float* dy, float* dw, float* partial,
-                           size_t partial_bytes, int accumulate, int x_bf16, int dy_bf16) {
+                           size_t partial_bytes, int accumulate, int x_bf16, int dy_bf16, int x3) {
   int n_tiles, tiles0, tiles1, tiles2;
   const int grid = bf_grid(ctx, g, &n_tiles, &tiles0, &tiles1, &tiles2);
   if (partial_bytes < conv_wgrad_bf16_partial_bytes(ctx, g))
     S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16: partial buffer too small");
+  if (x3 && (x_bf16 || dy_bf16)) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16: the split-bf16 kernel takes fp32 operands");
   if (dy_bf16 && (!x_bf16 || (g.Cout & 3))) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16: bf16 dPre needs bf16 x and C_out % 4 == 0");
   static bool attr_set = false;
   if (!attr_set) {
@@ -969,6 +1135,8 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_ws_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x3_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
     attr_set = true;
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
@@ -978,7 +1146,10 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                   g.O[0] % BT0 == 0 && g.O[1] % BT1 == 0 && g.O[2] % BT2 == 0 && g.Cout >= BCT && g.Cout % 8 == 0 &&
                   (int64_t)g.D[0] * g.D[1] * g.D[2] * 64 < ((int64_t)1 << 31) &&
                   (int64_t)g.O[0] * g.O[1] * g.O[2] * g.Cout < ((int64_t)1 << 31);
-  if (ws)
+  if (x3)
+    hipLaunchKernelGGL(conv3_wgrad_x3_kernel, dim3(grid, n_ct), dim3(BNT), X3_LDS, ctx->stream,
+                       x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles);
+  else if (ws)
     hipLaunchKernelGGL(conv3_wgrad_bf16_ws_kernel, dim3(grid, n_ct), dim3(WS_NT), WS_LDS, ctx->stream,
                        (const unsigned short*)x, (const unsigned short*)dy, partial, g, tiles0, tiles1, tiles2,
                        n_tiles);

@@ -1656,7 +1656,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
           {
             const bool dy16 = only16 || (dpre16 && o.io.in_bf16 && (g.Cout & 3) == 0);
             rc = launch_conv_wgrad_bf16(ctx, g, tptr(pl, d.in0), dy16 ? (const float*)dpre16 : dpre, G + P->p[d.w].offset,
-                                        pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16, dy16 ? 1 : 0);
+                                        pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16, dy16 ? 1 : 0,
+                                        pl->precision == S3_PREC_BF16X3 ? 1 : 0);
           }
           else if (o.wgrad_mfma)
             rc = launch_conv_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
