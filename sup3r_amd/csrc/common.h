@@ -60,6 +60,7 @@
   X(NO_PERSIST_DGRAD) \
   X(NO_REPEAT_FUSE) \
   X(NO_WGRAD_X3) \
+  X(NO_GCONV_X3) \
   X(NO_PLAIN_FOLD16) \
   X(NO_SEG_REDUCE) \
   X(NO_TAIL_BAND) \
@@ -253,12 +254,12 @@ int launch_conv_wgrad_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const 
 // bf16 operands): forward and data gradient
 bool conv_gconv_supported(const ConvGeom& g, int precision);
 bool conv_gconv_dgrad_supported(const ConvGeom& g, int precision);
-size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad);
-int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad);
+size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad, int x3 = 0);
+int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad, int x3 = 0);
 int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
-                     const float* bias, const float* res, void* y, int out_bf16, int in_bf16 = 0);
+                     const float* bias, const float* res, void* y, int out_bf16, int in_bf16 = 0, int x3 = 0);
 int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* packed_t,
-                       float* dx, int accumulate, int frame, int dy_bf16 = 0);
+                       float* dx, int accumulate, int frame, int dy_bf16 = 0, int x3 = 0);
 
 // MFMA backward of the 3x3x3 stride-1 trunk convs.
 bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision);

@@ -3,7 +3,12 @@
 // 32, fp32 activations — the strided / valid-padded discriminator convs (K3 of
 // 32->32 s2, 32->64, 64->64 s2, 64->128 ...), forward, data
 // gradient and weight gradient.  bf16 operands, fp32 accumulate
-// (v_mfma_f32_16x16x32_bf16); used by S3_PREC_BF16 plans only.
+// (v_mfma_f32_16x16x32_bf16).  S3_PREC_BF16 plans; S3_PREC_BF16X3 plans run
+// the X3 variant of the same kernel: the gathered fp32 cell and the filter are
+// split into bf16 pairs (hi = bf16(v), lo = bf16(v - hi); the filter's lo
+// image sits behind its hi image) and every product is lo*hi + hi*lo + hi*hi
+// — fp32-class forward and data gradients of the discriminator convs at three
+// MFMAs per product instead of the direct fp32 kernels.
 //
 // No LDS halo: with strides and ragged valid extents a halo tile is mostly
 // padding, so the position operand is GATHERED — lane (position p, k-group kq)
@@ -43,12 +48,24 @@ __device__ inline bf16x8 pack8(const float4& a, const float4& b) {
   uint4 u = make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
   return __builtin_bit_cast(bf16x8, u);
 }
+// the same with the rounding residue: hi = bf16(v), lo = bf16(v - hi)
+__device__ inline void split8(const float4& a, const float4& b, bf16x8& hi, bf16x8& lo) {
+  const uint4 h = make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
+  auto lo_f = [](unsigned u) { return __uint_as_float(u << 16); };
+  auto hi_f = [](unsigned u) { return __uint_as_float(u & 0xFFFF0000u); };
+  const uint4 l = make_uint4(pk2(a.x - lo_f(h.x), a.y - hi_f(h.x)), pk2(a.z - lo_f(h.y), a.w - hi_f(h.y)),
+                             pk2(b.x - lo_f(h.z), b.y - hi_f(h.z)), pk2(b.z - lo_f(h.w), b.w - hi_f(h.w)));
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
 
 // fp32 [taps][K][R] (canonical [tap][ci][co], R = C_out) or its transpose
 // -> bf16 [taps][R_pad][K]; transpose_flip = 0: rows = co, K = ci (forward);
 // 1: rows = ci, K = co (data gradient; tap order is handled by the kernel)
+// lo != nullptr (BF16X3): also the image of the rounding residues bf16(v - bf16(v))
 __global__ void gconv_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                  int taps, int cin, int cout, int rows_pad, int mode) {
+                                  int taps, int cin, int cout, int rows_pad, int mode,
+                                  unsigned short* __restrict__ lo = nullptr) {
   const int R = mode == 0 ? cout : cin, Kx = mode == 0 ? cin : cout;
   const int K = (Kx + 7) / 8 * 8;              // rows padded to whole 16-B chunks
   const int64_t total = (int64_t)taps * rows_pad * K;
@@ -63,7 +80,9 @@ __global__ void gconv_pack_kernel(const float* __restrict__ w, unsigned short* _
       const int ci = mode == 0 ? k : row, co = mode == 0 ? row : k;
       v = w[((int64_t)tap * cin + ci) * cout + co];
     }
-    out[idx] = (unsigned short)(pk2(v, 0.f) & 0xFFFFu);
+    const unsigned h = pk2(v, 0.f) & 0xFFFFu;
+    out[idx] = (unsigned short)h;
+    if (lo) lo[idx] = (unsigned short)(pk2(v - __uint_as_float(h << 16), 0.f) & 0xFFFFu);
   }
 }
 
@@ -74,12 +93,12 @@ __global__ void gconv_pack_kernel(const float* __restrict__ w, unsigned short* _
 // wave's vector-memory bytes (4 KB of filter + 2 KB of gathered cells per 8
 // MFMAs), with MF = 4 half (4 + 4 KB per 16 MFMAs) — used whenever the grid
 // still fills the chip.
-template <bool ADJ, int MF>
+template <bool ADJ, int MF, bool X3 = false>
 __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, const float* __restrict__ res,
     void* __restrict__ yv, ConvGeom g, int64_t P, int rows_pad, int accumulate, int frame,
-    int out_bf16, int x16, int nsplit, float* __restrict__ part) {
+    int out_bf16, int x16, int nsplit, float* __restrict__ part, int64_t lo_off = 0) {
   float* __restrict__ y = reinterpret_cast<float*>(yv);
   // nsplit > 1 (few positions, long contraction): blockIdx.z also enumerates
   // slices of the (tap, k-chunk) sequence; a slice leaves its raw fp32 sums in
@@ -215,12 +234,17 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
         for (int kc = 0; kc < kchunks; ++kc) {
           if (it_tap + kc < it_lo || it_tap + kc >= it_hi) continue;
           bf16x8 wf[4], xf[MF];
+          bf16x8 wl[X3 ? 4 : 1], xl[X3 ? MF : 1];     // BF16X3: the residue halves
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf)
-            if (nf < nfv) wf[nf] = *reinterpret_cast<const bf16x8*>(wt + (int64_t)nf * 16 * Kp + kc * 32);
+            if (nf < nfv) {
+              wf[nf] = *reinterpret_cast<const bf16x8*>(wt + (int64_t)nf * 16 * Kp + kc * 32);
+              if constexpr (X3)
+                wl[nf] = *reinterpret_cast<const bf16x8*>(wt + lo_off + (int64_t)nf * 16 * Kp + kc * 32);
+            }
 #pragma unroll
           for (int m = 0; m < MF; ++m) {
-            if (x16) {
+            if (!X3 && x16) {
               // bf16 cells (bf16 saved activations, K % 8 == 0): the lane's 8
               // channels are one 16-B load; src[] was computed in fp32 elements
               uint4 u = make_uint4(0, 0, 0, 0);
@@ -240,14 +264,20 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
                 a.x = t.x; a.y = t.y;
               }
             }
-            xf[m] = pack8(a, b);
+            if constexpr (X3) split8(a, b, xf[m], xl[m]);
+            else xf[m] = pack8(a, b);
           }
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf)
             if (nf < nfv) {       // wave-uniform: fragments past the last channel are skipped
 #pragma unroll
-              for (int m = 0; m < MF; ++m)
+              for (int m = 0; m < MF; ++m) {
+                if constexpr (X3) {   // small terms first
+                  acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nf], xf[m], acc[m][nf], 0, 0, 0);
+                  acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xl[m], acc[m][nf], 0, 0, 0);
+                }
                 acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[m], acc[m][nf], 0, 0, 0);
+              }
             }
         }
       }
@@ -373,11 +403,13 @@ int gconv_splits(const s3_ctx* ctx, int64_t wgs, int iters) {
 constexpr int FC_MF = 4;                       // position fragments per wave
 constexpr int FC_POS = GT_WAVES * FC_MF * 16;  // 256 positions per workgroup
 
-template <int CIN>
+// X3 (BF16X3 plans): gathered taps and filter split into bf16 pairs, three
+// MFMAs per product; the filter's residue image sits lo_off elements behind
+template <int CIN, bool X3 = false>
 __global__ __launch_bounds__(GT_WAVES * 64) void gconv_fewch_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, const float* __restrict__ res,
-    void* __restrict__ yv, ConvGeom g, int64_t P, int out_bf16) {
+    void* __restrict__ yv, ConvGeom g, int64_t P, int out_bf16, int lo_off = 0) {
   constexpr int TPL = 8 / CIN;                 // taps per lane per chunk
   constexpr int KC = (27 * CIN + 31) / 32;     // chunks of 32
   constexpr int KP = KC * 32;
@@ -404,13 +436,18 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_fewch_kernel(
     }
   // filter fragments (A operand: rows = output channels)
   bf16x8 wf[KC][4];
+  bf16x8 wl[X3 ? KC : 1][4];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf)
-      if (nf < nfv)
+      if (nf < nfv) {
         wf[kc][nf] = *reinterpret_cast<const bf16x8*>(
             wpk + ((int64_t)ct * GT_N + nf * 16 + p16) * KP + kc * 32 + kq * 8);
+        if constexpr (X3)
+          wl[kc][nf] = *reinterpret_cast<const bf16x8*>(
+              wpk + lo_off + ((int64_t)ct * GT_N + nf * 16 + p16) * KP + kc * 32 + kq * 8);
+      }
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
   float bv[4][4];
 #pragma unroll
@@ -466,12 +503,22 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_fewch_kernel(
           v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
         }
       }
-      const uint4 u = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
-      const bf16x8 xf = __builtin_bit_cast(bf16x8, u);
+      bf16x8 xf, xl;
+      if constexpr (X3) {
+        split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), xf, xl);
+      } else {
+        const uint4 u = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+        xf = __builtin_bit_cast(bf16x8, u);
+      }
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf)
-        if (nf < nfv)
+        if (nf < nfv) {
+          if constexpr (X3) {
+            acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[kc][nf], xf, acc[nf], 0, 0, 0);
+            acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kc][nf], xl, acc[nf], 0, 0, 0);
+          }
           acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kc][nf], xf, acc[nf], 0, 0, 0);
+        }
     }
     if (!pok) continue;
 #pragma unroll
@@ -793,13 +840,16 @@ bool fewch_halo_ok(const s3_ctx* ctx, const ConvGeom& g, const float* res, int o
 
 // fp32 [27][cin][cout] -> bf16 [rows_pad][KP], k = tap * cin + ci
 __global__ void gconv_fewch_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                        int cin, int cout, int rows_pad, int kp) {
+                                        int cin, int cout, int rows_pad, int kp,
+                                        unsigned short* __restrict__ lo = nullptr) {
   const int total = rows_pad * kp;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int k = idx % kp, row = idx / kp;
     float v = 0.f;
     if (row < cout && k < 27 * cin) v = w[(int64_t)k * cout + row];
-    out[idx] = (unsigned short)(pk2(v, 0.f) & 0xFFFFu);
+    const unsigned h = pk2(v, 0.f) & 0xFFFFu;
+    out[idx] = (unsigned short)h;
+    if (lo) lo[idx] = (unsigned short)(pk2(v - __uint_as_float(h << 16), 0.f) & 0xFFFFu);
   }
 }
 
@@ -811,7 +861,7 @@ bool fewch_geom(const ConvGeom& g) {
 }  // namespace
 
 bool conv_gconv_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16) return false;
+  if (precision == S3_PREC_BF16X3 ? s3_opt_has(S3O_NO_GCONV_X3) : precision != S3_PREC_BF16) return false;
   if (s3_opt_has(S3O_NO_GCONV)) return false;
   if (g.d2s != 1) return false;
   // C_in = 4: the generator's first conv (a cell is one float4)
@@ -822,7 +872,7 @@ bool conv_gconv_supported(const ConvGeom& g, int precision) {
 
 // data gradient through the same kernel: contraction over C_out
 bool conv_gconv_dgrad_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16) return false;
+  if (precision == S3_PREC_BF16X3 ? s3_opt_has(S3O_NO_GCONV_X3) : precision != S3_PREC_BF16) return false;
   if (s3_opt_has(S3O_NO_GCONV)) return false;
   // (a depth-to-space store is undone by the epilogue adjoint: dPre arrives in
   // the conv's own output layout)
@@ -835,9 +885,21 @@ bool conv_gconv_dgrad_supported(const ConvGeom& g, int precision) {
 
 static int rows_padded(int r) { return (r + GT_N - 1) / GT_N * GT_N; }
 
-size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad) {
+// element offset of the residue (lo) image of a BF16X3 plan behind the hi image
+static int64_t x3_lo_offset(const ConvGeom& g, int dgrad) {
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int R = dgrad ? g.Cin : g.Cout, K = dgrad ? g.Cout : g.Cin;
+  return (int64_t)taps * rows_padded(R) * ((K + 7) / 8 * 8) + 32;
+}
+
+static int x3_fewch_lo_offset(const ConvGeom& g) { return rows_padded(g.Cout) * ((27 * g.Cin + 31) / 32 * 32); }
+
+size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad, int x3) {
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int R = dgrad ? g.Cin : g.Cout, K = dgrad ? g.Cout : g.Cin;
+  // (few-channel geometry: the taps-in-K images only, hi then lo)
+  if (x3 && !dgrad && fewch_geom(g)) return 2 * (size_t)x3_fewch_lo_offset(g) * 2 + 64;
+  if (x3) return 2 * ((size_t)x3_lo_offset(g, dgrad) * 2);
   size_t fewch = 0;
   if (!dgrad && fewch_geom(g)) fewch = (size_t)rows_padded(g.Cout) * ((27 * g.Cin + 31) / 32 * 32) * 2;
   return (size_t)taps * rows_padded(R) * ((K + 7) / 8 * 8) * 2 + 64 + fewch;   // + over-read of a masked K tail
@@ -849,16 +911,25 @@ static size_t fewch_image_offset(const ConvGeom& g) {
   return (size_t)taps * rows_padded(g.Cout) * ((g.Cin + 7) / 8 * 8) * 2 + 64;
 }
 
-int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad) {
+int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad, int x3) {
+  if (x3 && !dgrad && fewch_geom(g)) {
+    const int kp = (27 * g.Cin + 31) / 32 * 32;
+    hipLaunchKernelGGL(gconv_fewch_pack_kernel, dim3((rows_padded(g.Cout) * kp + 255) / 256), dim3(256), 0,
+                       ctx->stream, w, (unsigned short*)packed, g.Cin, g.Cout, rows_padded(g.Cout), kp,
+                       (unsigned short*)packed + x3_fewch_lo_offset(g));
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int R = dgrad ? g.Cin : g.Cout, K = dgrad ? g.Cout : g.Cin;
   const int64_t total = (int64_t)taps * rows_padded(R) * ((K + 7) / 8 * 8);
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(gconv_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, w,
-                     (unsigned short*)packed, taps, g.Cin, g.Cout, rows_padded(R), dgrad);
+                     (unsigned short*)packed, taps, g.Cin, g.Cout, rows_padded(R), dgrad,
+                     x3 ? (unsigned short*)packed + x3_lo_offset(g, dgrad) : (unsigned short*)nullptr);
   S3_HIP(ctx, hipGetLastError());
-  if (!dgrad && fewch_geom(g)) {
+  if (!dgrad && fewch_geom(g) && !x3) {
     const int kp = (27 * g.Cin + 31) / 32 * 32;
     hipLaunchKernelGGL(gconv_fewch_pack_kernel, dim3((rows_padded(g.Cout) * kp + 255) / 256), dim3(256), 0,
                        ctx->stream, w, (unsigned short*)((char*)packed + fewch_image_offset(g)), g.Cin,
@@ -869,11 +940,23 @@ int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* pack
 }
 
 int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
-                     const float* bias, const float* res, void* y, int out_bf16, int in_bf16) {
+                     const float* bias, const float* res, void* y, int out_bf16, int in_bf16, int x3) {
   if (out_bf16 && g.Cout % 4 != 0) S3_FAIL(ctx, S3_EINVAL, "gconv: bf16 output needs C_out % 4 == 0");
   if (in_bf16 && (g.Cin % 8 != 0 || fewch_geom(g))) S3_FAIL(ctx, S3_EINVAL, "gconv: bf16 input needs C_in % 8 == 0");
+  if (x3 && (out_bf16 || in_bf16)) S3_FAIL(ctx, S3_EINVAL, "gconv: the split-bf16 variant takes and writes fp32");
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
-  if (fewch_geom(g)) {
+  if (fewch_geom(g) && x3) {
+    dim3 fgrid((unsigned)((P + FC_POS - 1) / FC_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
+    if (g.Cin == 2)
+      hipLaunchKernelGGL((gconv_fewch_kernel<2, true>), fgrid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
+                         (const unsigned short*)packed, bias, res, y, g, P, 0, x3_fewch_lo_offset(g));
+    else
+      hipLaunchKernelGGL((gconv_fewch_kernel<4, true>), fgrid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
+                         (const unsigned short*)packed, bias, res, y, g, P, 0, x3_fewch_lo_offset(g));
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
+  if (fewch_geom(g) && !x3) {
     dim3 fgrid((unsigned)((P + FC_POS - 1) / FC_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
     const unsigned short* img = (const unsigned short*)((const char*)packed + fewch_image_offset(g));
     if (fewch_halo_ok(ctx, g, res, out_bf16)) {
@@ -912,7 +995,15 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
   int ns = gconv_splits(ctx, (int64_t)nblk * n_ct, iters);
   if (ns > 1 && ensure_scratch(ctx, (size_t)ns * P * g.Cout * sizeof(float)) != S3_OK) ns = 1;
   dim3 grid((unsigned)nblk, (unsigned)n_ct, (unsigned)ns);
-  if (wide)
+  if (x3 && wide)
+    hipLaunchKernelGGL((gconv_mfma_kernel<false, 4, true>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
+                       (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, 0, 0,
+                       ns, ctx->scratch, x3_lo_offset(g, 0));
+  else if (x3)
+    hipLaunchKernelGGL((gconv_mfma_kernel<false, 2, true>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
+                       (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, 0, 0,
+                       ns, ctx->scratch, x3_lo_offset(g, 0));
+  else if (wide)
     hipLaunchKernelGGL((gconv_mfma_kernel<false, 4>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, x,
                        (const unsigned short*)packed, bias, res, y, g, P, rows_padded(g.Cout), 0, 0, out_bf16, in_bf16,
                        ns, ctx->scratch);
@@ -935,7 +1026,8 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
 }
 
 int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* packed_t,
-                       float* dx, int accumulate, int frame, int dy_bf16) {
+                       float* dx, int accumulate, int frame, int dy_bf16, int x3) {
+  if (x3 && dy_bf16) S3_FAIL(ctx, S3_EINVAL, "gconv: the split-bf16 variant takes fp32 dPre");
   // dy_bf16: dy is the bf16 copy of dPre (C_out % 8 == 0)
   const int64_t P = frame ? (int64_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
                                 (g.D[2] + 2 * g.lo[2])
@@ -960,7 +1052,11 @@ int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const vo
   int ns = nz == 1 ? gconv_splits(ctx, (int64_t)nblk * n_ct, g.k[0] * g.k[1] * g.k[2] * ((g.Cout + 31) / 32)) : 1;
   if (ns > 1 && ensure_scratch(ctx, (size_t)ns * P * g.Cin * sizeof(float)) != S3_OK) ns = 1;
   dim3 grid((unsigned)nblk, (unsigned)n_ct, (unsigned)(nz * ns));
-  if (wide)
+  if (x3)
+    hipLaunchKernelGGL((gconv_mfma_kernel<true, 2, true>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
+                       (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
+                       rows_padded(g.Cin), accumulate, frame, 0, 0, ns, ctx->scratch, x3_lo_offset(g, 1));
+  else if (wide)
     hipLaunchKernelGGL((gconv_mfma_kernel<true, 4>), grid, dim3(GT_WAVES * 64), 0, ctx->stream, dy,
                        (const unsigned short*)packed_t, nullptr, nullptr, dx, g, P,
                        rows_padded(g.Cin), accumulate, frame, 0, dy_bf16, ns, ctx->scratch);

@@ -624,7 +624,8 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
               conv_dgrad_mfma_valid_supported(g, precision)) {
             o.dgrad_mfma = o.dgrad_valid = true;
           }
-          if (!o.dgrad_mfma && !o.fewpos && precision == S3_PREC_BF16 && !s3_opt_has(S3O_NO_DGRAD_FEWCH) &&
+          if (!o.dgrad_mfma && !o.fewpos && (precision == S3_PREC_BF16 || precision == S3_PREC_BF16X3) &&
+              !s3_opt_has(S3O_NO_DGRAD_FEWCH) &&
               (g.Cout == 2 || g.Cout == 4) && g.Cin % 4 == 0 && g.d2s == 1 &&
               (int64_t)g.N * g.D[0] * g.D[1] * g.D[2] >= 4096) {
             // hi-res tail conv (8 -> 2): its data gradient is a conv with 2 input
@@ -957,7 +958,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         continue;
       }
       if (!rc && precision != S3_PREC_F32)
-        rc = plan_alloc(pl, &o.dg_wbf, o.dgrad_fewch ? conv_gconv_packed_bytes(o.dg, 0)
+        rc = plan_alloc(pl, &o.dg_wbf, o.dgrad_fewch ? conv_gconv_packed_bytes(o.dg, 0, precision == S3_PREC_BF16X3)
                                                      : conv_mfma_packed_bytes(o.dg, precision));
     }
     if (rc) { s3_plan_destroy(pl); return rc; }
@@ -984,7 +985,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
   for (auto& o : pl->ops) {
     if (o.d.kind != S3_OP_CONV) continue;
     if (o.gconv) {
-      int rc = plan_alloc(pl, &o.gc_w, conv_gconv_packed_bytes(o.cg, 0));
+      int rc = plan_alloc(pl, &o.gc_w, conv_gconv_packed_bytes(o.cg, 0, precision == S3_PREC_BF16X3));
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
     if (o.halo32 || o.halo_s2) {
@@ -1000,7 +1001,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
     if (o.gconv_dgrad) {
-      int rc = plan_alloc(pl, &o.gc_wt, conv_gconv_packed_bytes(o.cg, 1));
+      int rc = plan_alloc(pl, &o.gc_wt, conv_gconv_packed_bytes(o.cg, 1, precision == S3_PREC_BF16X3));
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
   }
@@ -1186,11 +1187,12 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
       if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
           (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
         if (o.gc_version != P->version) {
-          int rc = launch_gconv_pack(ctx, o.cg, w, o.gc_w, 0);
+          int rc = launch_gconv_pack(ctx, o.cg, w, o.gc_w, 0, pl->precision == S3_PREC_BF16X3);
           if (rc) return rc;
           o.gc_version = P->version;
         }
-        return launch_gconv_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.gc_w, b, res, tptr(pl, d.out), o.io.out_bf16, o.io.in_bf16);
+        return launch_gconv_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.gc_w, b, res, tptr(pl, d.out), o.io.out_bf16, o.io.in_bf16,
+                                pl->precision == S3_PREC_BF16X3);
       }
       if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16)
         return launch_conv_fewpos_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out), pl->fp_partial, pl->fp_partial_bytes);
@@ -1785,7 +1787,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             if (o.dg_version != P->version) {
               rc = launch_conv_dgrad_pack(ctx, g, W + P->p[d.w].offset, o.dg_w32);
               if (!rc && o.dgrad_fewch)
-                rc = launch_gconv_pack(ctx, o.dg, o.dg_w32, o.dg_wbf, 0);
+                rc = launch_gconv_pack(ctx, o.dg, o.dg_w32, o.dg_wbf, 0, pl->precision == S3_PREC_BF16X3);
               else if (!rc && pl->precision != S3_PREC_F32)
                 rc = launch_conv_mfma_pack(ctx, o.dg, pl->precision, o.dg_w32, o.dg_wbf);
               if (rc) return rc;
@@ -1793,7 +1795,7 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             }
             const void* wp = pl->precision != S3_PREC_F32 ? (const void*)o.dg_wbf : (const void*)o.dg_w32;
             if (o.dgrad_fewch)
-              rc = launch_gconv_fwd(ctx, o.dg, dpre, o.dg_wbf, nullptr, nullptr, pl->dxp, 0);
+              rc = launch_gconv_fwd(ctx, o.dg, dpre, o.dg_wbf, nullptr, nullptr, pl->dxp, 0, 0, pl->precision == S3_PREC_BF16X3);
             else if (o.use16 && dpre16 && pl->precision == S3_PREC_BF16 &&
                      conv_mfma_persist_dgrad_supported(ctx, o.dg)) {
               // the persistent trunk kernel over the stacked frames (a valid conv's
@@ -1863,13 +1865,13 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             rc = launch_conv_dgrad_c2(ctx, g, only16 ? (const float*)dpre16 : dpre, o.dc2_w, dst, only16 ? 1 : 0);
           } else if (o.gconv_dgrad) {
             if (o.gct_version != P->version) {
-              rc = launch_gconv_pack(ctx, g, W + P->p[d.w].offset, o.gc_wt, 1);
+              rc = launch_gconv_pack(ctx, g, W + P->p[d.w].offset, o.gc_wt, 1, pl->precision == S3_PREC_BF16X3);
               if (rc) return rc;
               o.gct_version = P->version;
             }
             if (g.pad_mode == S3_PAD_REFLECT) {
               // dXpad over the reflect-padded frame, then fold the border back
-              rc = launch_gconv_dgrad(ctx, g, dpre, o.gc_wt, pl->dxp, 0, 1);
+              rc = launch_gconv_dgrad(ctx, g, dpre, o.gc_wt, pl->dxp, 0, 1, 0, pl->precision == S3_PREC_BF16X3);
               if (rc) return rc;
               GatherGeom fg;
               fg.kind = S3_OP_PAD; fg.N = g.N;
@@ -1879,7 +1881,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
               rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
             } else {
               const bool dy16 = o.use16 && dpre16 != nullptr;
-              rc = launch_gconv_dgrad(ctx, g, dy16 ? (const float*)dpre16 : dpre, o.gc_wt, dst, 0, 0, dy16 ? 1 : 0);
+              rc = launch_gconv_dgrad(ctx, g, dy16 ? (const float*)dpre16 : dpre, o.gc_wt, dst, 0, 0, dy16 ? 1 : 0,
+                                      pl->precision == S3_PREC_BF16X3);
             }
           } else if (o.fewpos && o.fp_wt) {
             if (o.fp_version != P->version) {

@@ -164,6 +164,12 @@ def test_bf16x3_edge_shapes_and_backward():
         y_ref = ref.forward(x)
         net = _hip(spec, ref.weights, 'bf16x3')
         ph = net.plan(shape, training=True)
+        if shape[0] == 12:
+            # round 3: the 64 -> C_out weight gradients run split-bf16 too
+            # (conv3_wgrad_x3_kernel), not on the exact-fp32 MFMA
+            wg = [ph.op_info(i)['wgrad'] for i, op in enumerate(ph.plan.ops)
+                  if op['kind'] == 1 and op.get('cin') == 64]
+            assert wg.count('bf16_trunk') == 3, wg
         y = ph.forward(net.dev.to_device(x)).cpu().numpy()
         assert rel_linf(y, y_ref) < 2e-5, (shape, rel_linf(y, y_ref))
         dy = rng.standard_normal(y_ref.shape).astype(np.float32)
@@ -277,6 +283,13 @@ def test_production_discriminators_fwd_bwd(cfg, shape):
     spec = _load(cfg)
     _fwd_bwd_vs_oracle(spec, shape, 'f32', 31, 1e-4, 1e-3)
     _fwd_bwd_vs_oracle(spec, shape, 'bf16', 31, 3e-2, 2e-2)
+    # round 3: BF16X3 plans run these convs split-bf16 on the gather-MFMA
+    # kernel (forward and data gradient) at the fp32 bounds
+    ph = _fwd_bwd_vs_oracle(spec, shape, 'bf16x3', 31, 1e-4, 1e-3)
+    fwd, dg = _kernels(ph, 'fwd'), _kernels(ph, 'dgrad')
+    print('bf16x3 fwd', fwd, 'dgrad', dg)
+    assert sum(k.startswith('gconv') for k in fwd) >= 2, fwd
+    assert dg.count('gconv') >= 2, dg
 
 
 def test_disc_st_production_kernels_at_reduced_shape():
@@ -310,6 +323,9 @@ def test_disc_st_production_kernels_at_reduced_shape():
     assert chosen is not None, 'no reduced shape selects every kernel'
     _fwd_bwd_vs_oracle(spec, chosen, 'bf16', 17, 3e-2, 2e-2, replicate=True)
     _fwd_bwd_vs_oracle(spec, chosen, 'f32', 17, 1e-4, 1e-3, replicate=True)
+    ph = _fwd_bwd_vs_oracle(spec, chosen, 'bf16x3', 17, 1e-4, 1e-3,
+                            replicate=True)
+    assert sum(k.startswith('gconv') for k in _kernels(ph, 'fwd')) >= 5
 
 
 # --------------------------------------------------- generators, masks fixed
