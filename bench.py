@@ -125,13 +125,13 @@ def train_models(config, precision='bf16'):
 
 
 def train_leg(config, global_batch, world, rank, min_seconds, max_steps,
-              multi_gpu):
+              multi_gpu, precision='bf16'):
     """ms per ``Sup3rGan._train_batch`` (generator step + discriminator step)
     on synthetic batches; with ``multi_gpu`` every rank computes its 1 / world
     shard of the global batch and the gradients are SUMMED over RCCL."""
     import torch
     from sup3r_amd.engine import Device
-    model, lr_s, hr_s, what, gflop = train_models(config)
+    model, lr_s, hr_s, what, gflop = train_models(config, precision)
     lr_shape, hr_shape = (global_batch,) + lr_s, (global_batch,) + hr_s
     rng = np.random.default_rng(0)        # every rank draws the SAME batch
     dev = Device.get()
@@ -170,7 +170,12 @@ def train_leg(config, global_batch, world, rank, min_seconds, max_steps,
     dt = el / n
     out = {'workload': f'Sup3rGan._train_batch (gen step + disc step), {what}, '
                        f'global batch {global_batch}, lr {lr_shape} -> hr '
-                       f'{hr_shape}, bf16 MFMA operands, MeanAbsoluteError'
+                       f'{hr_shape}, ' + {
+                           'bf16': 'bf16 MFMA operands',
+                           'bf16x3': 'split-bf16 (hi*hi + hi*lo + lo*hi) MFMA '
+                                     'operands, fp32 activations',
+                           'f32': 'exact fp32'}[precision] +
+                       ', MeanAbsoluteError'
                        + (f', batch split over {world} GPUs, RCCL gradient '
                           'SUM' if multi_gpu and world > 1 else ''),
            'ms_per_step': dt * 1e3, 'value': global_batch / dt,
@@ -611,7 +616,7 @@ def main():
             raise SystemExit(f'global batch {gb} does not divide over {world}')
         barrier()
         out = train_leg(args.config, gb, world, rank, 1e9, args.steps,
-                        multi_gpu=True)
+                        multi_gpu=True, precision=args.precision)
         barrier()
         if rank == 0:
             print(json.dumps(dict(
@@ -619,7 +624,7 @@ def main():
                              'step + discriminator step)',
                 value=out['value'], unit='samples/s',
                 ms_per_step=out['ms_per_step'], scaling='strong',
-                dtype='bf16', steps=out['steps'],
+                dtype=args.precision, steps=out['steps'],
                 config={'workload': out['workload'], 'global_batch': gb,
                         'parallelism': f'batch split x{world}, RCCL all-'
                                        'reduce (SUM) of the flat gradient '
@@ -837,6 +842,16 @@ def main():
         # the headline, not part of `value`
         result['train'] = train_leg('c2', 8, 1, 0, args.train_seconds, 400,
                                     multi_gpu=False)
+        if not args.no_parity_mode:
+            # the training mode whose gradients meet the fp32 tolerance
+            # (tests/test_parity_r03.py: 1.2e-5 / 3.7e-5 vs the fp32 oracle)
+            x3 = train_leg('c2', 8, 1, 0, min(args.train_seconds, 3.0), 100,
+                           multi_gpu=False, precision='bf16x3')
+            result['train']['parity_mode'] = dict(
+                dtype='bf16x3', ms_per_step=x3['ms_per_step'],
+                value=x3['value'], unit=x3['unit'], steps=x3['steps'],
+                tolerance='gradients of both steps <= 1e-4 of the fp32 '
+                          'oracle under the device masks')
     if single and not args.no_traffic:
         traffic, note = measure_traffic(B)
         result['roofline']['traffic'] = traffic

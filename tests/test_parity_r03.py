@@ -339,6 +339,15 @@ def test_c2_train_batch_fp32_under_device_masks():
     _train_batch_vs_oracle('f32', 1, 1e-4, 1e-4)
 
 
+def test_c2_train_batch_bf16x3_under_device_masks():
+    """the fp32-class training mode (round 3): one C2 ``_train_batch`` in
+    ``precision='bf16x3'`` — trunk forward / data gradient / weight gradient,
+    the discriminator's gather-MFMA convs and the few-channel hi-res convs all
+    split-bf16 (hi*hi + hi*lo + lo*hi) on the bf16 matrix cores — against the
+    fp32 oracle under the device's masks: gradients and loss scalars 1e-4"""
+    _train_batch_vs_oracle('bf16x3', 1, 1e-4, 1e-4)
+
+
 def test_c2_train_batch_bf16_batch8_vs_emulating_oracle():
     """the benched training step (``bench.py --mode train``: bf16, batch 8):
     per-op forward of the generator and of the discriminator on both fields,
