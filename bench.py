@@ -673,7 +673,9 @@ def main():
     if args.mode == 'c3':
         b = args.batch or 8
         barrier()
-        n, el = c3_leg(b, args.steps, args.warmup, world, rank,
+        # (>= 4 untimed batches: the ring of pinned 368 MB output buffers is
+        # 3 deep, each first allocation costs ~35 ms of hipHostMalloc)
+        n, el = c3_leg(b, args.steps, max(args.warmup, 4), world, rank,
                        entry=args.c3_entry)
         barrier()
         el = max_over_ranks(el)
@@ -740,6 +742,10 @@ def main():
     achieved = flop / (body_ms * 1e-3) / 1e12
     esize = 2 if args.precision == 'bf16' else 4
     body_bytes = BODY_CONV_ELEMS_PER_SAMPLE * esize * B
+    # (17 of the 33 body convs also read a SkipConnection residual — a
+    # compulsory third stream of the fused op, half the in + out bytes)
+    n_res = sum(1 for i in body if ph.plan.ops[i].get('res', -1) >= 0)
+    body_bytes_res = body_bytes * (1.0 + 0.5 * n_res / max(1, len(body)))
     peak = PEAK_TFLOPS[args.precision]
     conv_ms = sum(ms[i] for i, op in enumerate(ph.plan.ops) if 'cout' in op)
     kclass = ph.op_kernel_class(body[0]) if body else 0
@@ -766,6 +772,7 @@ def main():
             'bound': 'mfma', 'achieved': achieved, 'peak': peak,
             'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
             'algorithmic_bytes_per_launch': body_bytes,
+            'algorithmic_bytes_incl_residual_reads': body_bytes_res,
             'launches_per_step': len(body), 'avg_launch_ms': body_ms,
             'hbm_algorithmic_GBps': body_bytes / (body_ms * 1e-3) / 1e9,
             'hbm_frac': body_bytes / (body_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
@@ -859,6 +866,8 @@ def main():
         if traffic:
             result['roofline']['traffic_over_algorithmic'] = \
                 traffic / body_bytes
+            result['roofline']['traffic_over_algorithmic_incl_residual'] = \
+                traffic / body_bytes_res
         tail = getattr(measure_traffic, 'tail', None)
         for o in result['roofline']['hbm_bound_ops']:
             if tail and 'tail_mfma' in o['what']:

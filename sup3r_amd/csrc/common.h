@@ -187,6 +187,21 @@ __device__ inline int s3_xcd_tile(int b, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// The same for PERSISTENT workgroups that walk a list of n items (tiles,
+// k-steps): the XCD of this block owns the contiguous share [lo, hi) — sized by
+// its number of blocks — and block k of its nk blocks takes lo + k, lo + k +
+// nk, ...  Neighbouring items (halo overlap, the 3 x 3 window rows of a
+// weight gradient) are then fetched into ONE L2 instead of up to eight.
+__device__ inline void s3_xcd_share(int64_t n, int64_t& lo, int64_t& hi, int& k, int& nk) {
+  const int G = gridDim.x, b = blockIdx.x, xcd = b % 8;
+  int before = 0;
+  for (int q = 0; q < xcd; ++q) before += (G - q + 7) / 8;
+  nk = (G - xcd + 7) / 8;
+  k = b / 8;
+  lo = n * before / G;
+  hi = n * (before + nk) / G;
+}
+
 // ---- launchers (defined in the .hip files) ------------------------------
 // element types of a fused conv's activations (0 = fp32, 1 = bf16)
 struct ConvIO {

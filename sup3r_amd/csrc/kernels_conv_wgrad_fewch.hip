@@ -83,7 +83,16 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int64_t n_waves = (int64_t)gridDim.x * C2_WAVES;
+  // k-steps of this workgroup: its XCD's contiguous share of the step list
+  // (steps run along t, then s2, then s1: the 3 x 3 window rows of a step are
+  // the neighbours' rows — with block b on XCD b % 8 and steps dealt round
+  // robin, all eight L2s fetched every x row: FETCH 1.86 GB for 1.0 GB of
+  // operands, profiles/r03/pmc_train.txt)
+  int64_t st_lo, st_hi;
+  int xk, xnk;
+  s3_xcd_share(n_steps, st_lo, st_hi, xk, xnk);
+  const int64_t n_waves = (int64_t)xnk * C2_WAVES;
+  n_steps = st_hi;
   if constexpr (DY16 && CIN == 2) {
     if (xwin) {
       // Round 3: the same k-steps, software-pipelined.  The generic loop
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
                 x + ((((int64_t)n * D0 + o0 + rw / 3) * S1 + o1 + rw % 3) * S2 + tt) * 2);
         }
       };
-      int64_t step = (int64_t)blockIdx.x * C2_WAVES + wave;
+      int64_t step = st_lo + (int64_t)xk * C2_WAVES + wave;
       if (step < n_steps) fetch(step);
       for (; step < n_steps; step += n_waves) {
         char* d = dst + wave * 2048 + r * 64 + ((hf ^ ((r >> 3) & 1)) << 5);
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
       goto reduce;
     }
   }
-  for (int64_t step = (int64_t)blockIdx.x * C2_WAVES + wave; step < n_steps; step += n_waves) {
+  for (int64_t step = st_lo + (int64_t)xk * C2_WAVES + wave; step < n_steps; step += n_waves) {
     int64_t row = step / chunks;
     const int t0 = (int)(step % chunks) * 32 + kg * 8;
     const int o1 = (int)(row % O1); row /= O1;
@@ -445,7 +454,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
   for (int b = 0; b < 18; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int item = tid; item < (16 - Cout) * TWN; item += 256) dsT[Cout * TWN + item] = 0;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // (XCD-contiguous tile shares: s3_xcd_share, common.h)
+  int64_t xt_lo, xt_hi;
+  int xt_k, xt_nk;
+  s3_xcd_share(n_tiles, xt_lo, xt_hi, xt_k, xt_nk);
+  for (int tile = (int)xt_lo + xt_k; tile < (int)xt_hi; tile += xt_nk) {
     int tr = tile;
     const int t2i = tr % tiles2; tr /= tiles2;
     const int t1i = tr % tiles1; tr /= tiles1;
