@@ -153,10 +153,10 @@ struct ConvGeom {
   // of being materialised; 0 / 1 = plain input
   int in_rep = 0;
   // ... and the same for the residual operand (d2s == 1): res[.., j, :] is
-  // cell j / res_rep of a tensor with O[2] / res_rep steps.  res_rep_magic =
-  // ceil(2^16 / res_rep): (j * magic) >> 16 == j / res_rep for every j < O[2]
-  // (checked where the plan sets it)
-  int res_rep = 0, res_rep_magic = 0;
+  // cell j / res_rep of a tensor with O[2] / res_rep steps.  A conv has ONE
+  // repeat factor (in_rep == res_rep when both are set), 2, 3 or 4: the
+  // kernel variants carry it as a compile-time constant
+  int res_rep = 0;
 };
 
 // generic gather op (pad / crop / repeat / roll / d2s / concat): out <- in
@@ -235,6 +235,7 @@ bool conv_mfma_bf16_out_ok(const ConvGeom& g);
 // persistent wave-specialised variant for the all-bf16 64 -> 64 trunk; its
 // filter image (LDS layout) is appended to the packed buffer of the conv
 bool conv_mfma_persist_geom_ok(const ConvGeom& g);
+bool conv_mfma_persist_rep_ok(int rep);
 bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
                                  bool has_res);
 size_t conv_mfma_persist_image_bytes(const ConvGeom& g);

@@ -179,7 +179,7 @@ __global__ void pack_jobs_kernel(const S3PackJob* __restrict__ jobs) {
 // a tile may straddle frames.  The halo tables carry a "zero row" flag (bit 30
 // of the element offset; a chunk is zeroed before it lands in LDS if any of
 // its three axes is flagged) instead of the reflect rule.
-template <int NFV, bool DG, bool REP = false>
+template <int NFV, bool DG, int REP = 0, bool RIN = false>
 __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg,
     const float* __restrict__ bias, const unsigned short* __restrict__ res,
@@ -278,12 +278,15 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       const int ax = lane < H0 ? 0 : (lane < H0 + H1 ? 1 : 2);                         \
       const int c = lane - (ax == 0 ? 0 : (ax == 1 ? H0 : H0 + H1));                   \
       const int org = ax == 0 ? o0_ : (ax == 1 ? o1_ : o2_);                           \
-      const int D = ax == 0 ? D0 : (ax == 1 ? D1 : D2);                                \
+      /* RIN (input through a fused temporal repeat): g.D[2] is the SOURCE extent */   \
+      constexpr bool rp = REP > 1 && RIN && !DG;                                       \
+      /* (per-lane VALU arithmetic with immediates on purpose: the producer waves */   \
+      /* are at the SGPR limit here — one more scalar is a spill into a VGPR, and */   \
+      /* at 168 VGPRs that spills eight more) */                                       \
+      const int is2 = rp ? (ax >> 1) : 0;                    /* 1 on the t axis */     \
+      const int D = (ax == 0 ? D0 : (ax == 1 ? D1 : D2)) * (1 + (REP > 1 ? REP - 1 : 0) * is2); \
       const int cs = (DG && g.in_cstride) ? g.in_cstride : 64;  /* channel slice of a wider dPre */ \
-      /* a fused temporal repeat: D2 is the repeated extent, the tensor holds D2 / rp */ \
-      const int rp = (REP && !DG && g.in_rep > 1) ? g.in_rep : 1;                             \
-      const int D2s = D2 / rp;                                                         \
-      const int stride = ax == 0 ? D1 * D2s * cs : (ax == 1 ? D2s * cs : cs);          \
+      const int stride = ax == 0 ? D1 * D2 * cs : (ax == 1 ? D2 * cs : cs);            \
       if (DG) {                                                                        \
         /* stacked frames on axes 0 / 1 (extent E = D + 2, gs frames), plain zero */  \
         /* boundary on axis 2; flagged rows load a legal address and are zeroed */    \
@@ -296,12 +299,24 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
         htab = zero ? 0x40000000 : qoff + (j - 1) * stride;                            \
         hx = x;                                                                        \
       } else {                                                                         \
-      int i = s3_reflect(org + c - g.lo[ax], D);                                       \
+      /* (repeat variants: one padding for all axes, checked by the plan — two scalars less) */ \
+      int i = s3_reflect(org + c - (REP > 1 ? g.lo[0] : g.lo[ax]), D);                 \
       /* ragged tiles: keep addresses legal (results are masked at the store) */      \
       i = i < 0 ? 0 : (i > D - 1 ? D - 1 : i);                                         \
-      if (ax == 2 && rp > 1) i /= rp;                                                  \
+      if (rp) {                                                                        \
+        if (REP == 2) i >>= is2;                                                       \
+        else if (REP == 4) i >>= 2 * is2;                                              \
+        else {   /* i / 3 = (i * 0x5556) >> 16 for i < 2^15, by shifts and adds with */ \
+                 /* inline constants; blended in by is2 instead of a lane mask */      \
+          const unsigned u = (unsigned)i;                                              \
+          unsigned t = u + (u << 2);                                                   \
+          t += t << 4;                                                                 \
+          t += t << 8;                                                                 \
+          i = (int)(u + (unsigned)is2 * (((t + u) >> 16) - u));                        \
+        }                                                                              \
+      }                                                                                \
       htab = i * stride;                                                               \
-      hx = x + (size_t)n_ * D0 * D1 * D2s * 64;                                        \
+      hx = x + (size_t)n_ * D0 * D1 * D2 * 64;                                         \
       }                                                                                \
       _Pragma("unroll") for (int j = 0; j < JR; ++j) {                                 \
         int cell = pcell + 32 * j;                                                     \
@@ -333,7 +348,16 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
           const unsigned row = (unsigned)__builtin_amdgcn_readlane(htab, r);
           if (((row + in_off[j]) >> 30) || cdead) w = (u32x4){0u, 0u, 0u, 0u};
         }
-        *reinterpret_cast<u32x4*>(smem + r * (ROWC * 128) + lds_off[j]) = w;
+        unsigned lo = lds_off[j];
+        if constexpr (REP > 1) {
+          // (the repeat variants recompute it: six registers less in the
+          // producer waves keeps them inside the 168-register budget without
+          // a spill — tests/test_abi.py::test_persistent_kernel_has_no_scratch)
+          int cell = pcell + 32 * j;
+          if (cell > ROWC - 1) cell = ROWC - 1;
+          lo = (unsigned)(cell * 128 + ((pch ^ ((cell % H2) & 7)) << 4));
+        }
+        *reinterpret_cast<u32x4*>(smem + r * (ROWC * 128) + lo) = w;
       }
     };
 
@@ -417,7 +441,9 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
   // this lane's two 8-channel chunks: block (bi, bj) and channel offset cc of
   // the depth-to-space store (b = 1: bi = bj = 0, cc = the channel itself)
-  const int db = g.d2s, cpo = g.Cout / (db * db);
+  // (the repeat variants are plain 64 -> 64 trunk convs: no depth-to-space
+  // store — two scalars less, which is what keeps them free of spills)
+  const int db = REP > 1 ? 1 : g.d2s, cpo = REP > 1 ? g.Cout : g.Cout / (db * db);
   unsigned c_off[2];
   bool c_ok[2];
 #pragma unroll
@@ -563,8 +589,8 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     if (res) {
       // a residual read through a fused temporal repeat (d2s == 1, cpo = 64):
       // cell o2 of the skip tensor is cell o2 / res_rep of what is stored
-      const bool rr = REP && !DG && g.res_rep > 1;
-      const int O2s = rr ? g.O[2] / g.res_rep : g.O[2];
+      const bool rr = REP > 1 && !DG && g.res_rep > 1;       // (then res_rep == REP)
+      const int O2s = rr ? g.O[2] / (REP > 1 ? REP : 1) : g.O[2];
       const size_t r_base = rr ? (size_t)n * g.O[0] * g.O[1] * O2s * g.Cout : e_base;
 #pragma unroll
       for (int m = 0; m < MFW; ++m) {
@@ -572,7 +598,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
         if (rr) {
           const int mf = mf0 + m;
           const int o0 = org0 + mf / TS1, o1 = org1 + mf % TS1, o2 = org2 + frow;
-          r_pos = (unsigned)(((o0 * g.O[1] + o1) * O2s + ((o2 * g.res_rep_magic) >> 16)) * cpo);
+          r_pos = (unsigned)(((o0 * g.O[1] + o1) * O2s + o2 / (REP > 1 ? REP : 1)) * cpo);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -699,6 +725,8 @@ int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* d
   return S3_OK;
 }
 
+bool conv_mfma_persist_rep_ok(int rep) { return rep == 2 || rep == 3 || rep == 4; }
+
 bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io,
                                  bool has_res) {
   // read per call: the parity tests flip it between two forwards
@@ -739,10 +767,13 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false, true>),
+#define S3_REP_ATTR(R)                                                                                          \
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false, R, true>),  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));                     \
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false, R, false>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    S3_REP_ATTR(2) S3_REP_ATTR(3) S3_REP_ATTR(4)
+#undef S3_REP_ATTR
     attr_set = true;
   }
   const int tiles0 = (g.O[0] + TS0 - 1) / TS0, tiles1 = (g.O[1] + TS1 - 1) / TS1,
@@ -751,17 +782,30 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
   int grid = ctx->num_cu;
   if (grid > n_tiles) grid = n_tiles;
   const int n_ct = (g.Cout + 63) / 64;
-  // (operands read through a fused temporal repeat: a variant of its own, the
-  // index arithmetic does not fit the 168-register budget of the plain one)
-  const bool rep = g.in_rep > 1 || g.res_rep > 1;
+  // (operands read through a fused temporal repeat: variants of their own with
+  // the factor a compile-time constant — the index arithmetic with a run-time
+  // factor does not fit the 168-register budget: 8 VGPRs spilled, and a spill
+  // next to the hand-ordered in-flight loads is not safe)
+  const int rep = g.in_rep > 1 ? g.in_rep : (g.res_rep > 1 ? g.res_rep : 0);
+  const bool rin = g.in_rep > 1;
+  ConvGeom gk = g;                 // what the kernel sees
+  if (rep) {
+    bool ok = conv_mfma_persist_rep_ok(rep) && g.Cout == 64 && g.d2s == 1 &&
+              !(g.in_rep > 1 && g.res_rep > 1 && g.in_rep != g.res_rep);
+    for (int d = 0; d < 3; ++d) ok = ok && g.lo[d] == g.lo[0] && g.O[d] == g.D[d];
+    if (!ok) S3_FAIL(ctx, S3_ESTATE, "persistent conv: unsupported fused temporal repeat");
+    if (rin) gk.D[2] = g.D[2] / rep;
+  }
   for (int ct = 0; ct < n_ct; ++ct) {
     // a last tile with <= 32 valid channels computes two N fragments only
     const bool half = g.Cout - ct * 64 <= 32;
-    auto kern = rep ? (half ? conv3_mfma_persist_kernel<2, false, true> : conv3_mfma_persist_kernel<4, false, true>)
-                    : (half ? conv3_mfma_persist_kernel<2, false> : conv3_mfma_persist_kernel<4, false>);
+    auto kern = half ? conv3_mfma_persist_kernel<2, false> : conv3_mfma_persist_kernel<4, false>;
+    if (rep == 2) kern = rin ? conv3_mfma_persist_kernel<4, false, 2, true> : conv3_mfma_persist_kernel<4, false, 2, false>;
+    else if (rep == 3) kern = rin ? conv3_mfma_persist_kernel<4, false, 3, true> : conv3_mfma_persist_kernel<4, false, 3, false>;
+    else if (rep == 4) kern = rin ? conv3_mfma_persist_kernel<4, false, 4, true> : conv3_mfma_persist_kernel<4, false, 4, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
                        (const unsigned short*)x, (const char*)image + (size_t)ct * 27 * 8192, bias,
-                       (const unsigned short*)res, (unsigned short*)y, g, tiles0,
+                       (const unsigned short*)res, (unsigned short*)y, gk, tiles0,
                        tiles1, tiles2, n_tiles, ct, 1, 1);
   }
   S3_HIP(ctx, hipGetLastError());

@@ -832,12 +832,14 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
   if (!training && precision == S3_PREC_BF16 && !s3_opt_has(S3O_NO_REPEAT_FUSE)) {
     for (int i = 0; i < n_ops; ++i) {
       OpRec& r = pl->ops[i];
-      if (r.d.kind != S3_OP_REPEAT_T || r.d.rep < 2 || r.d.rep > 8) continue;
+      if (r.d.kind != S3_OP_REPEAT_T || !conv_mfma_persist_rep_ok(r.d.rep)) continue;
       const int rt = root_of(pl, r.d.out);
       if (rt == root_of(pl, output) || pl->t[root_of(pl, r.d.in0)].dtype != pl->t[rt].dtype) continue;
-      // every consumer is a persistent-kernel conv taking it as the input or
-      // (no depth-to-space store) as the residual — SkipConnection sources sit
+      // every consumer is a plain 64 -> 64 trunk conv on the persistent kernel
+      // ('same' extents, one padding for all axes, no depth-to-space store)
+      // taking it as the input or as the residual — SkipConnection sources sit
       // right behind the last temporal expansion in the reference's generators
+      // — and carries no other repeat factor yet
       bool ok = true;
       int n_use = 0;
       for (int k = 0; k < n_ops && ok; ++k) {
@@ -848,20 +850,18 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         if (!as_in && !as_in1 && !as_res) continue;
         ++n_use;
         ok = k > i && !as_in1 && c.d.kind == S3_OP_CONV && c.mfma &&
-             conv_mfma_persist_supported(ctx, c.cg, c.io, c.d.res >= 0) && (!as_res || c.cg.d2s == 1) &&
-             c.cg.O[2] <= 8192;
+             conv_mfma_persist_supported(ctx, c.cg, c.io, c.d.res >= 0) && c.cg.d2s == 1 && c.cg.Cout == 64 &&
+             c.cg.O[2] < 32768 && c.cg.O[2] % r.d.rep == 0;
+        for (int q = 0; q < 3; ++q) ok = ok && c.cg.lo[q] == c.cg.lo[0] && c.cg.O[q] == c.cg.D[q];
+        const int have = c.cg.in_rep > 1 ? c.cg.in_rep : c.cg.res_rep;
+        if (have > 1 && have != r.d.rep) ok = false;
       }
       if (!ok || !n_use) continue;
-      const int magic = (65536 + r.d.rep - 1) / r.d.rep;
       for (int k = i + 1; k < n_ops; ++k) {
         OpRec& c = pl->ops[k];
         if (c.d.kind != S3_OP_CONV) continue;
         if (root_of(pl, c.d.in0) == rt) { c.cg.in_rep = r.d.rep; c.rep_src = r.d.in0; }
-        if (c.d.res >= 0 && root_of(pl, c.d.res) == rt) {
-          for (int q = 0; q < c.cg.O[2]; ++q)
-            if (((q * magic) >> 16) != q / r.d.rep) S3_FAIL(ctx, S3_ESTATE, "repeat fusion: division constant");
-          c.cg.res_rep = r.d.rep; c.cg.res_rep_magic = magic; c.res_src = r.d.in0;
-        }
+        if (c.d.res >= 0 && root_of(pl, c.d.res) == rt) { c.cg.res_rep = r.d.rep; c.res_src = r.d.in0; }
       }
       r.fused_away = true;
     }
