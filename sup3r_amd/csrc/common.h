@@ -282,7 +282,7 @@ bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
                                float* dw, float* partial, size_t partial_bytes, int accumulate,
-                               int x_bf16 = 0);
+                               int x_bf16 = 0, int x3 = 0);
 // stride-2 valid conv with C_in = 32 on an LDS halo (kernels_conv_halo_s2.hip)
 bool conv_halo_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision);
 size_t conv_halo_s2_packed_bytes(const ConvGeom& g);
@@ -319,7 +319,7 @@ int launch_conv_wgrad_bf16_2d(s3_ctx* ctx, const ConvGeom& g, const float* x, co
 bool conv_wgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_c2_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                         float* dw, float* partial, size_t partial_bytes, int accumulate, int dy_bf16 = 0);
+                         float* dw, float* partial, size_t partial_bytes, int accumulate, int dy_bf16 = 0, int x3 = 0);
 // LDS-halo wgrad of the hi-res tail conv (C_in = 8), kernels_conv_wgrad_fewch.hip
 bool conv_wgrad_tail_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_tail_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);

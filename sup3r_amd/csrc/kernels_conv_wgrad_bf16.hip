@@ -620,7 +620,10 @@ struct BfGen {
 // are fetched into registers before the k-steps of the current tile and dropped
 // into LDS after them (zero padding / ragged tiles: per-chunk zero masks), so
 // the staging traffic runs under the MFMAs.  Same operands, same order.
-template <int CIB, int STR, bool IN16, bool PF = false>
+// X3 (S3_PREC_BF16X3 plans; fp32 x and dPre, C_in walked in tiles of 32 so
+// that the hi AND lo images of both operands fit LDS): operands split in the
+// staging, hi*hi + hi*lo + lo*hi per fragment pair, as conv3_wgrad_x3_kernel.
+template <int CIB, int STR, bool IN16, bool PF = false, bool X3 = false>
 __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int tiles0, int tiles1,
@@ -629,8 +632,11 @@ __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
   constexpr int T1 = W::T1, T2 = W::T2, G1 = W::G1, G2 = W::G2, HP = W::HP, NP = W::NP;
   constexpr int CB = W::CB, NBW = W::NBW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(!X3 || (CIB == 2 && !IN16 && !PF), "the split-bf16 variant: fp32 operands, 32-channel tiles");
   char* xs = smem;
-  char* ds = smem + W::XS;
+  char* ds = smem + (X3 ? 2 : 1) * W::XS;
+  char* xl = smem + W::XS;                  // X3: residue images
+  char* dl = ds + NP * 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int q = lane & 15, kg = lane >> 4;
@@ -813,8 +819,13 @@ __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
       } else {
         float4 v = make_float4(0, 0, 0, 0);
         if (valid) v = *reinterpret_cast<const float4*>(x + e);
-        *reinterpret_cast<uint2*>(cell + (((ch >> 2) ^ W::key(u)) << 5) + ((ch & 3) << 3)) =
-            make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+        const uint2 hi = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+        char* at = cell + (((ch >> 2) ^ W::key(u)) << 5) + ((ch & 3) << 3);
+        *reinterpret_cast<uint2*>(at) = hi;
+        if constexpr (X3)
+          *reinterpret_cast<uint2*>(at + W::XS) = make_uint2(
+              pk2(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xFFFF0000u)),
+              pk2(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xFFFF0000u)));
       }
     }
     // ---- stage the dPre tile: NP positions x 8 float4
@@ -827,8 +838,13 @@ __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
       if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2] && co < Cout)
         v = *reinterpret_cast<const float4*>(
             dy + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * Cout + co);
-      *reinterpret_cast<uint2*>(ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3)) =
-          make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+      const uint2 hi = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+      char* at = ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3);
+      *reinterpret_cast<uint2*>(at) = hi;
+      if constexpr (X3)
+        *reinterpret_cast<uint2*>(at + NP * 64) = make_uint2(
+            pk2(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xFFFF0000u)),
+            pk2(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xFFFF0000u)));
     }
     __syncthreads();
     // ---- k-steps of 32 positions (2 rows x 16 t)
@@ -836,12 +852,17 @@ __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
     for (int ks = 0; ks < NP / 32; ++ks) {
       // rows 2 ks, 2 ks + 1 of the tile: r0 = (2 ks) / T1, r1 = (2 ks) % T1 + (kg >> 1)
       const int rowb = ((((2 * ks) / T1) * STR * G1) + ((2 * ks) % T1) * STR) * G2 * CB;
-      bf16x8 bfr[NBW];
+      bf16x8 bfr[NBW], bfl[X3 ? NBW : 1];
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) {
         const s16x4 lo = lds_tr(ds + b_off[nb][0] + ks * 32 * 64);
         const s16x4 hi = lds_tr(ds + b_off[nb][1] + ks * 32 * 64);
         bfr[nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (X3) {
+          const s16x4 l0 = lds_tr(dl + b_off[nb][0] + ks * 32 * 64);
+          const s16x4 l1 = lds_tr(dl + b_off[nb][1] + ks * 32 * 64);
+          bfl[nb] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
       }
 #pragma unroll
       for (int b = 0; b < 3; ++b)
@@ -850,9 +871,20 @@ __global__ __launch_bounds__(BNT) void conv_wgrad_bf16_gen_kernel(
           const s16x4 lo = lds_tr(xs + a_off[c][0] + rowb + b * G2 * CB);
           const s16x4 hi = lds_tr(xs + a_off[c][1] + rowb + b * G2 * CB);
           const bf16x8 afr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          bf16x8 afl = afr;
+          if constexpr (X3) {
+            const s16x4 l0 = lds_tr(xl + a_off[c][0] + rowb + b * G2 * CB);
+            const s16x4 l1 = lds_tr(xl + a_off[c][1] + rowb + b * G2 * CB);
+            afl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
 #pragma unroll
-          for (int nb = 0; nb < NBW; ++nb)
+          for (int nb = 0; nb < NBW; ++nb) {
+            if constexpr (X3) {   // small terms first
+              acc[b * 3 + c][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl, bfr[nb], acc[b * 3 + c][nb], 0, 0, 0);
+              acc[b * 3 + c][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfl[nb], acc[b * 3 + c][nb], 0, 0, 0);
+            }
             acc[b * 3 + c][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nb], acc[b * 3 + c][nb], 0, 0, 0);
+          }
         }
     }
   }
@@ -884,6 +916,36 @@ int bf_gen_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t0, int
   if (grid < 1) grid = 1;
   if (grid > *n_tiles) grid = *n_tiles;
   return grid;
+}
+
+// BF16X3 plans: 32-channel C_in tiles, hi + lo images (2 x the LDS of the bf16 form)
+template <int STR>
+int bf_gen_launch_x3(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy, float* dw,
+                     float* partial, size_t partial_bytes, int accumulate) {
+  using W = BfGen<2, STR>;
+  int n_tiles, t0, t1, t2;
+  const int grid = bf_gen_grid<2, STR>(ctx, g, &n_tiles, &t0, &t1, &t2);
+  const size_t need = (size_t)grid * 27 * g.Cin * g.Cout * sizeof(float);
+  if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_gen: partial buffer too small");
+  auto kern = conv_wgrad_bf16_gen_kernel<2, STR, false, false, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * W::LDS)));
+    attr_set = true;
+  }
+  const int n_ct = (g.Cout + BCT - 1) / BCT;
+  const int n_cit = (g.Cin + 31) / 32;
+  hipLaunchKernelGGL(kern, dim3(grid, n_ct, n_cit), dim3(BNT), 2 * W::LDS, ctx->stream, x, dy, partial,
+                     g, t0, t1, t2, n_tiles);
+  S3_HIP(ctx, hipGetLastError());
+  const int64_t wsize = (int64_t)27 * g.Cin * g.Cout;
+  int rg = (int)((wsize + 255) / 256);
+  if (rg > 4096) rg = 4096;
+  hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial, grid,
+                     wsize, dw, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
 }
 
 template <int CIB, int STR, bool IN16 = false>
@@ -1182,7 +1244,8 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
 
 // ---- general variant (discriminator convs)
 bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_BF16)) return false;
+  if (precision == S3_PREC_BF16X3 ? s3_opt_has(S3O_NO_WGRAD_X3) : precision != S3_PREC_BF16) return false;
+  if (s3_opt_has(S3O_NO_WGRAD_BF16)) return false;
   if (g.d2s != 1 || g.Cin % 32 != 0 || g.Cin < 32 || g.Cout % 4 != 0 || g.Cout < 16) return false;
   if (g.Cin > 64 && g.Cin % 64 != 0) return false;
   for (int d = 0; d < 3; ++d)
@@ -1196,8 +1259,13 @@ size_t conv_wgrad_bf16_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
 
 int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
                                float* dw, float* partial, size_t partial_bytes, int accumulate,
-                               int x_bf16) {
+                               int x_bf16, int x3) {
   const bool s2 = g.s[0] == 2;
+  if (x3) {
+    if (x_bf16) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_gen: the split-bf16 kernel takes fp32 operands");
+    return s2 ? bf_gen_launch_x3<2>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
+              : bf_gen_launch_x3<1>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
+  }
   if (x_bf16) {
     if (g.Cin == 32)
       return s2 ? bf_gen_launch<2, 2, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)

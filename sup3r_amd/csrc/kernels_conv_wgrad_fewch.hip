@@ -39,7 +39,10 @@ constexpr int C2_WAVES = 4;
 // exactly as in conv3_wgrad_bf16_kernel (same 32-B segment swizzle).  No
 // workgroup barrier: a wave's LDS operations complete in issue order.  (Per-
 // lane 4-B pair loads + unpacking were measured 1.6x SLOWER than the fp32 path.)
-template <int CIN, int NB, bool DY16 = false>
+// X3 (S3_PREC_BF16X3 plans, fp32 operands): both fragments are split into
+// bf16 pairs in registers (hi = bf16(v), lo = bf16(v - hi)), three MFMAs per
+// fragment pair — fp32-class gradients of the hi-res few-channel convs.
+template <int CIN, int NB, bool DY16 = false, bool X3 = false>
 __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int chunks, int64_t n_steps) {
@@ -196,7 +199,20 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
     const int shift = t0 - tl;                 // 0, or how many of the 8 slots repeat earlier t
     const float* dr = dy + ((((int64_t)n * O0 + o0) * O1 + o1) * O2 + tl) * Cout;
     const int xstep = CIN * g.s[2];
-    bf16x8 bfr[NB];
+    static_assert(!(X3 && DY16), "the split-bf16 variant takes fp32 dPre");
+    bf16x8 bfr[NB], bfl[X3 ? NB : 1];
+    // hi | lo split of 8 fp32 values (lo = the rounding residue)
+    auto split = [](const float* v, bf16x8& hi, bf16x8& lo) __attribute__((always_inline)) {
+      const uint4 h = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+      hi = __builtin_bit_cast(bf16x8, h);
+      if constexpr (X3) {
+        auto lf = [](unsigned u) { return __uint_as_float(u << 16); };
+        auto hf = [](unsigned u) { return __uint_as_float(u & 0xFFFF0000u); };
+        const uint4 l = make_uint4(pk2(v[0] - lf(h.x), v[1] - hf(h.x)), pk2(v[2] - lf(h.y), v[3] - hf(h.y)),
+                                   pk2(v[4] - lf(h.z), v[5] - hf(h.z)), pk2(v[6] - lf(h.w), v[7] - hf(h.w)));
+        lo = __builtin_bit_cast(bf16x8, l);
+      }
+    };
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       if constexpr (DY16) {
@@ -243,8 +259,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
         // slot e holds t = tl + e; it belongs to this k-step iff e >= shift
         v[e] = (e >= shift && tl + e < O2) ? t : 0.f;
       }
-      const uint4 u = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
-      bfr[nb] = __builtin_bit_cast(bf16x8, u);
+      split(v, bfr[nb], bfl[X3 ? nb : 0]);
     }
     if constexpr (DY16 && CIN == 2) {
       if (xwin) {
@@ -309,11 +324,16 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
           }
         }
       }
-      const uint4 u = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
-      const bf16x8 afr = __builtin_bit_cast(bf16x8, u);
+      bf16x8 afr, afl;
+      split(v, afr, afl);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb) {
+        if constexpr (X3) {   // small terms first
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl, bfr[nb], acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfl[nb], acc[mb][nb], 0, 0, 0);
+        }
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[nb], acc[mb][nb], 0, 0, 0);
+      }
     }
   }
 reduce:
@@ -369,7 +389,8 @@ int64_t c2_steps(const ConvGeom& g, int* chunks) {
 }  // namespace
 
 bool conv_wgrad_c2_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_C2)) return false;
+  if (precision == S3_PREC_BF16X3 ? s3_opt_has(S3O_NO_WGRAD_X3) : precision != S3_PREC_BF16) return false;
+  if (s3_opt_has(S3O_NO_WGRAD_C2)) return false;
   // 2 -> 16 / 32 / 64 (discriminator input layer) or 8 -> C_out <= 16 (hi-res tail)
   const bool a = g.Cin == 2 && (g.Cout == 16 || g.Cout == 32 || g.Cout == 64);
   const bool b = g.Cin == 8 && g.Cout <= 16;
@@ -388,7 +409,7 @@ size_t conv_wgrad_c2_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
 }
 
 int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                         float* dw, float* partial, size_t partial_bytes, int accumulate, int dy_bf16) {
+                         float* dw, float* partial, size_t partial_bytes, int accumulate, int dy_bf16, int x3) {
   int chunks;
   const int64_t n_steps = c2_steps(g, &chunks);
   const int grid = c2_grid(ctx, n_steps);
@@ -398,7 +419,16 @@ int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const f
 #define S3_C2(C, B)                                                                          \
   hipLaunchKernelGGL((conv_wgrad_c2_kernel<C, B>), dim3(grid), dim3(C2_WAVES * 64), 0, ctx->stream, \
                      x, dy, partial, g, chunks, n_steps)
-  if (dy_bf16) {
+#define S3_C2X(C, B)                                                                                        \
+  hipLaunchKernelGGL((conv_wgrad_c2_kernel<C, B, false, true>), dim3(grid), dim3(C2_WAVES * 64), 0, ctx->stream, \
+                     x, dy, partial, g, chunks, n_steps)
+  if (x3) {
+    if (dy_bf16) S3_FAIL(ctx, S3_EINVAL, "wgrad_c2: the split-bf16 kernel takes fp32 dPre");
+    if (g.Cin == 8) S3_C2X(8, 1);
+    else if (nb == 1) S3_C2X(2, 1);
+    else if (nb == 2) S3_C2X(2, 2);
+    else S3_C2X(2, 4);
+  } else if (dy_bf16) {
     if (g.Cin != 2 || g.Cout != 32) S3_FAIL(ctx, S3_EINVAL, "wgrad_c2: bf16 dPre needs C_in = 2, C_out = 32");
     hipLaunchKernelGGL((conv_wgrad_c2_kernel<2, 2, true>), dim3(grid), dim3(C2_WAVES * 64), 0, ctx->stream,
                        x, dy, partial, g, chunks, n_steps);
@@ -407,6 +437,7 @@ int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const f
   else if (nb == 2) S3_C2(2, 2);
   else S3_C2(2, 4);
 #undef S3_C2
+#undef S3_C2X
   S3_HIP(ctx, hipGetLastError());
   const int wsize = 27 * g.Cin * g.Cout;
   hipLaunchKernelGGL(wgrad_c2_partial_reduce, dim3((wsize + 63) / 64), dim3(256), 0, ctx->stream,

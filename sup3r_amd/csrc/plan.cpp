@@ -1647,11 +1647,13 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
             rc = launch_conv_wgrad_tail(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16);
           else if (o.wgrad_c2)
             rc = launch_conv_wgrad_c2(ctx, g, tptr(pl, d.in0), only16 ? (const float*)dpre16 : dpre, G + P->p[d.w].offset,
-                                      pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, only16 ? 1 : 0);
+                                      pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, only16 ? 1 : 0,
+                                      pl->precision == S3_PREC_BF16X3);
           else if (o.wgrad_bf16_2d)
             rc = launch_conv_wgrad_bf16_2d(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16_gen)
-            rc = launch_conv_wgrad_bf16_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16);
+            rc = launch_conv_wgrad_bf16_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16,
+                                            pl->precision == S3_PREC_BF16X3);
           else if (o.wgrad_gen)
             rc = launch_conv_wgrad_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else if (o.wgrad_bf16)

@@ -6,8 +6,12 @@
 OUT=${1:-gpurun_out/pmc_bench}; shift
 ROOTD=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOTD/$OUT"; cd /tmp; export TMPDIR=/tmp
-CMD="python $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train $@"
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOTD/$OUT/stats" -- $CMD > "$ROOTD/$OUT/stats.log" 2>&1
+# (no parity-mode / power / traffic legs: every dispatch is a forward of the timed workload on its random operands)
+CMD="python $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-parity-mode --no-traffic $@"
+# (the stats pass at the bench's own default step count: its per-kernel average is
+# what roofline.avg_launch_ms of the bench line has to agree with)
+STATCMD="python $ROOTD/bench.py --no-cpu-baseline --no-train --no-parity-mode --no-traffic $@"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOTD/$OUT/stats" -- $STATCMD > "$ROOTD/$OUT/stats.log" 2>&1
 i=0
 for grp in \
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
