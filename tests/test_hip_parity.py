@@ -228,11 +228,13 @@ def test_persistent_kernel_cout_tiles_and_depth_to_space():
     assert np.abs(y - y_tile).max() / scale < 1e-2
 
 
-def test_temporal_repeat_read_through_the_trunk_kernel():
-    """Inference plans: SpatioTemporalExpansion(temporal_mult=4, nearest)
+@pytest.mark.parametrize('rep2', [3, 4])
+def test_temporal_repeat_read_through_the_trunk_kernel(rep2):
+    """Inference plans: SpatioTemporalExpansion(temporal_mult=r, nearest),
+    r = 2 / 3 / 4 (the kernel variants carry r as a compile-time constant),
     followed by 64 -> 64 trunk convs (as input and as SkipConnection
     residual, the gen_5x_12x_2f arrangement) is not materialised — the persistent
-    kernel's halo index reads cell t of the repeated tensor from cell t // 4
+    kernel's halo index reads cell t of the repeated tensor from cell t // r
     of the source (sup3r.models ... SpatioTemporalExpansion, phygnn
     layers/custom_layers.py `_temporal_expand` nearest = tf.repeat on the
     time axis).  Bit-identical to the plan that writes the repeat out, and
@@ -243,7 +245,7 @@ def test_temporal_repeat_read_through_the_trunk_kernel():
     spec = pcc(3, 64) + pcc(3, 64) + \
         [{'class': 'SpatioTemporalExpansion', 'temporal_mult': 2,
           'temporal_method': 'nearest'}] + pcc(3, 64) + \
-        [{'class': 'SpatioTemporalExpansion', 'temporal_mult': 3,
+        [{'class': 'SpatioTemporalExpansion', 'temporal_mult': rep2,
           'temporal_method': 'nearest'},
          {'class': 'SkipConnection', 'name': 'a'},
          {'class': 'SkipConnection', 'name': 'b'}] + \
@@ -264,13 +266,13 @@ def test_temporal_repeat_read_through_the_trunk_kernel():
     brief = [(d['kind'], d['fwd'], d['in_rep'], d['res_rep']) for d in info]
     assert len(rep) == 2 and all(info[i]['in_rep'] == 1 for i in rep), brief
     convs = [d for d in info if d['kind'] == S.OP_CONV]
-    # the x2 repeat feeds one conv; the x3 repeat the first body conv and,
+    # the x2 repeat feeds one conv; the second repeat the first body conv and,
     # as the residual, the closing convs of SkipConnection 'b' and 'a'
-    assert [d['in_rep'] for d in convs] == [0, 0, 2, 3, 0, 0, 0, 0], convs
-    assert [d['res_rep'] for d in convs] == [0, 0, 0, 0, 3, 3, 0, 0], convs
+    assert [d['in_rep'] for d in convs] == [0, 0, 2, rep2, 0, 0, 0, 0], convs
+    assert [d['res_rep'] for d in convs] == [0, 0, 0, 0, rep2, rep2, 0, 0], convs
     assert all(d['fwd'] == 'mfma_persist' for d in convs[2:6]), convs
     y = net(x).cpu().numpy()
-    assert y.shape == (9, 18, 20, 78, 2)
+    assert y.shape == (9, 18, 20, 26 * rep2, 2)
     scale = max(1.0, np.abs(y_ref).max())
     assert np.abs(y - y_ref).max() / scale < 3e-2
     switch('NO_REPEAT_FUSE', 1)
