@@ -30,6 +30,7 @@ extern "C" {
 #define S3_ENOMEM (-3)
 #define S3_ERCCL (-4)
 #define S3_ESTATE (-5)   /* call sequence error (e.g. backward w/o forward) */
+#define S3_ETIMEOUT (-6) /* s3_comm_wait: the device work (collectives) did not finish in time */
 
 /* op kinds of the fused plan (sup3r_amd/spec.py lowers the reference's
  * hidden_layers JSON — sup3r/configs/<family>/<model>.json — to these) */
@@ -476,6 +477,16 @@ int s3_params_arm_allreduce(s3_params* p, int64_t bucket_bytes);
 int s3_params_broadcast(s3_params* p, int which, int root);
 int s3_broadcast(s3_ctx* ctx, float* buf, int64_t n, int root);
 void s3_comm_destroy(s3_ctx* ctx);
+/* Watchdog of the collectives: bounded host wait for everything enqueued on
+ * the context's streams so far (the data-parallel step reads its loss scalars
+ * back once per batch, abstract.py:843-914 — this is that wait, with a
+ * deadline).  While waiting it polls ncclCommGetAsyncError.  On a timeout or
+ * an asynchronous RCCL error the communicator is aborted (ncclCommAbort: a
+ * rank stuck in a collective whose peer died never returns otherwise), the
+ * context falls back to single-rank state and S3_ETIMEOUT / S3_ERCCL comes
+ * back with s3_last_error naming what was pending.  timeout_ms < 0: no
+ * deadline (plain s3_ctx_sync + the error poll). */
+int s3_comm_wait(s3_ctx* ctx, int64_t timeout_ms);
 
 /* library / build information */
 const char* s3_version(void);

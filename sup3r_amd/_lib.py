@@ -17,6 +17,7 @@ PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 LOSS_MAE, LOSS_MSE, LOSS_EXP = 0, 1, 2
 BUF_W, BUF_G, BUF_M, BUF_V = 0, 1, 2, 3
 OPT_ADAM = 0
+E_TIMEOUT = -6
 PRECISIONS = {'f32': PREC_F32, 'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
 
 EXPORTS = [
@@ -42,7 +43,7 @@ EXPORTS = [
     's3_comm_unique_id', 's3_comm_init', 's3_params_allreduce_grads',
     's3_params_arm_allreduce',
     's3_allreduce_sum', 's3_params_broadcast', 's3_broadcast',
-    's3_comm_destroy', 's3_version',
+    's3_comm_destroy', 's3_comm_wait', 's3_version',
 ]
 
 
@@ -180,6 +181,7 @@ def lib():
         's3_params_broadcast': (i32, [vp, i32, i32]),
         's3_broadcast': (i32, [vp, vp, i64, i32]),
         's3_comm_destroy': (None, [vp]),
+        's3_comm_wait': (i32, [vp, i64]),
         's3_version': (C.c_char_p, []),
     }
     for name in EXPORTS:
@@ -234,4 +236,6 @@ def check(rc, ctx=None, what=''):
     if ctx:
         raw = lib().s3_last_error(ctx)
         msg = raw.decode() if raw else ''
+    if rc == E_TIMEOUT:
+        raise TimeoutError(f'sup3r_amd: {msg or what}')
     raise RuntimeError(f'sup3r_amd HIP call failed ({what}, code {rc}): {msg}')

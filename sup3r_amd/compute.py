@@ -125,12 +125,18 @@ class LossFuture:
     returns the ``loss_details`` dict; until then the host keeps enqueuing the
     all-reduce, the Adam step and the next network's work."""
 
-    def __init__(self, scal, recipe, scale=1.0):
+    def __init__(self, scal, recipe, scale=1.0, dev=None):
         self._scal, self._recipe, self._scale = scal, recipe, float(scale)
         self._details = None
+        self._dev = dev
 
     def resolve(self):
         if self._details is None:
+            # with replicas the step behind these scalars went through RCCL: a
+            # peer that never arrives must not park this host in a blocking
+            # copy for ever (Device.wait: deadline + communicator abort)
+            if self._dev is not None and self._dev.nranks > 1:
+                self._dev.wait()
             vals = self._scal.cpu().numpy().astype(np.float64) * self._scale
             self._details = self._recipe(vals)
             self._scal = None
@@ -459,7 +465,7 @@ class HipGanCompute:
                         det[k] = LossValue(float(det[k]) + w_obs * l_obs)
             return det
         if defer:
-            return None, LossFuture(scal, recipe), hr_gen
+            return None, LossFuture(scal, recipe, dev=self.dev), hr_gen
         details = recipe(scal.cpu().numpy())   # one sync per mini-batch
         loss = details.get(loss_key) if loss_key else None
         return loss, details, hr_gen
@@ -693,3 +699,7 @@ class HipGanCompute:
             if net is not None and net.built:
                 for which in (_lib.BUF_W, _lib.BUF_M, _lib.BUF_V):
                     net.broadcast(which, root)
+        # the first collectives of the job: a rank that never joined shows up
+        # here, as a TimeoutError instead of a hang
+        if self.dev.nranks > 1:
+            self.dev.wait()

@@ -6,7 +6,9 @@
 // librccl.so is resolved lazily with dlopen so that libsup3r_hip.so loads (and
 // exports every symbol) on a box without RCCL / without a GPU.
 #include <dlfcn.h>
+#include <chrono>
 #include <cstring>
+#include <thread>
 
 #include "common.h"
 
@@ -22,6 +24,8 @@ typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStre
 typedef int (*fn_bcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*fn_errstr)(int);
 typedef int (*fn_destroy)(void*);
+typedef int (*fn_abort)(void*);
+typedef int (*fn_async_err)(void*, int*);
 
 struct Rccl {
   void* h = nullptr;
@@ -31,6 +35,8 @@ struct Rccl {
   fn_bcast bcast = nullptr;
   fn_errstr errstr = nullptr;
   fn_destroy destroy = nullptr;
+  fn_abort abort = nullptr;
+  fn_async_err async_err = nullptr;
   bool load(std::string& err) {
     if (h) return true;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -45,6 +51,8 @@ struct Rccl {
     bcast = (fn_bcast)dlsym(h, "ncclBroadcast");
     errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
     destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
+    abort = (fn_abort)dlsym(h, "ncclCommAbort");
+    async_err = (fn_async_err)dlsym(h, "ncclCommGetAsyncError");
     if (!get_uid || !init_rank || !allreduce) { err = "librccl.so lacks nccl symbols"; return false; }
     return true;
   }
@@ -88,6 +96,7 @@ extern "C" int s3_allreduce_sum(s3_ctx* ctx, float* buf, int64_t n) {
     ctx->err = std::string("ncclAllReduce: ") + (g_rccl.errstr ? g_rccl.errstr(rc) : "error");
     return S3_ERCCL;
   }
+  ++ctx->comm_issued;
   return S3_OK;
 }
 
@@ -119,6 +128,7 @@ extern "C" int s3_comm_reduce_range(s3_ctx* ctx, float* buf, int64_t n) {
     return S3_ERCCL;
   }
   ctx->stat[S3_STAT_BUCKET_ELEMS] += n;
+  ++ctx->comm_issued;
   return S3_OK;
 }
 
@@ -141,6 +151,65 @@ extern "C" int s3_broadcast(s3_ctx* ctx, float* buf, int64_t n, int root) {
     ctx->err = std::string("ncclBroadcast: ") + (g_rccl.errstr ? g_rccl.errstr(rc) : "error");
     return S3_ERCCL;
   }
+  ++ctx->comm_issued;
+  return S3_OK;
+}
+
+// ---- watchdog ----------------------------------------------------------------
+// A collective whose peer never arrives does not return an error: the kernel
+// spins on the device and every later host sync blocks for ever.  The training
+// host reads its loss scalars back once per batch; s3_comm_wait is that wait
+// with a deadline and an exit.
+static void comm_abort(s3_ctx* ctx) {
+  if (!ctx->comm) return;
+  if (g_rccl.abort) (void)g_rccl.abort(ctx->comm);   // frees the communicator, kills its kernels
+  ctx->comm = nullptr;
+  ctx->rank = 0;
+  ctx->nranks = 1;
+}
+
+extern "C" int s3_comm_wait(s3_ctx* ctx, int64_t timeout_ms) {
+  if (!ctx) return S3_EINVAL;
+  for (int i = 0; i < 2; ++i)
+    if (!ctx->wd_ev[i]) S3_HIP(ctx, hipEventCreateWithFlags(&ctx->wd_ev[i], hipEventDisableTiming));
+  S3_HIP(ctx, hipEventRecord(ctx->wd_ev[0], ctx->stream));
+  const bool two = ctx->comm_stream != nullptr;
+  if (two) S3_HIP(ctx, hipEventRecord(ctx->wd_ev[1], ctx->comm_stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  int spins = 0;
+  for (;;) {
+    hipError_t e0 = hipEventQuery(ctx->wd_ev[0]);
+    hipError_t e1 = two ? hipEventQuery(ctx->wd_ev[1]) : hipSuccess;
+    if (e0 == hipSuccess && e1 == hipSuccess) break;
+    for (hipError_t e : {e0, e1})
+      if (e != hipSuccess && e != hipErrorNotReady) {
+        ctx->err = std::string("s3_comm_wait: ") + hipGetErrorString(e);
+        return S3_EHIP;
+      }
+    if (ctx->comm && g_rccl.async_err) {
+      int aerr = 0;
+      if (g_rccl.async_err(ctx->comm, &aerr) == 0 && aerr != 0) {
+        ctx->err = std::string("s3_comm_wait: asynchronous RCCL error: ") +
+                   (g_rccl.errstr ? g_rccl.errstr(aerr) : "error") + "; communicator aborted";
+        comm_abort(ctx);
+        return S3_ERCCL;
+      }
+    }
+    const int64_t ms = std::chrono::duration_cast<std::chrono::milliseconds>(
+                           std::chrono::steady_clock::now() - t0).count();
+    if (timeout_ms >= 0 && ms >= timeout_ms) {
+      ctx->err = "s3_comm_wait: device work not finished after " + std::to_string(ms) + " ms (" +
+                 std::to_string(ctx->comm_issued) + " collective(s) enqueued since the last completed wait, rank " +
+                 std::to_string(ctx->rank) + " of " + std::to_string(ctx->nranks) + ")" +
+                 (ctx->comm ? "; communicator aborted" : "");
+      comm_abort(ctx);
+      return S3_ETIMEOUT;
+    }
+    // a short busy phase for the common case (the step is about done), then back off
+    if (++spins < 200) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000 ? 50 : 1000));
+  }
+  ctx->comm_issued = 0;
   return S3_OK;
 }
 

@@ -114,6 +114,8 @@ struct s3_ctx {
   S3Options opt;                     // defaults of the plans created from this context
   hipStream_t comm_stream = nullptr; // bucketed gradient all-reduce under the backward pass
   hipEvent_t comm_ev[2] = {nullptr, nullptr};   // [0] compute -> comm, [1] comm -> compute
+  hipEvent_t wd_ev[2] = {nullptr, nullptr};     // s3_comm_wait: tail of the compute / comm stream
+  int64_t comm_issued = 0;           // collectives enqueued since the last completed s3_comm_wait
 };
 
 #define S3_HIP(ctx, call)                                                    \

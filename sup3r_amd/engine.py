@@ -59,6 +59,23 @@ class Device:
     def sync(self):
         _lib.check(_lib.lib().s3_ctx_sync(self.ctx), self.ctx, 'sync')
 
+    # seconds the host waits for a step whose gradients cross RCCL before it
+    # gives the communicator up (``wait``; ``None`` = no deadline)
+    comm_timeout_s = 600.0
+
+    def wait(self, timeout_s=None):
+        """Bounded host wait for everything enqueued so far — the watchdog
+        of the collectives (``s3_comm_wait``): raises ``TimeoutError`` after
+        ``timeout_s`` (default ``comm_timeout_s``) with the communicator
+        aborted, ``RuntimeError`` on an asynchronous RCCL error."""
+        if timeout_s is None:
+            timeout_s = self.comm_timeout_s
+        ms = -1 if timeout_s is None else int(round(float(timeout_s) * 1e3))
+        rc = _lib.lib().s3_comm_wait(self.ctx, ms)
+        if rc != 0:
+            self.rank, self.nranks = 0, 1      # (the C side fell back too)
+        _lib.check(rc, self.ctx, 's3_comm_wait')
+
     def option_names(self):
         if Device._option_names is None:
             Device._option_names = _lib.option_names()

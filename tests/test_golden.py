@@ -159,6 +159,51 @@ def test_rccl_single_rank_allreduce():
 
 
 @pytest.mark.gpu
+def test_collective_watchdog_deadline_and_abort():
+    """``Device.wait`` (``s3_comm_wait``): the bounded host wait behind the
+    loss read-back of a data-parallel step.  Nothing pending -> returns; a
+    deadline shorter than the queued work -> ``TimeoutError`` naming what was
+    pending, the communicator aborted (``ncclCommAbort``) and the context back
+    in single-rank state, the device still usable afterwards."""
+    import ctypes as C
+    from sup3r_amd import _lib
+    from sup3r_amd.engine import Device, Network
+    L = _lib.lib()
+    dev = Device.get()
+    dev.sync()
+    dev.wait(timeout_s=30)                       # idle: immediate
+    uid = (C.c_char * 128)()
+    assert L.s3_comm_unique_id(uid) == 0
+    dev.init_comm(0, 1, uid)
+    net = Network([{'class': 'Conv3D', 'filters': 64, 'kernel_size': 3,
+                    'padding': 'same'}] * 6, precision='f32')
+    shape = (8, 24, 24, 48, 64)
+    net.build(shape, seed=0)
+    ph = net.plan(shape, training=False)
+    x = dev.to_device(np.zeros(shape, np.float32))
+    ph.forward(x)
+    net.set_weights([np.ones_like(w) for w in net.weights], which=_lib.BUF_G)
+    net.allreduce_grads()
+    dev.wait(timeout_s=120)                      # completes: counters reset
+    # a queue of exact-fp32 forwards (tens of ms) + a collective behind it,
+    # and a 0 ms deadline
+    for _ in range(6):
+        ph.forward(x)
+    net.allreduce_grads()
+    with pytest.raises(TimeoutError) as ei:
+        dev.wait(timeout_s=0.0)
+    msg = str(ei.value)
+    assert 'not finished' in msg and '1 collective' in msg and \
+        'communicator aborted' in msg, msg
+    assert dev.nranks == 1
+    dev.sync()                                   # the queued work still drains
+    net.allreduce_grads()                        # single rank again: identity
+    dev.wait(timeout_s=60)
+    for g in net.grads:
+        assert np.all(g == 1.0)
+
+
+@pytest.mark.gpu
 def test_bucketed_allreduce_under_the_backward_pass_single_rank():
     """``s3_params_arm_allreduce``: the backward pass hands the finished tail
     of the gradient buffer to RCCL bucket by bucket on the comm stream.  With
