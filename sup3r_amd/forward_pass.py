@@ -240,9 +240,17 @@ class ForwardPass:
     def _reshape_data_chunk(model, data_chunk, exo_data):
         """forward_pass.py:274-337."""
         if exo_data is not None:
+            # every exo entry takes the layout of the model STEP that consumes
+            # it (a multi-step model may run a spatial step, time on the batch
+            # axis, in front of a spatio-temporal one)
+            steps_of = getattr(model, 'models', [model])
             for feature in exo_data:
                 for i, entry in enumerate(exo_data[feature]['steps']):
-                    if model.is_4d:
+                    k = entry.get('model', 0)
+                    assert k < len(steps_of), (
+                        f'model index ({k}) for exo step {i} of "{feature}" '
+                        'exceeds the number of model steps')
+                    if steps_of[k].is_4d:
                         out = np.transpose(entry['data'], axes=(2, 0, 1, 3))
                     else:
                         out = np.expand_dims(entry['data'], axis=0)

@@ -276,3 +276,35 @@ def test_failed_chunk_raises_memory_error():
     st = ArrayStrategy(domain, {'model_dir': 'flat'}, (8, 8, 10), 1, 1,
                        model_class='Flat', model=m, allowed_const=[0])
     assert ForwardPass.run(st, 0) == 1
+
+
+def test_reshape_data_chunk_lays_exo_out_per_model_step():
+    """forward_pass.py:303-337: an exo entry takes the layout of the model
+    step that consumes it — (t, s1, s2, f) for a spatial step, a leading
+    batch axis for a spatio-temporal one — not that of the first step"""
+    from sup3r_amd.forward_pass import ForwardPass
+
+    class Step:
+        def __init__(self, is_4d):
+            self.is_4d = is_4d
+
+    class Chain:
+        models = [Step(True), Step(False)]
+        is_4d = True                     # the first step is spatial
+
+    x = np.arange(5 * 6 * 4 * 2, dtype=np.float32).reshape(5, 6, 4, 2)
+    e0 = np.arange(5 * 6 * 4, dtype=np.float32).reshape(5, 6, 4, 1)
+    e1 = np.arange(10 * 12, dtype=np.float32).reshape(10, 12, 1)
+    exo = {'topography': {'steps': [
+        {'model': 0, 'combine_type': 'input', 'data': e0},
+        {'model': 1, 'combine_type': 'layer', 'data': e1}]}}
+    d, out, i_t, i_s = ForwardPass._reshape_data_chunk(Chain(), x, exo)
+    assert d.shape == (4, 5, 6, 2) and (i_t, i_s) == (0, 1)
+    np.testing.assert_array_equal(d, np.transpose(x, (2, 0, 1, 3)))
+    s0, s1 = out['topography']['steps']
+    np.testing.assert_array_equal(s0['data'], np.transpose(e0, (2, 0, 1, 3)))
+    assert s1['data'].shape == (1, 10, 12, 1)
+    bad = {'topography': {'steps': [{'model': 2, 'combine_type': 'layer',
+                                     'data': e1}]}}
+    with pytest.raises(AssertionError):
+        ForwardPass._reshape_data_chunk(Chain(), x, bad)

@@ -224,6 +224,70 @@ def test_strategy_chunks_with_exo_on_the_device(tmp_path):
                                 hs[1].stop - hs[1].start)
 
 
+def test_multi_step_model_with_per_step_exo_through_run_chunk():
+    """The production arrangement of the reference's forward-pass configs:
+    ``model_class: MultiStepGan`` = a spatial (4-D) step followed by a
+    spatio-temporal one, hi-res topography entering the SECOND step
+    (``exo_data[feature]['steps'][k]['model'] == 1``, exo.py:108-130).  The
+    chunk goes through ``ForwardPass.run_chunk`` (forward_pass.py:582-673 —
+    ``_reshape_data_chunk`` :303-337 moves time to the batch axis for the
+    spatial step) and must equal the manual chain on the same padded input."""
+    from sup3r_amd import MultiStepGan, Sup3rGan
+    from sup3r_amd.forward_pass import (ForwardPass, ForwardPassChunk,
+                                        register_model)
+    from sup3r_amd.strategy import ArrayStrategy
+    feats = ['u_10m', 'v_10m']
+    Sup3rGan.seed(11)
+    m_s = Sup3rGan(os.path.join(CFG, 'test_gen_s_2x_2f.json'),
+                   os.path.join(CFG, 'test_disc_s_same.json'),
+                   means={f: np.float32(0.1) for f in feats},
+                   stdevs={f: np.float32(2.0) for f in feats})
+    m_s.set_model_params(lr_features=feats, hr_out_features=feats,
+                         s_enhance=2, t_enhance=1)
+    m_s.init_weights((4, 6, 6, 2), (4, 12, 12, 2))
+    m_st = _topo_model()
+    ms = MultiStepGan([m_s, m_st])
+    assert ms.s_enhance == 6 and ms.t_enhance == 4
+    register_model('MultiStepGan', {'model_dirs': ['s', 'st-topo']}, ms)
+    rng = np.random.default_rng(21)
+    domain = (rng.standard_normal((10, 9, 8, 2)) * 2 + 0.3).astype(np.float32)
+    # topography at the resolution the second step's Sup3rConcat sees:
+    # lo-res x 2 (step 0) x 3 (step 1)
+    topo = (300 + 150 * rng.standard_normal((60, 54, 1))).astype(np.float32)
+    exo = {'topography': {'steps': [
+        {'model': 1, 'combine_type': 'layer', 'data': topo, 's_enhance': 6,
+         't_enhance': 4}]}}
+    st = ArrayStrategy(domain, {'model_dirs': ['s', 'st-topo']}, (5, 5, 4),
+                       spatial_pad=1, temporal_pad=1, exo_data=exo,
+                       model_class='MultiStepGan', model=ms)
+    fwp = ForwardPass(st, 0)
+    sl = st.fwp_slicer
+    assert sl.n_chunks == 8
+    for i in (0, 3, 7):
+        c = fwp.get_input_chunk(i)
+        assert isinstance(c, ForwardPassChunk)
+        failed, data = ForwardPass.run_chunk(
+            c, st.model_kwargs, 'MultiStepGan', False)
+        assert not failed
+        want = tuple((s_.stop - s_.start) for s_ in sl.chunks[i]['hr_slice'])
+        assert data.shape == want + (2,), (data.shape, want)
+        # the manual chain on the same padded lo-res window (a fresh chunk:
+        # run_chunk re-lays the exo entries of the one it was given in place,
+        # as the reference does)
+        c = fwp.get_input_chunk(i)
+        x = c.input_data                                   # (s1, s2, t, f)
+        y1 = m_s.generate(np.transpose(x, (2, 0, 1, 3)))   # time as batch
+        y1 = np.transpose(y1, (1, 2, 0, 3))[None]
+        t = c.exo_data['topography']['steps'][0]['data'][None]
+        y2 = m_st.generate(y1, exogenous_data={'topography': {'steps': [
+            {'model': 0, 'combine_type': 'layer', 'data': t}]}})
+        np.testing.assert_array_equal(
+            data, y2[0][tuple(c.hr_crop_slice)])
+    # the node runner takes the same route for every chunk
+    done, kept = ForwardPass.run(st, 0, return_data=True)
+    assert done == 8 and len(kept) == 8
+
+
 def test_residency_is_explicit():
     """``run_batched`` never serves a stale upload: a second array of the same
     shape (CPython may even give it the same ``id``), or the same array
