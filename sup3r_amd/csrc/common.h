@@ -61,6 +61,7 @@
   X(NO_REPEAT_FUSE) \
   X(NO_WGRAD_X3) \
   X(NO_GCONV_X3) \
+  X(NO_SIGN_BYTES) \
   X(NO_PLAIN_FOLD16) \
   X(NO_SEG_REDUCE) \
   X(NO_TAIL_BAND) \
@@ -275,7 +276,9 @@ bool conv_gconv_dgrad_supported(const ConvGeom& g, int precision);
 size_t conv_gconv_packed_bytes(const ConvGeom& g, int dgrad, int x3 = 0);
 int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* packed, int dgrad, int x3 = 0);
 int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
-                     const float* bias, const float* res, void* y, int out_bf16, int in_bf16 = 0, int x3 = 0);
+                     const float* bias, const float* res, void* y, int out_bf16, int in_bf16 = 0, int x3 = 0,
+                     void* sign_bytes = nullptr);
+bool conv_gconv_writes_sign_bytes(const s3_ctx* ctx, const ConvGeom& g, int out_bf16);
 int launch_gconv_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* packed_t,
                        float* dx, int accumulate, int frame, int dy_bf16 = 0, int x3 = 0);
 
@@ -304,7 +307,7 @@ size_t conv_dgrad_s2_packed_bytes(const ConvGeom& g);
 int launch_conv_dgrad_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
 int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx,
                          const void* mask_y, float mask_slope, int mask_bf16 = 0, int out_bf16 = 0,
-                         float* bsum = nullptr);
+                         float* bsum = nullptr, const void* mask_bits = nullptr);
 bool conv_dgrad_s2_out16_ok(const ConvGeom& g);
 int conv_dgrad_s2_blocks(const ConvGeom& g);
 // dgrad of the few-channel hi-res conv with an LDS halo (kernels_conv_dgrad_fewch.hip)

@@ -57,11 +57,19 @@ __global__ void dgrad_s2_pack_kernel(const float* __restrict__ w, unsigned short
 // across the k-groups.  A lane owns the same 8 channels throughout, so their
 // sums — the bias gradient of that conv — accumulate in registers and leave as
 // one partial row per workgroup (bsum[block][32], for bias_grad_stage2).
-template <int NF, bool O16 = false>
+// MB (with O16): the activation mask comes as sign BYTES — bit q of byte
+// [position][kg] = "channel 8 kg + q of y is > 0", written by the forward
+// kernel next to y (gconv_fewch_halo_kernel) — instead of the bf16 tensor y
+// itself: 4 B per position instead of 64.  The 64-B rows of y at the 128-B
+// pitch of a parity class were fetched 1.7 times each (the other half of a
+// line is wanted one class later: FETCH 1.51 GB for 0.89 GB of mask,
+// profiles/r03/README.md).
+template <int NF, bool O16 = false, bool MB = false>
 __global__ __launch_bounds__(SNT) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_dgrad_s2_kernel(
     const float* __restrict__ dy, const unsigned short* __restrict__ img,
     float* __restrict__ dx, ConvGeom g, int rows_pad, int tiles0, int tiles1, int tiles2,
     const void* __restrict__ mask_y, float mask_slope, int mask_bf16, float* __restrict__ bsum) {
+  static_assert(!MB || O16, "sign bytes: the bf16-only output path");
   extern __shared__ __attribute__((aligned(16))) char halo[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kg = lane >> 4;
@@ -124,28 +132,36 @@ __global__ __launch_bounds__(SNT) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // class do not depend on its MFMAs but sat behind them — waves were parked
   // in s_waitcnt 79 % of the time (profiles/r03/pmc_train_start.txt).  They
   // are issued one class AHEAD now, under the tap loop of the class before.
-  const bool mpre = O16 && mask_y && mask_bf16;
-  uint4 mk[8], mk_next[8];
+  const bool mpre = O16 && !MB && mask_y && mask_bf16;
+  uint4 mk[MB ? 1 : 8], mk_next[MB ? 1 : 8];
+  unsigned mb[MB ? 8 : 1], mb_next[MB ? 8 : 1];        // MB: one sign byte per (position, kg)
   auto mask_fetch = [&](int cls_, uint4* dst8) __attribute__((always_inline)) {
     const int q0 = cls_ >> 2, q1 = (cls_ >> 1) & 1, q2 = cls_ & 1;
     const int i0 = 2 * (u0 + wave) + q0, i2 = 2 * (u2 + j) + q2;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int i1 = 2 * (u1 + m) + q1;
-      dst8[m] = make_uint4(0u, 0u, 0u, 0u);
-      if (i0 < g.D[0] && i1 < g.D[1] && i2 < g.D[2])
-        dst8[m] = *reinterpret_cast<const uint4*>(
-            reinterpret_cast<const unsigned short*>(mask_y) +
-            ((((size_t)n * g.D[0] + i0) * g.D[1] + i1) * g.D[2] + i2) * 32 + kg * 8);
+      if (i0 < g.D[0] && i1 < g.D[1] && i2 < g.D[2]) {
+        const size_t pos = (((size_t)n * g.D[0] + i0) * g.D[1] + i1) * g.D[2] + i2;
+        if constexpr (MB)
+          reinterpret_cast<unsigned*>(dst8)[m] = reinterpret_cast<const unsigned char*>(mask_y)[pos * 4 + kg];
+        else
+          dst8[m] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(mask_y) + pos * 32 + kg * 8);
+      } else {
+        if constexpr (MB) reinterpret_cast<unsigned*>(dst8)[m] = 0u;
+        else dst8[m] = make_uint4(0u, 0u, 0u, 0u);
+      }
     }
   };
   if (mpre) mask_fetch(0, mk);
+  if (MB) mask_fetch(0, reinterpret_cast<uint4*>(mb));
   // wave w owns the u rows (r0 = w, r1 = 0..7)
 #pragma unroll 1
   for (int cls = 0; cls < 8; ++cls) {
     const int p0 = cls >> 2, p1 = (cls >> 1) & 1, p2 = cls & 1;
     const int n0 = p0 ? 1 : 2, n1 = p1 ? 1 : 2, n2 = p2 ? 1 : 2;   // taps per axis
     if (mpre && cls < 7) mask_fetch(cls + 1, mk_next);
+    if (MB && cls < 7) mask_fetch(cls + 1, reinterpret_cast<uint4*>(mb_next));
     f32x4 acc[8][NF];
 #pragma unroll
     for (int m = 0; m < 8; ++m)
@@ -174,6 +190,11 @@ __global__ __launch_bounds__(SNT) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // ---- store the class: x position i = 2 u + p
     const int i0 = 2 * (u0 + wave) + p0, i2 = 2 * (u2 + j) + p2;
     if constexpr (O16) {
+      // (no FMA contraction here: the masked value is stored AND summed — with
+      // v * mask folded into the channel sum's add in one template variant and
+      // not in the other, the bias gradient differed in its last bits between
+      // the mask sources)
+#pragma clang fp contract(off)
       unsigned short* dx16 = reinterpret_cast<unsigned short*>(dx);
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
@@ -183,7 +204,10 @@ __global__ __launch_bounds__(SNT) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         float v[8];
 #pragma unroll
         for (int q8 = 0; q8 < 8; ++q8) v[q8] = acc[m][q8 >> 2][q8 & 3];
-        if (mask_y) {
+        if constexpr (MB) {
+#pragma unroll
+          for (int q8 = 0; q8 < 8; ++q8) v[q8] *= ((mb[m] >> q8) & 1u) ? 1.f : mask_slope;
+        } else if (mask_y) {
           float yv[8];
           if (mask_bf16) {
             const uint4 h = mpre ? mk[m] : *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(mask_y) + e);
@@ -208,6 +232,10 @@ __global__ __launch_bounds__(SNT) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       if (mpre) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) mk[m] = mk_next[m];
+      }
+      if constexpr (MB) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mb[m] = mb_next[m];
       }
       continue;
     }
@@ -295,7 +323,8 @@ int conv_dgrad_s2_blocks(const ConvGeom& g) {
 }
 
 int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx,
-                         const void* mask_y, float mask_slope, int mask_bf16, int out_bf16, float* bsum) {
+                         const void* mask_y, float mask_slope, int mask_bf16, int out_bf16, float* bsum,
+                         const void* mask_bits) {
   const int U0 = (g.D[0] + 1) / 2, U1 = (g.D[1] + 1) / 2, U2 = (g.D[2] + 1) / 2;
   const int tiles0 = (U0 + ST0 - 1) / ST0, tiles1 = (U1 + ST1 - 1) / ST1, tiles2 = (U2 + ST2 - 1) / ST2;
   const int n_ct = (g.Cin + 63) / 64;
@@ -303,6 +332,11 @@ int launch_conv_dgrad_s2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const 
   const int rp = s2_rows_pad(g.Cin);
   if (out_bf16) {
     if (!conv_dgrad_s2_out16_ok(g)) S3_FAIL(ctx, S3_EINVAL, "dgrad_s2: bf16 output needs C_in = 32");
+    if (mask_bits)
+      hipLaunchKernelGGL((conv_dgrad_s2_kernel<2, true, true>), grid, dim3(SNT), SLDS, ctx->stream, dy,
+                         (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_bits, mask_slope, 1,
+                         bsum);
+    else
     hipLaunchKernelGGL((conv_dgrad_s2_kernel<2, true>), grid, dim3(SNT), SLDS, ctx->stream, dy,
                        (const unsigned short*)img, dx, g, rp, tiles0, tiles1, tiles2, mask_y, mask_slope, mask_bf16,
                        bsum);

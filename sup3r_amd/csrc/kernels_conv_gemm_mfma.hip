@@ -580,7 +580,7 @@ template <int CIN, int MODE, int NFP = 4>
 __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, void* __restrict__ yv, ConvGeom g, int tiles0, int tiles1,
-    int tiles2, int out_bf16) {
+    int tiles2, int out_bf16, unsigned char* __restrict__ sign) {
   constexpr int TPL = 8 / CIN;                 // taps per lane per chunk
   constexpr int KC = (27 * CIN + 31) / 32;     // chunks of 32
   constexpr int KP = KC * 32;
@@ -738,8 +738,20 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
             const float a = acc[(2 * h + (q >> 2)) % NFP][q & 3];
             o[q] = fmaxf(a, slope * a);              // slope in [0, 1]: identity / ReLU / LeakyReLU
           }
-          *reinterpret_cast<uint4*>(yrow + off + h * 32) =
-              make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7]));
+          const uint4 w4 = make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7]));
+          *reinterpret_cast<uint4*>(yrow + off + h * 32) = w4;
+          if (sign) {
+            // (C_out = 32, one cout tile) bit q of byte [position][kq]: channel
+            // 8 kq + q of the STORED bf16 value is > 0 — the activation mask
+            // conv_dgrad_s2_kernel<.., MB> applies, at 4 B per position
+            auto two = [](unsigned u) {
+              const unsigned lo = u & 0xFFFFu, hi = u >> 16;
+              return ((lo & 0x8000u) == 0 && (lo & 0x7FFFu) != 0 ? 1u : 0u) |
+                     ((hi & 0x8000u) == 0 && (hi & 0x7FFFu) != 0 ? 2u : 0u);
+            };
+            const unsigned bits = two(w4.x) | (two(w4.y) << 2) | (two(w4.z) << 4) | (two(w4.w) << 6);
+            sign[(row_el + off) / 8] = (unsigned char)bits;    // element (pos * 32 + 8 kq) / 8 = pos * 4 + kq
+          }
         }
       }
       // next tile row: every halo address moves one row of cells
@@ -860,6 +872,13 @@ bool fewch_geom(const ConvGeom& g) {
 
 }  // namespace
 
+// launch_gconv_fwd writes sign bytes (4 B per position: bit q of byte
+// [position][kq] = channel 8 kq + q of the stored output is > 0) for this
+// geometry when it is handed a buffer: the permuted lean walk, C_out = 32
+bool conv_gconv_writes_sign_bytes(const s3_ctx* ctx, const ConvGeom& g, int out_bf16) {
+  return fewch_geom(g) && g.Cout == 32 && fewch_halo_ok(ctx, g, nullptr, out_bf16) && fewch_halo_perm(g, out_bf16);
+}
+
 bool conv_gconv_supported(const ConvGeom& g, int precision) {
   if (precision == S3_PREC_BF16X3 ? s3_opt_has(S3O_NO_GCONV_X3) : precision != S3_PREC_BF16) return false;
   if (s3_opt_has(S3O_NO_GCONV)) return false;
@@ -940,7 +959,8 @@ int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* pack
 }
 
 int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void* packed,
-                     const float* bias, const float* res, void* y, int out_bf16, int in_bf16, int x3) {
+                     const float* bias, const float* res, void* y, int out_bf16, int in_bf16, int x3,
+                     void* sign_bytes) {
   if (out_bf16 && g.Cout % 4 != 0) S3_FAIL(ctx, S3_EINVAL, "gconv: bf16 output needs C_out % 4 == 0");
   if (in_bf16 && (g.Cin % 8 != 0 || fewch_geom(g))) S3_FAIL(ctx, S3_EINVAL, "gconv: bf16 input needs C_in % 8 == 0");
   if (x3 && (out_bf16 || in_bf16)) S3_FAIL(ctx, S3_EINVAL, "gconv: the split-bf16 variant takes and writes fp32");
@@ -973,7 +993,9 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
       if (!pm && nf32 == 1) kern = g.Cin == 2 ? gconv_fewch_halo_kernel<2, 2, 1> : gconv_fewch_halo_kernel<4, 2, 1>;
       else if (!pm && nf32 == 2) kern = g.Cin == 2 ? gconv_fewch_halo_kernel<2, 2, 2> : gconv_fewch_halo_kernel<4, 2, 2>;
       else if (!pm && nf32 >= 3) kern = g.Cin == 2 ? gconv_fewch_halo_kernel<2, 2, 4> : gconv_fewch_halo_kernel<4, 2, 4>;
-      hipLaunchKernelGGL(kern, hgrid, dim3(FHW * 64), 0, ctx->stream, x, img, bias, y, g, t0, t1, t2, out_bf16);
+      // sign bytes next to y: the permuted lean walk with C_out = 32 only
+      unsigned char* sb = (pm && two && g.Cout == 32) ? (unsigned char*)sign_bytes : nullptr;
+      hipLaunchKernelGGL(kern, hgrid, dim3(FHW * 64), 0, ctx->stream, x, img, bias, y, g, t0, t1, t2, out_bf16, sb);
       S3_HIP(ctx, hipGetLastError());
       return S3_OK;
     }

@@ -69,6 +69,7 @@ struct OpRec {
   ConvGeom dg;                 // geometry of the dgrad-as-conv launch
   int rep_src = -1;            // conv: tensor read through a fused temporal repeat (cg.in_rep)
   int res_src = -1;            // ... and the residual (cg.res_rep)
+  void* sign_bytes = nullptr;  // training: activation sign bytes next to the output (conv_dgrad_s2's mask)
   bool fused_away = false;     // repeat op absorbed by its consumer conv: no launch
   float* dg_w32 = nullptr;     // flipped / transposed fp32 filter
   void* dg_wbf = nullptr;      // its bf16 slabs (bf16 mode)
@@ -995,6 +996,16 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
     if (o.dgrad_s2) {
       int rc = plan_alloc(pl, &o.dc2_w, conv_dgrad_s2_packed_bytes(o.cg));
       if (rc) { s3_plan_destroy(pl); return rc; }
+      // its fused activation mask as sign bytes written by the producer's
+      // forward kernel (4 B instead of 64 B per position read back)
+      if (o.mask_prod >= 0 && precision == S3_PREC_BF16 && !s3_opt_has(S3O_NO_SIGN_BYTES)) {
+        OpRec& po = pl->ops[o.mask_prod];
+        if (po.gconv && !po.sign_bytes && conv_gconv_writes_sign_bytes(ctx, po.cg, po.io.out_bf16)) {
+          const size_t npos = (size_t)po.cg.N * po.cg.O[0] * po.cg.O[1] * po.cg.O[2];
+          rc = plan_alloc(pl, &po.sign_bytes, npos * 4);
+          if (rc) { s3_plan_destroy(pl); return rc; }
+        }
+      }
     }
     if (o.dgrad_c2) {
       int rc = plan_alloc(pl, &o.dc2_w, conv_dgrad_c2_packed_bytes());
@@ -1192,7 +1203,7 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
           o.gc_version = P->version;
         }
         return launch_gconv_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.gc_w, b, res, tptr(pl, d.out), o.io.out_bf16, o.io.in_bf16,
-                                pl->precision == S3_PREC_BF16X3);
+                                pl->precision == S3_PREC_BF16X3, o.sign_bytes);
       }
       if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16)
         return launch_conv_fewpos_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out), pl->fp_partial, pl->fp_partial_bytes);
@@ -1852,7 +1863,8 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
                               !s3_opt_has(S3O_NO_DPRE16);
             rc = launch_conv_dgrad_s2(ctx, g, dpre, o.dc2_w, to16 ? (float*)pl->dpre16 : dst,
                                       fuse ? tptr(pl, d.in0) : nullptr, pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f,
-                                      o.io.in_bf16, to16 ? 1 : 0, (to16 && sums) ? pl->bsum : nullptr);
+                                      o.io.in_bf16, to16 ? 1 : 0, (to16 && sums) ? pl->bsum : nullptr,
+                                      (to16 && fuse && o.io.in_bf16) ? po.sign_bytes : nullptr);
             if (!rc && fuse) pl->premasked[rin] = 1;
             if (!rc && to16) {
               pl->dpre16_for = rin; pl->dpre16_only = true;

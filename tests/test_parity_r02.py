@@ -788,6 +788,43 @@ def test_stride2_lds_halo_conv_matches_the_gather_kernel(monkeypatch):
     _fwd_bwd_vs_oracle(spec, shape, 'bf16', 13, 3e-2, 2e-2)
 
 
+def test_activation_sign_bytes_for_the_stride2_data_gradient_change_nothing():
+    """Round 3: the first discriminator layer's forward (gconv_fewch_halo)
+    writes sign bytes next to its bf16 output — bit q of byte [position][kq] =
+    channel 8 kq + q > 0 — and the stride-2 data gradient behind it reads
+    those 4 B per position as its fused LeakyReLU mask instead of the 64-B row
+    of y at a 128-B pitch (FETCH 1.77 -> GB).  Same mask, so dx and every
+    weight gradient are bit-identical with the bytes switched off; the
+    production shape class (hi-res disc_st, bf16-only dPre) is the one run."""
+    spec = _load('disc_st.json')
+    shape = (4, 64, 64, 112, 2)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+
+    def run():
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=0)
+        ph = net.plan(shape, training=True)
+        assert 's2' in _kernels(ph, 'dgrad'), _kernels(ph, 'dgrad')
+        y = ph.forward(net.dev.to_device(x))
+        dy = net.dev.to_device(
+            np.random.default_rng(9).standard_normal(tuple(y.shape)).astype(np.float32))
+        dx = ph.backward(dy, need_dx=True).cpu().numpy()
+        g = [a.copy() for a in net.grads]
+        del ph
+        net.clear_plans()
+        return dx, g
+    dx1, g1 = run()
+    switch('NO_SIGN_BYTES', 1)
+    dx0, g0 = run()
+    switch('NO_SIGN_BYTES', None)
+    assert np.abs(dx1).max() > 0
+    np.testing.assert_array_equal(dx1, dx0)
+    for a, b in zip(g1, g0):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_bf16_side_copy_of_dpre_changes_nothing(monkeypatch):
     """The halo-tile data gradient rounds dPre to bf16 while staging it; in
     bf16 training plans the fold / mask pass that produces dPre leaves a bf16
