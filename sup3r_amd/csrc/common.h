@@ -62,6 +62,7 @@
   X(NO_WGRAD_X3) \
   X(NO_GCONV_X3) \
   X(NO_SIGN_BYTES) \
+  X(NO_HALO_S2_K64) \
   X(NO_PLAIN_FOLD16) \
   X(NO_SEG_REDUCE) \
   X(NO_TAIL_BAND) \

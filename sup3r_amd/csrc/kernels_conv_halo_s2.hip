@@ -203,25 +203,195 @@ __global__ __launch_bounds__(SNT) void conv_halo_s2_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// C_in = C_out = 64 (the discriminator's 64 -> 64 stride-2 layer: 35 GFLOP at
+// C2 batch 8, 263 us on the gather kernel with every input cell fetched 2.3
+// times).  A 64-channel halo of a useful tile and the 221 KB filter do not fit
+// LDS together, so the contraction is split over the two 32-channel halves of
+// the input: pass 0 leaves raw fp32 sums, pass 1 adds them and finishes (bias,
+// activation, bf16 / fp32 store).  Per pass a persistent 8-wave workgroup keeps
+// its half filter (27 x 64 rows x 64 B = 110,592 B) and the de-interleaved
+// halo of a 2 x 2 x 16 output tile (5 x 5 x 33 cells x 64 B = 52,800 B) in LDS
+// — 163,392 of 163,840 B — and prefetches the next halo into registers under
+// the taps; waves 0-3 / 4-7 take the output channels 0-31 / 32-63 of the four
+// (s0, s1) rows.
+constexpr int KT0 = 2, KT1 = 2, KT2 = 16;
+constexpr int KH0 = 2 * KT0 + 1, KH1 = 2 * KT1 + 1, KH2 = 2 * KT2 + 1;   // 5 x 5 x 33
+constexpr int KHP = KH0 * KH1 * KH2;                       // 825 halo cells
+constexpr int KNW = 8, KNT = KNW * 64;
+constexpr int K_HALO = KHP * 64;                           // 52,800 B
+constexpr int K_FILT = 27 * 64 * 64;                       // 110,592 B
+constexpr int K_LDS = K_HALO + K_FILT;                     // 163,392 B
+constexpr int KNCH = (KHP * 4 + KNT - 1) / KNT;            // 7 chunks per lane
+
+// fp32 w[tap][64][cout 64] -> bf16 img[pass 2][tap][64 rows (cout)][32 ci of that half]
+__global__ void halo_s2_k64_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ img) {
+  const int total = 2 * 27 * 64 * 32;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int k = idx & 31, row = (idx >> 5) & 63;
+    const int tp = (idx >> 11) % 27, ps = idx / (27 * 2048);
+    img[idx] = (unsigned short)(pk2(w[((size_t)tp * 64 + ps * 32 + k) * 64 + row], 0.f) & 0xFFFFu);
+  }
+}
+
+// ps = 0: part[pos][64] = raw sums over input channels 0..31;  ps = 1: y =
+// act(part + sums over channels 32..63 + bias)
+__global__ __launch_bounds__(KNT) void conv_halo_s2_k64_kernel(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ img,
+    const float* __restrict__ bias, float* __restrict__ part, void* __restrict__ yv, ConvGeom g,
+    int tiles0, int tiles1, int tiles2, int n_tiles, int out16, int ps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* filt = smem + K_HALO;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  const int row = wave & 3, nh = wave >> 2;                // (s0, s1) row of the tile, cout half
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+  const int rank = s3_xcd_tile(blockIdx.x, gridDim.x);
+  const int t_first = (int)((int64_t)rank * n_tiles / gridDim.x);
+  const int t_end = (int)((int64_t)(rank + 1) * n_tiles / gridDim.x);
+  if (t_first >= t_end) return;
+
+  for (int i = tid; i < K_FILT / 16; i += KNT)
+    reinterpret_cast<uint4*>(filt)[i] = reinterpret_cast<const uint4*>(img + (size_t)ps * 27 * 2048)[i];
+
+  int c_pack[KNCH];              // c0 | c1 << 8 | c2 << 16 | ch << 24, -1 past the end
+  unsigned l_off[KNCH];
+#pragma unroll
+  for (int u = 0; u < KNCH; ++u) {
+    const int item = tid + u * KNT;
+    c_pack[u] = -1; l_off[u] = 0;
+    if (item < KHP * 4) {
+      const int hp = item >> 2, ch = item & 3;
+      int h = hp;
+      const int c2 = h % KH2; h /= KH2;
+      const int c1 = h % KH1; h /= KH1;
+      const int c0 = h;
+      const int e = row_slot(c2);
+      c_pack[u] = c0 | (c1 << 8) | (c2 << 16) | (ch << 24);
+      l_off[u] = (unsigned)((((c0 * KH1 + c1) * KH2) + e) * 64 + ((ch ^ slot_key(e)) << 4));
+    }
+  }
+  auto tile_org = [&](int tile, int& n, int& o0, int& o1, int& o2) {
+    int tr = tile;
+    o2 = (tr % tiles2) * KT2; tr /= tiles2;
+    o1 = (tr % tiles1) * KT1; tr /= tiles1;
+    o0 = (tr % tiles0) * KT0; tr /= tiles0;
+    n = tr;
+  };
+  uint4 pre[KNCH];
+  auto halo_fetch = [&](int tile) {
+    int n, o0, o1, o2;
+    tile_org(tile, n, o0, o1, o2);
+    const unsigned short* xb = x + (size_t)n * D0 * D1 * D2 * 64 + ps * 32;
+#pragma unroll
+    for (int u = 0; u < KNCH; ++u) {
+      pre[u] = make_uint4(0u, 0u, 0u, 0u);
+      const int cp = c_pack[u];
+      const int i0 = 2 * o0 + (cp & 255), i1 = 2 * o1 + ((cp >> 8) & 255), i2 = 2 * o2 + ((cp >> 16) & 255);
+      // (cells past the tensor feed only the masked overhang of ragged tiles)
+      if (cp >= 0 && i0 < D0 && i1 < D1 && i2 < D2)
+        pre[u] = *reinterpret_cast<const uint4*>(xb + (((size_t)i0 * D1 + i1) * D2 + i2) * 64 + (cp >> 24) * 8);
+    }
+  };
+  auto halo_put = [&]() {
+#pragma unroll
+    for (int u = 0; u < KNCH; ++u)
+      if (c_pack[u] >= 0) *reinterpret_cast<uint4*>(halo + l_off[u]) = pre[u];
+  };
+  halo_fetch(t_first);
+  halo_put();
+  __syncthreads();
+
+  int off_c[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int e = (c == 1 ? NEVEN : (c >> 1)) + j;
+    off_c[c] = e * 64 + ((kg ^ slot_key(e)) << 4);
+  }
+  const int rowb = ((2 * (row / KT1)) * KH1 + 2 * (row % KT1)) * KH2 * 64;
+  const char* fa = filt + (nh * 32 + j) * 64 + kg * 16;
+  const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+
+  for (int tile = t_first; tile < t_end; ++tile) {
+    const bool has_next = tile + 1 < t_end;
+    if (has_next) halo_fetch(tile + 1);
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = acc[0];
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) {
+      const int a = tp / 9, b = (tp / 3) % 3, c = tp % 3;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(fa + (tp * 64) * 64);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(fa + (tp * 64 + 16) * 64);
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(halo + rowb + (a * KH1 + b) * KH2 * 64 + off_c[c]);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr, acc[1], 0, 0, 0);
+    }
+    // ---- C/D: col = t, row = 4 kg + r (channel 32 nh + 16 nf + 4 kg + r)
+    int n, o0b, o1b, o2b;
+    tile_org(tile, n, o0b, o1b, o2b);
+    const int o0 = o0b + row / KT1, o1 = o1b + row % KT1, o2 = o2b + j;
+    if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2]) {
+      const size_t oi = ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * 64;
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        const int ch = nh * 32 + nf * 16 + kg * 4;
+        float4 v = make_float4(acc[nf][0], acc[nf][1], acc[nf][2], acc[nf][3]);
+        if (ps == 0) {
+          *reinterpret_cast<float4*>(part + oi + ch) = v;
+          continue;
+        }
+        const float4 pv = *reinterpret_cast<const float4*>(part + oi + ch);
+        float o[4] = {v.x + pv.x, v.y + pv.y, v.z + pv.z, v.w + pv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] += bias ? bias[ch + r] : 0.f;
+          o[r] = o[r] > 0.f ? o[r] : slope * o[r];
+        }
+        if (out16)
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(yv) + oi + ch) =
+              make_uint2(pk2(o[0], o[1]), pk2(o[2], o[3]));
+        else
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + oi + ch) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    __syncthreads();          // every wave is past its last halo read
+    if (has_next) halo_put();
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+static bool halo_s2_k64_geom(const ConvGeom& g) { return g.Cin == 64 && g.Cout == 64; }
 
 bool conv_halo_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_HALO_S2)) return false;
-  if (g.Cin != 32 || g.Cout % 4 != 0 || g.Cout < 16 || g.Cout > 32 || g.d2s != 1) return false;
+  const bool k64 = halo_s2_k64_geom(g) && !s3_opt_has(S3O_NO_HALO_S2_K64);
+  if (!k64 && (g.Cin != 32 || g.Cout % 4 != 0 || g.Cout < 16 || g.Cout > 32)) return false;
+  if (g.d2s != 1) return false;
   if (g.pad_mode == S3_PAD_REFLECT) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 2 || g.lo[d] != 0 || (g.O[d] - 1) * 2 + 3 > g.D[d]) return false;
-  if ((int64_t)g.D[0] * g.D[1] * g.D[2] * 32 >= ((int64_t)1 << 31)) return false;
+  if ((int64_t)g.D[0] * g.D[1] * g.D[2] * g.Cin >= ((int64_t)1 << 31)) return false;
   const int64_t min_tiles = s3_opt_has(S3O_HALO_S2_MIN_TILES) ? s3_opt_int(S3O_HALO_S2_MIN_TILES, 0)
                                                                   : 4 * (int64_t)ctx->num_cu;
+  const int t0 = k64 ? KT0 : ST0, t1 = k64 ? KT1 : ST1;
   return g.O[2] >= 8 &&
-         (int64_t)g.N * ((g.O[0] + ST0 - 1) / ST0) * ((g.O[1] + ST1 - 1) / ST1) *
+         (int64_t)g.N * ((g.O[0] + t0 - 1) / t0) * ((g.O[1] + t1 - 1) / t1) *
                  ((g.O[2] + ST2 - 1) / ST2) >= min_tiles;
 }
 
-size_t conv_halo_s2_packed_bytes(const ConvGeom&) { return (size_t)S_FILT; }
+size_t conv_halo_s2_packed_bytes(const ConvGeom& g) { return halo_s2_k64_geom(g) ? (size_t)2 * K_FILT : (size_t)S_FILT; }
 
 int launch_conv_halo_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img) {
+  if (halo_s2_k64_geom(g)) {
+    hipLaunchKernelGGL(halo_s2_k64_pack_kernel, dim3(216), dim3(256), 0, ctx->stream, w, (unsigned short*)img);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   hipLaunchKernelGGL(halo_s2_pack_kernel, dim3(108), dim3(256), 0, ctx->stream, w, (unsigned short*)img, g.Cout);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
@@ -230,6 +400,27 @@ int launch_conv_halo_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, voi
 int launch_conv_halo_s2_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* img,
                             const float* bias, void* y, int out_bf16) {
   static bool attr_set = false;
+  if (halo_s2_k64_geom(g)) {
+    static bool k_attr = false;
+    if (!k_attr) {
+      S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_s2_k64_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, K_LDS));
+      k_attr = true;
+    }
+    const int t0 = (g.O[0] + KT0 - 1) / KT0, t1 = (g.O[1] + KT1 - 1) / KT1, t2 = (g.O[2] + KT2 - 1) / KT2;
+    const int n_tiles = g.N * t0 * t1 * t2;
+    int grid = ctx->num_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    const size_t pbytes = (size_t)g.N * g.O[0] * g.O[1] * g.O[2] * 64 * sizeof(float);
+    int rc = ensure_scratch(ctx, pbytes);
+    if (rc) return rc;
+    for (int ps = 0; ps < 2; ++ps)
+      hipLaunchKernelGGL(conv_halo_s2_k64_kernel, dim3(grid), dim3(KNT), K_LDS, ctx->stream,
+                         (const unsigned short*)x, (const unsigned short*)img, bias, (float*)ctx->scratch, y, g,
+                         t0, t1, t2, n_tiles, out_bf16, ps);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_s2_kernel<2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS));

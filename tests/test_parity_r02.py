@@ -788,6 +788,53 @@ def test_stride2_lds_halo_conv_matches_the_gather_kernel(monkeypatch):
     _fwd_bwd_vs_oracle(spec, shape, 'bf16', 13, 3e-2, 2e-2)
 
 
+def test_stride2_64_channel_conv_on_the_split_lds_halo_kernel():
+    """conv_halo_s2_k64_kernel (round 3): the discriminator's 64 -> 64
+    stride-2 valid conv with the contraction split over the two 32-channel
+    halves of the input (half filter + de-interleaved halo of a 2 x 2 x 16
+    tile resident in LDS, raw fp32 sums of pass 0 added by pass 1).  Against
+    the gather kernel on the same bf16 cells — same products, another fp32
+    summation order: the bf16 outputs differ on a handful of elements by one
+    spacing — and against the oracle per op; ragged tiles in every axis."""
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(64, 1) + conv(64, 2) + conv(64, 1) + \
+        [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (2, 19, 22, 47, 2)
+    switch('HALO_S2_MIN_TILES', 1)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+    net = Network(spec, precision='bf16')
+    net.build(shape, seed=0)
+    ph = net.plan(shape, training=True)
+    k = _kernels(ph)
+    assert k[2] == 'halo_s2', k
+    y1 = ph.forward(net.dev.to_device(x)).cpu().numpy()
+    t1 = ph.tensor(ph.plan.ops[2]['out'])
+    switch('NO_HALO_S2_K64', 1)
+    net2 = Network(spec, precision='bf16')
+    net2.build(shape, seed=0)
+    ph2 = net2.plan(shape, training=True)
+    assert _kernels(ph2)[2] != 'halo_s2'
+    y2 = ph2.forward(net2.dev.to_device(x)).cpu().numpy()
+    t2 = ph2.tensor(ph2.plan.ops[2]['out'])
+    switch('NO_HALO_S2_K64', None)
+    # the conv's own output: equal up to one bf16 spacing on a few elements
+    diff = np.abs(t1 - t2)
+    frac = float((diff > 0).mean())
+    print(f'64 -> 64 s2: {frac:.2e} of the outputs differ from the gather '
+          f'kernel, worst {float((diff / np.maximum(np.abs(t2), 1e-6)).max()):.2e}')
+    assert frac < 2e-2
+    assert float((diff / np.maximum(np.abs(t2), 1e-3)).max()) < 1.0 / 64
+    assert rel_linf(y1, y2) < 2e-2
+    del ph, ph2
+    net.clear_plans(); net2.clear_plans()
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 14, 3e-2, 2e-2)
+
+
 def test_activation_sign_bytes_for_the_stride2_data_gradient_change_nothing():
     """Round 3: the first discriminator layer's forward (gconv_fewch_halo)
     writes sign bytes next to its bf16 output — bit q of byte [position][kq] =
