@@ -138,13 +138,24 @@ __global__ __launch_bounds__(HNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) acc[m][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const unsigned short* wrow = img + ((size_t)ct * 64 + j) * 32 + kg * 8;
+  // the next tap's filter fragments (L2-resident image, 110 KB: it does not fit
+  // L1) are fetched under this tap's 32 MFMAs — loading them at the top of
+  // their own tap left the waves in front of an L2 round trip 27 times per tile
+  bf16x8 anext[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+    anext[nf] = *reinterpret_cast<const bf16x8*>(wrow + ((size_t)nf * 16) * 32);
 #pragma unroll 1
   for (int tp = 0; tp < 27; ++tp) {
     const int a = tp / 9, b = (tp / 3) % 3, c = tp % 3;
     bf16x8 afr[NF];
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
-      afr[nf] = *reinterpret_cast<const bf16x8*>(wrow + ((size_t)tp * rows_pad + nf * 16) * 32);
+    for (int nf = 0; nf < NF; ++nf) afr[nf] = anext[nf];
+    if (tp + 1 < 27) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+        anext[nf] = *reinterpret_cast<const bf16x8*>(wrow + ((size_t)(tp + 1) * rows_pad + nf * 16) * 32);
+    }
     const char* hb = halo + (((wave + a) * HH1 + b) * HH2) * 64 + off_c[c];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {

@@ -18,8 +18,8 @@ GB = 1e9
 ALG = {
     'gconv_fewch_halo_kernel<2, 1, 2>': ('disc 2->32 forward', P0 * 8, P1 * 64),
     'conv_halo_s2_kernel<2>': ('disc 32->32 s2 forward', P1 * 64, P2 * 64),
-    'conv_dgrad_s2_kernel<2, true>': ('disc 32->32 s2 data gradient (fp32 dPre + bf16 mask in, bf16 out)',
-                                      P2 * 128 + P1 * 64, P1 * 64),
+    'conv_dgrad_s2_kernel<2, true, true>': ('disc 32->32 s2 data gradient (fp32 dPre + sign bytes in, bf16 out)',
+                                            P2 * 128 + P1 * 4, P1 * 64),
     'conv_dgrad_c2_slide_kernel': ('disc 2->32 data gradient', P1 * 64, P0 * 8),
     'conv_wgrad_c2_kernel<2, 2, true, false>': ('disc 2->32 weight gradient', P1 * 64 + P0 * 8, 0),
     'conv_wgrad_bf16_gen_kernel<2, 2, true, true, false>': ('disc 32->32 s2 weight gradient', P1 * 64 + P2 * 128, 0),
