@@ -294,8 +294,9 @@ bool conv_dgrad_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision
   if (g.Cout != 32 || g.Cin % 16 != 0 || g.Cin < 16 || g.d2s != 1) return false;
   for (int d = 0; d < 3; ++d) {
     if (g.k[d] != 3 || g.s[d] != 2 || g.lo[d] != 0) return false;
-    // valid padding: every x position i < D has its sources inside or zero; u grid covers D
-    if ((g.O[d] - 1) * 2 + 3 > g.D[d]) return false;
+    // valid padding — or TF 'same' on an even extent (lo = 0, one zero cell past
+    // the end): every x position i < D has its sources inside or zero; u grid covers D
+    if ((g.O[d] - 1) * 2 + 3 > g.D[d] + 1) return false;
   }
   const int64_t min_tiles = s3_opt_has(S3O_DGRAD_S2_MIN_TILES) ? s3_opt_int(S3O_DGRAD_S2_MIN_TILES, 0)
                                                                    : ctx->num_cu;

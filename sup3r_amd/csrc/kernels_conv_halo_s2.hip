@@ -374,7 +374,9 @@ bool conv_halo_s2_supported(const s3_ctx* ctx, const ConvGeom& g, int precision)
   if (g.d2s != 1) return false;
   if (g.pad_mode == S3_PAD_REFLECT) return false;
   for (int d = 0; d < 3; ++d)
-    if (g.k[d] != 3 || g.s[d] != 2 || g.lo[d] != 0 || (g.O[d] - 1) * 2 + 3 > g.D[d]) return false;
+    // valid padding, or TF 'same' on an even extent (one zero cell past the end,
+    // none in front: the halo fetch zero-fills cells past the tensor anyway)
+    if (g.k[d] != 3 || g.s[d] != 2 || g.lo[d] != 0 || (g.O[d] - 1) * 2 + 3 > g.D[d] + 1) return false;
   if ((int64_t)g.D[0] * g.D[1] * g.D[2] * g.Cin >= ((int64_t)1 << 31)) return false;
   const int64_t min_tiles = s3_opt_has(S3O_HALO_S2_MIN_TILES) ? s3_opt_int(S3O_HALO_S2_MIN_TILES, 0)
                                                                   : 4 * (int64_t)ctx->num_cu;

@@ -835,6 +835,57 @@ def test_stride2_64_channel_conv_on_the_split_lds_halo_kernel():
     _fwd_bwd_vs_oracle(spec, shape, 'bf16', 14, 3e-2, 2e-2)
 
 
+def test_stride2_kernels_on_same_padded_convs():
+    """TF 'same' padding of a stride-2 conv on an EVEN extent is one zero cell
+    past the end and none in front — the LDS-halo stride-2 kernels
+    zero-fill what lies past the tensor anyway, so the reference's test
+    discriminators (`config_disc_st_test.json` layout, C4) run on them too:
+    32 -> 32 forward and data gradient bit-identical to the gather kernels, the
+    64 -> 64 forward within a bf16 spacing, everything against the oracle."""
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'same'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(32, 2) + conv(64, 1) + conv(64, 2) + \
+        [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    shape = (2, 24, 20, 44, 2)
+    switch('HALO_S2_MIN_TILES', 1)
+    switch('DGRAD_S2_MIN_TILES', 1)
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(shape).astype(np.float32)
+    from sup3r_amd.engine import Network
+
+    def run():
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=0)
+        ph = net.plan(shape, training=True)
+        kf, kd = _kernels(ph), _kernels(ph, 'dgrad')
+        y = ph.forward(net.dev.to_device(x))
+        t1 = ph.tensor(ph.plan.ops[1]['out'])
+        dy = net.dev.to_device(np.ones(tuple(y.shape), np.float32))
+        dx = ph.backward(dy, need_dx=True).cpu().numpy()
+        g = [a.copy() for a in net.grads]
+        y = y.cpu().numpy()
+        del ph
+        net.clear_plans()
+        return kf, kd, y, t1, dx, g
+    kf, kd, y1, t1, dx1, g1 = run()
+    assert kf[1] == 'halo_s2' and kf[3] == 'halo_s2', kf
+    assert kd[1] == 's2', kd
+    switch('NO_HALO_S2', 1)
+    switch('NO_DGRAD_S2', 1)
+    kf0, kd0, y0, t0, dx0, g0 = run()
+    switch('NO_HALO_S2', None)
+    switch('NO_DGRAD_S2', None)
+    assert 'halo_s2' not in kf0 and 's2' not in kd0
+    np.testing.assert_array_equal(t1, t0)            # 32 -> 32 s2 forward
+    assert rel_linf(y1, y0) < 2e-2                   # (64 -> 64: another fp32 order)
+    assert rel_max(dx1, dx0) < 2e-2
+    for a, b in zip(g1, g0):
+        assert rel_max(a, b) < 2e-2
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 15, 3e-2, 2e-2)
+
+
 def test_activation_sign_bytes_for_the_stride2_data_gradient_change_nothing():
     """Round 3: the first discriminator layer's forward (gconv_fewch_halo)
     writes sign bytes next to its bf16 output — bit q of byte [position][kq] =
