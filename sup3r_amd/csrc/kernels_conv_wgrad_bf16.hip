@@ -1250,7 +1250,10 @@ bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision) {
   if (g.Cin > 64 && g.Cin % 64 != 0) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != g.s[0] || (g.s[d] != 1 && g.s[d] != 2)) return false;
-  return g.O[2] >= 8 && (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 512;
+  // (t extents below the 16-wide run of a tile are masked through dPre: still
+  // several times the exact-fp32 MFMA kernel's rate — 256 -> 256 s2 at 3 x 3 x 6
+  // outputs, batch 32: 388 us there)
+  return g.O[2] >= 4 && (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 512;
 }
 
 size_t conv_wgrad_bf16_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {

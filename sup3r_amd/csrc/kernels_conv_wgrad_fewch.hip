@@ -64,8 +64,10 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
   float (*red)[MB * NB][64][4] = reinterpret_cast<float (*)[MB * NB][64][4]>(lds_all);
   char* dst = lds_all;
   float2* xw = reinterpret_cast<float2*>(lds_all + DST_BYTES);
+  // (zero padding in front — TF 'same' — is window cells outside the tensor: zeros)
   const bool xwin = DY16 && CIN == 2 && !(g.pad_mode == S3_PAD_REFLECT) && g.s[0] == 1 && g.s[1] == 1 &&
-                    g.s[2] == 1 && g.lo[0] == 0 && g.lo[1] == 0 && g.lo[2] == 0;
+                    g.s[2] == 1 && g.lo[0] >= 0 && g.lo[0] <= 1 && g.lo[1] >= 0 && g.lo[1] <= 1 &&
+                    g.lo[2] >= 0 && g.lo[2] <= 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kg = lane >> 4;
   const int S1 = g.D[1], S2 = g.D[2];
@@ -125,12 +127,12 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
         for (int k = 0; k < 5; ++k) {
           const int item = lane + 64 * k;
           const int rw = item / 34, cl = item - rw * 34;
-          int tt = tch + cl;
-          tt = tt > S2 - 1 ? S2 - 1 : tt;          // (past the row: feeds t >= O2 only, zero dPre)
+          // (cells outside the tensor: the zero padding, or past the row end
+          // where they feed t >= O2 only)
+          const int i0 = o0 + rw / 3 - g.lo[0], i1 = o1 + rw % 3 - g.lo[1], tt = tch + cl - g.lo[2];
           c5[k] = make_float2(0.f, 0.f);
-          if (item < XW_CELLS)
-            c5[k] = *reinterpret_cast<const float2*>(
-                x + ((((int64_t)n * D0 + o0 + rw / 3) * S1 + o1 + rw % 3) * S2 + tt) * 2);
+          if (item < XW_CELLS && i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < S1 && tt >= 0 && tt < S2)
+            c5[k] = *reinterpret_cast<const float2*>(x + ((((int64_t)n * D0 + i0) * S1 + i1) * S2 + tt) * 2);
         }
       };
       int64_t step = st_lo + (int64_t)xk * C2_WAVES + wave;

@@ -397,3 +397,26 @@ def test_condmom_bf16_step_on_the_3x_4x_body():
     print(f'CondMom bf16 on gen_3x_4x_2f: worst gradient error '
           f'{max(errs):.2e}')
     assert max(errs) < 1e-2, errs          # measured 1.6e-3
+
+
+# ------------------------------------- (f) the C4 discriminator as benched
+def test_c4_discriminator_at_the_benched_shape():
+    """``disc_st_same`` (the reference's test discriminator layout with TF
+    'same' padding) at the hi-res shape of ``bench.py --mode train --config
+    c4``, batch 8 of a replicated sample, bf16: per-op forward, gradients
+    under the device masks 2e-2, and the kernels the round-3 widening put
+    under it — the stride-2 LDS-halo forward / data gradient on 'same'
+    padded convs, transpose-read weight gradients down to 6-long t extents"""
+    from tests.test_parity_r02 import _fwd_bwd_vs_oracle
+    spec = _load('disc_st_same.json')
+    ph = _fwd_bwd_vs_oracle(spec, (8, 48, 48, 96, 2), 'bf16', 23, 3e-2, 2e-2,
+                            replicate=True)
+    fwd, wg, dg = (_conv_kernels(ph, f) for f in ('fwd', 'wgrad', 'dgrad'))
+    print('fwd', fwd, 'wgrad', wg, 'dgrad', dg)
+    # (the 64 -> 64 stride-2 layer has too few tiles for its LDS-halo kernel at
+    # batch 8; at the benched batch 32 it is on it too)
+    assert fwd.count('halo_s2') >= 1 and 'halo32' in fwd, fwd
+    assert 's2' in dg, dg
+    # (only the last layer — 432 output positions at batch 8 — stays on the
+    # exact-fp32 weight gradient)
+    assert wg.count('f32_gen') <= 1 and wg.count('bf16_gen') >= 5, wg
