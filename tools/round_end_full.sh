@@ -1,5 +1,5 @@
 #!/bin/bash
-OUT=gpurun_out/r03_final3
+OUT=gpurun_out/r03_final4
 mkdir -p $OUT
 python -m pytest tests -m gpu -q -x > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
