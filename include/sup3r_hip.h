@@ -383,6 +383,20 @@ int s3_copy_block(s3_ctx* ctx, const float* src, float* dst, int64_t d0, int64_t
  * NaN count) per slab of positions; the caller folds the 64 slabs. */
 int s3_chunk_stats(s3_ctx* ctx, const float* x, int n_chunks,
                    int64_t pos_per_chunk, int c, float* partial);
+/* everything between the generator's last layer and the delivery of a batch of
+ * chunks in one pass: un-normalisation (x * scale + shift per channel, the two
+ * roundings of un_norm_output, sup3r/models/abstract.py:240-275; NULL scale /
+ * shift: none), the halo crop hi_res[0][hr_crop_slices]
+ * (sup3r/pipeline/forward_pass.py:272) and the statistics of _output_check
+ * (:384-425; partial as s3_chunk_stats).  y = (n_chunks, dims[0..2], c) fp32,
+ * yc = (n_chunks, crop_n[0..2], c).  c must divide 1024 and rows must be
+ * 16-byte aligned ((crop_lo[2] c), (crop_n[2] c), (dims[2] c) multiples of 4):
+ * S3_EINVAL otherwise, and the caller runs s3_affine_channels / s3_copy_block /
+ * s3_chunk_stats instead (bit-identical results). */
+int s3_chunk_epilogue(s3_ctx* ctx, const float* y, int n_chunks, const int64_t* dims,
+                      const int64_t* crop_lo, const int64_t* crop_n, int c,
+                      const float* scale_host, const float* shift_host, float* yc,
+                      float* partial);
 /* placement of a cropped hi-res chunk straight into the caller's host array
  * (the `out[hr_slice] = chunk` of the forward pass, sup3r/pipeline/
  * forward_pass.py:582-673 + the writers' window placement): one pitched
@@ -396,6 +410,37 @@ int s3_host_unregister(s3_ctx* ctx, void* ptr);
 int s3_d2h_window(s3_ctx* ctx, const float* src, float* dst_host, int64_t d0,
                   int64_t d1, int64_t row_elems, int64_t dst_stride0,
                   int64_t dst_stride1, void* stream);
+/* the delivery of a batch of cropped hi-res chunks to the host (the
+ * `.numpy()` at the end of generate, sup3r/models/abstract.py:1100, as the
+ * chunk executor of sup3r/pipeline/forward_pass.py:451-500 needs it: under the
+ * NEXT batch's forward): a contiguous device buffer -> pinned (mapped) host
+ * memory by a kernel of `blocks` workgroups (<= 0: 16) on `stream` (NULL: the
+ * context stream) that writes through PCIe directly — throttled on purpose so
+ * that it shares the chip with the compute stream instead of occupying every
+ * wave slot like the runtime's full-grid blit copy.  16-byte aligned pointers,
+ * bytes % 16 == 0. */
+int s3_d2h_stream(s3_ctx* ctx, const void* src, void* dst_host, size_t bytes,
+                  void* stream, int blocks);
+/* delivery buffers of the chunk executor (what the reference's workers return
+ * through the process pool, sup3r/pipeline/forward_pass.py:526-580): pinned,
+ * device-mapped host memory.  noncoherent != 0: coarse-grained (the GPU may
+ * cache its writes in L2 until the kernel ends; the host must only read after
+ * the stream / event that follows the copy has completed — which is how the
+ * executor uses it).  s3_d2h_async: plain hipMemcpyAsync(DeviceToHost). */
+int s3_host_alloc(s3_ctx* ctx, size_t bytes, int noncoherent, void** out);
+int s3_host_free(s3_ctx* ctx, void* ptr);
+int s3_d2h_async(s3_ctx* ctx, const void* src, void* dst_host, size_t bytes,
+                 void* stream);
+/* the same delivery on an SDMA engine (ROCr hsa_amd_memory_async_copy): the
+ * shader-side copies above stall the chip's other memory traffic while PCIe
+ * drains them, the DMA engines do not.  Ordering is the caller's: call _begin
+ * only after the work that produced `src` has COMPLETED (host-synchronised
+ * event), read `dst_host` (an s3_host_alloc buffer) only after s3_dma_wait
+ * returned S3_OK.  *ticket identifies the copy; s3_dma_wait consumes it
+ * (timeout_ms <= 0: no deadline). */
+int s3_dma_d2h_begin(s3_ctx* ctx, const void* src, void* dst_host, size_t bytes,
+                     uint64_t* ticket);
+int s3_dma_wait(s3_ctx* ctx, uint64_t ticket, int timeout_ms);
 
 /* ---- batch transform on the device ----------------------
  * replaces the host numpy of SingleBatchQueue.transform

@@ -38,7 +38,10 @@ EXPORTS = [
     's3_specmap',
     's3_copy_channels', 's3_affine_channels', 's3_fill', 's3_copy_block',
     's3_coarsen', 's3_gaussian_smooth', 's3_chunk_stats',
+    's3_chunk_epilogue',
     's3_host_register', 's3_host_unregister', 's3_d2h_window',
+    's3_d2h_stream', 's3_host_alloc', 's3_host_free', 's3_d2h_async',
+    's3_dma_d2h_begin', 's3_dma_wait',
     's3_invert_uv', 's3_clip_channels', 's3_range_mask', 's3_fill_indexed',
     's3_comm_unique_id', 's3_comm_init', 's3_params_allreduce_grads',
     's3_params_arm_allreduce',
@@ -162,6 +165,9 @@ def lib():
         's3_fill': (i32, [vp, vp, i64, f32]),
         's3_copy_block': (i32, [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64]),
         's3_chunk_stats': (i32, [vp, vp, i32, i64, i32, vp]),
+        's3_chunk_epilogue': (i32, [vp, vp, i32, C.POINTER(i64),
+                                    C.POINTER(i64), C.POINTER(i64), i32, pf,
+                                    pf, vp, vp]),
         's3_invert_uv': (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp]),
         's3_clip_channels': (i32, [vp, vp, i32, i64, pf, pf]),
         's3_range_mask': (i32, [vp, vp, i32, i32, i64, f32, f32, vp]),
@@ -169,6 +175,13 @@ def lib():
         's3_host_register': (i32, [vp, vp, C.c_size_t]),
         's3_host_unregister': (i32, [vp, vp]),
         's3_d2h_window': (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+        's3_d2h_stream': (i32, [vp, vp, vp, C.c_size_t, vp, i32]),
+        's3_host_alloc': (i32, [vp, C.c_size_t, i32, C.POINTER(vp)]),
+        's3_host_free': (i32, [vp, vp]),
+        's3_d2h_async': (i32, [vp, vp, vp, C.c_size_t, vp]),
+        's3_dma_d2h_begin': (i32, [vp, vp, vp, C.c_size_t,
+                                   C.POINTER(C.c_uint64)]),
+        's3_dma_wait': (i32, [vp, C.c_uint64, i32]),
         's3_coarsen': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                              vp]),
         's3_gaussian_smooth': (i32, [vp, vp, i32, i32, i32, i32, i32, pf, i32,

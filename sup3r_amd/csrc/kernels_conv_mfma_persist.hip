@@ -194,37 +194,45 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
   const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
 
   // ---- this workgroup's work list.  The unit is HALF a tile (two s0 rows =
-  // the four consumer waves of one row pair, one per SIMD): workgroup rank w
-  // owns the half-tiles [w H / G, (w+1) H / G) and walks them as whole tiles
-  // where it can.  That balances the tail (1152 tiles on 256 CUs is 4.5 tiles
-  // each, not 5 rounds) and puts neighbouring workgroups half a tile out of
+  // the four consumer waves of one row pair, one per SIMD), and the half-tiles
+  // of one (n, s1, t) column of tiles are numbered along s0 FIRST: index
+  // h = ((n tiles1 + t1) tiles2 + t2) nh0 + hs0 with nh0 = ceil(rows / 2),
+  // origin row 2 hs0.  Workgroup rank w owns [w H / G, (w+1) H / G) and walks
+  // it in whole tiles (two consecutive half rows of one column, at ANY even
+  // origin) where it can.  That balances the tail (1152 tiles on 256 CUs is 4.5
+  // tiles each, not 5 rounds), puts neighbouring workgroups half a tile out of
   // phase, so their epilogue / halo traffic does not hit HBM in the same
-  // microsecond.  Ranks are XCD-major (block b sits on XCD b % 8): each XCD
-  // owns a contiguous run of tiles and neighbouring halos share its L2.
+  // microsecond — and an extent that is not a multiple of 4 rows (the 22 x 22
+  // chunks of the C3 executor: 11 half rows) costs no edge tile along s0.
+  // Ranks are XCD-major (block b sits on XCD b % 8): each XCD owns a
+  // contiguous run of items and neighbouring halos share its L2.
+  // (kernel argument tiles0 = nh0, n_tiles = H)
   int h_cur, h_end;
   {
     const int nblk = gridDim.x, b = blockIdx.x;
     const int xcd = b % 8, k = b / 8;
     int rank = k;
     for (int xx = 0; xx < xcd; ++xx) rank += (nblk - xx + 7) / 8;
-    const long long H = 2ll * n_tiles;
+    const long long H = n_tiles;
     h_cur = (int)((rank * H) / nblk);
     h_end = (int)(((rank + 1) * H) / nblk);
   }
-  // work item starting at half-tile h: tile, first row, rows; returns next h
-  auto item_at = [&](int h, int& tile, int& r0, int& nr) __attribute__((always_inline)) {
-    tile = h >> 1;
-    if (h & 1) { r0 = 2; nr = 2; return h + 1; }
-    if (h + 1 < h_end) { r0 = 0; nr = 4; return h + 2; }
-    r0 = 0; nr = 2;
-    return h + 1;
-  };
-  auto tile_org = [&](int tile, int& n, int& o0, int& o1, int& o2) __attribute__((always_inline)) {
-    int tr = tile;
+  // origin of the item starting at half-tile h
+  auto tile_org = [&](int h, int& n, int& o0, int& o1, int& o2) __attribute__((always_inline)) {
+    int tr = h;
+    o0 = (tr % tiles0) * 2; tr /= tiles0;
     o2 = (tr % tiles2) * TS2; tr /= tiles2;
     o1 = (tr % tiles1) * TS1; tr /= tiles1;
-    o0 = (tr % tiles0) * TS0; tr /= tiles0;
     n = tr;
+  };
+  // work item starting at half-tile h, whose half-row index hs0 = h % nh0 is
+  // carried along (no division per item): rows (2 or 4); returns the next h
+  auto item_at = [&](int h, int& hs0, int& nr) __attribute__((always_inline)) {
+    const bool whole = hs0 + 1 < tiles0 && h + 1 < h_end;
+    nr = whole ? 4 : 2;
+    hs0 += whole ? 2 : 1;
+    if (hs0 >= tiles0) hs0 = 0;
+    return h + (whole ? 2 : 1);
   };
 
   if (wave >= NCW) {
@@ -239,7 +247,9 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       unsigned vo;
       asm volatile("v_mov_b32 %0, %1" : "=v"(vo) : "v"(dma_voff));
       const char* sb = wimg + (size_t)tap * 8192 + vo;
-      char* d = smem + SLAB_OFF + slot * 8192 + pw * 2048;
+      // (pw * 2048 re-read from lane 0 of the opaque copy: a scalar of its own
+      // held across the tap loop is one SGPR more than the producers have)
+      char* d = smem + SLAB_OFF + slot * 8192 + __builtin_amdgcn_readfirstlane((int)vo);
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)sb,
           (__attribute__((address_space(3))) void*)d, 16, 0, 0);
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     dma_slab(0, 0);
     dma_slab(1, 1);
     if (h_cur < h_end) {
-      HALO_TABLE(h_cur >> 1);
+      HALO_TABLE(h_cur);
 #pragma unroll
       for (int r = 0; r < H0; ++r) {
 #pragma unroll
@@ -383,11 +393,15 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     WG_BARRIER();
 
     for (int h = h_cur; h < h_end;) {
-      int tile, r0_, nr_;
-      h = item_at(h, tile, r0_, nr_);
-      const bool has_next = h < h_end;
-      // without a next item the prefetch re-reads this tile (same op count)
-      HALO_TABLE(has_next ? (h >> 1) : tile);
+      // (h % nh0 per item rather than a carried scalar: the producer waves
+      // are at the SGPR limit)
+      int nr_, hs0_ = h % tiles0;
+      h = item_at(h, hs0_, nr_);
+      // (re-evaluated at each use instead of one more live scalar)
+#define has_next (h < h_end)
+      // without a next item the prefetch re-reads this rank's last tile (same
+      // op count)
+      HALO_TABLE(h < h_end - 1 ? h : h_end - 1);
 #pragma unroll
       for (int tap = 0; tap < 27; ++tap) {
         // rows 0 / 1 of the current halo were last read in taps 8 / 17
@@ -414,6 +428,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       }
       WAIT_LGKM0();
       WG_BARRIER();
+#undef has_next
     }
 #undef HALO_TABLE
     return;
@@ -460,16 +475,19 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
 
   const int my_row = mf0 / TS1;                 // s0 row of this wave's fragments
   for (int h = h_cur; h < h_end;) {
-    int tile, r0, nr;
-    h = item_at(h, tile, r0, nr);
-    if (my_row < r0 || my_row >= r0 + nr) {
-      // half-tile item owned by the other row pair: keep the barrier count
+    int nr, n, org0, org1, org2;
+    const int tile = h;                         // (the item's first half-tile)
+    tile_org(tile, n, org0, org1, org2);
+    {
+      int hs0 = org0 >> 1;
+      h = item_at(h, hs0, nr);
+    }
+    if (my_row >= nr) {
+      // half-tile item: the second row pair idles, keeping the barrier count
 #pragma unroll 1
       for (int t = 0; t < 28; ++t) WG_BARRIER();
       continue;
     }
-    int n, org0, org1, org2;
-    tile_org(tile, n, org0, org1, org2);
     f32x4 acc[MFW][NFV];
 #pragma unroll
     for (int nf = 0; nf < NFV; ++nf) {
@@ -535,8 +553,6 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
 
     if constexpr (DG) {
       // ---- fp32 store over the stacked frames: S = q E + u per axis
-      int n_, org0, org1, org2;
-      tile_org(tile, n_, org0, org1, org2);
       float* yf = reinterpret_cast<float*>(y);
       const int E0 = g.O[0], E1 = g.O[1];
 #pragma unroll
@@ -677,7 +693,8 @@ static void persist_dgrad_grid(const ConvGeom& g, int* gs0, int* gs1) {
   for (int a = 1; a <= g.N; ++a) {
     if (g.N % a) continue;
     const int b = g.N / a;
-    const int64_t t = (int64_t)((a * g.O[0] + TS0 - 1) / TS0) * ((b * g.O[1] + TS1 - 1) / TS1);
+    // (half-tile units: two s0 rows x TS1 columns)
+    const int64_t t = (int64_t)((a * g.O[0] + 1) / 2) * ((b * g.O[1] + TS1 - 1) / TS1);
     if (best < 0 || t < best) { best = t; *gs0 = a; *gs1 = b; }
   }
 }
@@ -687,11 +704,15 @@ bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g) {
   if (!conv_mfma_persist_dgrad_geom_ok(g)) return false;
   int gs0 = 1, gs1 = 1;
   persist_dgrad_grid(g, &gs0, &gs1);
+  const int64_t halves = (int64_t)((gs0 * g.O[0] + 1) / 2) * ((gs1 * g.O[1] + TS1 - 1) / TS1) *
+                         ((g.O[2] + TS2 - 1) / TS2);
+  // (the "fills the chip" threshold keeps counting whole 4-row tiles, as the
+  // plans and their tests were tuned with)
   const int64_t tiles = (int64_t)((gs0 * g.O[0] + TS0 - 1) / TS0) * ((gs1 * g.O[1] + TS1 - 1) / TS1) *
                         ((g.O[2] + TS2 - 1) / TS2);
-  // worth it unless the stacked 4 x 8 x 16 tiles cover clearly more than the
+  // worth it unless the stacked 2 x 8 x 16 half-tiles cover clearly more than the
   // halo-tile kernel's 6 x 6 x 16 ones would (both share the overhang along t)
-  const int64_t covered = tiles * TS0 * TS1 * TS2;
+  const int64_t covered = halves * 2 * TS1 * TS2;
   const int64_t six = (int64_t)g.N * ((g.O[0] + 5) / 6) * ((g.O[1] + 5) / 6) * ((g.O[2] + 15) / 16) * 576;
   const int64_t min_tiles = s3_opt_has(S3O_PERSIST_DGRAD_MIN_TILES)
                                 ? s3_opt_int(S3O_PERSIST_DGRAD_MIN_TILES, 0) : ctx->num_cu;
@@ -710,11 +731,12 @@ int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* d
   }
   int gs0 = 1, gs1 = 1;
   persist_dgrad_grid(g, &gs0, &gs1);
-  const int tiles0 = (gs0 * g.O[0] + TS0 - 1) / TS0, tiles1 = (gs1 * g.O[1] + TS1 - 1) / TS1,
+  // (tiles0 = half rows along the stacked s0 axis, n_tiles = half-tiles)
+  const int tiles0 = (gs0 * g.O[0] + 1) / 2, tiles1 = (gs1 * g.O[1] + TS1 - 1) / TS1,
             tiles2 = (g.O[2] + TS2 - 1) / TS2;
   const int n_tiles = tiles0 * tiles1 * tiles2;
   int grid = ctx->num_cu;
-  if (grid > n_tiles) grid = n_tiles;
+  if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
   auto kern = g.Cout <= 32 ? conv3_mfma_persist_kernel<2, true> : conv3_mfma_persist_kernel<4, true>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
                      (const unsigned short*)dpre16, (const char*)image, (const float*)nullptr,
@@ -734,6 +756,7 @@ bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io
   if (!io.in_bf16 || !io.out_bf16 || (has_res && !io.res_bf16)) return false;
   if (!conv_mfma_persist_geom_ok(g)) return false;
   if (has_res && g.d2s != 1) return false;
+  // (counted in whole 4-row tiles, as before the half-row work list)
   const int64_t tiles = (int64_t)g.N * ((g.O[0] + TS0 - 1) / TS0) *
                         ((g.O[1] + TS1 - 1) / TS1) * ((g.O[2] + TS2 - 1) / TS2);
   return tiles >= ctx->num_cu;
@@ -776,11 +799,12 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
 #undef S3_REP_ATTR
     attr_set = true;
   }
-  const int tiles0 = (g.O[0] + TS0 - 1) / TS0, tiles1 = (g.O[1] + TS1 - 1) / TS1,
+  // (tiles0 = half rows along s0, n_tiles = half-tiles: the kernel's work units)
+  const int tiles0 = (g.O[0] + 1) / 2, tiles1 = (g.O[1] + TS1 - 1) / TS1,
             tiles2 = (g.O[2] + TS2 - 1) / TS2;
   const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
   int grid = ctx->num_cu;
-  if (grid > n_tiles) grid = n_tiles;
+  if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
   const int n_ct = (g.Cout + 63) / 64;
   // (operands read through a fused temporal repeat: variants of their own with
   // the factor a compile-time constant — the index arithmetic with a run-time

@@ -795,6 +795,85 @@ __global__ void chunk_stats_kernel(const float* __restrict__ x, int64_t pos_per_
   }
 }
 
+// ---- the chunk executor's output epilogue in ONE pass over the hi-res batch:
+// un-normalisation (s3_affine_channels' two roundings), halo crop
+// (chunk.hr_crop_slice) and the output check's statistics (chunk_stats_kernel's
+// partial[chunk][64][c][3]; min / max / NaN count do not depend on the order
+// they are folded in).  Separately these were an in-place pass over the
+// un-cropped 483 MB, eight block copies and a re-read of the 368 MB result per
+// batch of eight C3 chunks (0.86 ms); fused, the cropped window is read once
+// and written once.  Workgroup (slab, chunk) walks the cropped rows slab,
+// slab + 64, ...; a row is c3 * c contiguous floats moved as float4.  With
+// 1024 % c == 0 (c = 1, 2, 4, 8, ...) the channel of component k of thread t is
+// (4 t + k) % c for every row and every stride of 256 float4, so the running
+// min / max / NaN count live in four fixed register triples per thread.
+struct ChunkEpi {
+  int64_t y_chunk, y_s0, y_s1;     // element strides of the un-cropped batch
+  int64_t y_org;                   // element offset of the crop origin in a chunk
+  int c0, c1;                      // cropped rows: c0 x c1
+  int row4;                        // float4 per cropped row (c2 * c / 4)
+  int c;
+  int affine;
+  float scale[16], shift[16];
+};
+__global__ __launch_bounds__(256) void chunk_epilogue_kernel(const float* __restrict__ y,
+                                                             float* __restrict__ yc,
+                                                             float* __restrict__ partial, ChunkEpi e) {
+  const int chunk = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+  const float* yb = y + (int64_t)chunk * e.y_chunk + e.y_org;
+  float* ob = yc + (int64_t)chunk * e.c0 * e.c1 * e.row4 * 4;
+  float mn[4], mx[4], nn[4], sc[4], sh[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ch = (4 * tid + k) % e.c;
+    mn[k] = INFINITY; mx[k] = -INFINITY; nn[k] = 0.f;
+    sc[k] = e.scale[ch]; sh[k] = e.shift[ch];
+  }
+  const int rows = e.c0 * e.c1;
+  for (int r = slab; r < rows; r += kStatSlabs) {
+    const int a = r / e.c1, b = r - a * e.c1;
+    const float4* src = reinterpret_cast<const float4*>(yb + a * e.y_s0 + b * e.y_s1);
+    float4* dst = reinterpret_cast<float4*>(ob + (int64_t)r * e.row4 * 4);
+    for (int q = tid; q < e.row4; q += 256) {
+      const float4 v4 = src[q];
+      float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (e.affine) {
+          float t = v[k] * sc[k];
+          asm volatile("" : "+v"(t));          // (x * scale) + shift, two roundings
+          v[k] = t + sh[k];
+        }
+        if (v[k] != v[k]) nn[k] += 1.f;
+        else { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+      }
+      dst[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  __shared__ float smin[256], smax[256], snan[256];
+  for (int ch = 0; ch < e.c; ++ch) {
+    float m0 = INFINITY, m1 = -INFINITY, m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((4 * tid + k) % e.c == ch) { m0 = fminf(m0, mn[k]); m1 = fmaxf(m1, mx[k]); m2 += nn[k]; }
+    smin[tid] = m0; smax[tid] = m1; snan[tid] = m2;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) {
+      if (tid < s_) {
+        smin[tid] = fminf(smin[tid], smin[tid + s_]);
+        smax[tid] = fmaxf(smax[tid], smax[tid + s_]);
+        snan[tid] += snan[tid + s_];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      float* o = partial + (((int64_t)chunk * kStatSlabs + slab) * e.c + ch) * 3;
+      o[0] = smin[0]; o[1] = smax[0]; o[2] = snan[0];
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 // ================================================================ launchers
@@ -1244,6 +1323,40 @@ extern "C" int s3_chunk_stats(s3_ctx* ctx, const float* x, int n_chunks,
   return S3_OK;
 }
 
+extern "C" int s3_chunk_epilogue(s3_ctx* ctx, const float* y, int n_chunks, const int64_t* dims,
+                                 const int64_t* crop_lo, const int64_t* crop_n, int c,
+                                 const float* scale_host, const float* shift_host, float* yc,
+                                 float* partial) {
+  if (!ctx || !y || !yc || !partial || !dims || !crop_lo || !crop_n) return S3_EINVAL;
+  if (n_chunks < 1 || c < 1 || c > 16 || 1024 % c != 0)
+    S3_FAIL(ctx, S3_EINVAL, "chunk_epilogue: 1 .. 16 channels, a divisor of 1024");
+  for (int d = 0; d < 3; ++d)
+    if (crop_lo[d] < 0 || crop_n[d] < 1 || crop_lo[d] + crop_n[d] > dims[d])
+      S3_FAIL(ctx, S3_EINVAL, "chunk_epilogue: the crop window leaves the chunk");
+  // float4 rows: 16-byte aligned row starts and lengths (else the caller takes
+  // the three-kernel path)
+  if ((crop_n[2] * c) % 4 || (crop_lo[2] * c) % 4 || (dims[2] * c) % 4 || ((uintptr_t)y & 15) ||
+      ((uintptr_t)yc & 15))
+    S3_FAIL(ctx, S3_EINVAL, "chunk_epilogue: rows are not 16-byte aligned");
+  ChunkEpi e;
+  e.y_s1 = dims[2] * c;
+  e.y_s0 = dims[1] * e.y_s1;
+  e.y_chunk = dims[0] * e.y_s0;
+  e.y_org = crop_lo[0] * e.y_s0 + crop_lo[1] * e.y_s1 + crop_lo[2] * c;
+  e.c0 = (int)crop_n[0]; e.c1 = (int)crop_n[1];
+  e.row4 = (int)(crop_n[2] * c / 4);
+  e.c = c;
+  e.affine = scale_host && shift_host;
+  for (int i = 0; i < 16; ++i) {
+    e.scale[i] = e.affine && i < c ? scale_host[i] : 1.f;
+    e.shift[i] = e.affine && i < c ? shift_host[i] : 0.f;
+  }
+  hipLaunchKernelGGL(chunk_epilogue_kernel, dim3(kStatSlabs, n_chunks), dim3(256), 0, ctx->stream, y, yc,
+                     partial, e);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 // ---- direct device -> host placement of a cropped chunk -------------------
 extern "C" int s3_host_register(s3_ctx* ctx, void* ptr, size_t bytes) {
   if (!ctx || !ptr) return S3_EINVAL;
@@ -1272,6 +1385,75 @@ extern "C" int s3_d2h_window(s3_ctx* ctx, const float* src, float* dst_host, int
   p.extent = make_hipExtent(row_bytes, (size_t)d1, (size_t)d0);
   p.kind = hipMemcpyDeviceToHost;
   S3_HIP(ctx, hipMemcpy3DAsync(&p, stream ? (hipStream_t)stream : ctx->stream));
+  return S3_OK;
+}
+
+// ---- throttled device -> pinned-host stream (the C3 executor's hi-res chunks)
+// hipMemcpyAsync(DeviceToHost) of a large buffer runs as a full-grid blit
+// kernel on this runtime (__amd_rocclr_copyBuffer): its waves park on PCIe
+// write credit in every wave slot of the chip, and the NEXT batch's first
+// kernels — on the compute stream, meant to overlap it — queue behind them
+// (the 4 -> 64 head conv of a C3 batch took 3.0 ms instead of 20 us next to
+// it).  PCIe Gen5 x16 moves ~55 GB/s: a handful of workgroups with a few
+// 16-B stores in flight per lane saturate it, so the copy is a grid of
+// `blocks` workgroups (default 16 of the 256 CUs' worth) writing through the
+// host-mapped pointer; everything else of the chip stays with the forward pass.
+typedef unsigned d2h_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void d2h_stream_kernel(const d2h_u32x4* __restrict__ src,
+                                                         d2h_u32x4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
+    d2h_u32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (i + q * 256 < n16) v[q] = __builtin_nontemporal_load(src + i + q * 256);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (i + q * 256 < n16) dst[i + q * 256] = v[q];
+  }
+}
+
+extern "C" int s3_d2h_stream(s3_ctx* ctx, const void* src, void* dst_host, size_t bytes,
+                             void* stream, int blocks) {
+  if (!ctx || !src || !dst_host) return S3_EINVAL;
+  if ((bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst_host & 15))
+    S3_FAIL(ctx, S3_EINVAL, "d2h_stream: 16-byte aligned buffers of a multiple of 16 bytes");
+  if (bytes == 0) return S3_OK;
+  void* dptr = nullptr;
+  // (pinned host memory: the device-side alias of the host pointer)
+  if (hipHostGetDevicePointer(&dptr, dst_host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    S3_FAIL(ctx, S3_EINVAL, "d2h_stream: the destination is not pinned (mapped) host memory");
+  }
+  if (blocks < 1) blocks = 16;
+  const size_t n16 = bytes / 16;
+  const size_t need = (n16 + 1023) / 1024;
+  if ((size_t)blocks > need) blocks = (int)need;
+  hipLaunchKernelGGL(d2h_stream_kernel, dim3(blocks), dim3(256), 0,
+                     stream ? (hipStream_t)stream : ctx->stream, (const d2h_u32x4*)src, (d2h_u32x4*)dptr, n16);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+extern "C" int s3_host_alloc(s3_ctx* ctx, size_t bytes, int noncoherent, void** out) {
+  if (!ctx || !out || bytes == 0) return S3_EINVAL;
+  *out = nullptr;
+  const unsigned flags = hipHostMallocPortable | hipHostMallocMapped |
+                         (noncoherent ? hipHostMallocNonCoherent : hipHostMallocCoherent);
+  S3_HIP(ctx, hipHostMalloc(out, bytes, flags));
+  return S3_OK;
+}
+
+extern "C" int s3_host_free(s3_ctx* ctx, void* ptr) {
+  if (!ctx) return S3_EINVAL;
+  if (ptr) S3_HIP(ctx, hipHostFree(ptr));
+  return S3_OK;
+}
+
+extern "C" int s3_d2h_async(s3_ctx* ctx, const void* src, void* dst_host, size_t bytes, void* stream) {
+  if (!ctx || !src || !dst_host) return S3_EINVAL;
+  S3_HIP(ctx, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost,
+                             stream ? (hipStream_t)stream : ctx->stream));
   return S3_OK;
 }
 

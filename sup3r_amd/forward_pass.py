@@ -683,12 +683,22 @@ class ForwardPass:
         output epilogue (u/v inversion, limits: ``DeviceOutputTransform``)
         runs on the device and the registered ``OUTPUT_HANDLER_CLASS`` entry
         writes the result.  ``return_data=False`` skips the raw download when
-        only the files are wanted (``run``)."""
+        only the files are wanted (``run``).
+
+        ``output_data`` of a device batch is a VIEW into a ring of pinned
+        delivery buffers (``d2h_ring`` per output shape, filled by the SDMA
+        engines): it stays valid until two further batches have been yielded —
+        consume it (write it, place it) or copy it before asking for more
+        than that.  ``run`` / ``run_chunk`` hand out copies."""
         import collections
 
         pending = collections.deque()
 
         def flush(keep):
+            # the newest batch is on the device's queue: the one before it may
+            # start crossing PCIe (its forward is the one running or done)
+            if len(pending) > 1:
+                pending[-2].deliver()
             while len(pending) > keep:
                 yield from pending.popleft()()
 
@@ -840,58 +850,90 @@ class ForwardPass:
             raise RuntimeError(msg)
         n_out = int(y.shape[-1])
         pf = C.POINTER(C.c_float)
+        scale = shift = None
         if model.means is not None:
             mu, sd = model._stats_for(model.hr_out_features)
             scale = np.ascontiguousarray(sd, dtype=np.float32)
             shift = np.ascontiguousarray(mu, dtype=np.float32)
-            rc = L.s3_affine_channels(
-                dev.ctx, C.c_void_p(y.data_ptr()), C.c_void_p(y.data_ptr()),
-                n_out, y.numel() // n_out, scale.ctypes.data_as(pf),
-                shift.ctypes.data_as(pf))
-            _lib.check(rc, dev.ctx, 's3_affine_channels')
         y1, y2, y3 = (int(v) for v in y.shape[1:4])
         cr = cls._crop_bounds(group[0].hr_crop_slice, (y1, y2, y3))
         c1, c2, c3 = (b - a for a, b in cr)
         yc = dev.empty((n, c1, c2, c3, n_out))
-        for k in range(n):
-            src = y[k].data_ptr() + 4 * n_out * (
-                (cr[0][0] * y2 + cr[1][0]) * y3 + cr[2][0])
-            rc = L.s3_copy_block(
-                dev.ctx, C.c_void_p(src), C.c_void_p(yc[k].data_ptr()), c1,
-                c2, c3 * n_out, y2 * y3 * n_out, y3 * n_out, c2 * c3 * n_out,
-                c3 * n_out)
-            _lib.check(rc, dev.ctx, 's3_copy_block')
-        del y
         stats_d = dev.empty((n, 64, n_out, 3))
-        rc = L.s3_chunk_stats(dev.ctx, C.c_void_p(yc.data_ptr()), n,
-                              yc.numel() // (n * n_out), n_out,
-                              C.c_void_p(stats_d.data_ptr()))
-        _lib.check(rc, dev.ctx, 's3_chunk_stats')
+        # un-normalisation, halo crop and the output check's statistics: one
+        # pass over the cropped window (s3_chunk_epilogue) where the rows are
+        # 16-byte aligned, the three separate kernels otherwise — same bits
+        fused = 1024 % n_out == 0 and n_out <= 16 and not any(
+            (v * n_out) % 4 for v in (c3, cr[2][0], y3))
+        if fused:
+            i64x3 = C.c_int64 * 3
+            rc = L.s3_chunk_epilogue(
+                dev.ctx, C.c_void_p(y.data_ptr()), n, i64x3(y1, y2, y3),
+                i64x3(cr[0][0], cr[1][0], cr[2][0]), i64x3(c1, c2, c3), n_out,
+                scale.ctypes.data_as(pf) if scale is not None else None,
+                shift.ctypes.data_as(pf) if shift is not None else None,
+                C.c_void_p(yc.data_ptr()), C.c_void_p(stats_d.data_ptr()))
+            _lib.check(rc, dev.ctx, 's3_chunk_epilogue')
+        else:
+            if scale is not None:
+                rc = L.s3_affine_channels(
+                    dev.ctx, C.c_void_p(y.data_ptr()),
+                    C.c_void_p(y.data_ptr()), n_out, y.numel() // n_out,
+                    scale.ctypes.data_as(pf), shift.ctypes.data_as(pf))
+                _lib.check(rc, dev.ctx, 's3_affine_channels')
+            for k in range(n):
+                src = y[k].data_ptr() + 4 * n_out * (
+                    (cr[0][0] * y2 + cr[1][0]) * y3 + cr[2][0])
+                rc = L.s3_copy_block(
+                    dev.ctx, C.c_void_p(src), C.c_void_p(yc[k].data_ptr()),
+                    c1, c2, c3 * n_out, y2 * y3 * n_out, y3 * n_out,
+                    c2 * c3 * n_out, c3 * n_out)
+                _lib.check(rc, dev.ctx, 's3_copy_block')
+            rc = L.s3_chunk_stats(dev.ctx, C.c_void_p(yc.data_ptr()), n,
+                                  yc.numel() // (n * n_out), n_out,
+                                  C.c_void_p(stats_d.data_ptr()))
+            _lib.check(rc, dev.ctx, 's3_chunk_stats')
+        del y
         copy_stream = cls._copy_stream(dev)
         stats_h = torch.empty(tuple(stats_d.shape), dtype=torch.float32,
                               pin_memory=True)
-        host = torch.empty(tuple(yc.shape), dtype=torch.float32,
-                           pin_memory=True) if return_data else None
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(ready)
             stats_h.copy_(stats_d, non_blocking=True)
-            if host is not None:
-                host.copy_(yc, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(copy_stream)
-        yc.record_stream(copy_stream)
         stats_d.record_stream(copy_stream)
+        state = {'ticket': None, 'host': None}
+
+        def deliver():
+            """start the batch's device -> host DMA (idempotent).  The SDMA
+            engine is driven through ROCr (s3_dma_d2h_begin), which takes no
+            HIP event as a dependency: the host waits for the batch's forward
+            first — by the time ``iter_chunks`` calls this the NEXT batch is
+            already enqueued behind it, so the device does not idle."""
+            if not return_data or state['host'] is not None:
+                return
+            ready.synchronize()
+            host_ptr, host_arr = cls._delivery_buffer(dev, tuple(yc.shape))
+            ticket = C.c_uint64()
+            rc = L.s3_dma_d2h_begin(
+                dev.ctx, C.c_void_p(yc.data_ptr()), C.c_void_p(host_ptr),
+                host_arr.size * 4, C.byref(ticket))
+            _lib.check(rc, dev.ctx, 's3_dma_d2h_begin')
+            state['ticket'], state['host'] = ticket, host_arr
 
         def finish():
+            deliver()
             ev.synchronize()
             staged.clear()
             st = stats_h.numpy().reshape(n, 64, n_out, 3)
             mn, mx = st[..., 0].min(1), st[..., 1].max(1)
             nn = st[..., 2].sum(1)
             skip, allowed = cls._const_ok(allowed_const)
-            for k, chunk in enumerate(group):
+            fails = []
+            for k in range(n):
                 failed = False
                 if not skip:
                     if nn[k].any():
@@ -906,13 +948,23 @@ class ForwardPass:
                                              f'feature channel {i}!')
                                 failed = True
                                 break
-                if write and chunk.out_file is not None and not failed:
+                fails.append(failed)
+            for k, chunk in enumerate(group):
+                if write and chunk.out_file is not None and not fails[k]:
                     cls._write_chunk(chunk, model, yc[k], invert_uv, nn_fill,
                                      meta, output_workers)
-                # (a view of this batch's own pinned buffer, alive as long as
-                # the caller keeps the array: no extra host copy of 46 MB)
-                yield (chunk, failed,
-                       host[k].numpy() if host is not None else None)
+            host_arr = state['host']
+            if state['ticket'] is not None:
+                rc = L.s3_dma_wait(dev.ctx, state['ticket'],
+                                   int(dev.comm_timeout_s * 1000))
+                state['ticket'] = None
+                _lib.check(rc, dev.ctx, 's3_dma_wait')
+            for k, chunk in enumerate(group):
+                # (a view into the executor's ring of delivery buffers: valid
+                # until ``d2h_ring - 3`` further batches have been yielded)
+                yield (chunk, fails[k],
+                       host_arr[k] if host_arr is not None else None)
+        finish.deliver = deliver
         return finish
 
     @staticmethod
@@ -941,6 +993,32 @@ class ForwardPass:
         return ExoData({f: {'steps': [dict(st, data=np.asarray(st['data'])[
             None]) for st in e['steps']]} for f, e in exo.items()})
 
+    #: a batch's hi-res chunks land in a ring of pinned host buffers
+    #: (s3_host_alloc) per output shape, allocated once: pinning 368 MB per
+    #: batch cost 8.9 ms of host time each (torch.empty(pin_memory=True))
+    d2h_ring = 4
+    _delivery = {}
+
+    @classmethod
+    def _delivery_buffer(cls, dev, shape):
+        import ctypes as C
+
+        from . import _lib
+        key = (dev.index, shape)
+        ring = cls._delivery.setdefault(key, {'bufs': [], 'next': 0})
+        if len(ring['bufs']) < cls.d2h_ring:
+            n = int(np.prod(shape))
+            ptr = C.c_void_p()
+            rc = _lib.lib().s3_host_alloc(dev.ctx, n * 4, 0, C.byref(ptr))
+            _lib.check(rc, dev.ctx, 's3_host_alloc')
+            arr = np.ctypeslib.as_array(
+                (C.c_float * n).from_address(ptr.value)).reshape(shape)
+            ring['bufs'].append((ptr.value, arr))
+            return ring['bufs'][-1]
+        buf = ring['bufs'][ring['next'] % cls.d2h_ring]
+        ring['next'] += 1
+        return buf
+
     _copy_streams = {}
 
     @classmethod
@@ -968,7 +1046,8 @@ class ForwardPass:
             [chunk], model, allowed_const=allowed_const, batch=1,
             invert_uv=invert_uv, nn_fill=nn_fill, meta=meta,
             output_workers=output_workers)
-        return failed, output_data
+        # (the caller owns what it gets: not a view of the delivery ring)
+        return failed, np.array(output_data)
 
     @classmethod
     def run(cls, strategy, node_index, batch=8, return_data=False):
@@ -1003,7 +1082,7 @@ class ForwardPass:
             if hasattr(strategy, 'mark_finished'):
                 strategy.mark_finished(chunk.index)
             if return_data:
-                kept.append((chunk.index, data))
+                kept.append((chunk.index, np.array(data)))
             done += 1
         logger.info('Finished forward passes on %d chunks', done)
         return (done, kept) if return_data else done

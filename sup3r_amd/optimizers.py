@@ -7,10 +7,17 @@ The update itself is one fused multi-tensor HIP kernel per step
 (``s3_adam_step`` / ``s3_optimizer_step``): keras-2.15 ``update_step`` of
 Adam, SGD (momentum / nesterov), RMSprop (not centered), Adagrad, Adamax and
 AdamW.  Anything else (Nadam, Ftrl, Adadelta, Adafactor, Lion, amsgrad,
-centered RMSprop, gradient clipping / EMA options) raises ``KeyError``."""
+centered RMSprop, gradient clipping or EMA switched ON) raises ``KeyError``;
+a verbatim keras ``get_config()`` dict (``ema_momentum=0.99`` with
+``use_ema=False``, ``jit_compile=True``, ...) loads."""
 
-_UNSUPPORTED_KW = ('clipnorm', 'clipvalue', 'global_clipnorm', 'use_ema',
-                   'ema_momentum', 'ema_overwrite_frequency', 'jit_compile')
+# options of keras' base optimizer (every ``get_config()`` carries them,
+# abstract.py:544-557 writes them into model_params.json).  Only the ones that
+# change the update are refused, and only when they are switched on:
+_CLIP_KW = ('clipnorm', 'clipvalue', 'global_clipnorm')      # on when not None
+_EMA_KW = ('ema_momentum', 'ema_overwrite_frequency')        # read iff use_ema
+_IGNORED_KW = ('jit_compile', 'is_legacy_optimizer')         # no maths in them
+_BASE_KW = _CLIP_KW + _EMA_KW + _IGNORED_KW + ('use_ema',)
 
 
 class _Optimizer:
@@ -18,10 +25,15 @@ class _Optimizer:
     DEFAULTS = {}
 
     def __init__(self, learning_rate=None, name=None, **kwargs):
-        for k in _UNSUPPORTED_KW:
-            if kwargs.pop(k, None) not in (None, False, 0):
+        for k in _CLIP_KW:
+            if kwargs.pop(k, None) is not None:
                 raise KeyError(f'optimizer option "{k}" has no MI355X kernel '
                                'mapping')
+        if kwargs.pop('use_ema', False):
+            raise KeyError('optimizer option "use_ema" has no MI355X kernel '
+                           'mapping')
+        for k in _EMA_KW + _IGNORED_KW:
+            kwargs.pop(k, None)
         if 'weight_decay' not in self.DEFAULTS and \
                 kwargs.pop('weight_decay', None) not in (None, 0, 0.0):
             raise KeyError('weight_decay on this optimizer has no MI355X '
@@ -143,7 +155,7 @@ def init_optimizer(optimizer, learning_rate):
     if isinstance(optimizer, dict):
         cls = get_optimizer_class(optimizer)
         conf = {k: v for k, v in optimizer.items()
-                if k in cls.DEFAULTS or k in _UNSUPPORTED_KW
+                if k in cls.DEFAULTS or k in _BASE_KW
                 or k == 'weight_decay'}
         if optimizer.get('name') not in (cls.__name__.lower(),):
             conf['name'] = optimizer['name']

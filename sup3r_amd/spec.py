@@ -584,6 +584,25 @@ def build_plan(layers, in_shape, param_table=None, fuse=True):
             # mean) — the fill is applied where the field is prepared
             # (Sup3rGan._reshape_norm_exo / Sup3rGanWithObs), the device op is
             # the plain concat.  UNVERIFIED against phygnn.
+            if cls == 'Sup3rConcatObs':
+                # one observation channel per layer is all that is restated
+                # here: a layer with several `features` or with
+                # `exo_features` (abstract.py:1001-1035 stacks them into two
+                # extra call arguments) would be lowered wrongly, not slowly
+                if len(kw.get('features', [L.name])) > 1 or \
+                        kw.get('exo_features'):
+                    raise KeyError(
+                        f'Sup3rConcatObs layer "{L.name}" with several '
+                        '`features` or with `exo_features` has no kernel '
+                        'mapping (one observation channel per layer only)')
+                import warnings
+                warnings.warn(
+                    f'Sup3rConcatObs layer "{L.name}": phygnn is not '
+                    'available to this build, the layer is lowered as a '
+                    'channel concat with un-observed (NaN) cells at the '
+                    'feature mean — UNVERIFIED against phygnn; a generator '
+                    'trained with the reference\'s layer may produce '
+                    'different fields', RuntimeWarning, stacklevel=2)
             flush_pad()
             sh = cur_dims()
             if cls in ('Sup3rConcat', 'Sup3rConcatObs'):

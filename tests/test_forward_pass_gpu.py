@@ -103,6 +103,137 @@ def test_chunk_stats_kernel():
     assert mn[1, 1] == mx[1, 1] == np.float32(0.75)
 
 
+@pytest.mark.parametrize('affine', [True, False])
+def test_fused_chunk_epilogue_equals_the_three_kernels(affine):
+    """s3_chunk_epilogue (un-norm + halo crop + output-check statistics in one
+    pass) against s3_affine_channels -> s3_copy_block -> s3_chunk_stats: the
+    cropped batch bit for bit, the folded statistics exactly — with NaNs, a
+    constant channel and a negative zero in the window."""
+    import ctypes as C
+    from sup3r_amd import _lib
+    from sup3r_amd.engine import Device
+    dev, L = Device.get(), _lib.lib()
+    rng = np.random.default_rng(11)
+    n, dims, c = 3, (13, 11, 20), 2
+    lo, cn = (2, 1, 4), (9, 8, 14)
+    y = rng.standard_normal((n,) + dims + (c,)).astype(np.float32)
+    y[1, ..., 1] = 0.5
+    y[2, 5, 5, 9, 0] = np.nan
+    y[0, 3, 3, 6, 1] = -0.0
+    scale = np.array([1.75, 0.5], np.float32)
+    shift = np.array([0.3, -2.0], np.float32)
+    pf, i64x3 = C.POINTER(C.c_float), C.c_int64 * 3
+    yd = dev.to_device(y)
+    yc = dev.empty((n,) + cn + (c,))
+    st = dev.empty((n, 64, c, 3))
+    rc = L.s3_chunk_epilogue(
+        dev.ctx, C.c_void_p(yd.data_ptr()), n, i64x3(*dims), i64x3(*lo),
+        i64x3(*cn), c, scale.ctypes.data_as(pf) if affine else None,
+        shift.ctypes.data_as(pf) if affine else None,
+        C.c_void_p(yc.data_ptr()), C.c_void_p(st.data_ptr()))
+    _lib.check(rc, dev.ctx, 's3_chunk_epilogue')
+    got, gs = yc.cpu().numpy(), st.cpu().numpy()
+    # the separate kernels
+    y2 = dev.to_device(y)
+    if affine:
+        rc = L.s3_affine_channels(
+            dev.ctx, C.c_void_p(y2.data_ptr()), C.c_void_p(y2.data_ptr()), c,
+            y2.numel() // c, scale.ctypes.data_as(pf), shift.ctypes.data_as(pf))
+        _lib.check(rc, dev.ctx, 's3_affine_channels')
+    ref = dev.empty((n,) + cn + (c,))
+    for k in range(n):
+        src = y2[k].data_ptr() + 4 * c * (
+            (lo[0] * dims[1] + lo[1]) * dims[2] + lo[2])
+        rc = L.s3_copy_block(
+            dev.ctx, C.c_void_p(src), C.c_void_p(ref[k].data_ptr()), cn[0],
+            cn[1], cn[2] * c, dims[1] * dims[2] * c, dims[2] * c,
+            cn[1] * cn[2] * c, cn[2] * c)
+        _lib.check(rc, dev.ctx, 's3_copy_block')
+    st2 = dev.empty((n, 64, c, 3))
+    rc = L.s3_chunk_stats(dev.ctx, C.c_void_p(ref.data_ptr()), n,
+                          int(np.prod(cn)), c, C.c_void_p(st2.data_ptr()))
+    _lib.check(rc, dev.ctx, 's3_chunk_stats')
+    want, ws = ref.cpu().numpy(), st2.cpu().numpy()
+    assert got.tobytes() == want.tobytes()
+    for g, w in ((gs, ws),):
+        np.testing.assert_array_equal(g[..., 0].min(1), w[..., 0].min(1))
+        np.testing.assert_array_equal(g[..., 1].max(1), w[..., 1].max(1))
+        np.testing.assert_array_equal(g[..., 2].sum(1), w[..., 2].sum(1))
+    assert gs[..., 2].sum() == 1 and \
+        gs[1, :, 1, 0].min() == gs[1, :, 1, 1].max()
+    # rows that are not 16-byte aligned are refused (the executor then takes
+    # the three kernels)
+    rc = L.s3_chunk_epilogue(
+        dev.ctx, C.c_void_p(yd.data_ptr()), n, i64x3(*dims), i64x3(2, 1, 3),
+        i64x3(9, 8, 14), c, None, None, C.c_void_p(yc.data_ptr()),
+        C.c_void_p(st.data_ptr()))
+    assert rc == -1
+
+
+def test_sdma_delivery_round_trip():
+    """s3_host_alloc + s3_dma_d2h_begin / s3_dma_wait (ROCr SDMA copy): the
+    bytes of a device buffer arrive in the pinned host buffer; a buffer ROCr
+    does not know is refused."""
+    import ctypes as C
+    import torch
+    from sup3r_amd import _lib
+    from sup3r_amd.engine import Device
+    dev, L = Device.get(), _lib.lib()
+    n = 3 * 1024 * 1024 + 5
+    x = np.random.default_rng(3).standard_normal(n).astype(np.float32)
+    xd = dev.to_device(x)
+    torch.cuda.synchronize()
+    hp = C.c_void_p()
+    _lib.check(L.s3_host_alloc(dev.ctx, n * 4, 0, C.byref(hp)), dev.ctx,
+               's3_host_alloc')
+    try:
+        arr = np.ctypeslib.as_array((C.c_float * n).from_address(hp.value))
+        arr[:] = 0
+        t = C.c_uint64()
+        _lib.check(L.s3_dma_d2h_begin(dev.ctx, C.c_void_p(xd.data_ptr()), hp,
+                                      n * 4, C.byref(t)), dev.ctx, 'begin')
+        _lib.check(L.s3_dma_wait(dev.ctx, t, 10000), dev.ctx, 'wait')
+        np.testing.assert_array_equal(arr, x)
+        plain = np.zeros(16, np.float32)
+        rc = L.s3_dma_d2h_begin(dev.ctx, C.c_void_p(xd.data_ptr()),
+                                plain.ctypes.data_as(C.c_void_p), 64,
+                                C.byref(t))
+        assert rc < 0
+    finally:
+        _lib.check(L.s3_host_free(dev.ctx, hp), dev.ctx, 's3_host_free')
+
+
+def test_iter_chunks_views_stay_valid_for_two_batches():
+    """the delivery ring: a yielded array is still intact after two further
+    batches have been yielded (the documented life time)"""
+    from sup3r_amd import ForwardPass
+    from sup3r_amd.strategy import ArrayStrategy
+    model = _model()
+    rng = np.random.default_rng(4)
+    domain = (rng.standard_normal((12, 12, 40, 2))).astype(np.float32)
+    from sup3r_amd.forward_pass import register_model
+    register_model('Sup3rGan', {'model_dir': 'ring-test'}, model)
+    st = ArrayStrategy(domain, {'model_dir': 'ring-test'}, (6, 6, 4),
+                       spatial_pad=1, temporal_pad=1, max_nodes=1, model=model)
+    fwp = ForwardPass(st, 0)
+    ids = [int(i) for i in st.node_chunks[0]]
+    assert len(ids) >= 12
+    ref = {}
+    for i in ids:
+        (c, failed, d), = ForwardPass.iter_chunks(
+            [fwp.get_input_chunk(i)], model, batch=1)
+        ref[i] = np.array(d)
+    held = []
+    for c, failed, d in ForwardPass.iter_chunks(
+            (fwp.get_input_chunk(i) for i in ids), model, batch=2):
+        assert not failed
+        held.append((c.index, d))
+        batch_now = (len(held) - 1) // 2
+        for pos, (idx, arr) in enumerate(held):
+            if pos // 2 >= batch_now - 2:   # this batch + the two before it
+                np.testing.assert_array_equal(arr, ref[idx])
+
+
 # ------------------------------------------- the reference's entry points
 def _topo_model(tmp_path=None):
     """a topography-conditioned 3x / 4x generator (Sup3rConcat mid-network)"""

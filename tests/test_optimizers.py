@@ -37,6 +37,55 @@ def test_optimizer_config_surface():
             init_optimizer(bad, None)
 
 
+# what keras 2.15 `tf.keras.optimizers.<Name>().get_config()` returns — the
+# dict abstract.py:544-557 writes into model_params.json and `Sup3rGan.load`
+# hands back to `init_optimizer` (abstract.py:339-346)
+_KERAS_BASE = {'weight_decay': None, 'clipnorm': None, 'global_clipnorm': None,
+               'clipvalue': None, 'use_ema': False, 'ema_momentum': 0.99,
+               'ema_overwrite_frequency': None, 'jit_compile': True,
+               'is_legacy_optimizer': False}
+KERAS_CONFIGS = [
+    dict(_KERAS_BASE, name='Adam', learning_rate=1e-4, beta_1=0.9,
+         beta_2=0.999, epsilon=1e-07, amsgrad=False),
+    dict(_KERAS_BASE, name='SGD', learning_rate=0.01, momentum=0.0,
+         nesterov=False),
+    dict(_KERAS_BASE, name='RMSprop', learning_rate=0.001, rho=0.9,
+         momentum=0.0, epsilon=1e-07, centered=False),
+    dict(_KERAS_BASE, name='AdamW', learning_rate=0.001, weight_decay=0.004,
+         beta_1=0.9, beta_2=0.999, epsilon=1e-07, amsgrad=False),
+]
+
+
+@pytest.mark.parametrize('conf', KERAS_CONFIGS, ids=lambda c: c['name'])
+def test_verbatim_keras_get_config_loads(conf):
+    """round 3 refused `ema_momentum=0.99` / `jit_compile=True`, which every
+    keras config carries: no model_params.json of the reference loaded"""
+    from sup3r_amd.optimizers import init_optimizer
+    o = init_optimizer(dict(conf), None)
+    assert type(o).__name__ == conf['name']
+    assert o.learning_rate == conf['learning_rate']
+    for k, v in o.get_config().items():
+        assert conf[k] == v, k
+    # switched ON, the same options are refused
+    for k, v in (('use_ema', True), ('clipnorm', 1.0), ('clipvalue', 0.5),
+                 ('global_clipnorm', 2.0)):
+        with pytest.raises(KeyError):
+            init_optimizer(dict(conf, **{k: v}), None)
+
+
+def test_model_params_with_keras_optimizer_config_load(tmp_path):
+    """`Sup3rGan.load` on a params file whose optimizer entries are keras
+    configs (base.py:133-214)"""
+    import json
+    from sup3r_amd.optimizers import init_optimizer
+    params = {'optimizer': KERAS_CONFIGS[0], 'optimizer_disc': KERAS_CONFIGS[1]}
+    fp = tmp_path / 'model_params.json'
+    fp.write_text(json.dumps(params))
+    back = json.loads(fp.read_text())
+    assert init_optimizer(back['optimizer'], None).beta_2 == 0.999
+    assert init_optimizer(back['optimizer_disc'], None).momentum == 0.0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,kw', CASES)
 def test_device_steps_vs_keras_restatement(name, kw):
