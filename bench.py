@@ -209,9 +209,12 @@ def c3_leg(batch, steps, warmup, world, rank, entry='strategy'):
     Sup3rGan.seed(0)
     m.init_weights((1, 22, 22, 52, 4), (1, 110, 110, 624, 2))
     rng = np.random.default_rng(7)
-    # only the first rows of the domain are visited by the bounded run
-    domain = rng.standard_normal((400, 400, 720, 4), dtype=np.float32)
+    # (an 80-row random block repeated along s0: drawing all 461 M values
+    # took longer than the bounded run that visits a few rows of them)
+    domain = np.tile(rng.standard_normal((80, 400, 720, 4), dtype=np.float32),
+                     (5, 1, 1, 1))
     seen = [0, 0.0]
+    extra = {}
 
     def writer(idx, hr_slice, data):
         seen[0] += 1
@@ -237,8 +240,34 @@ def c3_leg(batch, steps, warmup, world, rank, entry='strategy'):
         run(mine[:warmup * batch])
         torch.cuda.synchronize()
         seen[0] = 0
+        # HIP events around every op of the timed batches, in situ (beside the
+        # SDMA delivery of the previous batch)
+        ph = m._gen.plan((batch, 22, 22, 52, 4), training=False)
+        ph.profile_begin(steps)
         t0 = time.perf_counter()
         n = run(mine[warmup * batch:(warmup + steps) * batch])
+        torch.cuda.synchronize()
+        el0 = time.perf_counter() - t0
+        n_prof, ms = ph.profile_end()
+        assert n == seen[0] == steps * batch, (n, seen[0], steps * batch)
+        trunk = [ms[i] for i, op in enumerate(ph.plan.ops)
+                 if op.get('cin') == 64 and op.get('cout') == 64
+                 and ph.plan.tensors[op['out']][1:4] == [22, 22, 624]]
+        if trunk and n_prof > 0:
+            t_ms = float(np.mean(trunk))
+            gflop = batch * 22 * 22 * 624 * 27 * 64 * 64 * 2 / 1e9
+            extra = {
+                'forwards_profiled': n_prof,
+                'all_ops_ms_per_batch': float(sum(ms)),
+                'head_conv_4_64_us': ms[0] * 1e3,
+                'trunk_conv_launches': len(trunk),
+                'trunk_conv_avg_us': t_ms * 1e3,
+                'trunk_conv_useful_tflops': gflop / t_ms,
+                'trunk_conv_frac_of_peak': gflop / t_ms / PEAK_TFLOPS['bf16'],
+                'note': 'useful = the 22 x 22 x 624 positions of a chunk (11 '
+                        'half rows x 3 column tiles of 8: 1.09 x of them are '
+                        'computed)'}
+        return n, el0, extra
     else:
         slicer = ChunkSlicer((400, 400), 720, 5, 12, (20, 20, 48),
                              spatial_pad=1, temporal_pad=2)
@@ -255,7 +284,7 @@ def c3_leg(batch, steps, warmup, world, rank, entry='strategy'):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     assert n == seen[0] == steps * batch, (n, seen[0], steps * batch)
-    return n, el
+    return n, el, extra
 
 
 # ---------------------------------------------------- power / clock evidence
@@ -673,10 +702,10 @@ def main():
     if args.mode == 'c3':
         b = args.batch or 8
         barrier()
-        # (>= 4 untimed batches: the ring of pinned 368 MB output buffers is
-        # 3 deep, each first allocation costs ~35 ms of hipHostMalloc)
-        n, el = c3_leg(b, args.steps, max(args.warmup, 4), world, rank,
-                       entry=args.c3_entry)
+        # (>= 5 untimed batches: the ring of pinned 368 MB delivery buffers is
+        # 4 deep, each first allocation costs 12 - 25 ms of hipHostMalloc)
+        n, el, extra = c3_leg(b, args.steps, max(args.warmup, 5), world, rank,
+                              entry=args.c3_entry)
         barrier()
         el = max_over_ranks(el)
         if rank == 0:
@@ -685,7 +714,7 @@ def main():
                              'domain tiled into 20x20x48 chunks, 5x/12x ST-GAN',
                 value=world * n / el, unit='chunks/s',
                 ms_per_step=el / args.steps * 1e3, scaling='weak',
-                dtype='bf16',
+                dtype='bf16', in_situ=extra,
                 px_per_sec=world * n / el * 100 * 100 * 576,
                 config={'workload': 'C3: gen_5x_12x_2f through ' + (
                     'ForwardPassChunk structures (ArrayStrategy.init_chunk '
@@ -859,6 +888,27 @@ def main():
                 value=x3['value'], unit=x3['unit'], steps=x3['steps'],
                 tolerance='gradients of both steps <= 1e-4 of the fp32 '
                           'oracle under the device masks')
+    if single and not args.no_train:
+        # the path ForwardPassStrategy drives (BASELINE.json config 3, one
+        # rank's share): ForwardPassChunk structures through iter_chunks, the
+        # cropped hi-res chunks delivered to the host
+        try:
+            n3, el3, extra3 = c3_leg(8, 16, 5, 1, 0)
+            result['c3'] = dict(
+                value=n3 / el3, unit='chunks/s', ms_per_step=el3 / 16 * 1e3,
+                steps=16, warmup=5, chunks_per_step=8,
+                px_per_sec=n3 / el3 * 100 * 100 * 576,
+                gflop_per_chunk=1872.0,
+                whole_path_tflops=n3 / el3 * 1.872,
+                workload='C3: 400x400x720 domain in 20x20x48 chunks + halo '
+                         '(22,22,52,4), 8 per launch sequence, through '
+                         'ForwardPass.get_input_chunk -> iter_chunks; cropped '
+                         '(100,100,576,2) fp32 chunks delivered to pinned host '
+                         'memory by SDMA under the next batch',
+                in_situ=extra3)
+        except Exception as e:              # a leg, never the headline
+            result['c3'] = {'error': repr(e)[:300]}
+        torch.cuda.empty_cache()
     if single and not args.no_traffic:
         traffic, note = measure_traffic(B)
         result['roofline']['traffic'] = traffic

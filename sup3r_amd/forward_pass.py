@@ -1014,6 +1014,7 @@ class ForwardPass:
             arr = np.ctypeslib.as_array(
                 (C.c_float * n).from_address(ptr.value)).reshape(shape)
             ring['bufs'].append((ptr.value, arr))
+            ring['next'] = len(ring['bufs']) % cls.d2h_ring
             return ring['bufs'][-1]
         buf = ring['bufs'][ring['next'] % cls.d2h_ring]
         ring['next'] += 1
