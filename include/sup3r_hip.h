@@ -511,10 +511,15 @@ int s3_allreduce_sum(s3_ctx* ctx, float* buf, int64_t n);
 /* Overlap with the backward pass: arm the store BEFORE the s3_plan_backward
  * call that finalises its gradients (need_wgrad; the last one when several
  * accumulate).  That call then hands the finished tail of the gradient buffer
- * to RCCL bucket by bucket (>= bucket_bytes each; <= 0: one bucket) on a second
+ * to RCCL bucket by bucket (>= bucket_bytes each; 0: one bucket) on a second
  * stream behind an event, so the xGMI traffic runs under the remaining
  * gradient kernels; the following s3_params_allreduce_grads only joins the two
- * streams.  Every rank arms the same store with the same bucket size. */
+ * streams.  Every rank arms the same store with the same bucket size.
+ * The backward pass CONSUMES the arming (also when it fails), bucket_bytes < 0
+ * disarms, and a context without a communicator is never armed: no later
+ * backward pass on the store can issue a collective the other ranks do not.
+ * A parameter layout whose offsets do not grow with the op order gets one
+ * reduction after the last op instead of buckets. */
 int s3_params_arm_allreduce(s3_params* p, int64_t bucket_bytes);
 /* replicas must start from identical weights (the reference's towers read ONE
  * set of tf.Variables, abstract.py:827-841): ncclBroadcast of a store buffer

@@ -1,25 +1,32 @@
-"""TF-free batch queue feeding the device.
+"""TF-free batch supply for training on the device.
 
-Mirrors ``AbstractBatchQueue`` / ``SingleBatchQueue``
-(sup3r/preprocessing/batch_queues/abstract.py:30-364, base.py:12-87): a
-dedicated thread keeps a FIFO of raw hi-res sample batches drawn from a list of
-samplers; ``__next__`` dequeues one, squeezes the time axis of spatial-only
-samples and runs ``transform`` — coarsening + smoothing, here on the GPU through
-``DeviceBatchTransform`` — into a ``DsetTuple(low_res, high_res)``.  The
-reference's FIFO is ``tf.queue.FIFOQueue`` (abstract.py:135-141) and therefore
-needs TensorFlow; this one is a ``queue.Queue`` and hands out device tensors.
+What ``Sup3rGan.train`` consumes from a batch handler is small: iterate it for
+``n_batches`` objects with ``.low_res`` / ``.high_res``, ``len()``, ``start()``
+/ ``stop()``, ``shapes``, ``means`` / ``stds``, ``s_enhance`` / ``t_enhance``,
+the feature lists and ``val_data`` (sup3r/models/base.py:624-828,1097-1191).
+The reference supplies that with ``AbstractBatchQueue`` + ``SingleBatchQueue``
+(sup3r/preprocessing/batch_queues/abstract.py:30-364, base.py:12-87) around a
+``tf.queue.FIFOQueue`` and numpy / scipy coarsening on the host; this module
+supplies the same surface — same constructor keywords, same attribute names —
+with its own machinery:
 
-Samplers are duck-typed exactly as the reference uses them: ``features``,
-``sample_shape`` (hi-res s1, s2, t), ``batch_size``, ``size`` (optional,
-relative sampling weight), ``next(sampler)`` -> (batch, s1, s2, t, features),
-and optionally ``lr_features`` / ``hr_features`` / ``hr_features_ind`` /
-``hr_out_features`` / ``hr_exo_features``.
+* a :class:`_Feeder` owns the background thread: it draws raw hi-res batches
+  from the samplers (weighted by their ``size``) into a bounded
+  ``queue.Queue`` until told to stop — no TensorFlow anywhere;
+* coarsening + smoothing (``SingleBatchQueue.transform``) run on the GPU
+  (:class:`~sup3r_amd.batch_transform.DeviceBatchTransform`) when a batch is
+  handed out, so what the training loop receives are device tensors.
+
+Samplers are duck-typed the way the reference uses them: ``features``,
+``sample_shape`` (hi-res s1, s2, t), ``batch_size``, optional ``size``
+(relative sampling weight) and ``compute()``, ``next(sampler)`` ->
+``(batch, s1, s2, t, features)``, optional ``lr_features`` / ``hr_features``
+/ ``hr_features_ind`` / ``hr_out_features`` / ``hr_exo_features``.
 """
 import logging
 import queue
 import threading
-import time
-from concurrent.futures import ThreadPoolExecutor, as_completed
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -28,35 +35,115 @@ from .utilities import Timer
 logger = logging.getLogger(__name__)
 
 
-class DsetTuple:
-    """namedtuple-like batch with dynamic attributes
-    (sup3r/preprocessing/base.py:73-98)"""
+class DsetTuple(dict):
+    """One batch: an ordered mapping member name -> array whose members are
+    attributes as well and which indexes by position like a tuple
+    (the role of sup3r/preprocessing/base.py:73-98)."""
 
-    def __init__(self, **kwargs):
-        self.dset_names = list(kwargs)
-        self.__dict__.update(kwargs)
+    def __init__(self, **members):
+        super().__init__(members)
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def __getitem__(self, key):
+        if isinstance(key, (int, np.integer)):
+            return tuple(self.values())[key]
+        return super().__getitem__(key)
+
+    def __iter__(self):
+        return iter(self.values())
+
+    @property
+    def dset_names(self):
+        return list(self.keys())
 
     @property
     def dsets(self):
-        return {k: v for k, v in self.__dict__.items() if k in self.dset_names}
+        return dict(self.items())
 
-    def __iter__(self):
-        return iter(self.dsets.values())
 
-    def __getitem__(self, key):
-        if isinstance(key, int):
-            key = list(self.dsets)[key]
-        return self.dsets[key]
+def _as_arrays(raw):
+    """a sampler's return value (an array, or a tuple of them for dual
+    samplers) as numpy"""
+    if isinstance(raw, tuple):
+        return tuple(np.asarray(a) for a in raw)
+    return np.asarray(raw)
 
-    def __len__(self):
-        return len(self.dsets)
 
-    def __repr__(self):
-        return f'DsetTuple({self.dsets})'
+class _Feeder:
+    """The background half of a queue: one daemon thread that keeps ``fifo``
+    topped up with whatever ``draw()`` returns, ``workers`` draws at a time
+    when a pool is given.  Restartable (a finished thread is replaced on the
+    next ``start``)."""
+
+    def __init__(self, draw, capacity, name, workers):
+        self.draw, self.name = draw, name
+        self.fifo = queue.Queue(maxsize=max(int(capacity), 0))
+        self.capacity = int(capacity)
+        self.workers = int(workers)
+        self.pool = ThreadPoolExecutor(max_workers=self.workers)
+        self.go = threading.Event()
+        self.thread = self._new_thread()
+
+    def _new_thread(self):
+        return threading.Thread(target=self._loop, name=self.name,
+                                daemon=True)
+
+    def _loop(self):
+        while self.go.is_set():
+            want = self.capacity - self.fifo.qsize()
+            if want <= 0:
+                self.go.wait(0.001)              # full: look again shortly
+                continue
+            if self.workers > 1 and want > 1:
+                drawn = list(self.pool.map(lambda _: self.draw(),
+                                           range(want)))
+            else:
+                drawn = (self.draw() for _ in range(want))
+            for item in drawn:
+                while self.go.is_set():
+                    try:
+                        self.fifo.put(item, timeout=0.05)
+                        break
+                    except queue.Full:
+                        continue
+
+    def start(self):
+        self.go.set()
+        if self.capacity <= 0 or self.thread.is_alive():
+            return
+        if self.thread.ident is not None:        # ran before: threads are
+            self.thread = self._new_thread()     # single-use
+        logger.info('%s queue: feeder thread started', self.name)
+        self.thread.start()
+
+    def stop(self):
+        self.go.clear()
+        if self.thread.is_alive():
+            self.thread.join()
+            logger.info('%s queue: feeder thread joined', self.name)
+
+    def take(self):
+        """next raw item, or None once the thread is gone and the FIFO empty"""
+        while True:
+            try:
+                return self.fifo.get(timeout=0.05)
+            except queue.Empty:
+                if not self.thread.is_alive():
+                    return None
+
+    @property
+    def backlog(self):
+        return self.fifo.qsize()
 
 
 class DeviceBatchQueue:
-    """Queue of hi-res sample batches, coarsened / smoothed on the device."""
+    """Hi-res sample batches from a list of samplers, coarsened / smoothed on
+    the device when they are handed out."""
 
     BATCH_MEMBERS = ('low_res', 'high_res')
 
@@ -64,118 +151,142 @@ class DeviceBatchQueue:
                  t_enhance=1, queue_cap=None, transform_kwargs=None,
                  max_workers=1, thread_name='training', mode='lazy',
                  verbose=False, transform=None, seed=None):
-        msg = (f'{self.__class__.__name__} requires a list of samplers. '
-               f'Received type {type(samplers)}')
-        assert isinstance(samplers, list), msg
+        assert isinstance(samplers, list), (
+            f'{type(self).__name__} requires a list of samplers. Received '
+            f'type {type(samplers)}')
         self.containers = samplers
-        self._batch_count = 0
-        self._queue_thread = None
-        self._training_flag = threading.Event()
-        self._thread_name = thread_name
-        self._thread_pool = ThreadPoolExecutor(max_workers=max_workers)
-        self._rng = np.random.default_rng(seed)
-        self.mode = mode
-        self.s_enhance = s_enhance
-        self.t_enhance = t_enhance
-        self.batch_size = batch_size
-        self.n_batches = n_batches
-        self.queue_cap = n_batches if queue_cap is None else queue_cap
-        self.max_workers = max_workers
-        self.container_index = self.get_container_index()
-        self.queue = queue.Queue(maxsize=max(self.queue_cap, 0))
-        self.lr_sample_shape = (self.hr_sample_shape[0] // s_enhance,
-                                self.hr_sample_shape[1] // s_enhance,
-                                self.hr_sample_shape[2] // t_enhance)
-        self.transform_kwargs = transform_kwargs or {'smoothing_ignore': [],
-                                                     'smoothing': None}
-        self.verbose = verbose
-        self.timer = Timer()
+        self.batch_size, self.n_batches = int(batch_size), int(n_batches)
+        self.s_enhance, self.t_enhance = int(s_enhance), int(t_enhance)
+        self.mode, self.verbose = mode, verbose
+        self.max_workers = int(max_workers)
+        self.queue_cap = self.n_batches if queue_cap is None else queue_cap
+        self.transform_kwargs = dict(transform_kwargs) if transform_kwargs \
+            else {'smoothing_ignore': [], 'smoothing': None}
         self._transform = transform
-        self.preflight()
+        self._rng = np.random.default_rng(seed)
+        self._rng_lock = threading.Lock()
+        self._handed_out = 0
+        self.container_index = 0
+        self.timer = Timer()
+        self._check_samplers()
+        self._feeder = _Feeder(self.sample_batch,
+                               0 if mode == 'eager' else self.queue_cap,
+                               thread_name, self.max_workers)
+        self._thread_name = thread_name
 
-    # ------------------------------------------------------------ collection
-    def check_shared_attr(self, attr):
-        """the attribute every sampler must agree on (collections/base.py)"""
-        vals = [getattr(c, attr) for c in self.containers]
-        first = vals[0]
-        msg = f'Samplers have different values of "{attr}": {vals}'
-        assert all(np.array_equal(np.asarray(v, dtype=object),
-                                  np.asarray(first, dtype=object))
-                   for v in vals), msg
-        return first
+    # ------------------------------------------------- what the samplers say
+    def _first(self, attr, default=None):
+        return getattr(self.containers[0], attr, default)
 
     @property
     def features(self):
-        return list(self.containers[0].features)
+        return list(self._first('features'))
 
     @property
     def sample_shape(self):
-        return tuple(self.containers[0].sample_shape)
+        return tuple(self._first('sample_shape'))
 
     hr_sample_shape = sample_shape
 
     @property
-    def hr_features_ind(self):
-        c = self.containers[0]
-        if hasattr(c, 'hr_features_ind'):
-            return list(c.hr_features_ind)
-        return [self.features.index(f) for f in self.hr_features]
+    def lr_sample_shape(self):
+        s1, s2, t = self.sample_shape
+        return (s1 // self.s_enhance, s2 // self.s_enhance,
+                t // self.t_enhance)
 
     @property
     def lr_features(self):
-        return list(getattr(self.containers[0], 'lr_features', self.features))
+        return list(self._first('lr_features', self.features))
 
     @property
     def hr_features(self):
-        return list(getattr(self.containers[0], 'hr_features', self.features))
+        return list(self._first('hr_features', self.features))
 
     @property
     def hr_out_features(self):
-        return list(getattr(self.containers[0], 'hr_out_features',
-                            self.hr_features))
+        return list(self._first('hr_out_features', self.hr_features))
 
     @property
     def hr_exo_features(self):
-        return list(getattr(self.containers[0], 'hr_exo_features', []))
+        return list(self._first('hr_exo_features', []))
+
+    @property
+    def hr_features_ind(self):
+        ind = self._first('hr_features_ind')
+        if ind is not None:
+            return list(ind)
+        feats = self.features
+        return [feats.index(f) for f in self.hr_features]
 
     @property
     def container_weights(self):
-        sizes = np.array([getattr(c, 'size', 1) for c in self.containers],
-                         dtype=np.float64)
-        return (sizes / sizes.sum()).astype(np.float32)
+        """sampling probability of each sampler: its share of the data"""
+        w = np.fromiter((getattr(c, 'size', 1) for c in self.containers),
+                        dtype=np.float64, count=len(self.containers))
+        return (w / w.sum()).astype(np.float32)
 
-    # --------------------------------------------------------------- checks
-    def preflight(self):
-        """Consistency of the samplers with each other and with the queue
-        (feature lists, sample shape vs enhancement factors, batch size);
-        eager mode materialises the sampler data first."""
-        self.check_features()
-        self.check_enhancement_factors()
-        self.check_shared_attr('sample_shape')
-        sizes = {int(c.batch_size) for c in self.containers}
-        assert sizes == {int(self.batch_size)}, (
-            f'Samplers have a different batch_size: {sorted(sizes)} than the '
-            f'BatchQueue: {self.batch_size}')
-        if self.mode == 'eager':
-            logger.info('Received mode = "eager".')
-            for c in self.containers:
-                getattr(c, 'compute', lambda: None)()
-
-    def check_features(self):
-        ref = self.features
+    def _check_samplers(self):
+        """the samplers must describe ONE kind of batch, and that batch must
+        coarsen to whole cells; 'eager' mode loads their data up front"""
+        feats, shape = self.features, self.sample_shape
         for c in self.containers[1:]:
-            assert list(c.features) == ref, \
+            assert list(c.features) == feats, \
                 'Received samplers with different sets of features.'
+            assert tuple(c.sample_shape) == shape, (
+                'Samplers have different values of "sample_shape": '
+                f'{[tuple(k.sample_shape) for k in self.containers]}')
+        seen = sorted({int(c.batch_size) for c in self.containers})
+        assert seen == [self.batch_size], (
+            f'Samplers have a different batch_size: {seen} than the '
+            f'BatchQueue: {self.batch_size}')
+        rem = (shape[0] % self.s_enhance, shape[1] % self.s_enhance,
+               shape[2] % self.t_enhance)
+        assert not any(rem), (
+            f'The sample_shape {shape} is not consistent with the '
+            f'enhancement factors {self.s_enhance, self.t_enhance}.')
+        if self.mode == 'eager':
+            logger.info('mode "eager": loading the sampler data now')
+            for c in self.containers:
+                if hasattr(c, 'compute'):
+                    c.compute()
 
-    def check_enhancement_factors(self):
-        s1, s2, t = self.sample_shape
-        ok = not (s1 % self.s_enhance or s2 % self.s_enhance
-                  or t % self.t_enhance)
-        assert ok, (f'The sample_shape {self.sample_shape} is not consistent '
-                    'with the enhancement factors '
-                    f'{self.s_enhance, self.t_enhance}.')
+    # ----------------------------------------------------------- raw batches
+    def get_random_container(self):
+        with self._rng_lock:                     # (pool workers draw too)
+            self.container_index = int(self._rng.choice(
+                len(self.containers), p=self.container_weights))
+        return self.containers[self.container_index]
 
-    # ------------------------------------------------------------ transform
+    def sample_batch(self):
+        """one raw batch from a sampler picked by weight"""
+        return _as_arrays(next(self.get_random_container()))
+
+    @property
+    def queue_thread(self):
+        return self._feeder.thread
+
+    @property
+    def queue_len(self):
+        return self._feeder.backlog
+
+    @property
+    def running(self):
+        return self._feeder.go.is_set()
+
+    def start(self):
+        """Keep the FIFO of raw batches full from now on (no-op in eager
+        mode and for ``queue_cap`` 0: batches are then drawn on demand)."""
+        self._feeder.start()
+
+    def stop(self):
+        """Stop drawing and join the feeder thread."""
+        self._feeder.stop()
+
+    def log_queue_info(self):
+        return (f'{self._thread_name.title()} queue length: '
+                f'{self.queue_len} / {self.queue_cap}')
+
+    # -------------------------------------------------------- handing out
     def transform(self, samples, smoothing=None, smoothing_ignore=None,
                   temporal_coarsening_method='subsample'):
         """``SingleBatchQueue.transform`` (batch_queues/base.py:32-87) on the
@@ -191,159 +302,57 @@ class DeviceBatchQueue:
             temporal_coarsening_method=temporal_coarsening_method)
 
     def post_proc(self, samples):
-        tsamps = self.transform(samples, **self.transform_kwargs)
-        return DsetTuple(**dict(zip(self.BATCH_MEMBERS, tsamps)))
+        return DsetTuple(**dict(zip(
+            self.BATCH_MEMBERS,
+            self.transform(samples, **self.transform_kwargs))))
 
-    # ---------------------------------------------------------------- queue
-    @property
-    def queue_shape(self):
-        return [(self.batch_size, *self.hr_sample_shape, len(self.features))]
+    def get_batch(self):
+        """the next batch: a raw one from the feeder (drawn on the spot when
+        no feeder runs), the length-1 time axis of spatial-only samples
+        dropped, coarsened / smoothed"""
+        raw = self._feeder.take() if self.queue_thread.is_alive() else None
+        if raw is None:
+            raw = self.sample_batch()
+        if self.sample_shape[2] == 1:
+            raw = tuple(a[..., 0, :] for a in raw) \
+                if isinstance(raw, tuple) else raw[..., 0, :]
+        return self.post_proc(raw)
 
-    @property
-    def queue_len(self):
-        return self.queue.qsize() + self.queue_futures
-
-    @property
-    def queue_futures(self):
-        return self._thread_pool._work_queue.qsize()
-
-    @property
-    def queue_thread(self):
-        if self._queue_thread is None or not self._queue_thread.is_alive() \
-                and self._queue_thread.ident is not None:
-            self._queue_thread = threading.Thread(
-                target=self.enqueue_batches, name=self._thread_name,
-                daemon=True)
-        return self._queue_thread
-
-    def start(self):
-        """Start thread to keep sample queue full for batches."""
-        self._training_flag.set()
-        if (not self.queue_thread.is_alive() and self.mode == 'lazy'
-                and self.queue_cap > 0):
-            logger.info(f'Starting {self._thread_name} queue.')
-            self.queue_thread.start()
-
-    def stop(self):
-        """Stop loading batches."""
-        self._training_flag.clear()
-        thread = self._queue_thread
-        if thread is not None and thread.is_alive():
-            logger.info(f'Stopping {self._thread_name} queue.')
-            thread.join()
-
-    @property
-    def running(self):
-        return self._training_flag.is_set()
-
-    def sample_batches(self, n_batches):
-        """``n_batches`` raw batches: a list of arrays, or of futures when the
-        thread pool has more than one worker"""
-        if self.max_workers > 1 and n_batches > 1:
-            return [self._thread_pool.submit(self.sample_batch)
-                    for _ in range(n_batches)]
-        return [self.sample_batch() for _ in range(n_batches)]
-
-    def enqueue_batches(self):
-        """Body of the queue thread: top the FIFO up to ``queue_cap`` until
-        ``stop()`` clears the flag."""
-        last_log = time.time()
-        while self.running:
-            room = self.queue_cap - self.queue.qsize()
-            if room <= 0:
-                time.sleep(0.001)
-            else:
-                for item in self.sample_batches(room):
-                    done = item.result() if hasattr(item, 'result') else item
-                    if not self._put(done):
-                        break
-            if time.time() - last_log > 60:
-                logger.debug(self.log_queue_info())
-                last_log = time.time()
-
-    def _put(self, batch):
-        """blocking put that gives up when the queue is stopped"""
-        while self.running:
-            try:
-                self.queue.put(batch, timeout=0.05)
-                return True
-            except queue.Full:
-                pass
-        return False
-
-    def get_container_index(self):
-        indices = np.arange(0, len(self.containers))
-        return int(self._rng.choice(indices, p=self.container_weights))
-
-    def get_random_container(self):
-        self.container_index = self.get_container_index()
-        return self.containers[self.container_index]
-
-    def sample_batch(self):
-        """a batch of samples from a randomly chosen sampler, in memory"""
-        out = next(self.get_random_container())
-        if not isinstance(out, tuple):
-            return np.asarray(out)
-        return tuple(np.asarray(o) for o in out)
-
-    # ------------------------------------------------------------- iteration
     def __len__(self):
         return self.n_batches
 
     def __iter__(self):
-        self._batch_count = 0
+        self._handed_out = 0
         self.start()
         return self
 
-    def get_batch(self):
-        """next raw batch (from the FIFO while its thread is alive, otherwise
-        sampled on the spot), time axis squeezed for spatial-only samples,
-        then ``post_proc``"""
-        use_queue = (self.mode != 'eager' and self.queue_cap > 0
-                     and self.queue_thread.is_alive())
-        samples = None
-        while use_queue and samples is None:
-            try:
-                samples = self.queue.get(timeout=0.05)
-            except queue.Empty:
-                use_queue = self.queue_thread.is_alive()
-        if samples is None:
-            samples = self.sample_batch()
-        if self.sample_shape[2] == 1:
-            squeeze = lambda a: a[..., 0, :]          # noqa: E731
-            samples = (tuple(squeeze(a) for a in samples)
-                       if isinstance(samples, (list, tuple))
-                       else squeeze(samples))
-        return self.post_proc(samples)
-
     def __next__(self):
-        if self._batch_count < self.n_batches:
-            batch = self.timer(self.get_batch, log=self.verbose)()
-            self._batch_count += 1
-        else:
+        if self._handed_out >= self.n_batches:
             raise StopIteration
-        return batch
+        self._handed_out += 1
+        return self.timer(self.get_batch, log=self.verbose)()
 
-    def log_queue_info(self):
-        return '{} queue length: {} / {}'.format(
-            self._thread_name.title(), self.queue_len, self.queue_cap)
-
+    # --------------------------------------------------------------- shapes
     @property
     def lr_shape(self):
-        return (*self.lr_sample_shape, len(self.lr_features))
+        return self.lr_sample_shape + (len(self.lr_features),)
 
     @property
     def hr_shape(self):
-        return (*self.hr_sample_shape, len(self.hr_features))
+        return self.sample_shape + (len(self.hr_features),)
+
+    @property
+    def queue_shape(self):
+        return [(self.batch_size,) + self.sample_shape
+                + (len(self.features),)]
 
     @property
     def shapes(self):
-        """Shapes of batches returned by ``__next__``"""
-        lr_shape, hr_shape = self.lr_shape, self.hr_shape
-        if self.sample_shape[2] == 1:
-            lr_shape = (*lr_shape[:2], lr_shape[-1])
-            hr_shape = (*hr_shape[:2], hr_shape[-1])
-        return (self.batch_size, *lr_shape), (self.batch_size, *hr_shape)
+        """(low_res, high_res) shapes of the batches ``__next__`` returns"""
+        lr, hr = self.lr_shape, self.hr_shape
+        if self.sample_shape[2] == 1:            # spatial-only: no time axis
+            lr, hr = lr[:2] + lr[3:], hr[:2] + hr[3:]
+        return (self.batch_size,) + lr, (self.batch_size,) + hr
 
 
 class DeviceBatchHandler(DeviceBatchQueue):
@@ -359,48 +368,41 @@ class DeviceBatchHandler(DeviceBatchQueue):
                  n_batches=64, s_enhance=1, t_enhance=1, means=None, stds=None,
                  queue_cap=None, transform_kwargs=None, max_workers=1,
                  mode='lazy', transform=None, seed=None):
-        feats = list(train_samplers[0].features)
-        self.means = dict(means) if means is not None else {
-            f: np.float32(0.0) for f in feats}
-        self.stds = dict(stds) if stds is not None else {
-            f: np.float32(1.0) for f in feats}
-        if not val_samplers:
-            self.val_data = []
-        else:
-            self.val_data = DeviceBatchQueue(
-                samplers=val_samplers, n_batches=n_batches,
-                thread_name='validation', batch_size=batch_size,
-                s_enhance=s_enhance, t_enhance=t_enhance, queue_cap=queue_cap,
-                transform_kwargs=transform_kwargs, max_workers=max_workers,
-                mode=mode, transform=transform, seed=seed)
-        super().__init__(samplers=train_samplers, n_batches=n_batches,
-                         batch_size=batch_size, s_enhance=s_enhance,
-                         t_enhance=t_enhance, queue_cap=queue_cap,
-                         transform_kwargs=transform_kwargs,
-                         max_workers=max_workers, mode=mode,
-                         transform=transform, seed=seed)
+        common = dict(batch_size=batch_size, n_batches=n_batches,
+                      s_enhance=s_enhance, t_enhance=t_enhance,
+                      queue_cap=queue_cap, transform_kwargs=transform_kwargs,
+                      max_workers=max_workers, mode=mode, transform=transform,
+                      seed=seed)
+        super().__init__(samplers=train_samplers, **common)
+        self.val_data = DeviceBatchQueue(
+            samplers=val_samplers, thread_name='validation',
+            **common) if val_samplers else []
+        feats = self.features
+        self.means = {f: np.float32(0.0) for f in feats} if means is None \
+            else dict(means)
+        self.stds = {f: np.float32(1.0) for f in feats} if stds is None \
+            else dict(stds)
 
     @property
     def smoothing(self):
-        return self.transform_kwargs.get('smoothing', None)
+        return self.transform_kwargs.get('smoothing')
 
     @property
     def smoothed_features(self):
-        ignore = self.transform_kwargs.get('smoothing_ignore', None) or []
         if self.smoothing is None:
             return []
-        return [f for f in self.lr_features if f not in ignore]
+        skip = self.transform_kwargs.get('smoothing_ignore') or ()
+        return [f for f in self.lr_features if f not in skip]
+
+    def _both(self, what):
+        if isinstance(self.val_data, DeviceBatchQueue):
+            getattr(self.val_data, what)()
+        getattr(DeviceBatchQueue, what)(self)
 
     def start(self):
-        """Start the val data batch queue in addition to the train batch
-        queue."""
-        if hasattr(self.val_data, 'start'):
-            self.val_data.start()
-        super().start()
+        """start the validation queue along with the training queue"""
+        self._both('start')
 
     def stop(self):
-        """Stop the val data batch queue in addition to the train batch
-        queue."""
-        if hasattr(self.val_data, 'stop'):
-            self.val_data.stop()
-        super().stop()
+        """stop both queues"""
+        self._both('stop')

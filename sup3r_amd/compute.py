@@ -409,7 +409,17 @@ class HipGanCompute:
                         n_pos, wq, self._ptr(scal, base + SLOTS_PER_TERM * q),
                         self._ptr(dgq) if dgq is not None else None, 1)
                     _lib.check(rc, dev.ctx, 's3_loss_content_masked')
-                obs_info = (base, n_tot, n_obs, float(w_obs or 0.0))
+                # the counts travel WITH the sums (two spare slots of the
+                # observed term): under sharded / multi-GPU steps the loss
+                # scalars of the shards are added (and all-reduced), and every
+                # shard draws its own mask — the ratio n_tot / n_obs of the
+                # details must be the one of the summed cells, not the last
+                # shard's
+                for q, cnt in ((1, n_obs), (2, n_tot)):
+                    rc = L.s3_fill(dev.ctx, self._ptr(scal, base + q), 1,
+                                   float(cnt))
+                    _lib.check(rc, dev.ctx, 's3_fill')
+                obs_info = (base, float(w_obs or 0.0))
             if need_disc:
                 # adversarial term: roles swapped (base.py:899-901); only
                 # D(gen) depends on the generator
@@ -431,8 +441,12 @@ class HipGanCompute:
                     d_hr_gen = d_gen_full
                 if overlap_bucket:
                     self.gen.arm_allreduce(overlap_bucket)
-                gph.backward(d_hr_gen, need_wgrad=True,
-                             accumulate_wgrad=accumulate_wgrad)
+                try:
+                    gph.backward(d_hr_gen, need_wgrad=True,
+                                 accumulate_wgrad=accumulate_wgrad)
+                except BaseException:
+                    self.gen.arm_allreduce(-1)          # disarm
+                    raise
             loss_key = 'loss_gen'
         elif train_disc:
             if disc_train:
@@ -440,7 +454,12 @@ class HipGanCompute:
                                accumulate_wgrad=accumulate_wgrad)
                 if overlap_bucket:
                     self.disc.arm_allreduce(overlap_bucket)
-                dph_g.backward(g_g, need_wgrad=True, accumulate_wgrad=True)
+                try:
+                    dph_g.backward(g_g, need_wgrad=True,
+                                   accumulate_wgrad=True)
+                except BaseException:
+                    self.disc.arm_allreduce(-1)         # disarm
+                    raise
             loss_key = 'loss_disc'
         with_disc = need_disc and (compute_disc or train_disc)
         coefs = term_coefs if train_gen else None
@@ -451,7 +470,10 @@ class HipGanCompute:
                                        train_gen, need_disc,
                                        weight_gen_advers)
             if obs_info is not None:
-                base, n_tot, n_obs, w_obs = obs_info
+                base, w_obs = obs_info
+                # (summed over the shards like the losses: their ratio is what
+                # matters, any common scale of the future cancels)
+                n_obs, n_tot = float(vals[base + 1]), float(vals[base + 2])
                 n_non = n_tot - n_obs
                 l_obs = float(vals[base]) * n_tot / n_obs if n_obs else \
                     float('nan')

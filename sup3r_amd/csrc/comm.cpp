@@ -114,7 +114,7 @@ static int comm_stream_ready(s3_ctx* ctx) {
   return S3_OK;
 }
 
-extern "C" int s3_comm_reduce_range(s3_ctx* ctx, float* buf, int64_t n) {
+extern "C" S3_INTERNAL int s3_comm_reduce_range(s3_ctx* ctx, float* buf, int64_t n) {
   if (!ctx || !buf || n <= 0) return S3_EINVAL;
   if (!ctx->comm) return S3_OK;               // single rank: nothing to sum
   int rc = comm_stream_ready(ctx);

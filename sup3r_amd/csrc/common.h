@@ -418,10 +418,13 @@ int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
 int launch_optimizer(s3_ctx* ctx, int kind, float* w, const float* g, float* m, float* v,
                      int64_t n, const float* h);
 int launch_fill(s3_ctx* ctx, float* p, int64_t n, float v);
+// (cross-file helpers of the library, not part of its ABI: hidden, so that the
+// .so exports exactly what include/sup3r_hip.h declares — tests/test_abi.py)
+#define S3_INTERNAL __attribute__((visibility("hidden")))
 // comm.cpp: SUM over the ranks of buf[0 .. n) on the context's comm stream,
 // after everything enqueued so far on its compute stream
-extern "C" int s3_comm_reduce_range(s3_ctx* ctx, float* buf, int64_t n);
-extern "C" int s3_params_take_armed(s3_params* p, int* n_buckets);
+extern "C" S3_INTERNAL int s3_comm_reduce_range(s3_ctx* ctx, float* buf, int64_t n);
+extern "C" S3_INTERNAL int s3_params_take_armed(s3_params* p, int* n_buckets);
 int launch_mean_abs(s3_ctx* ctx, const float* p, int64_t n, float* out_dev);
 int ensure_scratch(s3_ctx* ctx, size_t bytes);
 

@@ -24,7 +24,8 @@ struct s3_params {
   uint64_t version = 1;  // bumped whenever W changes (re-pack trigger)
   // bucketed gradient all-reduce under the backward pass (s3_params_arm_allreduce):
   // [0, reduce_end) of the gradient buffer is not yet handed to RCCL
-  bool armed = false;
+  bool armed = false;     // the next backward pass that writes G reduces it as it goes
+  bool reduced = false;   // ... and has done so: s3_params_allreduce_grads only joins
   int64_t reduce_end = 0, bucket_elems = 0;
   int buckets_issued = 0;
 };
@@ -379,6 +380,16 @@ extern "C" int s3_adam_step(s3_params* p, float lr, float beta1, float beta2,
 
 extern "C" int s3_params_arm_allreduce(s3_params* p, int64_t bucket_bytes) {
   if (!p) return S3_EINVAL;
+  // bucket_bytes < 0 disarms (the caller's try / finally around the backward
+  // pass it armed for); without a communicator there is nothing to overlap —
+  // an armed store would only leave a flag behind for a later backward pass
+  p->reduced = false;
+  if (bucket_bytes < 0 || !p->ctx || !p->ctx->comm) {
+    p->armed = false;
+    p->reduce_end = 0;
+    p->buckets_issued = 0;
+    return S3_OK;
+  }
   p->armed = true;
   p->reduce_end = p->total;
   p->bucket_elems = bucket_bytes > 0 ? bucket_bytes / (int64_t)sizeof(float) : p->total;
@@ -390,12 +401,16 @@ extern "C" int s3_params_arm_allreduce(s3_params* p, int64_t bucket_bytes) {
 // reduction covered the whole buffer (the caller only joins the streams),
 // 0 = nothing was armed (reduce the whole buffer now), -1 = armed but the
 // backward pass did not reach the start of the buffer
-extern "C" int s3_params_take_armed(s3_params* p, int* n_buckets) {
-  if (!p || !p->armed) return 0;
-  const bool complete = p->reduce_end == 0;
+extern "C" S3_INTERNAL int s3_params_take_armed(s3_params* p, int* n_buckets) {
+  if (!p) return 0;
   if (n_buckets) *n_buckets = p->buckets_issued;
-  p->armed = false;
-  return complete ? 1 : -1;
+  if (p->reduced) {        // an armed backward pass covered the buffer
+    p->reduced = false;
+    return 1;
+  }
+  if (!p->armed) return 0;
+  p->armed = false;        // armed, but no backward pass wrote the gradients
+  return -1;
 }
 
 // Hyper-parameters arrive as doubles (they are Python floats in the keras
@@ -1548,9 +1563,27 @@ static const float* grad_of(s3_plan* pl, int r) {
   return pl->gwritten[r] == 2 ? pl->gsrc[r] : pl->t[r].gptr;
 }
 
+static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, int need_wgrad,
+                              int accumulate_wgrad);
+
 extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input,
                                 int need_wgrad, int accumulate_wgrad) {
   if (!pl || !d_output) return S3_EINVAL;
+  const int rc = plan_backward_impl(pl, d_output, d_input, need_wgrad, accumulate_wgrad);
+  if (rc != S3_OK && pl->params && (pl->params->armed || pl->params->reduced)) {
+    pl->params->reduced = false;
+    // an armed store must not outlive the backward pass it was armed for: the
+    // next one on this store (a validation step, a non-sharded step) would
+    // enqueue collectives the other ranks never issue
+    pl->params->armed = false;
+    pl->params->reduce_end = 0;
+    pl->params->buckets_issued = 0;
+  }
+  return rc;
+}
+
+static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, int need_wgrad,
+                              int accumulate_wgrad) {
   s3_ctx* ctx = pl->ctx;
   S3OptScope opt_scope(&pl->opt);
   if (!pl->training) S3_FAIL(ctx, S3_ESTATE, "backward on an inference plan");
@@ -1558,6 +1591,30 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
   s3_params* P = pl->params;
   float* W = P->buf[S3_BUF_W];
   float* G = P->buf[S3_BUF_G];
+  // (gradients about to be rewritten: a reduction nobody joined is moot)
+  if (need_wgrad) P->reduced = false;
+  if (need_wgrad && P->armed) {
+    // the bucketed reduction hands over "everything at or above this op's
+    // lowest offset" as the walk passes an op: true only if the parameter
+    // offsets grow with the op order and no parameter is shared between ops.
+    // Checked here, once per armed pass; a store laid out any other way gets
+    // ONE reduction of the whole buffer after the last op instead.
+    int64_t prev_end = 0;
+    bool monotone = true;
+    for (size_t i = 0; i < pl->ops.size() && monotone; ++i) {
+      const s3_op_desc& d = pl->ops[i].d;
+      int64_t lo = INT64_MAX, hi = -1;
+      for (int id : {d.w, d.b}) {
+        if (id < 0) continue;
+        lo = std::min(lo, P->p[id].offset);
+        hi = std::max(hi, P->p[id].offset + P->p[id].size);
+      }
+      if (hi < 0) continue;
+      if (lo < prev_end) monotone = false;
+      prev_end = hi;
+    }
+    if (!monotone) P->bucket_elems = P->total + 1;
+  }
   std::fill(pl->gwritten.begin(), pl->gwritten.end(), 0);
   pl->premasked.assign(pl->gwritten.size(), 0);
   pl->gsrc.assign(pl->gwritten.size(), nullptr);
@@ -2003,6 +2060,10 @@ extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input
       P->reduce_end = 0;
       P->buckets_issued++;
     }
+    // consumed: a later backward pass on this store issues no collective
+    // unless it is armed again
+    P->armed = false;
+    P->reduced = true;
   }
   if (d_input) {
     if (x_id < 0 || !pl->gwritten[x_id]) S3_FAIL(ctx, S3_ESTATE, "backward: no gradient reached the input");

@@ -472,7 +472,9 @@ class Network:
 
     def arm_allreduce(self, bucket_bytes):
         """the next backward pass that writes this store's gradients reduces
-        them over the ranks bucket by bucket while it runs"""
+        them over the ranks bucket by bucket while it runs (``bucket_bytes``
+        < 0 disarms; without a communicator arming is a no-op).  The pass
+        consumes the arming — also when it fails."""
         rc = _lib.lib().s3_params_arm_allreduce(self.params,
                                                 int(bucket_bytes))
         _lib.check(rc, self.dev.ctx, 's3_params_arm_allreduce')

@@ -424,7 +424,10 @@ class ForwardPass:
         from . import _lib
         model, sl = self.model, self.slicer
         gen = getattr(model, '_gen', None)
+        # (models that override generate — SolarCC's temporal padding — or
+        # that a user registered do not declare a device chunk path)
         simple = (gen is not None and getattr(model, 'is_5d', False)
+                  and getattr(model, 'supports_device_chunks', False)
                   and not getattr(model, 'hr_exo_features', [])
                   and domain.shape[-1] == len(model.lr_features))
         if not simple:
@@ -1122,6 +1125,7 @@ class ForwardPass:
         model = self.model
         if getattr(model, '_gen', None) is not None and \
                 getattr(model, 'is_5d', False) and \
+                getattr(model, 'supports_device_chunks', False) and \
                 not getattr(model, 'hr_exo_features', []) and \
                 domain.shape[-1] == len(getattr(model, 'lr_features', [])):
             return self.run_batched(domain, out=out, writer=writer,

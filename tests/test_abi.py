@@ -30,6 +30,23 @@ def test_library_exports_every_declared_symbol():
     assert b'gfx950' in L.s3_version()
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """exported == declared: cross-file helpers (s3_comm_reduce_range,
+    s3_params_take_armed leaked through round 3) are hidden"""
+    import subprocess
+    from sup3r_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libsup3r_hip.so not built (run __graft_entry__.build())')
+    nm = '/opt/rocm/lib/llvm/bin/llvm-nm'
+    if not os.path.exists(nm):
+        nm = 'nm'
+    out = subprocess.run([nm, '-D', '--defined-only', _lib.LIB_PATH],
+                         capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines()
+                       if re.search(r' [TW] s3_', ln)})
+    assert exported == _declared()
+
+
 def test_struct_layouts():
     from sup3r_amd import _lib
     assert C.sizeof(_lib.TensorDesc) == 40

@@ -86,6 +86,35 @@ def test_chunked_equals_unchunked():
     np.testing.assert_array_equal(out1, full)
 
 
+def test_models_without_a_device_chunk_path_take_the_generate_loop():
+    """a model that carries an engine network (``_gen``) but
+    overrides ``generate`` (``SolarCC``: ``supports_device_chunks = False``)
+    must reach ``run_chunks`` from ``run_batched`` and ``run_domain`` too — the
+    device path would bypass the override."""
+    class Overriding(LocalModel):
+        _gen = object()                      # "has a device network"
+        supports_device_chunks = False
+        lr_features = ['a', 'b']
+        hr_exo_features = []
+        calls = 0
+
+        def generate(self, x, exogenous_data=None):
+            type(self).calls += 1
+            return super().generate(x, exogenous_data)
+    rng = np.random.default_rng(1)
+    domain = rng.standard_normal((10, 9, 8, 2))
+    model = Overriding()
+    s = ChunkSlicer((10, 9), 8, 2, 3, (5, 5, 4), spatial_pad=1,
+                    temporal_pad=1)
+    for runner in ('run_domain', 'run_batched'):
+        Overriding.calls = 0
+        out = np.zeros(s.hr_shape + (2,))
+        n = getattr(ForwardPass(model, s), runner)(domain, out=out)
+        assert n == s.n_chunks == Overriding.calls, runner
+        np.testing.assert_allclose(out, model.generate(domain[None])[0],
+                                   atol=1e-12)
+
+
 def test_output_check_and_errors():
     assert ForwardPass._output_check(np.full((4, 4, 4, 1), np.nan))
     assert ForwardPass._output_check(np.ones((4, 4, 4, 2)))

@@ -257,5 +257,34 @@ def test_bucketed_allreduce_under_the_backward_pass_single_rank():
                 np.testing.assert_array_equal(a, b)
         for a, b in zip(w1, w0):
             np.testing.assert_array_equal(a, b)
+    # the arming belongs to ONE backward pass: consumed by it,
+    # removable by the caller, never set without a communicator
+    Sup3rGan.seed(4)
+    m = Sup3rGan(os.path.join(cfg, 'test_gen_st_2x_4x_2f.json'),
+                 os.path.join(cfg, 'test_disc_st_same.json'),
+                 loss='MeanAbsoluteError', learning_rate=1e-3)
+    m.init_weights(lr.shape, hr.shape)
+    kw = dict(train_gen=True, train_disc=False)
+    m._compute.loss_and_grads(lr, hr, m._loss_terms, weight_gen_advers=1e-2,
+                              overlap_bucket=4096, **kw)
+    before = dev.stat('bucket_elems')
+    # (no allreduce_grads in between — as after an exception in the caller)
+    m._compute.loss_and_grads(lr, hr, m._loss_terms, weight_gen_advers=1e-2,
+                              **kw)
+    dev.sync()
+    assert dev.stat('bucket_elems') == before
+    m.generator.arm_allreduce(4096)
+    m.generator.arm_allreduce(-1)
+    m._compute.loss_and_grads(lr, hr, m._loss_terms, weight_gen_advers=1e-2,
+                              **kw)
+    m._compute.allreduce_grads('gen')        # nothing armed: the plain SUM
+    dev.sync()
+    assert dev.stat('bucket_elems') == before
     L.s3_comm_destroy(dev.ctx)
     dev.rank, dev.nranks = 0, 1
+    m.generator.arm_allreduce(4096)          # no communicator: a no-op
+    m._compute.loss_and_grads(lr, hr, m._loss_terms, weight_gen_advers=1e-2,
+                              **kw)
+    m._compute.allreduce_grads('gen')
+    dev.sync()
+    assert dev.stat('bucket_elems') == before

@@ -14,7 +14,7 @@ if __name__ == '__main__':
     pr = cProfile.Profile()
     t0 = time.perf_counter()
     pr.enable()
-    n, el = bench.c3_leg(8, 4, 2, 1, 0, entry='strategy')
+    n, el, _ = bench.c3_leg(8, 4, 2, 1, 0, entry='strategy')
     pr.disable()
     print('chunks', n, 'seconds', el, 'chunks/s', n / el)
     pstats.Stats(pr).sort_stats('cumulative').print_stats(35)
