@@ -233,7 +233,9 @@ enum {
                                   repeat of this factor; a repeat op: 1 = absorbed
                                   by its consumer (no launch)                   */
   S3_OPINFO_RES_REP = 10,      /* ... and its residual operand                  */
-  S3_OPINFO_COUNT = 11
+  S3_OPINFO_DGRAD_FRAME16 = 11, /* the padded-frame data gradient is stored as
+                                  bf16 between the conv kernel and its fold    */
+  S3_OPINFO_COUNT = 12
 };
 enum {
   S3_FWD_DIRECT = 0, S3_FWD_MFMA_TILE = 1, S3_FWD_MFMA_PERSIST = 2, S3_FWD_GCONV = 3,

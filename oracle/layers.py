@@ -31,10 +31,35 @@ import numpy as np
 def round_bf16(x):
     """fp32 -> bfloat16 (round to nearest even) -> back, any float dtype."""
     a = np.ascontiguousarray(x, dtype=np.float32)
-    u = a.view(np.uint32).astype(np.uint64)
-    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
-    out = u.astype(np.uint32).view(np.float32).reshape(a.shape)
+    # in 32-bit arithmetic: the rounding increment cannot wrap for finite
+    # values (biased exponent < 0xFF), and Inf / NaN keep their class
+    u = a.view(np.uint32)
+    r = (u >> np.uint32(16)) & np.uint32(1)
+    r += np.uint32(0x7FFF)
+    r += u
+    r &= np.uint32(0xFFFF0000)
+    special = (u & np.uint32(0x7F800000)) == np.uint32(0x7F800000)
+    if special.any():
+        r[special] = u[special] & np.uint32(0xFFFF0000)
+        nan = special & ((u & np.uint32(0x007FFFFF)) != 0)
+        r[nan] |= np.uint32(0x00400000)
+    out = r.view(np.float32).reshape(a.shape)
     return out.astype(np.asarray(x).dtype, copy=False)
+
+
+def _limit_blas_threads():
+    """The oracle's GEMMs are tall and skinny (1e5 positions x 64 channels):
+    OpenBLAS at its default of 64 threads on the 256-CPU GPU host ran them
+    4 x SLOWER than at 8 (tools/dbg/blas_threads.py: 0.51 s vs 0.13 s per
+    full-size C2 conv), which was most of the GPU suite's wall time."""
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=8, user_api='blas')
+    except Exception:        # no threadpoolctl: slower, not wrong
+        pass
+
+
+_limit_blas_threads()
 
 
 def _tuple(v, n):
@@ -82,6 +107,10 @@ class FlexiblePadding(Layer):
     def backward(self, dy):
         # adjoint of the gather x_pad = x[idx]: scatter-add through the same
         # index map, one axis at a time
+        if getattr(self, 'emu_grad_round', False):
+            # (the device keeps the padded-frame data gradient of the conv
+            # behind this pad as bf16 between its kernel and the fold)
+            dy = round_bf16(dy)
         dx = dy
         for ax, (lo, hi) in enumerate(self.paddings):
             if lo == 0 and hi == 0:
@@ -93,13 +122,15 @@ class FlexiblePadding(Layer):
                 dx = dx[tuple(sl)]
                 continue
             idx = np.pad(np.arange(n), (lo, hi), mode=self._np_mode())
-            out_shape = list(dx.shape)
-            out_shape[ax] = n
-            out = np.zeros(out_shape, dtype=dx.dtype)
             dxm = np.moveaxis(dx, ax, 0)
-            outm = np.moveaxis(out, ax, 0)
-            np.add.at(outm, idx, dxm)
-            dx = out
+            # the un-padded middle maps one to one (a bulk copy); the lo + hi
+            # border planes are added one by one in index order — what
+            # np.add.at(out, idx, dx) does, without its per-element dispatch
+            # (6 s of a full-size C2 backward pass)
+            outm = np.array(dxm[lo:lo + n])
+            for j in list(range(lo)) + list(range(lo + n, lo + n + hi)):
+                outm[idx[j]] += dxm[j]
+            dx = np.moveaxis(outm, 0, ax)
         return dx
 
 
@@ -223,16 +254,42 @@ class ConvND(Layer):
         w = self.kernel.astype(x.dtype, copy=False)
         if getattr(self, 'emu_fwd_round', False):
             x, w = round_bf16(x), round_bf16(w)
-        y = np.zeros((n * int(np.prod(out_sp)), self.filters), dtype=x.dtype)
-        for tap in np.ndindex(*self.kernel_size):
-            xs = x[self._tap_slices(tap)]
-            y += xs.reshape(-1, cin) @ w[tap]
-        y = y.reshape((n,) + out_sp + (self.filters,))
+        if all(s == 1 for s in self.strides):
+            # unit strides: in the FLAT index of the padded array a tap is a
+            # constant offset, so x[p + tap] for every output position p is
+            # the contiguous slice x2[off:] — one GEMM per tap on views, no
+            # gather copy (the per-tap window copies of the general path were
+            # most of the oracle's time at full C2 size).  Rows of the result
+            # that are not output positions (p beyond an extent) are cropped.
+            x2 = np.ascontiguousarray(x).reshape(-1, cin)
+            ypad = np.zeros((x2.shape[0], self.filters), dtype=x.dtype)
+            for tap in np.ndindex(*self.kernel_size):
+                off = self._flat_offset(tap, x.shape)
+                m = x2.shape[0] - off
+                ypad[:m] += x2[off:] @ w[tap]
+            crop = (slice(None),) + tuple(slice(0, o) for o in out_sp)
+            y = np.ascontiguousarray(
+                ypad.reshape(x.shape[:-1] + (self.filters,))[crop])
+        else:
+            y = np.zeros((n * int(np.prod(out_sp)), self.filters),
+                         dtype=x.dtype)
+            for tap in np.ndindex(*self.kernel_size):
+                xs = x[self._tap_slices(tap)]
+                y += xs.reshape(-1, cin) @ w[tap]
+            y = y.reshape((n,) + out_sp + (self.filters,))
         if self.use_bias:
             y = y + self.bias.astype(x.dtype, copy=False)
         self._pre = y
         self._y = _act_forward(self.activation, y)
         return self._y
+
+    def _flat_offset(self, tap, xshape):
+        """offset of ``tap`` in the flat position index of the padded array"""
+        off, stride = 0, 1
+        for d in range(self.nd - 1, -1, -1):
+            off += tap[d] * stride
+            stride *= xshape[1 + d]
+        return off
 
     def _tap_slices(self, tap):
         sl = [slice(None)]
@@ -262,11 +319,30 @@ class ConvND(Layer):
             w, dyd = round_bf16(w), round_bf16(dy2)
         dw = np.zeros(self.kernel.shape, dtype=dy.dtype)
         dxp = np.zeros(x.shape, dtype=dy.dtype)
-        for tap in np.ndindex(*self.kernel_size):
-            sl = self._tap_slices(tap)
-            xs = x[sl]
-            dw[tap] = xs.reshape(-1, cin).T @ dyw
-            dxp[sl] += (dyd @ w[tap].T).reshape(xs.shape)
+        if all(s_ == 1 for s_ in self.strides):
+            # (the flat-offset form of forward(): dPre embedded in a zero
+            # array of the padded extent, contiguous slices on both sides)
+            emb = (slice(None),) + tuple(slice(0, o) for o in self._out_sp)
+
+            def embed(a2):
+                e = np.zeros(x.shape[:-1] + (self.filters,), dtype=a2.dtype)
+                e[emb] = a2.reshape(dy.shape)
+                return e.reshape(-1, self.filters)
+            ew = embed(dyw)
+            ed = ew if dyd is dyw else embed(dyd)
+            x2 = np.ascontiguousarray(x).reshape(-1, cin)
+            dx2 = dxp.reshape(-1, cin)
+            for tap in np.ndindex(*self.kernel_size):
+                off = self._flat_offset(tap, x.shape)
+                m = x2.shape[0] - off
+                dw[tap] = x2[off:].T @ ew[:m]
+                dx2[off:] += ed[:m] @ w[tap].T
+        else:
+            for tap in np.ndindex(*self.kernel_size):
+                sl = self._tap_slices(tap)
+                xs = x[sl]
+                dw[tap] = xs.reshape(-1, cin).T @ dyw
+                dxp[sl] += (dyd @ w[tap].T).reshape(xs.shape)
         self.grads = [dw, db] if self.use_bias else [dw]
         sl = [slice(None)]
         for d, (lo, hi) in enumerate(self._pads):

@@ -48,6 +48,7 @@
   X(NO_FEWCH_HALO) \
   X(NO_FEWPOS) \
   X(NO_FOLD16) \
+  X(NO_FRAME16) \
   X(NO_FUSED2D) \
   X(NO_GCONV) \
   X(NO_GCONV_DY16) \
@@ -257,8 +258,9 @@ int launch_pack_jobs(s3_ctx* ctx, const S3PackJob* jobs_dev, int n_jobs, int max
 // the trunk's data gradient on the persistent kernel (bf16 dPre in, fp32 frame out)
 bool conv_mfma_persist_dgrad_geom_ok(const ConvGeom& g);
 bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g);
+// frame16: the padded frame dxp is written as bf16 (no accumulate then)
 int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* dpre16, const void* image,
-                                   float* dxp, int accumulate = 0);
+                                   float* dxp, int accumulate = 0, int frame16 = 0);
 int launch_conv_mfma_persist_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
 int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                              const void* image, const float* bias,
@@ -378,12 +380,13 @@ int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
 
 int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
                   int esize);
+// (frame16: dout is a bf16 frame — float4-fold geometries only)
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
-                      float* din, void* side16 = nullptr);
+                      float* din, void* side16 = nullptr, int frame16 = 0);
 bool gather_bwd_mask_ok(const GatherGeom& g);
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
                              const void* mask_y, int y_bf16, float slope, float* bsum = nullptr,
-                             int out_bf16 = 0);
+                             int out_bf16 = 0, int frame16 = 0);
 int launch_act(s3_ctx* ctx, const float* x, float* y, int64_t n, int act,
                float alpha);
 // dx = dy * act'(y)  (y is the activation OUTPUT; sign-preserving acts only)
@@ -400,7 +403,7 @@ int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
                int c, int bcast_c);
 int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n);  // y += x
 int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add,
-                          float* bsum = nullptr, void* side16 = nullptr);
+                          float* bsum = nullptr, void* side16 = nullptr, int frame16 = 0);
 bool gather_bwd_bsum_ok(const GatherGeom& g);
 int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g);
 int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, int c, float* db, int accumulate);

@@ -179,7 +179,12 @@ __global__ void pack_jobs_kernel(const S3PackJob* __restrict__ jobs) {
 // a tile may straddle frames.  The halo tables carry a "zero row" flag (bit 30
 // of the element offset; a chunk is zeroed before it lands in LDS if any of
 // its three axes is flagged) instead of the reflect rule.
-template <int NFV, bool DG, int REP = 0, bool RIN = false>
+// F16 (DG only): the padded frame is stored as bf16 — 96 instead of 192 MB per
+// trunk conv at C2 batch 8, written once here and read once by the fold; the
+// fold's sum of <= 8 frame cells is then the sum of bf16-rounded terms (the
+// rounding point tests/helpers.emulate_plan installs in the oracle's pad
+// adjoint).
+template <int NFV, bool DG, int REP = 0, bool RIN = false, bool F16 = false>
 __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg,
     const float* __restrict__ bias, const unsigned short* __restrict__ res,
@@ -561,11 +566,19 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
         const int S0 = org0 + mf / TS1, S1 = org1 + mf % TS1, o2 = org2 + frow;
         if (S0 >= gs0 * E0 || S1 >= gs1 * E1 || o2 >= g.O[2]) continue;
         const int q0 = S0 / E0, u0 = S0 - q0 * E0, q1 = S1 / E1, u1 = S1 - q1 * E1;
-        float* yp = yf + ((((size_t)(q0 * gs1 + q1) * E0 + u0) * E1 + u1) * g.O[2] + o2) * g.Cout + kq * 8;
+        const size_t yo = ((((size_t)(q0 * gs1 + q1) * E0 + u0) * E1 + u1) * g.O[2] + o2) * g.Cout + kq * 8;
+        float* yp = yf + yo;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           if (2 * h >= NFV) continue;
           f32x4 a0 = acc[m][(2 * h) % NFV], a1 = acc[m][(2 * h + 1) % NFV];
+          if constexpr (F16) {
+            uint4 o;
+            o.x = pk_bf16(a0[0], a0[1]); o.y = pk_bf16(a0[2], a0[3]);
+            o.z = pk_bf16(a1[0], a1[1]); o.w = pk_bf16(a1[2], a1[3]);
+            *reinterpret_cast<uint4*>(y + yo + h * 32) = o;
+            continue;
+          }
           if (res) {   // a later channel slice of the contraction: add to the earlier ones
             const float4 p0 = *reinterpret_cast<const float4*>(yp + h * 32);
             const float4 p1 = *reinterpret_cast<const float4*>(yp + h * 32 + 4);
@@ -720,15 +733,19 @@ bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g) {
 }
 
 int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* dpre16, const void* image,
-                                   float* dxp, int accumulate) {
+                                   float* dxp, int accumulate, int frame16) {
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, true, 0, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
+  if (frame16 && (accumulate || g.Cout != 64))
+    S3_FAIL(ctx, S3_ESTATE, "persistent data gradient: a bf16 frame is written once, 64 channels wide");
   int gs0 = 1, gs1 = 1;
   persist_dgrad_grid(g, &gs0, &gs1);
   // (tiles0 = half rows along the stacked s0 axis, n_tiles = half-tiles)
@@ -738,6 +755,7 @@ int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* d
   int grid = ctx->num_cu;
   if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
   auto kern = g.Cout <= 32 ? conv3_mfma_persist_kernel<2, true> : conv3_mfma_persist_kernel<4, true>;
+  if (frame16) kern = conv3_mfma_persist_kernel<4, true, 0, false, true>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
                      (const unsigned short*)dpre16, (const char*)image, (const float*)nullptr,
                      (const unsigned short*)(accumulate ? dxp : nullptr), (unsigned short*)dxp, g, tiles0, tiles1,

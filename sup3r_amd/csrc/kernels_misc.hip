@@ -164,7 +164,9 @@ __global__ void gather_bwd_kernel(const float* __restrict__ dout,
 // and whose bias gradient rides along in bsum — nothing reads it as fp32
 // SIDE16: fp32 store to din AND a bf16 copy to side16 (a tensor that stays
 // fp32 for the skip path but whose producer conv stages bf16)
-template <int MASK, bool OUT16 = false, bool SIDE16 = false>
+// FR16: the frame `dout` is stored as bf16 (round 4: the persistent data
+// gradient kernel writes its padded frame that way — half the round trip)
+template <int MASK, bool OUT16 = false, bool SIDE16 = false, bool FR16 = false>
 __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
                                        float* __restrict__ din, GatherGeom g,
                                        const void* __restrict__ mask_y, float slope,
@@ -213,9 +215,16 @@ __global__ void gather_bwd_pad4_kernel(const float* __restrict__ dout,
     for (int a = 0; a < cnt[0]; ++a)
       for (int b = 0; b < cnt[1]; ++b)
         for (int e = 0; e < cnt[2]; ++e) {
-          const float4 v = *reinterpret_cast<const float4*>(
-              dout + ((((int64_t)n * g.Do[0] + cand[0][a]) * g.Do[1] + cand[1][b]) * g.Do[2] +
-                      cand[2][e]) * g.Co + c4 * 4);
+          const int64_t fo = ((((int64_t)n * g.Do[0] + cand[0][a]) * g.Do[1] + cand[1][b]) * g.Do[2] +
+                              cand[2][e]) * g.Co + c4 * 4;
+          float4 v;
+          if constexpr (FR16) {
+            const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dout) + fo);
+            v = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xFFFF0000u),
+                            __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xFFFF0000u));
+          } else {
+            v = *reinterpret_cast<const float4*>(dout + fo);
+          }
           acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     if (MASK == 1) {
@@ -926,9 +935,21 @@ int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g) {
 }
 
 int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din,
-                             const void* mask_y, int y_bf16, float slope, float* bsum, int out_bf16) {
+                             const void* mask_y, int y_bf16, float slope, float* bsum, int out_bf16,
+                             int frame16) {
   if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_masked: unsupported geometry");
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  if (frame16) {    // (dout: bf16 frame)
+    const dim3 gridf(grid_for(n / 4, ctx->num_cu));
+#define S3_FOLD16(M, O16)                                                                                    \
+    hipLaunchKernelGGL((gather_bwd_pad4_kernel<M, O16, false, true>), gridf, dim3(kBlock), 0, ctx->stream,   \
+                       dout, din, g, mask_y, slope, bsum)
+    if (out_bf16) { if (y_bf16) S3_FOLD16(2, true); else S3_FOLD16(1, true); }
+    else { if (y_bf16) S3_FOLD16(2, false); else S3_FOLD16(1, false); }
+#undef S3_FOLD16
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   if (out_bf16) {   // (din: bf16 buffer)
     const dim3 grid16(grid_for(n / 4, ctx->num_cu));
     if (y_bf16)
@@ -958,9 +979,20 @@ int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, i
 
 // fold of a padded frame plus an earlier contribution: din = fold(dout) + add
 int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, float* din, const float* add,
-                          float* bsum, void* side16) {
+                          float* bsum, void* side16, int frame16) {
   if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd_add: unsupported geometry");
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  if (frame16) {
+    if (side16)
+      hipLaunchKernelGGL((gather_bwd_pad4_kernel<3, false, true, true>), dim3(grid_for(n / 4, ctx->num_cu)),
+                         dim3(kBlock), 0, ctx->stream, dout, din, g, (const void*)add, 0.f, bsum,
+                         (unsigned short*)side16);
+    else
+      hipLaunchKernelGGL((gather_bwd_pad4_kernel<3, false, false, true>), dim3(grid_for(n / 4, ctx->num_cu)),
+                         dim3(kBlock), 0, ctx->stream, dout, din, g, (const void*)add, 0.f, bsum);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   if (side16) {
     hipLaunchKernelGGL((gather_bwd_pad4_kernel<3, false, true>), dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,
                        ctx->stream, dout, din, g, (const void*)add, 0.f, bsum, (unsigned short*)side16);
@@ -974,8 +1006,20 @@ int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, f
 }
 
 int launch_gather_bwd(s3_ctx* ctx, const GatherGeom& g, const float* dout,
-                      float* din, void* side16) {
+                      float* din, void* side16, int frame16) {
   int64_t n = (int64_t)g.N * g.Di[0] * g.Di[1] * g.Di[2] * g.Ci;
+  if (frame16) {
+    if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd: a bf16 frame needs the float4 fold");
+    if (side16)
+      hipLaunchKernelGGL((gather_bwd_pad4_kernel<0, false, true, true>), dim3(grid_for(n / 4, ctx->num_cu)),
+                         dim3(kBlock), 0, ctx->stream, dout, din, g, (const void*)nullptr, 0.f, (float*)nullptr,
+                         (unsigned short*)side16);
+    else
+      hipLaunchKernelGGL((gather_bwd_pad4_kernel<0, false, false, true>), dim3(grid_for(n / 4, ctx->num_cu)),
+                         dim3(kBlock), 0, ctx->stream, dout, din, g, (const void*)nullptr, 0.f, (float*)nullptr);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   if (side16) {   // (callers check gather_bwd_mask_ok: the float4 fold)
     if (!gather_bwd_mask_ok(g)) S3_FAIL(ctx, S3_EINVAL, "gather_bwd: bf16 side copy needs the float4 fold");
     hipLaunchKernelGGL((gather_bwd_pad4_kernel<0, false, true>), dim3(grid_for(n / 4, ctx->num_cu)), dim3(kBlock), 0,

@@ -53,6 +53,7 @@ struct OpRec {
   // MFMA backward (training plans)
   bool wgrad_mfma = false, dgrad_mfma = false, wgrad_bf16 = false, wgrad_c2 = false, wgrad_bf16_gen = false, wgrad_bf16_2d = false, wgrad_tail = false;
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
+  bool dgrad_frame16 = false;  // the persistent kernel writes the padded frame as bf16
   bool use16 = false;          // data gradient stages the bf16 copy of dPre its mask pass leaves behind
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
   bool dgrad_s2 = false;       // stride-2 valid conv, C_out = 32: residue classes on an LDS halo
@@ -947,6 +948,11 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         if (o.dgrad_chunked && ((o.cg.Cout & 7) || s3_opt_has(S3O_NO_CHUNKED_DY16))) continue;
         o.use16 = true;
         max16 = std::max(max16, (size_t)pl->t[root_of(pl, o.d.out)].numel * 2);
+        // the reflect-padded 64 -> 64 trunk conv on the persistent kernel:
+        // its padded frame is written — and folded from — as bf16 (round 4)
+        o.dgrad_frame16 = training && o.dgrad_mfma && !o.dgrad_valid && !o.dgrad_chunked && !o.dgrad_fewch &&
+                          o.dg.Cout == 64 && (o.cg.Cin & 3) == 0 && o.cg.pad_mode == S3_PAD_REFLECT &&
+                          conv_mfma_persist_dgrad_supported(ctx, o.dg) && !s3_opt_has(S3O_NO_FRAME16);
       }
       // ... and for the stride-2 data gradient that stores dPre of the
       // few-channel conv below it as bf16 only (see the dgrad_s2 branch)
@@ -1511,6 +1517,7 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
       else if (o.gconv_dgrad) dg = S3_DGRAD_GCONV;
       else if (o.fewpos && o.fp_wt) dg = S3_DGRAD_FEWPOS;
       v[S3_OPINFO_DGRAD] = dg;
+      v[S3_OPINFO_DGRAD_FRAME16] = o.dgrad_frame16 ? 1 : 0;
       v[S3_OPINFO_MASK_FUSED_FROM] = o.mask_prod;
     }
   }
@@ -1744,7 +1751,7 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
           // fold of the padded-frame data gradient; when this conv is the only
           // consumer of an activated conv's output the fold applies that
           // activation's adjoint (the producer then skips its mask pass)
-          auto fold_frame = [&](const GatherGeom& fg, float* out) -> int {
+          auto fold_frame = [&](const GatherGeom& fg, float* out, int frame16 = 0) -> int {
             const int rin = root_of(pl, d.in0);
             const bool fuse = o.mask_prod >= 0 && !pl->gwritten[rin] && gather_bwd_mask_ok(fg) &&
                               !s3_opt_has(S3O_NO_MASK_FUSE);
@@ -1771,7 +1778,7 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
                 const OpRec& po = pl->ops[o.in_prod];
                 if (po.use16 && po.cg.act == S3_ACT_NONE && po.cg.d2s <= 1 && (po.cg.Cout & 3) == 0) side = pl->dpre16;
               }
-              int arc = launch_gather_bwd_add(ctx, fg, pl->dxp, out, first, bs, side);
+              int arc = launch_gather_bwd_add(ctx, fg, pl->dxp, out, first, bs, side, frame16);
               if (!arc && side) { pl->dpre16_for = rin; pl->dpre16_only = false; }
               return arc;
             }
@@ -1789,7 +1796,7 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
                     pl->dpre16_bytes >= (size_t)pl->t[rin].numel * 2)
                   side = pl->dpre16;
               }
-              int prc = launch_gather_bwd(ctx, fg, pl->dxp, out, side);
+              int prc = launch_gather_bwd(ctx, fg, pl->dxp, out, side, frame16);
               if (!prc && side) { pl->dpre16_for = rin; pl->dpre16_only = false; }
               return prc;
             }
@@ -1808,7 +1815,7 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
                               (!need_wgrad || po.d.b < 0 || bs != nullptr) && pl->precision == S3_PREC_BF16;
             int frc = launch_gather_bwd_masked(ctx, fg, pl->dxp, to16 ? (float*)pl->dpre16 : out, tptr(pl, d.in0),
                                                pl->t[rin].dtype, pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f, bs,
-                                               to16 ? 1 : 0);
+                                               to16 ? 1 : 0, frame16);
             if (!frc) pl->premasked[rin] = 1;
             if (!frc && to16) { pl->dpre16_for = rin; pl->dpre16_only = true; }
             return frc;
@@ -1864,6 +1871,7 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
               o.dg_version = P->version;
             }
             const void* wp = pl->precision != S3_PREC_F32 ? (const void*)o.dg_wbf : (const void*)o.dg_w32;
+            int frame16 = 0;
             if (o.dgrad_fewch)
               rc = launch_gconv_fwd(ctx, o.dg, dpre, o.dg_wbf, nullptr, nullptr, pl->dxp, 0, 0, pl->precision == S3_PREC_BF16X3);
             else if (o.use16 && dpre16 && pl->precision == S3_PREC_BF16 &&
@@ -1871,8 +1879,9 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
               // the persistent trunk kernel over the stacked frames (a valid conv's
               // full correlation lands on x's own grid: straight into dst)
               const size_t tile_img = (size_t)((o.dg.Cout + 63) / 64) * 27 * 64 * 64 * 2;
+              frame16 = o.dgrad_frame16;
               rc = launch_conv_mfma_persist_dgrad(ctx, o.dg, dpre16, (const char*)o.dg_wbf + tile_img,
-                                                  o.dgrad_valid ? dst : pl->dxp);
+                                                  o.dgrad_valid ? dst : pl->dxp, 0, frame16);
             } else {
               ConvIO dio;
               dio.in_bf16 = (o.use16 && dpre16) ? 1 : 0;
@@ -1890,7 +1899,7 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
             for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2; fg.lo[q] = 1; }
             fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
             fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
-            rc = fold_frame(fg, dst);
+            rc = fold_frame(fg, dst, frame16);
           } else if (o.dgrad_s2) {
             if (o.dc2_version != (int64_t)P->version) {
               rc = launch_conv_dgrad_s2_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);

@@ -168,6 +168,21 @@ def emulate_plan(ref, ph, masks=False, rounding=True, sample=slice(None)):
             wl[0].emu_wgrad_round = is_bf16_plan and info['wgrad'] in _BF16_WGRAD
             wl[0].emu_dgrad_round = is_bf16_plan and info['dgrad'] in _BF16_DGRAD
             n_ops += int(info['fwd_bf16_ops'])
+            if is_bf16_plan and info.get('dgrad_frame16'):
+                # the conv's padded-frame data gradient is stored as bf16: the
+                # pad layer of the group folds rounded values
+                # (a pad fused into the conv produces no op of its own: it
+                # sits right before the group, with op index -1)
+                li = min(lj for lj in lis if hasattr(ref.layers[lj], 'kernel'))
+                pads = []
+                while li > 0 and not pads:
+                    li -= 1
+                    if type(ref.layers[li]).__name__ == 'FlexiblePadding':
+                        pads.append(ref.layers[li])
+                    elif li not in lis and plan.layer_out[li][1] >= 0:
+                        break
+                assert len(pads) == 1, (oi, lis)
+                pads[0].emu_grad_round = True
         if masks and op.get('act', 0):
             y = ph.tensor(op['out'])[sample]
             acts = [ref.layers[li] for li in lis

@@ -52,6 +52,17 @@ CASES = [
 ]
 
 
+def _tight_vs_oracle(spec, shape, seed):
+    """the bf16 plan of ``spec`` against the oracle the way round 2 onwards
+    checks bf16: forward per op (teacher forced) + 3e-2 end to end, every
+    gradient <= 2e-2 of its tensor's largest value on the device's activations
+    and masks with the device's roundings (tests/test_parity_r02.py::
+    _fwd_bwd_vs_oracle).  Replaces the 1e-1 L-inf / 2e-1 rel-rms oracle bounds
+    these kernel tests carried since round 1."""
+    from tests.test_parity_r02 import _fwd_bwd_vs_oracle
+    return _fwd_bwd_vs_oracle(spec, shape, 'bf16', seed, 3e-2, 2e-2)
+
+
 @pytest.mark.parametrize('cfg,shape,exo_name,out_shape', CASES)
 def test_forward_backward_fp32(cfg, shape, exo_name, out_shape):
     rng = np.random.default_rng(11)
@@ -477,7 +488,7 @@ def test_trunk_wgrad_bf16_transpose_read_kernel(monkeypatch):
     """conv3_wgrad_bf16_kernel (bf16 MFMA fed by ds_read_b64_tr_b16) on ragged
     tiles (s1 = 9, s2 = 10 not multiples of 4, t = 37 not of 16) with the
     reflect halo: the 64 -> 64 and 64 -> 72 weight gradients against the
-    oracle (bf16-mode bound 1e-1 of the largest value) and against the exact
+    oracle (2e-2 under the device's masks and roundings) and against the exact
     fp32-MFMA kernel of the same plan (SUP3R_AMD_NO_WGRAD_BF16=1; only the bf16
     rounding of x and dPre differs: rel. rms < 1e-2)."""
     from sup3r_amd.configs.author_configs import pcc
@@ -496,11 +507,11 @@ def test_trunk_wgrad_bf16_transpose_read_kernel(monkeypatch):
         ph.forward(net.dev.to_device(x))
         ph.backward(net.dev.to_device(dy), need_dx=False)
         return [np.array(g) for g in net.grads]
+    _tight_vs_oracle(spec, shape, 31)
     g_bf = grads()
     switch('NO_WGRAD_BF16', 1)
     g_32 = grads()
-    for i, (a, b, r) in enumerate(zip(g_bf, g_32, ref.grads)):
-        assert np.abs(a - r).max() < 1e-1 * np.abs(r).max(), i
+    for i, (a, b) in enumerate(zip(g_bf, g_32)):
         rms = np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean())
         assert rms < 1e-2, (i, rms)
     # the two kernels were really different ones
@@ -511,7 +522,7 @@ def test_disc_wgrad_bf16_transpose_read_general_kernel(monkeypatch):
     """conv_wgrad_bf16_gen_kernel — C_in 32 / 64 / 128 (two channel tiles),
     strides 1 and 2, valid and zero 'same' padding, ragged tiles — and the
     LDS-free 2-channel kernel of the first layer: weight gradients against
-    the oracle (bf16-mode bound) and against the exact fp32-MFMA kernels of
+    the oracle (2e-2, device masks / roundings) and against the exact fp32-MFMA kernels of
     the same plan (SUP3R_AMD_NO_WGRAD_BF16 / _C2: rel. rms < 1e-2)."""
     rng = np.random.default_rng(33)
 
@@ -535,13 +546,12 @@ def test_disc_wgrad_bf16_transpose_read_general_kernel(monkeypatch):
         ph.forward(net.dev.to_device(x))
         ph.backward(net.dev.to_device(dy), need_dx=False)
         return [np.array(g) for g in net.grads]
+    _tight_vs_oracle(spec, shape, 33)
     g_bf = grads()
     switch('NO_WGRAD_BF16', 1)
     switch('NO_WGRAD_C2', 1)
     g_32 = grads()
-    gmax = max(float(np.abs(g).max()) for g in ref.grads)
-    for i, (a, b, r) in enumerate(zip(g_bf, g_32, ref.grads)):
-        assert np.abs(a - r).max() < 1e-1 * np.abs(r).max() + 1e-3 * gmax, i
+    for i, (a, b) in enumerate(zip(g_bf, g_32)):
         rms = np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean())
         assert rms < 1e-2, (i, rms)
     assert sum(np.abs(a - b).max() > 0 for a, b in zip(g_bf, g_32)) >= 5
@@ -552,7 +562,7 @@ def test_valid_conv_dgrad_on_halo_tile_kernel(monkeypatch):
     (discriminator 32 -> 64, 64 -> 64) as a full correlation on the halo-tile
     MFMA kernel, written straight onto x's grid, and of the 2 -> 32 first
     layer on the LDS-halo few-channel kernel: against the oracle
-    (bf16-mode bound) and against the gather-MFMA data gradient
+    (2e-2, device masks / roundings) and against the gather-MFMA data gradient
     (SUP3R_AMD_NO_MFMA_BWD=1, same bf16 operands: rel. rms < 1e-2)."""
     rng = np.random.default_rng(35)
 
@@ -575,27 +585,24 @@ def test_valid_conv_dgrad_on_halo_tile_kernel(monkeypatch):
         ph.forward(net.dev.to_device(x))
         dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
         return dx, [np.array(g) for g in net.grads]
+    _tight_vs_oracle(spec, shape, 35)
     dx, g = run()
     switch('NO_MFMA_BWD', 1)
     switch('NO_DGRAD_C2', 1)   # 32 -> 2: LDS-halo kernel off too
     dx2, g2 = run()
     assert np.abs(dx - dx2).max() > 0
-    assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
     rms = np.sqrt(((dx - dx2) ** 2).mean()) / np.sqrt((dx2 ** 2).mean())
     assert rms < 1e-2, rms
-    # bias gradients are cancellation-heavy sums over all positions: bound the
-    # relative rms (2e-1 in bf16 mode, cf. the production-config test) against
-    # the oracle, and the two bf16 kernel paths against each other tightly
-    for a, b, r in zip(g, g2, ref.grads):
-        assert np.sqrt(((a - r) ** 2).mean()) / np.sqrt((r ** 2).mean()) < 2e-1
+    # the two bf16 kernel paths against each other
+    for a, b in zip(g, g2):
         assert np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()) < 2e-2
 
 
 def test_2d_wgrad_bf16_transpose_read_kernel(monkeypatch):
     """conv2_wgrad_bf16_kernel (spatial models, k = 3 x 3): C_in 32 / 64,
     strides 1 / 2, valid and 'same' padding, ragged 8 x 16 tiles — weight
-    gradients against the oracle (relative rms, bf16 mode) and against the
-    generic fp32 kernel of the same plan (SUP3R_AMD_NO_WGRAD_BF16=1)."""
+    gradients against the oracle (2e-2, device masks / roundings) and against
+    the generic fp32 kernel of the same plan (SUP3R_AMD_NO_WGRAD_BF16=1)."""
     rng = np.random.default_rng(37)
 
     def conv(f, s, pad='valid'):
@@ -618,12 +625,12 @@ def test_2d_wgrad_bf16_transpose_read_kernel(monkeypatch):
         ph.forward(net.dev.to_device(x))
         ph.backward(net.dev.to_device(dy), need_dx=False)
         return [np.array(g) for g in net.grads]
+    _tight_vs_oracle(spec, shape, 37)
     g_bf = grads()
     switch('NO_WGRAD_BF16', 1)
     g_32 = grads()
     ndiff = 0
-    for i, (a, b, r) in enumerate(zip(g_bf, g_32, ref.grads)):
-        assert np.sqrt(((a - r) ** 2).mean()) / np.sqrt((r ** 2).mean()) < 2e-1, i
+    for i, (a, b) in enumerate(zip(g_bf, g_32)):
         rms = np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean())
         assert rms < 1e-2, (i, rms)
         ndiff += np.abs(a - b).max() > 0
@@ -654,10 +661,11 @@ def test_tail_conv_wgrad_ldsfree_kernel_with_reflect_padding(monkeypatch):
         ph.forward(net.dev.to_device(x))
         ph.backward(net.dev.to_device(dy), need_dx=False)
         return [np.array(g) for g in net.grads]
+    _tight_vs_oracle(spec, shape, 39)
     g_bf = grads()
     switch('NO_WGRAD_C2', 1)
     g_32 = grads()
-    a, b, r = g_bf[2], g_32[2], ref.grads[2]          # the 8 -> 2 kernel
+    a, b = g_bf[2], g_32[2]                           # the 8 -> 2 kernel
     assert a.shape == (3, 3, 3, 8, 2)
     # its data gradient runs as a 2-channel forward conv over the padded frame
     # (SUP3R_AMD_NO_DGRAD_FEWCH=1: direct kernel, fp32): the first conv's
@@ -668,7 +676,6 @@ def test_tail_conv_wgrad_ldsfree_kernel_with_reflect_padding(monkeypatch):
     rms0 = np.sqrt(((g_32[0] - g_dd[0]) ** 2).mean()) / np.sqrt((g_dd[0] ** 2).mean())
     assert rms0 < 1e-2, rms0
     assert np.abs(a - b).max() > 0
-    assert np.sqrt(((a - r) ** 2).mean()) / np.sqrt((r ** 2).mean()) < 5e-2
     assert np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()) < 1e-2
 
 
@@ -677,7 +684,8 @@ def test_training_plan_bf16_saved_activations(monkeypatch):
     forward is the inference trunk: persistent / tile kernel with bf16 I/O;
     the weight gradient stages bf16 cells directly, the LeakyReLU mask pass
     reads the sign of a bf16 output; gradients stay fp32).  Against the oracle
-    (bf16-mode bounds) and against the same plan with fp32 saved activations
+    (per op + 2e-2 gradients under the device's masks / roundings) and against
+    the same plan with fp32 saved activations
     (SUP3R_AMD_BF16_TRAIN_ACT=0): forward 2e-2, gradients rel. rms 3e-2."""
     from sup3r_amd.configs.author_configs import pcc
     rng = np.random.default_rng(41)
@@ -699,6 +707,7 @@ def test_training_plan_bf16_saved_activations(monkeypatch):
         y = ph.forward(net.dev.to_device(x)).cpu().numpy()
         dx = ph.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
         return y, dx, [np.array(g) for g in net.grads]
+    _tight_vs_oracle(spec, shape, 41)
     y16, dx16, g16 = run()
     switch('BF16_TRAIN_ACT', 0)
     y32, dx32, g32 = run()
@@ -707,11 +716,9 @@ def test_training_plan_bf16_saved_activations(monkeypatch):
         return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
     assert np.abs(y16 - y32).max() > 0           # the two plans really differ
     scale = max(1.0, np.abs(y_ref).max())
-    assert np.abs(y16 - y_ref).max() < 5e-2 * scale
     assert np.abs(y16 - y32).max() < 2e-2 * scale
-    assert rel_rms(dx16, dx_ref) < 1e-1 and rel_rms(dx16, dx32) < 3e-2
-    for a, b, r in zip(g16, g32, ref.grads):
-        assert rel_rms(a, r) < 1e-1
+    assert rel_rms(dx16, dx32) < 3e-2
+    for a, b in zip(g16, g32):
         assert rel_rms(a, b) < 3e-2
 
 
@@ -746,6 +753,10 @@ def test_training_plan_bf16_first_discriminator_activation(monkeypatch, capfd):
         return y, dx, [np.array(g) for g in net.grads]
     y16, dx16, g16 = run()
     trace = capfd.readouterr().err
+    switch('TRACE', None)
+    _tight_vs_oracle(spec, shape, 47)
+    switch('TRACE', 1)
+    capfd.readouterr()
     first = [ln for ln in trace.splitlines() if 'conv 2->32 train' in ln]
     second = [ln for ln in trace.splitlines() if 'conv 32->32 train' in ln]
     assert first and 'out16 1' in first[0], trace
@@ -764,9 +775,8 @@ def test_training_plan_bf16_first_discriminator_activation(monkeypatch, capfd):
     scale = max(1.0, np.abs(y_ref).max())
     assert np.abs(y16 - y_ref).max() < 3e-2 * scale
     assert np.abs(y16 - y32).max() < 1e-5 * scale
-    assert rel_rms(dx16, dx_ref) < 1e-1 and rel_rms(dx16, dx32) < 1e-4
-    for a, b, r in zip(g16, g32, ref.grads):
-        assert rel_rms(a, r) < 2e-1
+    assert rel_rms(dx16, dx32) < 1e-4
+    for a, b in zip(g16, g32):
         assert rel_rms(a, b) < 1e-4
 
 
