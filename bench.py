@@ -152,6 +152,7 @@ def train_leg(config, global_batch, world, rank, min_seconds, max_steps,
                                   False, 1e-3, multi_gpu=multi_gpu)
     step()
     torch.cuda.synchronize()
+    c0 = {k: dev.stat(k) for k in ('buckets', 'allreduces', 'bucket_elems')}
     n, t0 = 0, time.perf_counter()
     while True:
         step()
@@ -183,6 +184,21 @@ def train_leg(config, global_batch, world, rank, min_seconds, max_steps,
     if gflop:
         out['algorithmic_gflop_per_sample'] = gflop
         out['tflops'] = gflop * global_batch / dt / 1e3
+    # what RCCL itself reports + the collectives this rank issued per step: a
+    # first run on a multi-GPU node verifies itself (world ranks, > 0 buckets)
+    import ctypes as _C
+    from sup3r_amd import _lib as _L
+    nr, rk = _C.c_int32(0), _C.c_int32(0)
+    _L.check(_L.lib().s3_comm_info(dev.ctx, _C.byref(nr), _C.byref(rk)),
+             dev.ctx, 's3_comm_info')
+    out['comm'] = {
+        'rccl_comm_count': int(nr.value), 'rccl_user_rank': int(rk.value),
+        'world': world,
+        'bucket_allreduces_per_step': (dev.stat('buckets') - c0['buckets']) / n,
+        'other_allreduces_per_step':
+            (dev.stat('allreduces') - c0['allreduces']) / n,
+        'gradient_mb_reduced_per_step':
+            (dev.stat('bucket_elems') - c0['bucket_elems']) * 4 / n / 1e6}
     del model
     torch.cuda.empty_cache()
     return out
@@ -637,6 +653,17 @@ def main():
 
     base = {'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'higher_is_better': True, 'vs_baseline': None, 'data': 'synthetic'}
+    if world > 1:
+        # self-verification of a multi-GPU line: the process group's size and
+        # the distinct devices its ranks sit on (an all-gather over RCCL)
+        ids = [None] * world
+        dist.all_gather_object(ids, (rank, local_rank,
+                                     torch.cuda.get_device_properties(
+                                         local_rank).name))
+        base['ranks'] = {'dist_world_size': dist.get_world_size(),
+                         'backend': dist.get_backend(),
+                         'devices': sorted({(r, lr) for r, lr, _ in ids}),
+                         'gpu': ids[0][2]}
 
     if args.mode == 'train':
         gb = args.batch or (8 * world if args.config == 'c2' else

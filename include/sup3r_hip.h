@@ -100,7 +100,9 @@ enum { S3_STAT_PERSIST_DGRAD = 0, /* trunk data gradients on the persistent kern
        S3_STAT_GCONV_SPLITK = 1,  /* gather-MFMA launches with a split contraction  */
        S3_STAT_BUCKET_ELEMS = 2,  /* gradient elements all-reduced bucket by bucket  */
        S3_STAT_DGRAD_C2_SLIDE = 3, /* first-layer data gradients on the sliding kernel */
-       S3_STAT_COUNT = 4 };
+       S3_STAT_BUCKETS = 4,       /* bucket collectives issued under backward passes */
+       S3_STAT_ALLREDUCES = 5,    /* whole-buffer / scalar all-reduces issued        */
+       S3_STAT_COUNT = 6 };
 int64_t s3_ctx_stat(const s3_ctx* ctx, int which);
 
 /* ---- parameter store ---------------------------------------------------
@@ -510,6 +512,10 @@ int s3_comm_unique_id(void* out128); /* rank 0; 128 bytes                  */
 int s3_comm_init(s3_ctx* ctx, int rank, int nranks, const void* unique_id128);
 int s3_params_allreduce_grads(s3_params* p);
 int s3_allreduce_sum(s3_ctx* ctx, float* buf, int64_t n);
+/* the communicator as RCCL reports it (ncclCommCount / ncclCommUserRank; 1 / 0
+ * without one): what a multi-GPU bench line prints so that the first run on
+ * real xGMI verifies itself. */
+int s3_comm_info(s3_ctx* ctx, int* n_ranks, int* rank);
 /* Overlap with the backward pass: arm the store BEFORE the s3_plan_backward
  * call that finalises its gradients (need_wgrad; the last one when several
  * accumulate).  That call then hands the finished tail of the gradient buffer

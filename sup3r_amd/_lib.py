@@ -46,7 +46,7 @@ EXPORTS = [
     's3_comm_unique_id', 's3_comm_init', 's3_params_allreduce_grads',
     's3_params_arm_allreduce',
     's3_allreduce_sum', 's3_params_broadcast', 's3_broadcast',
-    's3_comm_destroy', 's3_comm_wait', 's3_version',
+    's3_comm_destroy', 's3_comm_wait', 's3_comm_info', 's3_version',
 ]
 
 
@@ -191,6 +191,7 @@ def lib():
         's3_params_allreduce_grads': (i32, [vp]),
         's3_params_arm_allreduce': (i32, [vp, i64]),
         's3_allreduce_sum': (i32, [vp, vp, i64]),
+        's3_comm_info': (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
         's3_params_broadcast': (i32, [vp, i32, i32]),
         's3_broadcast': (i32, [vp, vp, i64, i32]),
         's3_comm_destroy': (None, [vp]),
@@ -205,7 +206,7 @@ def lib():
 
 
 STATS = {'persist_dgrad': 0, 'gconv_splitk': 1, 'bucket_elems': 2,
-         'dgrad_c2_slide': 3}
+         'dgrad_c2_slide': 3, 'buckets': 4, 'allreduces': 5}
 
 
 def option_names():

@@ -26,6 +26,7 @@ typedef const char* (*fn_errstr)(int);
 typedef int (*fn_destroy)(void*);
 typedef int (*fn_abort)(void*);
 typedef int (*fn_async_err)(void*, int*);
+typedef int (*fn_comm_int)(void*, int*);
 
 struct Rccl {
   void* h = nullptr;
@@ -37,6 +38,7 @@ struct Rccl {
   fn_destroy destroy = nullptr;
   fn_abort abort = nullptr;
   fn_async_err async_err = nullptr;
+  fn_comm_int comm_count = nullptr, comm_rank = nullptr;
   bool load(std::string& err) {
     if (h) return true;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -53,6 +55,8 @@ struct Rccl {
     destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
     abort = (fn_abort)dlsym(h, "ncclCommAbort");
     async_err = (fn_async_err)dlsym(h, "ncclCommGetAsyncError");
+    comm_count = (fn_comm_int)dlsym(h, "ncclCommCount");
+    comm_rank = (fn_comm_int)dlsym(h, "ncclCommUserRank");
     if (!get_uid || !init_rank || !allreduce) { err = "librccl.so lacks nccl symbols"; return false; }
     return true;
   }
@@ -96,6 +100,7 @@ extern "C" int s3_allreduce_sum(s3_ctx* ctx, float* buf, int64_t n) {
     ctx->err = std::string("ncclAllReduce: ") + (g_rccl.errstr ? g_rccl.errstr(rc) : "error");
     return S3_ERCCL;
   }
+  ++ctx->stat[S3_STAT_ALLREDUCES];
   ++ctx->comm_issued;
   return S3_OK;
 }
@@ -128,6 +133,7 @@ extern "C" S3_INTERNAL int s3_comm_reduce_range(s3_ctx* ctx, float* buf, int64_t
     return S3_ERCCL;
   }
   ctx->stat[S3_STAT_BUCKET_ELEMS] += n;
+  ++ctx->stat[S3_STAT_BUCKETS];
   ++ctx->comm_issued;
   return S3_OK;
 }
@@ -220,6 +226,21 @@ extern "C" void s3_comm_destroy(s3_ctx* ctx) {
   ctx->comm = nullptr;
   ctx->rank = 0;
   ctx->nranks = 1;
+}
+
+// what RCCL itself says about the communicator (ncclCommCount /
+// ncclCommUserRank) — not what the caller passed to s3_comm_init
+extern "C" int s3_comm_info(s3_ctx* ctx, int* n_ranks, int* rank) {
+  if (!ctx) return S3_EINVAL;
+  int n = 1, r = 0;
+  if (ctx->comm) {
+    if (!g_rccl.comm_count || !g_rccl.comm_rank) S3_FAIL(ctx, S3_ERCCL, "librccl.so lacks ncclCommCount");
+    if (g_rccl.comm_count(ctx->comm, &n) != 0 || g_rccl.comm_rank(ctx->comm, &r) != 0)
+      S3_FAIL(ctx, S3_ERCCL, "ncclCommCount / ncclCommUserRank failed");
+  }
+  if (n_ranks) *n_ranks = n;
+  if (rank) *rank = r;
+  return S3_OK;
 }
 
 extern "C" int s3_params_broadcast(s3_params* p, int which, int root) {
