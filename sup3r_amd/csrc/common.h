@@ -44,6 +44,7 @@
   X(NO_DGRAD_S2) \
   X(NO_DISC_BF16) \
   X(NO_DPRE16) \
+  X(NO_DPRE16_ONLY_MASK) \
   X(NO_FEWCH) \
   X(NO_FEWCH_HALO) \
   X(NO_FEWPOS) \

@@ -468,8 +468,11 @@ constexpr int TG0 = TW0 + 2, TG1 = TW1 + 2, TG2 = TW2 + 2;
 constexpr int TWP = TG0 * TG1 * TG2;            // 2040 halo cells of 16 B
 constexpr int TWN = TW0 * TW1 * TW2;            // 1024 positions
 constexpr int TW_XS = (TWP + 2) * 16;           // + over-read of the junk tap
-constexpr int TW_DS = 16 * TWN * 2;             // dPre^T: 16 rows x 1024 positions bf16
-constexpr int TW_LDS = TW_XS + TW_DS;           // 65,440 B
+constexpr int TW_CO = 4;                        // C_out rows kept in LDS (the tail convs have 2 - 4)
+constexpr int TW_DPT = TW_CO * TWN / 256;       // dPre values per thread (8)
+constexpr int TW_DS = TW_CO * TWN * 2;          // dPre^T: C_out rows x 1024 positions bf16
+// (the epilogue's reduction image needs 4 waves x 9 blocks x 256 floats)
+constexpr int TW_LDS = (TW_XS + TW_DS) > 36864 ? (TW_XS + TW_DS) : 36864;
 
 template <bool IN16>
 __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
@@ -486,22 +489,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
 #pragma unroll
   for (int b = 0; b < 18; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int item = tid; item < (16 - Cout) * TWN; item += 256) dsT[Cout * TWN + item] = 0;
-  // (XCD-contiguous tile shares: s3_xcd_share, common.h)
-  int64_t xt_lo, xt_hi;
-  int xt_k, xt_nk;
-  s3_xcd_share(n_tiles, xt_lo, xt_hi, xt_k, xt_nk);
-  for (int tile = (int)xt_lo + xt_k; tile < (int)xt_hi; tile += xt_nk) {
+  // Round 4: the tile loop is software-pipelined.  It ran load -> LDS ->
+  // barrier -> 144 MFMAs per wave back to back: ~10 us of exposed load latency
+  // per 1.1 us of matrix work (0.14 of the HBM roofline).  Now the NEXT tile's
+  // halo cells (8 x 16 B per thread) and dPre values (TW_DPT per thread) are
+  // fetched into registers before the current tile's k-steps and dropped into
+  // LDS after them, and dPre^T keeps only its C_out <= TW_CO rows (the B
+  // fragment's other columns are zero registers), which takes the LDS image
+  // from 65 to 37 KB: four workgroups per CU instead of two.
+  constexpr int NH = (TWP + 255) / 256;           // halo cells per thread (8)
+  uint4 hreg[NH];
+  float dreg[TW_DPT];
+  auto tile_org = [&](int tile, int& n, int& o0, int& o1, int& o2) {
     int tr = tile;
-    const int t2i = tr % tiles2; tr /= tiles2;
-    const int t1i = tr % tiles1; tr /= tiles1;
-    const int t0i = tr % tiles0; tr /= tiles0;
-    const int n = tr;
-    const int org0 = t0i * TW0, org1 = t1i * TW1, org2 = t2i * TW2;
-    __syncthreads();
+    o2 = (tr % tiles2) * TW2; tr /= tiles2;
+    o1 = (tr % tiles1) * TW1; tr /= tiles1;
+    o0 = (tr % tiles0) * TW0; tr /= tiles0;
+    n = tr;
+  };
+  auto fetch = [&](int tile) {
+    int n, org0, org1, org2;
+    tile_org(tile, n, org0, org1, org2);
     // ---- x halo: cell = 8 channels -> 16 B of bf16
-    for (int hp = tid; hp < TWP; hp += 256) {
-      int h = hp;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int hp = tid + 256 * k;
+      int h = hp < TWP ? hp : TWP - 1;
       const int c2 = h % TG2; h /= TG2;
       const int c1 = h % TG1; h /= TG1;
       const int c0 = h;
@@ -511,36 +524,60 @@ __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
       }
       const bool ok = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
       const int64_t cell = (((int64_t)n * D0 + i0) * D1 + i1) * D2 + i2;
+      uint4 v = make_uint4(0, 0, 0, 0);
       if constexpr (IN16) {                      // bf16 cells (bf16 saved activations)
-        uint4 v = make_uint4(0, 0, 0, 0);
         if (ok) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(x) + cell * 8);
-        *reinterpret_cast<uint4*>(xs + hp * 16) = v;
       } else {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
         if (ok) {
-          a = *reinterpret_cast<const float4*>(x + cell * 8);
-          b = *reinterpret_cast<const float4*>(x + cell * 8 + 4);
+          const float4 a = *reinterpret_cast<const float4*>(x + cell * 8);
+          const float4 b = *reinterpret_cast<const float4*>(x + cell * 8 + 4);
+          v = make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
         }
-        *reinterpret_cast<uint4*>(xs + hp * 16) =
-            make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
       }
+      hreg[k] = v;
     }
-    if (tid < 2) *reinterpret_cast<uint4*>(xs + (TWP + tid) * 16) = make_uint4(0, 0, 0, 0);
-    // ---- dPre tile, transposed: dsT[co][pl] (rows >= C_out were zeroed once)
-    for (int item = tid; item < Cout * TWN; item += 256) {
+    // ---- dPre of the tile: item = co * TWN + position (coalesced along t)
+#pragma unroll
+    for (int k = 0; k < TW_DPT; ++k) {
+      const int item = tid + 256 * k;
       const int pl = item % TWN, co = item / TWN;
       const int row = pl / TW2, tt = pl % TW2;
       const int o0 = org0 + row / TW1, o1 = org1 + row % TW1, o2 = org2 + tt;
       float v = 0.f;
       if (co < Cout && o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2])
         v = dy[((((int64_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * Cout + co];
-      dsT[co * TWN + pl] = (unsigned short)(pk2(v, 0.f) & 0xFFFFu);
+      dreg[k] = v;
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int hp = tid + 256 * k;
+      if (hp < TWP) *reinterpret_cast<uint4*>(xs + hp * 16) = hreg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < TW_DPT; ++k) {
+      const int item = tid + 256 * k;
+      if (item < Cout * TWN) dsT[item] = (unsigned short)(pk2(dreg[k], 0.f) & 0xFFFFu);
+    }
+  };
+  if (tid < 2) *reinterpret_cast<uint4*>(xs + (TWP + tid) * 16) = make_uint4(0, 0, 0, 0);
+  // (XCD-contiguous tile shares: s3_xcd_share, common.h)
+  int64_t xt_lo, xt_hi;
+  int xt_k, xt_nk;
+  s3_xcd_share(n_tiles, xt_lo, xt_hi, xt_k, xt_nk);
+  int tile = (int)xt_lo + xt_k;
+  if (tile < (int)xt_hi) fetch(tile);
+  for (; tile < (int)xt_hi; tile += xt_nk) {
+    __syncthreads();                 // every wave is done with the previous image
+    commit();
     __syncthreads();
+    if (tile + xt_nk < (int)xt_hi) fetch(tile + xt_nk);   // in flight under the k-steps
     // ---- 32 k-steps (one (s1, s2) row of 32 t each), 8 per wave
     for (int ks = wave; ks < TW0 * TW1; ks += 4) {
       const int r0 = ks / TW1, r1 = ks % TW1;
-      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(dsT + q * TWN + ks * TW2 + kg * 8);
+      bf16x8 bfr = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < Cout) bfr = *reinterpret_cast<const bf16x8*>(dsT + q * TWN + ks * TW2 + kg * 8);
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -592,7 +629,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
 
 bool conv_wgrad_tail_supported(const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_TAIL)) return false;
-  if (g.Cin != 8 || g.Cout > 16 || g.Cout < 1 || g.d2s != 1) return false;
+  if (g.Cin != 8 || g.Cout > TW_CO || g.Cout < 1 || g.d2s != 1) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] < 0 || g.lo[d] > 2) return false;
   return (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 65536;

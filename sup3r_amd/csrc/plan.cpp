@@ -1695,10 +1695,22 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
           // the bias gradient = channel sums of dpre: they ride along this pass
           mask_sums = need_wgrad && d.b >= 0 && pl->bsum2 && conv_epilogue_bwd_bsum_ok(g) &&
                       !s3_opt_has(S3O_NO_BIAS_FUSE);
-          rc = launch_conv_epilogue_bwd(ctx, g, tptr(pl, d.out), dy, pl->dpre, o.io.out_bf16, side,
-                                        mask_sums ? pl->bsum2 : nullptr);
+          // Every reader of this dPre takes the bf16 copy — transpose-read /
+          // wave-specialised weight gradient, MFMA data gradient over the
+          // frame, bias gradient from the channel sums riding along: the
+          // fp32 dPre (151 MB per trunk conv at C2 batch 8) is not written.
+          const int64_t n_el = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout;
+          const bool wg16 = o.wgrad_bf16 && !o.fewpos && !o.wgrad_tail && !o.wgrad_c2 && !o.wgrad_bf16_2d &&
+                            !o.wgrad_bf16_gen && !o.wgrad_gen && o.io.in_bf16 && (g.Cout & 3) == 0;
+          const bool dg16 = o.dgrad_mfma && !o.dgrad_chunked && !o.dgrad_fewch && o.use16;
+          const bool skip32 = side && g.d2s <= 1 && (n_el & 3) == 0 && pl->precision == S3_PREC_BF16 &&
+                              (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU) &&
+                              (!need_wgrad || (wg16 && (d.b < 0 || mask_sums))) &&
+                              (!wants_grad(d.in0) || dg16) && !s3_opt_has(S3O_NO_DPRE16_ONLY_MASK);
+          rc = launch_conv_epilogue_bwd(ctx, g, tptr(pl, d.out), dy, skip32 ? nullptr : pl->dpre, o.io.out_bf16,
+                                        side, mask_sums ? pl->bsum2 : nullptr);
           if (rc) return rc;
-          dpre = pl->dpre;
+          dpre = skip32 ? nullptr : pl->dpre;
           dpre16 = side;
         }
         const int64_t npos = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
