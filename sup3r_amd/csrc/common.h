@@ -60,6 +60,7 @@
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \
+  X(PERSIST2) \
   X(NO_REPEAT_FUSE) \
   X(NO_WGRAD_X3) \
   X(NO_GCONV_X3) \
@@ -263,6 +264,10 @@ bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* dpre16, const void* image,
                                    float* dxp, int accumulate = 0, int frame16 = 0);
 int launch_conv_mfma_persist_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
+// round-4 experiment: 128-position consumer waves, filter fragments from L1 / L2
+bool conv_mfma_persist2_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io, bool has_res);
+int launch_conv_mfma_persist2(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image,
+                              const float* bias, const void* res, void* y);
 int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                              const void* image, const float* bias,
                              const void* res, void* y);

@@ -800,6 +800,8 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
                          const void* x, const void* packed, const float* bias,
                          const void* res, void* y, ConvIO io) {
   if (precision == S3_PREC_BF16) {
+    if (!g.in_cstride && conv_mfma_persist2_supported(ctx, g, io, res != nullptr))
+      return launch_conv_mfma_persist2(ctx, g, x, (const char*)packed + (size_t)((g.Cout + CT - 1) / CT) * 27 * CT * CIN * 2, bias, res, y);
     if (!g.in_cstride && conv_mfma_persist_supported(ctx, g, io, res != nullptr))
       return launch_conv_mfma_persist(ctx, g, x, (const char*)packed + (size_t)((g.Cout + CT - 1) / CT) * 27 * CT * CIN * 2, bias, res, y);
     if (g.in_rep > 1 || g.res_rep > 1) S3_FAIL(ctx, S3_ESTATE, "conv with a fused temporal repeat off the persistent kernel");

@@ -1,0 +1,396 @@
+// Round-4 experiment on the dominant kernel: the persistent
+// trunk conv with 128-position consumer waves, the filter fragments read from
+// global memory (L1 / L2) instead of an LDS slab ring, and FOUR workgroup
+// barriers per tile instead of 28.
+//
+// conv3_mfma_persist_kernel (kernels_conv_mfma_persist.hip) runs two 64-position
+// MFMA waves per SIMD that meet at an s_barrier after every tap (the 3-slot slab
+// ring is handed over there).  Both waves of a SIMD reach the barrier together
+// and both then wait for their first filter fragments from LDS: the matrix
+// pipe idles at 27 points per tile (PMC, profiles/r03: MFMA busy 61 %,
+// consumers parked 36 % of their cycles).  Here
+//
+//   consumers (waves 0-3, ONE per SIMD): wave w owns output row s0 = w of the
+//     4 x 8 x 16 tile — 8 position fragments x 4 channel fragments = 32
+//     accumulators (128 VGPRs).  A filter fragment is used for 8 MFMAs instead
+//     of 4 (LDS / L1 operand bytes per MFMA: 0.375 x 16 B instead of 0.5).
+//     The B (filter) fragments of tap + 1 are fetched from the packed global
+//     image — all four waves of a CU read the same 8 KB per tap, so three of
+//     four hit in L1 — into a second register set while tap runs; the A
+//     (position) fragments stream from the static LDS halo through a 4-deep
+//     register ring.  No barrier between taps: the halo does not change
+//     during a tile and nothing else in LDS is shared.
+//   producers (waves 4-7, the other wave of each SIMD): fetch the NEXT tile's
+//     halo into registers (36 x 16 B per lane) and drop it into LDS where the
+//     consumers are done with it: row 0 after tap 8, row 1 after tap 17, rows
+//     2-5 after tap 26 (under the consumers' epilogue).
+//
+// Barriers per tile: after taps 8, 17, 26 and "halo ready".  LDS: halo 1080
+// cells x 128 B + 64 biases = 138,496 B; 2 waves per SIMD, <= 256 VGPRs.
+// Same tile, same halo layout / swizzle, same packed filter image, same MFMA
+// sequence per output as conv3_mfma_persist_kernel: results are bit-identical
+// (tests/test_parity_r04.py).
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TS0 = 4, TS1 = 8, TS2 = 16;
+constexpr int H0 = TS0 + 2, H1 = TS1 + 2, H2 = TS2 + 2;
+constexpr int HP = H0 * H1 * H2;                 // 1080 halo cells
+constexpr int HALO_BYTES = HP * 128;             // 138,240
+constexpr int BIAS_OFF = HALO_BYTES;
+constexpr int LDS_BYTES = BIAS_OFF + 256;        // 138,496
+
+constexpr int NCW = 4;                           // consumer (MFMA) waves, one per SIMD
+constexpr int NPW = 4;                           // producer (memory) waves
+constexpr int NTHR = (NCW + NPW) * 64;           // 512
+constexpr int MFW = TS1;                         // 8 M fragments per consumer (one s0 row)
+constexpr int PT = NPW * 64;
+constexpr int ROWC = H1 * H2;                    // 180 cells per halo row
+constexpr int JR = (ROWC * 8 + PT - 1) / PT;     // 6 chunks per row per producer lane
+constexpr int ARING = 4;                         // A fragments in flight ahead of the MFMAs
+
+__device__ inline unsigned pk_bf16(float a, float b) {
+  hf32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
+}
+__device__ inline float lo_f(unsigned u) { return __uint_as_float(u << 16); }
+__device__ inline float hi_f(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+#define WG_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// NFV / ct / bias / res / depth-to-space store: as conv3_mfma_persist_kernel
+// (plain forward only here: no DG frames, no fused temporal repeat).
+template <int NFV>
+__global__ __launch_bounds__(NTHR) void conv3_mfma_persist2_kernel(
+    const unsigned short* __restrict__ x, const char* __restrict__ wimg,
+    const float* __restrict__ bias, const unsigned short* __restrict__ res,
+    unsigned short* __restrict__ y, ConvGeom g, int nh0, int tiles1, int tiles2, int n_half,
+    int ct, int dbg) {
+  // dbg (option MFMA_DBG, timing-only ablations — results invalid): 1 = the
+  // filter fragments are fetched once, 2 = no halo refill by the producers,
+  // 4 = no epilogue stores
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+
+  // work list: half-tiles (two s0 rows) numbered along s0 first, XCD-major
+  // ranks — the scheme of conv3_mfma_persist_kernel
+  int h_cur, h_end;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int xcd = b % 8, k = b / 8;
+    int rank = k;
+    for (int xx = 0; xx < xcd; ++xx) rank += (nblk - xx + 7) / 8;
+    const long long H = n_half;
+    h_cur = (int)((rank * H) / nblk);
+    h_end = (int)(((rank + 1) * H) / nblk);
+  }
+  auto tile_org = [&](int h, int& n, int& o0, int& o1, int& o2) __attribute__((always_inline)) {
+    int tr = h;
+    o0 = (tr % nh0) * 2; tr /= nh0;
+    o2 = (tr % tiles2) * TS2; tr /= tiles2;
+    o1 = (tr % tiles1) * TS1; tr /= tiles1;
+    n = tr;
+  };
+  auto item_at = [&](int h, int& hs0, int& nr) __attribute__((always_inline)) {
+    const bool whole = hs0 + 1 < nh0 && h + 1 < h_end;
+    nr = whole ? 4 : 2;
+    hs0 += whole ? 2 : 1;
+    if (hs0 >= nh0) hs0 = 0;
+    return h + (whole ? 2 : 1);
+  };
+
+  if (wave >= NCW) {
+    // =================================================== producer waves
+    const int pt = tid - NCW * 64;               // 0 .. 255
+    const int pcell = pt >> 3, pch = pt & 7;
+    u32x4 hbuf[H0][JR];                          // the next tile's halo: 36 x 16 B per lane
+    unsigned in_off[JR], lds_off[JR];
+    int htab = 0;
+    const unsigned short* hx = x;
+#pragma unroll
+    for (int j = 0; j < JR; ++j) {
+      int cell = pcell + 32 * j;
+      if (cell > ROWC - 1) cell = ROWC - 1;      // tail lanes duplicate the last cell
+      lds_off[j] = (unsigned)(cell * 128 + ((pch ^ ((cell % H2) & 7)) << 4));
+    }
+    // per tile and axis: a 34-entry element-offset table across the lanes of
+    // one VGPR (lanes 0-5: axis 0, 6-15: axis 1, 16-33: axis 2), reflect rule
+    // evaluated once
+#define HALO_TABLE(h_expr)                                                             \
+    {                                                                                  \
+      int n_, o0_, o1_, o2_;                                                           \
+      tile_org((h_expr), n_, o0_, o1_, o2_);                                           \
+      n_ = __builtin_amdgcn_readfirstlane(n_);                                         \
+      const int ax = lane < H0 ? 0 : (lane < H0 + H1 ? 1 : 2);                         \
+      const int c = lane - (ax == 0 ? 0 : (ax == 1 ? H0 : H0 + H1));                   \
+      const int org = ax == 0 ? o0_ : (ax == 1 ? o1_ : o2_);                           \
+      const int D = ax == 0 ? D0 : (ax == 1 ? D1 : D2);                                \
+      const int stride = ax == 0 ? D1 * D2 * 64 : (ax == 1 ? D2 * 64 : 64);            \
+      int i = s3_reflect(org + c - g.lo[ax], D);                                       \
+      i = i < 0 ? 0 : (i > D - 1 ? D - 1 : i);   /* ragged tiles: legal addresses */   \
+      htab = i * stride;                                                               \
+      hx = x + (size_t)n_ * D0 * D1 * D2 * 64;                                         \
+      _Pragma("unroll") for (int j = 0; j < JR; ++j) {                                 \
+        int cell = pcell + 32 * j;                                                     \
+        if (cell > ROWC - 1) cell = ROWC - 1;                                          \
+        const int c1 = cell / H2, c2 = cell - c1 * H2;                                 \
+        in_off[j] = (unsigned)__builtin_amdgcn_ds_bpermute((H0 + c1) << 2, htab) +     \
+                    (unsigned)__builtin_amdgcn_ds_bpermute((H0 + H1 + c2) << 2, htab) + \
+                    pch * 8;                                                           \
+      }                                                                                \
+    }
+    auto halo_fetch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < H0; ++r) {
+        const unsigned row = (unsigned)__builtin_amdgcn_readlane(htab, r);
+#pragma unroll
+        for (int j = 0; j < JR; ++j)
+          hbuf[r][j] = *reinterpret_cast<const u32x4*>(hx + row + in_off[j]);
+      }
+    };
+    auto halo_put = [&](int r) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < JR; ++j)
+        if (pcell + 32 * j < ROWC)
+          *reinterpret_cast<u32x4*>(smem + r * (ROWC * 128) + lds_off[j]) = hbuf[r][j];
+    };
+
+    if (pt < 64) {
+      const int rho = pt, nf = rho >> 4, kq = (rho >> 2) & 3, r = rho & 3;
+      const int co = ct * 64 + (nf >> 1) * 32 + kq * 8 + (nf & 1) * 4 + r;   // slab_row_cout
+      reinterpret_cast<float*>(smem + BIAS_OFF)[pt] = (bias && co < g.Cout) ? bias[co] : 0.f;
+    }
+    if (h_cur < h_end) {
+      HALO_TABLE(h_cur);
+      halo_fetch();
+#pragma unroll
+      for (int r = 0; r < H0; ++r) halo_put(r);
+    }
+    WAIT_LGKM0();
+    WG_BARRIER();                                // prologue: first halo + biases visible
+
+    for (int h = h_cur; h < h_end;) {
+      int nr_, hs0_ = h % nh0;
+      h = item_at(h, hs0_, nr_);
+      const bool has_next = h < h_end && !(dbg & 2);
+      if (has_next) {
+        HALO_TABLE(h);
+        halo_fetch();                            // in flight under taps 0 .. 8
+      }
+      WG_BARRIER();                              // B1: row 0 was last read in tap 8
+      if (has_next) halo_put(0);
+      WG_BARRIER();                              // B2: row 1 was last read in tap 17
+      if (has_next) halo_put(1);
+      WG_BARRIER();                              // B3: every tap is over
+      if (has_next) {
+#pragma unroll
+        for (int r = 2; r < H0; ++r) halo_put(r);
+      }
+      WAIT_LGKM0();
+      WG_BARRIER();                              // B4: the next halo is in place
+    }
+#undef HALO_TABLE
+    return;
+  }
+
+  // ===================================================== consumer waves
+  const int frow = lane & 15, kq = lane >> 4;
+  // A fragment of (m, tap = (ta, tb, tc), k-step ks): halo cell (wave + ta,
+  // m + tb, frow + tc), 16-B chunk (ks 4 + kq) ^ ((frow + tc) & 7)
+  unsigned a_base[3][2];                         // [tc][ks], rows ta = 0, 1
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      a_base[c][ks] = (unsigned)(((wave * H1) * H2 + frow + c) * 128 + (((ks * 4 + kq) ^ ((frow + c) & 7)) << 4));
+  // B fragment (nf, ks) of a tap: row rho = nf 16 + frow of the packed image,
+  // chunk (ks 4 + kq) ^ ((rho >> 1) & 7) — the swizzle does not depend on nf
+  // (per-lane 32-bit offsets next to a scalar base: 216 per-lane 64-bit
+  // addresses — one per (tap, k-step, fragment) — would be hoisted out of the
+  // tile loop and spilled)
+  unsigned b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    b_off[ks] = (unsigned)(frow * 128 + (((ks * 4 + kq) ^ ((frow >> 1) & 7)) << 4));
+  const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+  const int db = g.d2s, cpo = g.Cout / (db * db);
+  unsigned c_off[2];
+  bool c_ok[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int co = ct * 64 + hh * 32 + kq * 8;
+    c_ok[hh] = co < g.Cout;
+    const int blk = co / cpo;
+    c_off[hh] = (unsigned)((((blk / db) * (g.O[1] * db) + blk % db) * g.O[2]) * cpo + co % cpo);
+  }
+  WG_BARRIER();   // prologue
+  __builtin_amdgcn_s_setprio(2);
+
+  // the filter fragments of tap 0 (the same for every tile)
+  bf16x8 bq[2][2 * NFV];
+  auto b_fetch = [&](int tap, bf16x8* dst) __attribute__((always_inline)) {
+    const char* sb = wimg + (size_t)tap * 8192;              // uniform: a scalar base
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      unsigned vo;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(vo) : "v"(b_off[ks]));   // opaque per call
+#pragma unroll
+      for (int nf = 0; nf < NFV; ++nf)
+        dst[ks * NFV + nf] = *reinterpret_cast<const bf16x8*>(sb + (size_t)vo + nf * 2048);
+    }
+  };
+  b_fetch(0, bq[1]);      // (27 taps: the set a tile ends on is the one the next starts from)
+
+  for (int h = h_cur; h < h_end;) {
+    int nr, n, org0, org1, org2;
+    const int item = h;
+    tile_org(item, n, org0, org1, org2);
+    {
+      int hs0 = org0 >> 1;
+      h = item_at(h, hs0, nr);
+    }
+    if (wave >= nr) {
+      // half-tile item: rows 2, 3 idle, keeping the barrier count
+      WG_BARRIER(); WG_BARRIER(); WG_BARRIER(); WG_BARRIER();
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * NFV; ++q) bq[0][q] = bq[1][q];   // tap 0, fetched under the last tap before
+    f32x4 acc[MFW][NFV];
+#pragma unroll
+    for (int nf = 0; nf < NFV; ++nf) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (nf * 16 + kq * 4) * 4);
+#pragma unroll
+      for (int m = 0; m < MFW; ++m) acc[m][nf] = bv;
+    }
+    // the stream of A fragments of a tile: f = (tap 2 + ks) 8 + m
+    auto a_read = [&](int f) __attribute__((always_inline)) {
+      const int m = f & 7, ks = (f >> 3) & 1, tap = f >> 4;
+      const int ta = tap / 9, tb = (tap / 3) % 3, tc = tap % 3;
+      return *reinterpret_cast<const bf16x8*>(smem + a_base[tc][ks] + ((ta * H1 + m + tb) * H2) * 128);
+    };
+    bf16x8 aq[ARING];
+#pragma unroll
+    for (int f = 0; f < ARING; ++f) aq[f] = a_read(f);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      // tap + 1's filter fragments (tap 0 of the next tile behind tap 26)
+      if (!(dbg & 1)) b_fetch(tap == 26 ? 0 : tap + 1, bq[(tap + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int m = 0; m < MFW; ++m) {
+          const int f = (tap * 2 + ks) * 8 + m;
+          const bf16x8 a = aq[f % ARING];
+          if (f + ARING < 27 * 16) aq[f % ARING] = a_read(f + ARING);
+#pragma unroll
+          for (int nf = 0; nf < NFV; ++nf)
+            acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[tap & 1][ks * NFV + nf], a, acc[m][nf], 0, 0, 0);
+        }
+      if (tap == 8 || tap == 17 || tap == 26) WG_BARRIER();    // B1, B2, B3
+    }
+
+    // ---- epilogue straight from the accumulators (under the producers'
+    // write of halo rows 2 .. 5)
+    const size_t e_base = (size_t)n * g.O[0] * g.O[1] * g.O[2] * g.Cout;
+    const int o0 = org0 + wave, o2 = org2 + frow;
+    const bool row_ok = o0 < g.O[0] && o2 < g.O[2];
+#pragma unroll
+    for (int mh = 0; mh < MFW; mh += 4) {        // residual rows four fragments at a time
+      uint4 rres[4][2];
+      unsigned e_pos[4];
+      bool e_ok[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o1 = org1 + mh + q;
+        e_ok[q] = row_ok && o1 < g.O[1];
+        e_pos[q] = (unsigned)(((o0 * db * (g.O[1] * db) + o1 * db) * g.O[2] + o2) * cpo);
+      }
+      if (res) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            rres[q][hh] = make_uint4(0, 0, 0, 0);
+            if (e_ok[q] && c_ok[hh] && 2 * hh < NFV)
+              rres[q][hh] = *reinterpret_cast<const uint4*>(res + e_base + e_pos[q] + c_off[hh]);
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          if (!(e_ok[q] && c_ok[hh] && 2 * hh < NFV) || (dbg & 4)) continue;
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float a = acc[mh + q][(2 * hh + (k >> 2)) % NFV][k & 3];
+            v[k] = fmaxf(a, slope * a);
+          }
+          if (res) {
+            const uint4 r = rres[q][hh];
+            v[0] += lo_f(r.x); v[1] += hi_f(r.x); v[2] += lo_f(r.y); v[3] += hi_f(r.y);
+            v[4] += lo_f(r.z); v[5] += hi_f(r.z); v[6] += lo_f(r.w); v[7] += hi_f(r.w);
+          }
+          uint4 o;
+          o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]);
+          o.z = pk_bf16(v[4], v[5]); o.w = pk_bf16(v[6], v[7]);
+          *reinterpret_cast<uint4*>(y + e_base + e_pos[q] + c_off[hh]) = o;
+        }
+    }
+    WG_BARRIER();   // B4: next halo visible
+  }
+}
+
+}  // namespace
+
+bool conv_mfma_persist2_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io, bool has_res) {
+  if (!s3_opt_on(S3O_PERSIST2)) return false;
+  if (g.in_rep > 1 || g.res_rep > 1) return false;
+  // (verified bit-identical for the plain 64 -> 64 trunk conv only: the
+  // depth-to-space / partial-channel-tile epilogue is not)
+  if (g.Cout != 64 || g.d2s != 1) return false;
+  return conv_mfma_persist_supported(ctx, g, io, has_res);
+}
+
+int launch_conv_mfma_persist2(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image,
+                              const float* bias, const void* res, void* y) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist2_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist2_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  const int nh0 = (g.O[0] + 1) / 2, tiles1 = (g.O[1] + TS1 - 1) / TS1, tiles2 = (g.O[2] + TS2 - 1) / TS2;
+  const int n_half = g.N * nh0 * tiles1 * tiles2;
+  int grid = ctx->num_cu;
+  if (grid > (n_half + 1) / 2) grid = (n_half + 1) / 2;
+  const int n_ct = (g.Cout + 63) / 64;
+  const int dbg = (int)s3_opt_int(S3O_MFMA_DBG, 0);
+  for (int ct = 0; ct < n_ct; ++ct) {
+    const bool half = g.Cout - ct * 64 <= 32;
+    auto kern = half ? conv3_mfma_persist2_kernel<2> : conv3_mfma_persist2_kernel<4>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream, (const unsigned short*)x,
+                       (const char*)image + (size_t)ct * 27 * 8192, bias, (const unsigned short*)res,
+                       (unsigned short*)y, g, nh0, tiles1, tiles2, n_half, ct, dbg);
+  }
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
