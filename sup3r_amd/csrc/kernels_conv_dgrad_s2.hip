@@ -155,6 +155,15 @@ __global__ __launch_bounds__(SNT) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   };
   if (mpre) mask_fetch(0, mk);
   if (MB) mask_fetch(0, reinterpret_cast<uint4*>(mb));
+  // O16: the two t-parity classes of a (p0, p1) pair are adjacent positions of
+  // x — 64 B each.  Stored class by class they left every 128-B line half
+  // written for the length of a class (the tile's 262 KB of output per
+  // workgroup do not stay in L2 that long); the even class is now held packed
+  // (8 x 16 B per lane) and goes out together with the odd one: both halves of
+  // a line within one pair of store instructions.
+  // (with the sign-byte mask only: the bf16-mask variant has no registers left)
+  constexpr bool PAIR = O16 && MB;
+  uint4 keep[PAIR ? 8 : 1];
   // wave w owns the u rows (r0 = w, r1 = 0..7)
 #pragma unroll 1
   for (int cls = 0; cls < 8; ++cls) {
@@ -226,8 +235,17 @@ __global__ __launch_bounds__(SNT) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
 #pragma unroll
         for (int q8 = 0; q8 < 8; ++q8) csum[q8] += v[q8];
-        *reinterpret_cast<uint4*>(dx16 + e) =
-            make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+        const uint4 pk = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+        if constexpr (!PAIR) {
+          *reinterpret_cast<uint4*>(dx16 + e) = pk;
+        } else if (p2 == 0) {
+          // (the last even position of an odd extent has no partner)
+          if (i2 + 1 < g.D[2]) keep[m] = pk;
+          else *reinterpret_cast<uint4*>(dx16 + e) = pk;
+        } else {
+          *reinterpret_cast<uint4*>(dx16 + e - 32) = keep[m];
+          *reinterpret_cast<uint4*>(dx16 + e) = pk;
+        }
       }
       if (mpre) {
 #pragma unroll

@@ -110,7 +110,8 @@ def test_persistent_kernel_has_no_scratch(tmp_path):
         assert scratch == 0 and spills == 0, (scratch, spills)
 
 
-def test_profiles_table_regenerates():
+@pytest.mark.parametrize('rnd', ['r03', 'r04'])
+def test_profiles_table_regenerates(rnd):
     """``tools/pmc_table.py`` (the counter-bytes vs algorithmic-bytes table of
     ``profiles/r03/README.md`` / DESIGN.md 6.1) still parses the committed
     rocprofv3 summaries and finds every HBM-class kernel it lists."""
@@ -119,8 +120,8 @@ def test_profiles_table_regenerates():
     root = os.path.join(os.path.dirname(__file__), '..')
     out = subprocess.run(
         [sys.executable, os.path.join(root, 'tools', 'pmc_table.py'),
-         os.path.join(root, 'profiles', 'r03', 'pmc_train.txt'),
-         os.path.join(root, 'profiles', 'r03', 'train_kernel_stats.txt')],
+         os.path.join(root, 'profiles', rnd, 'pmc_train.txt'),
+         os.path.join(root, 'profiles', rnd, 'train_kernel_stats.txt')],
         capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr[-1000:]
     rows = [ln for ln in out.stdout.splitlines() if ln.startswith('| `')]
