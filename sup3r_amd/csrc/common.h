@@ -42,6 +42,7 @@
   X(NO_DGRAD_CHUNKED) \
   X(NO_DGRAD_FEWCH) \
   X(NO_DGRAD_S2) \
+  X(NO_DGRAD_X3) \
   X(NO_DISC_BF16) \
   X(NO_DPRE16) \
   X(NO_DPRE16_ONLY_MASK) \
@@ -264,6 +265,16 @@ bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* dpre16, const void* image,
                                    float* dxp, int accumulate = 0, int frame16 = 0);
 int launch_conv_mfma_persist_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
+// split-bf16 (BF16X3) LDS-halo data gradients of the hi-res discriminator layers
+bool conv_dgrad_c2_x3_supported(const ConvGeom& g, int precision);
+size_t conv_dgrad_c2_x3_packed_bytes();
+int launch_conv_dgrad_c2_x3_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
+int launch_conv_dgrad_c2_x3(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx);
+bool conv_dgrad_s2_x3_supported(const s3_ctx* ctx, const ConvGeom& g, int precision);
+size_t conv_dgrad_s2_x3_packed_bytes(const ConvGeom& g);
+int launch_conv_dgrad_s2_x3_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* img);
+int launch_conv_dgrad_s2_x3(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx,
+                            const float* mask_y, float mask_slope);
 // round-4 experiment: 128-position consumer waves, filter fragments from L1 / L2
 bool conv_mfma_persist2_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io, bool has_res);
 int launch_conv_mfma_persist2(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image,

@@ -657,8 +657,11 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
             o.dgrad_mfma = o.dgrad_chunked = true;
             o.dgrad_valid = g.lo[0] == 0;
           }
-          o.dgrad_c2 = !o.dgrad_mfma && !o.fewpos && conv_dgrad_c2_supported(g, precision);
-          o.dgrad_s2 = !o.dgrad_mfma && !o.dgrad_c2 && !o.fewpos && conv_dgrad_s2_supported(ctx, g, precision);
+          // (BF16X3 plans: the split-bf16 forms of the same two kernels, round 4)
+          o.dgrad_c2 = !o.dgrad_mfma && !o.fewpos &&
+                       (conv_dgrad_c2_supported(g, precision) || conv_dgrad_c2_x3_supported(g, precision));
+          o.dgrad_s2 = !o.dgrad_mfma && !o.dgrad_c2 && !o.fewpos &&
+                       (conv_dgrad_s2_supported(ctx, g, precision) || conv_dgrad_s2_x3_supported(ctx, g, precision));
           o.gconv_dgrad = !o.dgrad_mfma && !o.dgrad_c2 && !o.dgrad_s2 && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
           if (o.gconv_dgrad && g.pad_mode == S3_PAD_REFLECT)
             max_dxp = std::max(max_dxp, (size_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
@@ -1015,7 +1018,8 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
     if (o.dgrad_s2) {
-      int rc = plan_alloc(pl, &o.dc2_w, conv_dgrad_s2_packed_bytes(o.cg));
+      int rc = plan_alloc(pl, &o.dc2_w, precision == S3_PREC_BF16X3 ? conv_dgrad_s2_x3_packed_bytes(o.cg)
+                                                                    : conv_dgrad_s2_packed_bytes(o.cg));
       if (rc) { s3_plan_destroy(pl); return rc; }
       // its fused activation mask as sign bytes written by the producer's
       // forward kernel (4 B instead of 64 B per position read back)
@@ -1029,7 +1033,8 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
       }
     }
     if (o.dgrad_c2) {
-      int rc = plan_alloc(pl, &o.dc2_w, conv_dgrad_c2_packed_bytes());
+      int rc = plan_alloc(pl, &o.dc2_w, precision == S3_PREC_BF16X3 ? conv_dgrad_c2_x3_packed_bytes()
+                                                                    : conv_dgrad_c2_packed_bytes());
       if (rc) { s3_plan_destroy(pl); return rc; }
     }
     if (o.gconv_dgrad) {
@@ -1912,6 +1917,19 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
             fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
             fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
             rc = fold_frame(fg, dst, frame16);
+          } else if (o.dgrad_s2 && pl->precision == S3_PREC_BF16X3) {
+            if (o.dc2_version != (int64_t)P->version) {
+              rc = launch_conv_dgrad_s2_x3_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);
+              if (rc) return rc;
+              o.dc2_version = (int64_t)P->version;
+            }
+            const int rin = root_of(pl, d.in0);
+            const bool fuse = o.mask_prod >= 0 && !pl->gwritten[rin] && !s3_opt_has(S3O_NO_MASK_FUSE) &&
+                              pl->t[rin].dtype == 0;
+            const ConvGeom& pg = pl->ops[fuse ? o.mask_prod : i].cg;
+            rc = launch_conv_dgrad_s2_x3(ctx, g, dpre, o.dc2_w, dst, fuse ? (const float*)tptr(pl, d.in0) : nullptr,
+                                         pg.act == S3_ACT_LEAKY ? pg.alpha : 0.f);
+            if (!rc && fuse) pl->premasked[rin] = 1;
           } else if (o.dgrad_s2) {
             if (o.dc2_version != (int64_t)P->version) {
               rc = launch_conv_dgrad_s2_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);
@@ -1948,6 +1966,13 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
               pl->dpre16_for = rin; pl->dpre16_only = true;
               if (sums) { pl->bsum_for = rin; pl->bsum_nblk = nblk; }
             }
+          } else if (o.dgrad_c2 && pl->precision == S3_PREC_BF16X3) {
+            if (o.dc2_version != (int64_t)P->version) {
+              rc = launch_conv_dgrad_c2_x3_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);
+              if (rc) return rc;
+              o.dc2_version = (int64_t)P->version;
+            }
+            rc = launch_conv_dgrad_c2_x3(ctx, g, dpre, o.dc2_w, dst);
           } else if (o.dgrad_c2) {
             if (o.dc2_version != (int64_t)P->version) {
               rc = launch_conv_dgrad_c2_pack(ctx, g, W + P->p[d.w].offset, o.dc2_w);

@@ -34,7 +34,7 @@ def _trunk_spec(tail_d2s=False):
     ((16, 16, 16, 48, 4), False),      # whole tiles
     ((6, 22, 22, 48, 4), False),       # the C3 chunk: 11 half rows, ragged s1
     ((6, 21, 19, 40, 4), False),       # odd rows, ragged everywhere
-    ((8, 16, 16, 32, 4), True),        # 64 -> 200 + depth-to-space, 4 channel tiles
+    ((8, 16, 16, 64, 4), True),        # 64 -> 200 + depth-to-space, 4 channel tiles
 ])
 def test_persist2_is_bit_identical_to_the_persistent_kernel(shape, d2s):
     from sup3r_amd.engine import Network
@@ -57,3 +57,53 @@ def test_persist2_is_bit_identical_to_the_persistent_kernel(shape, d2s):
     assert np.isfinite(ref[0]).all() and np.abs(ref[0]).max() > 0
     for y in got + ref[1:]:
         np.testing.assert_array_equal(y, ref[0])
+
+
+def test_bf16x3_lds_halo_data_gradients_of_the_hires_discriminator_layers():
+    """``conv_dgrad_c2_x3_kernel`` (32 -> 2 full correlation behind the first
+    discriminator layer) and ``conv_dgrad_s2_x3_kernel`` (32 -> 32 stride 2),
+    the split-bf16 forms BF16X3 plans use since round 4, on ragged tiles:
+    forward 1e-4 / every gradient 1e-3 against the fp32 oracle under the
+    device's masks (the BF16X3 bounds of tests/test_parity_r02.py), the two
+    kernels selected, and agreement with the gather-MFMA adjoint they replace
+    (option ``NO_DGRAD_X3``) to fp32 summation order.  Reference:
+    sup3r/models/base.py:283-313 (``_tf_discriminate``) under
+    ``abstract.py:1190-1238``."""
+    from sup3r_amd import spec as S
+    from sup3r_amd.engine import Network
+    from tests.helpers import rel_max
+    from tests.test_parity_r02 import _fwd_bwd_vs_oracle
+
+    def conv(f, s):
+        return [{'class': 'Conv3D', 'filters': f, 'kernel_size': 3,
+                 'strides': s, 'padding': 'valid'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = conv(32, 1) + conv(32, 2) + conv(16, 1)
+    shape = (2, 21, 23, 37, 2)
+    switch('DGRAD_S2_MIN_TILES', 1)
+    ph = _fwd_bwd_vs_oracle(spec, shape, 'bf16x3', 53, 1e-4, 1e-3)
+    dg = [ph.op_info(i)['dgrad'] for i, op in enumerate(ph.plan.ops)
+          if op['kind'] == S.OP_CONV]
+    assert dg[0] == 'c2' and dg[1] == 's2', dg
+    rng = np.random.default_rng(54)
+    x = rng.standard_normal(shape).astype(np.float32)
+
+    def run():
+        net = Network(spec, precision='bf16x3')
+        net.build(shape, seed=7)
+        p = net.plan(shape, training=True)
+        y = p.forward(net.dev.to_device(x))
+        dy = net.dev.to_device(np.random.default_rng(55).standard_normal(
+            tuple(y.shape)).astype(np.float32))
+        dx = p.backward(dy, need_dx=True).cpu().numpy()
+        g = [a.copy() for a in net.grads]
+        net.clear_plans()
+        return dx, g
+    dx1, g1 = run()
+    switch('NO_DGRAD_X3', 1)
+    dx0, g0 = run()
+    switch('NO_DGRAD_X3', None)
+    assert np.abs(dx1 - dx0).max() > 0            # another kernel ran
+    assert rel_max(dx1, dx0) < 1e-4, rel_max(dx1, dx0)
+    for a, b in zip(g1, g0):
+        assert rel_max(a, b) < 1e-4
