@@ -61,6 +61,7 @@
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \
+  X(NO_PERSIST_STRIP) \
   X(PERSIST2) \
   X(NO_REPEAT_FUSE) \
   X(NO_WGRAD_X3) \

@@ -72,6 +72,28 @@ constexpr int early_k(int t) { return (t >= 0 && t < JR) || (t >= 9 && t < 9 + J
 constexpr int late_k(int t) { return t >= 0 && t < NLATE ? 1 : 0; }
 constexpr int halo_k(int t) { return early_k(t) + late_k(t); }
 
+// Round 4: the tile width along s1 is a template parameter TW (8, or 6 for the
+// last column strip of an extent like the C3 chunk's 22 = 8 + 8 + 6: three
+// 8-column tiles compute 24 columns).  PGeo<TW> carries what depends on it; the
+// kernel body names them as before (local constants shadow the TW = 8 ones
+// above, which the launch code keeps using).  A 6-column tile is 4 rows x 2
+// groups of 3 position fragments per consumer wave.
+template <int TW>
+struct PGeo {
+  static constexpr int TS1 = TW, H1 = TW + 2;
+  static constexpr int HP = H0 * H1 * H2, HALO_BYTES = HP * 128, SLAB_OFF = HALO_BYTES;
+  static constexpr int BIAS_OFF = SLAB_OFF + 3 * 8192, LDS_BYTES = BIAS_OFF + 256;
+  static constexpr int MFW = TS0 * TW / NCW;
+  static constexpr int ROWC = H1 * H2;
+  static constexpr int JR = (ROWC * 8 + PT - 1) / PT;
+  static constexpr int NLATE = (H0 - 2) * JR;
+  static_assert(MFW * NCW == TS0 * TW && TW % MFW == 0 && (MFW == 4 || MFW == 3), "tile / wave split");
+  static_assert(JR <= 6 && NLATE <= 24 && H0 + H1 + H2 <= 64, "producer tap schedule / halo table");
+  static constexpr int early_k(int t) { return (t >= 0 && t < JR) || (t >= 9 && t < 9 + JR) ? 1 : 0; }
+  static constexpr int late_k(int t) { return t >= 0 && t < NLATE ? 1 : 0; }
+  static constexpr int halo_k(int t) { return early_k(t) + late_k(t); }
+};
+
 __device__ inline unsigned pk_bf16(float a, float b) {
   hf32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
@@ -184,7 +206,7 @@ __global__ void pack_jobs_kernel(const S3PackJob* __restrict__ jobs) {
 // fold's sum of <= 8 frame cells is then the sum of bf16-rounded terms (the
 // rounding point tests/helpers.emulate_plan installs in the oracle's pad
 // adjoint).
-template <int NFV, bool DG, int REP = 0, bool RIN = false, bool F16 = false>
+template <int NFV, bool DG, int REP = 0, bool RIN = false, bool F16 = false, int TW = 8>
 __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg,
     const float* __restrict__ bias, const unsigned short* __restrict__ res,
@@ -192,6 +214,11 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     int tiles2, int n_tiles, int ct, int gs0, int gs1) {
   // ct: which 64-wide output-channel tile this launch computes (C_out > 64:
   // one launch per tile; wimg / bias already point at the tile's image)
+  // gs1 (forward launches, !DG): first s1 column of this launch's strip
+  using PG = PGeo<TW>;
+  constexpr int TS1 = PG::TS1, H1 = PG::H1, HP = PG::HP, SLAB_OFF = PG::SLAB_OFF, BIAS_OFF = PG::BIAS_OFF;
+  constexpr int MFW = PG::MFW, ROWC = PG::ROWC, JR = PG::JR, NLATE = PG::NLATE;
+  (void)HP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -227,7 +254,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     int tr = h;
     o0 = (tr % tiles0) * 2; tr /= tiles0;
     o2 = (tr % tiles2) * TS2; tr /= tiles2;
-    o1 = (tr % tiles1) * TS1; tr /= tiles1;
+    o1 = (tr % tiles1) * TS1 + (DG ? 0 : gs1); tr /= tiles1;
     n = tr;
   };
   // work item starting at half-tile h, whose half-row index hs0 = h % nh0 is
@@ -423,7 +450,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
         // consumers pass this barrier.  Younger vector-memory ops: the halo
         // chunks of the previous tap (issued after its DMA), this tap's 2 DMA
         // pieces and its chunks.
-        wait_vm_n(2 + halo_k(tap) + halo_k(tap - 1));
+        wait_vm_n(2 + PG::halo_k(tap) + PG::halo_k(tap - 1));
         WG_BARRIER();
       }
       // every consumer is past its last halo read: rows 2..5 may land
@@ -815,6 +842,9 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     S3_REP_ATTR(2) S3_REP_ATTR(3) S3_REP_ATTR(4)
 #undef S3_REP_ATTR
+    S3_HIP(ctx, hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false, 0, false, false, 6>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, PGeo<6>::LDS_BYTES));
     attr_set = true;
   }
   // (tiles0 = half rows along s0, n_tiles = half-tiles: the kernel's work units)
@@ -838,6 +868,29 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
     if (!ok) S3_FAIL(ctx, S3_ESTATE, "persistent conv: unsupported fused temporal repeat");
     if (rin) gk.D[2] = g.D[2] / rep;
   }
+  // Column strips (round 4): an s1 extent with 1 .. 6 columns beyond a multiple
+  // of 8 runs its last columns as ONE strip of 6-column tiles in a launch of
+  // its own (TW = 6: 22 columns = 8 + 8 + 6 computed, not 24) — plain 64 -> 64
+  // trunk convs only, and only when that strip still fills the chip.
+  const int rem1 = g.O[1] % TS1;
+  const int64_t strip_halves = (int64_t)g.N * tiles0 * tiles2;
+  if (!rep && g.Cout == 64 && g.d2s == 1 && rem1 >= 1 && rem1 <= 6 && g.O[1] > TS1 &&
+      strip_halves >= 2 * (int64_t)ctx->num_cu && !s3_opt_has(S3O_NO_PERSIST_STRIP)) {
+    const int t1a = g.O[1] / TS1;
+    const int na = g.N * tiles0 * t1a * tiles2, nb = (int)strip_halves;
+    int ga = ctx->num_cu, gb = ctx->num_cu;
+    if (ga > (na + 1) / 2) ga = (na + 1) / 2;
+    if (gb > (nb + 1) / 2) gb = (nb + 1) / 2;
+    hipLaunchKernelGGL((conv3_mfma_persist_kernel<4, false>), dim3(ga), dim3(NTHR), LDS_BYTES, ctx->stream,
+                       (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res,
+                       (unsigned short*)y, gk, tiles0, t1a, tiles2, na, 0, 1, 0);
+    hipLaunchKernelGGL((conv3_mfma_persist_kernel<4, false, 0, false, false, 6>), dim3(gb), dim3(NTHR),
+                       PGeo<6>::LDS_BYTES, ctx->stream, (const unsigned short*)x, (const char*)image, bias,
+                       (const unsigned short*)res, (unsigned short*)y, gk, tiles0, 1, tiles2, nb, 0, 1,
+                       t1a * TS1);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   for (int ct = 0; ct < n_ct; ++ct) {
     // a last tile with <= 32 valid channels computes two N fragments only
     const bool half = g.Cout - ct * 64 <= 32;
@@ -848,7 +901,7 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, ctx->stream,
                        (const unsigned short*)x, (const char*)image + (size_t)ct * 27 * 8192, bias,
                        (const unsigned short*)res, (unsigned short*)y, gk, tiles0,
-                       tiles1, tiles2, n_tiles, ct, 1, 1);
+                       tiles1, tiles2, n_tiles, ct, 1, 0);
   }
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;

@@ -107,3 +107,33 @@ def test_bf16x3_lds_halo_data_gradients_of_the_hires_discriminator_layers():
     assert rel_max(dx1, dx0) < 1e-4, rel_max(dx1, dx0)
     for a, b in zip(g1, g0):
         assert rel_max(a, b) < 1e-4
+
+
+@pytest.mark.parametrize('shape', [(8, 22, 22, 208, 4), (4, 20, 13, 400, 4),
+                                   (8, 19, 9, 256, 4)])
+def test_last_column_strip_on_six_column_tiles_is_bit_identical(shape):
+    """An s1 extent of 8 k + r, 1 <= r <= 6 (the C3 chunk's 22 = 8 + 8 + 6)
+    runs its last columns as a strip of 6-column tiles
+    (``conv3_mfma_persist_kernel<.., TW = 6>``, second launch of the conv):
+    same MFMA sequence per output as the 8-column tiles, so bit-identical to
+    the single launch (``NO_PERSIST_STRIP``) — with residuals, r = 6 / 5 / 1."""
+    from sup3r_amd.engine import Network
+    spec = _trunk_spec(False)
+    x = np.random.default_rng(6).standard_normal(shape).astype(np.float32)
+
+    def run(strip):
+        switch('NO_PERSIST_STRIP', None if strip else 1)
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=4)
+        ph = net.plan(shape, training=False)
+        kinds = [ph.op_kernel_class(i) for i in range(len(ph.plan.ops))]
+        assert kinds.count(2) >= 2, kinds
+        ys = [ph.forward(net.dev.to_device(x)).cpu().numpy() for _ in range(3)]
+        net.clear_plans()
+        return ys
+    got = run(True)
+    ref = run(False)
+    switch('NO_PERSIST_STRIP', None)
+    assert np.isfinite(ref[0]).all() and np.abs(ref[0]).max() > 0
+    for y in got + ref[1:]:
+        np.testing.assert_array_equal(y, ref[0])

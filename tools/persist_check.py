@@ -18,7 +18,8 @@ spec = pcc(3, 64) + [{'class': 'SkipConnection', 'name': 'a'}] + \
     pcc(3, 64) + pcc(3, 2, act=False)
 # (22 x 22: 11 half rows, the C3 chunk; 21 x 19: an odd number of rows)
 for shape in [(5, 18, 20, 72, 4), (8, 16, 16, 64, 4), (3, 16, 24, 112, 4),
-              (6, 22, 22, 48, 4), (6, 21, 19, 40, 4), (16, 16, 16, 288, 4)]:
+              (6, 22, 22, 48, 4), (6, 21, 19, 40, 4), (8, 22, 22, 208, 4),
+              (4, 20, 13, 400, 4), (16, 16, 16, 288, 4)]:
     rng = np.random.default_rng(1)
     x = rng.standard_normal(shape).astype(np.float32)
     net = Network(spec, precision='bf16')
