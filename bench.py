@@ -281,8 +281,8 @@ def c3_leg(batch, steps, warmup, world, rank, entry='strategy'):
                 'trunk_conv_useful_tflops': gflop / t_ms,
                 'trunk_conv_frac_of_peak': gflop / t_ms / PEAK_TFLOPS['bf16'],
                 'note': 'useful = the 22 x 22 x 624 positions of a chunk (11 '
-                        'half rows x 3 column tiles of 8: 1.09 x of them are '
-                        'computed)'}
+                        'half rows; columns 8 + 8 + a strip of 6-column tiles '
+                        'in a second launch: no edge tile)'}
         return n, el0, extra
     else:
         slicer = ChunkSlicer((400, 400), 720, 5, 12, (20, 20, 48),

@@ -845,6 +845,9 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
     S3_HIP(ctx, hipFuncSetAttribute(
                     reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false, 0, false, false, 6>),
                     hipFuncAttributeMaxDynamicSharedMemorySize, PGeo<6>::LDS_BYTES));
+    S3_HIP(ctx, hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, false, 0, false, false, 6>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, PGeo<6>::LDS_BYTES));
     attr_set = true;
   }
   // (tiles0 = half rows along s0, n_tiles = half-tiles: the kernel's work units)
@@ -874,20 +877,25 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
   // trunk convs only, and only when that strip still fills the chip.
   const int rem1 = g.O[1] % TS1;
   const int64_t strip_halves = (int64_t)g.N * tiles0 * tiles2;
-  if (!rep && g.Cout == 64 && g.d2s == 1 && rem1 >= 1 && rem1 <= 6 && g.O[1] > TS1 &&
-      strip_halves >= 2 * (int64_t)ctx->num_cu && !s3_opt_has(S3O_NO_PERSIST_STRIP)) {
+  if (!rep && rem1 >= 1 && rem1 <= 6 && g.O[1] > TS1 && strip_halves >= 2 * (int64_t)ctx->num_cu &&
+      !s3_opt_on(S3O_NO_PERSIST_STRIP)) {
     const int t1a = g.O[1] / TS1;
     const int na = g.N * tiles0 * t1a * tiles2, nb = (int)strip_halves;
     int ga = ctx->num_cu, gb = ctx->num_cu;
     if (ga > (na + 1) / 2) ga = (na + 1) / 2;
     if (gb > (nb + 1) / 2) gb = (nb + 1) / 2;
-    hipLaunchKernelGGL((conv3_mfma_persist_kernel<4, false>), dim3(ga), dim3(NTHR), LDS_BYTES, ctx->stream,
-                       (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res,
-                       (unsigned short*)y, gk, tiles0, t1a, tiles2, na, 0, 1, 0);
-    hipLaunchKernelGGL((conv3_mfma_persist_kernel<4, false, 0, false, false, 6>), dim3(gb), dim3(NTHR),
-                       PGeo<6>::LDS_BYTES, ctx->stream, (const unsigned short*)x, (const char*)image, bias,
-                       (const unsigned short*)res, (unsigned short*)y, gk, tiles0, 1, tiles2, nb, 0, 1,
-                       t1a * TS1);
+    for (int ct = 0; ct < n_ct; ++ct) {          // (C_out > 64: one pair of launches per channel tile)
+      const bool half = g.Cout - ct * 64 <= 32;
+      const char* img = (const char*)image + (size_t)ct * 27 * 8192;
+      auto k8 = half ? conv3_mfma_persist_kernel<2, false> : conv3_mfma_persist_kernel<4, false>;
+      auto k6 = half ? conv3_mfma_persist_kernel<2, false, 0, false, false, 6>
+                     : conv3_mfma_persist_kernel<4, false, 0, false, false, 6>;
+      hipLaunchKernelGGL(k8, dim3(ga), dim3(NTHR), LDS_BYTES, ctx->stream, (const unsigned short*)x, img, bias,
+                         (const unsigned short*)res, (unsigned short*)y, gk, tiles0, t1a, tiles2, na, ct, 1, 0);
+      hipLaunchKernelGGL(k6, dim3(gb), dim3(NTHR), PGeo<6>::LDS_BYTES, ctx->stream, (const unsigned short*)x,
+                         img, bias, (const unsigned short*)res, (unsigned short*)y, gk, tiles0, 1, tiles2, nb,
+                         ct, 1, t1a * TS1);
+    }
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }

@@ -109,16 +109,20 @@ def test_bf16x3_lds_halo_data_gradients_of_the_hires_discriminator_layers():
         assert rel_max(a, b) < 1e-4
 
 
-@pytest.mark.parametrize('shape', [(8, 22, 22, 208, 4), (4, 20, 13, 400, 4),
-                                   (8, 19, 9, 256, 4)])
-def test_last_column_strip_on_six_column_tiles_is_bit_identical(shape):
+@pytest.mark.parametrize('shape,d2s', [((8, 22, 22, 208, 4), False),
+                                       ((4, 20, 13, 400, 4), False),
+                                       ((8, 19, 9, 256, 4), False),
+                                       ((8, 22, 22, 104, 4), True)])
+def test_last_column_strip_on_six_column_tiles_is_bit_identical(shape, d2s):
     """An s1 extent of 8 k + r, 1 <= r <= 6 (the C3 chunk's 22 = 8 + 8 + 6)
     runs its last columns as a strip of 6-column tiles
     (``conv3_mfma_persist_kernel<.., TW = 6>``, second launch of the conv):
     same MFMA sequence per output as the 8-column tiles, so bit-identical to
-    the single launch (``NO_PERSIST_STRIP``) — with residuals, r = 6 / 5 / 1."""
+    the single launch (``NO_PERSIST_STRIP``) — with residuals, r = 6 / 5 / 1,
+    and the 64 -> 200 conv with its depth-to-space store (four channel tiles,
+    the last one 32 wide)."""
     from sup3r_amd.engine import Network
-    spec = _trunk_spec(False)
+    spec = _trunk_spec(d2s)
     x = np.random.default_rng(6).standard_normal(shape).astype(np.float32)
 
     def run(strip):
