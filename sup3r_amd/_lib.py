@@ -244,6 +244,12 @@ DGRAD_KERNELS = ('direct', 'mfma_frame', 'mfma_valid', 'mfma_chunked',
 TC_METHODS = {'subsample': 0, 'average': 1, 'total': 2, 'max': 3, 'min': 4}
 
 
+def last_error(ctx):
+    """text of the context's last error ('' if none)"""
+    raw = lib().s3_last_error(ctx) if ctx else None
+    return raw.decode() if raw else ''
+
+
 def check(rc, ctx=None, what=''):
     if rc == 0:
         return

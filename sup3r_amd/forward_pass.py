@@ -921,10 +921,27 @@ class ForwardPass:
             ready.synchronize()
             host_ptr, host_arr = cls._delivery_buffer(dev, tuple(yc.shape))
             ticket = C.c_uint64()
-            rc = L.s3_dma_d2h_begin(
-                dev.ctx, C.c_void_p(yc.data_ptr()), C.c_void_p(host_ptr),
-                host_arr.size * 4, C.byref(ticket))
-            _lib.check(rc, dev.ctx, 's3_dma_d2h_begin')
+            rc = -1
+            if cls.sdma_delivery:
+                rc = L.s3_dma_d2h_begin(
+                    dev.ctx, C.c_void_p(yc.data_ptr()), C.c_void_p(host_ptr),
+                    host_arr.size * 4, C.byref(ticket))
+                if rc != 0:
+                    # ROCr refused (no SDMA queue in this container, a foreign
+                    # allocator ...): say so once and copy through HIP instead
+                    logger.warning(
+                        'SDMA delivery unavailable (%s): falling back to '
+                        'hipMemcpyAsync for the chunk batches',
+                        _lib.last_error(dev.ctx))
+                    cls.sdma_delivery = False
+            if rc != 0:
+                rc = L.s3_d2h_async(
+                    dev.ctx, C.c_void_p(yc.data_ptr()), C.c_void_p(host_ptr),
+                    host_arr.size * 4, C.c_void_p(copy_stream.cuda_stream))
+                _lib.check(rc, dev.ctx, 's3_d2h_async')
+                state['copy_ev'] = torch.cuda.Event()
+                state['copy_ev'].record(copy_stream)
+                ticket = None
             state['ticket'], state['host'] = ticket, host_arr
 
         def finish():
@@ -962,6 +979,8 @@ class ForwardPass:
                                    int(dev.comm_timeout_s * 1000))
                 state['ticket'] = None
                 _lib.check(rc, dev.ctx, 's3_dma_wait')
+            elif state.get('copy_ev') is not None:
+                state['copy_ev'].synchronize()
             for k, chunk in enumerate(group):
                 # (a view into the executor's ring of delivery buffers: valid
                 # until ``d2h_ring - 3`` further batches have been yielded)
@@ -1000,7 +1019,24 @@ class ForwardPass:
     #: (s3_host_alloc) per output shape, allocated once: pinning 368 MB per
     #: batch cost 8.9 ms of host time each (torch.empty(pin_memory=True))
     d2h_ring = 4
+    #: deliver by the SDMA engines through ROCr (s3_dma_d2h_begin); switched
+    #: off (with a warning) the first time ROCr refuses a copy
+    sdma_delivery = True
     _delivery = {}
+
+    @classmethod
+    def release_delivery_buffers(cls):
+        """free the pinned delivery rings (up to ``d2h_ring`` x the batch's
+        cropped output per output shape); views handed out earlier become
+        invalid"""
+        from . import _lib
+        from .engine import Device
+        import ctypes as C
+        for (index, _), ring in list(cls._delivery.items()):
+            dev = Device.get(index)
+            for ptr, _arr in ring['bufs']:
+                _lib.lib().s3_host_free(dev.ctx, C.c_void_p(ptr))
+        cls._delivery.clear()
 
     @classmethod
     def _delivery_buffer(cls, dev, shape):

@@ -203,6 +203,41 @@ def test_sdma_delivery_round_trip():
         _lib.check(L.s3_host_free(dev.ctx, hp), dev.ctx, 's3_host_free')
 
 
+def test_delivery_falls_back_to_hipmemcpy_and_the_ring_can_be_released():
+    """``ForwardPass.sdma_delivery = False`` (what a refused ROCr copy switches
+    to): the same chunks through hipMemcpyAsync on the copy stream; then the
+    pinned rings are given back"""
+    from sup3r_amd import ForwardPass
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    model = _model()
+    domain = np.random.default_rng(8).standard_normal((12, 12, 16, 2)).astype(
+        np.float32)
+    register_model('Sup3rGan', {'model_dir': 'fallback-test'}, model)
+    st = ArrayStrategy(domain, {'model_dir': 'fallback-test'}, (6, 6, 4),
+                       spatial_pad=1, temporal_pad=1, max_nodes=1, model=model)
+    fwp = ForwardPass(st, 0)
+    ids = [int(i) for i in st.node_chunks[0]]
+
+    def run():
+        return [np.array(d) for _, failed, d in ForwardPass.iter_chunks(
+            (fwp.get_input_chunk(i) for i in ids), model, batch=3)]
+    ref = run()
+    try:
+        ForwardPass.sdma_delivery = False
+        got = run()
+    finally:
+        ForwardPass.sdma_delivery = True
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    assert ForwardPass._delivery
+    ForwardPass.release_delivery_buffers()
+    assert not ForwardPass._delivery
+    again = run()                      # rings come back on demand
+    for a, b in zip(again, ref):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_iter_chunks_views_stay_valid_for_two_batches():
     """the delivery ring: a yielded array is still intact after two further
     batches have been yielded (the documented life time)"""
