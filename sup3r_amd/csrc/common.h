@@ -73,6 +73,7 @@
   X(NO_TAIL_BAND) \
   X(NO_TAIL_MFMA) \
   X(NO_TAIL_SLIDE) \
+  X(NO_TAIL_X3) \
   X(NO_TILE66) \
   X(NO_TILE_NF2) \
   X(NO_WGRAD_BF16) \
@@ -223,6 +224,10 @@ int launch_conv_generic_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x,
 bool conv_small_supported(const ConvGeom& g, int in_bf16);
 // hi-res tail conv C_in = 8 (bf16 cells) -> C_out <= 16 (fp32) on MFMA
 bool conv_tail_mfma_supported(const ConvGeom& g);
+// split-bf16 form for BF16X3 plans (fp32 in / out, C_out == 2)
+bool conv_tail_x3_supported(const ConvGeom& g, int precision);
+int launch_conv_tail_x3(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* w,
+                        const float* bias, float* y);
 int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
                           const float* w, const float* bias, float* y);
 int launch_conv_generic_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,

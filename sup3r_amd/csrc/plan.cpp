@@ -64,6 +64,7 @@ struct OpRec {
   void* dgc_wbf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool halo32 = false;         // C_in = 32 stride-1 conv: LDS-halo forward
   bool halo_s2 = false;        // C_in = 32 stride-2 valid conv: LDS-halo forward (bf16 cells in)
+  bool tail_x3 = false;        // BF16X3 plans: banded split-bf16 MFMA tail (8 -> 2, fp32 in / out)
   void* h32_w = nullptr;
   uint64_t h32_version = 0;
   void* dc2_w = nullptr;
@@ -587,6 +588,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         o.gconv = !o.mfma && !o.fewpos && conv_gconv_supported(g, precision);
         o.halo32 = o.gconv && d.res < 0 && conv_halo32_supported(ctx, g, precision);
         o.halo_s2 = o.gconv && d.res < 0 && conv_halo_s2_supported(ctx, g, precision);
+        o.tail_x3 = !o.mfma && !o.fewpos && d.res < 0 && conv_tail_x3_supported(g, precision);
         if (o.fewpos) {
           max_fp = std::max(max_fp, conv_fewpos_partial_bytes(g));
           if (training) {
@@ -1221,6 +1223,8 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
         }
         return launch_conv_halo_s2_fwd(ctx, o.cg, tptr(pl, d.in0), o.h32_w, b, tptr(pl, d.out), o.io.out_bf16);
       }
+      if (o.tail_x3 && !res && !o.io.in_bf16 && !o.io.out_bf16)
+        return launch_conv_tail_x3(ctx, o.cg, (const float*)tptr(pl, d.in0), w, b, (float*)tptr(pl, d.out));
       if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
           (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
         if (o.gc_version != P->version) {
@@ -1480,6 +1484,8 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
       fwd = S3_FWD_HALO32;
     } else if (o.halo_s2 && !res && o.io.in_bf16) {
       fwd = S3_FWD_HALO_S2;
+    } else if (o.tail_x3 && !res && !o.io.in_bf16 && !o.io.out_bf16) {
+      fwd = S3_FWD_TAIL_MFMA;
     } else if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
                (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
       fwd = o.cg.Cin <= 4 ? S3_FWD_GCONV_FEWCH : S3_FWD_GCONV;

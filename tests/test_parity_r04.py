@@ -141,3 +141,50 @@ def test_last_column_strip_on_six_column_tiles_is_bit_identical(shape, d2s):
     assert np.isfinite(ref[0]).all() and np.abs(ref[0]).max() > 0
     for y in got + ref[1:]:
         np.testing.assert_array_equal(y, ref[0])
+
+
+@pytest.mark.parametrize('padding,shape', [
+    ('reflect', (2, 11, 13, 45, 8)),
+    ('reflect', (1, 4, 8, 32, 8)),
+    ('same', (3, 9, 10, 70, 8)),
+])
+def test_bf16x3_tail_conv_on_the_banded_split_mfma_kernel(padding, shape):
+    """``conv_tail_x3_kernel``: the 8 -> 2 tail conv of a BF16X3 plan (fp32 in
+    / out) as banded split-bf16 MFMAs instead of the direct fp32 kernel (4.4 ms
+    -> of the 52.9 ms C2 forward at 32 chunks).  Forward 1e-4 against the fp32
+    oracle (the BF16X3 forward bound of tests/test_parity_r02.py) on ragged
+    tiles, reflect (FlexiblePadding) and zero ('same') borders, with the
+    kernel selected; and against the direct kernel it replaces
+    (``NO_TAIL_X3``).  Reference: the last Conv3D of
+    sup3r/models/abstract.py:926-987 (``generate`` layer walk)."""
+    from sup3r_amd.engine import Network
+    from tests.helpers import rel_max
+    from tests.test_parity_r02 import _fwd_bwd_vs_oracle
+    if padding == 'reflect':
+        spec = [{'class': 'FlexiblePadding',
+                 'paddings': [[0, 0], [1, 1], [1, 1], [1, 1], [0, 0]],
+                 'mode': 'REFLECT'},
+                {'class': 'Conv3D', 'filters': 2, 'kernel_size': 3,
+                 'strides': 1, 'padding': 'valid'}]
+    else:
+        spec = [{'class': 'Conv3D', 'filters': 2, 'kernel_size': 3,
+                 'strides': 1, 'padding': 'same'},
+                {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    ph = _fwd_bwd_vs_oracle(spec, shape, 'bf16x3', 61, 1e-4, 1e-3)
+    fwd = [ph.op_info(i)['fwd'] for i in range(len(ph.plan.ops))]
+    assert 'tail_mfma' in fwd, fwd
+    x = np.random.default_rng(62).standard_normal(shape).astype(np.float32)
+
+    def run():
+        net = Network(spec, precision='bf16x3')
+        net.build(shape, seed=9)
+        p = net.plan(shape, training=False)
+        y = p.forward(net.dev.to_device(x)).cpu().numpy()
+        net.clear_plans()
+        return y
+    y1 = run()
+    switch('NO_TAIL_X3', 1)
+    y0 = run()
+    switch('NO_TAIL_X3', None)
+    assert np.abs(y1 - y0).max() > 0              # another kernel ran
+    assert rel_max(y1, y0) < 2e-5, rel_max(y1, y0)
