@@ -150,7 +150,8 @@ def train_leg(config, global_batch, world, rank, min_seconds, max_steps,
     def step():
         return model._train_batch(Batch, True, False, False, True, False,
                                   False, 1e-3, multi_gpu=multi_gpu)
-    step()
+    for _ in range(4):        # (a launch-bound step is recorded on its third call)
+        step()
     torch.cuda.synchronize()
     c0 = {k: dev.stat(k) for k in ('buckets', 'allreduces', 'bucket_elems')}
     n, t0 = 0, time.perf_counter()
@@ -181,6 +182,11 @@ def train_leg(config, global_batch, world, rank, min_seconds, max_steps,
                           'SUM' if multi_gpu and world > 1 else ''),
            'ms_per_step': dt * 1e3, 'value': global_batch / dt,
            'unit': 'samples/s', 'steps': n, 'seconds': el}
+    rec = getattr(model, '_recorder', None)
+    if rec is not None and rec.replays:
+        # launch-bound step: recorded once, one hipGraphLaunch per mini-batch
+        out['recorded'] = {'replays': rec.replays, 'graph_nodes': max(
+            e['rec'].nodes for e in rec._entries.values() if e['rec'])}
     if gflop:
         out['algorithmic_gflop_per_sample'] = gflop
         out['tflops'] = gflop * global_batch / dt / 1e3

@@ -150,6 +150,36 @@ typedef enum {
 } s3_optimizer_kind;
 int s3_optimizer_step(s3_params* p, int kind, const double* hp, int n_hp,
                       int64_t t);
+/* The same step in two halves, for a captured graph (below): `stage` writes
+ * the scalars of step t (alpha(t) of Adam, ...) to the device with a 1-thread
+ * launch and is called OUTSIDE the graph before every replay; `step_staged`
+ * is the update launch, reading them from there — identical every step, so it
+ * can be recorded.  (Adagrad's step 1 fills the accumulator: run it with
+ * s3_optimizer_step.)  `touch` tells the host side that the weights changed
+ * behind its back (after a replay): packed filter images are stale. */
+int s3_optimizer_stage(s3_params* p, int kind, const double* hp, int n_hp,
+                       int64_t t);
+int s3_optimizer_step_staged(s3_params* p, int kind);
+int s3_params_touch(s3_params* p);
+
+/* ---- captured steps ----------------------------------------------------------
+ * A launch-bound training step — the reference's own CPU-runnable case
+ * (tests/training/test_train_gan.py:45-114, batch 15 of 5 x 5 -> 10 x 10) is
+ * ~650 launches of a few microseconds — recorded once as a hipGraph and
+ * replayed with ONE launch per Sup3rGan._train_batch (base.py:944-1031).
+ * Between begin and end every launch of the context is recorded instead of
+ * executed.  The caller guarantees what a replay needs: every buffer the step
+ * touches stays alive and in place (inputs are copied INTO the recorded input
+ * buffers), no host read-back / collective / plan creation inside, the
+ * optimizer steps staged.  A call that cannot be recorded fails capture_end
+ * (S3_EHIP); s3_capture_abort drops a capture after an error. */
+typedef struct s3_graph s3_graph;
+int s3_capture_begin(s3_ctx* ctx);
+int s3_capture_end(s3_ctx* ctx, s3_graph** out);
+int s3_capture_abort(s3_ctx* ctx);
+int s3_graph_launch(s3_graph* g);
+int64_t s3_graph_nodes(const s3_graph* g);
+void s3_graph_destroy(s3_graph* g);
 
 /* ---- options ---------------------------------------------------------------
  * Kernel-selection switches (the A/B comparisons of the parity tests, the

@@ -25,7 +25,10 @@ EXPORTS = [
     's3_ctx_stream', 's3_ctx_stat', 's3_params_create', 's3_params_destroy',
     's3_params_total', 's3_params_set', 's3_params_get', 's3_params_dptr',
     's3_params_zero_grad', 's3_params_version', 's3_params_mean_abs',
-    's3_adam_step', 's3_optimizer_step',
+    's3_adam_step', 's3_optimizer_step', 's3_optimizer_stage',
+    's3_optimizer_step_staged', 's3_params_touch', 's3_capture_begin',
+    's3_capture_end', 's3_capture_abort', 's3_graph_launch', 's3_graph_nodes',
+    's3_graph_destroy',
     's3_ctx_set_option', 's3_ctx_get_option', 's3_option_name_at',
     's3_plan_create', 's3_plan_create_opt', 's3_plan_destroy', 's3_plan_forward',
     's3_plan_backward', 's3_plan_tensor', 's3_plan_workspace_bytes',
@@ -118,6 +121,15 @@ def lib():
         's3_params_mean_abs': (i32, [vp, i32, i32, pf]),
         's3_adam_step': (i32, [vp, f32, f32, f32, f32, i64]),
         's3_optimizer_step': (i32, [vp, i32, C.POINTER(C.c_double), i32, i64]),
+        's3_optimizer_stage': (i32, [vp, i32, C.POINTER(C.c_double), i32, i64]),
+        's3_optimizer_step_staged': (i32, [vp, i32]),
+        's3_params_touch': (i32, [vp]),
+        's3_capture_begin': (i32, [vp]),
+        's3_capture_end': (i32, [vp, C.POINTER(vp)]),
+        's3_capture_abort': (i32, [vp]),
+        's3_graph_launch': (i32, [vp]),
+        's3_graph_nodes': (i64, [vp]),
+        's3_graph_destroy': (None, [vp]),
         's3_plan_create': (i32, [vp, vp, C.POINTER(TensorDesc), i32,
                                  C.POINTER(OpDesc), i32, C.POINTER(i32), i32,
                                  i32, i32, i32, C.POINTER(vp)]),

@@ -707,6 +707,14 @@ class HipGanCompute:
         kind = getattr(optimizer, 'KIND', None)
         if kind is None or not hasattr(optimizer, 'hyper'):
             raise KeyError(f'optimizer "{optimizer}" has no MI355X kernel')
+        rec = getattr(self, '_recording', None)
+        if rec is not None:
+            # a step being recorded (captured.py): the update launch reads the
+            # step's scalars from the device; the replay stages them and
+            # counts the iteration
+            rec.append((net, optimizer))
+            net.optimizer_step_staged(kind)
+            return
         optimizer.iterations += 1
         net.optimizer_step(kind, optimizer.hyper(), optimizer.iterations)
 

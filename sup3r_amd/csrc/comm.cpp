@@ -247,7 +247,7 @@ extern "C" int s3_params_broadcast(s3_params* p, int which, int root) {
   if (!p || which < 0 || which > 3) return S3_EINVAL;
   s3_ctx* ctx = reinterpret_cast<s3_params_view*>(p)->ctx;
   int rc = s3_broadcast(ctx, (float*)s3_params_dptr(p, which, -1), s3_params_total(p), root);
-  if (rc == S3_OK && which == S3_BUF_W) s3_params_touch(p);
+  if (rc == S3_OK && which == S3_BUF_W) (void)s3_params_touch(p);
   return rc;
 }
 

@@ -124,6 +124,14 @@ struct s3_ctx {
   hipEvent_t comm_ev[2] = {nullptr, nullptr};   // [0] compute -> comm, [1] comm -> compute
   hipEvent_t wd_ev[2] = {nullptr, nullptr};     // s3_comm_wait: tail of the compute / comm stream
   int64_t comm_issued = 0;           // collectives enqueued since the last completed s3_comm_wait
+  // stream capture (s3_capture_begin .. s3_capture_end): launches go to a
+  // non-blocking side stream while it records; `stream` is restored afterwards
+  hipStream_t cap_stream = nullptr, saved_stream = nullptr;
+  bool capturing = false;
+  // recorded graphs hold the scratch pointer of their time: once one exists a
+  // scratch block that is outgrown is retired (freed with the context), not freed
+  bool graphs_made = false;
+  std::vector<void*> retired;
 };
 
 #define S3_HIP(ctx, call)                                                    \
@@ -440,9 +448,11 @@ int launch_dense_dgrad(s3_ctx* ctx, const float* dy, const float* w, float* dx,
 int launch_dense_wgrad(s3_ctx* ctx, const float* x, const float* dy, float* dw,
                        int n, int cin, int cout, int accumulate);
 int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
-                int64_t n, float alpha, float one_minus_b1, float one_minus_b2, float eps);
+                int64_t n, float alpha, float one_minus_b1, float one_minus_b2, float eps,
+                const float* h_dev = nullptr);
 int launch_optimizer(s3_ctx* ctx, int kind, float* w, const float* g, float* m, float* v,
-                     int64_t n, const float* h);
+                     int64_t n, const float* h, const float* h_dev = nullptr);
+int launch_stage_hyper(s3_ctx* ctx, float* dst, const float* h);
 int launch_fill(s3_ctx* ctx, float* p, int64_t n, float v);
 // (cross-file helpers of the library, not part of its ABI: hidden, so that the
 // .so exports exactly what include/sup3r_hip.h declares — tests/test_abi.py)
@@ -466,4 +476,3 @@ Fused2dPlan* fused2d_build(s3_ctx* ctx, const std::vector<Fused2dLayer>& layers,
 int fused2d_run(s3_ctx* ctx, Fused2dPlan* p, const float* W, uint64_t wversion, const float* x,
                 float* y);
 void fused2d_free(Fused2dPlan* p);
-void s3_params_touch(s3_params* p);   // weights changed behind the store's back: bump the version

@@ -815,7 +815,10 @@ __global__ void rel_bce_kernel(const float* __restrict__ dt,
 __global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v,
                             int64_t n, float alpha, float omb1, float omb2,
-                            float eps) {
+                            float eps, const float* __restrict__ hd) {
+  // hd: the step's scalars staged on the device (s3_optimizer_stage) — the
+  // launch is then the same every step and can live in a captured graph
+  if (hd) { alpha = hd[0]; omb1 = hd[1]; omb2 = hd[2]; eps = hd[3]; }
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t n4 = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
@@ -992,9 +995,14 @@ __global__ __launch_bounds__(256) void chunk_epilogue_kernel(const float* __rest
 // ================================================================ launchers
 int ensure_scratch(s3_ctx* ctx, size_t bytes) {
   if (ctx->scratch_bytes >= bytes) return S3_OK;
+  if (ctx->capturing) S3_FAIL(ctx, S3_EINVAL, "scratch would grow inside a capture (run the step eagerly once first)");
   if (ctx->scratch) {
-    S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    S3_HIP(ctx, hipFree(ctx->scratch));
+    if (ctx->graphs_made) {
+      ctx->retired.push_back(ctx->scratch);
+    } else {
+      S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      S3_HIP(ctx, hipFree(ctx->scratch));
+    }
     ctx->scratch = nullptr; ctx->scratch_bytes = 0;
   }
   size_t want = bytes < (size_t)(1 << 20) ? (size_t)(1 << 20) : bytes;
@@ -1345,7 +1353,9 @@ int launch_mean_abs(s3_ctx* ctx, const float* p, int64_t n, float* out_dev) {
 template <int KIND>
 __global__ void optimizer_kernel(float* __restrict__ w, const float* __restrict__ g,
                                  float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                 float h0, float h1, float h2, float h3, float h4) {
+                                 float h0, float h1, float h2, float h3, float h4,
+                                 const float* __restrict__ hd) {
+  if (hd) { h0 = hd[0]; h1 = hd[1]; h2 = hd[2]; h3 = hd[3]; h4 = hd[4]; }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float gi = g[i];
@@ -1392,11 +1402,11 @@ __global__ void optimizer_kernel(float* __restrict__ w, const float* __restrict_
 }
 
 int launch_optimizer(s3_ctx* ctx, int kind, float* w, const float* g, float* m, float* v,
-                     int64_t n, const float* h) {
+                     int64_t n, const float* h, const float* h_dev) {
   const dim3 grid(grid_for(n, ctx->num_cu)), blk(kBlock);
 #define S3_OPT_LAUNCH(K)                                                                   \
   hipLaunchKernelGGL(optimizer_kernel<K>, grid, blk, 0, ctx->stream, w, g, m, v, n, h[0], \
-                     h[1], h[2], h[3], h[4])
+                     h[1], h[2], h[3], h[4], h_dev)
   switch (kind) {
     case S3_OPT_SGD: S3_OPT_LAUNCH(S3_OPT_SGD); break;
     case S3_OPT_RMSPROP: S3_OPT_LAUNCH(S3_OPT_RMSPROP); break;
@@ -1411,8 +1421,18 @@ int launch_optimizer(s3_ctx* ctx, int kind, float* w, const float* g, float* m, 
 }
 
 int launch_adam(s3_ctx* ctx, float* w, const float* g, float* m, float* v,
-                int64_t n, float alpha, float omb1, float omb2, float eps) {
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, w, g, m, v, n, alpha, omb1, omb2, eps);
+                int64_t n, float alpha, float omb1, float omb2, float eps, const float* h_dev) {
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, w, g, m, v, n, alpha, omb1, omb2, eps, h_dev);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+__global__ void stage_hyper_kernel(float* __restrict__ dst, float h0, float h1, float h2, float h3, float h4) {
+  dst[0] = h0; dst[1] = h1; dst[2] = h2; dst[3] = h3; dst[4] = h4;
+}
+
+int launch_stage_hyper(s3_ctx* ctx, float* dst, const float* h) {
+  hipLaunchKernelGGL(stage_hyper_kernel, dim3(1), dim3(1), 0, ctx->stream, dst, h[0], h[1], h[2], h[3], h[4]);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -28,6 +28,7 @@ struct s3_params {
   bool reduced = false;   // ... and has done so: s3_params_allreduce_grads only joins
   int64_t reduce_end = 0, bucket_elems = 0;
   int buckets_issued = 0;
+  float* hyper_dev = nullptr;   // the optimizer step's scalars, staged (s3_optimizer_stage)
 };
 
 struct TensorRec {
@@ -250,6 +251,8 @@ extern "C" int s3_ctx_create(int device_id, void* stream, int create_stream,
 extern "C" void s3_ctx_destroy(s3_ctx* ctx) {
   if (!ctx) return;
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->capturing) (void)s3_capture_abort(ctx);
+  if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -306,6 +309,7 @@ extern "C" void s3_params_destroy(s3_params* p) {
   (void)hipStreamSynchronize(p->ctx->stream);
   for (int k = 0; k < 4; ++k)
     if (p->buf[k]) (void)hipFree(p->buf[k]);
+  if (p->hyper_dev) (void)hipFree(p->hyper_dev);
   delete p;
 }
 
@@ -348,7 +352,6 @@ extern "C" void* s3_params_dptr(s3_params* p, int which, int idx) {
   return p->buf[which] + p->p[idx].offset;
 }
 
-void s3_params_touch(s3_params* p) { if (p) p->version++; }
 
 extern "C" uint64_t s3_params_version(const s3_params* p) { return p ? p->version : 0; }
 
@@ -420,21 +423,17 @@ extern "C" S3_INTERNAL int s3_params_take_armed(s3_params* p, int* n_buckets) {
 // double and THEN rounded to fp32 (keras multiplies the fp32 tensor by the
 // Python scalar 1 - beta), the powers beta^t in fp32 (tf.pow of the cast
 // beta).  fp32(1) - fp32(0.999) would be off by 4.7e-5 of itself.
-extern "C" int s3_optimizer_step(s3_params* p, int kind, const double* hp, int n_hp, int64_t t) {
-  if (!p || !hp || t < 1) return S3_EINVAL;
-  s3_ctx* ctx = p->ctx;
-  float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+// the step's scalars h[0..4] as the kernels take them
+static int optimizer_scalars(s3_ctx* ctx, int kind, const double* hp, int n_hp, int64_t t, float* h) {
+  for (int q = 0; q < 5; ++q) h[q] = 0.f;
   auto need = [&](int n) { return n_hp >= n; };
   switch (kind) {
     case S3_OPT_ADAM: {
       if (!need(4)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(Adam): {lr, beta_1, beta_2, epsilon}");
       const float b1p = powf((float)hp[1], (float)t), b2p = powf((float)hp[2], (float)t);
-      const float alpha = (float)hp[0] * sqrtf(1.f - b2p) / (1.f - b1p);
-      int rc = launch_adam(ctx, p->buf[S3_BUF_W], p->buf[S3_BUF_G], p->buf[S3_BUF_M], p->buf[S3_BUF_V],
-                           p->total, alpha, (float)(1.0 - hp[1]), (float)(1.0 - hp[2]), (float)hp[3]);
-      if (rc) return rc;
-      p->version++;
-      return S3_OK;
+      h[0] = (float)hp[0] * sqrtf(1.f - b2p) / (1.f - b1p);
+      h[1] = (float)(1.0 - hp[1]); h[2] = (float)(1.0 - hp[2]); h[3] = (float)hp[3];
+      break;
     }
     case S3_OPT_SGD:
       if (!need(3)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(SGD): {lr, momentum, nesterov}");
@@ -448,10 +447,6 @@ extern "C" int s3_optimizer_step(s3_params* p, int kind, const double* hp, int n
     case S3_OPT_ADAGRAD:
       if (!need(3)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(Adagrad): {lr, epsilon, initial_accumulator_value}");
       h[0] = (float)hp[0]; h[1] = (float)hp[1];
-      if (t == 1) {   // keras creates the accumulator filled with its initial value
-        int rc = launch_fill(ctx, p->buf[S3_BUF_V], p->total, (float)hp[2]);
-        if (rc) return rc;
-      }
       break;
     case S3_OPT_ADAMAX: {
       if (!need(4)) S3_FAIL(ctx, S3_EINVAL, "optimizer_step(Adamax): {lr, beta_1, beta_2, epsilon}");
@@ -469,11 +464,161 @@ extern "C" int s3_optimizer_step(s3_params* p, int kind, const double* hp, int n
     }
     default: S3_FAIL(ctx, S3_EINVAL, "optimizer_step: unknown optimizer kind");
   }
-  int rc = launch_optimizer(ctx, kind, p->buf[S3_BUF_W], p->buf[S3_BUF_G], p->buf[S3_BUF_M],
-                            p->buf[S3_BUF_V], p->total, h);
+  return S3_OK;
+}
+
+static int optimizer_launch(s3_params* p, int kind, const float* h, const float* h_dev) {
+  s3_ctx* ctx = p->ctx;
+  int rc;
+  if (kind == S3_OPT_ADAM)
+    rc = launch_adam(ctx, p->buf[S3_BUF_W], p->buf[S3_BUF_G], p->buf[S3_BUF_M], p->buf[S3_BUF_V], p->total,
+                     h[0], h[1], h[2], h[3], h_dev);
+  else
+    rc = launch_optimizer(ctx, kind, p->buf[S3_BUF_W], p->buf[S3_BUF_G], p->buf[S3_BUF_M], p->buf[S3_BUF_V],
+                          p->total, h, h_dev);
   if (rc) return rc;
   p->version++;
   return S3_OK;
+}
+
+extern "C" int s3_optimizer_step(s3_params* p, int kind, const double* hp, int n_hp, int64_t t) {
+  if (!p || !hp || t < 1) return S3_EINVAL;
+  s3_ctx* ctx = p->ctx;
+  float h[5];
+  int rc = optimizer_scalars(ctx, kind, hp, n_hp, t, h);
+  if (rc) return rc;
+  if (kind == S3_OPT_ADAGRAD && t == 1) {   // keras creates the accumulator filled with its initial value
+    rc = launch_fill(ctx, p->buf[S3_BUF_V], p->total, (float)hp[2]);
+    if (rc) return rc;
+  }
+  return optimizer_launch(p, kind, h, nullptr);
+}
+
+// The same step in two halves, for a captured graph: the scalars of step t are
+// written to the device by a 1-thread launch OUTSIDE the graph (kernel
+// arguments: no host buffer has to outlive the call), the update launch inside
+// it reads them from there and is identical every step.
+extern "C" int s3_optimizer_stage(s3_params* p, int kind, const double* hp, int n_hp, int64_t t) {
+  if (!p || !hp || t < 1) return S3_EINVAL;
+  s3_ctx* ctx = p->ctx;
+  if (kind == S3_OPT_ADAGRAD && t == 1)
+    S3_FAIL(ctx, S3_EINVAL, "optimizer_stage(Adagrad): the first step creates the accumulator, run it with s3_optimizer_step");
+  float h[5];
+  int rc = optimizer_scalars(ctx, kind, hp, n_hp, t, h);
+  if (rc) return rc;
+  if (!p->hyper_dev) S3_HIP(ctx, hipMalloc((void**)&p->hyper_dev, 8 * sizeof(float)));
+  return launch_stage_hyper(ctx, p->hyper_dev, h);
+}
+
+extern "C" int s3_optimizer_step_staged(s3_params* p, int kind) {
+  if (!p) return S3_EINVAL;
+  s3_ctx* ctx = p->ctx;
+  // (recorded before the first stage: the replay stages before it launches)
+  if (!p->hyper_dev) S3_HIP(ctx, hipMalloc((void**)&p->hyper_dev, 8 * sizeof(float)));
+  if (kind < S3_OPT_ADAM || kind > S3_OPT_ADAMW) S3_FAIL(ctx, S3_EINVAL, "optimizer_step: unknown optimizer kind");
+  const float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  return optimizer_launch(p, kind, h, p->hyper_dev);
+}
+
+// the weights changed behind the host's back (a replayed graph stepped the
+// optimizer): packed filter images of every plan are stale
+extern "C" int s3_params_touch(s3_params* p) {
+  if (!p) return S3_EINVAL;
+  p->version++;
+  return S3_OK;
+}
+
+// ------------------------------------------------------------ stream capture
+// A launch-bound step (the C1 training step is ~650 launches of a few
+// microseconds each) recorded once and replayed as ONE hipGraphLaunch.  Between
+// begin and end every launch of this context goes to a non-blocking side
+// stream that records instead of executing; what is recorded must be the same
+// every step: static pointers (the caller keeps every buffer of the step
+// alive), no host read-back, no collective, step-dependent scalars staged
+// (s3_optimizer_stage).  A call that cannot be captured fails the capture; the
+// caller then runs eagerly.
+struct s3_graph {
+  s3_ctx* ctx = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  size_t n_nodes = 0;
+};
+
+extern "C" int s3_capture_begin(s3_ctx* ctx) {
+  if (!ctx) return S3_EINVAL;
+  if (ctx->capturing) S3_FAIL(ctx, S3_EINVAL, "capture_begin: already capturing");
+  if (ctx->comm) S3_FAIL(ctx, S3_EINVAL, "capture_begin: not with a communicator (collectives are not captured)");
+  if (!ctx->cap_stream) S3_HIP(ctx, hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+  // what was enqueued so far runs before anything the capture stream does later
+  S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  S3_HIP(ctx, hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed));
+  ctx->saved_stream = ctx->stream;
+  ctx->stream = ctx->cap_stream;
+  ctx->capturing = true;
+  return S3_OK;
+}
+
+static int capture_stop(s3_ctx* ctx, hipGraph_t* g) {
+  hipError_t e = hipStreamEndCapture(ctx->cap_stream, g);
+  ctx->stream = ctx->saved_stream;
+  ctx->capturing = false;
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e);
+    return S3_EHIP;
+  }
+  return S3_OK;
+}
+
+extern "C" int s3_capture_abort(s3_ctx* ctx) {
+  if (!ctx) return S3_EINVAL;
+  if (!ctx->capturing) return S3_OK;
+  hipGraph_t g = nullptr;
+  const std::string keep = ctx->err;
+  (void)capture_stop(ctx, &g);
+  if (g) (void)hipGraphDestroy(g);
+  ctx->err = keep;
+  return S3_OK;
+}
+
+extern "C" int s3_capture_end(s3_ctx* ctx, s3_graph** out) {
+  if (!ctx || !out) return S3_EINVAL;
+  if (!ctx->capturing) S3_FAIL(ctx, S3_EINVAL, "capture_end: not capturing");
+  hipGraph_t g = nullptr;
+  int rc = capture_stop(ctx, &g);
+  if (rc) return rc;
+  if (!g) S3_FAIL(ctx, S3_EHIP, "capture_end: empty graph");
+  s3_graph* G = new s3_graph();
+  G->ctx = ctx;
+  G->graph = g;
+  hipError_t e = hipGraphInstantiate(&G->exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    delete G;
+    ctx->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+    return S3_EHIP;
+  }
+  (void)hipGraphGetNodes(g, nullptr, &G->n_nodes);
+  ctx->graphs_made = true;
+  *out = G;
+  return S3_OK;
+}
+
+extern "C" int s3_graph_launch(s3_graph* g) {
+  if (!g || !g->exec) return S3_EINVAL;
+  s3_ctx* ctx = g->ctx;
+  if (ctx->capturing) S3_FAIL(ctx, S3_EINVAL, "graph_launch: inside a capture");
+  S3_HIP(ctx, hipGraphLaunch(g->exec, ctx->stream));
+  return S3_OK;
+}
+
+extern "C" int64_t s3_graph_nodes(const s3_graph* g) { return g ? (int64_t)g->n_nodes : -1; }
+
+extern "C" void s3_graph_destroy(s3_graph* g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
 }
 
 // --------------------------------------------------------------------- plan

@@ -47,6 +47,9 @@ class Device:
         self.ctx = h
         self.rank, self.nranks = 0, 1
         self._set, self.options_key = {}, ()   # options changed since creation
+        # a list while a training step is being recorded (captured.py): every
+        # buffer handed out then must live as long as the recorded graph
+        self._retain = None
 
     @classmethod
     def get(cls, index=None):
@@ -87,14 +90,22 @@ class Device:
 
     def empty(self, shape):
         torch = _torch()
-        return torch.empty(tuple(int(v) for v in shape), dtype=torch.float32,
-                           device=self.torch_device)
+        t = torch.empty(tuple(int(v) for v in shape), dtype=torch.float32,
+                        device=self.torch_device)
+        if self._retain is not None:
+            self._retain.append(t)
+        return t
 
     def to_device(self, arr):
         """numpy / torch / anything with .numpy() -> contiguous fp32 device
         tensor (batch payloads are duck-typed like the reference does,
         preprocessing/utilities.py:255-257)."""
         torch = _torch()
+        if self._retain is not None and not (
+                isinstance(arr, torch.Tensor) and arr.is_cuda
+                and arr.dtype == torch.float32 and arr.is_contiguous()):
+            raise RuntimeError('an upload / conversion inside a recorded '
+                               'step: it would not be part of the replay')
         if isinstance(arr, torch.Tensor):
             return arr.to(device=self.torch_device,
                           dtype=torch.float32).contiguous()
@@ -393,6 +404,8 @@ class Network:
 
     def clear_plans(self):
         self._plans = {}
+        # recorded steps (captured.py) hold pointers into the plans' arenas
+        self.plan_epoch = getattr(self, 'plan_epoch', 0) + 1
 
     # -- weights, keras layout / keras order
     def _get(self, which):
@@ -469,6 +482,25 @@ class Network:
         rc = _lib.lib().s3_optimizer_step(self.params, int(kind), hp,
                                           len(hyper), int(t))
         _lib.check(rc, self.dev.ctx, 's3_optimizer_step')
+
+    def optimizer_stage(self, kind, hyper, t):
+        """first half of ``optimizer_step`` for a recorded step: the scalars
+        of step ``t`` go to the device now (outside the graph) ..."""
+        hp = (C.c_double * len(hyper))(*[float(v) for v in hyper])
+        rc = _lib.lib().s3_optimizer_stage(self.params, int(kind), hp,
+                                           len(hyper), int(t))
+        _lib.check(rc, self.dev.ctx, 's3_optimizer_stage')
+
+    def optimizer_step_staged(self, kind):
+        """... and the update launch reads them there (recordable)"""
+        rc = _lib.lib().s3_optimizer_step_staged(self.params, int(kind))
+        _lib.check(rc, self.dev.ctx, 's3_optimizer_step_staged')
+
+    def touch(self):
+        """the weights changed behind the host's back (a replayed graph
+        stepped the optimizer): packed filter images are stale"""
+        _lib.check(_lib.lib().s3_params_touch(self.params), self.dev.ctx,
+                   's3_params_touch')
 
     def arm_allreduce(self, bucket_bytes):
         """the next backward pass that writes this store's gradients reduces

@@ -805,33 +805,69 @@ class Sup3rGan:
         """Enqueue the generator and / or discriminator step of one
         mini-batch (base.py:944-1031) without reading anything back.
         Returns ([LossFuture | dict, ...], trained_gen, trained_disc)."""
-        steps = []
         do_gen = only_gen or (train_gen and not gen_too_good)
         do_disc = only_disc or (train_disc and not disc_too_good)
-        # one upload per mini-batch: both steps read the same device tensors
-        # (and the discriminator's pass over the true field is shared)
-        batch = self._resident(batch)
         scope = getattr(self._compute, 'batch_scope', None)
-        if scope is not None:
-            scope(True)
-        try:
-            if do_gen:
-                steps.append(self.run_gradient_descent(
-                    batch.low_res, batch.high_res, None,
-                    optimizer=self.optimizer,
-                    weight_gen_advers=weight_gen_advers, train_gen=True,
-                    train_disc=False, compute_disc=train_disc,
-                    multi_gpu=multi_gpu, defer=True))
-            if do_disc:
-                steps.append(self.run_gradient_descent(
-                    batch.low_res, batch.high_res, None,
-                    optimizer=self.optimizer_disc,
-                    weight_gen_advers=weight_gen_advers, train_gen=False,
-                    train_disc=True, multi_gpu=multi_gpu, defer=True))
-        finally:
+
+        def body(batch):
+            steps = []
             if scope is not None:
-                scope(False)
+                scope(True)
+            try:
+                if do_gen:
+                    steps.append(self.run_gradient_descent(
+                        batch.low_res, batch.high_res, None,
+                        optimizer=self.optimizer,
+                        weight_gen_advers=weight_gen_advers, train_gen=True,
+                        train_disc=False, compute_disc=train_disc,
+                        multi_gpu=multi_gpu, defer=True))
+                if do_disc:
+                    steps.append(self.run_gradient_descent(
+                        batch.low_res, batch.high_res, None,
+                        optimizer=self.optimizer_disc,
+                        weight_gen_advers=weight_gen_advers, train_gen=False,
+                        train_disc=True, multi_gpu=multi_gpu, defer=True))
+            finally:
+                if scope is not None:
+                    scope(False)
+            return steps
+        rec = self._step_recorder(batch, multi_gpu) if (do_gen or do_disc) \
+            else None
+        if rec is not None:
+            # a launch-bound step is recorded once and replayed as one graph
+            # launch (captured.py)
+            opts = ([self.optimizer] if do_gen else []) + \
+                ([self.optimizer_disc] if do_disc else [])
+            steps = rec.run(batch, (do_gen, do_disc, bool(train_disc),
+                                    float(weight_gen_advers)), opts, body)
+        else:
+            # one upload per mini-batch: both steps read the same device
+            # tensors (and the discriminator's pass over the true field is
+            # shared)
+            steps = body(self._resident(batch))
         return steps, do_gen, do_disc
+
+    # 'auto': record the launch sequence of small (launch-bound) mini-batches
+    # and replay it as one hipGraphLaunch; True: whenever possible; False: never
+    capture_steps = 'auto'
+
+    def _step_recorder(self, batch, multi_gpu):
+        mode = self.capture_steps
+        # (multi_gpu on a single rank without virtual shards is the plain step)
+        if not mode or self._replica_layout(multi_gpu)[1] != 1:
+            return None
+        from .compute import HipGanCompute
+        own = (type(self).get_single_grad is Sup3rGan.get_single_grad
+               and type(self).run_gradient_descent
+               is Sup3rGan.run_gradient_descent
+               and type(self._compute) is HipGanCompute)
+        if not own:
+            return None
+        rec = getattr(self, '_recorder', None)
+        if rec is None or rec.compute is not self._compute:
+            from .captured import StepRecorder
+            rec = self._recorder = StepRecorder(self._compute)
+        return rec if rec.eligible(self, batch, mode, False) else None
 
     def _resident(self, batch):
         dev = getattr(self._gen, 'dev', None)
