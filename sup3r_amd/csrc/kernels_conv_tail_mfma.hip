@@ -343,7 +343,7 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
 // banded MFMAs in the same order as the tile kernel: bit-identical results),
 // 4 staging waves (LDS-DMA of the next plane under the current row's MFMAs),
 // one raw barrier per row.
-constexpr int S1 = 16, S2 = 64, SEG0 = 20;
+constexpr int S1 = 16, S2 = 64;   // (rows per segment: chosen per launch, see launch_conv_tail_mfma)
 constexpr int P1 = S1 + 2, P2 = S2 + 2;
 constexpr int PLANE_CELLS = P1 * P2;                    // 1188
 constexpr int PLANE_BYTES = ((PLANE_CELLS + 63) / 64) * 64 * 16;   // 19,456 incl. pad
@@ -360,7 +360,7 @@ constexpr int SLIDE_LDS = NSLOT * PLANE_BYTES;          // 97,280
 __global__ __launch_bounds__(NTH) void conv_tail_slide_kernel(
     const unsigned short* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ bias, float* __restrict__ y, ConvGeom g,
-    int segs0, int tiles1, int tiles2, int n_units) {
+    int segs0, int tiles1, int tiles2, int n_units, int SEG0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -552,12 +552,31 @@ int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SLIDE_LDS));
       slide_attr = true;
     }
-    const int segs0 = (g.O[0] + SEG0 - 1) / SEG0, st1 = (g.O[1] + S1 - 1) / S1, st2 = (g.O[2] + S2 - 1) / S2;
+    const int st1 = (g.O[1] + S1 - 1) / S1, st2 = (g.O[2] + S2 - 1) / S2;
+    // rows per segment: a workgroup brings in seg + 2 planes per unit and the
+    // launch lasts as long as its busiest workgroup — ceil(units / CUs) units.
+    // 20 rows (1.10 planes per row) suit large batches; at C2 batch 8 (800
+    // units of 20 rows on 256 CUs: 4 rounds of 22 planes) 16 rows make it 1000
+    // units: 4 rounds of 18 planes.
+    int seg = 20;
+    {
+      long long best = -1;
+      for (int cand : {8, 10, 12, 16, 20, 24, 32, 40}) {
+        if (cand > g.O[0] && cand != 8) continue;
+        const int sg = (g.O[0] + cand - 1) / cand;
+        const long long units = (long long)g.N * sg * st1 * st2;
+        const long long rounds = (units + ctx->num_cu - 1) / ctx->num_cu;
+        // planes of the busiest workgroup (+ 3 per unit: pipeline fill)
+        const long long cost = rounds * (cand + 2 + 3);
+        if (best < 0 || cost < best) { best = cost; seg = cand; }
+      }
+    }
+    const int segs0 = (g.O[0] + seg - 1) / seg;
     const int n_units = g.N * segs0 * st1 * st2;
     int sgrid = ctx->num_cu;
     if (sgrid > n_units) sgrid = n_units;
     hipLaunchKernelGGL(conv_tail_slide_kernel, dim3(sgrid), dim3(NTH), SLIDE_LDS, ctx->stream,
-                       (const unsigned short*)x, w, bias, y, g, segs0, st1, st2, n_units);
+                       (const unsigned short*)x, w, bias, y, g, segs0, st1, st2, n_units, seg);
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }
