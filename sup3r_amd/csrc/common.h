@@ -43,6 +43,7 @@
   X(NO_DGRAD_FEWCH) \
   X(NO_DGRAD_S2) \
   X(NO_DGRAD_X3) \
+  X(NO_DIRECT_OUTPUT) \
   X(NO_DISC_BF16) \
   X(NO_DPRE16) \
   X(NO_DPRE16_ONLY_MASK) \

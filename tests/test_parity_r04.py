@@ -188,3 +188,41 @@ def test_bf16x3_tail_conv_on_the_banded_split_mfma_kernel(padding, shape):
     switch('NO_TAIL_X3', None)
     assert np.abs(y1 - y0).max() > 0              # another kernel ran
     assert rel_max(y1, y0) < 2e-5, rel_max(y1, y0)
+
+
+def test_inference_forward_writes_the_callers_buffer_directly():
+    """An inference plan's last op writes ``s3_plan_forward``'s output buffer
+    itself (no device-to-device copy of the whole model output; option
+    ``NO_DIRECT_OUTPUT`` restores the copy): same bits, also into a buffer
+    that is a window of a larger allocation, and ``out=None`` still returns
+    the plan's own result."""
+    import torch
+    from sup3r_amd.engine import Network
+    spec = _trunk_spec(True) + [
+        {'class': 'FlexiblePadding',
+         'paddings': [[0, 0], [1, 1], [1, 1], [1, 1], [0, 0]],
+         'mode': 'REFLECT'},
+        {'class': 'Conv3D', 'filters': 2, 'kernel_size': 3, 'strides': 1,
+         'padding': 'valid'}]
+    shape = (3, 9, 10, 40, 4)
+    x = np.random.default_rng(8).standard_normal(shape).astype(np.float32)
+    net = Network(spec, precision='bf16')
+    net.build(shape, seed=3)
+    ph = net.plan(shape, training=False)
+    xd = net.dev.to_device(x)
+    y_own = ph.forward(xd).cpu().numpy()
+    n = int(np.prod(ph.out_shape))
+    big = torch.full((n + 64,), 7.0, dtype=torch.float32, device='cuda')
+    out = big[32:32 + n].view(*ph.out_shape)
+    y_direct = ph.forward(xd, out=out).cpu().numpy()
+    guard = big.cpu().numpy()
+    assert (guard[:32] == 7.0).all() and (guard[32 + n:] == 7.0).all()
+    switch('NO_DIRECT_OUTPUT', 1)          # (a plan keeps its options: new plan)
+    ph2 = net.plan(shape, training=False)
+    assert ph2 is not ph
+    y_copy = ph2.forward(xd, out=net.dev.empty(ph.out_shape)).cpu().numpy()
+    switch('NO_DIRECT_OUTPUT', None)
+    y_again = ph.forward(xd).cpu().numpy()
+    assert np.abs(y_own).max() > 0
+    for y in (y_direct, y_copy, y_again):
+        np.testing.assert_array_equal(y, y_own)
