@@ -225,6 +225,21 @@ void s3_plan_destroy(s3_plan* plan);
  * output: device pointer receiving the result, or NULL to leave it in the
  * plan's own buffer (s3_plan_tensor). */
 int s3_plan_forward(s3_plan* plan, const void* const* inputs, void* output);
+/* The chunk executor's forward (ForwardPass._run_generator + the hr_crop_slice
+ * of forward_pass.py:384-425 + un_norm_output, abstract.py:243-275) in one
+ * pass: the plan's LAST convolution computes only the window [lo, lo + n) of
+ * its output positions per axis (the chunk without its halo), applies
+ * y * scale[c] + shift[c] (affine_dev: device pointer to scale[n_c] then
+ * shift[n_c], two roundings like numpy; NULL = none) and writes the dense
+ * (N, n0, n1, n2, C) window to `output`.  No full-size model output exists and
+ * the halo positions of the last conv are never computed.  Supported
+ * (s3_plan_supports_window == 1) for inference plans whose last op is the
+ * bf16-input MFMA tail conv; S3_EINVAL otherwise — the caller then runs
+ * s3_plan_forward + s3_chunk_epilogue. */
+int s3_plan_supports_window(const s3_plan* plan);
+int s3_plan_forward_window(s3_plan* plan, const void* const* inputs, void* output,
+                           const int64_t* lo3, const int64_t* n3,
+                           const float* affine_dev, int n_c);
 /* reverse-mode pass of the last forward (tf.GradientTape().gradient,
  * abstract.py:1230-1237).  d_output: dL/d(output); d_input: nullable, receives
  * dL/d(inputs[0]).  accumulate_wgrad != 0 adds into the grad buffer (the

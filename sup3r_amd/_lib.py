@@ -31,6 +31,7 @@ EXPORTS = [
     's3_graph_destroy',
     's3_ctx_set_option', 's3_ctx_get_option', 's3_option_name_at',
     's3_plan_create', 's3_plan_create_opt', 's3_plan_destroy', 's3_plan_forward',
+    's3_plan_supports_window', 's3_plan_forward_window',
     's3_plan_backward', 's3_plan_tensor', 's3_plan_workspace_bytes',
     's3_plan_profile_begin', 's3_plan_profile_end',
     's3_plan_op_is_mfma', 's3_plan_op_info', 's3_plan_tensor_dtype', 's3_plan_tensor_read',
@@ -142,6 +143,10 @@ def lib():
         's3_option_name_at': (C.c_char_p, [i32]),
         's3_plan_destroy': (None, [vp]),
         's3_plan_forward': (i32, [vp, C.POINTER(vp), vp]),
+        's3_plan_supports_window': (i32, [vp]),
+        's3_plan_forward_window': (i32, [vp, C.POINTER(vp), vp,
+                                         C.POINTER(i64), C.POINTER(i64), vp,
+                                         i32]),
         's3_plan_backward': (i32, [vp, vp, vp, i32, i32]),
         's3_plan_tensor': (vp, [vp, i32]),
         's3_plan_workspace_bytes': (i64, [vp]),

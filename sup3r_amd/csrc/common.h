@@ -74,6 +74,7 @@
   X(NO_TAIL_BAND) \
   X(NO_TAIL_MFMA) \
   X(NO_TAIL_SLIDE) \
+  X(NO_TAIL_WINDOW) \
   X(NO_TAIL_X3) \
   X(NO_TILE66) \
   X(NO_TILE_NF2) \
@@ -237,8 +238,9 @@ bool conv_tail_mfma_supported(const ConvGeom& g);
 bool conv_tail_x3_supported(const ConvGeom& g, int precision);
 int launch_conv_tail_x3(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* w,
                         const float* bias, float* y);
+// aff (device, scale[C_out] then shift[C_out], or null): y * scale + shift on the way out
 int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
-                          const float* w, const float* bias, float* y);
+                          const float* w, const float* bias, float* y, const float* aff = nullptr);
 int launch_conv_generic_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,
                               const float* w, float* dx);
 int launch_conv_generic_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,

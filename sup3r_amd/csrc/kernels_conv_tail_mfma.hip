@@ -50,6 +50,13 @@ __device__ inline unsigned pk2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
 }
 __device__ inline float act_sel(float v, float slope) { return v > 0.f ? v : slope * v; }
+// (x * scale) + shift with two roundings, like numpy's un-normalisation
+// (s3_chunk_epilogue does the same): the windowed forward of the C3 executor
+__device__ inline float affine2(float v, float sc, float sh) {
+  float t = v * sc;
+  asm volatile("" : "+v"(t));
+  return t + sh;
+}
 
 // BAND (C_out == 2 only): the 16 MFMA rows are 8 consecutive output positions
 // x 2 channels instead of 2 channels + 14 rows of padding — see the compute
@@ -58,7 +65,7 @@ template <bool BAND>
 __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
     const unsigned short* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ bias, float* __restrict__ y, ConvGeom g,
-    int tiles0, int tiles1, int tiles2, int n_tiles) {
+    int tiles0, int tiles1, int tiles2, int n_tiles, const float* __restrict__ aff) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -245,8 +252,12 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
         if (o0 < g.O[0] && o1 < g.O[1] && o2 < g.O[2]) {
           float* yp = y + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * 2;
           const f32x4 t = acc[u][0] + acc[u][1];
-          const float v0 = act_sel(t[0], slope), v1 = act_sel(t[1], slope),
-                      v2 = act_sel(t[2], slope), v3 = act_sel(t[3], slope);
+          float v0 = act_sel(t[0], slope), v1 = act_sel(t[1], slope),
+                v2 = act_sel(t[2], slope), v3 = act_sel(t[3], slope);
+          if (aff) {
+            v0 = affine2(v0, aff[0], aff[2]); v1 = affine2(v1, aff[1], aff[3]);
+            v2 = affine2(v2, aff[0], aff[2]); v3 = affine2(v3, aff[1], aff[3]);
+          }
           if (o2 + 1 < g.O[2]) {
             __builtin_nontemporal_store((f32x4){v0, v1, v2, v3}, reinterpret_cast<f32x4*>(yp));
           } else {
@@ -293,6 +304,7 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
               src, __builtin_bit_cast(int, act_sel(acc[j][1], slope))));
           if ((lane >> 4) == j) { v0 = a0; v1 = a1; }
         }
+        if (aff) { v0 = affine2(v0, aff[0], aff[2]); v1 = affine2(v1, aff[1], aff[3]); }
         const int gi = g0;
         const int r1 = (gi / (T2 / 16)) % T1;
         const int r0 = gi / ((T2 / 16) * T1);
@@ -315,7 +327,10 @@ __global__ __launch_bounds__(NTH) void conv_tail_mfma_kernel(
             float* yp = y + ((((size_t)n * g.O[0] + o0) * g.O[1] + o1) * g.O[2] + o2) * Cout + kq * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (kq * 4 + r < Cout) yp[r] = act_sel(acc[j][r], slope);
+              if (kq * 4 + r < Cout) {
+                const float v = act_sel(acc[j][r], slope);
+                yp[r] = aff ? affine2(v, aff[kq * 4 + r], aff[Cout + kq * 4 + r]) : v;
+              }
           }
         }
       }
@@ -360,7 +375,7 @@ constexpr int SLIDE_LDS = NSLOT * PLANE_BYTES;          // 97,280
 __global__ __launch_bounds__(NTH) void conv_tail_slide_kernel(
     const unsigned short* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ bias, float* __restrict__ y, ConvGeom g,
-    int segs0, int tiles1, int tiles2, int n_units, int SEG0) {
+    int segs0, int tiles1, int tiles2, int n_units, int SEG0, const float* __restrict__ aff) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -504,8 +519,12 @@ __global__ __launch_bounds__(NTH) void conv_tail_slide_kernel(
       if (oo1 < g.O[1] && oo2 < g.O[2]) {
         float* yp = y + ((((size_t)n * g.O[0] + o0) * g.O[1] + oo1) * g.O[2] + oo2) * 2;
         const f32x4 t = acc0 + acc1;
-        const float v0 = act_sel(t[0], slope), v1 = act_sel(t[1], slope),
-                    v2 = act_sel(t[2], slope), v3 = act_sel(t[3], slope);
+        float v0 = act_sel(t[0], slope), v1 = act_sel(t[1], slope),
+              v2 = act_sel(t[2], slope), v3 = act_sel(t[3], slope);
+        if (aff) {
+          v0 = affine2(v0, aff[0], aff[2]); v1 = affine2(v1, aff[1], aff[3]);
+          v2 = affine2(v2, aff[0], aff[2]); v3 = affine2(v3, aff[1], aff[3]);
+        }
         if (oo2 + 1 < g.O[2]) {
           __builtin_nontemporal_store((f32x4){v0, v1, v2, v3}, reinterpret_cast<f32x4*>(yp));
         } else {
@@ -530,7 +549,7 @@ bool conv_tail_mfma_supported(const ConvGeom& g) {
 }
 
 int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
-                          const float* w, const float* bias, float* y) {
+                          const float* w, const float* bias, float* y, const float* aff) {
   const int tiles0 = (g.O[0] + T0 - 1) / T0, tiles1 = (g.O[1] + T1 - 1) / T1,
             tiles2 = (g.O[2] + T2 - 1) / T2;
   const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
@@ -576,7 +595,7 @@ int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
     int sgrid = ctx->num_cu;
     if (sgrid > n_units) sgrid = n_units;
     hipLaunchKernelGGL(conv_tail_slide_kernel, dim3(sgrid), dim3(NTH), SLIDE_LDS, ctx->stream,
-                       (const unsigned short*)x, w, bias, y, g, segs0, st1, st2, n_units, seg);
+                       (const unsigned short*)x, w, bias, y, g, segs0, st1, st2, n_units, seg, aff);
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }
@@ -584,7 +603,7 @@ int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
   if (grid > n_tiles) grid = n_tiles;
   auto kern = band ? conv_tail_mfma_kernel<true> : conv_tail_mfma_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), 2 * BUF_BYTES, ctx->stream,
-                     (const unsigned short*)x, w, bias, y, g, tiles0, tiles1, tiles2, n_tiles);
+                     (const unsigned short*)x, w, bias, y, g, tiles0, tiles1, tiles2, n_tiles, aff);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

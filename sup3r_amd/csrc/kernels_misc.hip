@@ -911,6 +911,59 @@ __global__ void chunk_stats_kernel(const float* __restrict__ x, int64_t pos_per_
   }
 }
 
+// The same statistics at memory speed for dense, 16-byte aligned chunks with
+// 1024 % c == 0 (c = 1, 2, 4, 8, 16: every real output feature count): the
+// chunk is walked as float4 with four loads in flight per lane; component k of
+// float4 number q = slab * 256 + tid + j * (64 * 256) is channel (4 tid + k) % c
+// for every j, so the running triples sit in fixed registers.  (The plain
+// kernel above reads the chunk once PER CHANNEL with a stride of c floats:
+// 423 us for the 368 MB of a C3 batch of 16; this one 70 - 90 us.)
+__global__ __launch_bounds__(256) void chunk_stats4_kernel(const float* __restrict__ x, int64_t n4_per_chunk,
+                                                           int c, float* __restrict__ partial) {
+  const int chunk = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+  const float4* xc = reinterpret_cast<const float4*>(x) + (int64_t)chunk * n4_per_chunk;
+  float mn[4], mx[4], nn[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; nn[k] = 0.f; }
+  auto fold = [&](const float4& v4) {
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (v[k] != v[k]) nn[k] += 1.f;
+      else { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+    }
+  };
+  const int64_t step = (int64_t)kStatSlabs * 256;
+  int64_t q = (int64_t)slab * 256 + tid;
+  for (; q + 3 * step < n4_per_chunk; q += 4 * step) {
+    const float4 a = xc[q], b = xc[q + step], d = xc[q + 2 * step], e = xc[q + 3 * step];
+    fold(a); fold(b); fold(d); fold(e);
+  }
+  for (; q < n4_per_chunk; q += step) fold(xc[q]);
+  __shared__ float smin[256], smax[256], snan[256];
+  for (int ch = 0; ch < c; ++ch) {
+    float m0 = INFINITY, m1 = -INFINITY, m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((4 * tid + k) % c == ch) { m0 = fminf(m0, mn[k]); m1 = fmaxf(m1, mx[k]); m2 += nn[k]; }
+    smin[tid] = m0; smax[tid] = m1; snan[tid] = m2;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) {
+      if (tid < s_) {
+        smin[tid] = fminf(smin[tid], smin[tid + s_]);
+        smax[tid] = fmaxf(smax[tid], smax[tid + s_]);
+        snan[tid] += snan[tid + s_];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      float* o = partial + (((int64_t)chunk * kStatSlabs + slab) * c + ch) * 3;
+      o[0] = smin[0]; o[1] = smax[0]; o[2] = snan[0];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- the chunk executor's output epilogue in ONE pass over the hi-res batch:
 // un-normalisation (s3_affine_channels' two roundings), halo crop
 // (chunk.hr_crop_slice) and the output check's statistics (chunk_stats_kernel's
@@ -1534,8 +1587,13 @@ extern "C" int s3_chunk_stats(s3_ctx* ctx, const float* x, int n_chunks,
                               int64_t pos_per_chunk, int c, float* partial) {
   if (!ctx) return S3_EINVAL;
   if (n_chunks < 1 || c < 1) S3_FAIL(ctx, S3_EINVAL, "chunk_stats: empty input");
-  hipLaunchKernelGGL(chunk_stats_kernel, dim3(kStatSlabs, n_chunks), dim3(256), 0,
-                     ctx->stream, x, pos_per_chunk, c, partial);
+  const int64_t per = pos_per_chunk * c;
+  if (c <= 16 && 1024 % c == 0 && per % 4 == 0 && !((uintptr_t)x & 15))
+    hipLaunchKernelGGL(chunk_stats4_kernel, dim3(kStatSlabs, n_chunks), dim3(256), 0, ctx->stream, x, per / 4, c,
+                       partial);
+  else
+    hipLaunchKernelGGL(chunk_stats_kernel, dim3(kStatSlabs, n_chunks), dim3(256), 0,
+                       ctx->stream, x, pos_per_chunk, c, partial);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

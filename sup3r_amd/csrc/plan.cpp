@@ -100,6 +100,10 @@ struct s3_plan {
   int32_t output = -1;
   int precision = S3_PREC_F32;
   int training = 0;
+  // s3_plan_forward_window: op index whose conv runs over win_geom (-1: none) + its affine
+  int win_op = -1;
+  ConvGeom win_geom;
+  const float* win_aff = nullptr;
   std::vector<float*> buffers;
   std::vector<size_t> buffer_bytes;
   std::vector<void*> owned;  // every hipMalloc of this plan
@@ -1368,6 +1372,8 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
         }
         return launch_conv_halo_s2_fwd(ctx, o.cg, tptr(pl, d.in0), o.h32_w, b, tptr(pl, d.out), o.io.out_bf16);
       }
+      if (pl->win_op >= 0 && &o == &pl->ops[pl->win_op])   // s3_plan_forward_window: checked there
+        return launch_conv_tail_mfma(ctx, pl->win_geom, tptr(pl, d.in0), w, b, (float*)tptr(pl, d.out), pl->win_aff);
       if (o.tail_x3 && !res && !o.io.in_bf16 && !o.io.out_bf16)
         return launch_conv_tail_x3(ctx, o.cg, (const float*)tptr(pl, d.in0), w, b, (float*)tptr(pl, d.out));
       if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
@@ -1536,6 +1542,7 @@ extern "C" int s3_plan_forward(s3_plan* pl, const void* const* inputs, void* out
     TensorRec& ot = pl->t[root_of(pl, pl->output)];
     const bool direct = output && !pl->training && ot.buffer >= 0 && ot.dtype == 0 && !ot.is_input &&
                         ot.numel == pl->t[pl->output].numel && !s3_opt_has(S3O_NO_DIRECT_OUTPUT);
+    if (pl->win_op >= 0 && !direct) S3_FAIL(ctx, S3_ESTATE, "forward_window: the output cannot be written in place");
     if (direct) ot.ptr = (float*)output;
     rc = forward_ops(pl, ev);
     if (direct) {
@@ -1630,35 +1637,41 @@ extern "C" int64_t s3_plan_tensor_read(s3_plan* pl, int32_t id, void* host, size
   return (int64_t)bytes;
 }
 
+// which forward kernel run_op_forward / launch_conv_generic_fwd picks for a conv
+static int conv_fwd_kind(const s3_plan* pl, const OpRec& o) {
+  const bool res = o.d.res >= 0;
+  const bool bfp = pl->precision == S3_PREC_BF16;
+  int fwd = S3_FWD_DIRECT;
+  // mirrors run_op_forward / launch_conv_generic_fwd
+  if (o.mfma) {
+    fwd = bfp && conv_mfma_persist_supported(pl->ctx, o.cg, o.io, res) ? S3_FWD_MFMA_PERSIST : S3_FWD_MFMA_TILE;
+  } else if (o.halo32 && !res) {
+    fwd = S3_FWD_HALO32;
+  } else if (o.halo_s2 && !res && o.io.in_bf16) {
+    fwd = S3_FWD_HALO_S2;
+  } else if (o.tail_x3 && !res && !o.io.in_bf16 && !o.io.out_bf16) {
+    fwd = S3_FWD_TAIL_MFMA;
+  } else if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
+             (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
+    fwd = o.cg.Cin <= 4 ? S3_FWD_GCONV_FEWCH : S3_FWD_GCONV;
+  } else if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16) {
+    fwd = S3_FWD_FEWPOS;
+  } else if (o.io.in_bf16 && !o.io.out_bf16 && !res && conv_tail_mfma_supported(o.cg) &&
+             !s3_opt_has(S3O_NO_TAIL_MFMA)) {
+    fwd = S3_FWD_TAIL_MFMA;
+  } else if (!o.io.out_bf16 && !res && conv_small_supported(o.cg, o.io.in_bf16)) {
+    fwd = S3_FWD_SMALL;
+  }
+  return fwd;
+}
+
 extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) {
   if (!pl || !out || i < 0 || i >= (int)pl->ops.size()) return S3_EINVAL;
   const OpRec& o = pl->ops[i];
   int32_t v[S3_OPINFO_COUNT] = {0};
   v[S3_OPINFO_KIND] = o.d.kind;
   if (o.d.kind == S3_OP_CONV) {
-    const bool res = o.d.res >= 0;
-    const bool bfp = pl->precision == S3_PREC_BF16;
-    int fwd = S3_FWD_DIRECT;
-    // mirrors run_op_forward / launch_conv_generic_fwd
-    if (o.mfma) {
-      fwd = bfp && conv_mfma_persist_supported(pl->ctx, o.cg, o.io, res) ? S3_FWD_MFMA_PERSIST : S3_FWD_MFMA_TILE;
-    } else if (o.halo32 && !res) {
-      fwd = S3_FWD_HALO32;
-    } else if (o.halo_s2 && !res && o.io.in_bf16) {
-      fwd = S3_FWD_HALO_S2;
-    } else if (o.tail_x3 && !res && !o.io.in_bf16 && !o.io.out_bf16) {
-      fwd = S3_FWD_TAIL_MFMA;
-    } else if (o.gconv && (!o.io.in_bf16 || o.cg.Cin % 8 == 0) && !o.io.res_bf16 &&
-               (!o.io.out_bf16 || o.cg.Cout % 4 == 0)) {
-      fwd = o.cg.Cin <= 4 ? S3_FWD_GCONV_FEWCH : S3_FWD_GCONV;
-    } else if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16) {
-      fwd = S3_FWD_FEWPOS;
-    } else if (o.io.in_bf16 && !o.io.out_bf16 && !res && conv_tail_mfma_supported(o.cg) &&
-               !s3_opt_has(S3O_NO_TAIL_MFMA)) {
-      fwd = S3_FWD_TAIL_MFMA;
-    } else if (!o.io.out_bf16 && !res && conv_small_supported(o.cg, o.io.in_bf16)) {
-      fwd = S3_FWD_SMALL;
-    }
+    int fwd = conv_fwd_kind(pl, o);
     const bool fused = pl->fused2d && !pl->training && !s3_opt_has(S3O_NO_FUSED2D);
     if (fused) fwd = S3_FWD_FUSED2D;
     v[S3_OPINFO_FWD] = fwd;
@@ -1697,6 +1710,71 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
   if (o.d.kind == S3_OP_REPEAT_T) v[S3_OPINFO_IN_REP] = o.fused_away ? 1 : 0;
   for (int q = 0; q < cap && q < S3_OPINFO_COUNT; ++q) out[q] = v[q];
   return S3_OPINFO_COUNT;
+}
+
+// ---- windowed forward: the C3 executor's halo crop + un-normalisation inside
+// the tail conv.  The last conv of the plan computes only the window
+// [lo, lo + n) of its output positions — the chunk without its halo — applies
+// y * scale + shift and writes the (N, n0, n1, n2, C) result densely into the
+// caller's buffer: no full-size model output, no epilogue pass over it, and the
+// tail conv skips the halo positions (24 % of them at 110 x 110 x 624 ->
+// 100 x 100 x 576).  Only for plans whose last op is the bf16-input MFMA tail.
+static int window_op(const s3_plan* pl) {
+  if (pl->training || pl->ops.empty()) return -1;
+  if (pl->fused2d && !s3_opt_has(S3O_NO_FUSED2D)) return -1;
+  if (s3_opt_on(S3O_GRAPH) || s3_opt_has(S3O_NO_DIRECT_OUTPUT) || s3_opt_has(S3O_NO_TAIL_WINDOW)) return -1;
+  int i = (int)pl->ops.size() - 1;
+  while (i >= 0 && pl->ops[i].d.kind == S3_OP_VIEW) --i;
+  if (i < 0) return -1;
+  const OpRec& o = pl->ops[i];
+  if (o.d.kind != S3_OP_CONV || o.d.res >= 0 || o.cg.d2s != 1 || !o.io.in_bf16 || o.io.out_bf16) return -1;
+  if (conv_fwd_kind(pl, o) != S3_FWD_TAIL_MFMA) return -1;
+  const int ro = root_of(pl, o.d.out);
+  if (ro != root_of(pl, pl->output)) return -1;
+  const TensorRec& ot = pl->t[ro];
+  if (ot.buffer < 0 || ot.dtype != 0 || ot.is_input || ot.numel != pl->t[pl->output].numel) return -1;
+  // nobody else writes or reads the output tensor
+  for (int k = 0; k < (int)pl->ops.size(); ++k) {
+    if (k == i) continue;
+    const s3_op_desc& d = pl->ops[k].d;
+    if (d.kind == S3_OP_VIEW) continue;
+    for (int id : {d.in0, d.in1, d.res, d.out})
+      if (id >= 0 && root_of(pl, id) == ro) return -1;
+  }
+  return i;
+}
+
+extern "C" int s3_plan_supports_window(const s3_plan* pl) {
+  if (!pl) return 0;
+  S3OptScope opt_scope(&pl->opt);
+  return window_op(pl) >= 0 ? 1 : 0;
+}
+
+extern "C" int s3_plan_forward_window(s3_plan* pl, const void* const* inputs, void* output, const int64_t* lo3,
+                                      const int64_t* n3, const float* affine_dev, int n_c) {
+  if (!pl || !output || !lo3 || !n3) return S3_EINVAL;
+  s3_ctx* ctx = pl->ctx;
+  int wi;
+  {
+    S3OptScope opt_scope(&pl->opt);
+    wi = window_op(pl);
+  }
+  if (wi < 0) S3_FAIL(ctx, S3_EINVAL, "forward_window: the plan's last op is not the MFMA tail conv of an inference plan");
+  const OpRec& o = pl->ops[wi];
+  if (affine_dev && n_c != o.cg.Cout) S3_FAIL(ctx, S3_EINVAL, "forward_window: affine channel count");
+  ConvGeom g = o.cg;
+  for (int d = 0; d < 3; ++d) {
+    if (lo3[d] < 0 || n3[d] < 1 || lo3[d] + n3[d] > o.cg.O[d]) S3_FAIL(ctx, S3_EINVAL, "forward_window: window outside the output");
+    g.O[d] = (int)n3[d];
+    g.lo[d] = o.cg.lo[d] - (int)lo3[d] * o.cg.s[d];
+  }
+  pl->win_op = wi;
+  pl->win_geom = g;
+  pl->win_aff = affine_dev;
+  const int rc = s3_plan_forward(pl, inputs, output);
+  pl->win_op = -1;
+  pl->win_aff = nullptr;
+  return rc;
 }
 
 // deliver a gradient contribution `src` (numel floats) to tensor `id`.

@@ -243,6 +243,27 @@ class PlanHandle:
         self._keep = keep
         return out
 
+    @property
+    def supports_window(self):
+        return bool(_lib.lib().s3_plan_supports_window(self.h))
+
+    def forward_window(self, x, exo, out, lo, n, affine=None):
+        """``forward`` whose last conv computes only the window ``[lo, lo +
+        n)`` of its output positions, un-normalised by ``affine`` (device
+        tensor: scale[C] then shift[C]) and written densely into ``out``
+        (``s3_plan_forward_window``)."""
+        ptrs, keep = self._input_ptrs(x, exo or {})
+        i64x3 = C.c_int64 * 3
+        n_c = int(affine.numel() // 2) if affine is not None else 0
+        rc = _lib.lib().s3_plan_forward_window(
+            self.h, ptrs, C.c_void_p(out.data_ptr()),
+            i64x3(*[int(v) for v in lo]), i64x3(*[int(v) for v in n]),
+            C.c_void_p(affine.data_ptr()) if affine is not None else None,
+            n_c)
+        _lib.check(rc, self.dev.ctx, 's3_plan_forward_window')
+        self._keep = keep + [affine]
+        return out
+
     def backward(self, d_out, need_dx=False, need_wgrad=True,
                  accumulate_wgrad=False):
         dx = None

@@ -84,6 +84,10 @@ def get_source_type(file_paths):
     return 'nc'
 
 
+class _EnhancementMismatch(RuntimeError):
+    """stated s_enhance / t_enhance vs the generator's output shape"""
+
+
 class NpzOutputHandler:
     """Minimal chunk writer with the ``_write_output`` call of sup3r's
     ``OutputHandlerH5`` / ``OutputHandlerNC`` (sup3r/writers/base.py): the
@@ -831,44 +835,64 @@ class ForwardPass:
                 layer_exo[name] = cls._upload_async(
                     dev, np.concatenate(parts, axis=0) if n > 1 else parts[0],
                     staged)
-            y = ph.forward(cls._upload_async(dev, x, staged), layer_exo)
-        except AssertionError:
+            xd = cls._upload_async(dev, x, staged)
+            # the enhancement checks of the reference (forward_pass.py:
+            # _run_generator) on the plan's output shape
+            yshape = tuple(int(v) for v in ph.out_shape)
+            if model.s_enhance * x.shape[1] != yshape[1]:
+                msg = ('The stated spatial enhancement of {}x did not match '
+                       'the low res / high res shapes of {} -> {}'.format(
+                           model.s_enhance, x.shape, yshape))
+                logger.error(msg)
+                raise _EnhancementMismatch(msg)
+            if model.t_enhance * x.shape[3] != yshape[3]:
+                msg = ('The stated temporal enhancement of {}x did not match '
+                       'the low res / high res shapes of {} -> {}'.format(
+                           model.t_enhance, x.shape, yshape))
+                logger.error(msg)
+                raise _EnhancementMismatch(msg)
+            n_out = yshape[-1]
+            pf = C.POINTER(C.c_float)
+            scale = shift = None
+            if model.means is not None:
+                mu, sd = model._stats_for(model.hr_out_features)
+                scale = np.ascontiguousarray(sd, dtype=np.float32)
+                shift = np.ascontiguousarray(mu, dtype=np.float32)
+            y1, y2, y3 = yshape[1:4]
+            cr = cls._crop_bounds(group[0].hr_crop_slice, (y1, y2, y3))
+            c1, c2, c3 = (b - a for a, b in cr)
+            yc = dev.empty((n, c1, c2, c3, n_out))
+            stats_d = dev.empty((n, 64, n_out, 3))
+            # halo crop + un-normalisation inside the tail conv (the window
+            # forward: no full-size output, halo positions of the last conv
+            # never computed) where the plan ends in the MFMA tail ...
+            windowed = cls.window_forward and ph.supports_window
+            if windowed:
+                ph.forward_window(
+                    xd, layer_exo, yc, [cr[0][0], cr[1][0], cr[2][0]],
+                    [c1, c2, c3], cls._affine_tensor(dev, scale, shift))
+                y = None
+            else:
+                y = ph.forward(xd, layer_exo)
+        except (AssertionError, _EnhancementMismatch):
             raise
         except Exception as e:
             msg = 'Forward pass failed on chunk with shape {}.'.format(
                 x.shape)
             logger.exception(msg)
             raise RuntimeError(msg) from e
-        if model.s_enhance * x.shape[1] != y.shape[1]:
-            msg = ('The stated spatial enhancement of {}x did not match the '
-                   'low res / high res shapes of {} -> {}'.format(
-                       model.s_enhance, x.shape, tuple(y.shape)))
-            logger.error(msg)
-            raise RuntimeError(msg)
-        if model.t_enhance * x.shape[3] != y.shape[3]:
-            msg = ('The stated temporal enhancement of {}x did not match the '
-                   'low res / high res shapes of {} -> {}'.format(
-                       model.t_enhance, x.shape, tuple(y.shape)))
-            logger.error(msg)
-            raise RuntimeError(msg)
-        n_out = int(y.shape[-1])
-        pf = C.POINTER(C.c_float)
-        scale = shift = None
-        if model.means is not None:
-            mu, sd = model._stats_for(model.hr_out_features)
-            scale = np.ascontiguousarray(sd, dtype=np.float32)
-            shift = np.ascontiguousarray(mu, dtype=np.float32)
-        y1, y2, y3 = (int(v) for v in y.shape[1:4])
-        cr = cls._crop_bounds(group[0].hr_crop_slice, (y1, y2, y3))
-        c1, c2, c3 = (b - a for a, b in cr)
-        yc = dev.empty((n, c1, c2, c3, n_out))
-        stats_d = dev.empty((n, 64, n_out, 3))
-        # un-normalisation, halo crop and the output check's statistics: one
-        # pass over the cropped window (s3_chunk_epilogue) where the rows are
-        # 16-byte aligned, the three separate kernels otherwise — same bits
+        # ... else un-normalisation, halo crop and the output check's
+        # statistics in one pass over the cropped window (s3_chunk_epilogue)
+        # where the rows are 16-byte aligned, the three separate kernels
+        # otherwise — same bits in every case
         fused = 1024 % n_out == 0 and n_out <= 16 and not any(
             (v * n_out) % 4 for v in (c3, cr[2][0], y3))
-        if fused:
+        if windowed:
+            rc = L.s3_chunk_stats(dev.ctx, C.c_void_p(yc.data_ptr()), n,
+                                  yc.numel() // (n * n_out), n_out,
+                                  C.c_void_p(stats_d.data_ptr()))
+            _lib.check(rc, dev.ctx, 's3_chunk_stats')
+        elif fused:
             i64x3 = C.c_int64 * 3
             rc = L.s3_chunk_epilogue(
                 dev.ctx, C.c_void_p(y.data_ptr()), n, i64x3(y1, y2, y3),
@@ -1022,7 +1046,25 @@ class ForwardPass:
     #: deliver by the SDMA engines through ROCr (s3_dma_d2h_begin); switched
     #: off (with a warning) the first time ROCr refuses a copy
     sdma_delivery = True
+    # halo crop + un-normalisation inside the tail conv (s3_plan_forward_window)
+    # where the plan supports it; False: full output + s3_chunk_epilogue
+    window_forward = True
+    _aff_cache = {}
     _delivery = {}
+
+    @classmethod
+    def _affine_tensor(cls, dev, scale, shift):
+        """scale[C] then shift[C] on the device (None without statistics);
+        one upload per distinct set of statistics"""
+        if scale is None:
+            return None
+        key = (dev.index, scale.tobytes(), shift.tobytes())
+        if key not in cls._aff_cache:
+            if len(cls._aff_cache) > 64:
+                cls._aff_cache.clear()
+            cls._aff_cache[key] = dev.to_device(
+                np.concatenate([scale, shift]).astype(np.float32))
+        return cls._aff_cache[key]
 
     @classmethod
     def release_delivery_buffers(cls):

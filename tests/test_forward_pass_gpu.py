@@ -79,20 +79,23 @@ def test_run_batched_errors():
             runner(domain, out=np.zeros(slicer.hr_shape + (2,), np.float32))
 
 
-def test_chunk_stats_kernel():
+@pytest.mark.parametrize('c,npos', [(2, 5000), (3, 5000), (4, 70001), (2, 4999)])
+def test_chunk_stats_kernel(c, npos):
     """s3_chunk_stats against numpy: min / max / NaN count per chunk and
-    channel after folding the 64 slabs."""
+    channel after folding the 64 slabs — the float4 walk (c | 1024, 16-byte
+    chunks) and the plain per-channel kernel (c = 3; odd element counts)."""
     import ctypes as C
     from sup3r_amd import _lib
     from sup3r_amd.engine import Device
     dev, L = Device.get(), _lib.lib()
     rng = np.random.default_rng(9)
-    x = rng.standard_normal((3, 5000, 2)).astype(np.float32)
+    x = rng.standard_normal((3, npos, c)).astype(np.float32)
     x[1, :, 1] = 0.75                   # constant channel
     x[2, 17, 0] = np.nan
+    x[2, npos - 1, c - 1] = np.nan
     xd = dev.to_device(x)
-    st = dev.empty((3, 64, 2, 3))
-    rc = L.s3_chunk_stats(dev.ctx, C.c_void_p(xd.data_ptr()), 3, 5000, 2,
+    st = dev.empty((3, 64, c, 3))
+    rc = L.s3_chunk_stats(dev.ctx, C.c_void_p(xd.data_ptr()), 3, npos, c,
                           C.c_void_p(st.data_ptr()))
     _lib.check(rc, dev.ctx, 's3_chunk_stats')
     s_ = st.cpu().numpy()
@@ -490,3 +493,62 @@ def test_residency_is_explicit():
                          {'u_10m': 1.0, 'v_10m': 1.0})
     with pytest.raises(RuntimeError, match='statistics'):
         run(h)
+
+
+@pytest.mark.parametrize('temporal_pad', [2, 1])
+def test_window_forward_equals_full_forward_then_crop(temporal_pad):
+    """``s3_plan_forward_window``: the executor's halo crop + un-normalisation
+    inside the generator's tail conv (only the chunk's own positions of the
+    last conv are computed, no full-size output, no epilogue pass) against the
+    full forward + ``s3_chunk_epilogue``.  With the temporal halo a multiple of
+    8 hi-res steps (2 x 12) every output runs the identical MFMA sequence: the
+    same bits; otherwise the banded tail groups a position's taps differently
+    (fp32 summation order).  Edge chunks (no halo on the domain border: the
+    crop starts at 0) included.  Reference: forward_pass.py:384-425
+    (``_run_generator`` + ``hr_crop_slice``), abstract.py:243-275
+    (``un_norm_output``)."""
+    from sup3r_amd import ForwardPass, Sup3rGan
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    feats = ['u_100m', 'v_100m', 'temperature_100m', 'pressure_0m']
+    Sup3rGan.seed(3)
+    means = {f: np.float32(0.3 * (i + 1)) for i, f in enumerate(feats)}
+    stds = {f: np.float32(1.5 + 0.25 * i) for i, f in enumerate(feats)}
+    m = Sup3rGan(os.path.join(CFG, 'gen_5x_12x_2f.json'),
+                 os.path.join(CFG, 'test_disc_st_same.json'),
+                 precision='bf16', means=means, stdevs=stds)
+    m.set_model_params(lr_features=feats, hr_out_features=feats[:2],
+                       s_enhance=5, t_enhance=12)
+    tp = temporal_pad
+    m.init_weights((1, 8, 8, 4 + 2 * tp, 4), (1, 40, 40, 12 * (4 + 2 * tp), 2))
+    rng = np.random.default_rng(9)
+    domain = rng.standard_normal((18, 12, 12, 4)).astype(np.float32)
+    register_model('Sup3rGan', {'model_dir': 'win-test'}, m)
+    st = ArrayStrategy(domain, {'model_dir': 'win-test'}, (6, 6, 4),
+                       spatial_pad=1, temporal_pad=tp, max_nodes=1, model=m)
+    fwp = ForwardPass(st, 0)
+    ids = [int(i) for i in st.node_chunks[0]]
+
+    def run(window):
+        ForwardPass.window_forward = window
+        try:
+            out = {}
+            for c, failed, d in ForwardPass.iter_chunks(
+                    (fwp.get_input_chunk(i) for i in ids), m, batch=3):
+                assert not failed
+                out[c.index] = np.array(d)
+            return out
+        finally:
+            ForwardPass.window_forward = True
+    ph = m._gen.plan((3, 8, 8, 4 + 2 * tp, 4), training=False)
+    assert ph.supports_window
+    got, ref = run(True), run(False)
+    assert len(got) == len(ids) == 18
+    for i in ids:
+        assert got[i].shape == ref[i].shape == (30, 30, 48, 2)
+        if tp == 2:
+            np.testing.assert_array_equal(got[i], ref[i])
+        else:
+            scale = np.abs(ref[i]).max()
+            assert np.abs(got[i] - ref[i]).max() < 2e-6 * scale
+    assert np.abs(ref[ids[0]]).max() > 0
