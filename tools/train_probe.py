@@ -22,6 +22,8 @@ def main():
     ap.add_argument('--precision', default='f32')
     ap.add_argument('--hr-features', type=int, default=2,
                     help='output features of the generator')
+    ap.add_argument('--capture', action='store_true',
+                    help='record the step as a hipGraph whatever its size')
     args = ap.parse_args()
     import torch
     from sup3r_amd import Sup3rGan
@@ -36,10 +38,13 @@ def main():
     lr = rng.standard_normal(lr_shape).astype(np.float32)
     hr = rng.standard_normal(hr_shape).astype(np.float32)
     model.init_weights(lr_shape, hr_shape)
+    if args.capture:
+        model.capture_steps = True
 
     class B:
         low_res, high_res = lr, hr
     step = lambda: model._train_batch(B, True, False, False, True, False, False, 1e-3)
+    step()
     step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
