@@ -350,7 +350,12 @@ class HipGanCompute:
         loss_key = None
         if train_gen:
             d_gen_full = dev.empty(tuple(gen_full.shape)) if gen_train else None
-            if gen_train:
+            # the first term of a dense content loss WRITES its gradient (no
+            # zero fill of the hi-res gradient tensor: 118 MB at C2 batch 8)
+            first_writes = bool(
+                gen_train and loss_terms and mask_d is None and
+                not isinstance(loss_terms[0][1], str) and c_used == c_true)
+            if gen_train and not first_writes:
                 L.s3_fill(dev.ctx, self._ptr(d_gen_full), d_gen_full.numel(),
                           0.0)
             n_pos = gen_full.numel() // c_true
@@ -372,7 +377,8 @@ class HipGanCompute:
                         dev.ctx, kind, self._ptr(gen_full), c_true,
                         self._ptr(hr_true), c_true, c_used, n_pos, w,
                         self._ptr(scal, slot),
-                        self._ptr(dg) if gen_train else None, 1)
+                        self._ptr(dg) if gen_train else None,
+                        0 if (first_writes and i == 0) else 1)
                 else:
                     rc = L.s3_loss_content_masked(
                         dev.ctx, kind, self._ptr(gen_full), c_true,

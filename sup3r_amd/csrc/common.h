@@ -134,6 +134,10 @@ struct s3_ctx {
   // scratch block that is outgrown is retired (freed with the context), not freed
   bool graphs_made = false;
   std::vector<void*> retired;
+  // a bias gradient's second stage (channel sums of per-workgroup partials)
+  // waiting to ride along the next weight-gradient reduction launch
+  // (launch_bias_grad_from_partial(.., defer) / s3_take_pending_bias)
+  struct PendingBias { const float* partial = nullptr; int nblk = 0, c = 0; float* db = nullptr; int accumulate = 0; } pend_bias;
 };
 
 #define S3_HIP(ctx, call)                                                    \
@@ -440,7 +444,23 @@ int launch_gather_bwd_add(s3_ctx* ctx, const GatherGeom& g, const float* dout, f
                           float* bsum = nullptr, void* side16 = nullptr, int frame16 = 0);
 bool gather_bwd_bsum_ok(const GatherGeom& g);
 int gather_bwd_bsum_blocks(const s3_ctx* ctx, const GatherGeom& g);
-int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, int c, float* db, int accumulate);
+int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, int c, float* db, int accumulate,
+                                  bool defer = false);
+// the deferred job, if any, launched on its own (nothing took it along)
+int s3_flush_pending_bias(s3_ctx* ctx);
+// workgroup `ch` of a 256-thread launch: db[ch] (+)= sum over the nblk rows of partial[.][c]
+__device__ inline void s3_bias_stage2_body(const float* __restrict__ partial, int nblk, int c, int ch,
+                                           float* __restrict__ db, int accumulate, float* sm /* [256] */) {
+  float t = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 256) t += partial[(int64_t)b * c + ch];
+  sm[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) db[ch] = accumulate ? db[ch] + sm[0] : sm[0];
+}
 int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
                      float* db, int accumulate);
 int launch_dense_fwd(s3_ctx* ctx, const float* x, const float* w,

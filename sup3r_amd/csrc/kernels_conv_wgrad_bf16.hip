@@ -551,11 +551,20 @@ __global__ __launch_bounds__(BNT) void conv3_wgrad_x3_kernel(
 }
 constexpr int X3_LDS = 2 * (4 * BH1 * BH2) * 128 + 2 * (2 * BT1 * BT2) * 64;   // 126,976 B
 
+// workgroups [0, wblocks): the weight gradient's partials; workgroups past
+// them (b_c of them, when a bias job rides along): bias_grad_stage2's channels
 __global__ void wgrad_bf16_partial_reduce(const float* __restrict__ partial,
                                           int n_part, int64_t wsize,
-                                          float* __restrict__ dw, int accumulate) {
+                                          float* __restrict__ dw, int accumulate, int wblocks,
+                                          const float* __restrict__ b_partial, int b_nblk, int b_c,
+                                          float* __restrict__ b_db, int b_accumulate) {
+  if ((int)blockIdx.x >= wblocks) {
+    __shared__ float sm[256];
+    s3_bias_stage2_body(b_partial, b_nblk, b_c, (int)blockIdx.x - wblocks, b_db, b_accumulate, sm);
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < wsize;
-       i += (int64_t)gridDim.x * blockDim.x) {
+       i += (int64_t)wblocks * blockDim.x) {
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     int s = 0;
     for (; s + 4 <= n_part; s += 4) {
@@ -568,6 +577,18 @@ __global__ void wgrad_bf16_partial_reduce(const float* __restrict__ partial,
     const float t = (t0 + t1) + (t2 + t3);
     dw[i] = accumulate ? dw[i] + t : t;
   }
+}
+
+static int launch_wgrad_bf16_reduce(s3_ctx* ctx, const float* partial, int n_part, int64_t wsize, float* dw,
+                                    int accumulate, int wblocks) {
+  // a bias gradient's second stage waiting in the context rides along
+  const s3_ctx::PendingBias j = ctx->pend_bias;
+  ctx->pend_bias.partial = nullptr;
+  const int extra = j.partial ? j.c : 0;
+  hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3(wblocks + extra), dim3(256), 0, ctx->stream, partial,
+                     n_part, wsize, dw, accumulate, wblocks, j.partial, j.nblk, j.c, j.db, j.accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
 }
 
 int bf_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles_out, int* t0,
@@ -942,10 +963,7 @@ int bf_gen_launch_x3(s3_ctx* ctx, const ConvGeom& g, const float* x, const float
   const int64_t wsize = (int64_t)27 * g.Cin * g.Cout;
   int rg = (int)((wsize + 255) / 256);
   if (rg > 4096) rg = 4096;
-  hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial, grid,
-                     wsize, dw, accumulate);
-  S3_HIP(ctx, hipGetLastError());
-  return S3_OK;
+  return launch_wgrad_bf16_reduce(ctx, partial, grid, wsize, dw, accumulate, rg);
 }
 
 template <int CIB, int STR, bool IN16 = false>
@@ -977,10 +995,7 @@ int bf_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* d
   const int64_t wsize = (int64_t)27 * g.Cin * g.Cout;
   int rg = (int)((wsize + 255) / 256);
   if (rg > 4096) rg = 4096;
-  hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial, grid,
-                     wsize, dw, accumulate);
-  S3_HIP(ctx, hipGetLastError());
-  return S3_OK;
+  return launch_wgrad_bf16_reduce(ctx, partial, grid, wsize, dw, accumulate, rg);
 }
 
 
@@ -1163,10 +1178,7 @@ int bf_2d_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy
   const int64_t wsize = (int64_t)9 * g.Cin * g.Cout;
   int rg = (int)((wsize + 255) / 256);
   if (rg > 4096) rg = 4096;
-  hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3(rg), dim3(256), 0, ctx->stream, partial, grid,
-                     wsize, dw, accumulate);
-  S3_HIP(ctx, hipGetLastError());
-  return S3_OK;
+  return launch_wgrad_bf16_reduce(ctx, partial, grid, wsize, dw, accumulate, rg);
 }
 
 }  // namespace
@@ -1236,10 +1248,7 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                        ctx->stream, x, dy, partial, g, tiles0, tiles1, tiles2, n_tiles, dbg);
   S3_HIP(ctx, hipGetLastError());
   const int64_t wsize = (int64_t)27 * 64 * g.Cout;
-  hipLaunchKernelGGL(wgrad_bf16_partial_reduce, dim3((unsigned)((wsize + 255) / 256)), dim3(256), 0,
-                     ctx->stream, partial, grid, wsize, dw, accumulate);
-  S3_HIP(ctx, hipGetLastError());
-  return S3_OK;
+  return launch_wgrad_bf16_reduce(ctx, partial, grid, wsize, dw, accumulate, (int)((wsize + 255) / 256));
 }
 
 // ---- general variant (discriminator convs)

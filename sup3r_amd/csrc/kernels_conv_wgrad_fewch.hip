@@ -362,16 +362,28 @@ reduce:
 
 __global__ void wgrad_c2_partial_reduce(const float* __restrict__ partial, int n_part,
                                         int wsize, float* __restrict__ dw, int accumulate) {
-  // one workgroup per 64 elements, 4 lanes-groups split the partials
-  __shared__ float s[4][64];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  float t = 0.f;
-  if (e < wsize)
-    for (int p = q; p < n_part; p += 4) t += partial[(size_t)p * wsize + e];
-  s[q][threadIdx.x & 63] = t;
+  // one workgroup per 16 elements; 16 lane groups split the partials and each
+  // walks its share with four independent sums (up to 1 024 partials of 1 728
+  // elements: with 4 groups and one dependent sum per lane the 2 -> 32 layer's
+  // reduction took 66 us).  Fixed order: deterministic, identical on every rank.
+  __shared__ float s[16][16];
+  const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e < wsize) {
+    int p = q;
+    for (; p + 48 < n_part; p += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] += partial[(size_t)(p + 16 * u) * wsize + e];
+    }
+    for (int u = 0; p < n_part; p += 16, ++u) t[u & 3] += partial[(size_t)p * wsize + e];
+  }
+  s[q][el] = (t[0] + t[1]) + (t[2] + t[3]);
   __syncthreads();
   if (q == 0 && e < wsize) {
-    const float v = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += s[g][el];
     dw[e] = accumulate ? dw[e] + v : v;
   }
 }
@@ -442,7 +454,7 @@ int launch_conv_wgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* x, const f
 #undef S3_C2X
   S3_HIP(ctx, hipGetLastError());
   const int wsize = 27 * g.Cin * g.Cout;
-  hipLaunchKernelGGL(wgrad_c2_partial_reduce, dim3((wsize + 63) / 64), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(wgrad_c2_partial_reduce, dim3((wsize + 15) / 16), dim3(256), 0, ctx->stream,
                      partial, grid, wsize, dw, accumulate);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
@@ -671,7 +683,7 @@ int launch_conv_wgrad_tail(s3_ctx* ctx, const ConvGeom& g, const float* x, const
                        partial, g, t0, t1, t2, n_tiles);
   S3_HIP(ctx, hipGetLastError());
   const int wsize = 27 * 8 * g.Cout;
-  hipLaunchKernelGGL(wgrad_c2_partial_reduce, dim3((wsize + 63) / 64), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(wgrad_c2_partial_reduce, dim3((wsize + 15) / 16), dim3(256), 0, ctx->stream,
                      partial, grid, wsize, dw, accumulate);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;

@@ -460,7 +460,16 @@ __global__ void conv_epilogue_bwd_kernel(const float* __restrict__ y,
 template <bool Y16, bool D16 = false>
 __global__ void conv_epilogue_bwd_d2s4_kernel(const void* __restrict__ y, const float4* __restrict__ dy,
                                               float4* __restrict__ dpre, ConvGeom g, float slope,
-                                              unsigned short* __restrict__ d16 = nullptr) {
+                                              unsigned short* __restrict__ d16 = nullptr,
+                                              float* __restrict__ bsum = nullptr) {
+  // dpre (nullable with D16): every reader of this dPre takes the bf16 copy.
+  // bsum (nullable): per-workgroup channel sums of dpre = the conv's bias
+  // gradient for bias_grad_stage2; the launch then uses a block size that is
+  // a multiple of C_out / 4, so that a lane keeps one channel group
+  // (conv_epilogue_bwd_d2s4_block) — with the fp32 store gone too the 64 ->
+  // 200 conv of C2 (118 M elements) saves 0.47 GB of stores and the 0.47 GB
+  // bias_grad_stage1 read them back with.
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
   const unsigned b = (unsigned)g.d2s, co4 = ((unsigned)g.Cout / (b * b)) >> 2, C4 = (unsigned)g.Cout >> 2;
   const unsigned O0 = (unsigned)g.O[0], O1 = (unsigned)g.O[1], O2 = (unsigned)g.O[2];
   const int64_t total = (int64_t)g.N * O0 * O1 * O2 * C4;
@@ -495,7 +504,8 @@ __global__ void conv_epilogue_bwd_d2s4_kernel(const void* __restrict__ y, const 
       d.x *= v.x > 0.f ? 1.f : slope; d.y *= v.y > 0.f ? 1.f : slope;
       d.z *= v.z > 0.f ? 1.f : slope; d.w *= v.w > 0.f ? 1.f : slope;
     }
-    dpre[idx] = d;
+    if (dpre) dpre[idx] = d;
+    bs.x += d.x; bs.y += d.y; bs.z += d.z; bs.w += d.w;
     if constexpr (D16) {   // bf16 copy for the MFMA gradient kernels
       typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
       typedef float f2 __attribute__((ext_vector_type(2)));
@@ -503,6 +513,19 @@ __global__ void conv_epilogue_bwd_d2s4_kernel(const void* __restrict__ y, const 
       reinterpret_cast<uint2*>(d16)[idx] =
           make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf2)),
                      __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf2)));
+    }
+  }
+  if (bsum) {
+    __shared__ float4 bred[256];
+    bred[threadIdx.x] = bs;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (unsigned q = threadIdx.x; q < blockDim.x; q += C4) {
+        const float4 v = bred[q];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      reinterpret_cast<float4*>(bsum)[(int64_t)blockIdx.x * C4 + threadIdx.x] = t;
     }
   }
 }
@@ -679,16 +702,7 @@ __global__ void bias_grad_stage1_v4(const float4* __restrict__ dy, int64_t n_pos
 __global__ void bias_grad_stage2(const float* __restrict__ partial, int nblk,
                                  int c, float* __restrict__ db, int accumulate) {
   __shared__ float sm[256];
-  const int ch = blockIdx.x;
-  float t = 0.f;
-  for (int b = threadIdx.x; b < nblk; b += 256) t += partial[(int64_t)b * c + ch];
-  sm[threadIdx.x] = t;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) db[ch] = accumulate ? db[ch] + sm[0] : sm[0];
+  s3_bias_stage2_body(partial, nblk, c, blockIdx.x, db, accumulate, sm);
 }
 
 // wide-channel variant (dense layers: few rows, thousands of channels): one
@@ -756,6 +770,47 @@ __global__ void loss_content_kernel(int kind, const float* __restrict__ a,
     if (d_a) {
       float v = g * gscale * mk;
       d_a[p * c_a + c] = accumulate ? d_a[p * c_a + c] + v : v;
+    }
+  }
+  float t = block_sum(acc, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// the dense case (every channel used, no mask, n % 4 == 0): 16-B loads and
+// stores, no per-element division (the C2 hi-res batch — 29.5 M elements —
+// took 146 us on the walk above: 2 x what its 354 MB cost at 5 TB/s)
+__global__ void loss_content4_kernel(int kind, const float4* __restrict__ a, const float4* __restrict__ b,
+                                     int64_t n4, float gscale, float* __restrict__ partial,
+                                     float4* __restrict__ d_a, int accumulate) {
+  __shared__ float sm[8];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 va = a[i], vb = b[i];
+    const float d[4] = {va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w};
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (kind == S3_LOSS_MAE) {
+        acc += fabsf(d[q]);
+        g[q] = (d[q] > 0.f) ? 1.f : (d[q] < 0.f ? -1.f : 0.f);
+      } else if (kind == S3_LOSS_EXP) {
+        const float e = __expf(-d[q] * d[q]);
+        acc += 1.f - e;
+        g[q] = 2.f * d[q] * e;
+      } else {
+        acc += d[q] * d[q];
+        g[q] = 2.f * d[q];
+      }
+      g[q] *= gscale;
+    }
+    if (d_a) {
+      float4 v = make_float4(g[0], g[1], g[2], g[3]);
+      if (accumulate) {
+        const float4 o = d_a[i];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      d_a[i] = v;
     }
   }
   float t = block_sum(acc, sm);
@@ -1157,8 +1212,29 @@ int launch_gather_bwd_masked(s3_ctx* ctx, const GatherGeom& g, const float* dout
 }
 
 // stage 2 of the bias gradient from channel sums a fold kernel left behind
-int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, int c, float* db, int accumulate) {
+int launch_bias_grad_from_partial(s3_ctx* ctx, const float* partial, int nblk, int c, float* db, int accumulate,
+                                  bool defer) {
+  if (ctx->pend_bias.partial) {
+    int rc = s3_flush_pending_bias(ctx);
+    if (rc) return rc;
+  }
+  if (defer && !s3_opt_has(S3O_NO_SEG_REDUCE)) {
+    // (the 5 us launch rides along the weight gradient's reduction: 44 of the
+    // 56 per C2 training step)
+    ctx->pend_bias.partial = partial; ctx->pend_bias.nblk = nblk; ctx->pend_bias.c = c;
+    ctx->pend_bias.db = db; ctx->pend_bias.accumulate = accumulate;
+    return S3_OK;
+  }
   hipLaunchKernelGGL(bias_grad_stage2, dim3(c), dim3(256), 0, ctx->stream, partial, nblk, c, db, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int s3_flush_pending_bias(s3_ctx* ctx) {
+  if (!ctx->pend_bias.partial) return S3_OK;
+  const s3_ctx::PendingBias j = ctx->pend_bias;
+  ctx->pend_bias.partial = nullptr;
+  hipLaunchKernelGGL(bias_grad_stage2, dim3(j.c), dim3(256), 0, ctx->stream, j.partial, j.nblk, j.c, j.db, j.accumulate);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -1276,14 +1352,21 @@ bool conv_epilogue_bwd_d16_ok(const ConvGeom& g) {
 }
 
 // channel sums can ride along the mask pass (bias gradient): C_out / 4 | 256
+// (depth-to-space walk: any C_out / 4 <= 256, with a bf16 y and the bf16 copy)
+static int conv_epilogue_bwd_d2s4_block(const ConvGeom& g) {
+  const int c4n = g.Cout >> 2;
+  return c4n >= 1 && c4n <= 256 ? (256 / c4n) * c4n : 0;
+}
 bool conv_epilogue_bwd_bsum_ok(const ConvGeom& g) {
   const int c4n = g.Cout >> 2;
+  if (conv_epilogue_bwd_d2s4_geom(g)) return conv_epilogue_bwd_d2s4_block(g) > 0 && kBlock == 256;
   return g.d2s <= 1 && conv_epilogue_bwd_d16_ok(g) && (g.Cout & 3) == 0 && c4n >= 1 && c4n <= 64 && (256 % c4n) == 0 &&
          kBlock == 256;
 }
 int conv_epilogue_bwd_blocks(const s3_ctx* ctx, const ConvGeom& g, bool with_bsum) {
   const int64_t n4 = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout / 4;
-  const int64_t want = (n4 + kBlock - 1) / kBlock;
+  const int blk = (with_bsum && conv_epilogue_bwd_d2s4_geom(g)) ? conv_epilogue_bwd_d2s4_block(g) : kBlock;
+  const int64_t want = (n4 + blk - 1) / blk;
   const int64_t cap = with_bsum ? 16 * ctx->num_cu : 32 * ctx->num_cu;   // (bsum rows: <= 4096)
   return (int)(want < cap ? (want < 1 ? 1 : want) : cap);
 }
@@ -1291,7 +1374,8 @@ int conv_epilogue_bwd_blocks(const s3_ctx* ctx, const ConvGeom& g, bool with_bsu
 int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
                              const float* dy, float* dpre, int y_bf16, void* d16, float* bsum) {
   int64_t n = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] * g.Cout;
-  if (!dpre && !(d16 && g.d2s <= 1 && (n & 3) == 0 && (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU)))
+  if (!dpre && !(d16 && ((g.d2s <= 1 && (n & 3) == 0 && (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU)) ||
+                         (conv_epilogue_bwd_d2s4_geom(g) && y_bf16))))
     S3_FAIL(ctx, S3_EINVAL, "conv_epilogue_bwd: a bf16-only dPre needs the 4-channel mask pass");
   if (g.d2s <= 1 && (n & 3) == 0 && (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU)) {
     const float slope = g.act == S3_ACT_LEAKY ? g.alpha : 0.f;
@@ -1307,12 +1391,16 @@ int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }
-  if (bsum || (d16 && !(conv_epilogue_bwd_d2s4_geom(g) && y_bf16)))
+  if ((bsum || d16) && !(conv_epilogue_bwd_d2s4_geom(g) && y_bf16 && d16 && (!bsum || conv_epilogue_bwd_bsum_ok(g))))
     S3_FAIL(ctx, S3_EINVAL, "conv_epilogue_bwd: side outputs need the 4-channel path");
   if (conv_epilogue_bwd_d2s4_geom(g)) {
     const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
     const dim3 grid(grid_for(n / 4, ctx->num_cu));
-    if (y_bf16 && d16)
+    if (y_bf16 && d16 && bsum)
+      hipLaunchKernelGGL((conv_epilogue_bwd_d2s4_kernel<true, true>), dim3((unsigned)conv_epilogue_bwd_blocks(ctx, g, true)),
+                         dim3(conv_epilogue_bwd_d2s4_block(g)), 0, ctx->stream, (const void*)y, (const float4*)dy,
+                         (float4*)dpre, g, slope, (unsigned short*)d16, bsum);
+    else if (y_bf16 && d16)
       hipLaunchKernelGGL((conv_epilogue_bwd_d2s4_kernel<true, true>), grid, dim3(kBlock), 0, ctx->stream,
                          (const void*)y, (const float4*)dy, (float4*)dpre, g, slope, (unsigned short*)d16);
     else if (y_bf16)
@@ -1502,7 +1590,13 @@ static int loss_content_impl(s3_ctx* ctx, int kind, const float* a, int c_a,
   int rc = ensure_scratch(ctx, (size_t)(nblk + 4) * sizeof(float));
   if (rc) return rc;
   float gscale = weight / (float)total;
-  hipLaunchKernelGGL(loss_content_kernel, dim3(nblk), dim3(kBlock), 0, ctx->stream, kind, a, c_a, b, c_b, mask, c_m, c_used, n_pos, gscale, ctx->scratch, d_a, accumulate);
+  const bool dense = !mask && c_a == c_used && c_b == c_used && (total & 3) == 0 &&
+                     (((uintptr_t)a | (uintptr_t)b | (uintptr_t)d_a) & 15) == 0;
+  if (dense)
+    hipLaunchKernelGGL(loss_content4_kernel, dim3(nblk), dim3(kBlock), 0, ctx->stream, kind, (const float4*)a,
+                       (const float4*)b, total / 4, gscale, ctx->scratch, (float4*)d_a, accumulate);
+  else
+    hipLaunchKernelGGL(loss_content_kernel, dim3(nblk), dim3(kBlock), 0, ctx->stream, kind, a, c_a, b, c_b, mask, c_m, c_used, n_pos, gscale, ctx->scratch, d_a, accumulate);
   hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->scratch, nblk, 1.f / (float)total, loss_out, 0);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;

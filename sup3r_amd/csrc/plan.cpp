@@ -1945,7 +1945,7 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
                         (g.d2s <= 1 || o.io.out_bf16)) ? pl->dpre16 : nullptr;
           // the bias gradient = channel sums of dpre: they ride along this pass
           mask_sums = need_wgrad && d.b >= 0 && pl->bsum2 && conv_epilogue_bwd_bsum_ok(g) &&
-                      !s3_opt_has(S3O_NO_BIAS_FUSE);
+                      (g.d2s <= 1 || (side && o.io.out_bf16)) && !s3_opt_has(S3O_NO_BIAS_FUSE);
           // Every reader of this dPre takes the bf16 copy — transpose-read /
           // wave-specialised weight gradient, MFMA data gradient over the
           // frame, bias gradient from the channel sums riding along: the
@@ -1954,10 +1954,17 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
           const bool wg16 = o.wgrad_bf16 && !o.fewpos && !o.wgrad_tail && !o.wgrad_c2 && !o.wgrad_bf16_2d &&
                             !o.wgrad_bf16_gen && !o.wgrad_gen && o.io.in_bf16 && (g.Cout & 3) == 0;
           const bool dg16 = o.dgrad_mfma && !o.dgrad_chunked && !o.dgrad_fewch && o.use16;
-          const bool skip32 = side && g.d2s <= 1 && (n_el & 3) == 0 && pl->precision == S3_PREC_BF16 &&
-                              (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU) &&
+          // (64 -> C_out > 64 + depth-to-space: the slices of the chunked data
+          // gradient read the bf16 copy when they run on the persistent kernel)
+          const int nk16 = (g.Cout + 63) / 64;
+          const bool dgc16 = o.dgrad_chunked && o.use16 && side && (g.Cout & 7) == 0 &&
+                             conv_mfma_persist_dgrad_supported(ctx, conv_dgrad_chunk_geom(g, 0)) &&
+                             conv_mfma_persist_dgrad_geom_ok(conv_dgrad_chunk_geom(g, nk16 - 1));
+          const bool skip32 = side && pl->precision == S3_PREC_BF16 &&
+                              (g.d2s <= 1 ? ((n_el & 3) == 0 && (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU))
+                                          : o.io.out_bf16) &&
                               (!need_wgrad || (wg16 && (d.b < 0 || mask_sums))) &&
-                              (!wants_grad(d.in0) || dg16) && !s3_opt_has(S3O_NO_DPRE16_ONLY_MASK);
+                              (!wants_grad(d.in0) || dg16 || dgc16) && !s3_opt_has(S3O_NO_DPRE16_ONLY_MASK);
           rc = launch_conv_epilogue_bwd(ctx, g, tptr(pl, d.out), dy, skip32 ? nullptr : pl->dpre, o.io.out_bf16,
                                         side, mask_sums ? pl->bsum2 : nullptr);
           if (rc) return rc;
@@ -1967,12 +1974,15 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
         const int64_t npos = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
         if (need_wgrad) {
           if (d.b >= 0) {
+            // (its launch rides along the reduction of a bf16-family weight gradient)
+            const bool ride = !o.fewpos && !o.wgrad_tail && !o.wgrad_c2 &&
+                              (o.wgrad_bf16_2d || o.wgrad_bf16_gen || (!o.wgrad_gen && o.wgrad_bf16));
             if (mask_sums)
               rc = launch_bias_grad_from_partial(ctx, pl->bsum2, conv_epilogue_bwd_blocks(ctx, g, true), g.Cout,
-                                                 G + P->p[d.b].offset, accumulate_wgrad);
+                                                 G + P->p[d.b].offset, accumulate_wgrad, ride);
             else if (pl->bsum_for == ro && dpre == pl->t[ro].gptr && pl->gwritten[ro] == 1)
               rc = launch_bias_grad_from_partial(ctx, pl->bsum, pl->bsum_nblk, g.Cout, G + P->p[d.b].offset,
-                                                 accumulate_wgrad);
+                                                 accumulate_wgrad, ride);
             else if (only16)
               S3_FAIL(ctx, S3_ESTATE, "backward: bf16-only dPre without its channel sums");
             else
@@ -2007,6 +2017,8 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
             rc = launch_conv_fewpos_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
           else
             rc = launch_conv_generic_wgrad(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+          if (rc) return rc;
+          rc = s3_flush_pending_bias(ctx);     // (nothing took it along)
           if (rc) return rc;
         }
         if (wants_grad(d.in0)) {

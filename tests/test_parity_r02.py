@@ -1225,6 +1225,13 @@ def test_wide_conv_data_gradient_slices_on_the_persistent_kernel(monkeypatch, n_
     assert np.abs(dx1).max() > 0
     np.testing.assert_array_equal(dx1, dx0)
     for a, b in zip(g1, g0):
+        if a.shape == (200,):
+            # the expansion conv's bias gradient: with the bf16 copy its
+            # channel sums ride along the depth-to-space mask pass (per
+            # workgroup, then bias_grad_stage2), without it they are taken
+            # from the fp32 dPre — the same numbers in another fp32 order
+            assert rel_max(a, b) < 1e-5
+            continue
         np.testing.assert_array_equal(a, b)
 
 
