@@ -226,3 +226,23 @@ def test_inference_forward_writes_the_callers_buffer_directly():
     assert np.abs(y_own).max() > 0
     for y in (y_direct, y_copy, y_again):
         np.testing.assert_array_equal(y, y_own)
+
+
+@pytest.mark.parametrize('shape,units', [
+    ((11, 5, 5, 15, 4), (260, 512)),    # C_in 1500 (a ragged last 16-row step), ragged column tile, two batch passes
+    ((3, 4, 4, 16, 8), (1024, 256)),    # C_in 2048
+])
+def test_dense_layers_on_the_16_byte_walks_vs_oracle(shape, units):
+    """dense_fwd4_stage1 / dense_dgrad4_kernel / dense_wgrad4_kernel (a lane
+    owns four consecutive outputs, a wave four rows of W per step; taken when
+    C_in and C_out are multiples of 4 and C_out >= 256) against the oracle:
+    forward, input gradient and weight gradients of Flatten + Dense stacks
+    (sup3r/models/base.py:283-313 runs the discriminator's keras Dense
+    layers), batch > 8 (two register passes), ragged column tiles and slabs."""
+    from tests.test_parity_r02 import _fwd_bwd_vs_oracle
+    spec = [{'class': 'Flatten'}]
+    for u in units:
+        spec += [{'class': 'Dense', 'units': u}, {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec += [{'class': 'Dense', 'units': 1}]
+    _fwd_bwd_vs_oracle(spec, shape, 'f32', 31, 1e-4, 1e-3)
+    _fwd_bwd_vs_oracle(spec, shape, 'bf16', 32, 1e-3, 1e-3)
