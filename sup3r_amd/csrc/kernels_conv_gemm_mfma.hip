@@ -576,16 +576,23 @@ bool fewch_halo_perm(const ConvGeom& g, int out_bf16) {
 // permuted filter rows, bf16 out (C_out = 32 or a multiple of 64).  MODE 2:
 // lean walk, natural rows, fp32 out (C_out % 4 == 0; the 2 -> 8 data gradient of
 // the hi-res tail conv over its padded frame).  NFP: N fragments of the lean walks.
-template <int CIN, int MODE, int NFP = 4>
+// X3 (MODE 2 only: BF16X3 plans, fp32 in / out): the halo holds a second image
+// of the rounding residues lo = bf16(v - bf16(v)), the filter its lo fragments
+// (wpk + lo_off), and every product is hi * hi + hi * lo + lo * hi on the matrix
+// cores — the first discriminator layer of a BF16X3 training step left the
+// gather walk of gconv_fewch_kernel<.., true> (1.18 ms at C2 batch 8).
+template <int CIN, int MODE, int NFP = 4, bool X3 = false>
 __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wpk,
     const float* __restrict__ bias, void* __restrict__ yv, ConvGeom g, int tiles0, int tiles1,
-    int tiles2, int out_bf16, unsigned char* __restrict__ sign) {
+    int tiles2, int out_bf16, unsigned char* __restrict__ sign, int lo_off = 0) {
+  static_assert(!X3 || MODE == 2, "split-bf16: the lean fp32-out walk");
   constexpr int TPL = 8 / CIN;                 // taps per lane per chunk
   constexpr int KC = (27 * CIN + 31) / 32;     // chunks of 32
   constexpr int KP = KC * 32;
   constexpr int CELLB = 2 * CIN;               // bytes per halo cell (bf16)
-  __shared__ __attribute__((aligned(16))) char halo[(FHP + 1) * CELLB];   // + one zero cell
+  constexpr int LO_IMG = (FHP + 1) * CELLB;    // byte offset of the lo image (X3)
+  __shared__ __attribute__((aligned(16))) char halo[(FHP + 1) * CELLB * (X3 ? 2 : 1)];   // + one zero cell
   float* __restrict__ y = reinterpret_cast<float*>(yv);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p16 = lane & 15, kq = lane >> 4;
@@ -619,14 +626,23 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
     }
     const bool ok = hp < FHP && i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && i2 >= 0 && i2 < D2;
     const float* src = x + ((((int64_t)n * D0 + i0) * D1 + i1) * D2 + i2) * CIN;
+    auto lo_f = [](unsigned u) { return __uint_as_float(u << 16); };
+    auto hi_f = [](unsigned u) { return __uint_as_float(u & 0xFFFF0000u); };
     if (CIN == 2) {
       float2 t = make_float2(0.f, 0.f);
       if (ok) t = *reinterpret_cast<const float2*>(src);
-      *reinterpret_cast<unsigned*>(halo + hp * CELLB) = pk2(t.x, t.y);
+      const unsigned h = pk2(t.x, t.y);
+      *reinterpret_cast<unsigned*>(halo + hp * CELLB) = h;
+      if constexpr (X3)
+        *reinterpret_cast<unsigned*>(halo + LO_IMG + hp * CELLB) = pk2(t.x - lo_f(h), t.y - hi_f(h));
     } else {
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) t = *reinterpret_cast<const float4*>(src);
-      *reinterpret_cast<uint2*>(halo + hp * CELLB) = make_uint2(pk2(t.x, t.y), pk2(t.z, t.w));
+      const unsigned h0 = pk2(t.x, t.y), h1 = pk2(t.z, t.w);
+      *reinterpret_cast<uint2*>(halo + hp * CELLB) = make_uint2(h0, h1);
+      if constexpr (X3)
+        *reinterpret_cast<uint2*>(halo + LO_IMG + hp * CELLB) =
+            make_uint2(pk2(t.x - lo_f(h0), t.y - hi_f(h0)), pk2(t.z - lo_f(h1), t.w - hi_f(h1)));
     }
   }
   // this lane's taps: chunk kc, slot q -> tap = (kc*32 + kq*8) / CIN + q; byte offset
@@ -641,7 +657,7 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
       toff[kc][q] = tap < 27 ? ((ta * FG1 + tb) * FG2 + tc) * CELLB : -1;
     }
   constexpr int NFA = LEAN ? NFP : 4;
-  bf16x8 wf[KC][NFA];
+  bf16x8 wf[KC][NFA], wl[X3 ? KC : 1][X3 ? NFA : 1];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
@@ -650,6 +666,9 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
         const int row = perm ? (nf >> 1) * 32 + (p16 >> 2) * 8 + (nf & 1) * 4 + (p16 & 3) : nf * 16 + p16;
         wf[kc][nf] = *reinterpret_cast<const bf16x8*>(
             wpk + ((int64_t)ct * GT_N + row) * KP + kc * 32 + kq * 8);
+        if constexpr (X3)
+          wl[kc][nf] = *reinterpret_cast<const bf16x8*>(
+              wpk + lo_off + ((int64_t)ct * GT_N + row) * KP + kc * 32 + kq * 8);
       }
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
   float bv[NFA][4];
@@ -709,6 +728,24 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
             }
           }
           const bf16x8 xf = __builtin_bit_cast(bf16x8, make_uint4(u[0], u[1], u[2], u[3]));
+          if constexpr (X3) {
+            unsigned ul[4];
+#pragma unroll
+            for (int q = 0; q < TPL; ++q) {
+              if (CIN == 2) {
+                ul[q] = *reinterpret_cast<const unsigned*>(halo + LO_IMG + la[kc][q] + foff);
+              } else {
+                const uint2 t = *reinterpret_cast<const uint2*>(halo + LO_IMG + la[kc][q] + foff);
+                ul[2 * q] = t.x; ul[2 * q + 1] = t.y;
+              }
+            }
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, make_uint4(ul[0], ul[1], ul[2], ul[3]));
+#pragma unroll
+            for (int nf = 0; nf < NFP; ++nf) {
+              acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[kc][nf], xf, acc[nf], 0, 0, 0);
+              acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kc][nf], xl, acc[nf], 0, 0, 0);
+            }
+          }
 #pragma unroll
           for (int nf = 0; nf < NFP; ++nf)
             acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kc][nf], xf, acc[nf], 0, 0, 0);
@@ -965,6 +1002,23 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
   if (in_bf16 && (g.Cin % 8 != 0 || fewch_geom(g))) S3_FAIL(ctx, S3_EINVAL, "gconv: bf16 input needs C_in % 8 == 0");
   if (x3 && (out_bf16 || in_bf16)) S3_FAIL(ctx, S3_EINVAL, "gconv: the split-bf16 variant takes and writes fp32");
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  if (fewch_geom(g) && x3 && !res && !out_bf16 && (g.Cout & 3) == 0 && g.Cout <= GT_N &&
+      fewch_halo_ok(ctx, g, res, 0) && !s3_opt_has(S3O_NO_GCONV_X3)) {
+    // the LDS-halo lean walk with split operands (natural rows, fp32 out)
+    const int t0 = (g.O[0] + FH0 - 1) / FH0, t1 = (g.O[1] + FH1 - 1) / FH1, t2 = (g.O[2] + FH2 - 1) / FH2;
+    dim3 hgrid((unsigned)(g.N * t0 * t1 * t2), 1);
+    const int nf = (g.Cout + 15) / 16;      // (3 fragments run as 4: rows past C_out are zero)
+    auto kern = g.Cin == 2 ? (nf == 1 ? gconv_fewch_halo_kernel<2, 2, 1, true>
+                                      : (nf == 2 ? gconv_fewch_halo_kernel<2, 2, 2, true>
+                                                 : gconv_fewch_halo_kernel<2, 2, 4, true>))
+                           : (nf == 1 ? gconv_fewch_halo_kernel<4, 2, 1, true>
+                                      : (nf == 2 ? gconv_fewch_halo_kernel<4, 2, 2, true>
+                                                 : gconv_fewch_halo_kernel<4, 2, 4, true>));
+    hipLaunchKernelGGL(kern, hgrid, dim3(FHW * 64), 0, ctx->stream, x, (const unsigned short*)packed, bias, y, g,
+                       t0, t1, t2, 0, (unsigned char*)nullptr, x3_fewch_lo_offset(g));
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   if (fewch_geom(g) && x3) {
     dim3 fgrid((unsigned)((P + FC_POS - 1) / FC_POS), (unsigned)((g.Cout + GT_N - 1) / GT_N));
     if (g.Cin == 2)
@@ -995,7 +1049,7 @@ int launch_gconv_fwd(s3_ctx* ctx, const ConvGeom& g, const float* x, const void*
       else if (!pm && nf32 >= 3) kern = g.Cin == 2 ? gconv_fewch_halo_kernel<2, 2, 4> : gconv_fewch_halo_kernel<4, 2, 4>;
       // sign bytes next to y: the permuted lean walk with C_out = 32 only
       unsigned char* sb = (pm && two && g.Cout == 32) ? (unsigned char*)sign_bytes : nullptr;
-      hipLaunchKernelGGL(kern, hgrid, dim3(FHW * 64), 0, ctx->stream, x, img, bias, y, g, t0, t1, t2, out_bf16, sb);
+      hipLaunchKernelGGL(kern, hgrid, dim3(FHW * 64), 0, ctx->stream, x, img, bias, y, g, t0, t1, t2, out_bf16, sb, 0);
       S3_HIP(ctx, hipGetLastError());
       return S3_OK;
     }

@@ -269,9 +269,14 @@ __global__ __launch_bounds__(NW * 64) void conv3_mfma_kernel(
               va[u] = *reinterpret_cast<const uint4*>(
                   reinterpret_cast<const unsigned short*>(xv) + pos * CIN + ch * 8);
             } else if (X3) {
-              const float* src = reinterpret_cast<const float*>(xv) + pos * CIN + pass * 32 + ch * 8;
-              va[u] = *reinterpret_cast<const uint4*>(src);
-              vb[u] = *reinterpret_cast<const uint4*>(src + 4);
+              // (channel slice of a wider tensor — the chunked data gradient of
+              // the 64 -> 200 conv: chunks past in_cvalid stay zero)
+              const int cstr = g.in_cstride ? g.in_cstride : CIN;
+              if (!g.in_cstride || pass * 32 + ch * 8 < g.in_cvalid) {
+                const float* src = reinterpret_cast<const float*>(xv) + pos * cstr + pass * 32 + ch * 8;
+                va[u] = *reinterpret_cast<const uint4*>(src);
+                vb[u] = *reinterpret_cast<const uint4*>(src + 4);
+              }
             } else if (BF) {
               // (channel slice of a wider tensor: chunks past in_cvalid stay zero)
               const int cstr = g.in_cstride ? g.in_cstride : CIN;
@@ -708,7 +713,10 @@ ConvGeom conv_dgrad_chunk_geom(const ConvGeom& g, int k) {
 }
 
 bool conv_dgrad_chunked_supported(const ConvGeom& g, int precision) {
-  if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_DGRAD_CHUNKED)) return false;
+  // (BF16X3 plans since round 4: the split-bf16 tile kernel over fp32 slices)
+  if ((precision != S3_PREC_BF16 && (precision != S3_PREC_BF16X3 || s3_opt_has(S3O_NO_DGRAD_X3))) ||
+      s3_opt_has(S3O_NO_DGRAD_CHUNKED))
+    return false;
   if (g.Cin != 64 || g.Cout <= 64 || g.Cout % 8 != 0 || g.Cout > 512) return false;
   bool same = true, valid = g.pad_mode != S3_PAD_REFLECT && g.d2s == 1;
   for (int q = 0; q < 3; ++q) {

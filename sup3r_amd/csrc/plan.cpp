@@ -788,7 +788,11 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
             max_partial = std::max(max_partial, conv_fewpos_wgrad_partial_bytes(g));
           }
           o.dgrad_mfma = conv_dgrad_mfma_supported(g, precision);
-          if (!o.dgrad_mfma && !o.fewpos && precision == S3_PREC_BF16 &&
+          // (BF16X3: the split-bf16 tile kernel takes the same geometry — the
+          // discriminator's valid 32 -> 64 conv left the gather-MFMA adjoint,
+          // 2.25 -> 0.5 ms at C2 batch 8)
+          if (!o.dgrad_mfma && !o.fewpos &&
+              (precision == S3_PREC_BF16 || (precision == S3_PREC_BF16X3 && !s3_opt_has(S3O_NO_DGRAD_X3))) &&
               conv_dgrad_mfma_valid_supported(g, precision)) {
             o.dgrad_mfma = o.dgrad_valid = true;
           }
