@@ -773,7 +773,11 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const float a = acc[(2 * h + (q >> 2)) % NFP][q & 3];
-            o[q] = fmaxf(a, slope * a);              // slope in [0, 1]: identity / ReLU / LeakyReLU
+            // slope in [0, 1]: identity / ReLU / LeakyReLU.  (v_max_f32 by hand:
+            // fmaxf() first canonicalises an accumulator it cannot prove quiet —
+            // a second v_max per value in a loop that is 73 % VALU-busy)
+            const float sa = slope * a;
+            asm("v_max_f32 %0, %1, %2" : "=v"(o[q]) : "v"(a), "v"(sa));
           }
           const uint4 w4 = make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7]));
           *reinterpret_cast<uint4*>(yrow + off + h * 32) = w4;
@@ -781,12 +785,13 @@ __global__ __launch_bounds__(FHW * 64) void gconv_fewch_halo_kernel(
             // (C_out = 32, one cout tile) bit q of byte [position][kq]: channel
             // 8 kq + q of the STORED bf16 value is > 0 — the activation mask
             // conv_dgrad_s2_kernel<.., MB> applies, at 4 B per position
-            auto two = [](unsigned u) {
-              const unsigned lo = u & 0xFFFFu, hi = u >> 16;
-              return ((lo & 0x8000u) == 0 && (lo & 0x7FFFu) != 0 ? 1u : 0u) |
-                     ((hi & 0x8000u) == 0 && (hi & 0x7FFFu) != 0 ? 2u : 0u);
-            };
-            const unsigned bits = two(w4.x) | (two(w4.y) << 2) | (two(w4.z) << 4) | (two(w4.w) << 6);
+            // (taken from the fp32 value: it and its bf16 rounding have the same
+            // sign and are zero together down to the smallest bf16 denormal;
+            // one compare + one shift-or per channel instead of the 45
+            // instructions the test on the packed halves compiled to)
+            unsigned bits = 0u;
+#pragma unroll
+            for (int q = 7; q >= 0; --q) bits = (bits << 1) | (o[q] > 0.f ? 1u : 0u);
             sign[(row_el + off) / 8] = (unsigned char)bits;    // element (pos * 32 + 8 kq) / 8 = pos * 4 + kq
           }
         }
