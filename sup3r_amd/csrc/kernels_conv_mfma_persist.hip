@@ -679,7 +679,10 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
           // ReLU (0) or LeakyReLU (0 <= alpha <= 1); a per-element test of
           // the kind compiles to two scalar branches per value
           const float a = acc[m][(2 * h + (q >> 2)) % NFV][q & 3];
-          v[q] = fmaxf(a, slope * a);
+          // (v_max_f32 by hand: fmaxf() canonicalises the accumulator first —
+          // a second v_max per value)
+          const float sa = slope * a;
+          asm("v_max_f32 %0, %1, %2" : "=v"(v[q]) : "v"(a), "v"(sa));
         }
         if (res) {
           const uint4 r = rres[m][h];

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
   const bool xwin = DY16 && CIN == 2 && !(g.pad_mode == S3_PAD_REFLECT) && g.s[0] == 1 && g.s[1] == 1 &&
                     g.s[2] == 1 && g.lo[0] >= 0 && g.lo[0] <= 1 && g.lo[1] >= 0 && g.lo[1] <= 1 &&
                     g.lo[2] >= 0 && g.lo[2] <= 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (wave index on the scalar unit: the k-step -> (sample, row, chunk) chains of
+  // 64-bit divisions then run there, not on a VALU that PMC showed 71 % busy)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, kg = lane >> 4;
   const int S1 = g.D[1], S2 = g.D[2];
   const int O0 = g.O[0], O1 = g.O[1], O2 = g.O[2], Cout = g.Cout;
