@@ -111,12 +111,41 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
       const int r = lane >> 1, hf = lane & 1;
       uint4 q0, q1;
       float2 c5[5];
-      auto fetch = [&](int64_t st) __attribute__((always_inline)) {
-        int64_t row = st / chunks;
-        const int tch = (int)(st % chunks) * 32;
-        const int o1 = (int)(row % O1); row /= O1;
-        const int o0 = (int)(row % O0); row /= O0;
-        const int n = (int)row;
+      // (sample, s1 row, s2 row, t chunk) of the step being fetched, advanced by
+      // the grid stride with carries: the 64-bit divisions of step -> (n, o0,
+      // o1, chunk) were ~450 scalar instructions per k-step and wave next to
+      // its 8 MFMAs
+      int f_n, f_o0, f_o1, f_ch;
+      {
+        const int64_t st0 = st_lo + (int64_t)xk * C2_WAVES + wave;
+        int64_t row = st0 / chunks;
+        f_ch = (int)(st0 % chunks);
+        f_o1 = (int)(row % O1); row /= O1;
+        f_o0 = (int)(row % O0); row /= O0;
+        f_n = (int)row;
+      }
+      int d_n, d_o0, d_o1, d_ch;
+      {
+        int64_t row = n_waves / chunks;
+        d_ch = (int)(n_waves % chunks);
+        d_o1 = (int)(row % O1); row /= O1;
+        d_o0 = (int)(row % O0); row /= O0;
+        d_n = (int)row;
+      }
+      auto advance = [&]() __attribute__((always_inline)) {
+        f_ch += d_ch;
+        int c = f_ch >= chunks ? 1 : 0;
+        f_ch -= c * chunks;
+        f_o1 += d_o1 + c;
+        c = f_o1 >= O1 ? 1 : 0;
+        f_o1 -= c * O1;
+        f_o0 += d_o0 + c;
+        c = f_o0 >= O0 ? 1 : 0;
+        f_o0 -= c * O0;
+        f_n += d_n + c;
+      };
+      auto fetch = [&]() __attribute__((always_inline)) {
+        const int tch = f_ch * 32, o1 = f_o1, o0 = f_o0, n = f_n;
         const int tr = tch + r;
         q0 = make_uint4(0u, 0u, 0u, 0u); q1 = q0;
         if (tr < O2) {
@@ -138,7 +167,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
         }
       };
       int64_t step = st_lo + (int64_t)xk * C2_WAVES + wave;
-      if (step < n_steps) fetch(step);
+      if (step < n_steps) fetch();
       for (; step < n_steps; step += n_waves) {
         char* d = dst + wave * 2048 + r * 64 + ((hf ^ ((r >> 3) & 1)) << 5);
         float2* xb = xw + wave * XW_CELLS;
@@ -156,7 +185,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // the next step's loads fly under this step's LDS reads and MFMAs
-        if (step + n_waves < n_steps) fetch(step + n_waves);
+        if (step + n_waves < n_steps) { advance(); fetch(); }
         bf16x8 bfr[NB];
         const char* wb = dst + wave * 2048;
 #pragma unroll
@@ -189,12 +218,37 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
       goto reduce;
     }
   }
+  // (the step's (sample, rows, chunk) advanced with carries, as in the
+  // pipelined loop above: no 64-bit division per k-step)
+  int g_n, g_o0, g_o1, g_ch, e_n, e_o0, e_o1, e_ch;
+  {
+    const int64_t st0 = st_lo + (int64_t)xk * C2_WAVES + wave;
+    int64_t row = st0 / chunks;
+    g_ch = (int)(st0 % chunks);
+    g_o1 = (int)(row % O1); row /= O1;
+    g_o0 = (int)(row % O0); row /= O0;
+    g_n = (int)row;
+    row = n_waves / chunks;
+    e_ch = (int)(n_waves % chunks);
+    e_o1 = (int)(row % O1); row /= O1;
+    e_o0 = (int)(row % O0); row /= O0;
+    e_n = (int)row;
+  }
   for (int64_t step = st_lo + (int64_t)xk * C2_WAVES + wave; step < n_steps; step += n_waves) {
-    int64_t row = step / chunks;
-    const int t0 = (int)(step % chunks) * 32 + kg * 8;
-    const int o1 = (int)(row % O1); row /= O1;
-    const int o0 = (int)(row % O0); row /= O0;
-    const int n = (int)row;
+    const int s_ch = g_ch, o1 = g_o1, o0 = g_o0, n = g_n;
+    {
+      g_ch += e_ch;
+      int c = g_ch >= chunks ? 1 : 0;
+      g_ch -= c * chunks;
+      g_o1 += e_o1 + c;
+      c = g_o1 >= O1 ? 1 : 0;
+      g_o1 -= c * O1;
+      g_o0 += e_o0 + c;
+      c = g_o0 >= O0 ? 1 : 0;
+      g_o0 -= c * O0;
+      g_n += e_n + c;
+    }
+    const int t0 = s_ch * 32 + kg * 8;
     // clamp the lane's first t so that the 8 loads stay inside the row; the
     // shifted-out positions are masked through dPre
     // (DY16: no shift — the staged dPre rows carry the t >= O2 mask, the x
@@ -223,7 +277,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
         if (nb == 0) {
           // stage rows t = 32 chunk + r, r = lane >> 1; this lane's 32-B half
           const int r = lane >> 1, hf = lane & 1;
-          const int tr = (int)(step % chunks) * 32 + r;
+          const int tr = s_ch * 32 + r;
           uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0;
           if (tr < O2) {
             const uint4* src = reinterpret_cast<const uint4*>(
@@ -267,7 +321,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void conv_wgrad_c2_kernel(
     }
     if constexpr (DY16 && CIN == 2) {
       if (xwin) {
-        const int tch = (int)(step % chunks) * 32;
+        const int tch = s_ch * 32;
         float2* xb = xw + wave * XW_CELLS;
         float2 c5[5];
 #pragma unroll
