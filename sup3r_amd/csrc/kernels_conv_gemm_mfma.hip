@@ -149,10 +149,20 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gconv_mfma_kernel(
     pok[m] = p < Pc;
     if (!pok[m]) p = Pc - 1;
     plin[m] = p;
-    c2[m] = (int)(p % E2); p /= E2;
-    c1[m] = (int)(p % E1); p /= E1;
-    c0[m] = (int)(p % E0); p /= E0;
-    pn[m] = (int)p;
+    if (Pc <= 0x7fffffffLL) {
+      // (32-bit: three 64-bit divisions per fragment and lane were as many
+      // VALU instructions as the 27 taps' gathers)
+      unsigned r = (unsigned)p, q;
+      q = r / (unsigned)E2; c2[m] = (int)(r - q * (unsigned)E2); r = q;
+      q = r / (unsigned)E1; c1[m] = (int)(r - q * (unsigned)E1); r = q;
+      q = r / (unsigned)E0; c0[m] = (int)(r - q * (unsigned)E0);
+      pn[m] = (int)q;
+    } else {
+      c2[m] = (int)(p % E2); p /= E2;
+      c1[m] = (int)(p % E1); p /= E1;
+      c0[m] = (int)(p % E0); p /= E0;
+      pn[m] = (int)p;
+    }
     if (strided) {
       c0[m] = c0[m] * g.s[0] + r0; c1[m] = c1[m] * g.s[1] + r1; c2[m] = c2[m] * g.s[2] + r2;
       plin[m] = (((int64_t)pn[m] * G0 + c0[m]) * G1 + c1[m]) * G2 + c2[m];
