@@ -17,6 +17,8 @@ GB = 1e9
 # kernel -> (what, algorithmic read bytes, algorithmic write bytes)
 ALG = {
     'gconv_fewch_halo_kernel<2, 1, 2>': ('disc 2->32 forward', P0 * 8, P1 * 64),
+    # (round 4: the kernel gained its split-bf16 template flag)
+    'gconv_fewch_halo_kernel<2, 1, 2, false>': ('disc 2->32 forward', P0 * 8, P1 * 64),
     'conv_halo_s2_kernel<2>': ('disc 32->32 s2 forward', P1 * 64, P2 * 64),
     'conv_dgrad_s2_kernel<2, true, true>': ('disc 32->32 s2 data gradient (fp32 dPre + sign bytes in, bf16 out)',
                                             P2 * 128 + P1 * 4, P1 * 64),
