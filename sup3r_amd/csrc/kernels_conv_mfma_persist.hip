@@ -842,7 +842,13 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false, R, true>),  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));                     \
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false, R, false>), \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));                     \
+    S3_HIP(ctx, hipFuncSetAttribute(                                                                              \
+                    reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false, R, true, false, 6>),        \
+                    hipFuncAttributeMaxDynamicSharedMemorySize, PGeo<6>::LDS_BYTES));                             \
+    S3_HIP(ctx, hipFuncSetAttribute(                                                                              \
+                    reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false, R, false, false, 6>),       \
+                    hipFuncAttributeMaxDynamicSharedMemorySize, PGeo<6>::LDS_BYTES));
     S3_REP_ATTR(2) S3_REP_ATTR(3) S3_REP_ATTR(4)
 #undef S3_REP_ATTR
     S3_HIP(ctx, hipFuncSetAttribute(
@@ -880,8 +886,10 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
   // trunk convs only, and only when that strip still fills the chip.
   const int rem1 = g.O[1] % TS1;
   const int64_t strip_halves = (int64_t)g.N * tiles0 * tiles2;
-  if (!rep && rem1 >= 1 && rem1 <= 6 && g.O[1] > TS1 && strip_halves >= 2 * (int64_t)ctx->num_cu &&
-      !s3_opt_on(S3O_NO_PERSIST_STRIP)) {
+  // (the fused-repeat variants too since the end of round 4: the three convs
+  // behind the temporal repeats of a C3 chunk computed 24 columns for 22)
+  if (rem1 >= 1 && rem1 <= 6 && g.O[1] > TS1 && strip_halves >= 2 * (int64_t)ctx->num_cu &&
+      (!rep || n_ct == 1) && !s3_opt_on(S3O_NO_PERSIST_STRIP)) {
     const int t1a = g.O[1] / TS1;
     const int na = g.N * tiles0 * t1a * tiles2, nb = (int)strip_halves;
     int ga = ctx->num_cu, gb = ctx->num_cu;
@@ -893,6 +901,19 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
       auto k8 = half ? conv3_mfma_persist_kernel<2, false> : conv3_mfma_persist_kernel<4, false>;
       auto k6 = half ? conv3_mfma_persist_kernel<2, false, 0, false, false, 6>
                      : conv3_mfma_persist_kernel<4, false, 0, false, false, 6>;
+      if (rep == 2) {
+        k8 = rin ? conv3_mfma_persist_kernel<4, false, 2, true> : conv3_mfma_persist_kernel<4, false, 2, false>;
+        k6 = rin ? conv3_mfma_persist_kernel<4, false, 2, true, false, 6>
+                 : conv3_mfma_persist_kernel<4, false, 2, false, false, 6>;
+      } else if (rep == 3) {
+        k8 = rin ? conv3_mfma_persist_kernel<4, false, 3, true> : conv3_mfma_persist_kernel<4, false, 3, false>;
+        k6 = rin ? conv3_mfma_persist_kernel<4, false, 3, true, false, 6>
+                 : conv3_mfma_persist_kernel<4, false, 3, false, false, 6>;
+      } else if (rep == 4) {
+        k8 = rin ? conv3_mfma_persist_kernel<4, false, 4, true> : conv3_mfma_persist_kernel<4, false, 4, false>;
+        k6 = rin ? conv3_mfma_persist_kernel<4, false, 4, true, false, 6>
+                 : conv3_mfma_persist_kernel<4, false, 4, false, false, 6>;
+      }
       hipLaunchKernelGGL(k8, dim3(ga), dim3(NTHR), LDS_BYTES, ctx->stream, (const unsigned short*)x, img, bias,
                          (const unsigned short*)res, (unsigned short*)y, gk, tiles0, t1a, tiles2, na, ct, 1, 0);
       hipLaunchKernelGGL(k6, dim3(gb), dim3(NTHR), PGeo<6>::LDS_BYTES, ctx->stream, (const unsigned short*)x,
