@@ -26,7 +26,7 @@ for f in glob.glob(out + '/pass*/**/*counter_collection.csv', recursive=True):
         agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
 with open(out + '/pmc_summary.txt', 'w') as fo:
     for k, d in sorted(agg.items()):
-        if not any(s in k for s in ('wgrad_bf16', 'dgrad_c2', 'dgrad_s2', 'wgrad_c2', 'wgrad_tail', 'fewch', 'conv3_mfma', 'gconv', 'halo32', 'halo_s2', 'conv_tail', 'gather_bwd', 'epilogue_bwd')):
+        if not any(s in k for s in ('wgrad_bf16', 'dgrad_c2', 'dgrad_s2', 'wgrad_c2', 'wgrad_tail', 'fewch', 'conv3_mfma', 'gconv', 'halo32', 'halo_s2', 'conv_tail', 'gather_bwd', 'epilogue_bwd', 'fold16', 'dense_', 'loss_content', 'partial_reduce', 'adam')):
             continue
         fo.write(k + '\n')
         for c, v in sorted(d.items()):
