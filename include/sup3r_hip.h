@@ -282,7 +282,11 @@ enum {
   S3_OPINFO_RES_REP = 10,      /* ... and its residual operand                  */
   S3_OPINFO_DGRAD_FRAME16 = 11, /* the padded-frame data gradient is stored as
                                   bf16 between the conv kernel and its fold    */
-  S3_OPINFO_COUNT = 12
+  S3_OPINFO_FEWPOS_MFMA = 12,  /* the few-positions launches of this conv are the
+                                  one-launch fp32-MFMA kernels (forward, data
+                                  gradient from the untransposed filter, weight
+                                  + bias gradient)                              */
+  S3_OPINFO_COUNT = 13
 };
 enum {
   S3_FWD_DIRECT = 0, S3_FWD_MFMA_TILE = 1, S3_FWD_MFMA_PERSIST = 2, S3_FWD_GCONV = 3,

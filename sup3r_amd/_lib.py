@@ -250,7 +250,7 @@ def plan_options(options):
 # s3_plan_op_info fields / codes (include/sup3r_hip.h)
 OPINFO_FIELDS = ('kind', 'fwd', 'in16', 'out16', 'res16', 'fwd_bf16_ops',
                  'wgrad', 'dgrad', 'mask_fused_from', 'in_rep', 'res_rep',
-                 'dgrad_frame16')
+                 'dgrad_frame16', 'fewpos_mfma')
 FWD_KERNELS = ('direct', 'mfma_tile', 'mfma_persist', 'gconv', 'gconv_fewch',
                'halo32', 'fewpos', 'tail_mfma', 'small', 'fused2d', 'halo_s2')
 WGRAD_KERNELS = ('direct', 'f32_trunk', 'bf16_trunk', 'f32_gen', 'bf16_gen',

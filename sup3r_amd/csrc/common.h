@@ -50,6 +50,7 @@
   X(NO_FEWCH) \
   X(NO_FEWCH_HALO) \
   X(NO_FEWPOS) \
+  X(NO_FEWPOS_MFMA) \
   X(NO_FOLD16) \
   X(NO_FRAME16) \
   X(NO_FUSED2D) \
@@ -415,6 +416,13 @@ int launch_conv_fewpos_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,
                              int accumulate);
 int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
                                  float* wt);
+// ... the same three on the fp32 matrix instruction, one launch each, no
+// partial buffers and no filter transpose (kernels_conv_fewpos_mfma.hip)
+bool conv_fewpos_mfma_ok(const ConvGeom& g);
+int launch_conv_fewpos_mfma(s3_ctx* ctx, const ConvGeom& g, int mode, const float* src,
+                            const float* w, const float* bias, const float* res, float* y);
+int launch_conv_fewpos_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                                  float* dw, float* db, int accumulate);
 
 int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
                   int esize);

@@ -1,0 +1,312 @@
+// Few-positions convolutions on the fp32 matrix instruction: ONE launch per
+// forward conv / data gradient / weight gradient of the tiny-sample training
+// configs (C1: 64 -> 64 3x3 convs over 15 x 5 x 5 = 375 positions).
+//
+// A mini-batch of that size is a chain of dependent launches, each of which
+// costs >= 4.6 us on this part whatever it does, so the
+// split-K weight-streaming GEMM of kernels_conv_fewpos.hip (GEMM + epilogue,
+// weight gradient + reduce, a filter transpose in front of every data
+// gradient: 2 + 2 + 1 launches) pays mostly for its launch count.  Here:
+//
+//   * fewpos_mfma_kernel<MODE>: a workgroup owns 16 positions x 64 output
+//     channels; its four waves split the K = taps x C reduction in 16-channel
+//     chunks (v_mfma_f32_16x16x4_f32: exact fp32 products and sums), sum their
+//     partials through LDS in fixed order and apply bias / activation /
+//     residual / depth-to-space on the way out.  A operands are 16-B reads of
+//     the gathered source cell, B operands 16-B reads of the filter: a lane
+//     owns four consecutive output channels (MODE 0) — or, for the data
+//     gradient (MODE 1), reads the UNtransposed [tap][ci][co] filter along co,
+//     which is the K axis there: no transpose_taps launch.
+//   * fewpos_wgrad_mfma_kernel: a workgroup owns (tap, 64 ci, 16 co); its four
+//     waves interleave over the positions (M = ci, N = co, K = positions),
+//     LDS sum in fixed order, result (+)= straight into dW: no partial buffer,
+//     no reduce launch.  The workgroups of tap 0 / ci tile 0 also leave the
+//     bias gradient (column sums of dPre).
+//
+// Every output element is a fixed-order sum that does not depend on the batch
+// size or on which other positions share its workgroup.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MAX_TAPS = 27;
+
+__device__ inline float actf(float v, int act, float alpha) {
+  if (act == S3_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == S3_ACT_LEAKY) return v > 0.f ? v : alpha * v;
+  return v;
+}
+
+// source cell of row `row` under tap `tap` (-1: padding / no contribution)
+// MODE 0: row = output position, source = input cell
+// MODE 1: row = input position,  source = output cell that feeds it through the tap
+template <int MODE>
+__device__ inline int src_cell(const ConvGeom& g, unsigned row, int tap) {
+  const int kk[3] = {tap / (g.k[1] * g.k[2]), (tap / g.k[2]) % g.k[1], tap % g.k[2]};
+  int p[3], q[3];
+  unsigned r = row;
+  if (MODE == 0) {
+    p[2] = (int)(r % (unsigned)g.O[2]); r /= (unsigned)g.O[2];
+    p[1] = (int)(r % (unsigned)g.O[1]); r /= (unsigned)g.O[1];
+    p[0] = (int)(r % (unsigned)g.O[0]); r /= (unsigned)g.O[0];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      int i = p[d] * g.s[d] + kk[d] - g.lo[d];
+      if (g.pad_mode == S3_PAD_REFLECT) i = s3_reflect(i, g.D[d]);
+      if (i < 0 || i >= g.D[d]) return -1;
+      q[d] = i;
+    }
+    return (((int)r * g.D[0] + q[0]) * g.D[1] + q[1]) * g.D[2] + q[2];
+  }
+  p[2] = (int)(r % (unsigned)g.D[2]); r /= (unsigned)g.D[2];
+  p[1] = (int)(r % (unsigned)g.D[1]); r /= (unsigned)g.D[1];
+  p[0] = (int)(r % (unsigned)g.D[0]); r /= (unsigned)g.D[0];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int t = p[d] + g.lo[d] - kk[d];
+    if (t < 0 || t % g.s[d] != 0) return -1;
+    t /= g.s[d];
+    if (t >= g.O[d]) return -1;
+    q[d] = t;
+  }
+  return (((int)r * g.O[0] + q[0]) * g.O[1] + q[1]) * g.O[2] + q[2];
+}
+
+// y[row][n] = sum_tap sum_k src[cell(row, tap)][k] * B_tap[k][n]
+//   MODE 0: B_tap[k][n] = w[tap][k][n]   (K = C_in,  Nc = C_out), epilogue applied
+//   MODE 1: B_tap[k][n] = w[tap][n][k]   (K = C_out, Nc = C_in),  plain store
+template <int MODE>
+__global__ __launch_bounds__(256) void fewpos_mfma_kernel(
+    const float* __restrict__ src, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ res,
+    float* __restrict__ y, ConvGeom g, int rows, int K, int Nc) {
+  __shared__ int sidx[MAX_TAPS * 16];
+  __shared__ float red[4][16][64];
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int row0 = blockIdx.x * 16, n0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < taps * 16; i += 256) {
+    const int row = row0 + (i & 15);
+    sidx[i] = row < rows ? src_cell<MODE>(g, (unsigned)row, i >> 4) : -1;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int kch = K >> 4, nchunks = taps * kch;
+  f32x4 acc[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nl = n0 + c * 4;              // this lane's four output channels
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto load = [&](int ch, f32x4& a, f32x4 (&b)[4]) {
+    const int tap = ch / kch, kb = ch - tap * kch;
+    const int s = sidx[tap * 16 + c];
+    const int k0 = kb * 16 + q * 4;
+    a = s >= 0 ? *reinterpret_cast<const f32x4*>(src + (int64_t)s * K + k0) : zero4;
+    if (MODE == 0) {
+      // b[j][nf] = w[tap][k0 + j][nl + nf]
+      const float* wp = w + ((int64_t)tap * K + k0) * Nc + nl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        b[j] = nl < Nc ? *reinterpret_cast<const f32x4*>(wp + (int64_t)j * Nc) : zero4;
+    } else {
+      // b[nf][j] = w[tap][nl + nf][k0 + j]
+      const float* wp = w + ((int64_t)tap * Nc + nl) * K + k0;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        b[nf] = nl + nf < Nc ? *reinterpret_cast<const f32x4*>(wp + (int64_t)nf * K) : zero4;
+    }
+  };
+  auto fma16 = [&](const f32x4& a, const f32x4 (&b)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], MODE == 0 ? b[j][nf] : b[nf][j], acc[nf], 0, 0, 0);
+  };
+
+  // chunks wave, wave + 4, ...: the next chunk's operands are in flight under
+  // the sixteen MFMAs of the current one
+  int ch = wave;
+  f32x4 a0, b0[4], a1, b1[4];
+  if (ch < nchunks) load(ch, a0, b0);
+  while (ch < nchunks) {
+    const int nx = ch + 4;
+    if (nx < nchunks) load(nx, a1, b1);
+    fma16(a0, b0);
+    ch = nx;
+    if (ch >= nchunks) break;
+    const int nx2 = ch + 4;
+    if (nx2 < nchunks) load(nx2, a0, b0);
+    fma16(a1, b1);
+    ch = nx2;
+  }
+
+  // acc[nf][i] = C[row q*4+i][channel c*4+nf]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<f32x4*>(&red[wave][q * 4 + i][c * 4]) =
+        (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+  __syncthreads();
+  const int orow = threadIdx.x >> 4, og = threadIdx.x & 15;
+  const int grow = row0 + orow, n = n0 + og * 4;
+  if (grow >= rows || n >= Nc) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][orow][og * 4]);
+  v += *reinterpret_cast<const f32x4*>(&red[1][orow][og * 4]);
+  v += *reinterpret_cast<const f32x4*>(&red[2][orow][og * 4]);
+  v += *reinterpret_cast<const f32x4*>(&red[3][orow][og * 4]);
+  if (MODE == 1) {
+    *reinterpret_cast<f32x4*>(y + (int64_t)grow * Nc + n) = v;
+    return;
+  }
+  if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = actf(v[e], g.act, g.alpha);
+  const int b = g.d2s;
+  if (b <= 1) {
+    const int64_t dst = (int64_t)grow * Nc + n;
+    if (res) v += *reinterpret_cast<const f32x4*>(res + dst);
+    *reinterpret_cast<f32x4*>(y + dst) = v;
+    return;
+  }
+  unsigned r = (unsigned)grow;
+  const int o2 = (int)(r % (unsigned)g.O[2]); r /= (unsigned)g.O[2];
+  const int o1 = (int)(r % (unsigned)g.O[1]); r /= (unsigned)g.O[1];
+  const int o0 = (int)(r % (unsigned)g.O[0]); r /= (unsigned)g.O[0];
+  const int cpo = Nc / (b * b);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int co = n + e, blk = co / cpo, cc = co - blk * cpo;
+    const int64_t dst = ((((int64_t)r * g.O[0] * b + o0 * b + blk / b) * (g.O[1] * b) +
+                          o1 * b + blk % b) * g.O[2] + o2) * cpo + cc;
+    float t = v[e];
+    if (res) t += res[dst];
+    y[dst] = t;
+  }
+}
+
+// dW[tap][ci][co] (+)= sum_p x[cell(p, tap)][ci] * dPre[p][co]
+// grid (taps, C_in / 64 tiles, C_out / 16 tiles); db: column sums of dPre
+// (written by the workgroups of tap 0, ci tile 0) or nullptr
+__global__ __launch_bounds__(256) void fewpos_wgrad_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy,
+    float* __restrict__ dw, float* __restrict__ db, ConvGeom g, int rows,
+    int accumulate) {
+  extern __shared__ int sdyn[];           // source cell of every position under this tap
+  __shared__ float red[4][64][16];
+  __shared__ float bred[4][4][16];
+  const int tap = blockIdx.x, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 16;
+  for (int p = threadIdx.x; p < rows; p += 256) sdyn[p] = src_cell<0>(g, (unsigned)p, tap);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int Cin = g.Cin, Cout = g.Cout;
+  const int ci = ci0 + c * 4, co = co0 + c;
+  const bool want_b = db != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+  f32x4 acc[4];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) acc[mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int steps = (rows + 3) >> 2;
+  // two steps per trip, all four loads issued before the first MFMA
+  for (int st = wave; st < steps; st += 8) {
+    const int pa = st * 4 + q, pb = (st + 4) * 4 + q;
+    const int sa = pa < rows ? sdyn[pa] : -1, sb = pb < rows ? sdyn[pb] : -1;
+    const f32x4 xa = (sa >= 0 && ci < Cin) ? *reinterpret_cast<const f32x4*>(x + (int64_t)sa * Cin + ci) : zero4;
+    const f32x4 xb = (sb >= 0 && ci < Cin) ? *reinterpret_cast<const f32x4*>(x + (int64_t)sb * Cin + ci) : zero4;
+    const float da = (pa < rows && co < Cout) ? dy[(int64_t)pa * Cout + co] : 0.f;
+    const float dbv = (pb < rows && co < Cout) ? dy[(int64_t)pb * Cout + co] : 0.f;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[mf], da, acc[mf], 0, 0, 0);
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[mf], dbv, acc[mf], 0, 0, 0);
+    bsum += da;
+    bsum += dbv;
+  }
+  // acc[mf][i] = C[m = q*4+i][n = c]  with m <-> ci0 + m*4 + mf
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][(q * 4 + i) * 4 + mf][c] = acc[mf][i];
+  if (want_b) bred[wave][q][c] = bsum;
+  __syncthreads();
+  {
+    const int m = threadIdx.x >> 2, cg = (threadIdx.x & 3) * 4;
+    const int oci = ci0 + m, oco = co0 + cg;
+    if (oci < Cin && oco < Cout) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][m][cg]);
+      v += *reinterpret_cast<const f32x4*>(&red[1][m][cg]);
+      v += *reinterpret_cast<const f32x4*>(&red[2][m][cg]);
+      v += *reinterpret_cast<const f32x4*>(&red[3][m][cg]);
+      float* dst = dw + ((int64_t)tap * Cin + oci) * Cout + oco;
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  }
+  if (want_b && threadIdx.x < 16 && co0 + (int)threadIdx.x < Cout) {
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) t += bred[wv][qq][threadIdx.x];
+    float* dst = db + co0 + threadIdx.x;
+    *dst = accumulate ? *dst + t : t;
+  }
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+// geometry the one-launch kernels take (forward, data gradient and weight
+// gradient alike: the plan skips the filter transpose on this predicate)
+bool conv_fewpos_mfma_ok(const ConvGeom& g) {
+  if (s3_opt_has(S3O_NO_FEWPOS_MFMA)) return false;
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  const int64_t Pin = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
+  int64_t Pf = g.N;                       // padded frame of the reflect dgrad
+  for (int d = 0; d < 3; ++d) Pf *= g.D[d] + 2 * g.lo[d];
+  return taps <= MAX_TAPS && (g.Cin & 15) == 0 && (g.Cout & 15) == 0 &&
+         P <= 8192 && Pin <= 32768 && Pf <= 65536 &&
+         (g.d2s <= 1 || g.Cout % (g.d2s * g.d2s) == 0);
+}
+
+// mode 0: y = act(conv(x) + bias) (+ res), depth-to-space store; mode 1: dx = adjoint(dy)
+int launch_conv_fewpos_mfma(s3_ctx* ctx, const ConvGeom& g, int mode, const float* src,
+                            const float* w, const float* bias, const float* res, float* y) {
+  if (!aligned16(src) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) ||
+      (res && !aligned16(res)))
+    S3_FAIL(ctx, S3_EINVAL, "fewpos mfma: operand not 16-B aligned");
+  if (mode == 0) {
+    const int64_t rows = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+    dim3 grid((unsigned)((rows + 15) / 16), (g.Cout + 63) / 64);
+    hipLaunchKernelGGL(fewpos_mfma_kernel<0>, grid, dim3(256), 0, ctx->stream, src, w, bias, res, y, g,
+                       (int)rows, g.Cin, g.Cout);
+  } else {
+    const int64_t rows = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
+    dim3 grid((unsigned)((rows + 15) / 16), (g.Cin + 63) / 64);
+    hipLaunchKernelGGL(fewpos_mfma_kernel<1>, grid, dim3(256), 0, ctx->stream, src, w, nullptr, nullptr, y, g,
+                       (int)rows, g.Cout, g.Cin);
+  }
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_conv_fewpos_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
+                                  float* dw, float* db, int accumulate) {
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dw))
+    S3_FAIL(ctx, S3_EINVAL, "fewpos wgrad mfma: operand not 16-B aligned");
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int64_t rows = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  dim3 grid(taps, (g.Cin + 63) / 64, (g.Cout + 15) / 16);
+  hipLaunchKernelGGL(fewpos_wgrad_mfma_kernel, grid, dim3(256), (size_t)rows * sizeof(int), ctx->stream,
+                     x, dy, dw, db, g, (int)rows, accumulate);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}

@@ -86,6 +86,7 @@ struct OpRec {
   // few-positions GEMM path
   bool fewpos = false;
   bool fewpos_wgrad = false;   // few positions, small filter: only the weight gradient takes the fewpos kernel
+  bool fp_mfma = false;        // the fewpos launches of this conv are the one-launch fp32-MFMA kernels
   float* fp_wt = nullptr;      // [tap][co][ci] transposed filter (dgrad)
   uint64_t fp_version = 0;
 };
@@ -739,6 +740,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         o.halo_s2 = o.gconv && d.res < 0 && conv_halo_s2_supported(ctx, g, precision);
         o.tail_x3 = !o.mfma && !o.fewpos && d.res < 0 && conv_tail_x3_supported(g, precision);
         if (o.fewpos) {
+          o.fp_mfma = conv_fewpos_mfma_ok(g);
           max_fp = std::max(max_fp, conv_fewpos_partial_bytes(g));
           if (training) {
             max_partial = std::max(max_partial, conv_fewpos_wgrad_partial_bytes(g));
@@ -785,6 +787,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
           if (!o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_tail && !o.wgrad_bf16_gen && !o.wgrad_bf16_2d &&
               !o.wgrad_gen && conv_fewpos_wgrad_ok(g) && !s3_opt_has(S3O_NO_FEWPOS)) {
             o.fewpos_wgrad = true;
+            o.fp_mfma = conv_fewpos_mfma_ok(g);
             max_partial = std::max(max_partial, conv_fewpos_wgrad_partial_bytes(g));
           }
           o.dgrad_mfma = conv_dgrad_mfma_supported(g, precision);
@@ -1390,6 +1393,8 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
         return launch_gconv_fwd(ctx, o.cg, (const float*)tptr(pl, d.in0), o.gc_w, b, res, tptr(pl, d.out), o.io.out_bf16, o.io.in_bf16,
                                 pl->precision == S3_PREC_BF16X3, o.sign_bytes);
       }
+      if (o.fewpos && o.fp_mfma && !o.io.in_bf16 && !o.io.out_bf16)
+        return launch_conv_fewpos_mfma(ctx, o.cg, 0, tptr(pl, d.in0), w, b, res, tptr(pl, d.out));
       if (o.fewpos && !o.io.in_bf16 && !o.io.out_bf16)
         return launch_conv_fewpos_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out), pl->fp_partial, pl->fp_partial_bytes);
       return launch_conv_generic_fwd(ctx, o.cg, tptr(pl, d.in0), w, b, res, tptr(pl, d.out), o.io.out_bf16, o.io.in_bf16);
@@ -1686,6 +1691,7 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
     v[S3_OPINFO_FWD_BF16_OPS] = (pl->precision == S3_PREC_BF16 &&
                                  (fwd == S3_FWD_FUSED2D || fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 || fwd == S3_FWD_HALO_S2 ||
                                   fwd == S3_FWD_GCONV || fwd == S3_FWD_GCONV_FEWCH || fwd == S3_FWD_TAIL_MFMA)) ? 1 : 0;
+    v[S3_OPINFO_FEWPOS_MFMA] = o.fp_mfma ? 1 : 0;
     if (pl->training) {
       int wg = S3_WGRAD_DIRECT;
       if (o.fewpos || (o.fewpos_wgrad && !o.io.in_bf16)) wg = S3_WGRAD_FEWPOS;
@@ -1976,7 +1982,15 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
           dpre16 = side;
         }
         const int64_t npos = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
-        if (need_wgrad) {
+        // few positions: the one-launch weight gradient leaves the bias gradient too
+        const bool fp_wg = o.fp_mfma && dpre != nullptr &&
+                           (o.fewpos || (!o.wgrad_tail && !o.wgrad_c2 && !o.wgrad_bf16_2d && !o.wgrad_bf16_gen &&
+                                         !o.wgrad_gen && !o.wgrad_bf16 && !o.wgrad_mfma && o.fewpos_wgrad && !o.io.in_bf16));
+        if (need_wgrad && fp_wg) {
+          rc = launch_conv_fewpos_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset,
+                                             d.b >= 0 ? G + P->p[d.b].offset : nullptr, accumulate_wgrad);
+          if (rc) return rc;
+        } else if (need_wgrad) {
           if (d.b >= 0) {
             // (its launch rides along the reduction of a bf16-family weight gradient)
             const bool ride = !o.fewpos && !o.wgrad_tail && !o.wgrad_c2 &&
@@ -2262,6 +2276,21 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
               const bool dy16 = o.use16 && dpre16 != nullptr;
               rc = launch_gconv_dgrad(ctx, g, dy16 ? (const float*)dpre16 : dpre, o.gc_wt, dst, 0, 0, dy16 ? 1 : 0,
                                       pl->precision == S3_PREC_BF16X3);
+            }
+          } else if (o.fewpos && o.fp_mfma) {
+            // (reads the [tap][ci][co] filter along co: no transposed copy)
+            const float* wf = W + P->p[d.w].offset;
+            if (g.pad_mode == S3_PAD_REFLECT) {
+              rc = launch_conv_fewpos_mfma(ctx, conv_fewpos_frame_geom(g), 1, dpre, wf, nullptr, nullptr, pl->dxp);
+              if (rc) return rc;
+              GatherGeom fg;
+              fg.kind = S3_OP_PAD; fg.N = g.N;
+              for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2 * g.lo[q]; fg.lo[q] = g.lo[q]; }
+              fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
+              fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
+              rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+            } else {
+              rc = launch_conv_fewpos_mfma(ctx, g, 1, dpre, wf, nullptr, nullptr, dst);
             }
           } else if (o.fewpos && o.fp_wt) {
             if (o.fp_version != P->version) {

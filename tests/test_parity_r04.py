@@ -246,3 +246,77 @@ def test_dense_layers_on_the_16_byte_walks_vs_oracle(shape, units):
     spec += [{'class': 'Dense', 'units': 1}]
     _fwd_bwd_vs_oracle(spec, shape, 'f32', 31, 1e-4, 1e-3)
     _fwd_bwd_vs_oracle(spec, shape, 'bf16', 32, 1e-3, 1e-3)
+
+
+def _fewpos_specs():
+    from sup3r_amd.configs.author_configs import pcc
+
+    def conv(nd, f, s=1, pad='valid', act=True):
+        out = [{'class': f'Conv{nd}D', 'filters': f, 'kernel_size': 3,
+                'strides': s, 'padding': pad}]
+        if act:
+            out.append({'alpha': 0.2, 'class': 'LeakyReLU'})
+        return out
+    # the C1 generator's shapes: reflect-padded 64 -> 64 convs with skip
+    # connections, a 64 -> 256 conv + depth-to-space, 7 x 5 positions per sample
+    gen2d = pcc(2, 64) + [{'class': 'SkipConnection', 'name': 'a'}] + \
+        pcc(2, 64) + pcc(2, 64, act=False) + \
+        [{'class': 'SkipConnection', 'name': 'a'}] + pcc(2, 256) + \
+        [{'class': 'SpatialExpansion', 'spatial_mult': 2}] + pcc(2, 16)
+    # the C1 discriminator's shapes: strides 1 / 2, valid and 'same' padding,
+    # C_out 48 (one ragged 64-wide channel tile), Flatten + Dense behind
+    disc2d = conv(2, 32) + conv(2, 64, 2, 'same') + conv(2, 48, 1, 'same') + \
+        conv(2, 128, 2) + [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
+    # 27 taps, zero 'same' padding, a stride-2 layer
+    st3d = conv(3, 16) + conv(3, 48, 1, 'same') + conv(3, 32, 2, 'same') + \
+        conv(3, 16, 1, 'same', act=False)
+    return [('gen2d', gen2d, (5, 7, 5, 16)),
+            ('disc2d', disc2d, (3, 14, 13, 2)),
+            ('st3d', st3d, (2, 6, 5, 7, 3))]
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', [0, 1, 2])
+def test_fewpos_one_launch_mfma_kernels_vs_oracle_and_split_k_family(case, precision):
+    """``fewpos_mfma_kernel<0 / 1>`` and ``fewpos_wgrad_mfma_kernel`` (round 4:
+    forward conv + epilogue, data gradient from the untransposed filter, weight
+    + bias gradient — ONE launch each on ``v_mfma_f32_16x16x4_f32``) against
+    the oracle (forward 1e-4, every gradient 1e-4 under the device's masks:
+    exact fp32 products) and against the split-K weight-streaming family they
+    replace (option ``NO_FEWPOS_MFMA``) to fp32 summation order.  Ragged
+    16-position tiles, reflect / zero / no padding, strides 1 and 2, skip
+    connections, depth-to-space, C_out 48 / 256, 9 and 27 taps.  Reference:
+    sup3r/models/abstract.py:1131-1238 runs these layers through keras
+    Conv2D / Conv3D under ``tf.GradientTape``."""
+    from tests.test_parity_r02 import _fwd_bwd_vs_oracle, _oracle, _hip
+    name, spec, shape = _fewpos_specs()[case]
+    ph = _fwd_bwd_vs_oracle(spec, shape, precision, 11 + case, 1e-4 if precision == 'f32' else 3e-2,
+                            1e-4 if precision == 'f32' else 3e-2)
+    infos = [ph.op_info(i) for i in range(len(ph.plan.ops))]
+    n_new = sum(1 for i in infos if i['kind'] == 1 and i['fewpos_mfma'])
+    assert n_new >= 2, (name, infos)
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle(spec, x, None, seed=5)
+
+    def run(old):
+        switch('NO_FEWPOS_MFMA', 1 if old else None)
+        net = _hip(spec, ref.weights, precision)
+        p = net.plan(shape, training=True)
+        flags = [p.op_info(i)['fewpos_mfma'] for i in range(len(p.plan.ops))]
+        assert (sum(flags) == 0) == bool(old)
+        y = p.forward(net.dev.to_device(x)).cpu().numpy()
+        dy = np.random.default_rng(4).standard_normal(y.shape).astype(np.float32)
+        dx = p.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
+        out = [y, dx] + [np.array(g) for g in net.grads]
+        net.clear_plans()
+        return out
+    new, new2, old = run(False), run(False), run(True)
+    switch('NO_FEWPOS_MFMA', None)
+    for a, b in zip(new, new2):
+        np.testing.assert_array_equal(a, b)          # fixed summation order
+    tol = 2e-5 if precision == 'f32' else 2e-2       # (bf16 plans: other layers round)
+    for i, (a, b) in enumerate(zip(new, old)):
+        scale = max(float(np.abs(b).max()), 1e-6)
+        assert float(np.abs(a - b).max()) / scale < tol, (name, i)
