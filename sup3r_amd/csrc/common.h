@@ -420,9 +420,11 @@ int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
 // partial buffers and no filter transpose (kernels_conv_fewpos_mfma.hip)
 bool conv_fewpos_mfma_ok(const ConvGeom& g);
 int launch_conv_fewpos_mfma(s3_ctx* ctx, const ConvGeom& g, int mode, const float* src,
-                            const float* w, const float* bias, const float* res, float* y);
+                            const float* w, const float* bias, const float* res, float* y,
+                            const float* mask_y = nullptr, float slope = 0.f);
 int launch_conv_fewpos_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                                  float* dw, float* db, int accumulate);
+                                  float* dw, float* db, int accumulate,
+                                  const float* mask_y = nullptr, float slope = 0.f);
 
 int launch_gather(s3_ctx* ctx, const GatherGeom& g, const void* in, void* out,
                   int esize);

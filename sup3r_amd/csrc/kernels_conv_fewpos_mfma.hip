@@ -9,7 +9,7 @@
 // gradient: 2 + 2 + 1 launches) pays mostly for its launch count.  Here:
 //
 //   * fewpos_mfma_kernel<MODE>: a workgroup owns 16 positions x 64 output
-//     channels; its four waves split the K = taps x C reduction in 16-channel
+//     channels; its eight waves split the K = taps x C reduction in 16-channel
 //     chunks (v_mfma_f32_16x16x4_f32: exact fp32 products and sums), sum their
 //     partials through LDS in fixed order and apply bias / activation /
 //     residual / depth-to-space on the way out.  A operands are 16-B reads of
@@ -17,7 +17,7 @@
 //     owns four consecutive output channels (MODE 0) — or, for the data
 //     gradient (MODE 1), reads the UNtransposed [tap][ci][co] filter along co,
 //     which is the K axis there: no transpose_taps launch.
-//   * fewpos_wgrad_mfma_kernel: a workgroup owns (tap, 64 ci, 16 co); its four
+//   * fewpos_wgrad_mfma_kernel: a workgroup owns (tap, 64 ci, 16 co); its eight
 //     waves interleave over the positions (M = ci, N = co, K = positions),
 //     LDS sum in fixed order, result (+)= straight into dW: no partial buffer,
 //     no reduce launch.  The workgroups of tap 0 / ci tile 0 also leave the
@@ -32,6 +32,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MAX_TAPS = 27;
+constexpr int NW = 8;          // waves per workgroup (they split the reduction axis)
+constexpr int NT = NW * 64;
 
 __device__ inline float actf(float v, int act, float alpha) {
   if (act == S3_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -78,15 +80,19 @@ __device__ inline int src_cell(const ConvGeom& g, unsigned row, int tap) {
 //   MODE 0: B_tap[k][n] = w[tap][k][n]   (K = C_in,  Nc = C_out), epilogue applied
 //   MODE 1: B_tap[k][n] = w[tap][n][k]   (K = C_out, Nc = C_in),  plain store
 template <int MODE>
-__global__ __launch_bounds__(256) void fewpos_mfma_kernel(
+__global__ __launch_bounds__(NT) void fewpos_mfma_kernel(
     const float* __restrict__ src, const float* __restrict__ w,
     const float* __restrict__ bias, const float* __restrict__ res,
-    float* __restrict__ y, ConvGeom g, int rows, int K, int Nc) {
+    float* __restrict__ y, ConvGeom g, int rows, int K, int Nc,
+    const float* __restrict__ mask_y, float slope) {
+  // mask_y (MODE 1, nullable): the conv's own fp32 output — src is dL/dy and
+  // the activation's adjoint (x 1 where y > 0, x slope elsewhere) is applied
+  // to the operand as it is read: no mask pass in front of this kernel
   __shared__ int sidx[MAX_TAPS * 16];
-  __shared__ float red[4][16][64];
+  __shared__ float red[NW][16][64];
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int row0 = blockIdx.x * 16, n0 = blockIdx.y * 64;
-  for (int i = threadIdx.x; i < taps * 16; i += 256) {
+  for (int i = threadIdx.x; i < taps * 16; i += NT) {
     const int row = row0 + (i & 15);
     sidx[i] = row < rows ? src_cell<MODE>(g, (unsigned)row, i >> 4) : -1;
   }
@@ -106,6 +112,11 @@ __global__ __launch_bounds__(256) void fewpos_mfma_kernel(
     const int s = sidx[tap * 16 + c];
     const int k0 = kb * 16 + q * 4;
     a = s >= 0 ? *reinterpret_cast<const f32x4*>(src + (int64_t)s * K + k0) : zero4;
+    if (MODE == 1 && mask_y && s >= 0) {
+      const f32x4 m = *reinterpret_cast<const f32x4*>(mask_y + (int64_t)s * K + k0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] *= m[e] > 0.f ? 1.f : slope;
+    }
     if (MODE == 0) {
       // b[j][nf] = w[tap][k0 + j][nl + nf]
       const float* wp = w + ((int64_t)tap * K + k0) * Nc + nl;
@@ -128,21 +139,24 @@ __global__ __launch_bounds__(256) void fewpos_mfma_kernel(
         acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], MODE == 0 ? b[j][nf] : b[nf][j], acc[nf], 0, 0, 0);
   };
 
-  // chunks wave, wave + 4, ...: the next chunk's operands are in flight under
-  // the sixteen MFMAs of the current one
+  // chunks wave, wave + NW, ...: a ring of three operand sets, so that two
+  // chunks' loads are in flight under the sixteen MFMAs of the current one
+  // (the kernel is a chain of L2 / HBM round trips, not of MFMAs)
+  f32x4 ra[3], rb[3][4];
   int ch = wave;
-  f32x4 a0, b0[4], a1, b1[4];
-  if (ch < nchunks) load(ch, a0, b0);
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+    if (ch + u * NW < nchunks) load(ch + u * NW, ra[u], rb[u]);
   while (ch < nchunks) {
-    const int nx = ch + 4;
-    if (nx < nchunks) load(nx, a1, b1);
-    fma16(a0, b0);
-    ch = nx;
-    if (ch >= nchunks) break;
-    const int nx2 = ch + 4;
-    if (nx2 < nchunks) load(nx2, a0, b0);
-    fma16(a1, b1);
-    ch = nx2;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (ch < nchunks) {
+        fma16(ra[u], rb[u]);
+        const int nx = ch + 3 * NW;
+        if (nx < nchunks) load(nx, ra[u], rb[u]);
+        ch += NW;
+      }
+    }
   }
 
   // acc[nf][i] = C[row q*4+i][channel c*4+nf]
@@ -151,13 +165,13 @@ __global__ __launch_bounds__(256) void fewpos_mfma_kernel(
     *reinterpret_cast<f32x4*>(&red[wave][q * 4 + i][c * 4]) =
         (f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
   __syncthreads();
+  if (threadIdx.x >= 256) return;
   const int orow = threadIdx.x >> 4, og = threadIdx.x & 15;
   const int grow = row0 + orow, n = n0 + og * 4;
   if (grow >= rows || n >= Nc) return;
   f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][orow][og * 4]);
-  v += *reinterpret_cast<const f32x4*>(&red[1][orow][og * 4]);
-  v += *reinterpret_cast<const f32x4*>(&red[2][orow][og * 4]);
-  v += *reinterpret_cast<const f32x4*>(&red[3][orow][og * 4]);
+#pragma unroll
+  for (int wv = 1; wv < NW; ++wv) v += *reinterpret_cast<const f32x4*>(&red[wv][orow][og * 4]);
   if (MODE == 1) {
     *reinterpret_cast<f32x4*>(y + (int64_t)grow * Nc + n) = v;
     return;
@@ -191,15 +205,15 @@ __global__ __launch_bounds__(256) void fewpos_mfma_kernel(
 // dW[tap][ci][co] (+)= sum_p x[cell(p, tap)][ci] * dPre[p][co]
 // grid (taps, C_in / 64 tiles, C_out / 16 tiles); db: column sums of dPre
 // (written by the workgroups of tap 0, ci tile 0) or nullptr
-__global__ __launch_bounds__(256) void fewpos_wgrad_mfma_kernel(
+__global__ __launch_bounds__(NT) void fewpos_wgrad_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ dw, float* __restrict__ db, ConvGeom g, int rows,
-    int accumulate) {
+    int accumulate, const float* __restrict__ mask_y, float slope) {
   extern __shared__ int sdyn[];           // source cell of every position under this tap
-  __shared__ float red[4][64][16];
-  __shared__ float bred[4][4][16];
+  __shared__ float red[NW][64][16];
+  __shared__ float bred[NW][4][16];
   const int tap = blockIdx.x, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 16;
-  for (int p = threadIdx.x; p < rows; p += 256) sdyn[p] = src_cell<0>(g, (unsigned)p, tap);
+  for (int p = threadIdx.x; p < rows; p += NT) sdyn[p] = src_cell<0>(g, (unsigned)p, tap);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -213,20 +227,47 @@ __global__ __launch_bounds__(256) void fewpos_wgrad_mfma_kernel(
   float bsum = 0.f;
   const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int steps = (rows + 3) >> 2;
-  // two steps per trip, all four loads issued before the first MFMA
-  for (int st = wave; st < steps; st += 8) {
-    const int pa = st * 4 + q, pb = (st + 4) * 4 + q;
-    const int sa = pa < rows ? sdyn[pa] : -1, sb = pb < rows ? sdyn[pb] : -1;
-    const f32x4 xa = (sa >= 0 && ci < Cin) ? *reinterpret_cast<const f32x4*>(x + (int64_t)sa * Cin + ci) : zero4;
-    const f32x4 xb = (sb >= 0 && ci < Cin) ? *reinterpret_cast<const f32x4*>(x + (int64_t)sb * Cin + ci) : zero4;
-    const float da = (pa < rows && co < Cout) ? dy[(int64_t)pa * Cout + co] : 0.f;
-    const float dbv = (pb < rows && co < Cout) ? dy[(int64_t)pb * Cout + co] : 0.f;
+  // a step = four positions (one MFMA per ci fragment); the waves interleave
+  // over the steps, four steps per trip, and the next trip's operands are in
+  // flight under the sixteen MFMAs of the current one
+  constexpr int U = 4;
+  f32x4 xa[2][U];
+  float da[2][U];
+  auto load = [&](int st, f32x4 (&xv)[U], float (&dv)[U]) {
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[mf], da, acc[mf], 0, 0, 0);
+    for (int u = 0; u < U; ++u) {
+      const int p = (st + u * NW) * 4 + q;
+      const bool in = p < rows;
+      const int sc = in ? sdyn[p] : -1;
+      xv[u] = (sc >= 0 && ci < Cin) ? *reinterpret_cast<const f32x4*>(x + (int64_t)sc * Cin + ci) : zero4;
+      float d = (in && co < Cout) ? dy[(int64_t)p * Cout + co] : 0.f;
+      if (mask_y) {     // dy = dL/dy of an activated conv: its adjoint on the fly
+        const float m = (in && co < Cout) ? mask_y[(int64_t)p * Cout + co] : 0.f;
+        d *= m > 0.f ? 1.f : slope;
+      }
+      dv[u] = d;
+    }
+  };
+  auto fma = [&](const f32x4 (&xv)[U], const float (&dv)[U]) {
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[mf], dbv, acc[mf], 0, 0, 0);
-    bsum += da;
-    bsum += dbv;
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][mf], dv[u], acc[mf], 0, 0, 0);
+      bsum += dv[u];
+    }
+  };
+  int st = wave;
+  if (st < steps) load(st, xa[0], da[0]);
+  while (st < steps) {
+    int nx = st + U * NW;
+    if (nx < steps) load(nx, xa[1], da[1]);
+    fma(xa[0], da[0]);
+    st = nx;
+    if (st >= steps) break;
+    nx = st + U * NW;
+    if (nx < steps) load(nx, xa[0], da[0]);
+    fma(xa[1], da[1]);
+    st = nx;
   }
   // acc[mf][i] = C[m = q*4+i][n = c]  with m <-> ci0 + m*4 + mf
 #pragma unroll
@@ -235,26 +276,26 @@ __global__ __launch_bounds__(256) void fewpos_wgrad_mfma_kernel(
     for (int i = 0; i < 4; ++i) red[wave][(q * 4 + i) * 4 + mf][c] = acc[mf][i];
   if (want_b) bred[wave][q][c] = bsum;
   __syncthreads();
-  {
+  if (threadIdx.x < 256) {
     const int m = threadIdx.x >> 2, cg = (threadIdx.x & 3) * 4;
     const int oci = ci0 + m, oco = co0 + cg;
     if (oci < Cin && oco < Cout) {
       f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][m][cg]);
-      v += *reinterpret_cast<const f32x4*>(&red[1][m][cg]);
-      v += *reinterpret_cast<const f32x4*>(&red[2][m][cg]);
-      v += *reinterpret_cast<const f32x4*>(&red[3][m][cg]);
+#pragma unroll
+      for (int wv = 1; wv < NW; ++wv) v += *reinterpret_cast<const f32x4*>(&red[wv][m][cg]);
       float* dst = dw + ((int64_t)tap * Cin + oci) * Cout + oco;
       if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
       *reinterpret_cast<f32x4*>(dst) = v;
     }
   }
-  if (want_b && threadIdx.x < 16 && co0 + (int)threadIdx.x < Cout) {
+  if (want_b && threadIdx.x >= 256 && threadIdx.x < 272 && co0 + (int)threadIdx.x - 256 < Cout) {
+    const int bc = threadIdx.x - 256;
     float t = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < 4; ++wv)
+    for (int wv = 0; wv < NW; ++wv)
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) t += bred[wv][qq][threadIdx.x];
-    float* dst = db + co0 + threadIdx.x;
+      for (int qq = 0; qq < 4; ++qq) t += bred[wv][qq][bc];
+    float* dst = db + co0 + bc;
     *dst = accumulate ? *dst + t : t;
   }
 }
@@ -279,34 +320,37 @@ bool conv_fewpos_mfma_ok(const ConvGeom& g) {
 
 // mode 0: y = act(conv(x) + bias) (+ res), depth-to-space store; mode 1: dx = adjoint(dy)
 int launch_conv_fewpos_mfma(s3_ctx* ctx, const ConvGeom& g, int mode, const float* src,
-                            const float* w, const float* bias, const float* res, float* y) {
+                            const float* w, const float* bias, const float* res, float* y,
+                            const float* mask_y, float slope) {
+  if (mask_y && (mode != 1 || !aligned16(mask_y)))
+    S3_FAIL(ctx, S3_EINVAL, "fewpos mfma: mask operand");
   if (!aligned16(src) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) ||
       (res && !aligned16(res)))
     S3_FAIL(ctx, S3_EINVAL, "fewpos mfma: operand not 16-B aligned");
   if (mode == 0) {
     const int64_t rows = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
     dim3 grid((unsigned)((rows + 15) / 16), (g.Cout + 63) / 64);
-    hipLaunchKernelGGL(fewpos_mfma_kernel<0>, grid, dim3(256), 0, ctx->stream, src, w, bias, res, y, g,
-                       (int)rows, g.Cin, g.Cout);
+    hipLaunchKernelGGL(fewpos_mfma_kernel<0>, grid, dim3(NT), 0, ctx->stream, src, w, bias, res, y, g,
+                       (int)rows, g.Cin, g.Cout, (const float*)nullptr, 0.f);
   } else {
     const int64_t rows = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
     dim3 grid((unsigned)((rows + 15) / 16), (g.Cin + 63) / 64);
-    hipLaunchKernelGGL(fewpos_mfma_kernel<1>, grid, dim3(256), 0, ctx->stream, src, w, nullptr, nullptr, y, g,
-                       (int)rows, g.Cout, g.Cin);
+    hipLaunchKernelGGL(fewpos_mfma_kernel<1>, grid, dim3(NT), 0, ctx->stream, src, w, nullptr, nullptr, y, g,
+                       (int)rows, g.Cout, g.Cin, mask_y, slope);
   }
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
 
 int launch_conv_fewpos_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                                  float* dw, float* db, int accumulate) {
+                                  float* dw, float* db, int accumulate, const float* mask_y, float slope) {
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dw))
     S3_FAIL(ctx, S3_EINVAL, "fewpos wgrad mfma: operand not 16-B aligned");
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int64_t rows = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
   dim3 grid(taps, (g.Cin + 63) / 64, (g.Cout + 15) / 16);
-  hipLaunchKernelGGL(fewpos_wgrad_mfma_kernel, grid, dim3(256), (size_t)rows * sizeof(int), ctx->stream,
-                     x, dy, dw, db, g, (int)rows, accumulate);
+  hipLaunchKernelGGL(fewpos_wgrad_mfma_kernel, grid, dim3(NT), (size_t)rows * sizeof(int), ctx->stream,
+                     x, dy, dw, db, g, (int)rows, accumulate, mask_y, slope);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -989,7 +989,9 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
       }
       // (the stride-2 dgrad kernel masks from an fp32 y; the frame fold of the
       // halo-tile dgrad from fp32 or bf16)
-      const bool fold = o.dgrad_mfma && !o.dgrad_valid;
+      const bool fold = (o.dgrad_mfma && !o.dgrad_valid) ||
+                        (o.fewpos && o.fp_mfma && o.cg.pad_mode == S3_PAD_REFLECT && !o.dgrad_chunked &&
+                         !o.dgrad_s2 && !o.dgrad_c2 && !o.gconv_dgrad);   // (the one-launch fewpos dgrad folds its frame too)
       if (o.d.kind != S3_OP_CONV || !(o.dgrad_s2 || fold)) continue;
       const int r = root_of(pl, o.d.in0);
       const int pi = prod[r];
@@ -1949,7 +1951,22 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
           if (o.use16 && g.act == S3_ACT_NONE && g.d2s <= 1 && dy == pl->t[ro].gptr) dpre16 = pl->dpre16;
           pl->dpre16_for = -1;
         }
-        if ((g.act != S3_ACT_NONE || g.d2s > 1) && !pl->premasked[ro]) {
+        // one-launch fewpos kernels: the activation's adjoint is applied to dy as
+        // the weight / data gradient kernels read it (from y, like the mask pass)
+        const float* fp_mask_y = nullptr;
+        float fp_slope = 0.f;
+        // (both readers of dPre must be the one-launch kernels: the data gradient
+        // of a fewpos conv may still run on another family)
+        const bool fp_dg = o.fewpos && o.fp_mfma && !o.dgrad_chunked && !o.dgrad_mfma && !o.dgrad_s2 &&
+                           !o.dgrad_c2 && !o.gconv_dgrad;
+        if (o.fewpos && o.fp_mfma && (fp_dg || !wants_grad(d.in0)) &&
+            g.d2s <= 1 && !o.io.out_bf16 && pl->t[ro].dtype == 0 &&
+            (g.act == S3_ACT_LEAKY || g.act == S3_ACT_RELU) && !pl->premasked[ro] && !only16 &&
+            !s3_opt_has(S3O_NO_MASK_FUSE)) {
+          fp_mask_y = (const float*)tptr(pl, d.out);
+          fp_slope = g.act == S3_ACT_LEAKY ? g.alpha : 0.f;
+        }
+        if ((g.act != S3_ACT_NONE || g.d2s > 1) && !pl->premasked[ro] && !fp_mask_y) {
           // (never over a pending bf16-only dPre of another tensor)
           void* side = (o.use16 && pl->dpre16 && pl->dpre16_for < 0 && conv_epilogue_bwd_d16_ok(g) &&
                         (g.d2s <= 1 || o.io.out_bf16)) ? pl->dpre16 : nullptr;
@@ -1988,7 +2005,8 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
                                          !o.wgrad_gen && !o.wgrad_bf16 && !o.wgrad_mfma && o.fewpos_wgrad && !o.io.in_bf16));
         if (need_wgrad && fp_wg) {
           rc = launch_conv_fewpos_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset,
-                                             d.b >= 0 ? G + P->p[d.b].offset : nullptr, accumulate_wgrad);
+                                             d.b >= 0 ? G + P->p[d.b].offset : nullptr, accumulate_wgrad,
+                                             fp_mask_y, fp_slope);
           if (rc) return rc;
         } else if (need_wgrad) {
           if (d.b >= 0) {
@@ -2281,16 +2299,19 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
             // (reads the [tap][ci][co] filter along co: no transposed copy)
             const float* wf = W + P->p[d.w].offset;
             if (g.pad_mode == S3_PAD_REFLECT) {
-              rc = launch_conv_fewpos_mfma(ctx, conv_fewpos_frame_geom(g), 1, dpre, wf, nullptr, nullptr, pl->dxp);
+              rc = launch_conv_fewpos_mfma(ctx, conv_fewpos_frame_geom(g), 1, dpre, wf, nullptr, nullptr, pl->dxp,
+                                           fp_mask_y, fp_slope);
               if (rc) return rc;
               GatherGeom fg;
               fg.kind = S3_OP_PAD; fg.N = g.N;
               for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2 * g.lo[q]; fg.lo[q] = g.lo[q]; }
               fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
               fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
-              rc = launch_gather_bwd(ctx, fg, pl->dxp, dst);
+              // (with the producer's activation adjoint, or the first contribution
+              // of a skip tensor, in the same store: no mask pass, no axpy)
+              rc = fold_frame(fg, dst);
             } else {
-              rc = launch_conv_fewpos_mfma(ctx, g, 1, dpre, wf, nullptr, nullptr, dst);
+              rc = launch_conv_fewpos_mfma(ctx, g, 1, dpre, wf, nullptr, nullptr, dst, fp_mask_y, fp_slope);
             }
           } else if (o.fewpos && o.fp_wt) {
             if (o.fp_version != P->version) {
