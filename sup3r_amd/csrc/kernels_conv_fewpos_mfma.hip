@@ -202,6 +202,102 @@ __global__ __launch_bounds__(NT) void fewpos_mfma_kernel(
   }
 }
 
+// The same with a 16-channel tile: a 16 x 64 x (taps x C) tile is ~1.2 MFLOP =
+// 4 600 cycles of one CU's fp32 matrix pipes (256 FLOP / clk), and a C1 layer
+// has 24 such tiles for 256 CUs.  Four times the workgroups, a quarter of the
+// MFMAs each, and with 8 B of operands per lane and chunk a ring deep enough
+// that every load of a wave is in flight at once.
+template <int MODE>
+__global__ __launch_bounds__(NT) void fewpos_mfma16_kernel(
+    const float* __restrict__ src, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ res,
+    float* __restrict__ y, ConvGeom g, int rows, int K, int Nc,
+    const float* __restrict__ mask_y, float slope) {
+  __shared__ int sidx[MAX_TAPS * 16];
+  __shared__ float red[NW][16][16];
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int row0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+  for (int i = threadIdx.x; i < taps * 16; i += NT) {
+    const int row = row0 + (i & 15);
+    sidx[i] = row < rows ? src_cell<MODE>(g, (unsigned)row, i >> 4) : -1;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int kch = K >> 4, nchunks = taps * kch;
+  const int nl = n0 + c;                  // this lane's output channel
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc = zero4;
+
+  auto load = [&](int ch, f32x4& a, f32x4& b) {
+    const int tap = ch / kch, kb = ch - tap * kch;
+    const int s = sidx[tap * 16 + c];
+    const int k0 = kb * 16 + q * 4;
+    a = s >= 0 ? *reinterpret_cast<const f32x4*>(src + (int64_t)s * K + k0) : zero4;
+    if (MODE == 1 && mask_y && s >= 0) {
+      const f32x4 m = *reinterpret_cast<const f32x4*>(mask_y + (int64_t)s * K + k0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] *= m[e] > 0.f ? 1.f : slope;
+    }
+    if (MODE == 0) {          // b[j] = w[tap][k0 + j][nl]
+      const float* wp = w + ((int64_t)tap * K + k0) * Nc + nl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = nl < Nc ? wp[(int64_t)j * Nc] : 0.f;
+    } else {                  // b[j] = w[tap][nl][k0 + j]
+      b = nl < Nc ? *reinterpret_cast<const f32x4*>(w + ((int64_t)tap * Nc + nl) * K + k0) : zero4;
+    }
+  };
+  constexpr int R = 5;
+  f32x4 ra[R], rb[R];
+  int ch = wave;
+#pragma unroll
+  for (int u = 0; u < R; ++u)
+    if (ch + u * NW < nchunks) load(ch + u * NW, ra[u], rb[u]);
+  while (ch < nchunks) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (ch < nchunks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[u][j], rb[u][j], acc, 0, 0, 0);
+        const int nx = ch + R * NW;
+        if (nx < nchunks) load(nx, ra[u], rb[u]);
+        ch += NW;
+      }
+    }
+  }
+  // acc[i] = C[row q*4+i][channel c]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[wave][q * 4 + i][c] = acc[i];
+  __syncthreads();
+  if (threadIdx.x >= 256) return;
+  const int orow = threadIdx.x >> 4, oc = threadIdx.x & 15;
+  const int grow = row0 + orow, n = n0 + oc;
+  if (grow >= rows || n >= Nc) return;
+  float v = red[0][orow][oc];
+#pragma unroll
+  for (int wv = 1; wv < NW; ++wv) v += red[wv][orow][oc];
+  if (MODE == 1) {
+    y[(int64_t)grow * Nc + n] = v;
+    return;
+  }
+  if (bias) v += bias[n];
+  v = actf(v, g.act, g.alpha);
+  int64_t dst = (int64_t)grow * Nc + n;
+  const int b = g.d2s;
+  if (b > 1) {
+    unsigned r = (unsigned)grow;
+    const int o2 = (int)(r % (unsigned)g.O[2]); r /= (unsigned)g.O[2];
+    const int o1 = (int)(r % (unsigned)g.O[1]); r /= (unsigned)g.O[1];
+    const int o0 = (int)(r % (unsigned)g.O[0]); r /= (unsigned)g.O[0];
+    const int cpo = Nc / (b * b);
+    const int blk = n / cpo, cc = n - blk * cpo;
+    dst = ((((int64_t)r * g.O[0] * b + o0 * b + blk / b) * (g.O[1] * b) + o1 * b + blk % b) * g.O[2] + o2) * cpo + cc;
+  }
+  if (res) v += res[dst];
+  y[dst] = v;
+}
+
 // dW[tap][ci][co] (+)= sum_p x[cell(p, tap)][ci] * dPre[p][co]
 // grid (taps, C_in / 64 tiles, C_out / 16 tiles); db: column sums of dPre
 // (written by the workgroups of tap 0, ci tile 0) or nullptr
@@ -327,16 +423,26 @@ int launch_conv_fewpos_mfma(s3_ctx* ctx, const ConvGeom& g, int mode, const floa
   if (!aligned16(src) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) ||
       (res && !aligned16(res)))
     S3_FAIL(ctx, S3_EINVAL, "fewpos mfma: operand not 16-B aligned");
+  const int64_t rows = mode == 0 ? (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] : (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
+  const int K = mode == 0 ? g.Cin : g.Cout, Nc = mode == 0 ? g.Cout : g.Cin;
+  const unsigned rt = (unsigned)((rows + 15) / 16);
+  // 16-channel tiles while that still leaves every workgroup a CU of its own
+  const bool narrow = (int64_t)rt * ((Nc + 15) / 16) <= 2 * ctx->num_cu;
+  const dim3 grid(rt, narrow ? (Nc + 15) / 16 : (Nc + 63) / 64);
   if (mode == 0) {
-    const int64_t rows = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
-    dim3 grid((unsigned)((rows + 15) / 16), (g.Cout + 63) / 64);
-    hipLaunchKernelGGL(fewpos_mfma_kernel<0>, grid, dim3(NT), 0, ctx->stream, src, w, bias, res, y, g,
-                       (int)rows, g.Cin, g.Cout, (const float*)nullptr, 0.f);
+    if (narrow)
+      hipLaunchKernelGGL(fewpos_mfma16_kernel<0>, grid, dim3(NT), 0, ctx->stream, src, w, bias, res, y, g,
+                         (int)rows, K, Nc, (const float*)nullptr, 0.f);
+    else
+      hipLaunchKernelGGL(fewpos_mfma_kernel<0>, grid, dim3(NT), 0, ctx->stream, src, w, bias, res, y, g,
+                         (int)rows, K, Nc, (const float*)nullptr, 0.f);
   } else {
-    const int64_t rows = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
-    dim3 grid((unsigned)((rows + 15) / 16), (g.Cin + 63) / 64);
-    hipLaunchKernelGGL(fewpos_mfma_kernel<1>, grid, dim3(NT), 0, ctx->stream, src, w, nullptr, nullptr, y, g,
-                       (int)rows, g.Cout, g.Cin, mask_y, slope);
+    if (narrow)
+      hipLaunchKernelGGL(fewpos_mfma16_kernel<1>, grid, dim3(NT), 0, ctx->stream, src, w, (const float*)nullptr,
+                         (const float*)nullptr, y, g, (int)rows, K, Nc, mask_y, slope);
+    else
+      hipLaunchKernelGGL(fewpos_mfma_kernel<1>, grid, dim3(NT), 0, ctx->stream, src, w, (const float*)nullptr,
+                         (const float*)nullptr, y, g, (int)rows, K, Nc, mask_y, slope);
   }
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;

@@ -53,6 +53,8 @@ struct FL {
   int border;      // how the consumer pads dst: 0 zero, 1 reflect (dst in LDS)
   unsigned img;    // byte offset of this layer's packed filter image
   int bias;        // float offset into the weight buffer, -1: none
+  int cin;         // input channels
+  int w_off;       // float offset of the canonical filter in the weight buffer
 };
 
 __device__ __forceinline__ unsigned pk2(float a, float b) {
@@ -74,6 +76,27 @@ __global__ void fused2d_pack_kernel(const float* __restrict__ w, unsigned short*
     const int nf = r;
     const int ci = ks * 32 + k, co = nf * 16 + row;
     const float v = (ci < cin && co < cout) ? w[((size_t)tap * cin + ci) * cout + co] : 0.f;
+    img[idx] = (unsigned short)(pk2(v, 0.f) & 0xFFFFu);
+  }
+}
+
+// ... every layer of the stack in ONE launch (blockIdx.y = layer): a training
+// mini-batch re-packs after each weight update, and 36 dependent 4.6 us
+// launches were as long as the fused forward itself
+__global__ void fused2d_pack_all_kernel(const float* __restrict__ W, char* __restrict__ img_base,
+                                        const FL* __restrict__ L) {
+  const FL f = L[blockIdx.y];
+  const float* w = W + f.w_off;
+  unsigned short* img = reinterpret_cast<unsigned short*>(img_base + f.img);
+  const int total = f.n_nf * 9 * f.ck * 512;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int k = idx & 31, row = (idx >> 5) & 15;
+    int r = idx >> 9;
+    const int ks = r % f.ck; r /= f.ck;
+    const int tap = r % 9; r /= 9;
+    const int nf = r;
+    const int ci = ks * 32 + k, co = nf * 16 + row;
+    const float v = (ci < f.cin && co < f.cout) ? w[((size_t)tap * f.cin + ci) * f.cout + co] : 0.f;
     img[idx] = (unsigned short)(pk2(v, 0.f) & 0xFFFFu);
   }
 }
@@ -332,6 +355,8 @@ Fused2dPlan* fused2d_build(s3_ctx* ctx, const std::vector<Fused2dLayer>& L, int 
     f.border = f.dst >= 0 ? (border[L[i].out_t] < 0 ? 0 : border[L[i].out_t]) : 0;
     f.img = (unsigned)img;
     f.bias = L[i].b_off >= 0 ? (int)L[i].b_off : -1;
+    f.cin = g.Cin;
+    f.w_off = (int)L[i].w_off;
     img += (size_t)f.n_nf * 9 * f.ck * 1024;
     P->host.push_back(f);
   }
@@ -357,14 +382,12 @@ void fused2d_free(Fused2dPlan* P) {
 int fused2d_run(s3_ctx* ctx, Fused2dPlan* P, const float* W, uint64_t wversion, const float* x,
                 float* y) {
   if (P->version != wversion) {
-    for (size_t i = 0; i < P->host.size(); ++i) {
-      const FL& f = P->host[i];
-      const ConvGeom& g = P->in[i].g;
-      const int total = f.n_nf * 9 * f.ck * 512;
-      hipLaunchKernelGGL(fused2d_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream,
-                         W + P->in[i].w_off, (unsigned short*)(P->img + f.img), g.Cin, g.Cout, f.ck,
-                         f.n_nf);
-    }
+    int max_total = 0;
+    for (const FL& f : P->host) max_total = std::max(max_total, f.n_nf * 9 * f.ck * 512);
+    int gx = (max_total + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(fused2d_pack_all_kernel, dim3(gx, (unsigned)P->host.size()), dim3(256), 0, ctx->stream,
+                       W, P->img, (const FL*)P->dev);
     S3_HIP(ctx, hipGetLastError());
     P->version = wversion;
   }

@@ -77,7 +77,7 @@ def test_replayed_steps_are_the_eager_steps_bit_for_bit():
     # each before the record
     assert rec1.replays == len(SCHEDULE) - 6, rec1.replays
     nodes = sorted(e['rec'].nodes for e in rec1._entries.values())
-    assert len(nodes) == 3 and nodes[0] > 100, nodes
+    assert len(nodes) == 3 and nodes[0] > 30, nodes   # (round 4: one launch per fewpos conv pass)
     assert it0 == it1 == (sum(f != DISC for f in SCHEDULE),
                           sum(f != GEN for f in SCHEDULE))
     assert all(np.isfinite(a).all() for a in w0)
