@@ -87,7 +87,8 @@
   X(PERSIST_DGRAD_MIN_TILES) \
   X(POISON_ALLOC) \
   X(TRACE) \
-  X(WGRAD_DBG)
+  X(WGRAD_DBG) \
+  X(WGRAD_SIDE_STREAM)
 enum S3OptId {
 #define X(n) S3O_##n,
   S3_OPTION_LIST(X)
@@ -127,6 +128,12 @@ struct s3_ctx {
   hipEvent_t comm_ev[2] = {nullptr, nullptr};   // [0] compute -> comm, [1] comm -> compute
   hipEvent_t wd_ev[2] = {nullptr, nullptr};     // s3_comm_wait: tail of the compute / comm stream
   int64_t comm_issued = 0;           // collectives enqueued since the last completed s3_comm_wait
+  // option WGRAD_SIDE_STREAM (an experiment that lost, kept for the A/B): weight
+  // gradients of launch-bound backward passes beside the data-gradient chain
+  // (plan.cpp: wg_fork / wg_join; joins every s3_plan_backward)
+  hipStream_t wg_stream = nullptr;
+  hipEvent_t wg_ev[2] = {nullptr, nullptr};    // [0] compute -> side, [1] side -> compute
+  bool wg_forked = false;
   // stream capture (s3_capture_begin .. s3_capture_end): launches go to a
   // non-blocking side stream while it records; `stream` is restored afterwards
   hipStream_t cap_stream = nullptr, saved_stream = nullptr;
@@ -419,6 +426,7 @@ int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
 // ... the same three on the fp32 matrix instruction, one launch each, no
 // partial buffers and no filter transpose (kernels_conv_fewpos_mfma.hip)
 bool conv_fewpos_mfma_ok(const ConvGeom& g);
+bool conv_fewpos_wgrad_mfma_ok(const ConvGeom& g);
 int launch_conv_fewpos_mfma(s3_ctx* ctx, const ConvGeom& g, int mode, const float* src,
                             const float* w, const float* bias, const float* res, float* y,
                             const float* mask_y = nullptr, float slope = 0.f);

@@ -335,7 +335,12 @@ __global__ __launch_bounds__(NT) void fewpos_wgrad_mfma_kernel(
       const int p = (st + u * NW) * 4 + q;
       const bool in = p < rows;
       const int sc = in ? sdyn[p] : -1;
-      xv[u] = (sc >= 0 && ci < Cin) ? *reinterpret_cast<const f32x4*>(x + (int64_t)sc * Cin + ci) : zero4;
+      if ((Cin & 3) == 0) {
+        xv[u] = (sc >= 0 && ci < Cin) ? *reinterpret_cast<const f32x4*>(x + (int64_t)sc * Cin + ci) : zero4;
+      } else {          // (few input channels: the first layer of a network)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[u][e] = (sc >= 0 && ci + e < Cin) ? x[(int64_t)sc * Cin + ci + e] : 0.f;
+      }
       float d = (in && co < Cout) ? dy[(int64_t)p * Cout + co] : 0.f;
       if (mask_y) {     // dy = dL/dy of an activated conv: its adjoint on the fly
         const float m = (in && co < Cout) ? mask_y[(int64_t)p * Cout + co] : 0.f;
@@ -412,6 +417,15 @@ bool conv_fewpos_mfma_ok(const ConvGeom& g) {
   return taps <= MAX_TAPS && (g.Cin & 15) == 0 && (g.Cout & 15) == 0 &&
          P <= 8192 && Pin <= 32768 && Pf <= 65536 &&
          (g.d2s <= 1 || g.Cout % (g.d2s * g.d2s) == 0);
+}
+
+// the weight-gradient kernel alone takes any C_in (scalar operand reads when
+// it is not a multiple of 4) and any number of taps
+bool conv_fewpos_wgrad_mfma_ok(const ConvGeom& g) {
+  if (s3_opt_has(S3O_NO_FEWPOS_MFMA)) return false;
+  const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  const int64_t Pin = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
+  return (g.Cout & 3) == 0 && P <= 8192 && Pin < (1 << 24);
 }
 
 // mode 0: y = act(conv(x) + bias) (+ res), depth-to-space store; mode 1: dx = adjoint(dy)

@@ -87,6 +87,7 @@ struct OpRec {
   bool fewpos = false;
   bool fewpos_wgrad = false;   // few positions, small filter: only the weight gradient takes the fewpos kernel
   bool fp_mfma = false;        // the fewpos launches of this conv are the one-launch fp32-MFMA kernels
+  bool fp_wg_mfma = false;     // ... its weight gradient at least (fewpos_wgrad ops)
   float* fp_wt = nullptr;      // [tap][co][ci] transposed filter (dgrad)
   uint64_t fp_version = 0;
 };
@@ -258,6 +259,9 @@ extern "C" void s3_ctx_destroy(s3_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->capturing) (void)s3_capture_abort(ctx);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+  if (ctx->wg_stream) (void)hipStreamDestroy(ctx->wg_stream);
+  for (int k = 0; k < 2; ++k)
+    if (ctx->wg_ev[k]) (void)hipEventDestroy(ctx->wg_ev[k]);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -787,7 +791,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
           if (!o.wgrad_mfma && !o.fewpos && !o.wgrad_c2 && !o.wgrad_tail && !o.wgrad_bf16_gen && !o.wgrad_bf16_2d &&
               !o.wgrad_gen && conv_fewpos_wgrad_ok(g) && !s3_opt_has(S3O_NO_FEWPOS)) {
             o.fewpos_wgrad = true;
-            o.fp_mfma = conv_fewpos_mfma_ok(g);
+            o.fp_wg_mfma = conv_fewpos_wgrad_mfma_ok(g);
             max_partial = std::max(max_partial, conv_fewpos_wgrad_partial_bytes(g));
           }
           o.dgrad_mfma = conv_dgrad_mfma_supported(g, precision);
@@ -1693,7 +1697,7 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
     v[S3_OPINFO_FWD_BF16_OPS] = (pl->precision == S3_PREC_BF16 &&
                                  (fwd == S3_FWD_FUSED2D || fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 || fwd == S3_FWD_HALO_S2 ||
                                   fwd == S3_FWD_GCONV || fwd == S3_FWD_GCONV_FEWCH || fwd == S3_FWD_TAIL_MFMA)) ? 1 : 0;
-    v[S3_OPINFO_FEWPOS_MFMA] = o.fp_mfma ? 1 : 0;
+    v[S3_OPINFO_FEWPOS_MFMA] = (o.fp_mfma || o.fp_wg_mfma) ? 1 : 0;
     if (pl->training) {
       int wg = S3_WGRAD_DIRECT;
       if (o.fewpos || (o.fewpos_wgrad && !o.io.in_bf16)) wg = S3_WGRAD_FEWPOS;
@@ -1836,10 +1840,40 @@ static const float* grad_of(s3_plan* pl, int r) {
 static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, int need_wgrad,
                               int accumulate_wgrad);
 
+// Option WGRAD_SIDE_STREAM.  A launch-bound backward pass is a chain of
+// dependent launches (>= 4.6 us each on this part); the weight gradient of a
+// conv is not on that chain — nothing in the pass reads it — so it can go to a
+// side stream that forks off the compute stream where its operands are final
+// and joins before s3_plan_backward returns (inside a stream capture: a
+// parallel branch of the graph).  Measured on C1 (48 forks per mini-batch):
+// 2.37 -> 2.90 ms eager, 2.38 -> 2.89 ms as a recorded graph — a cross-stream
+// dependency costs more than the 6 us kernel it takes off the chain — so it is
+// off unless asked for (profiles/r04/README.md).
+static int wg_fork(s3_ctx* ctx, hipStream_t* side) {
+  if (!ctx->wg_stream) {
+    S3_HIP(ctx, hipStreamCreateWithFlags(&ctx->wg_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) S3_HIP(ctx, hipEventCreateWithFlags(&ctx->wg_ev[k], hipEventDisableTiming));
+  }
+  S3_HIP(ctx, hipEventRecord(ctx->wg_ev[0], ctx->stream));
+  S3_HIP(ctx, hipStreamWaitEvent(ctx->wg_stream, ctx->wg_ev[0], 0));
+  ctx->wg_forked = true;
+  *side = ctx->wg_stream;
+  return S3_OK;
+}
+static int wg_join(s3_ctx* ctx) {
+  if (!ctx->wg_forked) return S3_OK;
+  ctx->wg_forked = false;
+  S3_HIP(ctx, hipEventRecord(ctx->wg_ev[1], ctx->wg_stream));
+  S3_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->wg_ev[1], 0));
+  return S3_OK;
+}
+
 extern "C" int s3_plan_backward(s3_plan* pl, const void* d_output, void* d_input,
                                 int need_wgrad, int accumulate_wgrad) {
   if (!pl || !d_output) return S3_EINVAL;
-  const int rc = plan_backward_impl(pl, d_output, d_input, need_wgrad, accumulate_wgrad);
+  int rc = plan_backward_impl(pl, d_output, d_input, need_wgrad, accumulate_wgrad);
+  const int jrc = wg_join(pl->ctx);      // (also on a failed pass: a capture must not end forked)
+  if (rc == S3_OK) rc = jrc;
   if (rc != S3_OK && pl->params && (pl->params->armed || pl->params->reduced)) {
     pl->params->reduced = false;
     // an armed store must not outlive the backward pass it was armed for: the
@@ -2000,13 +2034,25 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
         }
         const int64_t npos = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
         // few positions: the one-launch weight gradient leaves the bias gradient too
-        const bool fp_wg = o.fp_mfma && dpre != nullptr &&
-                           (o.fewpos || (!o.wgrad_tail && !o.wgrad_c2 && !o.wgrad_bf16_2d && !o.wgrad_bf16_gen &&
+        const bool fp_wg = dpre != nullptr &&
+                           ((o.fewpos && o.fp_mfma) || (o.fp_wg_mfma && !o.fewpos && !o.wgrad_tail && !o.wgrad_c2 && !o.wgrad_bf16_2d && !o.wgrad_bf16_gen &&
                                          !o.wgrad_gen && !o.wgrad_bf16 && !o.wgrad_mfma && o.fewpos_wgrad && !o.io.in_bf16));
         if (need_wgrad && fp_wg) {
+          // beside the data-gradient chain when dPre is a tensor's own gradient
+          // buffer (final by now; the shared scratch buffers are rewritten by
+          // the ops that follow) and no collective reads G under this pass
+          const bool side = dpre != pl->dpre && dpre != pl->gtmp && dpre != pl->dxp && !ctx->comm &&
+                            !(P->armed || P->reduced) && s3_opt_has(S3O_WGRAD_SIDE_STREAM);
+          hipStream_t main_stream = ctx->stream, ws = nullptr;
+          if (side) {
+            rc = wg_fork(ctx, &ws);
+            if (rc) return rc;
+            ctx->stream = ws;
+          }
           rc = launch_conv_fewpos_wgrad_mfma(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset,
                                              d.b >= 0 ? G + P->p[d.b].offset : nullptr, accumulate_wgrad,
                                              fp_mask_y, fp_slope);
+          ctx->stream = main_stream;
           if (rc) return rc;
         } else if (need_wgrad) {
           if (d.b >= 0) {

@@ -280,7 +280,8 @@ def _fewpos_specs():
 def test_fewpos_one_launch_mfma_kernels_vs_oracle_and_split_k_family(case, precision):
     """``fewpos_mfma_kernel<0 / 1>`` and ``fewpos_wgrad_mfma_kernel`` (round 4:
     forward conv + epilogue, data gradient from the untransposed filter, weight
-    + bias gradient — ONE launch each on ``v_mfma_f32_16x16x4_f32``) against
+    + bias gradient — ONE launch each on ``v_mfma_f32_16x16x4_f32``; the
+    activation adjoint applied as dy is read) against
     the oracle (forward 1e-4, every gradient 1e-4 under the device's masks:
     exact fp32 products) and against the split-K weight-streaming family they
     replace (option ``NO_FEWPOS_MFMA``) to fp32 summation order.  Ragged
@@ -300,8 +301,9 @@ def test_fewpos_one_launch_mfma_kernels_vs_oracle_and_split_k_family(case, preci
     x = rng.standard_normal(shape).astype(np.float32)
     ref = _oracle(spec, x, None, seed=5)
 
-    def run(old):
+    def run(old, side=False):
         switch('NO_FEWPOS_MFMA', 1 if old else None)
+        switch('WGRAD_SIDE_STREAM', 1 if side else None)
         net = _hip(spec, ref.weights, precision)
         p = net.plan(shape, training=True)
         flags = [p.op_info(i)['fewpos_mfma'] for i in range(len(p.plan.ops))]
@@ -312,10 +314,14 @@ def test_fewpos_one_launch_mfma_kernels_vs_oracle_and_split_k_family(case, preci
         out = [y, dx] + [np.array(g) for g in net.grads]
         net.clear_plans()
         return out
-    new, new2, old = run(False), run(False), run(True)
+    new, new2, ser, old = run(False), run(False), run(False, side=True), run(True)
     switch('NO_FEWPOS_MFMA', None)
-    for a, b in zip(new, new2):
-        np.testing.assert_array_equal(a, b)          # fixed summation order
+    # fixed summation order; with option WGRAD_SIDE_STREAM the weight gradients
+    # run on a branch beside the data-gradient chain, joined before the pass
+    # returns, and read finished buffers only: same bits
+    for a, b, c in zip(new, new2, ser):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a, c)
     tol = 2e-5 if precision == 'f32' else 2e-2       # (bf16 plans: other layers round)
     for i, (a, b) in enumerate(zip(new, old)):
         scale = max(float(np.abs(b).max()), 1e-6)
