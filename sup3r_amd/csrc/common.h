@@ -51,6 +51,7 @@
   X(NO_FEWCH_HALO) \
   X(NO_FEWPOS) \
   X(NO_FEWPOS_MFMA) \
+  X(NO_FEWPOS_BWD_FUSE) \
   X(NO_FOLD16) \
   X(NO_FRAME16) \
   X(NO_FUSED2D) \
@@ -427,6 +428,10 @@ int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
 // partial buffers and no filter transpose (kernels_conv_fewpos_mfma.hip)
 bool conv_fewpos_mfma_ok(const ConvGeom& g);
 bool conv_fewpos_wgrad_mfma_ok(const ConvGeom& g);
+bool conv_fewpos_bwd_mfma_ok(const s3_ctx* ctx, const ConvGeom& g, const ConvGeom& gd);
+int launch_conv_fewpos_bwd_mfma(s3_ctx* ctx, const ConvGeom& g, const ConvGeom& gd, const float* x,
+                                const float* dy, const float* w, float* dx, float* dw, float* db,
+                                int accumulate, const float* mask_y, float slope);
 int launch_conv_fewpos_mfma(s3_ctx* ctx, const ConvGeom& g, int mode, const float* src,
                             const float* w, const float* bias, const float* res, float* y,
                             const float* mask_y = nullptr, float slope = 0.f);

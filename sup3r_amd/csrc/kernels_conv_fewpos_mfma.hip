@@ -208,15 +208,15 @@ __global__ __launch_bounds__(NT) void fewpos_mfma_kernel(
 // MFMAs each, and with 8 B of operands per lane and chunk a ring deep enough
 // that every load of a wave is in flight at once.
 template <int MODE>
-__global__ __launch_bounds__(NT) void fewpos_mfma16_kernel(
+__device__ __forceinline__ void mfma16_body(
+    const int bx, const int by, int* __restrict__ sidx /* [MAX_TAPS * 16] */,
+    float (*__restrict__ red)[16][16] /* [NW] */,
     const float* __restrict__ src, const float* __restrict__ w,
     const float* __restrict__ bias, const float* __restrict__ res,
-    float* __restrict__ y, ConvGeom g, int rows, int K, int Nc,
+    float* __restrict__ y, const ConvGeom& g, int rows, int K, int Nc,
     const float* __restrict__ mask_y, float slope) {
-  __shared__ int sidx[MAX_TAPS * 16];
-  __shared__ float red[NW][16][16];
   const int taps = g.k[0] * g.k[1] * g.k[2];
-  const int row0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+  const int row0 = bx * 16, n0 = by * 16;
   for (int i = threadIdx.x; i < taps * 16; i += NT) {
     const int row = row0 + (i & 15);
     sidx[i] = row < rows ? src_cell<MODE>(g, (unsigned)row, i >> 4) : -1;
@@ -298,17 +298,28 @@ __global__ __launch_bounds__(NT) void fewpos_mfma16_kernel(
   y[dst] = v;
 }
 
+template <int MODE>
+__global__ __launch_bounds__(NT) void fewpos_mfma16_kernel(
+    const float* __restrict__ src, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ res,
+    float* __restrict__ y, ConvGeom g, int rows, int K, int Nc,
+    const float* __restrict__ mask_y, float slope) {
+  __shared__ int sidx[MAX_TAPS * 16];
+  __shared__ float red[NW][16][16];
+  mfma16_body<MODE>(blockIdx.x, blockIdx.y, sidx, red, src, w, bias, res, y, g, rows, K, Nc, mask_y, slope);
+}
+
 // dW[tap][ci][co] (+)= sum_p x[cell(p, tap)][ci] * dPre[p][co]
 // grid (taps, C_in / 64 tiles, C_out / 16 tiles); db: column sums of dPre
 // (written by the workgroups of tap 0, ci tile 0) or nullptr
-__global__ __launch_bounds__(NT) void fewpos_wgrad_mfma_kernel(
+__device__ __forceinline__ void wgrad_body(
+    const int bx, const int by, const int bz,
+    int* __restrict__ sdyn /* [rows]: source cell of every position under this tap */,
+    float (*__restrict__ red)[64][16] /* [NW] */, float (*__restrict__ bred)[4][16] /* [NW] */,
     const float* __restrict__ x, const float* __restrict__ dy,
-    float* __restrict__ dw, float* __restrict__ db, ConvGeom g, int rows,
+    float* __restrict__ dw, float* __restrict__ db, const ConvGeom& g, int rows,
     int accumulate, const float* __restrict__ mask_y, float slope) {
-  extern __shared__ int sdyn[];           // source cell of every position under this tap
-  __shared__ float red[NW][64][16];
-  __shared__ float bred[NW][4][16];
-  const int tap = blockIdx.x, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 16;
+  const int tap = bx, ci0 = by * 64, co0 = bz * 16;
   for (int p = threadIdx.x; p < rows; p += NT) sdyn[p] = src_cell<0>(g, (unsigned)p, tap);
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(NT) void fewpos_wgrad_mfma_kernel(
   const int c = lane & 15, q = lane >> 4;
   const int Cin = g.Cin, Cout = g.Cout;
   const int ci = ci0 + c * 4, co = co0 + c;
-  const bool want_b = db != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+  const bool want_b = db != nullptr && bx == 0 && by == 0;
   f32x4 acc[4];
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf) acc[mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -385,8 +396,14 @@ __global__ __launch_bounds__(NT) void fewpos_wgrad_mfma_kernel(
 #pragma unroll
       for (int wv = 1; wv < NW; ++wv) v += *reinterpret_cast<const f32x4*>(&red[wv][m][cg]);
       float* dst = dw + ((int64_t)tap * Cin + oci) * Cout + oco;
-      if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-      *reinterpret_cast<f32x4*>(dst) = v;
+      if ((Cout & 3) == 0) {
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {            // (a tail conv: 2 or 3 output channels)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (oco + e < Cout) dst[e] = accumulate ? dst[e] + v[e] : v[e];
+      }
     }
   }
   if (want_b && threadIdx.x >= 256 && threadIdx.x < 272 && co0 + (int)threadIdx.x - 256 < Cout) {
@@ -399,6 +416,44 @@ __global__ __launch_bounds__(NT) void fewpos_wgrad_mfma_kernel(
     float* dst = db + co0 + bc;
     *dst = accumulate ? *dst + t : t;
   }
+}
+
+__global__ __launch_bounds__(NT) void fewpos_wgrad_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy,
+    float* __restrict__ dw, float* __restrict__ db, ConvGeom g, int rows,
+    int accumulate, const float* __restrict__ mask_y, float slope) {
+  extern __shared__ int sdyn[];
+  __shared__ float red[NW][64][16];
+  __shared__ float bred[NW][4][16];
+  wgrad_body(blockIdx.x, blockIdx.y, blockIdx.z, sdyn, red, bred, x, dy, dw, db, g, rows, accumulate, mask_y, slope);
+}
+
+// Data gradient AND weight (+ bias) gradient of a conv in one launch: both read
+// the same dPre and neither reads the other, so their workgroups share a grid —
+// the first nd_x * nd_y are 16 x 16 tiles of dX (over gd: the conv's geometry,
+// or its padded frame for reflect padding), the rest the (tap, ci tile, co
+// tile) items of dW.  One dependent launch (>= 4.6 us) less per conv and pass.
+__global__ __launch_bounds__(NT) void fewpos_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+    float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+    ConvGeom g, ConvGeom gd, int rows_d, int rows_w, int nd_x, int nd_y, int nw_y, int nw_z,
+    int accumulate, const float* __restrict__ mask_y, float slope) {
+  extern __shared__ int smem[];
+  const int nd = nd_x * nd_y;
+  if ((int)blockIdx.x < nd) {
+    int* sidx = smem;
+    float (*red)[16][16] = reinterpret_cast<float (*)[16][16]>(smem + MAX_TAPS * 16);
+    mfma16_body<1>(blockIdx.x % nd_x, blockIdx.x / nd_x, sidx, red, dy, w, nullptr, nullptr, dx, gd, rows_d,
+                   gd.Cout, gd.Cin, mask_y, slope);
+    return;
+  }
+  int item = blockIdx.x - nd;
+  const int bz = item % nw_z; item /= nw_z;
+  const int by = item % nw_y; item /= nw_y;
+  float (*red)[64][16] = reinterpret_cast<float (*)[64][16]>(smem);
+  float (*bred)[4][16] = reinterpret_cast<float (*)[4][16]>(smem + NW * 64 * 16);
+  int* sdyn = smem + NW * 64 * 16 + NW * 4 * 16;
+  wgrad_body(item, by, bz, sdyn, red, bred, x, dy, dw, db, g, rows_w, accumulate, mask_y, slope);
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -419,13 +474,13 @@ bool conv_fewpos_mfma_ok(const ConvGeom& g) {
          (g.d2s <= 1 || g.Cout % (g.d2s * g.d2s) == 0);
 }
 
-// the weight-gradient kernel alone takes any C_in (scalar operand reads when
-// it is not a multiple of 4) and any number of taps
+// the weight-gradient kernel alone takes any C_in / C_out (scalar operand reads
+// / stores when they are not multiples of 4) and any number of taps
 bool conv_fewpos_wgrad_mfma_ok(const ConvGeom& g) {
   if (s3_opt_has(S3O_NO_FEWPOS_MFMA)) return false;
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
   const int64_t Pin = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
-  return (g.Cout & 3) == 0 && P <= 8192 && Pin < (1 << 24);
+  return P <= 8192 && Pin < (1 << 24);
 }
 
 // mode 0: y = act(conv(x) + bias) (+ res), depth-to-space store; mode 1: dx = adjoint(dy)
@@ -471,6 +526,41 @@ int launch_conv_fewpos_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x
   dim3 grid(taps, (g.Cin + 63) / 64, (g.Cout + 15) / 16);
   hipLaunchKernelGGL(fewpos_wgrad_mfma_kernel, grid, dim3(NT), (size_t)rows * sizeof(int), ctx->stream,
                      x, dy, dw, db, g, (int)rows, accumulate, mask_y, slope);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+// whether launch_conv_fewpos_bwd_mfma takes this conv (16-channel dX tiles only)
+bool conv_fewpos_bwd_mfma_ok(const s3_ctx* ctx, const ConvGeom& g, const ConvGeom& gd) {
+  if (!conv_fewpos_mfma_ok(g)) return false;
+  const int64_t rows_d = (int64_t)gd.N * gd.D[0] * gd.D[1] * gd.D[2];
+  return ((rows_d + 15) / 16) * ((gd.Cin + 15) / 16) <= 2 * ctx->num_cu;
+}
+
+// dx = adjoint(dy) over gd (g or its padded frame) and dw (+)= x^T dy, db (+)= sum dy
+int launch_conv_fewpos_bwd_mfma(s3_ctx* ctx, const ConvGeom& g, const ConvGeom& gd, const float* x,
+                                const float* dy, const float* w, float* dx, float* dw, float* db,
+                                int accumulate, const float* mask_y, float slope) {
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(w) || !aligned16(dx) || !aligned16(dw) ||
+      (mask_y && !aligned16(mask_y)))
+    S3_FAIL(ctx, S3_EINVAL, "fewpos bwd mfma: operand not 16-B aligned");
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int64_t rows_w = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  const int64_t rows_d = (int64_t)gd.N * gd.D[0] * gd.D[1] * gd.D[2];
+  const int nd_x = (int)((rows_d + 15) / 16), nd_y = (gd.Cin + 15) / 16;
+  const int nw_y = (g.Cin + 63) / 64, nw_z = (g.Cout + 15) / 16;
+  const size_t lds_d = (size_t)(MAX_TAPS * 16 + NW * 16 * 16) * 4;
+  const size_t lds_w = (size_t)(NW * 64 * 16 + NW * 4 * 16 + rows_w) * 4;
+  const size_t lds = lds_d > lds_w ? lds_d : lds_w;
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fewpos_bwd_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fewpos_bwd_kernel, dim3((unsigned)(nd_x * nd_y + taps * nw_y * nw_z)), dim3(NT), lds,
+                     ctx->stream, x, dy, w, dx, dw, db, g, gd, (int)rows_d, (int)rows_w, nd_x, nd_y, nw_y, nw_z,
+                     accumulate, mask_y, slope);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -2037,7 +2037,13 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
         const bool fp_wg = dpre != nullptr &&
                            ((o.fewpos && o.fp_mfma) || (o.fp_wg_mfma && !o.fewpos && !o.wgrad_tail && !o.wgrad_c2 && !o.wgrad_bf16_2d && !o.wgrad_bf16_gen &&
                                          !o.wgrad_gen && !o.wgrad_bf16 && !o.wgrad_mfma && o.fewpos_wgrad && !o.io.in_bf16));
-        if (need_wgrad && fp_wg) {
+        // ... and when its data gradient is the one-launch kernel too, both go
+        // out as ONE launch (at the data gradient's place below)
+        const ConvGeom fp_gd = g.pad_mode == S3_PAD_REFLECT ? conv_fewpos_frame_geom(g) : g;
+        const bool fp_both = need_wgrad && fp_wg && fp_dg && wants_grad(d.in0) &&
+                             !s3_opt_has(S3O_WGRAD_SIDE_STREAM) && !s3_opt_has(S3O_NO_FEWPOS_BWD_FUSE) &&
+                             conv_fewpos_bwd_mfma_ok(ctx, g, fp_gd);
+        if (need_wgrad && fp_wg && !fp_both) {
           // beside the data-gradient chain when dPre is a tensor's own gradient
           // buffer (final by now; the shared scratch buffers are rewritten by
           // the ops that follow) and no collective reads G under this pass
@@ -2054,7 +2060,7 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
                                              fp_mask_y, fp_slope);
           ctx->stream = main_stream;
           if (rc) return rc;
-        } else if (need_wgrad) {
+        } else if (need_wgrad && !fp_both) {
           if (d.b >= 0) {
             // (its launch rides along the reduction of a bf16-family weight gradient)
             const bool ride = !o.fewpos && !o.wgrad_tail && !o.wgrad_c2 &&
@@ -2344,9 +2350,16 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
           } else if (o.fewpos && o.fp_mfma) {
             // (reads the [tap][ci][co] filter along co: no transposed copy)
             const float* wf = W + P->p[d.w].offset;
-            if (g.pad_mode == S3_PAD_REFLECT) {
-              rc = launch_conv_fewpos_mfma(ctx, conv_fewpos_frame_geom(g), 1, dpre, wf, nullptr, nullptr, pl->dxp,
-                                           fp_mask_y, fp_slope);
+            const bool reflect = g.pad_mode == S3_PAD_REFLECT;
+            if (fp_both) {
+              rc = launch_conv_fewpos_bwd_mfma(ctx, g, fp_gd, tptr(pl, d.in0), dpre, wf, reflect ? pl->dxp : dst,
+                                               G + P->p[d.w].offset, d.b >= 0 ? G + P->p[d.b].offset : nullptr,
+                                               accumulate_wgrad, fp_mask_y, fp_slope);
+              if (rc) return rc;
+            }
+            if (reflect) {
+              if (!fp_both)
+                rc = launch_conv_fewpos_mfma(ctx, fp_gd, 1, dpre, wf, nullptr, nullptr, pl->dxp, fp_mask_y, fp_slope);
               if (rc) return rc;
               GatherGeom fg;
               fg.kind = S3_OP_PAD; fg.N = g.N;
@@ -2356,7 +2369,7 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
               // (with the producer's activation adjoint, or the first contribution
               // of a skip tensor, in the same store: no mask pass, no axpy)
               rc = fold_frame(fg, dst);
-            } else {
+            } else if (!fp_both) {
               rc = launch_conv_fewpos_mfma(ctx, g, 1, dpre, wf, nullptr, nullptr, dst, fp_mask_y, fp_slope);
             }
           } else if (o.fewpos && o.fp_wt) {

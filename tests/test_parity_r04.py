@@ -301,9 +301,10 @@ def test_fewpos_one_launch_mfma_kernels_vs_oracle_and_split_k_family(case, preci
     x = rng.standard_normal(shape).astype(np.float32)
     ref = _oracle(spec, x, None, seed=5)
 
-    def run(old, side=False):
+    def run(old, side=False, fuse=True):
         switch('NO_FEWPOS_MFMA', 1 if old else None)
         switch('WGRAD_SIDE_STREAM', 1 if side else None)
+        switch('NO_FEWPOS_BWD_FUSE', None if fuse else 1)
         net = _hip(spec, ref.weights, precision)
         p = net.plan(shape, training=True)
         flags = [p.op_info(i)['fewpos_mfma'] for i in range(len(p.plan.ops))]
@@ -319,9 +320,13 @@ def test_fewpos_one_launch_mfma_kernels_vs_oracle_and_split_k_family(case, preci
     # fixed summation order; with option WGRAD_SIDE_STREAM the weight gradients
     # run on a branch beside the data-gradient chain, joined before the pass
     # returns, and read finished buffers only: same bits
-    for a, b, c in zip(new, new2, ser):
+    # ... and so does the data + weight gradient pair as one launch
+    # (``fewpos_bwd_kernel``) against the two separate launches
+    two = run(False, fuse=False)
+    for a, b, c, d in zip(new, new2, ser, two):
         np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(a, c)
+        np.testing.assert_array_equal(a, d)
     tol = 2e-5 if precision == 'f32' else 2e-2       # (bf16 plans: other layers round)
     for i, (a, b) in enumerate(zip(new, old)):
         scale = max(float(np.abs(b).max()), 1e-6)
