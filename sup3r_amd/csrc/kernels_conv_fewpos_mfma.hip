@@ -312,6 +312,7 @@ __global__ __launch_bounds__(NT) void fewpos_mfma16_kernel(
 // dW[tap][ci][co] (+)= sum_p x[cell(p, tap)][ci] * dPre[p][co]
 // grid (taps, C_in / 64 tiles, C_out / 16 tiles); db: column sums of dPre
 // (written by the workgroups of tap 0, ci tile 0) or nullptr
+template <bool VEC4>     // C_in and C_out multiples of 4: 16-B operand reads / stores
 __device__ __forceinline__ void wgrad_body(
     const int bx, const int by, const int bz,
     int* __restrict__ sdyn /* [rows]: source cell of every position under this tap */,
@@ -346,7 +347,7 @@ __device__ __forceinline__ void wgrad_body(
       const int p = (st + u * NW) * 4 + q;
       const bool in = p < rows;
       const int sc = in ? sdyn[p] : -1;
-      if ((Cin & 3) == 0) {
+      if (VEC4) {
         xv[u] = (sc >= 0 && ci < Cin) ? *reinterpret_cast<const f32x4*>(x + (int64_t)sc * Cin + ci) : zero4;
       } else {          // (few input channels: the first layer of a network)
 #pragma unroll
@@ -396,7 +397,7 @@ __device__ __forceinline__ void wgrad_body(
 #pragma unroll
       for (int wv = 1; wv < NW; ++wv) v += *reinterpret_cast<const f32x4*>(&red[wv][m][cg]);
       float* dst = dw + ((int64_t)tap * Cin + oci) * Cout + oco;
-      if ((Cout & 3) == 0) {
+      if (VEC4) {
         if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
         *reinterpret_cast<f32x4*>(dst) = v;
       } else {            // (a tail conv: 2 or 3 output channels)
@@ -418,6 +419,7 @@ __device__ __forceinline__ void wgrad_body(
   }
 }
 
+template <bool VEC4>
 __global__ __launch_bounds__(NT) void fewpos_wgrad_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ dw, float* __restrict__ db, ConvGeom g, int rows,
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(NT) void fewpos_wgrad_mfma_kernel(
   extern __shared__ int sdyn[];
   __shared__ float red[NW][64][16];
   __shared__ float bred[NW][4][16];
-  wgrad_body(blockIdx.x, blockIdx.y, blockIdx.z, sdyn, red, bred, x, dy, dw, db, g, rows, accumulate, mask_y, slope);
+  wgrad_body<VEC4>(blockIdx.x, blockIdx.y, blockIdx.z, sdyn, red, bred, x, dy, dw, db, g, rows, accumulate, mask_y, slope);
 }
 
 // Data gradient AND weight (+ bias) gradient of a conv in one launch: both read
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(NT) void fewpos_bwd_kernel(
   float (*red)[64][16] = reinterpret_cast<float (*)[64][16]>(smem);
   float (*bred)[4][16] = reinterpret_cast<float (*)[4][16]>(smem + NW * 64 * 16);
   int* sdyn = smem + NW * 64 * 16 + NW * 4 * 16;
-  wgrad_body(item, by, bz, sdyn, red, bred, x, dy, dw, db, g, rows_w, accumulate, mask_y, slope);
+  wgrad_body<true>(item, by, bz, sdyn, red, bred, x, dy, dw, db, g, rows_w, accumulate, mask_y, slope);
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -524,8 +526,12 @@ int launch_conv_fewpos_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int64_t rows = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
   dim3 grid(taps, (g.Cin + 63) / 64, (g.Cout + 15) / 16);
-  hipLaunchKernelGGL(fewpos_wgrad_mfma_kernel, grid, dim3(NT), (size_t)rows * sizeof(int), ctx->stream,
-                     x, dy, dw, db, g, (int)rows, accumulate, mask_y, slope);
+  if (((g.Cin | g.Cout) & 3) == 0)
+    hipLaunchKernelGGL(fewpos_wgrad_mfma_kernel<true>, grid, dim3(NT), (size_t)rows * sizeof(int), ctx->stream,
+                       x, dy, dw, db, g, (int)rows, accumulate, mask_y, slope);
+  else
+    hipLaunchKernelGGL(fewpos_wgrad_mfma_kernel<false>, grid, dim3(NT), (size_t)rows * sizeof(int), ctx->stream,
+                       x, dy, dw, db, g, (int)rows, accumulate, mask_y, slope);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
