@@ -52,6 +52,7 @@
   X(NO_FEWPOS) \
   X(NO_FEWPOS_MFMA) \
   X(NO_FEWPOS_BWD_FUSE) \
+  X(NO_FEWPOS_SMALL) \
   X(NO_FOLD16) \
   X(NO_FRAME16) \
   X(NO_FUSED2D) \
@@ -428,6 +429,7 @@ int launch_conv_fewpos_transpose(s3_ctx* ctx, const ConvGeom& g, const float* w,
 // partial buffers and no filter transpose (kernels_conv_fewpos_mfma.hip)
 bool conv_fewpos_mfma_ok(const ConvGeom& g);
 bool conv_fewpos_wgrad_mfma_ok(const ConvGeom& g);
+bool conv_fewpos_mfma_small_ok(const s3_ctx* ctx, const ConvGeom& g);
 bool conv_fewpos_bwd_mfma_ok(const s3_ctx* ctx, const ConvGeom& g, const ConvGeom& gd);
 int launch_conv_fewpos_bwd_mfma(s3_ctx* ctx, const ConvGeom& g, const ConvGeom& gd, const float* x,
                                 const float* dy, const float* w, float* dx, float* dw, float* db,

@@ -207,7 +207,10 @@ __global__ __launch_bounds__(NT) void fewpos_mfma_kernel(
 // has 24 such tiles for 256 CUs.  Four times the workgroups, a quarter of the
 // MFMAs each, and with 8 B of operands per lane and chunk a ring deep enough
 // that every load of a wave is in flight at once.
-template <int MODE>
+// VK: K is a multiple of 16 (16-B operand reads, no guards); otherwise the last
+// chunk of a tap is ragged and the operands are read element by element — the
+// few-channel head / tail convs of a network (C_in or C_out 2 ... 8)
+template <int MODE, bool VK>
 __device__ __forceinline__ void mfma16_body(
     const int bx, const int by, int* __restrict__ sidx /* [MAX_TAPS * 16] */,
     float (*__restrict__ red)[16][16] /* [NW] */,
@@ -225,7 +228,7 @@ __device__ __forceinline__ void mfma16_body(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, q = lane >> 4;
-  const int kch = K >> 4, nchunks = taps * kch;
+  const int kch = (K + 15) >> 4, nchunks = taps * kch;
   const int nl = n0 + c;                  // this lane's output channel
   const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 acc = zero4;
@@ -234,18 +237,31 @@ __device__ __forceinline__ void mfma16_body(
     const int tap = ch / kch, kb = ch - tap * kch;
     const int s = sidx[tap * 16 + c];
     const int k0 = kb * 16 + q * 4;
-    a = s >= 0 ? *reinterpret_cast<const f32x4*>(src + (int64_t)s * K + k0) : zero4;
-    if (MODE == 1 && mask_y && s >= 0) {
-      const f32x4 m = *reinterpret_cast<const f32x4*>(mask_y + (int64_t)s * K + k0);
+    if (VK) {
+      a = s >= 0 ? *reinterpret_cast<const f32x4*>(src + (int64_t)s * K + k0) : zero4;
+      if (MODE == 1 && mask_y && s >= 0) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mask_y + (int64_t)s * K + k0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] *= m[e] > 0.f ? 1.f : slope;
+        for (int e = 0; e < 4; ++e) a[e] *= m[e] > 0.f ? 1.f : slope;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool in = s >= 0 && k0 + e < K;
+        float v = in ? src[(int64_t)s * K + k0 + e] : 0.f;
+        if (MODE == 1 && mask_y && in) v *= mask_y[(int64_t)s * K + k0 + e] > 0.f ? 1.f : slope;
+        a[e] = v;
+      }
     }
     if (MODE == 0) {          // b[j] = w[tap][k0 + j][nl]
       const float* wp = w + ((int64_t)tap * K + k0) * Nc + nl;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = nl < Nc ? wp[(int64_t)j * Nc] : 0.f;
-    } else {                  // b[j] = w[tap][nl][k0 + j]
+      for (int j = 0; j < 4; ++j) b[j] = (nl < Nc && (VK || k0 + j < K)) ? wp[(int64_t)j * Nc] : 0.f;
+    } else if (VK) {          // b[j] = w[tap][nl][k0 + j]
       b = nl < Nc ? *reinterpret_cast<const f32x4*>(w + ((int64_t)tap * Nc + nl) * K + k0) : zero4;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = (nl < Nc && k0 + j < K) ? w[((int64_t)tap * Nc + nl) * K + k0 + j] : 0.f;
     }
   };
   constexpr int R = 5;
@@ -298,7 +314,7 @@ __device__ __forceinline__ void mfma16_body(
   y[dst] = v;
 }
 
-template <int MODE>
+template <int MODE, bool VK>
 __global__ __launch_bounds__(NT) void fewpos_mfma16_kernel(
     const float* __restrict__ src, const float* __restrict__ w,
     const float* __restrict__ bias, const float* __restrict__ res,
@@ -306,7 +322,7 @@ __global__ __launch_bounds__(NT) void fewpos_mfma16_kernel(
     const float* __restrict__ mask_y, float slope) {
   __shared__ int sidx[MAX_TAPS * 16];
   __shared__ float red[NW][16][16];
-  mfma16_body<MODE>(blockIdx.x, blockIdx.y, sidx, red, src, w, bias, res, y, g, rows, K, Nc, mask_y, slope);
+  mfma16_body<MODE, VK>(blockIdx.x, blockIdx.y, sidx, red, src, w, bias, res, y, g, rows, K, Nc, mask_y, slope);
 }
 
 // dW[tap][ci][co] (+)= sum_p x[cell(p, tap)][ci] * dPre[p][co]
@@ -435,6 +451,7 @@ __global__ __launch_bounds__(NT) void fewpos_wgrad_mfma_kernel(
 // the first nd_x * nd_y are 16 x 16 tiles of dX (over gd: the conv's geometry,
 // or its padded frame for reflect padding), the rest the (tap, ci tile, co
 // tile) items of dW.  One dependent launch (>= 4.6 us) less per conv and pass.
+template <bool V>     // C_in and C_out multiples of 16
 __global__ __launch_bounds__(NT) void fewpos_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
     float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(NT) void fewpos_bwd_kernel(
   if ((int)blockIdx.x < nd) {
     int* sidx = smem;
     float (*red)[16][16] = reinterpret_cast<float (*)[16][16]>(smem + MAX_TAPS * 16);
-    mfma16_body<1>(blockIdx.x % nd_x, blockIdx.x / nd_x, sidx, red, dy, w, nullptr, nullptr, dx, gd, rows_d,
+    mfma16_body<1, V>(blockIdx.x % nd_x, blockIdx.x / nd_x, sidx, red, dy, w, nullptr, nullptr, dx, gd, rows_d,
                    gd.Cout, gd.Cin, mask_y, slope);
     return;
   }
@@ -455,7 +472,7 @@ __global__ __launch_bounds__(NT) void fewpos_bwd_kernel(
   float (*red)[64][16] = reinterpret_cast<float (*)[64][16]>(smem);
   float (*bred)[4][16] = reinterpret_cast<float (*)[4][16]>(smem + NW * 64 * 16);
   int* sdyn = smem + NW * 64 * 16 + NW * 4 * 16;
-  wgrad_body<true>(item, by, bz, sdyn, red, bred, x, dy, dw, db, g, rows_w, accumulate, mask_y, slope);
+  wgrad_body<V>(item, by, bz, sdyn, red, bred, x, dy, dw, db, g, rows_w, accumulate, mask_y, slope);
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -485,36 +502,59 @@ bool conv_fewpos_wgrad_mfma_ok(const ConvGeom& g) {
   return P <= 8192 && Pin < (1 << 24);
 }
 
+// ... and the convs the split-K family never took (C_in or C_out below 16, small
+// filters: the head / tail convs of a network, the first discriminator layer)
+// while their 16 x 16 tiles still find the chip mostly idle: the 16-channel
+// kernel with ragged K.  In bf16 plans these leave the gather-MFMA kernel + its
+// per-step filter pack for exact fp32 products.
+bool conv_fewpos_mfma_small_ok(const s3_ctx* ctx, const ConvGeom& g) {
+  if (s3_opt_has(S3O_NO_FEWPOS_MFMA) || s3_opt_has(S3O_NO_FEWPOS_SMALL)) return false;
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  const int64_t Pin = (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
+  int64_t Pf = g.N;
+  for (int d = 0; d < 3; ++d) Pf *= g.D[d] + 2 * g.lo[d];
+  const int64_t rows_d = g.pad_mode == S3_PAD_REFLECT ? Pf : Pin;
+  const int64_t lim = 4 * (int64_t)ctx->num_cu;
+  return taps <= MAX_TAPS && P <= 4096 && Pin <= 32768 && Pf <= 65536 &&
+         (g.d2s <= 1 || g.Cout % (g.d2s * g.d2s) == 0) &&
+         ((P + 15) / 16) * ((g.Cout + 15) / 16) <= lim && ((rows_d + 15) / 16) * ((g.Cin + 15) / 16) <= lim;
+}
+
 // mode 0: y = act(conv(x) + bias) (+ res), depth-to-space store; mode 1: dx = adjoint(dy)
 int launch_conv_fewpos_mfma(s3_ctx* ctx, const ConvGeom& g, int mode, const float* src,
                             const float* w, const float* bias, const float* res, float* y,
                             const float* mask_y, float slope) {
-  if (mask_y && (mode != 1 || !aligned16(mask_y)))
-    S3_FAIL(ctx, S3_EINVAL, "fewpos mfma: mask operand");
-  if (!aligned16(src) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) ||
-      (res && !aligned16(res)))
-    S3_FAIL(ctx, S3_EINVAL, "fewpos mfma: operand not 16-B aligned");
+  if (mask_y && mode != 1) S3_FAIL(ctx, S3_EINVAL, "fewpos mfma: mask operand");
   const int64_t rows = mode == 0 ? (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] : (int64_t)g.N * g.D[0] * g.D[1] * g.D[2];
   const int K = mode == 0 ? g.Cin : g.Cout, Nc = mode == 0 ? g.Cout : g.Cin;
+  const bool vk = (K & 15) == 0;
   const unsigned rt = (unsigned)((rows + 15) / 16);
-  // 16-channel tiles while that still leaves every workgroup a CU of its own
-  const bool narrow = (int64_t)rt * ((Nc + 15) / 16) <= 2 * ctx->num_cu;
+  // 16-channel tiles while that still leaves the workgroups CUs of their own
+  const bool narrow = !vk || (Nc & 15) != 0 || (int64_t)rt * ((Nc + 15) / 16) <= 4 * ctx->num_cu;
+  if ((vk || !narrow) &&
+      (!aligned16(src) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)) ||
+       (res && !aligned16(res)) || (mask_y && !aligned16(mask_y))))
+    S3_FAIL(ctx, S3_EINVAL, "fewpos mfma: operand not 16-B aligned");
   const dim3 grid(rt, narrow ? (Nc + 15) / 16 : (Nc + 63) / 64);
+  const float* nof = nullptr;
+#define S3_FP16(M, V, B, R, MY, SL)                                                                          \
+  hipLaunchKernelGGL((fewpos_mfma16_kernel<M, V>), grid, dim3(NT), 0, ctx->stream, src, w, B, R, y, g,      \
+                     (int)rows, K, Nc, MY, SL)
   if (mode == 0) {
-    if (narrow)
-      hipLaunchKernelGGL(fewpos_mfma16_kernel<0>, grid, dim3(NT), 0, ctx->stream, src, w, bias, res, y, g,
-                         (int)rows, K, Nc, (const float*)nullptr, 0.f);
+    if (narrow && vk) S3_FP16(0, true, bias, res, nof, 0.f);
+    else if (narrow) S3_FP16(0, false, bias, res, nof, 0.f);
     else
       hipLaunchKernelGGL(fewpos_mfma_kernel<0>, grid, dim3(NT), 0, ctx->stream, src, w, bias, res, y, g,
-                         (int)rows, K, Nc, (const float*)nullptr, 0.f);
+                         (int)rows, K, Nc, nof, 0.f);
   } else {
-    if (narrow)
-      hipLaunchKernelGGL(fewpos_mfma16_kernel<1>, grid, dim3(NT), 0, ctx->stream, src, w, (const float*)nullptr,
-                         (const float*)nullptr, y, g, (int)rows, K, Nc, mask_y, slope);
+    if (narrow && vk) S3_FP16(1, true, nof, nof, mask_y, slope);
+    else if (narrow) S3_FP16(1, false, nof, nof, mask_y, slope);
     else
-      hipLaunchKernelGGL(fewpos_mfma_kernel<1>, grid, dim3(NT), 0, ctx->stream, src, w, (const float*)nullptr,
-                         (const float*)nullptr, y, g, (int)rows, K, Nc, mask_y, slope);
+      hipLaunchKernelGGL(fewpos_mfma_kernel<1>, grid, dim3(NT), 0, ctx->stream, src, w, nof, nof, y, g,
+                         (int)rows, K, Nc, mask_y, slope);
   }
+#undef S3_FP16
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -538,17 +578,19 @@ int launch_conv_fewpos_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x
 
 // whether launch_conv_fewpos_bwd_mfma takes this conv (16-channel dX tiles only)
 bool conv_fewpos_bwd_mfma_ok(const s3_ctx* ctx, const ConvGeom& g, const ConvGeom& gd) {
-  if (!conv_fewpos_mfma_ok(g)) return false;
+  if (!conv_fewpos_mfma_ok(g) && !conv_fewpos_mfma_small_ok(ctx, g)) return false;
   const int64_t rows_d = (int64_t)gd.N * gd.D[0] * gd.D[1] * gd.D[2];
-  return ((rows_d + 15) / 16) * ((gd.Cin + 15) / 16) <= 2 * ctx->num_cu;
+  const int64_t rows_w = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+  return ((rows_d + 15) / 16) * ((gd.Cin + 15) / 16) <= 4 * ctx->num_cu && rows_w <= 8192;
 }
 
 // dx = adjoint(dy) over gd (g or its padded frame) and dw (+)= x^T dy, db (+)= sum dy
 int launch_conv_fewpos_bwd_mfma(s3_ctx* ctx, const ConvGeom& g, const ConvGeom& gd, const float* x,
                                 const float* dy, const float* w, float* dx, float* dw, float* db,
                                 int accumulate, const float* mask_y, float slope) {
-  if (!aligned16(x) || !aligned16(dy) || !aligned16(w) || !aligned16(dx) || !aligned16(dw) ||
-      (mask_y && !aligned16(mask_y)))
+  const bool v = ((g.Cin | g.Cout) & 15) == 0;
+  if (v && (!aligned16(x) || !aligned16(dy) || !aligned16(w) || !aligned16(dx) || !aligned16(dw) ||
+            (mask_y && !aligned16(mask_y))))
     S3_FAIL(ctx, S3_EINVAL, "fewpos bwd mfma: operand not 16-B aligned");
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int64_t rows_w = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
@@ -560,13 +602,19 @@ int launch_conv_fewpos_bwd_mfma(s3_ctx* ctx, const ConvGeom& g, const ConvGeom& 
   const size_t lds = lds_d > lds_w ? lds_d : lds_w;
   static bool attr_set = false;
   if (!attr_set) {
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fewpos_bwd_kernel),
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fewpos_bwd_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fewpos_bwd_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(fewpos_bwd_kernel, dim3((unsigned)(nd_x * nd_y + taps * nw_y * nw_z)), dim3(NT), lds,
-                     ctx->stream, x, dy, w, dx, dw, db, g, gd, (int)rows_d, (int)rows_w, nd_x, nd_y, nw_y, nw_z,
-                     accumulate, mask_y, slope);
+  const dim3 grid((unsigned)(nd_x * nd_y + taps * nw_y * nw_z));
+  if (v)
+    hipLaunchKernelGGL(fewpos_bwd_kernel<true>, grid, dim3(NT), lds, ctx->stream, x, dy, w, dx, dw, db, g, gd,
+                       (int)rows_d, (int)rows_w, nd_x, nd_y, nw_y, nw_z, accumulate, mask_y, slope);
+  else
+    hipLaunchKernelGGL(fewpos_bwd_kernel<false>, grid, dim3(NT), lds, ctx->stream, x, dy, w, dx, dw, db, g, gd,
+                       (int)rows_d, (int)rows_w, nd_x, nd_y, nw_y, nw_z, accumulate, mask_y, slope);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -701,6 +701,12 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
     pl->t[inputs[i]].is_input = true;
   }
   auto bad = [&](const char* m) { ctx->err = m; delete pl; return S3_EINVAL; };
+  // a launch-bound plan: no tensor has more than 4 096 positions (the C1 / toy
+  // training shapes) — every step of it is a chain of ~5 us launches, and the
+  // few-channel head / tail convs go to the one-launch fewpos kernels as well
+  bool plan_tiny = true;
+  for (int i = 0; i < n_tensors; ++i)
+    if (pl->t[i].numel / std::max<int64_t>(1, pl->t[i].dims[4]) > 4096) plan_tiny = false;
   const int np = (int)params->p.size();
   pl->ops.resize(n_ops);
   size_t max_dpre = 0, max_partial = 0, max_t = 0, max_dxp = 0, max_fp = 0;
@@ -735,16 +741,26 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         o.fewpos = !o.mfma && !s3_opt_has(S3O_NO_FEWPOS) && conv_fewpos_supported(g);
         // bf16 plans: the weight-streaming fp32 path only for really few
         // positions; mid-size layers go to the gather-MFMA kernels
+        // (... unless the one-launch fp32-MFMA kernels take the layer while the
+        // chip is mostly idle: no per-step filter pack, no split-K epilogue)
+        // (BF16X3 plans keep their split-bf16 gather-MFMA kernels)
+        // (training plans only: an inference plan's kernels must not change
+        // with the batch size — chunk-by-chunk and batched runs agree bit for bit)
+        const bool fp_small = training && plan_tiny && !o.mfma && !s3_opt_has(S3O_NO_FEWPOS) && precision != S3_PREC_BF16X3 &&
+                              conv_fewpos_mfma_small_ok(ctx, g);
         if (o.fewpos && (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 256 &&
             conv_gconv_supported(g, precision) && conv_gconv_dgrad_supported(g, precision) &&
-            conv_wgrad_gen_supported(g))
+            conv_wgrad_gen_supported(g) && !(fp_small && conv_fewpos_mfma_ok(g)))
           o.fewpos = false;
+        // the few-channel head / tail convs and small filters on those kernels too
+        bool fp_small_taken = false;
+        if (!o.fewpos && fp_small) { o.fewpos = true; fp_small_taken = true; }
         o.gconv = !o.mfma && !o.fewpos && conv_gconv_supported(g, precision);
         o.halo32 = o.gconv && d.res < 0 && conv_halo32_supported(ctx, g, precision);
         o.halo_s2 = o.gconv && d.res < 0 && conv_halo_s2_supported(ctx, g, precision);
         o.tail_x3 = !o.mfma && !o.fewpos && d.res < 0 && conv_tail_x3_supported(g, precision);
         if (o.fewpos) {
-          o.fp_mfma = conv_fewpos_mfma_ok(g);
+          o.fp_mfma = fp_small_taken || conv_fewpos_mfma_ok(g);
           max_fp = std::max(max_fp, conv_fewpos_partial_bytes(g));
           if (training) {
             max_partial = std::max(max_partial, conv_fewpos_wgrad_partial_bytes(g));

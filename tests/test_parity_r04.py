@@ -301,8 +301,9 @@ def test_fewpos_one_launch_mfma_kernels_vs_oracle_and_split_k_family(case, preci
     x = rng.standard_normal(shape).astype(np.float32)
     ref = _oracle(spec, x, None, seed=5)
 
-    def run(old, side=False, fuse=True):
+    def run(old, side=False, fuse=True, small=True):
         switch('NO_FEWPOS_MFMA', 1 if old else None)
+        switch('NO_FEWPOS_SMALL', None if small else 1)
         switch('WGRAD_SIDE_STREAM', 1 if side else None)
         switch('NO_FEWPOS_BWD_FUSE', None if fuse else 1)
         net = _hip(spec, ref.weights, precision)
@@ -327,7 +328,13 @@ def test_fewpos_one_launch_mfma_kernels_vs_oracle_and_split_k_family(case, preci
         np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(a, c)
         np.testing.assert_array_equal(a, d)
+    # (launch-bound plans also route their few-channel head / tail convs to
+    # these kernels — exact fp32 where the gather-MFMA kernel of a bf16 plan
+    # rounds its operands — so the family comparison runs without that routing;
+    # the oracle check above covers it)
+    cmp_new = run(False, small=False)
+    switch('NO_FEWPOS_SMALL', None)
     tol = 2e-5 if precision == 'f32' else 2e-2       # (bf16 plans: other layers round)
-    for i, (a, b) in enumerate(zip(new, old)):
+    for i, (a, b) in enumerate(zip(cmp_new, old)):
         scale = max(float(np.abs(b).max()), 1e-6)
         assert float(np.abs(a - b).max()) / scale < tol, (name, i)
