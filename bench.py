@@ -945,6 +945,14 @@ def main():
         except Exception as e:              # a leg, never the headline
             result['c3'] = {'error': repr(e)[:300]}
         torch.cuda.empty_cache()
+        # the reference's own training test shape (BASELINE.json config 1,
+        # tests/training/test_train_gan.py:45-114): a launch-bound mini-batch
+        try:
+            result['train_c1'] = train_leg('c1', 15, 1, 0, 1.0, 400,
+                                           multi_gpu=False)
+        except Exception as e:
+            result['train_c1'] = {'error': repr(e)[:300]}
+        torch.cuda.empty_cache()
     if single and not args.no_traffic:
         traffic, note = measure_traffic(B)
         result['roofline']['traffic'] = traffic
