@@ -314,6 +314,11 @@ def test_fewpos_one_launch_mfma_kernels_vs_oracle_and_split_k_family(case, preci
         dy = np.random.default_rng(4).standard_normal(y.shape).astype(np.float32)
         dx = p.backward(net.dev.to_device(dy), need_dx=True).cpu().numpy()
         out = [y, dx] + [np.array(g) for g in net.grads]
+        if not old and fuse and not side:
+            # a second shard: the kernels add into dW / db (abstract.py:785-805)
+            p.backward(net.dev.to_device(dy), need_dx=True, accumulate_wgrad=True)
+            for g1, g2 in zip(out[2:], net.grads):
+                np.testing.assert_array_equal(np.array(g2), 2 * g1)
         net.clear_plans()
         return out
     new, new2, ser, old = run(False), run(False), run(False, side=True), run(True)
