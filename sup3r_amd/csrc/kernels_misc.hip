@@ -39,7 +39,7 @@ __global__ void gather_kernel(const T* __restrict__ in, T* __restrict__ out,
     switch (g.kind) {
       case S3_OP_REPEAT_T: i2 = o2 / g.rep; break;
       case S3_OP_ROLL_T: {
-        int s = g.rep % g.Do[2];
+        int s = g.rep % g.Do[2]; if (s < 0) s += g.Do[2];   // tf.roll: any sign
         i2 = o2 - s; if (i2 < 0) i2 += g.Do[2];
       } break;
       case S3_OP_D2S: {
@@ -107,7 +107,7 @@ __global__ void gather_bwd_kernel(const float* __restrict__ dout,
         for (int j = 0; j < g.rep; ++j) acc += at(i0, i1, i2 * g.rep + j, c, g.Co);
         break;
       case S3_OP_ROLL_T: {
-        int s = g.rep % g.Do[2];
+        int s = g.rep % g.Do[2]; if (s < 0) s += g.Do[2];
         int o2 = i2 + s; if (o2 >= g.Do[2]) o2 -= g.Do[2];
         acc = at(i0, i1, o2, c, g.Co);
       } break;

@@ -110,6 +110,8 @@ def run_plan(plan, params, inputs, dtype=np.float64):
             T[op['out']] = y
         elif kind == S.OP_VIEW:
             T[op['out']] = x.reshape(osh)
+        elif kind == S.OP_ROLL_T:
+            T[op['out']] = np.roll(x, op['rep'], axis=3)
         else:
             raise KeyError(kind)
         assert list(T[op['out']].shape) == list(osh), (op, T[op['out']].shape)

@@ -1,0 +1,357 @@
+"""The reference's whole shipped spec surface (``sup3r/configs/**``: 16
+generators + 2 discriminators, authored as data under
+``sup3r_amd/configs/sup3r/`` by ``configs/author_configs.py``) through this
+build, the way ``/root/reference/tests/training/test_load_configs.py:17-133``
+walks it — plus what that file cannot check without an oracle: the numbers.
+
+CPU (``-m "not gpu"``):
+* every authored spec EQUALS the reference's file (only where
+  ``/root/reference`` exists; everything below runs on the shipped copies and
+  is never skipped);
+* the shape contract of ``test_load_configs.py`` on every spec;
+* the fused and the unfused device plan of every spec, interpreted in float64
+  (``tests/plan_interp.py``), against the layer-by-layer oracle;
+* ``temporal_method: depth_to_time`` with ``t_roll`` in {0, m/2, > T, < 0}:
+  the oracle layer against the literal ``reshape`` + ``roll`` statement on
+  exact-integer inputs, the plan ops against the oracle, and the adjoint.
+
+GPU (``-m gpu``): every spec forward + backward through the C-ABI against the
+oracle — fp32 plans: forward L-inf < 1e-4 of the output scale, every gradient
+< 1e-3 of its tensor's largest value under the device's activation masks;
+bf16 plans: per op teacher-forced (at most one bf16 spacing on at most 1 % of
+an op's elements) + 3e-2 end to end, gradients 2e-2 — and the depth_to_time /
+roll kernels bit-exactly on integers.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.network import Network as OracleNet
+from sup3r_amd import spec as S
+from tests.plan_interp import run_plan
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SURFACE = os.path.join(HERE, '..', 'sup3r_amd', 'configs', 'sup3r')
+REF_CFG = '/root/reference/sup3r/configs'
+
+# rel. path -> (low-res input shape for the numeric tests, exo name or None).
+# Shapes follow test_load_configs.py's family ((1, 5, 5, 4, 2), (3, 6, 6, 8, 2),
+# (n, 5, 5, 2)) with unequal s1 / s2 so that a transposed axis cannot pass;
+# the discriminators get the smallest extent that survives four valid
+# stride-1 and four valid stride-2 convolutions (61).
+CASES = {
+    'spatial/disc.json': ((2, 61, 63, 2), None),
+    'spatial/gen_2x_1f.json': ((3, 7, 6, 1), None),
+    'spatial/gen_2x_2f.json': ((3, 7, 6, 2), None),
+    'spatial/gen_10x_2f.json': ((2, 5, 6, 2), None),
+    'spatiotemporal/disc.json': ((1, 61, 62, 61, 2), None),
+    'spatiotemporal/gen_2x_2x_2f.json': ((2, 5, 6, 4, 2), None),
+    'spatiotemporal/gen_2x_12x_14f.json': ((1, 5, 6, 4, 14), None),
+    'spatiotemporal/gen_3x_4x_1f.json': ((2, 5, 6, 4, 1), None),
+    'spatiotemporal/gen_3x_4x_2f.json': ((2, 6, 5, 4, 2), None),
+    'spatiotemporal/gen_3x_4x_10f.json': ((1, 5, 6, 4, 10), None),
+    'spatiotemporal/gen_3x_4x_14f.json': ((1, 6, 5, 4, 14), None),
+    'spatiotemporal/gen_4x_24x_3f.json': ((1, 5, 4, 4, 3), None),
+    'sup3rcc/gen_solar_1x_8x_1f.json': ((2, 6, 5, 4, 3), None),
+    'sup3rcc/gen_trh_1x_24x_2f.json': ((1, 5, 6, 4, 4), None),
+    'sup3rcc/gen_solar_5x_1x_1f.json': ((2, 6, 5, 3), None),
+    'sup3rcc/gen_wind_5x_1x_6f.json': ((2, 5, 6, 4), 'topography'),
+    'sup3rcc/gen_wind_1x_24x_6f.json': ((1, 5, 4, 3, 6), None),
+    'sup3rcc/gen_wind_3x_4x_2f.json': ((2, 5, 6, 4, 2), 'topography'),
+}
+
+
+def load_surface(rel):
+    with open(os.path.join(SURFACE, rel)) as f:
+        return json.load(f)
+
+
+def _enhancements(rel):
+    parts = os.path.basename(rel).replace('.json', '').split('_')
+    nums = [int(p[:-1]) for p in parts if p.endswith('x')]
+    nf = [int(p[:-1]) for p in parts if p.endswith('f')]
+    return nums, (nf[0] if nf else None)
+
+
+def _exo_for(plan, name, rng, dtype):
+    sh = plan.tensors[plan.inputs[name]]
+    keras = tuple(sh) if plan.out_rank == 5 else \
+        (sh[0], sh[1], sh[2], sh[4])
+    return {name: rng.standard_normal(tuple(keras)).astype(dtype)}
+
+
+def test_surface_is_complete():
+    files = sorted(os.path.relpath(p, SURFACE) for p in
+                   glob.glob(os.path.join(SURFACE, '*', '*.json')))
+    assert files == sorted(CASES), files
+    assert sum('gen_' in f for f in files) == 16
+    assert sum('disc' in f for f in files) == 2
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG),
+                    reason='reference configs not present on this box')
+def test_authored_surface_equals_reference():
+    """the authored files are the reference's spec surface, value for value,
+    and the reference ships nothing else there"""
+    ref_files = sorted(os.path.relpath(p, REF_CFG) for p in
+                       glob.glob(os.path.join(REF_CFG, '*', '*.json')))
+    assert ref_files == sorted(CASES)
+    for rel in ref_files:
+        with open(os.path.join(REF_CFG, rel)) as f:
+            assert json.load(f) == load_surface(rel), rel
+
+
+@pytest.mark.parametrize('rel', sorted(c for c in CASES if 'gen_' in c))
+def test_surface_shape_contract(rel):
+    """test_load_configs.py:41-133: output = enhancement x input for the
+    coarse shapes that file uses, features as the file name says"""
+    spec = load_surface(rel)
+    layers = S.parse_layers(spec)
+    nums, nf_out = _enhancements(rel)
+    s_enh = int(np.prod([L._spatial_mult for L in layers]))
+    t_enh = int(np.prod([L._temporal_mult for L in layers]))
+    is_5d = layers[0].rank == 5
+    # sup3rcc 1x/…x and …x/1x names carry both factors; spatial/ only one
+    if len(nums) == 2:
+        assert (s_enh, t_enh) == tuple(nums), rel
+    else:
+        assert (s_enh, t_enh) == (nums[0], 1), rel
+    shapes = ((1, 5, 5, 4, 2), (1, 7, 7, 9, 2), (3, 6, 6, 8, 2)) if is_5d \
+        else ((1, 5, 5, 2), (32, 5, 5, 2), (16, 10, 10, 2))
+    table = None
+    for shape in shapes:
+        plan = S.build_plan(layers, shape, param_table=table)
+        table = table or plan.params
+        out = plan.out_shape
+        assert len(out) == len(shape)
+        assert out[0] == shape[0]
+        assert out[1] == s_enh * shape[1] and out[2] == s_enh * shape[2]
+        if is_5d:
+            assert out[3] == t_enh * shape[3]
+        assert out[-1] == nf_out
+
+
+@pytest.mark.parametrize('rel', sorted(CASES))
+@pytest.mark.parametrize('fuse', [True, False])
+def test_surface_plan_matches_oracle(rel, fuse):
+    """the device plan (fused: virtual pads, epilogues, d2s stores; unfused:
+    one op per layer) interpreted in float64 == the layer-by-layer oracle"""
+    shape, exo_name = CASES[rel]
+    spec = load_surface(rel)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(shape)
+    layers = S.parse_layers(spec)
+    plan = S.build_plan(layers, shape, fuse=fuse)
+    exo = _exo_for(plan, exo_name, rng, np.float64) if exo_name else None
+    net = OracleNet(spec)
+    net.init_weights(x, exo, seed=3, bias_scale=0.1)
+    net.cast(np.float64)
+    y_ref = net.forward(x, exo)
+    assert tuple(plan.out_shape) == y_ref.shape
+    assert [tuple(p['shape']) for p in plan.params] == \
+        [w.shape for w in net.weights]
+    params = [np.asarray(w, np.float64) if p['layout'] == S.WL_CONV
+              else S.keras_to_canonical(w, p['layout']).astype(np.float64)
+              for w, p in zip(net.weights, plan.params)]
+    inputs = {'x': x}
+    inputs.update(exo or {})
+    y = run_plan(plan, params, inputs)
+    # ConvT canonical arrays went through float32
+    np.testing.assert_allclose(y, y_ref, rtol=0,
+                               atol=5e-6 * max(1.0, np.abs(y_ref).max()))
+    if fuse and 'gen_' in rel:
+        assert not any(op['kind'] in (S.OP_PAD, S.OP_CROP)
+                       for op in plan.ops)
+
+
+# ---------------------------------------------------------------- depth_to_time
+def _d2t_literal(x, m, roll):
+    """phygnn SpatioTemporalExpansion(temporal_method='depth_to_time'):
+    ``tf.reshape(x, (n, s1, s2, t * m, c // m))`` then ``tf.roll(x, t_roll,
+    axis=3)`` — out[..., (t m + j + roll) mod (T m), c'] = in[..., t,
+    j (c / m) + c']"""
+    n, s1, s2, t, c = x.shape
+    out = np.empty((n, s1, s2, t * m, c // m), x.dtype)
+    for ti in range(t):
+        for j in range(m):
+            out[:, :, :, (ti * m + j + roll) % (t * m)] = \
+                x[:, :, :, ti, j * (c // m):(j + 1) * (c // m)]
+    return out
+
+
+D2T = [(4, 0), (4, 2), (8, 4), (3, 17), (6, -5), (2, 12)]   # (mult, t_roll)
+
+
+@pytest.mark.parametrize('m,roll', D2T)
+def test_depth_to_time_oracle_and_plan_on_integers(m, roll):
+    spec = [{'class': 'SpatioTemporalExpansion', 'temporal_mult': m,
+             'temporal_method': 'depth_to_time', 't_roll': roll}]
+    shape = (2, 3, 4, 3, 2 * m)
+    x = np.arange(int(np.prod(shape)), dtype=np.float64).reshape(shape)
+    want = _d2t_literal(x, m, roll)
+    net = OracleNet(spec)
+    y = net.forward(x)
+    np.testing.assert_array_equal(y, want)
+    plan = S.build_plan(S.parse_layers(spec), shape)
+    kinds = [op['kind'] for op in plan.ops]
+    assert kinds[0] == S.OP_VIEW
+    assert (S.OP_ROLL_T in kinds) == (roll % (shape[3] * m) != 0)
+    np.testing.assert_array_equal(run_plan(plan, [], {'x': x}), want)
+    # adjoint: <dy, f(x)> == <f^T(dy), x>, and f^T f = identity (permutation)
+    dy = np.arange(want.size, dtype=np.float64).reshape(want.shape)[::-1] + 1
+    dx = net.backward(dy)
+    assert dx.shape == x.shape
+    assert float((dy * want).sum()) == float((dx * x).sum())
+    np.testing.assert_array_equal(net.backward(want), x)
+
+
+def test_depth_to_time_needs_divisible_channels():
+    spec = [{'class': 'SpatioTemporalExpansion', 'temporal_mult': 4,
+             'temporal_method': 'depth_to_time'}]
+    with pytest.raises(RuntimeError, match='divisible by the temporal'):
+        S.build_plan(S.parse_layers(spec), (1, 3, 3, 2, 6))
+    with pytest.raises(KeyError, match='no kernel mapping'):
+        S.build_plan(S.parse_layers([
+            {'class': 'SpatioTemporalExpansion', 'temporal_mult': 2,
+             'temporal_method': 'bilinear'}]), (1, 3, 3, 2, 6))
+
+
+PAD_CROP = [
+    # sup3rcc/gen_wind_1x_24x_6f head: pad 2 / crop 1
+    ([2, 2, 2], 1, (2, 5, 6, 4, 3)),
+    # sup3rcc/gen_solar_1x_8x_1f: pad [3, 3, 2] / crop [2, 2, 1]
+    ([3, 3, 2], [2, 2, 1], (2, 6, 5, 3, 3)),
+    # asymmetric leftover: pad 3 / crop [2, 1, 2] grows s2 by 2
+    ([3, 3, 3], [2, 1, 2], (1, 5, 4, 4, 2)),
+]
+
+
+@pytest.mark.parametrize('pad,crop,shape', PAD_CROP)
+@pytest.mark.parametrize('fuse', [True, False])
+def test_pad_crop_variants_plan_matches_oracle(pad, crop, shape, fuse):
+    from sup3r_amd.configs.author_configs import pcc
+    spec = pcc(3, 5, pad=pad, crop=crop) + pcc(3, 4, pad=pad, crop=crop,
+                                               act=False)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape)
+    net = OracleNet(spec)
+    net.init_weights(x, seed=1, bias_scale=0.1)
+    net.cast(np.float64)
+    y_ref = net.forward(x)
+    plan = S.build_plan(S.parse_layers(spec), shape, fuse=fuse)
+    y = run_plan(plan, [np.asarray(w, np.float64) for w in net.weights],
+                 {'x': x})
+    np.testing.assert_allclose(y, y_ref, rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------------ GPU
+def _fwd_bwd(spec, shape, precision, seed, tol_y, tol_g, exo_name=None):
+    from tests.test_parity_r02 import _fwd_bwd_vs_oracle
+    exo_shape = None
+    if exo_name:
+        plan = S.build_plan(S.parse_layers(spec), shape)
+        exo_shape = _exo_for(plan, exo_name, np.random.default_rng(0),
+                             np.float32)[exo_name].shape
+    return _fwd_bwd_vs_oracle(spec, shape, precision, seed, tol_y, tol_g,
+                              exo_name=exo_name, exo_shape=exo_shape)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rel', sorted(CASES))
+def test_surface_forward_backward_fp32(rel):
+    shape, exo_name = CASES[rel]
+    _fwd_bwd(load_surface(rel), shape, 'f32', 41, 1e-4, 1e-3, exo_name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rel', sorted(CASES))
+def test_surface_forward_backward_bf16(rel):
+    shape, exo_name = CASES[rel]
+    _fwd_bwd(load_surface(rel), shape, 'bf16', 43, 3e-2, 2e-2, exo_name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rel', sorted(c for c in CASES if 'gen_' in c))
+def test_surface_forward_bf16x3_meets_the_fp32_tolerance(rel):
+    """the mode that owns north_star's L-inf < 1e-3: every shipped generator"""
+    from tests.helpers import rel_linf
+    from tests.test_parity_r02 import _hip, _oracle
+    shape, exo_name = CASES[rel]
+    spec = load_surface(rel)
+    rng = np.random.default_rng(47)
+    x = rng.standard_normal(shape).astype(np.float32)
+    plan = S.build_plan(S.parse_layers(spec), shape)
+    exo = _exo_for(plan, exo_name, rng, np.float32) if exo_name else None
+    ref = _oracle(spec, x, exo, seed=47)
+    y_ref = ref.forward(x, exo)
+    net = _hip(spec, ref.weights, 'bf16x3')
+    dev = net.dev
+    ph = net.plan(shape, training=False)
+    y = ph.forward(dev.to_device(x), {k: dev.to_device(v) for k, v in
+                                      (exo or {}).items()}).cpu().numpy()
+    assert rel_linf(y, y_ref) < 1e-3, rel_linf(y, y_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,roll', D2T)
+def test_depth_to_time_device_is_exact_on_integers(m, roll):
+    """S3_OP_VIEW + S3_OP_ROLL_T forward and adjoint, bit-exact (integers
+    below 2^24 are exact in fp32); 16-byte and scalar channel paths (C / m =
+    2 and 4)"""
+    from sup3r_amd.engine import Network
+    for cmul in (2, 4):
+        spec = [{'class': 'SpatioTemporalExpansion', 'temporal_mult': m,
+                 'temporal_method': 'depth_to_time', 't_roll': roll}]
+        shape = (2, 3, 4, 3, cmul * m)
+        x = np.arange(int(np.prod(shape)), dtype=np.float32).reshape(shape)
+        want = _d2t_literal(x, m, roll)
+        for prec in ('f32', 'bf16'):
+            if prec == 'bf16' and x.max() >= 256:
+                # bf16 storage: integers below 2^8 only
+                x_ = np.mod(x, 251.0).astype(np.float32)
+                want_ = _d2t_literal(x_, m, roll)
+            else:
+                x_, want_ = x, want
+            net = Network(spec, precision=prec)
+            dev = net.dev
+            ph = net.plan(shape, training=True)
+            y = ph.forward(dev.to_device(x_)).cpu().numpy()
+            np.testing.assert_array_equal(y, want_)
+            dy = np.mod(np.arange(want.size, dtype=np.float32)[::-1] * 7,
+                        241.0).reshape(want.shape)
+            dx = ph.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
+            ref = OracleNet(spec)
+            ref.forward(x_)
+            np.testing.assert_array_equal(dx.reshape(shape), ref.backward(dy))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,roll', [(4, 2), (8, 4), (3, 17), (6, -5)])
+def test_depth_to_time_between_convolutions(m, roll):
+    """conv -> depth_to_time (+ roll) -> LeakyReLU -> conv, forward and every
+    gradient: fp32 at 1e-4 / 1e-3, and on 64-channel MFMA convs in bf16"""
+    from sup3r_amd.configs.author_configs import pcc
+    tail = [{'class': 'SpatioTemporalExpansion', 'temporal_mult': m,
+             'temporal_method': 'depth_to_time', 't_roll': roll},
+            {'alpha': 0.2, 'class': 'LeakyReLU'}]
+    spec = pcc(3, 8) + pcc(3, 3 * m, act=False) + tail + pcc(3, 2, act=False)
+    _fwd_bwd(spec, (2, 5, 6, 4, 3), 'f32', 5, 1e-4, 1e-3)
+    spec = pcc(3, 64) + pcc(3, 64, act=False, pad=[3, 3, 2],
+                            crop=[2, 2, 1]) + \
+        pcc(3, 16 * m, act=False) + tail + pcc(3, 2, act=False)
+    _fwd_bwd(spec, (2, 6, 5, 4, 4), 'bf16', 5, 3e-2, 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('pad,crop,shape', PAD_CROP)
+def test_pad_crop_variants_device(pad, crop, shape):
+    from sup3r_amd.configs.author_configs import pcc
+    spec = pcc(3, 5, pad=pad, crop=crop) + pcc(3, 4, pad=pad, crop=crop,
+                                               act=False)
+    _fwd_bwd(spec, shape, 'f32', 9, 1e-4, 1e-3)
+    spec = pcc(3, 64, pad=pad, crop=crop) + pcc(3, 64, pad=pad, crop=crop) + \
+        pcc(3, 4, pad=pad, crop=crop, act=False)
+    _fwd_bwd(spec, shape, 'bf16', 9, 3e-2, 2e-2)
