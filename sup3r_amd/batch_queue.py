@@ -253,9 +253,9 @@ class DeviceBatchQueue:
     # ----------------------------------------------------------- raw batches
     def get_random_container(self):
         with self._rng_lock:                     # (pool workers draw too)
-            self.container_index = int(self._rng.choice(
+            idx = self.container_index = int(self._rng.choice(
                 len(self.containers), p=self.container_weights))
-        return self.containers[self.container_index]
+        return self.containers[idx]
 
     def sample_batch(self):
         """one raw batch from a sampler picked by weight"""

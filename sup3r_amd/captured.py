@@ -29,6 +29,7 @@ structured loss terms (seeded projections), subclasses with their own
 gradient routine, anything that uploads inside the step.  A capture that
 fails falls back to eager for that key with one warning.
 """
+import collections
 import ctypes as C
 import logging
 from warnings import warn
@@ -63,12 +64,59 @@ class StepRecorder:
 
     WARM = 2          # eager runs of a key before it is recorded
     MAX_ELEMS = 1 << 20   # 'auto': hi-res batch elements up to which a step is launch-bound
+    # recorded graphs kept alive at once: each holds its hipGraph and every
+    # buffer of its step.  The key contains values that move during a long
+    # training (the adversarial weight of ``update_adversarial_weights``, a
+    # replaced optimizer, a new plan epoch): the least recently used records
+    # beyond this bound are destroyed, and records that can never be replayed
+    # again (stale plan epoch / options / optimizer objects) go at once.
+    MAX_RECORDS = 6
 
     def __init__(self, compute):
         self.compute = compute
         self.dev = compute.dev
-        self._entries = {}
+        self._entries = collections.OrderedDict()
         self.replays = 0
+        self.evicted = 0
+
+    def _state_digest(self, model, nets):
+        """what is baked into a recorded graph beyond shapes: the content-loss
+        terms (kinds, weights and kwargs are kernel arguments and part of the
+        LossFuture recipe), each network's precision (selects the plan) and
+        whether D(hi_res_true) may be shared between the two steps"""
+        def term(t):
+            name, kind, weight, kw = t
+            return (str(name), repr(kind), float(weight),
+                    tuple(sorted((str(k), repr(v))
+                                 for k, v in (kw or {}).items())))
+        return (tuple(term(t) for t in model._loss_terms),
+                tuple(str(getattr(n, 'precision', None)) for n in nets),
+                bool(getattr(self.compute, 'share_dtrue_allowed', True)))
+
+    def _prune(self, live):
+        """drop the records no key can reach any more, then the least recently
+        used ones beyond MAX_RECORDS (``live`` = (options_key, plan epochs,
+        optimizer ids) of the step being run)"""
+        stale = [k for k in self._entries if (k[2], k[3]) != live[:2]
+                 or not set(i for i, _ in k[4]) <= live[2]]
+        for k in stale:
+            self._drop(k)
+        recorded = [k for k, e in self._entries.items() if e['rec'] is not None]
+        for k in recorded[:max(0, len(recorded) - self.MAX_RECORDS)]:
+            self._drop(k)
+        # un-recorded bookkeeping entries are tiny but unbounded too
+        while len(self._entries) > 8 * self.MAX_RECORDS:
+            self._drop(next(iter(self._entries)))
+
+    def _drop(self, key):
+        ent = self._entries.pop(key, None)
+        if ent and ent['rec'] is not None:
+            rec, ent['rec'] = ent['rec'], None
+            if rec.graph:
+                _lib.lib().s3_graph_destroy(rec.graph)
+                rec.graph = None
+            rec.retained = []
+            self.evicted += 1
 
     # ------------------------------------------------------------------ use
     def eligible(self, model, batch, mode, multi_gpu):
@@ -85,18 +133,28 @@ class StepRecorder:
             return n <= self.MAX_ELEMS
         return True
 
-    def run(self, batch, key, optimizers, body):
+    def run(self, batch, key, optimizers, body, model=None):
         """``body(resident batch) -> [LossFuture, ...]`` is the eager step;
         returns its futures — from a replay once ``key`` has been seen
         ``WARM`` times."""
         nets = [n for n in (self.compute.gen, self.compute.disc)
                 if n is not None]
+        epochs = tuple(getattr(n, 'plan_epoch', 0) for n in nets)
         key = (tuple(batch.low_res.shape), tuple(batch.high_res.shape),
-               self.dev.options_key,
-               tuple(getattr(n, 'plan_epoch', 0) for n in nets),
-               tuple((id(o), o.KIND) for o in optimizers)) + tuple(key)
+               self.dev.options_key, epochs,
+               tuple((id(o), o.KIND) for o in optimizers),
+               self._state_digest(model, nets) if model is not None else ()
+               ) + tuple(key)
+        live_opts = set(id(o) for o in optimizers)
+        if model is not None:
+            live_opts |= {id(getattr(model, a, None))
+                          for a in ('optimizer', 'optimizer_disc')}
+        live = (self.dev.options_key, epochs, live_opts)
+        if key not in self._entries:
+            self._prune(live)
         ent = self._entries.setdefault(key, {'seen': 0, 'rec': None,
                                              'bad': False})
+        self._entries.move_to_end(key)
         if ent['rec'] is None:
             ready = all(o.iterations >= 1 for o in optimizers)
             if ent['bad'] or ent['seen'] < self.WARM or not ready:
@@ -111,6 +169,7 @@ class StepRecorder:
                 return body(self._resident(batch))
             logger.debug('recorded a training step: %d graph nodes',
                          ent['rec'].nodes)
+            self._prune(live)     # the new record is the most recent one
         return self._replay(ent['rec'], batch, nets)
 
     # ------------------------------------------------------------- internals

@@ -19,6 +19,7 @@
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 
+#include <chrono>
 #include <mutex>
 
 #include "common.h"
@@ -80,15 +81,24 @@ extern "C" int s3_dma_wait(s3_ctx* ctx, uint64_t ticket, int timeout_ms) {
   if (!ctx || !ticket) return S3_EINVAL;
   hsa_signal_t sig;
   sig.handle = ticket;
-  // (the timeout hint is in timestamp ticks; poll in slices of blocked waits)
-  const uint64_t slice = 100000000ull;   // generous; re-armed until the deadline
+  // The wait hint of hsa_signal_wait is in ticks of the HSA system timestamp:
+  // its frequency is queried, not assumed; the deadline itself is wall time.
+  uint64_t freq = 0;
+  if (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq) != HSA_STATUS_SUCCESS || freq == 0)
+    freq = 100000000ull;
+  const uint64_t slice = freq / 10 ? freq / 10 : 1;   // blocked waits of ~100 ms
+  const auto t0 = std::chrono::steady_clock::now();
   hsa_signal_value_t v = 1;
-  int64_t left_ms = timeout_ms > 0 ? timeout_ms : INT64_MAX;
   while (true) {
     v = hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, slice, HSA_WAIT_STATE_BLOCKED);
     if (v < 1) break;
-    left_ms -= 100;
-    if (left_ms <= 0) S3_FAIL(ctx, S3_ESTATE, "dma_wait: deadline passed, the copy has not completed");
+    if (timeout_ms > 0) {
+      const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(
+          std::chrono::steady_clock::now() - t0).count();
+      // the copy may still land: the signal is left alive (its destination must
+      // not be reused — the caller retires that buffer), the ticket stays valid
+      if (ms >= timeout_ms) S3_FAIL(ctx, S3_ESTATE, "dma_wait: deadline passed, the copy has not completed");
+    }
   }
   hsa_signal_destroy(sig);
   if (v < 0) S3_FAIL(ctx, S3_EHIP, "dma_wait: the copy engine reported an error");

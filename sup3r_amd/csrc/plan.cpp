@@ -257,6 +257,8 @@ extern "C" int s3_ctx_create(int device_id, void* stream, int create_stream,
 extern "C" void s3_ctx_destroy(s3_ctx* ctx) {
   if (!ctx) return;
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  for (void* p : ctx->retired) (void)hipFree(p);   // scratch blocks outgrown while a graph held them
+  ctx->retired.clear();
   if (ctx->capturing) (void)s3_capture_abort(ctx);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   if (ctx->wg_stream) (void)hipStreamDestroy(ctx->wg_stream);

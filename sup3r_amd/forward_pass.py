@@ -693,14 +693,30 @@ class ForwardPass:
         only the files are wanted (``run``).
 
         ``output_data`` of a device batch is a VIEW into a ring of pinned
-        delivery buffers (``d2h_ring`` per output shape, filled by the SDMA
-        engines): it stays valid until two further batches have been yielded —
-        consume it (write it, place it) or copy it before asking for more
-        than that.  ``run`` / ``run_chunk`` hand out copies."""
+        delivery buffers (``d2h_ring`` = 4 per output shape and per running
+        generator, filled by the SDMA engines): it stays valid while the next
+        ``d2h_ring - 2`` = two batches are yielded — consume it (write it,
+        place it) or copy it before asking for more than that, and do not keep
+        it past ``release_delivery_buffers``.  ``run`` / ``run_chunk`` hand
+        out copies."""
         import collections
 
         pending = collections.deque()
+        # the delivery rings belong to THIS generator: two interleaved
+        # ``iter_chunks`` runs (threads, two models with one output shape)
+        # get different lanes, consecutive runs reuse lane 0's pinned buffers
+        lane = cls._take_lane()
+        try:
+            yield from cls._iter_chunks_lane(
+                chunks, model, allowed_const, batch, invert_uv, nn_fill, meta,
+                output_workers, return_data, write, pending, lane)
+        finally:
+            cls._lanes.discard(lane)
 
+    @classmethod
+    def _iter_chunks_lane(cls, chunks, model, allowed_const, batch, invert_uv,
+                          nn_fill, meta, output_workers, return_data, write,
+                          pending, lane):
         def flush(keep):
             # the newest batch is on the device's queue: the one before it may
             # start crossing PCIe (its forward is the one running or done)
@@ -716,7 +732,7 @@ class ForwardPass:
                 if group:
                     pending.append(cls._launch_chunk_batch(
                         group, model, allowed_const, invert_uv, nn_fill, meta,
-                        output_workers, return_data, write))
+                        output_workers, return_data, write, lane))
                     group, shape = [], None
                     yield from flush(0)
                 yield cls._run_chunk_host(chunk, model, allowed_const,
@@ -731,7 +747,7 @@ class ForwardPass:
             if group and (key != shape or len(group) >= batch):
                 pending.append(cls._launch_chunk_batch(
                     group, model, allowed_const, invert_uv, nn_fill, meta,
-                    output_workers, return_data, write))
+                    output_workers, return_data, write, lane))
                 group = []
                 yield from flush(2)
             group.append(chunk)
@@ -739,7 +755,7 @@ class ForwardPass:
         if group:
             pending.append(cls._launch_chunk_batch(
                 group, model, allowed_const, invert_uv, nn_fill, meta,
-                output_workers, return_data, write))
+                output_workers, return_data, write, lane))
         yield from flush(0)
 
     @classmethod
@@ -787,7 +803,7 @@ class ForwardPass:
     @classmethod
     def _launch_chunk_batch(cls, group, model, allowed_const, invert_uv,
                             nn_fill, meta, output_workers, return_data,
-                            write):
+                            write, lane=0):
         """Enqueue one batch of equal-shaped chunks; returns the closure that
         waits for it and yields its ``(chunk, failed, output_data)``."""
         import ctypes as C
@@ -943,7 +959,9 @@ class ForwardPass:
             if not return_data or state['host'] is not None:
                 return
             ready.synchronize()
-            host_ptr, host_arr = cls._delivery_buffer(dev, tuple(yc.shape))
+            host_ptr, host_arr = cls._delivery_buffer(
+                dev, tuple(yc.shape), lane)
+            state['host_ptr'] = host_ptr
             ticket = C.c_uint64()
             rc = -1
             if cls.sdma_delivery:
@@ -1002,12 +1020,20 @@ class ForwardPass:
                 rc = L.s3_dma_wait(dev.ctx, state['ticket'],
                                    int(dev.comm_timeout_s * 1000))
                 state['ticket'] = None
+                if rc != 0:
+                    # the engine may still write into that buffer: it leaves
+                    # the ring for good (never reused, never freed)
+                    cls._retire_delivery_buffer(dev, tuple(yc.shape), lane,
+                                                state['host_ptr'])
                 _lib.check(rc, dev.ctx, 's3_dma_wait')
             elif state.get('copy_ev') is not None:
                 state['copy_ev'].synchronize()
             for k, chunk in enumerate(group):
-                # (a view into the executor's ring of delivery buffers: valid
-                # until ``d2h_ring - 3`` further batches have been yielded)
+                # (a view into this generator's ring of delivery buffers:
+                # valid while the next ``d2h_ring - 2`` batches are yielded —
+                # batch k + d2h_ring claims the buffer of batch k when batch
+                # k + d2h_ring + 1 is enqueued, just before k + d2h_ring - 1
+                # is handed out)
                 yield (chunk, fails[k],
                        host_arr[k] if host_arr is not None else None)
         finish.deliver = deliver
@@ -1051,6 +1077,24 @@ class ForwardPass:
     window_forward = True
     _aff_cache = {}
     _delivery = {}
+    _lanes = set()
+    _lane_lock = __import__('threading').Lock()
+
+    @classmethod
+    def _take_lane(cls):
+        with cls._lane_lock:
+            lane = 0
+            while lane in cls._lanes:
+                lane += 1
+            cls._lanes.add(lane)
+        return lane
+
+    @classmethod
+    def _retire_delivery_buffer(cls, dev, shape, lane, ptr):
+        ring = cls._delivery.get((dev.index, shape, lane))
+        if ring:
+            ring['bufs'] = [b for b in ring['bufs'] if b[0] != ptr]
+            ring['next'] = 0
 
     @classmethod
     def _affine_tensor(cls, dev, scale, shift):
@@ -1074,18 +1118,18 @@ class ForwardPass:
         from . import _lib
         from .engine import Device
         import ctypes as C
-        for (index, _), ring in list(cls._delivery.items()):
+        for (index, _, _), ring in list(cls._delivery.items()):
             dev = Device.get(index)
             for ptr, _arr in ring['bufs']:
                 _lib.lib().s3_host_free(dev.ctx, C.c_void_p(ptr))
         cls._delivery.clear()
 
     @classmethod
-    def _delivery_buffer(cls, dev, shape):
+    def _delivery_buffer(cls, dev, shape, lane=0):
         import ctypes as C
 
         from . import _lib
-        key = (dev.index, shape)
+        key = (dev.index, shape, lane)
         ring = cls._delivery.setdefault(key, {'bufs': [], 'next': 0})
         if len(ring['bufs']) < cls.d2h_ring:
             n = int(np.prod(shape))

@@ -839,7 +839,8 @@ class Sup3rGan:
             opts = ([self.optimizer] if do_gen else []) + \
                 ([self.optimizer_disc] if do_disc else [])
             steps = rec.run(batch, (do_gen, do_disc, bool(train_disc),
-                                    float(weight_gen_advers)), opts, body)
+                                    float(weight_gen_advers)), opts, body,
+                            model=self)
         else:
             # one upload per mini-batch: both steps read the same device
             # tensors (and the discriminator's pass over the true field is

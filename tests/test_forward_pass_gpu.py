@@ -272,6 +272,52 @@ def test_iter_chunks_views_stay_valid_for_two_batches():
                 np.testing.assert_array_equal(arr, ref[idx])
 
 
+def test_interleaved_generators_do_not_share_a_delivery_ring():
+    """two ``iter_chunks`` generators advanced in lock step over the same
+    output shape (the rings were class-level, keyed by shape
+    only): each keeps the documented two-batch life time, because each owns a
+    lane of the ring table; a finished generator gives its lane back"""
+    from sup3r_amd import ForwardPass
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    model = _model()
+    rng = np.random.default_rng(14)
+    doms = [rng.standard_normal((12, 12, 40, 2)).astype(np.float32)
+            for _ in range(2)]
+    register_model('Sup3rGan', {'model_dir': 'lane-test'}, model)
+    fwps, ids = [], None
+    for dom in doms:
+        st = ArrayStrategy(dom, {'model_dir': 'lane-test'}, (6, 6, 4),
+                           spatial_pad=1, temporal_pad=1, max_nodes=1,
+                           model=model)
+        fwps.append(ForwardPass(st, 0))
+        ids = [int(i) for i in st.node_chunks[0]]
+    refs = []
+    for fwp in fwps:
+        refs.append({c.index: np.array(d) for c, _, d in
+                     ForwardPass.iter_chunks(
+                         (fwp.get_input_chunk(i) for i in ids), model,
+                         batch=2)})
+    assert not ForwardPass._lanes
+    gens = [ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids),
+                                    model, batch=2) for fwp in fwps]
+    held = [[], []]
+    for step in range(len(ids)):
+        for g in range(2):
+            c, failed, d = next(gens[g])
+            held[g].append((c.index, d))
+            now = (len(held[g]) - 1) // 2
+            for pos, (idx, arr) in enumerate(held[g]):
+                if pos // 2 >= now - 2:
+                    np.testing.assert_array_equal(arr, refs[g][idx])
+        if step == 0:
+            assert ForwardPass._lanes == {0, 1}
+    for g in gens:
+        assert next(g, None) is None
+    assert not ForwardPass._lanes
+    ForwardPass.release_delivery_buffers()
+
+
 # ------------------------------------------- the reference's entry points
 def _topo_model(tmp_path=None):
     """a topography-conditioned 3x / 4x generator (Sup3rConcat mid-network)"""
