@@ -293,7 +293,11 @@ enum {
   S3_FWD_GCONV_FEWCH = 4, S3_FWD_HALO32 = 5, S3_FWD_FEWPOS = 6, S3_FWD_TAIL_MFMA = 7,
   S3_FWD_SMALL = 8,
   S3_FWD_FUSED2D = 9, /* the whole op list in one launch (small 2-D stacks) */
-  S3_FWD_HALO_S2 = 10 /* C_in = 32 stride-2 valid conv on an LDS halo          */
+  S3_FWD_HALO_S2 = 10, /* C_in = 32 stride-2 valid conv on an LDS halo         */
+  S3_FWD_MFMA_GEN = 11, /* halo-tile MFMA over logical axes: 2-D nets, few time steps,
+                           any C_in <= 256 / C_out (kernels_conv_mfma_gen.hip)     */
+  S3_FWD_CONV2D_WS = 12 /* weights-stationary persistent Conv2D, all-bf16 64 -> 64 k
+                           trunks of the 2-D generators (kernels_conv2d_ws.hip)    */
 };
 enum {
   S3_WGRAD_DIRECT = 0, S3_WGRAD_F32_TRUNK = 1, S3_WGRAD_BF16_TRUNK = 2, S3_WGRAD_F32_GEN = 3,

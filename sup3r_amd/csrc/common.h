@@ -62,6 +62,8 @@
   X(NO_HALO32) \
   X(NO_HALO_S2) \
   X(NO_MASK_FUSE) \
+  X(NO_MFMA_GEN) \
+  X(NO_CONV2D_WS) \
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \
@@ -191,6 +193,16 @@ struct ConvGeom {
   // repeat factor (in_rep == res_rep when both are set), 2, 3 or 4: the
   // kernel variants carry it as a compile-time constant
   int res_rep = 0;
+  // halo-tile kernel, GEN instantiations (kernels_conv_mfma_gen.hip): N, D, O,
+  // k, lo above are LOGICAL axes (a0, a1, a2) — a permutation of the tensor's
+  // (n, s1, s2, t) chosen so that a2 is a long axis (the 16-position run) and
+  // a k = 1 axis / the batch is a0.  xs / xn: input cell strides of the three
+  // axes / of the logical batch; ys / yn: the same for the FINAL output tensor
+  // (depth-to-space applied: a blocked axis' stride carries the factor b);
+  // yb: cell offsets of a unit step inside the b x b block (block row, column)
+  int gen = 0;
+  int64_t xn = 0, yn = 0;
+  int64_t xs[3] = {0, 0, 0}, ys[3] = {0, 0, 0}, yb[2] = {0, 0};
 };
 
 // generic gather op (pad / crop / repeat / roll / d2s / concat): out <- in
@@ -271,6 +283,22 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
                          const void* x, const void* packed, const float* bias,
                          const void* res, void* y, ConvIO io);
 bool conv_mfma_bf16_out_ok(const ConvGeom& g);
+// logical-axes instantiations (kernels_conv_mfma_gen.hip): 2-D nets, few time
+// steps, any C_in <= 256 / C_out; bf16 and BF16X3 plans, forward only
+bool conv_mfma_gen_supported(const ConvGeom& g, int precision);
+bool conv_mfma_is_gen(const ConvGeom& g, int precision);   // supported AND not a trunk geometry
+size_t conv_mfma_gen_packed_bytes(const ConvGeom& g, int precision);
+int launch_conv_mfma_gen_pack(s3_ctx* ctx, const ConvGeom& g, int precision, const float* w, void* packed);
+int launch_conv_mfma_gen_fwd(s3_ctx* ctx, const ConvGeom& g, int precision, const void* x, const void* packed,
+                             const float* bias, const void* res, void* y, ConvIO io);
+// weights-stationary persistent 2-D conv for the all-bf16 64 -> 64 k trunks of
+// the spatial generators (kernels_conv2d_ws.hip); physical 2-D geometry
+bool conv2d_ws_geom_ok(const ConvGeom& g);
+bool conv2d_ws_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);
+size_t conv2d_ws_image_bytes(const ConvGeom& g);
+int launch_conv2d_ws_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
+int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias,
+                     const void* res, void* y);
 // persistent wave-specialised variant for the all-bf16 64 -> 64 trunk; its
 // filter image (LDS layout) is appended to the packed buffer of the conv
 bool conv_mfma_persist_geom_ok(const ConvGeom& g);

@@ -1,0 +1,364 @@
+// Weights-stationary persistent Conv2D for the bf16 trunks of the 2-D
+// generators (sup3r/configs/spatial/gen_*: Conv2DTranspose 64 -> 64 x 33 + the
+// 64 -> 256 / 1600 expansion convs; sup3rcc/gen_{solar,wind}_5x_1x_*: Conv2D),
+// gfx950 only.  bf16 cells in and out, 3 x 3, stride 1, 'same' extents with
+// REFLECT boundary (the fused pad / conv / crop group), C_in = 64, C_out a
+// multiple of 64.
+//
+// Why not the halo-tile kernel (conv_mfma_tile.h): with 9 taps instead of 27 a
+// tile's MFMA time (0.43 us per tap) is shorter than the L2 latency of the
+// next tap's 8 KB filter slab, so its one-barrier-per-tap ring is bound by
+// nine exposed slab loads per tile (measured: 269 TFLOP/s on the 75 x 75 x 48
+// chunk of config_fwp_spatial.json).  But nine slabs are only 72 KB: they fit
+// in LDS next to one halo.  So here
+//
+//   * ONE 8-wave workgroup per CU loads the 9 x [64 x 64] bf16 filter image of
+//     its 64-channel output tile ONCE and keeps it (weights-stationary), then
+//     walks a contiguous list of 2 images x 16 rows x 16 columns position
+//     tiles (the time axis of a ForwardPass chunk is the batch axis of a 2-D
+//     net: /root/reference/sup3r/pipeline/forward_pass.py:274-337);
+//   * the NEXT tile's 2 x 18 x 18 halo (81 KB) is fetched into registers (11
+//     16-B loads per lane) before the 9-tap loop and dropped into LDS after
+//     it: HBM latency hides under the MFMAs, no barrier inside the tap loop;
+//   * MFMA operands are swapped as in kernels_conv_mfma_persist.hip (A =
+//     filter rows in a permuted order, B = positions): a lane's accumulators
+//     are 8 consecutive output channels of one position per pair of N
+//     fragments — bias, activation, skip add and the 16-B bf16 store happen
+//     from registers (depth-to-space is a store permutation: C_out / b^2 is a
+//     multiple of 8 wherever the plan stores bf16).
+//
+// LDS: halo 648 cells x 128 B | 9 slabs x 8 KB | 64 biases = 156,928 B.
+// Swizzles as in conv_mfma_tile.h (halo chunk ^ (cell column & 7), slab chunk
+// ^ ((row >> 1) & 7)): every ds_read_b128 is conflict-free.  Per wave and
+// (tap, k-step): 4 filter + 4 position fragments for 16 MFMAs — the 1 : 2
+// LDS-read : MFMA issue ratio of the 3-D trunk kernel.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WT_I = 2, WT_R = 16, WT_C = 16;       // tile: images x rows x columns
+constexpr int WH_R = WT_R + 2, WH_C = WT_C + 2;     // 18 x 18 halo per image
+constexpr int WHP = WT_I * WH_R * WH_C;             // 648 cells
+constexpr int W_HALO_BYTES = WHP * 128;             // 82,944
+constexpr int W_SLAB_OFF = W_HALO_BYTES;
+constexpr int W_BIAS_OFF = W_SLAB_OFF + 9 * 8192;   // 156,672
+constexpr int W_LDS = W_BIAS_OFF + 256;             // 156,928
+constexpr int W_NT = 512;
+constexpr int W_TRIPS = (WHP * 8 + W_NT - 1) / W_NT;   // 11 16-B chunks per lane
+
+__device__ inline unsigned ws_pk(float a, float b) {
+  hf32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
+}
+__device__ inline float ws_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ inline float ws_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+// LDS slab row rho = nf*16 + kq*4 + r  <->  output channel
+// (nf >> 1)*32 + kq*8 + (nf & 1)*4 + r  (kernels_conv_mfma_persist.hip)
+__device__ __host__ inline int ws_row_cout(int rho) {
+  const int nf = rho >> 4, kq = (rho >> 2) & 3, r = rho & 3;
+  return (nf >> 1) * 32 + kq * 8 + (nf & 1) * 4 + r;
+}
+
+// canonical fp32 w[tap 9][ci 64][co] -> bf16 images [ct][tap][rho 64][ci 64]
+__global__ void pack_ws_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cout,
+                               int n_ct) {
+  const int total = n_ct * 9 * 64 * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int ci = idx & 63, rho = (idx >> 6) & 63, tap = (idx >> 12) % 9, ct = (idx >> 12) / 9;
+    const int co = ct * 64 + ws_row_cout(rho);
+    const float v = co < cout ? w[((size_t)tap * 64 + ci) * cout + co] : 0.f;
+    const int slot = (ci >> 3) ^ ((rho >> 1) & 7);
+    out[(((size_t)ct * 9 + tap) * 64 + rho) * 64 + slot * 8 + (ci & 7)] = (unsigned short)(ws_pk(v, 0.f) & 0xFFFFu);
+  }
+}
+
+struct WsGeom {
+  int N, H, W;         // images, rows, columns
+  int Cout, b, cpo;    // output channels of the conv, depth-to-space block, Cout / b^2
+  int act;
+  float alpha;
+  int tiles_i, tiles_r, tiles_c;
+};
+
+__global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
+    const unsigned short* __restrict__ x, const char* __restrict__ wimg, const float* __restrict__ bias,
+    const unsigned short* __restrict__ res, unsigned short* __restrict__ y, WsGeom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = blockIdx.y;
+  const int frow = lane & 15, kq = lane >> 4;
+
+  // ---- this workgroup's contiguous run of tiles (neighbours share halo
+  // columns: the second read of a column hits this XCD's L2)
+  const int T = g.tiles_i * g.tiles_r * g.tiles_c;
+  int t_cur = (int)(((long long)blockIdx.x * T) / gridDim.x);
+  const int t_end = (int)(((long long)(blockIdx.x + 1) * T) / gridDim.x);
+  if (t_cur >= t_end) return;
+
+  // ---- the filter image of this output-channel tile: 72 KB, once
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(wimg + (size_t)ct * 9 * 8192);
+    uint4* dst = reinterpret_cast<uint4*>(smem + W_SLAB_OFF);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dst[tid + q * W_NT] = src[tid + q * W_NT];
+    if (tid < 64) {
+      const int co = ct * 64 + tid;
+      reinterpret_cast<float*>(smem + W_BIAS_OFF)[tid] = (bias && co < g.Cout) ? bias[co] : 0.f;
+    }
+  }
+
+  // ---- per-lane halo chunks: chunk id tid + 512 q -> (image, row, column,
+  // 16-B chunk) of the halo and its swizzled LDS byte offset.  Recomputed per
+  // trip (a handful of integer ops per 16-B load) rather than kept in 22
+  // registers next to the 44 of the prefetch and the 64 accumulators.
+  auto tile_org = [&](int t, int& i0, int& r0, int& c0) __attribute__((always_inline)) {
+    c0 = (t % g.tiles_c) * WT_C; t /= g.tiles_c;
+    r0 = (t % g.tiles_r) * WT_R; t /= g.tiles_r;
+    i0 = t * WT_I;
+  };
+  // (macros, not lambdas: the prefetch buffer is a loop-local array that must
+  // stay in registers — captured by a lambda it was demoted to scratch, and the
+  // scratch store waited for every load on the spot)
+#define WS_FETCH1(P, q, i0_, r0_, c0_)                                                          \
+  {                                                                                             \
+    /* every lane loads in every trip (lanes past the last chunk re-read a legal cell and do */ \
+    /* not commit it); ragged tiles: the address stays legal (masked at the store) */          \
+    int cl_ = (tid + q * W_NT) >> 3;                                                            \
+    cl_ = cl_ > WHP - 1 ? WHP - 1 : cl_;                                                        \
+    int im_ = i0_ + cl_ / (WH_C * WH_R);                                                        \
+    int r_ = s3_reflect(r0_ + (cl_ / WH_C) % WH_R - 1, g.H);                                    \
+    int c_ = s3_reflect(c0_ + cl_ % WH_C - 1, g.W);                                             \
+    im_ = im_ > g.N - 1 ? g.N - 1 : im_;                                                        \
+    r_ = r_ < 0 ? 0 : (r_ > g.H - 1 ? g.H - 1 : r_);                                            \
+    c_ = c_ < 0 ? 0 : (c_ > g.W - 1 ? g.W - 1 : c_);                                            \
+    const unsigned cell_ = ((unsigned)im_ * g.H + r_) * g.W + c_; /* < 2^25 */                  \
+    P = *reinterpret_cast<const uint4*>(x + (size_t)cell_ * 64 + (tid & 7) * 8);                \
+  }
+  // (named registers, not an array: an array that lives across the tap loop
+  // was demoted to scratch, and each scratch store waited for its load)
+#define WS_FETCH(T)                                                                             \
+  {                                                                                             \
+    int i0_, r0_, c0_;                                                                          \
+    tile_org((T), i0_, r0_, c0_);                                                               \
+    WS_FETCH1(p0, 0, i0_, r0_, c0_) WS_FETCH1(p1, 1, i0_, r0_, c0_) WS_FETCH1(p2, 2, i0_, r0_, c0_)   \
+    WS_FETCH1(p3, 3, i0_, r0_, c0_) WS_FETCH1(p4, 4, i0_, r0_, c0_) WS_FETCH1(p5, 5, i0_, r0_, c0_)   \
+    WS_FETCH1(p6, 6, i0_, r0_, c0_) WS_FETCH1(p7, 7, i0_, r0_, c0_) WS_FETCH1(p8, 8, i0_, r0_, c0_)   \
+    WS_FETCH1(p9, 9, i0_, r0_, c0_) WS_FETCH1(p10, 10, i0_, r0_, c0_)                           \
+  }
+#define WS_COMMIT1(P, q)                                                                        \
+  if (q * W_NT + tid < WHP * 8) {                                                               \
+    const int cl_ = (tid + q * W_NT) >> 3;                                                      \
+    *reinterpret_cast<uint4*>(smem + cl_ * 128 + (((tid & 7) ^ ((cl_ % WH_C) & 7)) << 4)) = P;  \
+  }
+#define WS_COMMIT()                                                                             \
+  {                                                                                             \
+    WS_COMMIT1(p0, 0) WS_COMMIT1(p1, 1) WS_COMMIT1(p2, 2) WS_COMMIT1(p3, 3) WS_COMMIT1(p4, 4)   \
+    WS_COMMIT1(p5, 5) WS_COMMIT1(p6, 6) WS_COMMIT1(p7, 7) WS_COMMIT1(p8, 8) WS_COMMIT1(p9, 9)   \
+    WS_COMMIT1(p10, 10)                                                                         \
+  }
+  static_assert(W_TRIPS == 11, "prefetch registers p0 .. p10");
+  uint4 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10;
+  WS_FETCH(t_cur);
+  WS_COMMIT();
+  __syncthreads();
+
+  // ---- fragment addresses: wave w = image w >> 2, rows 4 (w & 3) .. + 3
+  // position fragment (B operand) of row m, tap (tb, tc), k-step ks:
+  //   cell (img, 4 (w & 3) + m + tb, frow + tc), chunk (ks 4 + kq) ^ ((frow + tc) & 7)
+  // filter fragment (A operand) nf of tap: row nf 16 + frow, chunk (ks 4 + kq) ^ ((row >> 1) & 7)
+  const int w_img = wave >> 2, w_row = (wave & 3) * 4;
+  unsigned p_addr[3][2], f_addr[4][2];
+#pragma unroll
+  for (int tc = 0; tc < 3; ++tc)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      p_addr[tc][ks] = (unsigned)(((w_img * WH_R + w_row) * WH_C + frow + tc) * 128 +
+                                  (((ks * 4 + kq) ^ ((frow + tc) & 7)) << 4));
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) {
+    const int row = nf * 16 + frow;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      f_addr[nf][ks] = (unsigned)(W_SLAB_OFF + row * 128 + (((ks * 4 + kq) ^ ((row >> 1) & 7)) << 4));
+  }
+  // this lane's output channels: h 32 + kq 8 .. + 7 for h = 0, 1 (inside the tile)
+  const float* bl = reinterpret_cast<const float*>(smem + W_BIAS_OFF);
+  const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+
+  while (true) {
+    const bool has_next = t_cur + 1 < t_end;
+    if (has_next) WS_FETCH(t_cur + 1);
+    // this tile's skip rows (d2s == 1), fetched now: their latency hides under
+    // the tap loop as well
+    int i0, r0, c0;
+    tile_org(t_cur, i0, r0, c0);
+    const int im = i0 + w_img, c = c0 + frow;
+    const bool pos_ok = im < g.N && c < g.W;
+    uint4 rr[4][2];
+    if (res) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        int r = r0 + w_row + m;
+        r = r > g.H - 1 ? g.H - 1 : r;
+        const int imc = im > g.N - 1 ? g.N - 1 : im, cc = c > g.W - 1 ? g.W - 1 : c;
+        const size_t cellr = ((size_t)imc * g.H + r) * g.W + cc;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int co = ct * 64 + h * 32 + kq * 8;
+          co = co > g.Cout - 8 ? g.Cout - 8 : co;
+          rr[m][h] = *reinterpret_cast<const uint4*>(res + cellr * g.Cout + co);
+        }
+      }
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int cb = (nf >> 1) * 32 + kq * 8 + (nf & 1) * 4;
+      const f32x4 b4 = {bl[cb], bl[cb + 1], bl[cb + 2], bl[cb + 3]};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m][nf] = b4;
+    }
+    // (tried: (tc, k-step) outermost with the six halo rows m + tb read once
+    // and shared by the three taps — 18 instead of 24 fragment reads per 48
+    // MFMAs, but 32 spilled registers: 519 instead of 899 TFLOP/s at 512 x 64 x 64)
+#pragma unroll 1
+    for (int tb = 0; tb < 3; ++tb) {
+#pragma unroll
+      for (int tc = 0; tc < 3; ++tc) {
+        const int tap = tb * 3 + tc;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 wf[4], pf[4];
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+            wf[nf] = *reinterpret_cast<const bf16x8*>(smem + f_addr[nf][ks] + tap * 8192);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            pf[m] = *reinterpret_cast<const bf16x8*>(smem + p_addr[tc][ks] + (m + tb) * WH_C * 128);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+              acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], pf[m], acc[m][nf], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue from registers: lane (position column frow, channel
+    // group kq): rows m, halves h -> 8 consecutive channels, one 16-B store
+    {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int r = r0 + w_row + m;
+        if (!pos_ok || r >= g.H) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int co = ct * 64 + h * 32 + kq * 8;
+          if (co >= g.Cout) continue;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = acc[m][2 * h][e]; v[4 + e] = acc[m][2 * h + 1][e]; }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+          size_t dst;
+          if (g.b == 1) {
+            dst = (((size_t)im * g.H + r) * g.W + c) * g.Cout + co;
+          } else {
+            const int blk = co / g.cpo, cc = co % g.cpo;
+            dst = (((size_t)im * (g.H * g.b) + r * g.b + blk / g.b) * (g.W * g.b) + c * g.b + blk % g.b) *
+                      g.cpo + cc;
+          }
+          if (res) {
+            const uint4 q4 = rr[m][h];
+            v[0] += ws_lo(q4.x); v[1] += ws_hi(q4.x); v[2] += ws_lo(q4.y); v[3] += ws_hi(q4.y);
+            v[4] += ws_lo(q4.z); v[5] += ws_hi(q4.z); v[6] += ws_lo(q4.w); v[7] += ws_hi(q4.w);
+          }
+          uint4 o;
+          o.x = ws_pk(v[0], v[1]); o.y = ws_pk(v[2], v[3]); o.z = ws_pk(v[4], v[5]); o.w = ws_pk(v[6], v[7]);
+          *reinterpret_cast<uint4*>(y + dst) = o;
+        }
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();      // every wave is past its last read of this halo
+    WS_COMMIT();
+    __syncthreads();
+    ++t_cur;
+  }
+}
+
+#undef WS_FETCH
+#undef WS_FETCH1
+#undef WS_COMMIT
+#undef WS_COMMIT1
+
+}  // namespace
+
+// physical geometry of a 2-D conv: (N, s1, s2, 1, C), k = (3, 3, 1)
+bool conv2d_ws_geom_ok(const ConvGeom& g) {
+  if (g.Cin != 64 || g.Cout % 64 != 0 || g.Cout < 64) return false;
+  if (g.k[0] != 3 || g.k[1] != 3 || g.k[2] != 1 || g.D[2] != 1 || g.O[2] != 1) return false;
+  if (g.pad_mode != S3_PAD_REFLECT || g.in_cstride || g.in_rep > 1 || g.res_rep > 1) return false;
+  for (int d = 0; d < 2; ++d)
+    if (g.s[d] != 1 || g.lo[d] != 1 || g.O[d] != g.D[d] || g.D[d] < 2) return false;
+  if (g.s[2] != 1 || g.lo[2] != 0) return false;
+  const int b = g.d2s < 1 ? 1 : g.d2s;
+  if (g.Cout % (b * b) != 0 || (g.Cout / (b * b)) % 8 != 0) return false;
+  if (g.act == S3_ACT_LEAKY && !(g.alpha >= 0.f && g.alpha <= 1.f)) return false;
+  // per sample, like the logical-axes kernel it replaces for these layers
+  if ((int64_t)g.O[0] * g.O[1] < 256) return false;
+  return (int64_t)g.N * g.D[0] * g.D[1] * 64 < ((int64_t)1 << 31) &&
+         (int64_t)g.N * g.O[0] * g.O[1] * g.Cout < ((int64_t)1 << 31);
+}
+
+bool conv2d_ws_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res) {
+  if (precision != S3_PREC_BF16 || s3_opt_on(S3O_NO_CONV2D_WS)) return false;
+  if (!io.in_bf16 || !io.out_bf16 || (has_res && !io.res_bf16)) return false;
+  if (has_res && g.d2s > 1) return false;
+  return conv2d_ws_geom_ok(g);
+}
+
+size_t conv2d_ws_image_bytes(const ConvGeom& g) { return (size_t)(g.Cout / 64) * 9 * 8192; }
+
+int launch_conv2d_ws_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image) {
+  const int n_ct = g.Cout / 64;
+  int grid = (n_ct * 9 * 64 * 64 + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(pack_ws_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, (unsigned short*)image, g.Cout, n_ct);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias,
+                     const void* res, void* y) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+    attr_set = true;
+  }
+  WsGeom w;
+  w.N = g.N; w.H = g.D[0]; w.W = g.D[1];
+  w.Cout = g.Cout; w.b = g.d2s < 1 ? 1 : g.d2s; w.cpo = g.Cout / (w.b * w.b);
+  w.act = g.act; w.alpha = g.alpha;
+  w.tiles_i = (g.N + WT_I - 1) / WT_I; w.tiles_r = (w.H + WT_R - 1) / WT_R; w.tiles_c = (w.W + WT_C - 1) / WT_C;
+  const int T = w.tiles_i * w.tiles_r * w.tiles_c, n_ct = g.Cout / 64;
+  // ~one workgroup per CU over all output-channel tiles (each keeps ITS image)
+  int gx = (ctx->num_cu + n_ct - 1) / n_ct;
+  if (gx > T) gx = T;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(conv2d_ws_kernel, dim3(gx, n_ct), dim3(W_NT), W_LDS, ctx->stream,
+                     (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res,
+                     (unsigned short*)y, w);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}

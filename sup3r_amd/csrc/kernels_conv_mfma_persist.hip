@@ -703,6 +703,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
 
 bool conv_mfma_persist_geom_ok(const ConvGeom& g) {
   if (g.Cin != 64 || g.Cout % 8 != 0 || g.Cout < 64 || g.d2s < 1) return false;
+  if (g.D[2] < 8) return false;   // (few time steps: the logical-axes tile kernel, a2 = s2)
   if (g.d2s > 1 && (g.Cout % (g.d2s * g.d2s) != 0 || (g.Cout / (g.d2s * g.d2s)) % 8 != 0))
     return false;
   if (g.pad_mode != S3_PAD_REFLECT) return false;

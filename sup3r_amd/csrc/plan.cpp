@@ -926,6 +926,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
             if (training && d.res >= 0 && fewch_out[root_of(pl, d.res)]) demote(d.res, changed);
             if (o.mfma) {
               if (!conv_mfma_bf16_out_ok(o.cg)) demote(d.out, changed);
+              if (o.cg.Cin % 8 != 0) demote(d.in0, changed);   // (logical-axes kernel: 16-B bf16 chunks)
               // (a saved bf16 input is re-read by the weight gradient: the
               // transpose-read kernels stage bf16 directly)
               if (training && !o.wgrad_bf16 && !(o.wgrad_bf16_gen && !s3_opt_has(S3O_NO_DISC_BF16)))
@@ -1306,7 +1307,7 @@ static int pack_tables_build(s3_plan* pl) {
     if (o.d.kind != S3_OP_CONV) continue;
     const ConvGeom& g = o.cg;
     const bool k3 = g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3;
-    if (o.mfma && o.packed && g.Cin == 64 && k3) {
+    if (o.mfma && o.packed && g.Cin == 64 && k3 && !conv_mfma_is_gen(g, pl->precision)) {
       S3PackJob j;
       j.w = W + P->p[o.d.w].offset;
       j.cout = g.Cout; j.n_ct = (g.Cout + 63) / 64; j.dgrad = 0;
@@ -1637,6 +1638,7 @@ extern "C" int s3_plan_profile_end(s3_plan* pl, float* ms_per_op, int cap) {
 
 extern "C" int s3_plan_op_is_mfma(const s3_plan* pl, int i) {
   if (!pl || i < 0 || i >= (int)pl->ops.size()) return 0;
+  S3OptScope opt_scope(&pl->opt);
   const auto& o = pl->ops[i];
   if (o.d.kind != S3_OP_CONV || !o.mfma) return 0;
   if (pl->precision == S3_PREC_BF16 &&
@@ -1677,7 +1679,9 @@ static int conv_fwd_kind(const s3_plan* pl, const OpRec& o) {
   int fwd = S3_FWD_DIRECT;
   // mirrors run_op_forward / launch_conv_generic_fwd
   if (o.mfma) {
-    fwd = bfp && conv_mfma_persist_supported(pl->ctx, o.cg, o.io, res) ? S3_FWD_MFMA_PERSIST : S3_FWD_MFMA_TILE;
+    fwd = conv_mfma_is_gen(o.cg, pl->precision)
+              ? (conv2d_ws_supported(o.cg, pl->precision, o.io, res) ? S3_FWD_CONV2D_WS : S3_FWD_MFMA_GEN)
+          : bfp && conv_mfma_persist_supported(pl->ctx, o.cg, o.io, res) ? S3_FWD_MFMA_PERSIST : S3_FWD_MFMA_TILE;
   } else if (o.halo32 && !res) {
     fwd = S3_FWD_HALO32;
   } else if (o.halo_s2 && !res && o.io.in_bf16) {
@@ -1700,6 +1704,7 @@ static int conv_fwd_kind(const s3_plan* pl, const OpRec& o) {
 
 extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) {
   if (!pl || !out || i < 0 || i >= (int)pl->ops.size()) return S3_EINVAL;
+  S3OptScope opt_scope(&pl->opt);   // the launch-time kernel switches are the PLAN's options
   const OpRec& o = pl->ops[i];
   int32_t v[S3_OPINFO_COUNT] = {0};
   v[S3_OPINFO_KIND] = o.d.kind;
@@ -1713,7 +1718,7 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
     v[S3_OPINFO_RES_REP] = o.cg.res_rep;
     // operands rounded to bf16 by the forward kernel
     v[S3_OPINFO_FWD_BF16_OPS] = (pl->precision == S3_PREC_BF16 &&
-                                 (fwd == S3_FWD_FUSED2D || fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 || fwd == S3_FWD_HALO_S2 ||
+                                 (fwd == S3_FWD_FUSED2D || fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_GEN || fwd == S3_FWD_CONV2D_WS || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 || fwd == S3_FWD_HALO_S2 ||
                                   fwd == S3_FWD_GCONV || fwd == S3_FWD_GCONV_FEWCH || fwd == S3_FWD_TAIL_MFMA)) ? 1 : 0;
     v[S3_OPINFO_FEWPOS_MFMA] = (o.fp_mfma || o.fp_wg_mfma) ? 1 : 0;
     if (pl->training) {

@@ -17,6 +17,7 @@ import collections
 import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -196,7 +197,7 @@ def main():
                '|---|---|---|---|---|---|---|---|---|---|']
     detail = []
     for rel, shape, origin in SHAPES:
-        if a.only and a.only not in rel:
+        if a.only and not re.search(a.only, rel):
             continue
         for prec in a.precisions.split(','):
             try:
