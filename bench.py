@@ -311,6 +311,74 @@ def c3_leg(batch, steps, warmup, world, rank, entry='strategy'):
 
 
 # ---------------------------------------------------- power / clock evidence
+def fwd2d_leg(dev, steps=20, warmup=3, batch=48, seed=42):
+    """the production shape of the reference's SPATIAL step
+    (examples/sup3rwind/run_configs/wind/config_fwp_spatial.json: chunks of
+    75 x 75 x 38 + temporal_pad 5; a 2-D model sees the 48 time steps as its
+    batch axis, /root/reference/sup3r/pipeline/forward_pass.py:274-337) through
+    the reference's own spatial/gen_2x_2f.json: 33 x Conv2DTranspose 64 -> 64 +
+    64 -> 256 depth-to-space 2 on the weights-stationary Conv2D kernel
+    (kernels_conv2d_ws.hip), head / output conv on the logical-axes tile kernel."""
+    from sup3r_amd import spec as S
+    from sup3r_amd.engine import Network
+    with open(os.path.join(CFGDIR, 'sup3r', 'spatial', 'gen_2x_2f.json')) as f:
+        spec = json.load(f)
+    shape = (batch, 75, 75, 2)
+    net = Network(spec, name='generator2d', device=dev, precision='bf16')
+    net.build(shape, seed=0)
+    ph = net.plan(shape, training=False)
+    x = dev.to_device(np.random.default_rng(seed).standard_normal(
+        shape).astype(np.float32))
+    out = dev.empty(tuple(ph.out_shape))
+    for _ in range(warmup):
+        ph.forward(x, out=out)
+    dev.sync()
+    ph.profile_begin(steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ph.forward(x, out=out)
+    dev.sync()
+    el = time.perf_counter() - t0
+    _, ms = ph.profile_end()
+    sel = [ph.op_info(i)['fwd'] if op['kind'] == S.OP_CONV else None
+           for i, op in enumerate(ph.plan.ops)]
+    trunk = [i for i, op in enumerate(ph.plan.ops)
+             if sel[i] == 'conv2d_ws' and op['cout'] == 64]
+    npos = batch * 75 * 75
+    flop_conv = 2.0 * npos * 9 * 64 * 64
+    macs = sum(int(np.prod(ph.plan.tensors[op['out']][:4]))
+               // (op.get('d2s', 1) or 1) ** 2 * op['cin'] * op['cout'] * 9
+               for op in ph.plan.ops if op['kind'] == S.OP_CONV)
+    t_ms = float(np.mean([ms[i] for i in trunk])) if trunk else float('nan')
+    bytes_conv = npos * 64 * 2 * 2          # bf16 cells in + out
+    res = {
+        'value': batch * steps / el, 'unit': 'samples/s (time steps)',
+        'ms_per_step': el / steps * 1e3, 'steps': steps, 'warmup': warmup,
+        'workload': f'sup3r/configs/spatial/gen_2x_2f.json forward, lo-res '
+                    f'({batch},75,75,2) -> hi-res ({batch},150,150,2), the '
+                    'config_fwp_spatial.json chunk (75 x 75 x 38 + temporal_pad '
+                    '5), bf16 trunk / fp32 I/O, inputs resident in HBM',
+        'gflop_per_sample': 2.0 * macs / batch / 1e9,
+        'whole_path_tflops': 2.0 * macs * steps / el / 1e12,
+        'kernels': {k: sel.count(k) for k in sorted(set(k for k in sel if k))},
+        'roofline': {
+            'kernel': 'conv2d_ws_kernel (Conv2D / Conv2DTranspose 64->64 3x3, '
+                      'reflect pad fused, weights-stationary persistent)',
+            'bound': 'mfma', 'unit': 'TFLOP/s',
+            'achieved': flop_conv / (t_ms * 1e-3) / 1e12,
+            'peak': PEAK_TFLOPS['bf16'],
+            'frac': flop_conv / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS['bf16'],
+            'launches_per_step': len(trunk), 'avg_launch_ms': t_ms,
+            'algorithmic_bytes_per_launch': bytes_conv,
+            'hbm_algorithmic_GBps': bytes_conv / (t_ms * 1e-3) / 1e9,
+            'hbm_frac': bytes_conv / (t_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            'note': 'K = 9 x 64: 288 FLOP per HBM byte, the conv sits at the '
+                    'ridge of the bf16 MFMA / HBM rooflines; 600 tiles of 2 x '
+                    '16 x 16 positions on 256 CUs (2.3 per CU) at this shape'}}
+    del ph, net
+    return res
+
+
 def _smi_poll(stop, out):
     import re as _re
     while not stop.is_set():
@@ -596,7 +664,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mode', default='infer',
-                    choices=['infer', 'train', 'c3', 'c1'])
+                    choices=['infer', 'train', 'c3', 'c1', 'fwd2d'])
     ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c4toy', 'c1'],
                     help='--mode train: which GAN')
     ap.add_argument('--batch', type=int, default=None,
@@ -731,6 +799,27 @@ def main():
                         'kernel': 'fused2d_kernel (whole network, one launch)'
                         if fused else 'op-by-op launches',
                         'parallelism': f'observations sharded x{world}'})))
+        return
+
+    if args.mode == 'fwd2d':
+        from sup3r_amd.engine import Device
+        dev = Device.get(local_rank)
+        barrier()
+        out = fwd2d_leg(dev, args.steps, max(args.warmup, 3),
+                        args.batch or 48, seed=42 + rank)
+        barrier()
+        ms_ = max_over_ranks(out['ms_per_step'])
+        if rank == 0:
+            B2 = args.batch or 48
+            print(json.dumps(dict(
+                base, metric='samples/sec (time steps), 2-D generator forward, '
+                             'spatial 2x GAN at the config_fwp_spatial.json '
+                             'chunk shape',
+                value=world * B2 / (ms_ * 1e-3), unit='samples/s',
+                ms_per_step=ms_, scaling='weak', dtype='bf16',
+                config={'workload': out['workload'],
+                        'parallelism': f'chunks sharded x{world}, no collective'},
+                roofline=out['roofline'], fwd2d=out)))
         return
 
     if args.mode == 'c3':
@@ -944,6 +1033,12 @@ def main():
                 in_situ=extra3)
         except Exception as e:              # a leg, never the headline
             result['c3'] = {'error': repr(e)[:300]}
+        torch.cuda.empty_cache()
+        # the production shape of the reference's 2-D (spatial) steps
+        try:
+            result['fwd2d'] = fwd2d_leg(dev)
+        except Exception as e:
+            result['fwd2d'] = {'error': repr(e)[:300]}
         torch.cuda.empty_cache()
         # the reference's own training test shape (BASELINE.json config 1,
         # tests/training/test_train_gan.py:45-114): a launch-bound mini-batch

@@ -94,10 +94,12 @@ bool gen_map(const ConvGeom& p, int precision, GenMap* out) {
       if (p.lo[d] != 0 || p.O[d] != p.D[d]) return false;
       continue;
     }
-    // 'same' extents only (the generators' pad / conv / crop groups): the
-    // valid-padded discriminator layers keep their own LDS-halo kernels
+    // 'same' extents with the REFLECT boundary only (the generators' pad /
+    // conv / crop groups): the zero-padded 'same' and the valid discriminator
+    // layers keep their own LDS-halo kernels
     if (p.lo[d] != 1 || p.O[d] != p.D[d]) return false;
   }
+  if (p.pad_mode != S3_PAD_REFLECT) return false;
   // few-channel heads and hi-res tails with kernels of their own (gather-MFMA
   // with the taps in K, LDS-DMA tail kernels and their backward forms)
   if (p.Cin == 2 || p.Cin == 4 || p.Cin == 8) return false;

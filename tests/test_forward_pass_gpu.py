@@ -299,8 +299,10 @@ def test_interleaved_generators_do_not_share_a_delivery_ring():
                          (fwp.get_input_chunk(i) for i in ids), model,
                          batch=2)})
     assert not ForwardPass._lanes
-    gens = [ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids),
-                                    model, batch=2) for fwp in fwps]
+    def chunks_of(fwp):           # (binds fwp now, not when the generator runs)
+        return (fwp.get_input_chunk(i) for i in ids)
+    gens = [ForwardPass.iter_chunks(chunks_of(fwp), model, batch=2)
+            for fwp in fwps]
     held = [[], []]
     for step in range(len(ids)):
         for g in range(2):

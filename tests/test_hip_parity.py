@@ -154,12 +154,9 @@ def test_mfma_backward_edge_shapes():
     for g, g_ref in zip(net.grads, ref.grads):
         assert np.abs(g - 2 * g_ref).max() < 2e-3 * np.abs(g_ref).max() + 2e-5 * gmax
     # bf16 MFMA mode backward (every conv incl. the 4 -> 64 head on bf16
-    # operands): the bf16-mode gradient bound, 1e-1 of the largest value
-    net16 = _hip_net(spec, ref.weights, precision='bf16')
-    ph16 = net16.plan(shape, training=True)
-    ph16.forward(dev.to_device(x))
-    dx16 = ph16.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
-    assert np.abs(dx16 - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
+    # operands): per op teacher-forced forward, every gradient <= 2e-2 on the
+    # device's activations and masks (round 5: was 1e-1 of the largest value)
+    _tight_vs_oracle(spec, shape, 6)
 
 
 def test_bf16_mode_tolerance_c2_topology():
@@ -303,10 +300,10 @@ def test_gather_mfma_conv_strided_valid_vs_oracle():
     """Discriminator-style stack (valid padding, strides 1 / 2, channels 32 /
     64 / 96) on the general gather-MFMA kernels in bf16 mode: forward, data
     gradient and weight gradients against the oracle.  Tolerances of the
-    bf16 throughput mode (bf16 operands, fp32 accumulate, four stacked convs
-    with LeakyReLU masks that flip where a pre-activation is within bf16
-    round-off of zero): forward 5e-2, input and weight gradients 1e-1 of the
-    largest value.  The exact mode is covered by the fp32 cases."""
+    bf16 throughput mode: forward per op teacher-forced + 3e-2 end to end,
+    every gradient <= 2e-2 of its tensor's largest value on the device's
+    activations and masks (round 5: replaces the 5e-2 / 1e-1 bounds that had
+    to absorb mask flips).  The exact mode is covered by the fp32 cases."""
     rng = np.random.default_rng(12)
 
     def conv(f, s, pad='valid'):
@@ -316,21 +313,11 @@ def test_gather_mfma_conv_strided_valid_vs_oracle():
     spec = conv(32, 1) + conv(32, 2) + conv(64, 1, 'same') + conv(96, 2) + \
         [{'class': 'Flatten'}, {'class': 'Dense', 'units': 1}]
     shape = (2, 21, 18, 23, 2)
-    x = rng.standard_normal(shape).astype(np.float32)
-    ref = _oracle_net(spec, x, None)
-    y_ref = ref.forward(x)
-    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
-    dx_ref = ref.backward(dy)
-    net = _hip_net(spec, ref.weights, precision='bf16')
-    dev = net.dev
-    ph = net.plan(shape, training=True)
-    y = ph.forward(dev.to_device(x)).cpu().numpy()
-    assert np.abs(y - y_ref).max() < 5e-2 * max(1.0, np.abs(y_ref).max())
-    dx = ph.backward(dev.to_device(dy), need_dx=True).cpu().numpy()
-    assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
-    gmax = max(float(np.abs(g).max()) for g in ref.grads)
-    for g, g_ref in zip(net.grads, ref.grads):
-        assert np.abs(g - g_ref).max() < 1e-1 * np.abs(g_ref).max() + 1e-3 * gmax
+    ph = _tight_vs_oracle(spec, shape, 12)
+    kinds = [ph.op_info(i)['fwd'] for i, op in enumerate(ph.plan.ops)
+             if 'cout' in op and 'k' in op]
+    assert sum(k in ('gconv', 'gconv_fewch', 'halo32', 'halo_s2')
+               for k in kinds) >= 3, kinds
 
 
 @pytest.mark.parametrize('n_out', [2, 3])
@@ -875,11 +862,13 @@ def test_tail_conv_wgrad_halo_transpose_read_kernel(monkeypatch):
         a = grads()
         switch('NO_WGRAD_TAIL', 1)
         b = grads()
-        r = ref.grads[2]
         assert a.shape == (3, 3, 3, 8, n_out)
         assert np.abs(a - b).max() > 0
-        assert np.sqrt(((a - r) ** 2).mean()) / np.sqrt((r ** 2).mean()) < 5e-2
         assert np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()) < 2e-3
+        # vs the oracle on the device's activations and masks: 2e-2 per tensor
+        # (round 5: was 5e-2 rel. rms against the exact oracle)
+        switch('NO_WGRAD_TAIL', None)
+        _tight_vs_oracle(spec, shape, 47)
 
 
 def test_stride2_dgrad_residue_class_halo_kernel(monkeypatch, capfd):
@@ -918,9 +907,13 @@ def test_stride2_dgrad_residue_class_halo_kernel(monkeypatch, capfd):
         switch('NO_DGRAD_S2', 1)
         dx2, g02 = run()
         assert ' s2 1 ' not in capfd.readouterr().err      # ... and the gather kernel here
-        assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
         assert np.abs(g0 - g02).max() < 1e-4 * np.abs(g02).max()
         assert np.abs(dx - dx2).max() < 1e-4 * np.abs(dx2).max()
+        # vs the oracle on the device's activations and masks (round 5: was
+        # 1e-1 of the largest value against the exact oracle)
+        switch('TRACE', None)
+        switch('NO_DGRAD_S2', None)
+        _tight_vs_oracle(spec, shape, 49)
 
 
 def test_chunked_dgrad_of_wide_conv_on_tile_kernel(monkeypatch):
@@ -953,6 +946,9 @@ def test_chunked_dgrad_of_wide_conv_on_tile_kernel(monkeypatch):
 
     def rel_rms(a, b):
         return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
-    assert np.abs(dx - dx_ref).max() < 1e-1 * np.abs(dx_ref).max()
     assert np.abs(g0 - g02).max() > 0
     assert rel_rms(g0, g02) < 2e-3 and rel_rms(dx, dx2) < 2e-3
+    # vs the oracle on the device's activations and masks (round 5: was 1e-1
+    # of the largest value against the exact oracle)
+    switch('NO_DGRAD_CHUNKED', None)
+    _tight_vs_oracle(spec, shape, 51)
