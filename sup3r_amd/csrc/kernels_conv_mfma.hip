@@ -343,7 +343,9 @@ int launch_conv_mfma_fwd(s3_ctx* ctx, const ConvGeom& g, int precision,
     // fp32 activations, split on the fly; the 512-position tile when it fills
     // the chip, the 128-position one otherwise
     const int64_t big = (int64_t)g.N * ((g.O[0] + 3) / 4) * ((g.O[1] + 7) / 8) * ((g.O[2] + 15) / 16);
-    if (big >= ctx->num_cu)
+    // (option MFMA_TILE = 3: the 128-position tile on a full-size problem —
+    // the rows-per-filter-slab ablation of profiles/r05/winograd_ablation.md)
+    if (big >= ctx->num_cu && s3_opt_int(S3O_MFMA_TILE, -1) != 3)
       return launch_io<S3_PREC_BF16X3, 4, 8, 8, false, false>(ctx, g, x, packed, bias, res, y, 0);
     return launch_io<S3_PREC_BF16X3, 2, 4, 8, false, false>(ctx, g, x, packed, bias, res, y, 0);
   }
