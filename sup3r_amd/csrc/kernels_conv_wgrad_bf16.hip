@@ -1255,14 +1255,18 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
 bool conv_wgrad_bf16_gen_supported(const ConvGeom& g, int precision) {
   if (precision == S3_PREC_BF16X3 ? s3_opt_has(S3O_NO_WGRAD_X3) : precision != S3_PREC_BF16) return false;
   if (s3_opt_has(S3O_NO_WGRAD_BF16)) return false;
-  if (g.d2s != 1 || g.Cin % 32 != 0 || g.Cin < 32 || g.Cout % 4 != 0 || g.Cout < 16) return false;
+  // (dPre is in the conv's own [position][C_out] layout whatever the store
+  // permutation of its forward pass: a depth-to-space conv is no special case)
+  if (g.Cin % 32 != 0 || g.Cin < 32 || g.Cout % 4 != 0 || g.Cout < 16) return false;
   if (g.Cin > 64 && g.Cin % 64 != 0) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != g.s[0] || (g.s[d] != 1 && g.s[d] != 2)) return false;
   // (t extents below the 16-wide run of a tile are masked through dPre: still
   // several times the exact-fp32 MFMA kernel's rate — 256 -> 256 s2 at 3 x 3 x 6
   // outputs, batch 32: 388 us there)
-  return g.O[2] >= 4 && (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 512;
+  // (round 5: T = 3 — sup3rcc/gen_solar_1x_8x_1f — took the generic kernel at
+  // 480 us per conv; 13 of 16 run positions masked is still 10x that)
+  return g.O[2] >= 2 && (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 512;
 }
 
 size_t conv_wgrad_bf16_gen_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
@@ -1295,7 +1299,9 @@ int launch_conv_wgrad_bf16_gen(s3_ctx* ctx, const ConvGeom& g, const float* x, c
 // ---- 2-D variant (spatial models)
 bool conv_wgrad_bf16_2d_supported(const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_BF16)) return false;
-  if (g.d2s != 1 || g.Cin % 32 != 0 || g.Cin < 32 || g.Cout % 4 != 0 || g.Cout < 16) return false;
+  // (dPre is in the conv's own [position][C_out] layout whatever the store
+  // permutation of its forward pass: a depth-to-space conv is no special case)
+  if (g.Cin % 32 != 0 || g.Cin < 32 || g.Cout % 4 != 0 || g.Cout < 16) return false;
   if (g.Cin > 64 && g.Cin % 64 != 0) return false;
   if (g.k[0] != 3 || g.k[1] != 3 || g.k[2] != 1 || g.D[2] != 1 || g.O[2] != 1) return false;
   if (g.s[0] != g.s[1] || (g.s[0] != 1 && g.s[0] != 2)) return false;

@@ -423,10 +423,9 @@ int wgrad_gen_cib(const ConvGeom& g) { return g.Cin <= 16 ? 1 : (g.Cin <= 32 ? 2
 
 bool conv_wgrad_gen_supported(const ConvGeom& g) {
   if (s3_opt_has(S3O_NO_GCONV)) return false;
-  if (g.d2s != 1) return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != g.s[0] || (g.s[d] != 1 && g.s[d] != 2)) return false;
-  return g.O[2] >= 4;
+  return g.O[2] >= 2;
 }
 
 // co blocks per workgroup: as many as the conv has, rounded to a power of two

@@ -716,6 +716,27 @@ __global__ void bias_grad_cols(const float* __restrict__ dy, int64_t n_pos,
   db[ch] = accumulate ? db[ch] + t : t;
 }
 
+// ... the same for MANY rows and > 256 channels (the 64 -> 512 / 576 / 768 /
+// 1600 expansion convs of the shipped generators: one serial walk per channel
+// took 4 ms at 46 000 positions): blockIdx.y owns a slice of the rows and
+// writes one partial row; bias_grad_stage2 sums the slices
+__global__ void bias_grad_cols_split(const float* __restrict__ dy, int64_t n_pos, int c,
+                                     float* __restrict__ partial) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const int64_t per = (n_pos + gridDim.y - 1) / gridDim.y;
+  const int64_t p0 = (int64_t)blockIdx.y * per;
+  const int64_t p1 = p0 + per < n_pos ? p0 + per : n_pos;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  int64_t p = p0;
+  for (; p + 4 <= p1; p += 4) {
+    t0 += dy[p * c + ch]; t1 += dy[(p + 1) * c + ch];
+    t2 += dy[(p + 2) * c + ch]; t3 += dy[(p + 3) * c + ch];
+  }
+  for (; p < p1; ++p) t0 += dy[p * c + ch];
+  partial[(int64_t)blockIdx.y * c + ch] = (t0 + t1) + (t2 + t3);
+}
+
 __global__ void mean_abs_stage1(const float* __restrict__ p, int64_t n,
                                 float* __restrict__ partial) {
   __shared__ float sm[8];
@@ -1448,6 +1469,18 @@ int launch_fill(s3_ctx* ctx, float* p, int64_t n, float v) {
 int launch_bias_grad(s3_ctx* ctx, const float* dy, int64_t n_pos, int c,
                      float* db, int accumulate) {
   if (c > 256) {
+    if (n_pos >= 256) {
+      // conv layers: split the rows over ~4 blocks per CU, then the fixed-shape tree
+      const int cb = (c + 255) / 256;
+      int ns = (4 * ctx->num_cu + cb - 1) / cb;
+      if ((int64_t)ns * 32 > n_pos) ns = (int)((n_pos + 31) / 32);
+      int rc = ensure_scratch(ctx, (size_t)ns * c * sizeof(float));
+      if (rc) return rc;
+      hipLaunchKernelGGL(bias_grad_cols_split, dim3(cb, ns), dim3(256), 0, ctx->stream, dy, n_pos, c, ctx->scratch);
+      hipLaunchKernelGGL(bias_grad_stage2, dim3(c), dim3(256), 0, ctx->stream, ctx->scratch, ns, c, db, accumulate);
+      S3_HIP(ctx, hipGetLastError());
+      return S3_OK;
+    }
     hipLaunchKernelGGL(bias_grad_cols, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, dy, n_pos, c, db, accumulate);
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
