@@ -69,8 +69,18 @@ __global__ void gconv_pack_kernel(const float* __restrict__ w, unsigned short* _
   const int R = mode == 0 ? cout : cin, Kx = mode == 0 ? cin : cout;
   const int K = (Kx + 7) / 8 * 8;              // rows padded to whole 16-B chunks
   const int64_t total = (int64_t)taps * rows_pad * K;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+  // The kernels walk K in steps of 32 channels: with K < 32 (C_in = 2 / 4 off the
+  // taps-in-K path) the last row's step reads up to 48 B past the image — times
+  // zero-padded activations.  Those 64 B are part of the image and written HERE,
+  // so the product is 0 x 0 whatever the buffer held before (round 5: this used
+  // to rest on plan buffers being zero-filled at allocation).
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + 32;
        idx += (int64_t)gridDim.x * blockDim.x) {
+    if (idx >= total) {
+      out[idx] = 0;
+      if (lo) lo[idx] = 0;
+      continue;
+    }
     int64_t r = idx;
     const int k = (int)(r % K); r /= K;
     const int row = (int)(r % rows_pad); r /= rows_pad;
@@ -994,7 +1004,7 @@ int launch_gconv_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* pack
   const int taps = g.k[0] * g.k[1] * g.k[2];
   const int R = dgrad ? g.Cin : g.Cout, K = dgrad ? g.Cout : g.Cin;
   const int64_t total = (int64_t)taps * rows_padded(R) * ((K + 7) / 8 * 8);
-  int grid = (int)((total + 255) / 256);
+  int grid = (int)((total + 32 + 255) / 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(gconv_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, w,
                      (unsigned short*)packed, taps, g.Cin, g.Cout, rows_padded(R), dgrad,
