@@ -294,6 +294,7 @@ int launch_conv_mfma_gen_fwd(s3_ctx* ctx, const ConvGeom& g, int precision, cons
 // weights-stationary persistent 2-D conv for the all-bf16 64 -> 64 k trunks of
 // the spatial generators (kernels_conv2d_ws.hip); physical 2-D geometry
 bool conv2d_ws_geom_ok(const ConvGeom& g);
+bool conv2d_ws_tail_geom_ok(const ConvGeom& g);   // 64 -> C_out <= 16 output conv, fp32 out
 bool conv2d_ws_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);
 size_t conv2d_ws_image_bytes(const ConvGeom& g);
 int launch_conv2d_ws_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);

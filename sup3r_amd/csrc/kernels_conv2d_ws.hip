@@ -66,12 +66,13 @@ __device__ __host__ inline int ws_row_cout(int rho) {
 }
 
 // canonical fp32 w[tap 9][ci 64][co] -> bf16 images [ct][tap][rho 64][ci 64]
+// tail (C_out <= 16, one N fragment): rows 0 .. 15 are the channels in order
 __global__ void pack_ws_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cout,
-                               int n_ct) {
+                               int n_ct, int tail) {
   const int total = n_ct * 9 * 64 * 64;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int ci = idx & 63, rho = (idx >> 6) & 63, tap = (idx >> 12) % 9, ct = (idx >> 12) / 9;
-    const int co = ct * 64 + ws_row_cout(rho);
+    const int co = tail ? (rho < 16 ? rho : cout) : ct * 64 + ws_row_cout(rho);
     const float v = co < cout ? w[((size_t)tap * 64 + ci) * cout + co] : 0.f;
     const int slot = (ci >> 3) ^ ((rho >> 1) & 7);
     out[(((size_t)ct * 9 + tap) * 64 + rho) * 64 + slot * 8 + (ci & 7)] = (unsigned short)(ws_pk(v, 0.f) & 0xFFFFu);
@@ -86,9 +87,17 @@ struct WsGeom {
   int tiles_i, tiles_r, tiles_c;
 };
 
+// NF = 4: 64 output channels per workgroup, bf16 cells out (the trunk form).
+// NF = 1: the few-feature OUTPUT conv of a 2-D generator (64 -> C_out <= 16, fp32
+// out, no skip, no depth-to-space): one filter fragment per tap, channels in
+// natural order, scalar fp32 stores — read-bound (5 fragment reads per 4 MFMAs),
+// but the 150 x 150 x 48 output conv of gen_2x_2f drops from 178 us on the
+// one-barrier-per-tap tile kernel to a pass at the speed its input streams.
+template <int NF>
 __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg, const float* __restrict__ bias,
-    const unsigned short* __restrict__ res, unsigned short* __restrict__ y, WsGeom g) {
+    const unsigned short* __restrict__ res, void* __restrict__ yv, WsGeom g) {
+  unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(yv);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     const int im = i0 + w_img, c = c0 + frow;
     const bool pos_ok = im < g.N && c < g.W;
     uint4 rr[4][2];
-    if (res) {
+    if (NF == 4 && res) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         int r = r0 + w_row + m;
@@ -219,10 +228,10 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
       }
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NF];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-      const int cb = (nf >> 1) * 32 + kq * 8 + (nf & 1) * 4;
+    for (int nf = 0; nf < NF; ++nf) {
+      const int cb = NF == 1 ? kq * 4 : (nf >> 1) * 32 + kq * 8 + (nf & 1) * 4;
       const f32x4 b4 = {bl[cb], bl[cb + 1], bl[cb + 2], bl[cb + 3]};
 #pragma unroll
       for (int m = 0; m < 4; ++m) acc[m][nf] = b4;
@@ -237,9 +246,9 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
         const int tap = tb * 3 + tc;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 wf[4], pf[4];
+          bf16x8 wf[NF], pf[4];
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf)
+          for (int nf = 0; nf < NF; ++nf)
             wf[nf] = *reinterpret_cast<const bf16x8*>(smem + f_addr[nf][ks] + tap * 8192);
 #pragma unroll
           for (int m = 0; m < 4; ++m)
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
 #pragma unroll
           for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < NF; ++nf)
               acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], pf[m], acc[m][nf], 0, 0, 0);
         }
       }
@@ -260,13 +269,24 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
       for (int m = 0; m < 4; ++m) {
         const int r = r0 + w_row + m;
         if (!pos_ok || r >= g.H) continue;
+        if constexpr (NF == 1) {
+          // lane (column frow, kq): channels 4 kq .. 4 kq + 3 of C_out <= 16, fp32
+          float* yo = reinterpret_cast<float*>(yv) + (((size_t)im * g.H + r) * g.W + c) * g.Cout;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+          for (int e = 0; e < 4; ++e) {
+            const int co = kq * 4 + e;
+            const float v = acc[m][0][e];
+            if (co < g.Cout) yo[co] = v > 0.f ? v : slope * v;
+          }
+          continue;
+        }
+#pragma unroll
+        for (int h = 0; h < (NF == 4 ? 2 : 0); ++h) {
           const int co = ct * 64 + h * 32 + kq * 8;
           if (co >= g.Cout) continue;
           float v[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = acc[m][2 * h][e]; v[4 + e] = acc[m][2 * h + 1][e]; }
+          for (int e = 0; e < 4; ++e) { v[e] = acc[m][(2 * h) % NF][e]; v[4 + e] = acc[m][(2 * h + 1) % NF][e]; }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
           size_t dst;
@@ -320,20 +340,31 @@ bool conv2d_ws_geom_ok(const ConvGeom& g) {
          (int64_t)g.N * g.O[0] * g.O[1] * g.Cout < ((int64_t)1 << 31);
 }
 
+// the few-feature output conv: 64 -> C_out <= 16, no depth-to-space
+bool conv2d_ws_tail_geom_ok(const ConvGeom& g) {
+  if (g.Cout < 1 || g.Cout > 16 || (g.d2s > 1)) return false;
+  ConvGeom t = g;
+  t.Cout = 64;
+  t.d2s = 1;
+  return conv2d_ws_geom_ok(t);
+}
+
 bool conv2d_ws_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res) {
   if (precision != S3_PREC_BF16 || s3_opt_on(S3O_NO_CONV2D_WS)) return false;
+  if (conv2d_ws_tail_geom_ok(g)) return io.in_bf16 && !io.out_bf16 && !has_res;
   if (!io.in_bf16 || !io.out_bf16 || (has_res && !io.res_bf16)) return false;
   if (has_res && g.d2s > 1) return false;
   return conv2d_ws_geom_ok(g);
 }
 
-size_t conv2d_ws_image_bytes(const ConvGeom& g) { return (size_t)(g.Cout / 64) * 9 * 8192; }
+size_t conv2d_ws_image_bytes(const ConvGeom& g) { return (size_t)((g.Cout + 63) / 64) * 9 * 8192; }
 
 int launch_conv2d_ws_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image) {
-  const int n_ct = g.Cout / 64;
+  const int n_ct = (g.Cout + 63) / 64;
   int grid = (n_ct * 9 * 64 * 64 + 255) / 256;
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(pack_ws_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, (unsigned short*)image, g.Cout, n_ct);
+  hipLaunchKernelGGL(pack_ws_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, (unsigned short*)image, g.Cout, n_ct,
+                     conv2d_ws_tail_geom_ok(g) ? 1 : 0);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -342,7 +373,9 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
                      const void* res, void* y) {
   static bool attr_set = false;
   if (!attr_set) {
-    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel),
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel<1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
     attr_set = true;
   }
@@ -351,14 +384,18 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
   w.Cout = g.Cout; w.b = g.d2s < 1 ? 1 : g.d2s; w.cpo = g.Cout / (w.b * w.b);
   w.act = g.act; w.alpha = g.alpha;
   w.tiles_i = (g.N + WT_I - 1) / WT_I; w.tiles_r = (w.H + WT_R - 1) / WT_R; w.tiles_c = (w.W + WT_C - 1) / WT_C;
-  const int T = w.tiles_i * w.tiles_r * w.tiles_c, n_ct = g.Cout / 64;
+  const bool tail = conv2d_ws_tail_geom_ok(g);
+  const int T = w.tiles_i * w.tiles_r * w.tiles_c, n_ct = (g.Cout + 63) / 64;
   // ~one workgroup per CU over all output-channel tiles (each keeps ITS image)
   int gx = (ctx->num_cu + n_ct - 1) / n_ct;
   if (gx > T) gx = T;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(conv2d_ws_kernel, dim3(gx, n_ct), dim3(W_NT), W_LDS, ctx->stream,
-                     (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res,
-                     (unsigned short*)y, w);
+  if (tail)
+    hipLaunchKernelGGL(conv2d_ws_kernel<1>, dim3(gx, 1), dim3(W_NT), W_LDS, ctx->stream, (const unsigned short*)x,
+                       (const char*)image, bias, (const unsigned short*)nullptr, y, w);
+  else
+    hipLaunchKernelGGL(conv2d_ws_kernel<4>, dim3(gx, n_ct), dim3(W_NT), W_LDS, ctx->stream,
+                       (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res, y, w);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

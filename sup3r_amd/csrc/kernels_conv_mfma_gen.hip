@@ -102,7 +102,9 @@ bool gen_map(const ConvGeom& p, int precision, GenMap* out) {
   if (p.pad_mode != S3_PAD_REFLECT) return false;
   // few-channel heads and hi-res tails with kernels of their own (gather-MFMA
   // with the taps in K, LDS-DMA tail kernels and their backward forms)
-  if (p.Cin == 2 || p.Cin == 4 || p.Cin == 8) return false;
+  // (3-D: tuned for C2 / the discriminators.  The 2 / 4-feature heads of the 2-D
+  // nets took the per-tap gather walk at 114 us for 270 000 positions)
+  if ((p.Cin == 2 || p.Cin == 4 || p.Cin == 8) && !(p.k[2] == 1 && p.D[2] == 1 && p.Cin != 8)) return false;
   // (the reference's filters: 1 placeholder nets: nothing to put on a matrix core)
   if (p.Cin < 5 && p.Cout < 64) return false;
   const int b = p.d2s < 1 ? 1 : p.d2s;
@@ -207,7 +209,7 @@ size_t conv_mfma_gen_packed_bytes(const ConvGeom& g, int precision) {
   const int npass = (g.Cin + kch - 1) / kch;
   size_t b = (size_t)((g.Cout + CT - 1) / CT) * npass * m.ka * 9 * CT * CIN * 2;
   // the weights-stationary 2-D kernel's image rides behind the tile image
-  if (precision == S3_PREC_BF16 && conv2d_ws_geom_ok(g)) b += conv2d_ws_image_bytes(g);
+  if (precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g))) b += conv2d_ws_image_bytes(g);
   return b;
 }
 
@@ -232,7 +234,7 @@ int launch_conv_mfma_gen_pack(s3_ctx* ctx, const ConvGeom& g, int precision, con
     hipLaunchKernelGGL(pack_gen_bf16_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, (unsigned short*)packed, ltaps,
                        g.Cin, g.Cout, n_ct, npass, m.tp[0], m.tp[1], m.tp[2]);
   S3_HIP(ctx, hipGetLastError());
-  if (precision == S3_PREC_BF16 && conv2d_ws_geom_ok(g))
+  if (precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g)))
     return launch_conv2d_ws_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka));
   return S3_OK;
 }
