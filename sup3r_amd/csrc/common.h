@@ -63,6 +63,7 @@
   X(NO_HALO_S2) \
   X(NO_MASK_FUSE) \
   X(NO_MFMA_GEN) \
+  X(NO_DGRAD_GEN) \
   X(NO_CONV2D_WS) \
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
@@ -287,6 +288,9 @@ bool conv_mfma_bf16_out_ok(const ConvGeom& g);
 // steps, any C_in <= 256 / C_out; bf16 and BF16X3 plans, forward only
 bool conv_mfma_gen_supported(const ConvGeom& g, int precision);
 bool conv_mfma_is_gen(const ConvGeom& g, int precision);   // supported AND not a trunk geometry
+// ... and the data gradient of such a conv on the same kernel (padded frame + fold)
+ConvGeom conv_dgrad_gen_geom(const ConvGeom& g);
+bool conv_dgrad_gen_supported(const ConvGeom& g, int precision);
 size_t conv_mfma_gen_packed_bytes(const ConvGeom& g, int precision);
 int launch_conv_mfma_gen_pack(s3_ctx* ctx, const ConvGeom& g, int precision, const float* w, void* packed);
 int launch_conv_mfma_gen_fwd(s3_ctx* ctx, const ConvGeom& g, int precision, const void* x, const void* packed,

@@ -403,6 +403,15 @@ int wgrad_slabs(const ConvGeom& g) {
   const int64_t P = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
   int64_t s = (P + 2047) / 2048;
   if (s > 64) s = 64;
+  // Few filter elements over many positions (the 2 -> 64 / 64 -> 2 head and
+  // output convs of the 2-D generators: 1 152 elements, 270 000 – 1 080 000
+  // positions): 64 slabs x 9 taps are 576 workgroups walking 4 200 – 17 000
+  // positions each, 830 us.  More slabs while the partials stay small (32 MB).
+  const int64_t wbytes = (int64_t)g.k[0] * g.k[1] * g.k[2] * g.Cin * g.Cout * 4;
+  int64_t more = (P + 511) / 512;
+  if (more > 2048) more = 2048;
+  if (more * wbytes > ((int64_t)32 << 20)) more = ((int64_t)32 << 20) / wbytes;
+  if (more > s) s = more;
   if (s < 1) s = 1;
   return (int)s;
 }

@@ -153,15 +153,15 @@ bool conv_mfma_supported(const ConvGeom& g, int precision) {
 // transposed + flipped filter of the data gradient:
 // wt[tap'][co][ci] = w[26 - tap'][ci][co]
 __global__ void pack_dgrad_kernel(const float* __restrict__ w,
-                                  float* __restrict__ wt, int cin, int cout) {
-  const int64_t total = (int64_t)27 * cin * cout;
+                                  float* __restrict__ wt, int cin, int cout, int taps) {
+  const int64_t total = (int64_t)taps * cin * cout;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
        idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = idx;
     const int ci = (int)(r % cin); r /= cin;
     const int co = (int)(r % cout); r /= cout;
     const int tp = (int)r;
-    wt[idx] = w[((int64_t)(26 - tp) * cin + ci) * cout + co];
+    wt[idx] = w[((int64_t)(taps - 1 - tp) * cin + ci) * cout + co];
   }
 }
 
@@ -251,10 +251,12 @@ bool conv_dgrad_mfma_valid_supported(const ConvGeom& g, int precision) {
 
 int launch_conv_dgrad_pack(s3_ctx* ctx, const ConvGeom& g, const float* w,
                            float* wt) {
-  const int64_t total = (int64_t)27 * g.Cin * g.Cout;
+  // (k = 3 x 3 x 1 too: reversing the linear tap index flips every axis)
+  const int taps = g.k[0] * g.k[1] * g.k[2];
+  const int64_t total = (int64_t)taps * g.Cin * g.Cout;
   int grid = (int)((total + 255) / 256);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, wt, g.Cin, g.Cout);
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, wt, g.Cin, g.Cout, taps);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -94,12 +94,19 @@ bool gen_map(const ConvGeom& p, int precision, GenMap* out) {
       if (p.lo[d] != 0 || p.O[d] != p.D[d]) return false;
       continue;
     }
-    // 'same' extents with the REFLECT boundary only (the generators' pad /
-    // conv / crop groups): the zero-padded 'same' and the valid discriminator
-    // layers keep their own LDS-halo kernels
-    if (p.lo[d] != 1 || p.O[d] != p.D[d]) return false;
   }
-  if (p.pad_mode != S3_PAD_REFLECT) return false;
+  // 'same' extents with the REFLECT boundary (the generators' pad / conv / crop
+  // groups), or the full correlation over that conv's padded frame with a zero
+  // boundary (its data gradient, conv_dgrad_gen_geom): the zero-padded 'same'
+  // and the valid discriminator layers keep their own LDS-halo kernels
+  bool same = p.pad_mode == S3_PAD_REFLECT, full = p.pad_mode == S3_PAD_ZERO;
+  for (int d = 0; d < 3; ++d) {
+    if (p.k[d] != 3) continue;
+    same = same && p.lo[d] == 1 && p.O[d] == p.D[d];
+    full = full && p.lo[d] == 2 && p.O[d] == p.D[d] + 2;
+  }
+  if (!same && !full) return false;
+  if (full && (p.d2s > 1 || p.act != S3_ACT_NONE)) return false;
   // few-channel heads and hi-res tails with kernels of their own (gather-MFMA
   // with the taps in K, LDS-DMA tail kernels and their backward forms)
   // (3-D: tuned for C2 / the discriminators.  The 2 / 4-feature heads of the 2-D
@@ -199,6 +206,32 @@ int launch_gen_prec(s3_ctx* ctx, const ConvGeom& l, const void* x, const void* w
 }  // namespace
 
 bool conv_mfma_gen_supported(const ConvGeom& g, int precision) { return gen_map(g, precision, nullptr); }
+
+// data gradient of a reflect-'same' conv with k = 3 on some axes and k = 1 on the
+// others: the full correlation of dPre with the flipped / transposed filter over
+// the frame padded by one cell on the k = 3 axes, zero boundary; the fold
+// (adjoint of the virtual padding) follows
+ConvGeom conv_dgrad_gen_geom(const ConvGeom& g) {
+  ConvGeom d = g;
+  for (int q = 0; q < 3; ++q) {
+    d.D[q] = g.O[q];
+    if (g.k[q] == 3) { d.O[q] = g.D[q] + 2; d.lo[q] = 2; }
+    else { d.O[q] = g.D[q]; d.lo[q] = 0; }
+  }
+  d.Cin = g.Cout; d.Cout = g.Cin;
+  d.pad_mode = S3_PAD_ZERO; d.act = S3_ACT_NONE; d.alpha = 0.f; d.d2s = 1;
+  return d;
+}
+
+bool conv_dgrad_gen_supported(const ConvGeom& g, int precision) {
+  if (s3_opt_has(S3O_NO_DGRAD_GEN)) return false;
+  if (g.pad_mode != S3_PAD_REFLECT) return false;
+  for (int q = 0; q < 3; ++q) {
+    if (g.s[q] != 1 || (g.k[q] != 3 && g.k[q] != 1)) return false;
+    if (g.k[q] == 3 ? (g.lo[q] != 1 || g.O[q] != g.D[q]) : (g.lo[q] != 0 || g.O[q] != g.D[q])) return false;
+  }
+  return gen_map(conv_dgrad_gen_geom(g), precision, nullptr);
+}
 
 bool conv_mfma_gen_in16_ok(const ConvGeom& g) { return g.Cin % 8 == 0; }
 

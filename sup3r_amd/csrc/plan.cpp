@@ -56,6 +56,7 @@ struct OpRec {
   bool dgrad_valid = false;    // dgrad_mfma of a valid-padded conv: no frame / fold
   bool dgrad_frame16 = false;  // the persistent kernel writes the padded frame as bf16
   bool use16 = false;          // data gradient stages the bf16 copy of dPre its mask pass leaves behind
+  bool dgrad_gen = false;      // dgrad_mfma on the logical-axes tile kernel (2-D nets, few time steps, any channels)
   bool dgrad_c2 = false;       // few-channel hi-res conv: LDS-halo dgrad
   bool dgrad_s2 = false;       // stride-2 valid conv, C_out = 32: residue classes on an LDS halo
   int mask_prod = -1;          // producer conv of in0 whose activation adjoint is fused into this conv's dgrad store / fold
@@ -842,13 +843,18 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
                        (conv_dgrad_c2_supported(g, precision) || conv_dgrad_c2_x3_supported(g, precision));
           o.dgrad_s2 = !o.dgrad_mfma && !o.dgrad_c2 && !o.fewpos &&
                        (conv_dgrad_s2_supported(ctx, g, precision) || conv_dgrad_s2_x3_supported(ctx, g, precision));
+          // what is left behind a REFLECT pad (2-D nets, few time steps, odd channel
+          // counts): the padded-frame correlation on the logical-axes tile kernel
+          if (!o.dgrad_mfma && !o.dgrad_c2 && !o.dgrad_s2 && !o.fewpos && conv_dgrad_gen_supported(g, precision))
+            o.dgrad_mfma = o.dgrad_gen = true;
           o.gconv_dgrad = !o.dgrad_mfma && !o.dgrad_c2 && !o.dgrad_s2 && !o.fewpos && conv_gconv_dgrad_supported(g, precision);
           if (o.gconv_dgrad && g.pad_mode == S3_PAD_REFLECT)
             max_dxp = std::max(max_dxp, (size_t)g.N * (g.D[0] + 2 * g.lo[0]) * (g.D[1] + 2 * g.lo[1]) *
                                             (g.D[2] + 2 * g.lo[2]) * g.Cin * sizeof(float));
           if (o.dgrad_mfma) {
-            o.dg = o.dgrad_chunked ? conv_dgrad_chunk_geom(g, 0)
-                                   : (o.dgrad_valid ? conv_dgrad_valid_geom(g) : conv_dgrad_geom(g));
+            o.dg = o.dgrad_gen ? conv_dgrad_gen_geom(g)
+                   : o.dgrad_chunked ? conv_dgrad_chunk_geom(g, 0)
+                                     : (o.dgrad_valid ? conv_dgrad_valid_geom(g) : conv_dgrad_geom(g));
             max_dxp = std::max(max_dxp, (size_t)o.dg.N * o.dg.O[0] * o.dg.O[1] * o.dg.O[2] * o.dg.Cout * sizeof(float));
           }
         }
@@ -1131,6 +1137,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         const bool gadj = o.gconv_dgrad && (o.cg.Cout & 7) == 0 && o.cg.pad_mode != S3_PAD_REFLECT &&
                           !s3_opt_has(S3O_NO_GCONV_DY16);
         if (!gadj && (!o.dgrad_mfma || o.dgrad_fewch || (o.cg.Cout & 3))) continue;
+        if (o.dgrad_gen && (o.cg.Cout & 7)) continue;   // (16-B bf16 chunks of a dPre cell)
         if (o.dgrad_chunked && ((o.cg.Cout & 7) || s3_opt_has(S3O_NO_CHUNKED_DY16))) continue;
         o.use16 = true;
         max16 = std::max(max16, (size_t)pl->t[root_of(pl, o.d.out)].numel * 2);
@@ -1316,7 +1323,7 @@ static int pack_tables_build(s3_plan* pl) {
       fwd.push_back(j); pl->pack_fwd_ops.push_back(i);
       pl->pack_fwd_ct = std::max(pl->pack_fwd_ct, j.n_ct);
     }
-    if (pl->training && o.dgrad_mfma && !o.dgrad_fewch && !o.dgrad_chunked && o.dg_wbf && g.Cout == 64 && k3 &&
+    if (pl->training && o.dgrad_mfma && !o.dgrad_gen && !o.dgrad_fewch && !o.dgrad_chunked && o.dg_wbf && g.Cout == 64 && k3 &&
         o.dg.Cin == 64) {
       S3PackJob j;
       j.w = W + P->p[o.d.w].offset;
@@ -2282,7 +2289,10 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
             }
             GatherGeom fg;
             fg.kind = S3_OP_PAD; fg.N = g.N;
-            for (int q = 0; q < 3; ++q) { fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2; fg.lo[q] = 1; }
+            for (int q = 0; q < 3; ++q) {
+              const int pq = g.k[q] == 3 ? 1 : 0;      // (k = 1 axes of a 2-D conv carry no frame)
+              fg.Di[q] = g.D[q]; fg.Do[q] = g.D[q] + 2 * pq; fg.lo[q] = pq;
+            }
             fg.Ci = g.Cin; fg.Co = g.Cin; fg.pad_mode = g.pad_mode;
             fg.rep = 1; fg.d2s = 1; fg.c_off = 0;
             rc = fold_frame(fg, dst, frame16);
