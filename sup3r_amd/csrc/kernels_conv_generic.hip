@@ -337,12 +337,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
+  // the source cell of each of the step's 32 positions, decoded ONCE per
+  // position (round 5: every one of its 64 channel lanes used to redo the three
+  // divisions and the boundary rule — the kernel was bound by that index math
+  // on the few-channel head / output convs that still come here)
+  __shared__ int64_t xcell[WG_POS];       // input cell index, -1: outside / past the slab
   for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_POS) {
-    // stage: 32 positions x 64 channels each for x (tap-shifted) and dy
-    for (int e = threadIdx.x; e < WG_POS * WG_TILE; e += 256) {
-      const int pr = e / WG_TILE, ch = e % WG_TILE;
-      const int64_t pos = p0 + pr;
-      float xv = 0.f, dv = 0.f;
+    if (threadIdx.x < WG_POS) {
+      const int64_t pos = p0 + threadIdx.x;
+      int64_t cell = -1;
       if (pos < p_end) {
         int64_t r = pos;
         const int o2 = (int)(r % g.O[2]); r /= g.O[2];
@@ -353,8 +356,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
         const int i0 = src_index(o0, a, g.s[0], g.lo[0], g.D[0], g.pad_mode, v);
         const int i1 = src_index(o1, b, g.s[1], g.lo[1], g.D[1], g.pad_mode, v);
         const int i2 = src_index(o2, c, g.s[2], g.lo[2], g.D[2], g.pad_mode, v);
-        if (v && tci + ch < g.Cin)
-          xv = x[((((int64_t)n * g.D[0] + i0) * g.D[1] + i1) * g.D[2] + i2) * g.Cin + tci + ch];
+        if (v) cell = (((int64_t)n * g.D[0] + i0) * g.D[1] + i1) * g.D[2] + i2;
+      }
+      xcell[threadIdx.x] = cell;
+    }
+    __syncthreads();
+    // stage: 32 positions x 64 channels each for x (tap-shifted) and dy
+    for (int e = threadIdx.x; e < WG_POS * WG_TILE; e += 256) {
+      const int pr = e / WG_TILE, ch = e % WG_TILE;
+      const int64_t pos = p0 + pr;
+      float xv = 0.f, dv = 0.f;
+      if (pos < p_end) {
+        const int64_t cell = xcell[pr];
+        if (cell >= 0 && tci + ch < g.Cin) xv = x[cell * g.Cin + tci + ch];
         if (tco + ch < g.Cout) dv = dy[pos * g.Cout + tco + ch];
       }
       xs[pr][ch] = xv;
@@ -396,6 +410,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial,
     float t = 0.f;
     for (int s = 0; s < n_slabs; ++s) t += partial[(int64_t)s * wsize + i];
     dw[i] = accumulate ? dw[i] + t : t;
+  }
+}
+
+// first level of a long reduction: row j of out = sum of the slabs [32 j, 32 j + 32)
+__global__ void wgrad_reduce_group_kernel(const float* __restrict__ partial, int n_slabs, int64_t wsize,
+                                          float* __restrict__ out) {
+  const int s0 = blockIdx.y * 32, s1 = s0 + 32 < n_slabs ? s0 + 32 : n_slabs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < wsize;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int s = s0; s < s1; ++s) t += partial[(int64_t)s * wsize + i];
+    out[(int64_t)blockIdx.y * wsize + i] = t;
   }
 }
 
@@ -512,6 +538,19 @@ int launch_conv_generic_wgrad(s3_ctx* ctx, const ConvGeom& g, const float* x,
   const int64_t wsize = (int64_t)taps * g.Cin * g.Cout;
   int rg = (int)((wsize + 255) / 256);
   if (rg > 2048) rg = 2048;
+  if (n_slabs > 128) {
+    // (hundreds of slabs of a few-element filter: one thread per element
+    // walking them all was 77 us; two levels of 32)
+    const int ng = (n_slabs + 31) / 32;
+    int rc = ensure_scratch(ctx, (size_t)ng * wsize * sizeof(float));
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(rg, ng), dim3(256), 0, ctx->stream, partial, n_slabs, wsize,
+                       ctx->scratch);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, ctx->stream, (const float*)ctx->scratch, ng, wsize,
+                       dw, accumulate);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, ctx->stream, partial, n_slabs, wsize, dw, accumulate);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
