@@ -454,6 +454,17 @@ int s3_chunk_epilogue(s3_ctx* ctx, const float* y, int n_chunks, const int64_t* 
                       const int64_t* crop_lo, const int64_t* crop_n, int c,
                       const float* scale_host, const float* shift_host, float* yc,
                       float* partial);
+/* the same hand-over for a 2-D (spatial) model, whose batch axis is the chunk's
+ * time axis (ForwardPass._reshape_data_chunk, sup3r/pipeline/forward_pass.py:
+ * 274-337: np.transpose(data_chunk, (2, 0, 1, 3)) in, np.transpose(hi_res, (1,
+ * 2, 0, 3)) out, then hi_res[0][hr_crop_slices], :272): y = (n_chunks * thw[0],
+ * thw[1], thw[2], c) fp32 as generated, yc = (n_chunks, crop_n[0..2], c) in the
+ * chunk's (s1, s2, t) order, crop_lo / crop_n over (s1, s2, t); un-normalised
+ * with the two roundings of un_norm_output (sup3r/models/abstract.py:240-275;
+ * NULL scale / shift: none).  s3_chunk_stats on yc completes _output_check. */
+int s3_chunk_time_last(s3_ctx* ctx, const float* y, int n_chunks, const int64_t* thw,
+                       const int64_t* crop_lo, const int64_t* crop_n, int c,
+                       const float* scale_host, const float* shift_host, float* yc);
 /* placement of a cropped hi-res chunk straight into the caller's host array
  * (the `out[hr_slice] = chunk` of the forward pass, sup3r/pipeline/
  * forward_pass.py:582-673 + the writers' window placement): one pitched

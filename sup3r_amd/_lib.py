@@ -42,7 +42,7 @@ EXPORTS = [
     's3_specmap',
     's3_copy_channels', 's3_affine_channels', 's3_fill', 's3_copy_block',
     's3_coarsen', 's3_gaussian_smooth', 's3_chunk_stats',
-    's3_chunk_epilogue',
+    's3_chunk_epilogue', 's3_chunk_time_last',
     's3_host_register', 's3_host_unregister', 's3_d2h_window',
     's3_d2h_stream', 's3_host_alloc', 's3_host_free', 's3_d2h_async',
     's3_dma_d2h_begin', 's3_dma_wait',
@@ -185,6 +185,9 @@ def lib():
         's3_chunk_epilogue': (i32, [vp, vp, i32, C.POINTER(i64),
                                     C.POINTER(i64), C.POINTER(i64), i32, pf,
                                     pf, vp, vp]),
+        's3_chunk_time_last': (i32, [vp, vp, i32, C.POINTER(i64),
+                                     C.POINTER(i64), C.POINTER(i64), i32, pf,
+                                     pf, vp]),
         's3_invert_uv': (i32, [vp, vp, i64, i64, i32, i32, i32, vp, vp]),
         's3_clip_channels': (i32, [vp, vp, i32, i64, pf, pf]),
         's3_range_mask': (i32, [vp, vp, i32, i32, i64, f32, f32, vp]),

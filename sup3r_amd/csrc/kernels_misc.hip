@@ -1710,6 +1710,58 @@ extern "C" int s3_copy_block(s3_ctx* ctx, const float* src, float* dst, int64_t 
   return S3_OK;
 }
 
+// 2-D (spatial) models see a chunk's time steps as their batch axis: the
+// generated batch is (n_chunks * T, H, W, c); the chunk the executor delivers is
+// hi_res[0][hr_crop_slices] of its transpose to (H, W, T, c)
+// (sup3r/pipeline/forward_pass.py:274-337,272) — un-normalised on the way
+struct ChunkTL { int64_t T, H, W; int64_t lo[3], n[3]; int c, affine; float scale[16], shift[16]; };
+__global__ void chunk_time_last_kernel(const float* __restrict__ y, float* __restrict__ yc, ChunkTL e) {
+  const int64_t per = e.n[0] * e.n[1] * e.n[2] * e.c;
+  const int k = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int ch = (int)(r % e.c); r /= e.c;
+    const int64_t t = r % e.n[2]; r /= e.n[2];
+    const int64_t w = r % e.n[1]; r /= e.n[1];
+    const int64_t h = r;
+    float v = y[((((int64_t)k * e.T + e.lo[2] + t) * e.H + e.lo[0] + h) * e.W + e.lo[1] + w) * e.c + ch];
+    if (e.affine) {
+      // two roundings, as numpy's (x * scale) + shift (affine_channels_kernel)
+      float m = v * e.scale[ch];
+      asm volatile("" : "+v"(m));
+      v = m + e.shift[ch];
+    }
+    yc[(int64_t)k * per + i] = v;
+  }
+}
+
+extern "C" int s3_chunk_time_last(s3_ctx* ctx, const float* y, int n_chunks, const int64_t* thw,
+                                  const int64_t* crop_lo, const int64_t* crop_n, int c,
+                                  const float* scale_host, const float* shift_host, float* yc) {
+  if (!ctx || !y || !yc || !thw || !crop_lo || !crop_n) return S3_EINVAL;
+  if (n_chunks < 1 || c < 1 || c > 16) S3_FAIL(ctx, S3_EINVAL, "chunk_time_last: 1 .. 16 channels");
+  // crop axes are (H, W, T): the chunk's (s1, s2, t)
+  const int64_t ext[3] = {thw[1], thw[2], thw[0]};
+  for (int d = 0; d < 3; ++d)
+    if (crop_lo[d] < 0 || crop_n[d] < 1 || crop_lo[d] + crop_n[d] > ext[d])
+      S3_FAIL(ctx, S3_EINVAL, "chunk_time_last: the crop window leaves the chunk");
+  ChunkTL e;
+  e.T = thw[0]; e.H = thw[1]; e.W = thw[2];
+  for (int d = 0; d < 3; ++d) { e.lo[d] = crop_lo[d]; e.n[d] = crop_n[d]; }
+  e.c = c;
+  e.affine = scale_host && shift_host;
+  for (int i = 0; i < 16; ++i) {
+    e.scale[i] = e.affine && i < c ? scale_host[i] : 1.f;
+    e.shift[i] = e.affine && i < c ? shift_host[i] : 0.f;
+  }
+  const int64_t per = crop_n[0] * crop_n[1] * crop_n[2] * c;
+  int gx = grid_for(per, ctx->num_cu);
+  hipLaunchKernelGGL(chunk_time_last_kernel, dim3(gx, n_chunks), dim3(kBlock), 0, ctx->stream, y, yc, e);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 extern "C" int s3_chunk_stats(s3_ctx* ctx, const float* x, int n_chunks,
                               int64_t pos_per_chunk, int c, float* partial) {
   if (!ctx) return S3_EINVAL;

@@ -646,14 +646,19 @@ class ForwardPass:
     # -- the reference's entry points over ForwardPassChunk structures -----
     @classmethod
     def _device_path(cls, model, chunk):
-        """single-step 5-D generator on this package's engine, no exo field
+        """single-step generator on this package's engine, no exo field
         combined at the output: the chunk batches go through one plan on the
-        device; anything else (4-D models, ``MultiStepGan``, 'output' exo)
-        takes ``run_generator`` -> ``model.generate`` chunk by chunk"""
+        device — 5-D models, and (round 5) 4-D (spatial) models without
+        exogenous data, whose batch axis is the chunks' time axis
+        (forward_pass.py:274-337); anything else (``MultiStepGan``, 'output'
+        exo, spatial models with exo fields) takes ``run_generator`` ->
+        ``model.generate`` chunk by chunk"""
         if getattr(model, '_gen', None) is None or \
-                not getattr(model, 'is_5d', False) or \
                 not getattr(model, 'supports_device_chunks', False):
             return False
+        if not getattr(model, 'is_5d', False):
+            return bool(getattr(model, 'is_4d', False)) and \
+                not chunk.exo_data and cls.device_chunks_4d
         for entry in (chunk.exo_data or {}).values():
             if any(st['combine_type'].lower() == 'output'
                    for st in entry['steps']):
@@ -815,6 +820,7 @@ class ForwardPass:
         gen = model._gen
         dev, L = gen.dev, _lib.lib()
         n = len(group)
+        is_4d = not getattr(model, 'is_5d', False)
         xs, exos = [], []
         for chunk in group:
             mask = np.isnan(chunk.input_data).any(axis=(0, 1, 2))
@@ -827,10 +833,17 @@ class ForwardPass:
             if exo is not None and not isinstance(exo, ExoData):
                 exo = ExoData(exo)
             exos.append(exo)
-            x = model._combine_fwp_input(
-                np.asarray(chunk.input_data)[None], cls._batch_axis(exo))
+            if is_4d:
+                # (s1, s2, t, f) -> the t time steps as the batch of a 2-D
+                # model (``_reshape_data_chunk``, forward_pass.py:274-337)
+                x = model._combine_fwp_input(np.transpose(
+                    np.asarray(chunk.input_data), (2, 0, 1, 3)), None)
+            else:
+                x = model._combine_fwp_input(
+                    np.asarray(chunk.input_data)[None], cls._batch_axis(exo))
             xs.append(np.asarray(model.norm_input(x), dtype=np.float32))
         x = np.concatenate(xs, axis=0) if n > 1 else xs[0]
+        n_t = x.shape[0] // n          # 4-D: time steps per chunk
         staged = []               # pinned upload buffers, alive until finish()
         try:
             ph = gen.plan(x.shape, training=False)
@@ -861,7 +874,8 @@ class ForwardPass:
                            model.s_enhance, x.shape, yshape))
                 logger.error(msg)
                 raise _EnhancementMismatch(msg)
-            if model.t_enhance * x.shape[3] != yshape[3]:
+            if (model.t_enhance != 1) if is_4d else \
+                    (model.t_enhance * x.shape[3] != yshape[3]):
                 msg = ('The stated temporal enhancement of {}x did not match '
                        'the low res / high res shapes of {} -> {}'.format(
                            model.t_enhance, x.shape, yshape))
@@ -874,7 +888,8 @@ class ForwardPass:
                 mu, sd = model._stats_for(model.hr_out_features)
                 scale = np.ascontiguousarray(sd, dtype=np.float32)
                 shift = np.ascontiguousarray(mu, dtype=np.float32)
-            y1, y2, y3 = yshape[1:4]
+            # (4-D: the chunk's hi-res extents are (H, W, time steps))
+            y1, y2, y3 = (yshape[1], yshape[2], n_t) if is_4d else yshape[1:4]
             cr = cls._crop_bounds(group[0].hr_crop_slice, (y1, y2, y3))
             c1, c2, c3 = (b - a for a, b in cr)
             yc = dev.empty((n, c1, c2, c3, n_out))
@@ -882,7 +897,8 @@ class ForwardPass:
             # halo crop + un-normalisation inside the tail conv (the window
             # forward: no full-size output, halo positions of the last conv
             # never computed) where the plan ends in the MFMA tail ...
-            windowed = cls.window_forward and ph.supports_window
+            windowed = cls.window_forward and ph.supports_window and \
+                not is_4d
             if windowed:
                 ph.forward_window(
                     xd, layer_exo, yc, [cr[0][0], cr[1][0], cr[2][0]],
@@ -903,7 +919,22 @@ class ForwardPass:
         # otherwise — same bits in every case
         fused = 1024 % n_out == 0 and n_out <= 16 and not any(
             (v * n_out) % 4 for v in (c3, cr[2][0], y3))
-        if windowed:
+        if is_4d:
+            # transpose to the chunk's (s1, s2, t) order + halo crop +
+            # un-normalisation in one pass, then the output check's statistics
+            i64x3 = C.c_int64 * 3
+            rc = L.s3_chunk_time_last(
+                dev.ctx, C.c_void_p(y.data_ptr()), n, i64x3(n_t, y1, y2),
+                i64x3(cr[0][0], cr[1][0], cr[2][0]), i64x3(c1, c2, c3), n_out,
+                scale.ctypes.data_as(pf) if scale is not None else None,
+                shift.ctypes.data_as(pf) if shift is not None else None,
+                C.c_void_p(yc.data_ptr()))
+            _lib.check(rc, dev.ctx, 's3_chunk_time_last')
+            rc = L.s3_chunk_stats(dev.ctx, C.c_void_p(yc.data_ptr()), n,
+                                  yc.numel() // (n * n_out), n_out,
+                                  C.c_void_p(stats_d.data_ptr()))
+            _lib.check(rc, dev.ctx, 's3_chunk_stats')
+        elif windowed:
             rc = L.s3_chunk_stats(dev.ctx, C.c_void_p(yc.data_ptr()), n,
                                   yc.numel() // (n * n_out), n_out,
                                   C.c_void_p(stats_d.data_ptr()))
@@ -1075,6 +1106,9 @@ class ForwardPass:
     # halo crop + un-normalisation inside the tail conv (s3_plan_forward_window)
     # where the plan supports it; False: full output + s3_chunk_epilogue
     window_forward = True
+    # spatial (4-D) models without exo data on the device chunk path (False:
+    # chunk by chunk through model.generate, as before round 5)
+    device_chunks_4d = True
     _aff_cache = {}
     _delivery = {}
     _lanes = set()

@@ -320,6 +320,83 @@ def test_interleaved_generators_do_not_share_a_delivery_ring():
     ForwardPass.release_delivery_buffers()
 
 
+@pytest.mark.parametrize('cfg,precision', [
+    ('test_gen_s_2x_2f.json', 'f32'),
+    ('sup3r/spatial/gen_2x_2f.json', 'bf16'),     # conv2d_ws / logical-axes kernels
+])
+def test_spatial_model_chunks_on_the_device_equal_the_generate_path(cfg,
+                                                                    precision):
+    """a 2-D (spatial) model through ``iter_chunks``: its chunks' time steps
+    are the batch axis (forward_pass.py:274-337).  Round 5: batches of such
+    chunks run on the device (transpose back to (s1, s2, t), halo crop,
+    un-normalisation in ``s3_chunk_time_last``) — bit-identical to the
+    chunk-by-chunk ``run_generator`` -> ``model.generate`` path, ragged edge
+    chunks and temporal padding included"""
+    from sup3r_amd import ForwardPass, Sup3rGan
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    feats = ['u_10m', 'v_10m']
+    Sup3rGan.seed(9)
+    means = {f: np.float32(0.3 * (i + 1)) for i, f in enumerate(feats)}
+    stds = {f: np.float32(1.5 + 0.25 * i) for i, f in enumerate(feats)}
+    m = Sup3rGan(os.path.join(CFG, cfg),
+                 os.path.join(CFG, 'test_disc_s_same.json'), means=means,
+                 stdevs=stds, precision=precision)
+    m.set_model_params(lr_features=feats, hr_out_features=feats, s_enhance=2,
+                       t_enhance=1)
+    m.init_weights((1, 16, 16, 2), (1, 32, 32, 2))
+    assert m.is_4d
+    rng = np.random.default_rng(21)
+    domain = (rng.standard_normal((44, 37, 21, 2)) * 2 + 0.4).astype(
+        np.float32)
+    register_model('Sup3rGan', {'model_dir': 'fwp-4d'}, m)
+    # (44 = 2 x 22, 37 = 19 + 18: every chunk image has >= 256 positions, the
+    # size from which a bf16 plan's kernels do not depend on the batch — below
+    # it the few-position kernels are chosen by the batch's TOTAL positions
+    # and the two paths agree to bf16 accumulation-order noise only, see the
+    # last lines)
+    st = ArrayStrategy(domain, {'model_dir': 'fwp-4d'}, (22, 19, 8),
+                       spatial_pad=2, temporal_pad=3, max_nodes=1, model=m)
+    fwp = ForwardPass(st, 0)
+    ids = [int(i) for i in st.node_chunks[0]]
+    assert len(ids) >= 12
+
+    def run(batch):
+        return {c.index: np.array(d) for c, failed, d in
+                ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids),
+                                        m, batch=batch) if not failed}
+    try:
+        ForwardPass.device_chunks_4d = False
+        ref = run(1)
+    finally:
+        ForwardPass.device_chunks_4d = True
+    assert len(ref) == len(ids)
+    c0 = fwp.get_input_chunk(ids[0])
+    assert ForwardPass._device_path(m, c0)
+    for batch in (1, 3):
+        got = run(batch)
+        assert sorted(got) == sorted(ref)
+        for k in ref:
+            assert got[k].shape == ref[k].shape and got[k].ndim == 4
+            np.testing.assert_array_equal(got[k], ref[k])
+    # ragged 4-row edge chunks (8 x 22 = 176 positions per image)
+    st2 = ArrayStrategy(domain, {'model_dir': 'fwp-4d'}, (20, 18, 8),
+                        spatial_pad=2, temporal_pad=3, max_nodes=1, model=m)
+    fwp = ForwardPass(st2, 0)
+    ids = [int(i) for i in st2.node_chunks[0]]
+    try:
+        ForwardPass.device_chunks_4d = False
+        ref = run(1)
+    finally:
+        ForwardPass.device_chunks_4d = True
+    got = run(3)
+    for k in ref:
+        if precision == 'f32':
+            np.testing.assert_allclose(got[k], ref[k], rtol=0, atol=1e-4)
+        else:
+            assert np.abs(got[k] - ref[k]).max() < 3e-2 * np.abs(ref[k]).max()
+
+
 # ------------------------------------------- the reference's entry points
 def _topo_model(tmp_path=None):
     """a topography-conditioned 3x / 4x generator (Sup3rConcat mid-network)"""
