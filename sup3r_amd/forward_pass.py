@@ -823,8 +823,10 @@ class ForwardPass:
         is_4d = not getattr(model, 'is_5d', False)
         xs, exos = [], []
         for chunk in group:
-            mask = np.isnan(chunk.input_data).any(axis=(0, 1, 2))
-            if np.any(mask):
+            # (one flat pass; the per-feature reduction over a (…, 2 .. 8)-wide
+            # last axis — 0.7 ms per 75 x 75 x 48 chunk — only when it found one)
+            if np.isnan(chunk.input_data).any():
+                mask = np.isnan(chunk.input_data).any(axis=(0, 1, 2))
                 feats = np.array(model.lr_features[:len(mask)])[mask]
                 msg = f'Input data for {feats} contains NaN values!'
                 logger.error(msg)
@@ -836,8 +838,10 @@ class ForwardPass:
             if is_4d:
                 # (s1, s2, t, f) -> the t time steps as the batch of a 2-D
                 # model (``_reshape_data_chunk``, forward_pass.py:274-337)
-                x = model._combine_fwp_input(np.transpose(
-                    np.asarray(chunk.input_data), (2, 0, 1, 3)), None)
+                # (contiguous: the normalisation below walks a transposed
+                # view four times slower)
+                x = model._combine_fwp_input(np.ascontiguousarray(np.transpose(
+                    np.asarray(chunk.input_data), (2, 0, 1, 3))), None)
             else:
                 x = model._combine_fwp_input(
                     np.asarray(chunk.input_data)[None], cls._batch_axis(exo))

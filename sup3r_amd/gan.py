@@ -55,6 +55,31 @@ def _leading_int(text):
     return int(re.search(r'\d+', text).group(0))
 
 
+
+def _per_channel(x, mu, sigma, fn, _period=2048):
+    """``fn(x, mu, sigma)`` broadcast over the last (feature) axis — the same
+    element-wise arithmetic, hence the same bits, as the plain numpy
+    expression, but with the statistics tiled to rows of ``_period`` cells:
+    numpy walks a broadcast over a 2 … 8-wide last axis with an inner loop of
+    that length (2.4 ms for the (48, 75, 75, 2) batch of a spatial chunk,
+    0.3 ms this way)."""
+    x = np.asarray(x)
+    c = x.shape[-1] if x.ndim else 0
+    if not (x.ndim >= 2 and x.flags.c_contiguous and mu.shape == (c,)
+            and sigma.shape == (c,) and x.size >= 4 * c * _period):
+        return fn(x, mu, sigma)
+    flat = x.reshape(-1)
+    row = c * _period
+    main = (flat.size // row) * row
+    mu_t, sg_t = np.tile(mu, _period), np.tile(sigma, _period)
+    out = np.empty(flat.shape, np.result_type(x.dtype, mu.dtype, sigma.dtype))
+    out[:main].reshape(-1, row)[...] = fn(flat[:main].reshape(-1, row), mu_t,
+                                          sg_t)
+    if main < flat.size:
+        out[main:].reshape(-1, c)[...] = fn(flat[main:].reshape(-1, c), mu,
+                                            sigma)
+    return out.reshape(x.shape)
+
 class Sup3rGan:
     """Basic sup3r GAN model on MI355X."""
 
@@ -300,14 +325,15 @@ class Sup3rGan:
         if (sigma == 0).any():
             warn('a feature has zero standard deviation; dividing by 1')
             sigma = np.where(sigma == 0, 1, sigma)
-        return (low_res.copy() - mu) / sigma
+        return _per_channel(low_res, mu, sigma, lambda x, m, s_: (x - m) / s_)
 
     def un_norm_output(self, output):
         """abstract.py:240-275: x * std + mean per hi-res output feature."""
         if self._means is None:
             return output
         mu, sigma = self._stats_for(self.hr_out_features)
-        return numpy_if_tensor(output) * sigma + mu
+        return _per_channel(numpy_if_tensor(output), mu, sigma,
+                            lambda x, m, s_: x * s_ + m)
 
     # ------------------------------------------------------------- forward
     def _exo_channels(self, data, wanted, exogenous_data, combine_type):

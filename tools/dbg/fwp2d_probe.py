@@ -33,3 +33,11 @@ for rep in range(3):
         last = d
     el = time.perf_counter() - t0
     print(f'{n} chunks in {el*1e3:.1f} ms = {n/el:.1f} chunks/s, out {last.shape} {last.dtype}', flush=True)
+if os.environ.get('PROFILE'):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for c, failed, d in ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids), m, batch=4):
+        pass
+    pr.disable()
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
