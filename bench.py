@@ -379,6 +379,52 @@ def fwd2d_leg(dev, steps=20, warmup=3, batch=48, seed=42):
     return res
 
 
+def fwp2d_executor_leg(rank=0, batch=4, reps=3):
+    """the same spec through the reference's executor entry
+    (ForwardPassStrategy-shaped chunks -> ForwardPass.get_input_chunk ->
+    iter_chunks): a (150, 150, 190) lo-res domain in 75 x 75 x 38 chunks with
+    temporal_pad 5, normalisation statistics set, cropped (150, 150, 38, 2)
+    hi-res chunks delivered to the host — 2-D models run their chunks' time
+    steps as the batch (forward_pass.py:274-337)"""
+    from sup3r_amd import ForwardPass, Sup3rGan
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    feats = ['u_10m', 'v_10m']
+    Sup3rGan.seed(3)
+    m = Sup3rGan(os.path.join(CFGDIR, 'sup3r', 'spatial', 'gen_2x_2f.json'),
+                 os.path.join(CFGDIR, 'disc_s_same.json'),
+                 means={f: np.float32(0.1 * (i + 1)) for i, f in enumerate(feats)},
+                 stdevs={f: np.float32(1.5 + i) for i, f in enumerate(feats)},
+                 precision='bf16')
+    m.set_model_params(lr_features=feats, hr_out_features=feats, s_enhance=2,
+                       t_enhance=1)
+    m.init_weights((1, 16, 16, 2), (1, 32, 32, 2))
+    domain = np.random.default_rng(7 + rank).standard_normal(
+        (150, 150, 190, 2)).astype(np.float32)
+    register_model('Sup3rGan', {'model_dir': 'bench-fwp2d'}, m)
+    st = ArrayStrategy(domain, {'model_dir': 'bench-fwp2d'}, (75, 75, 38),
+                       spatial_pad=0, temporal_pad=5, max_nodes=1, model=m)
+    fwp = ForwardPass(st, 0)
+    ids = [int(i) for i in st.node_chunks[0]]
+    best = None
+    for _ in range(reps + 1):          # (first pass: plans, pinned rings)
+        t0 = time.perf_counter()
+        n = 0
+        for c, failed, d in ForwardPass.iter_chunks(
+                (fwp.get_input_chunk(i) for i in ids), m, batch=batch):
+            assert not failed and d.shape == (150, 150, 38, 2)
+            n += 1
+        el = time.perf_counter() - t0
+        best = el if best is None or el < best else best
+    return {'value': n / best, 'unit': 'chunks/s', 'chunks': n,
+            'chunks_per_launch_sequence': batch,
+            'px_per_sec': n / best * 150 * 150 * 38,
+            'workload': 'config_fwp_spatial.json shape: 75 x 75 x 38 chunks + '
+                        'temporal_pad 5 of a (150, 150, 190, 2) domain through '
+                        'ForwardPass.get_input_chunk -> iter_chunks, cropped '
+                        '(150, 150, 38, 2) fp32 chunks delivered to the host'}
+
+
 def _smi_poll(stop, out):
     import re as _re
     while not stop.is_set():
@@ -808,6 +854,10 @@ def main():
         out = fwd2d_leg(dev, args.steps, max(args.warmup, 3),
                         args.batch or 48, seed=42 + rank)
         barrier()
+        try:
+            out['executor'] = fwp2d_executor_leg(rank)
+        except Exception as e:          # a leg, never the line
+            out['executor'] = {'error': repr(e)[:300]}
         ms_ = max_over_ranks(out['ms_per_step'])
         if rank == 0:
             B2 = args.batch or 48
@@ -1037,8 +1087,9 @@ def main():
         # the production shape of the reference's 2-D (spatial) steps
         try:
             result['fwd2d'] = fwd2d_leg(dev)
+            result['fwd2d']['executor'] = fwp2d_executor_leg()
         except Exception as e:
-            result['fwd2d'] = {'error': repr(e)[:300]}
+            result.setdefault('fwd2d', {})['error'] = repr(e)[:300]
         torch.cuda.empty_cache()
         # the reference's own training test shape (BASELINE.json config 1,
         # tests/training/test_train_gan.py:45-114): a launch-bound mini-batch
