@@ -112,16 +112,14 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
   const int t_end = (int)(((long long)(blockIdx.x + 1) * T) / gridDim.x);
   if (t_cur >= t_end) return;
 
-  // ---- the filter image of this output-channel tile: 72 KB, once
+  // ---- the filter image of this output-channel tile: 72 KB, once.  Its nine
+  // 16-B loads per lane are issued here and land in LDS AFTER the first halo's
+  // eleven have been issued as well: one memory latency at kernel start, not two.
+  uint4 wimg_r[9];
   {
     const uint4* src = reinterpret_cast<const uint4*>(wimg + (size_t)ct * 9 * 8192);
-    uint4* dst = reinterpret_cast<uint4*>(smem + W_SLAB_OFF);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) dst[tid + q * W_NT] = src[tid + q * W_NT];
-    if (tid < 64) {
-      const int co = ct * 64 + tid;
-      reinterpret_cast<float*>(smem + W_BIAS_OFF)[tid] = (bias && co < g.Cout) ? bias[co] : 0.f;
-    }
+    for (int q = 0; q < 9; ++q) wimg_r[q] = src[tid + q * W_NT];
   }
 
   // ---- per-lane halo chunks: chunk id tid + 512 q -> (image, row, column,
@@ -176,6 +174,15 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
   static_assert(W_TRIPS == 11, "prefetch registers p0 .. p10");
   uint4 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10;
   WS_FETCH(t_cur);
+  {
+    uint4* dst = reinterpret_cast<uint4*>(smem + W_SLAB_OFF);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dst[tid + q * W_NT] = wimg_r[q];
+    if (tid < 64) {
+      const int co = ct * 64 + tid;
+      reinterpret_cast<float*>(smem + W_BIAS_OFF)[tid] = (bias && co < g.Cout) ? bias[co] : 0.f;
+    }
+  }
   WS_COMMIT();
   __syncthreads();
 
