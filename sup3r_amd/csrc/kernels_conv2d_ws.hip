@@ -85,6 +85,7 @@ struct WsGeom {
   int act;
   float alpha;
   int tiles_i, tiles_r, tiles_c;
+  int dbg;             // option MFMA_DBG (ablations): 1 no halo prefetch, 2 no tap loop, 4 no epilogue
 };
 
 // NF = 4: 64 output channels per workgroup, bf16 cells out (the trunk form).
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
 
   while (true) {
     const bool has_next = t_cur + 1 < t_end;
-    if (has_next) WS_FETCH(t_cur + 1);
+    if (has_next && !(g.dbg & 1)) WS_FETCH(t_cur + 1);
     // this tile's skip rows (d2s == 1), fetched now: their latency hides under
     // the tap loop as well
     int i0, r0, c0;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     // and shared by the three taps — 18 instead of 24 fragment reads per 48
     // MFMAs, but 32 spilled registers: 519 instead of 899 TFLOP/s at 512 x 64 x 64)
 #pragma unroll 1
-    for (int tb = 0; tb < 3; ++tb) {
+    for (int tb = 0; tb < ((g.dbg & 2) ? 0 : 3); ++tb) {
 #pragma unroll
       for (int tc = 0; tc < 3; ++tc) {
         const int tap = tb * 3 + tc;
@@ -269,13 +270,31 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
       }
     }
 
+    // ---- halo hand-over BEFORE the epilogue, behind raw barriers.  The wait for
+    // the prefetched loads is a vmcnt wait and on gfx9 stores count in vmcnt too
+    // (as does the vmcnt(0) inside __syncthreads()): in this order the loads have
+    // had the whole tap loop to arrive and the output stores are issued after the
+    // hand-over, free to drain under the next tile's taps.  Only LDS is handed
+    // over: every wave's fragment reads are back (lgkmcnt) before the first
+    // barrier, the ds_writes of the new halo before the second.
+    // Measured (tools/dbg/ws_scaling.py, option MFMA_DBG ablations, 16 tiles per
+    // CU): read-only 3.8 us per tile (5.5 TB/s), write-only 3.3 us (5.0 TB/s), tap
+    // loop 3.0 us, everything 10.4 - 10.7 us with either barrier order — the loop
+    // moves 145 KB per tile and CU, 3.5 TB/s of mixed read + write traffic in
+    // aggregate: the steady state is the HBM side of the ridge, not the MFMAs.
+    if (has_next) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      WS_COMMIT();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
     // ---- epilogue from registers: lane (position column frow, channel
     // group kq): rows m, halves h -> 8 consecutive channels, one 16-B store
     {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int r = r0 + w_row + m;
-        if (!pos_ok || r >= g.H) continue;
+        if (!pos_ok || r >= g.H || (g.dbg & 4)) continue;
         if constexpr (NF == 1) {
           // lane (column frow, kq): channels 4 kq .. 4 kq + 3 of C_out <= 16, fp32
           float* yo = reinterpret_cast<float*>(yv) + (((size_t)im * g.H + r) * g.W + c) * g.Cout;
@@ -316,9 +335,6 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
       }
     }
     if (!has_next) break;
-    __syncthreads();      // every wave is past its last read of this halo
-    WS_COMMIT();
-    __syncthreads();
     ++t_cur;
   }
 }
@@ -390,6 +406,7 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
   w.N = g.N; w.H = g.D[0]; w.W = g.D[1];
   w.Cout = g.Cout; w.b = g.d2s < 1 ? 1 : g.d2s; w.cpo = g.Cout / (w.b * w.b);
   w.act = g.act; w.alpha = g.alpha;
+  w.dbg = (int)s3_opt_int(S3O_MFMA_DBG, 0);
   w.tiles_i = (g.N + WT_I - 1) / WT_I; w.tiles_r = (w.H + WT_R - 1) / WT_R; w.tiles_c = (w.W + WT_C - 1) / WT_C;
   const bool tail = conv2d_ws_tail_geom_ok(g);
   const int T = w.tiles_i * w.tiles_r * w.tiles_c, n_ct = (g.Cout + 63) / 64;
