@@ -364,17 +364,24 @@ def fwd2d_leg(dev, steps=20, warmup=3, batch=48, seed=42):
         'roofline': {
             'kernel': 'conv2d_ws_kernel (Conv2D / Conv2DTranspose 64->64 3x3, '
                       'reflect pad fused, weights-stationary persistent)',
-            'bound': 'mfma', 'unit': 'TFLOP/s',
-            'achieved': flop_conv / (t_ms * 1e-3) / 1e12,
-            'peak': PEAK_TFLOPS['bf16'],
-            'frac': flop_conv / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS['bf16'],
+            # 288 FLOP per algorithmic byte: the ridge of the bf16 MFMA / HBM
+            # rooflines.  Ablations put the steady state on the
+            # HBM side: 3.5 TB/s of mixed read + write traffic, tap loop 3.0 of
+            # 10.5 us per tile
+            'bound': 'hbm', 'unit': 'GB/s',
+            'achieved': bytes_conv / (t_ms * 1e-3) / 1e9,
+            'peak': PEAK_HBM_GBS,
+            'frac': bytes_conv / (t_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            'traffic': None,
             'launches_per_step': len(trunk), 'avg_launch_ms': t_ms,
             'algorithmic_bytes_per_launch': bytes_conv,
-            'hbm_algorithmic_GBps': bytes_conv / (t_ms * 1e-3) / 1e9,
-            'hbm_frac': bytes_conv / (t_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            'note': 'K = 9 x 64: 288 FLOP per HBM byte, the conv sits at the '
-                    'ridge of the bf16 MFMA / HBM rooflines; 600 tiles of 2 x '
-                    '16 x 16 positions on 256 CUs (2.3 per CU) at this shape'}}
+            'mfma_tflops': flop_conv / (t_ms * 1e-3) / 1e12,
+            'mfma_frac': flop_conv / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS['bf16'],
+            'note': '600 tiles of 2 x 16 x 16 positions on 256 CUs (2.3 per '
+                    'CU: three rounds) at this shape; counter traffic per '
+                    'launch: profiles/r05/pmc_fwd2d.txt (95 MB vs 69 MB '
+                    'algorithmic: 18^2 / 16^2 halo overlap + 80^2 / 75^2 tile '
+                    'overhang)'}}
     del ph, net
     return res
 
