@@ -454,6 +454,16 @@ int s3_chunk_epilogue(s3_ctx* ctx, const float* y, int n_chunks, const int64_t* 
                       const int64_t* crop_lo, const int64_t* crop_n, int c,
                       const float* scale_host, const float* shift_host, float* yc,
                       float* partial);
+/* the way INTO a 2-D (spatial) model (ForwardPass._reshape_data_chunk,
+ * sup3r/pipeline/forward_pass.py:274-337: np.transpose(data_chunk, (2, 0, 1,
+ * 3))) fused with Sup3rGan.norm_input (sup3r/models/abstract.py:197-238): x =
+ * (n_chunks, hwt[0], hwt[1], hwt[2], c) fp32 raw chunks, out = (n_chunks *
+ * hwt[2], hwt[0], hwt[1], c) = (x - mean) / std per channel with numpy's
+ * arithmetic — fp32 when the statistics are fp32 arrays (stats_fp32 = 1), fp64
+ * rounded to fp32 otherwise; NULL mean / std: transpose only. */
+int s3_chunk_time_first(s3_ctx* ctx, const float* x, int n_chunks, const int64_t* hwt, int c,
+                        const double* mean_host, const double* std_host, int stats_fp32,
+                        float* out);
 /* the same hand-over for a 2-D (spatial) model, whose batch axis is the chunk's
  * time axis (ForwardPass._reshape_data_chunk, sup3r/pipeline/forward_pass.py:
  * 274-337: np.transpose(data_chunk, (2, 0, 1, 3)) in, np.transpose(hi_res, (1,

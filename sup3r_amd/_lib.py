@@ -42,7 +42,7 @@ EXPORTS = [
     's3_specmap',
     's3_copy_channels', 's3_affine_channels', 's3_fill', 's3_copy_block',
     's3_coarsen', 's3_gaussian_smooth', 's3_chunk_stats',
-    's3_chunk_epilogue', 's3_chunk_time_last',
+    's3_chunk_epilogue', 's3_chunk_time_last', 's3_chunk_time_first',
     's3_host_register', 's3_host_unregister', 's3_d2h_window',
     's3_d2h_stream', 's3_host_alloc', 's3_host_free', 's3_d2h_async',
     's3_dma_d2h_begin', 's3_dma_wait',
@@ -185,6 +185,9 @@ def lib():
         's3_chunk_epilogue': (i32, [vp, vp, i32, C.POINTER(i64),
                                     C.POINTER(i64), C.POINTER(i64), i32, pf,
                                     pf, vp, vp]),
+        's3_chunk_time_first': (i32, [vp, vp, i32, C.POINTER(i64), i32,
+                                      C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), i32, vp]),
         's3_chunk_time_last': (i32, [vp, vp, i32, C.POINTER(i64),
                                      C.POINTER(i64), C.POINTER(i64), i32, pf,
                                      pf, vp]),

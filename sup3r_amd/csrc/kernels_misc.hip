@@ -1736,6 +1736,53 @@ __global__ void chunk_time_last_kernel(const float* __restrict__ y, float* __res
   }
 }
 
+// ... and the way in: n chunks (s1, s2, t, c) -> the (n t, s1, s2, c) batch of a
+// 2-D model, normalised (x - mean) / std with numpy's arithmetic: in fp32 when
+// the statistics are fp32 arrays, in fp64 (then rounded to fp32) when they are
+// fp64 — the two cases of Sup3rGan.norm_input (abstract.py:197-238)
+struct ChunkTF { int64_t H, W, T; int c, mode; float mean[16], sd[16]; double dmean[16], dsd[16]; };
+__global__ void chunk_time_first_kernel(const float* __restrict__ x, float* __restrict__ out, ChunkTF e) {
+  const int64_t per = e.H * e.W * e.T * e.c;
+  const int k = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    // i runs over the OUTPUT (t, h, w, ch) of chunk k
+    int64_t r = i;
+    const int ch = (int)(r % e.c); r /= e.c;
+    const int64_t w = r % e.W; r /= e.W;
+    const int64_t h = r % e.H; r /= e.H;
+    const int64_t t = r;
+    float v = x[(int64_t)k * per + ((h * e.W + w) * e.T + t) * e.c + ch];
+    if (e.mode == 1) {
+      float d = v - e.mean[ch];
+      asm volatile("" : "+v"(d));
+      v = __fdiv_rn(d, e.sd[ch]);
+    } else if (e.mode == 2) {
+      v = (float)(((double)v - e.dmean[ch]) / e.dsd[ch]);
+    }
+    out[(int64_t)k * per + i] = v;
+  }
+}
+
+extern "C" int s3_chunk_time_first(s3_ctx* ctx, const float* x, int n_chunks, const int64_t* hwt, int c,
+                                   const double* mean_host, const double* std_host, int stats_fp32,
+                                   float* out) {
+  if (!ctx || !x || !out || !hwt) return S3_EINVAL;
+  if (n_chunks < 1 || c < 1 || c > 16) S3_FAIL(ctx, S3_EINVAL, "chunk_time_first: 1 .. 16 channels");
+  ChunkTF e;
+  e.H = hwt[0]; e.W = hwt[1]; e.T = hwt[2]; e.c = c;
+  e.mode = (mean_host && std_host) ? (stats_fp32 ? 1 : 2) : 0;
+  for (int i = 0; i < 16; ++i) {
+    const double m = e.mode && i < c ? mean_host[i] : 0.0, sd = e.mode && i < c ? std_host[i] : 1.0;
+    e.mean[i] = (float)m; e.sd[i] = (float)sd; e.dmean[i] = m; e.dsd[i] = sd;
+  }
+  const int64_t per = e.H * e.W * e.T * c;
+  hipLaunchKernelGGL(chunk_time_first_kernel, dim3(grid_for(per, ctx->num_cu), n_chunks), dim3(kBlock), 0,
+                     ctx->stream, x, out, e);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 extern "C" int s3_chunk_time_last(s3_ctx* ctx, const float* y, int n_chunks, const int64_t* thw,
                                   const int64_t* crop_lo, const int64_t* crop_n, int c,
                                   const float* scale_host, const float* shift_host, float* yc) {

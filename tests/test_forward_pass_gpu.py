@@ -320,6 +320,72 @@ def test_interleaved_generators_do_not_share_a_delivery_ring():
     ForwardPass.release_delivery_buffers()
 
 
+def test_chunk_time_first_and_last_kernels_vs_numpy():
+    """s3_chunk_time_first / s3_chunk_time_last against the numpy statements
+    they replace (forward_pass.py:274-337 transposes, abstract.py:197-275
+    norm_input / un_norm_output), bit for bit: fp32 statistics, fp64
+    statistics (numpy computes in fp64, the result is rounded to fp32), none"""
+    import ctypes as C
+
+    from sup3r_amd import _lib
+    from sup3r_amd.engine import Device
+    dev, L = Device.get(), _lib.lib()
+    rng = np.random.default_rng(33)
+    n, h, w, t, c = 3, 7, 5, 6, 3
+    x = (rng.standard_normal((n, h, w, t, c)) * 3 + 1).astype(np.float32)
+    xd = dev.to_device(x)
+    pd = C.POINTER(C.c_double)
+    i64x3 = C.c_int64 * 3
+    for mode in ('f32', 'f64', 'none'):
+        mu = rng.standard_normal(c) + 0.5
+        sd = rng.uniform(0.5, 2.0, c)
+        if mode == 'f32':
+            mu, sd = mu.astype(np.float32), sd.astype(np.float32)
+        want = np.concatenate([np.transpose(x[k], (2, 0, 1, 3))
+                               for k in range(n)], axis=0)
+        if mode != 'none':
+            want = ((want.copy() - mu) / sd).astype(np.float32)
+        out = dev.empty((n * t, h, w, c))
+        m64 = np.ascontiguousarray(mu, np.float64)
+        s64 = np.ascontiguousarray(sd, np.float64)
+        rc = L.s3_chunk_time_first(
+            dev.ctx, C.c_void_p(xd.data_ptr()), n, i64x3(h, w, t), c,
+            m64.ctypes.data_as(pd) if mode != 'none' else None,
+            s64.ctypes.data_as(pd) if mode != 'none' else None,
+            int(mode == 'f32'), C.c_void_p(out.data_ptr()))
+        _lib.check(rc, dev.ctx, 's3_chunk_time_first')
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+    # the way out: (n t, H, W, c) -> cropped (n, H', W', t', c), un-normalised
+    y = (rng.standard_normal((n * t, h, w, c)) * 2).astype(np.float32)
+    yd = dev.to_device(y)
+    sc = rng.uniform(0.5, 2.0, c).astype(np.float32)
+    sh = rng.standard_normal(c).astype(np.float32)
+    lo, cn = (1, 0, 2), (5, 4, 3)
+    pf = C.POINTER(C.c_float)
+    for affine in (True, False):
+        yc = dev.empty((n,) + cn + (c,))
+        rc = L.s3_chunk_time_last(
+            dev.ctx, C.c_void_p(yd.data_ptr()), n, i64x3(t, h, w),
+            i64x3(*lo), i64x3(*cn), c,
+            sc.ctypes.data_as(pf) if affine else None,
+            sh.ctypes.data_as(pf) if affine else None,
+            C.c_void_p(yc.data_ptr()))
+        _lib.check(rc, dev.ctx, 's3_chunk_time_last')
+        for k in range(n):
+            hi = np.transpose(y[k * t:(k + 1) * t], (1, 2, 0, 3))
+            if affine:
+                hi = hi * sc + sh
+            np.testing.assert_array_equal(
+                yc[k].cpu().numpy(),
+                hi[lo[0]:lo[0] + cn[0], lo[1]:lo[1] + cn[1],
+                   lo[2]:lo[2] + cn[2]])
+    # a crop window that leaves the chunk is refused
+    rc = L.s3_chunk_time_last(dev.ctx, C.c_void_p(yd.data_ptr()), n,
+                              i64x3(t, h, w), i64x3(0, 0, 4), i64x3(2, 2, 3),
+                              c, None, None, C.c_void_p(yc.data_ptr()))
+    assert rc < 0
+
+
 @pytest.mark.parametrize('cfg,precision', [
     ('test_gen_s_2x_2f.json', 'f32'),
     ('sup3r/spatial/gen_2x_2f.json', 'bf16'),     # conv2d_ws / logical-axes kernels
@@ -373,8 +439,14 @@ def test_spatial_model_chunks_on_the_device_equal_the_generate_path(cfg,
     assert len(ref) == len(ids)
     c0 = fwp.get_input_chunk(ids[0])
     assert ForwardPass._device_path(m, c0)
-    for batch in (1, 3):
-        got = run(batch)
+    for batch, dev_norm in ((1, True), (3, True), (3, False)):
+        # (dev_norm: transpose to time-major + norm_input in
+        # s3_chunk_time_first, numpy's fp32 arithmetic; False: host numpy)
+        ForwardPass.device_norm_4d = dev_norm
+        try:
+            got = run(batch)
+        finally:
+            ForwardPass.device_norm_4d = True
         assert sorted(got) == sorted(ref)
         for k in ref:
             assert got[k].shape == ref[k].shape and got[k].ndim == 4
