@@ -65,6 +65,7 @@
   X(NO_MFMA_GEN) \
   X(NO_DGRAD_GEN) \
   X(NO_CONV2D_WS) \
+  X(NO_TRAIN2D_BF16) \
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \
@@ -403,7 +404,7 @@ int launch_conv_dgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const 
 bool conv_wgrad_bf16_2d_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_2d_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_bf16_2d(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                              float* dw, float* partial, size_t partial_bytes, int accumulate);
+                              float* dw, float* partial, size_t partial_bytes, int accumulate, int x_bf16 = 0);
 // wgrad of the 2-channel hi-res conv, LDS-free bf16 MFMA (kernels_conv_wgrad_fewch.hip)
 bool conv_wgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_c2_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);

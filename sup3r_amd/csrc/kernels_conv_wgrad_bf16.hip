@@ -1022,7 +1022,9 @@ struct Bf2D {
   }
 };
 
-template <int CIB, int STR>
+// IN16: x is bf16 cells (C_in % 8 == 0; the activations a 2-D training plan
+// saves behind the weights-stationary / logical-axes forward kernels)
+template <int CIB, int STR, bool IN16 = false>
 __global__ __launch_bounds__(BNT) void conv2_wgrad_bf16_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int tiles1, int tiles2, int n_tiles) {
@@ -1079,6 +1081,22 @@ __global__ __launch_bounds__(BNT) void conv2_wgrad_bf16_kernel(
     const int org1 = t1i * T1, org2 = t2i * T2;
     __syncthreads();
     constexpr int CH = CIB * 4;
+    if constexpr (IN16) {
+      constexpr int CH8 = CIB * 2;
+      const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
+      for (int item = tid; item < HP * CH8; item += BNT) {
+        const int hp = item / CH8, ch = item % CH8;
+        const int c2 = hp % G2, c1 = hp / G2;
+        int i0 = org1 * STR + c1 - g.lo[0], i1 = org2 * STR + c2 - g.lo[1];
+        if (g.pad_mode == S3_PAD_REFLECT) { i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); }
+        const bool valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && ci0 + ch * 8 < Cin;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (valid)
+          v = *reinterpret_cast<const uint4*>(x16 + (((size_t)n * D0 + i0) * D1 + i1) * Cin + ci0 + ch * 8);
+        const int u = W::tau(c2);
+        *reinterpret_cast<uint4*>(xs + (c1 * G2 + u) * CB + (((ch >> 1) ^ W::key(u)) << 5) + ((ch & 1) << 4)) = v;
+      }
+    } else
     for (int item = tid; item < HP * CH; item += BNT) {
       const int hp = item / CH, ch = item % CH;
       const int c2 = hp % G2, c1 = hp / G2;
@@ -1086,8 +1104,18 @@ __global__ __launch_bounds__(BNT) void conv2_wgrad_bf16_kernel(
       if (g.pad_mode == S3_PAD_REFLECT) { i0 = s3_reflect(i0, D0); i1 = s3_reflect(i1, D1); }
       const bool valid = i0 >= 0 && i0 < D0 && i1 >= 0 && i1 < D1 && ci0 + ch * 4 < Cin;
       float4 v = make_float4(0, 0, 0, 0);
-      if (valid)
-        v = *reinterpret_cast<const float4*>(x + (((size_t)n * D0 + i0) * D1 + i1) * Cin + ci0 + ch * 4);
+      if (valid) {
+        const float* xp = x + (((size_t)n * D0 + i0) * D1 + i1) * Cin + ci0 + ch * 4;
+        if ((Cin & 3) == 0) {
+          v = *reinterpret_cast<const float4*>(xp);
+        } else {            // (C_in 1, 2, 3, 6, 7, 65: channel by channel, zeros behind the last)
+          const int left = Cin - (ci0 + ch * 4);
+          v.x = xp[0];
+          if (left > 1) v.y = xp[1];
+          if (left > 2) v.z = xp[2];
+          if (left > 3) v.w = xp[3];
+        }
+      }
       const int u = W::tau(c2);
       *reinterpret_cast<uint2*>(xs + (c1 * G2 + u) * CB + (((ch >> 2) ^ W::key(u)) << 5) +
                                 ((ch & 3) << 3)) = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
@@ -1097,8 +1125,18 @@ __global__ __launch_bounds__(BNT) void conv2_wgrad_bf16_kernel(
       const int o0 = org1 + pl / T2, o1 = org2 + pl % T2;
       const int co = ct * BCT + ch * 4;
       float4 v = make_float4(0, 0, 0, 0);
-      if (o0 < g.O[0] && o1 < g.O[1] && co < Cout)
-        v = *reinterpret_cast<const float4*>(dy + (((size_t)n * g.O[0] + o0) * g.O[1] + o1) * Cout + co);
+      if (o0 < g.O[0] && o1 < g.O[1] && co < Cout) {
+        const float* dp = dy + (((size_t)n * g.O[0] + o0) * g.O[1] + o1) * Cout + co;
+        if ((Cout & 3) == 0) {
+          v = *reinterpret_cast<const float4*>(dp);
+        } else {            // (C_out 1, 2, 6, 14)
+          const int left = Cout - co;
+          v.x = dp[0];
+          if (left > 1) v.y = dp[1];
+          if (left > 2) v.z = dp[2];
+          if (left > 3) v.w = dp[3];
+        }
+      }
       *reinterpret_cast<uint2*>(ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3)) =
           make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
     }
@@ -1155,7 +1193,7 @@ int bf_2d_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t1, int*
   return grid;
 }
 
-template <int CIB, int STR>
+template <int CIB, int STR, bool IN16 = false>
 int bf_2d_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy, float* dw,
                  float* partial, size_t partial_bytes, int accumulate) {
   using W = Bf2D<CIB, STR>;
@@ -1163,7 +1201,7 @@ int bf_2d_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy
   const int grid = bf_2d_grid<CIB, STR>(ctx, g, &n_tiles, &t1, &t2);
   const size_t need = (size_t)grid * 9 * g.Cin * g.Cout * sizeof(float);
   if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_2d: partial buffer too small");
-  auto kern = conv2_wgrad_bf16_kernel<CIB, STR>;
+  auto kern = conv2_wgrad_bf16_kernel<CIB, STR, IN16>;
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1301,8 +1339,11 @@ bool conv_wgrad_bf16_2d_supported(const ConvGeom& g, int precision) {
   if (precision != S3_PREC_BF16 || s3_opt_has(S3O_NO_WGRAD_BF16)) return false;
   // (dPre is in the conv's own [position][C_out] layout whatever the store
   // permutation of its forward pass: a depth-to-space conv is no special case)
-  if (g.Cin % 32 != 0 || g.Cin < 32 || g.Cout % 4 != 0 || g.Cout < 16) return false;
-  if (g.Cin > 64 && g.Cin % 64 != 0) return false;
+  // (round 5: any channel counts — the staging pads a ragged C_in / C_out with
+  // zeros channel by channel.  The head and output convs of the 2-D specs,
+  // 2 / 3 / 7 -> 64, 64 -> 1 / 2 / 6, and the 65 -> 64 conv behind a
+  // Sup3rConcat were 0.85 of a 4.6 ms fwd + bwd on the generic kernel)
+  if (g.Cin < 1 || g.Cout < 1) return false;
   if (g.k[0] != 3 || g.k[1] != 3 || g.k[2] != 1 || g.D[2] != 1 || g.O[2] != 1) return false;
   if (g.s[0] != g.s[1] || (g.s[0] != 1 && g.s[0] != 2)) return false;
   return g.O[1] >= 8 && (int64_t)g.N * g.O[0] * g.O[1] >= 1024;
@@ -1313,9 +1354,17 @@ size_t conv_wgrad_bf16_2d_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
 }
 
 int launch_conv_wgrad_bf16_2d(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                              float* dw, float* partial, size_t partial_bytes, int accumulate) {
+                              float* dw, float* partial, size_t partial_bytes, int accumulate, int x_bf16) {
   const bool s2 = g.s[0] == 2;
-  if (g.Cin == 32)
+  if (x_bf16) {
+    if (g.Cin % 8 != 0) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_2d: bf16 cells need C_in % 8 == 0");
+    if (g.Cin <= 32)
+      return s2 ? bf_2d_launch<2, 2, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
+                : bf_2d_launch<2, 1, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
+    return s2 ? bf_2d_launch<4, 2, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
+              : bf_2d_launch<4, 1, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
+  }
+  if (g.Cin <= 32)
     return s2 ? bf_2d_launch<2, 2>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)
               : bf_2d_launch<2, 1>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
   return s2 ? bf_2d_launch<4, 2>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate)

@@ -935,7 +935,11 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
               if (o.cg.Cin % 8 != 0) demote(d.in0, changed);   // (logical-axes kernel: 16-B bf16 chunks)
               // (a saved bf16 input is re-read by the weight gradient: the
               // transpose-read kernels stage bf16 directly)
-              if (training && !o.wgrad_bf16 && !(o.wgrad_bf16_gen && !s3_opt_has(S3O_NO_DISC_BF16)))
+              // (round 5: ... and so does the 2-D weight gradient, so that the
+              // 64 -> 64 layers of a 2-D training plan keep bf16 cells and run
+              // forward on the weights-stationary kernel)
+              if (training && !o.wgrad_bf16 && !(o.wgrad_bf16_gen && !s3_opt_has(S3O_NO_DISC_BF16)) &&
+                  !(o.wgrad_bf16_2d && o.cg.Cin % 8 == 0 && !s3_opt_has(S3O_NO_TRAIN2D_BF16)))
                 demote(d.in0, changed);
             } else if (training) {
               // every other conv reads / writes fp32 in training plans — except
@@ -2116,7 +2120,7 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
                                       pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, only16 ? 1 : 0,
                                       pl->precision == S3_PREC_BF16X3);
           else if (o.wgrad_bf16_2d)
-            rc = launch_conv_wgrad_bf16_2d(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad);
+            rc = launch_conv_wgrad_bf16_2d(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16);
           else if (o.wgrad_bf16_gen)
             rc = launch_conv_wgrad_bf16_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16,
                                             pl->precision == S3_PREC_BF16X3);

@@ -131,6 +131,54 @@ def test_gen_kernel_can_be_switched_off():
     assert np.abs(ya - yc).max() < 3e-2 * max(1.0, np.abs(yc).max())
 
 
+def test_2d_training_plan_keeps_bf16_cells():
+    """a 2-D training plan: the 64 -> 64 k layers keep bf16 cells (forward on
+    the weights-stationary kernel, weight gradient staged from bf16), EVERY
+    conv's weight gradient — the 2 -> 64 head and the 64 -> 2 output conv
+    included — on the transpose-read MFMA kernel; option NO_TRAIN2D_BF16 is
+    the fp32-cell plan of the start of round 5 and gives the same gradients to
+    bf16 noise.  (Parity with the oracle: the bf16 forward / backward tests
+    above run on this plan.)"""
+    from sup3r_amd.engine import Network
+    rel = 'spatial/gen_2x_2f.json'
+    spec = load_surface(rel)
+    shape = (3, 20, 18, 2)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(shape).astype(np.float32)
+    net = Network(spec, precision='bf16')
+    net.build(shape, seed=4)
+    dev = net.dev
+    out = {}
+    for name, opts in (('cells16', {}), ('cells32', {'NO_TRAIN2D_BF16': 1})):
+        ph = net.plan(shape, training=True, options=opts)
+        convs = [(i, op) for i, op in enumerate(ph.plan.ops)
+                 if op['kind'] == S.OP_CONV]
+        info = [ph.op_info(i) for i, _ in convs]
+        assert all(f['wgrad'] == 'bf16_2d' for f in info), [f['wgrad'] for f in info]
+        trunk = [f for f, (_, op) in zip(info, convs)
+                 if op['cin'] == 64 and op['cout'] % 64 == 0]
+        in16 = [ph.tensor_is_bf16(op['in0']) for _, op in convs if op['cin'] == 64]
+        if name == 'cells16':
+            assert all(f['fwd'] == 'conv2d_ws' for f in trunk) and len(trunk) >= 34
+            assert all(in16)
+        else:
+            assert all(f['fwd'] == 'mfma_gen' for f in trunk)
+            assert not any(in16)
+        y = ph.forward(dev.to_device(x))
+        dy = np.random.default_rng(6).standard_normal(
+            tuple(ph.out_shape)).astype(np.float32)
+        ph.backward(dev.to_device(dy), need_dx=False)
+        out[name] = (y.cpu().numpy(), [np.array(g) for g in net.grads])
+        del ph
+        net.clear_plans()
+    ya, ga = out['cells16']
+    yb, gb = out['cells32']
+    assert np.abs(ya - yb).max() < 3e-2 * max(1.0, np.abs(yb).max())
+    for a, b in zip(ga, gb):
+        assert np.abs(a - b).max() <= 3e-2 * max(np.abs(b).max(), 1e-6), \
+            (a.shape, np.abs(a - b).max(), np.abs(b).max())
+
+
 # ---------------------------------------------------------------------------
 # exact tests: one-hot filters.  Every output channel of every conv copies ONE
 # (tap, input channel) of its input (+ an integer bias); inputs are small
