@@ -648,17 +648,16 @@ class ForwardPass:
     def _device_path(cls, model, chunk):
         """single-step generator on this package's engine, no exo field
         combined at the output: the chunk batches go through one plan on the
-        device — 5-D models, and (round 5) 4-D (spatial) models without
-        exogenous data, whose batch axis is the chunks' time axis
-        (forward_pass.py:274-337); anything else (``MultiStepGan``, 'output'
-        exo, spatial models with exo fields) takes ``run_generator`` ->
+        device — 5-D models, and (round 5) 4-D (spatial) models, whose batch
+        axis is the chunks' time axis (forward_pass.py:274-337); anything
+        else (``MultiStepGan``, 'output' exo) takes ``run_generator`` ->
         ``model.generate`` chunk by chunk"""
         if getattr(model, '_gen', None) is None or \
                 not getattr(model, 'supports_device_chunks', False):
             return False
         if not getattr(model, 'is_5d', False):
-            return bool(getattr(model, 'is_4d', False)) and \
-                not chunk.exo_data and cls.device_chunks_4d
+            if not (getattr(model, 'is_4d', False) and cls.device_chunks_4d):
+                return False
         for entry in (chunk.exo_data or {}).values():
             if any(st['combine_type'].lower() == 'output'
                    for st in entry['steps']):
@@ -827,6 +826,7 @@ class ForwardPass:
         # its own norm_input
         from .gan import Sup3rGan as _BaseGan
         dev_norm = is_4d and cls.device_norm_4d and \
+            not any(c.exo_data for c in group) and \
             getattr(type(model).norm_input, '__func__',
                     type(model).norm_input) is _BaseGan.norm_input
         for chunk in group:
@@ -851,7 +851,8 @@ class ForwardPass:
                 # (contiguous: the normalisation below walks a transposed
                 # view four times slower)
                 x = model._combine_fwp_input(np.ascontiguousarray(np.transpose(
-                    np.asarray(chunk.input_data), (2, 0, 1, 3))), None)
+                    np.asarray(chunk.input_data), (2, 0, 1, 3))),
+                    cls._batch_axis(exo, time_first=True))
             else:
                 x = model._combine_fwp_input(
                     np.asarray(chunk.input_data)[None], cls._batch_axis(exo))
@@ -877,10 +878,13 @@ class ForwardPass:
                 for exo in exos:
                     assert exo is not None and name in exo, \
                         f'the generator needs exogenous feature "{name}"'
+                    field = np.asarray(exo.get_combine_type_data(
+                        name, 'layer'))
+                    # (4-D: the field's time steps on the batch axis too)
                     arr = model._reshape_norm_exo(
-                        tuple([1] + sh[1:]),
-                        np.asarray(exo.get_combine_type_data(
-                            name, 'layer'))[None], name)
+                        tuple([n_t if is_4d else 1] + sh[1:]),
+                        np.transpose(field, (2, 0, 1, 3)) if is_4d
+                        else field[None], name)
                     parts.append(arr.astype(np.float32, copy=False))
                 layer_exo[name] = cls._upload_async(
                     dev, np.concatenate(parts, axis=0) if n > 1 else parts[0],
@@ -1137,13 +1141,18 @@ class ForwardPass:
         return stage.to(dev.torch_device, non_blocking=True)
 
     @staticmethod
-    def _batch_axis(exo):
+    def _batch_axis(exo, time_first=False):
         """the exo structure of ONE chunk with a leading batch axis on every
-        field (``_reshape_data_chunk`` for 5-D models, forward_pass.py:
-        303-337), without touching the caller's arrays"""
+        field — or, for a 4-D model, the field's time axis moved there
+        (``_reshape_data_chunk``, forward_pass.py:303-337), without touching
+        the caller's arrays"""
         if exo is None:
             return None
         from .utilities import ExoData
+        if time_first:
+            return ExoData({f: {'steps': [dict(st, data=np.transpose(
+                np.asarray(st['data']), (2, 0, 1, 3))) for st in e['steps']]}
+                for f, e in exo.items()})
         return ExoData({f: {'steps': [dict(st, data=np.asarray(st['data'])[
             None]) for st in e['steps']]} for f, e in exo.items()})
 
@@ -1157,7 +1166,7 @@ class ForwardPass:
     # halo crop + un-normalisation inside the tail conv (s3_plan_forward_window)
     # where the plan supports it; False: full output + s3_chunk_epilogue
     window_forward = True
-    # spatial (4-D) models without exo data on the device chunk path (False:
+    # spatial (4-D) models on the device chunk path (False:
     # chunk by chunk through model.generate, as before round 5)
     device_chunks_4d = True
     # ... with the transpose to time-major + norm_input on the device (False:

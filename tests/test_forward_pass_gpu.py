@@ -469,6 +469,83 @@ def test_spatial_model_chunks_on_the_device_equal_the_generate_path(cfg,
             assert np.abs(got[k] - ref[k]).max() < 3e-2 * np.abs(ref[k]).max()
 
 
+def test_spatial_model_with_exo_chunks_on_the_device():
+    """the sup3rcc spatial step (``sup3rcc/gen_wind_5x_1x_6f.json``): lo-res
+    topography concatenated at the input ('input' combine type) and hi-res
+    topography through a mid-network ``Sup3rConcat`` ('layer'), on a 4-D model
+    whose batch axis is the chunk's time axis — exo fields move their time
+    axis to the batch too (forward_pass.py:303-337).  Batches of such chunks
+    on the device == chunk by chunk through ``run_generator`` ->
+    ``model.generate``, bit for bit."""
+    from sup3r_amd import ForwardPass, Sup3rGan
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    feats = ['u_10m', 'v_10m', 'u_100m', 'v_100m', 'u_200m', 'v_200m']
+    Sup3rGan.seed(13)
+    means = {f: np.float32(0.2 * (i + 1)) for i, f in enumerate(feats)}
+    stds = {f: np.float32(1.5 + 0.2 * i) for i, f in enumerate(feats)}
+    means['topography'] = np.float32(300.0)
+    stds['topography'] = np.float32(150.0)
+    m = Sup3rGan(os.path.join(CFG, 'sup3r/sup3rcc/gen_wind_5x_1x_6f.json'),
+                 os.path.join(CFG, 'test_disc_s_same.json'), means=means,
+                 stdevs=stds, precision='bf16')
+    m.set_model_params(lr_features=feats + ['topography'],
+                       hr_out_features=feats, hr_exo_features=['topography'],
+                       s_enhance=5, t_enhance=1)
+    m.init_weights((1, 18, 17, 7), (1, 90, 85, 7))
+    assert m.is_4d
+    rng = np.random.default_rng(23)
+    domain = (rng.standard_normal((32, 30, 9, 6)) * 2 + 0.4).astype(np.float32)
+    topo_hr = (300 + 150 * rng.standard_normal((160, 150, 1))).astype(
+        np.float32)
+    topo_lr = topo_hr.reshape(32, 5, 30, 5, 1).mean(axis=(1, 3)).astype(
+        np.float32)
+    exo = {'topography': {'steps': [
+        {'model': 0, 'combine_type': 'input', 'data': topo_lr,
+         's_enhance': 1, 't_enhance': 1},
+        {'model': 0, 'combine_type': 'layer', 'data': topo_hr,
+         's_enhance': 5, 't_enhance': 1}]}}
+    register_model('Sup3rGan', {'model_dir': 'fwp-4d-exo'}, m)
+    st = ArrayStrategy(domain, {'model_dir': 'fwp-4d-exo'}, (16, 15, 6),
+                       spatial_pad=1, temporal_pad=1, exo_data=exo,
+                       max_nodes=1, model=m)
+    fwp = ForwardPass(st, 0)
+    ids = [int(i) for i in st.node_chunks[0]]
+    assert len(ids) == 8
+
+    def run(batch):
+        return {c.index: np.array(d) for c, failed, d in
+                ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids),
+                                        m, batch=batch) if not failed}
+    c0 = fwp.get_input_chunk(ids[0])
+    assert c0.exo_data['topography']['steps'][1]['data'].ndim == 4
+    assert ForwardPass._device_path(m, c0)
+    try:
+        ForwardPass.device_chunks_4d = False
+        assert not ForwardPass._device_path(m, c0)
+        ref = run(1)
+    finally:
+        ForwardPass.device_chunks_4d = True
+    assert len(ref) == len(ids)
+    for batch in (1, 4):
+        got = run(batch)
+        assert sorted(got) == sorted(ref)
+        for k in ref:
+            assert got[k].shape == ref[k].shape and got[k].ndim == 4
+            assert got[k].shape[-1] == 6 and np.isfinite(got[k]).all()
+            np.testing.assert_array_equal(got[k], ref[k])
+    # the topography matters (a different field, different winds)
+    exo2 = {'topography': {'steps': [dict(st_, data=st_['data'][::-1].copy())
+                                     for st_ in exo['topography']['steps']]}}
+    st2 = ArrayStrategy(domain, {'model_dir': 'fwp-4d-exo'}, (16, 15, 6),
+                        spatial_pad=1, temporal_pad=1, exo_data=exo2,
+                        max_nodes=1, model=m)
+    fwp2 = ForwardPass(st2, 0)
+    other = next(np.array(d) for c, failed, d in ForwardPass.iter_chunks(
+        [fwp2.get_input_chunk(ids[0])], m, batch=1))
+    assert np.abs(other - ref[ids[0]]).max() > 1e-3
+
+
 # ------------------------------------------- the reference's entry points
 def _topo_model(tmp_path=None):
     """a topography-conditioned 3x / 4x generator (Sup3rConcat mid-network)"""
