@@ -464,6 +464,20 @@ int s3_chunk_epilogue(s3_ctx* ctx, const float* y, int n_chunks, const int64_t* 
 int s3_chunk_time_first(s3_ctx* ctx, const float* x, int n_chunks, const int64_t* hwt, int c,
                         const double* mean_host, const double* std_host, int stats_fp32,
                         float* out);
+/* between two steps of a MultiStepGan chain (MultiStepGan.generate,
+ * sup3r/models/multi_step.py:233-259) on the device, position by position: y =
+ * (n_pos, c_src) the NORMALISED output of step i's generator; x = (n_pos, c_sel
+ * + n_exo) the normalised input of step i + 1: channel k < c_sel = norm(
+ * un_norm(y[map[k]])) — un_norm_output of step i (y * scale[c] + shift[c] per
+ * SOURCE channel, abstract.py:240-275), _match_model_input's selection
+ * (multi_step.py:148-194), norm_input of step i + 1 ((v - mean[k]) / std[k] per
+ * DESTINATION channel, abstract.py:197-238); channel c_sel + j = norm(exo[j]),
+ * exo = (n_pos, n_exo) the raw 'input' exo fields _combine_fwp_input appends
+ * (interface.py:259-356).  numpy's fp32 arithmetic (one rounding per
+ * operation).  NULL scale / shift: no un-normalisation; NULL mean / std: none. */
+int s3_step_handover(s3_ctx* ctx, const float* y, int64_t n_pos, int c_src, const int* map_host,
+                     int c_sel, const float* scale_host, const float* shift_host, const float* exo,
+                     int n_exo, const float* mean_host, const float* std_host, float* x);
 /* the same hand-over for a 2-D (spatial) model, whose batch axis is the chunk's
  * time axis (ForwardPass._reshape_data_chunk, sup3r/pipeline/forward_pass.py:
  * 274-337: np.transpose(data_chunk, (2, 0, 1, 3)) in, np.transpose(hi_res, (1,

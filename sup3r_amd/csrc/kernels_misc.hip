@@ -1809,6 +1809,71 @@ extern "C" int s3_chunk_time_last(s3_ctx* ctx, const float* y, int n_chunks, con
   return S3_OK;
 }
 
+// One model step's output -> the next step's input of a MultiStepGan chain
+// (sup3r/models/multi_step.py:233-259), position by position:
+// un_norm_output of step i (y * std + mean, abstract.py:240-275),
+// _match_model_input's channel selection (multi_step.py:148-194), the 'input'
+// exo channels _combine_fwp_input appends (interface.py:259-356), norm_input
+// of step i + 1 ((x - mean) / std, abstract.py:197-238) — numpy's fp32
+// arithmetic: one rounding per operation, no fused multiply-add.
+struct StepHO { int c_src, c_sel, n_exo, un, nrm; int map[16]; float scale[16], shift[16], mean[16], sd[16]; };
+__global__ void step_handover_kernel(const float* __restrict__ y, const float* __restrict__ exo,
+                                     float* __restrict__ x, int64_t n_pos, StepHO e) {
+  const int c_dst = e.c_sel + e.n_exo;
+  const int64_t total = n_pos * c_dst;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / c_dst;
+    const int ch = (int)(i - p * c_dst);
+    float v;
+    if (ch < e.c_sel) {
+      const int sc = e.map[ch];
+      v = y[p * e.c_src + sc];
+      if (e.un) {
+        float m = v * e.scale[sc];
+        asm volatile("" : "+v"(m));
+        v = m + e.shift[sc];
+      }
+    } else {
+      v = exo[p * e.n_exo + (ch - e.c_sel)];
+    }
+    if (e.nrm) {
+      float d = v - e.mean[ch];
+      asm volatile("" : "+v"(d));
+      v = __fdiv_rn(d, e.sd[ch]);
+    }
+    x[i] = v;
+  }
+}
+
+extern "C" int s3_step_handover(s3_ctx* ctx, const float* y, int64_t n_pos, int c_src, const int* map_host,
+                                int c_sel, const float* scale_host, const float* shift_host, const float* exo,
+                                int n_exo, const float* mean_host, const float* std_host, float* x) {
+  if (!ctx || !y || !x || !map_host) return S3_EINVAL;
+  if (n_pos < 1 || c_src < 1 || c_src > 16 || c_sel < 1 || n_exo < 0 || c_sel + n_exo > 16)
+    S3_FAIL(ctx, S3_EINVAL, "step_handover: 1 .. 16 channels on either side");
+  if (n_exo > 0 && !exo) S3_FAIL(ctx, S3_EINVAL, "step_handover: exo channels without an exo tensor");
+  StepHO e;
+  e.c_src = c_src; e.c_sel = c_sel; e.n_exo = n_exo;
+  e.un = scale_host && shift_host;
+  e.nrm = mean_host && std_host;
+  for (int i = 0; i < 16; ++i) {
+    e.map[i] = 0;
+    if (i < c_sel) {
+      if (map_host[i] < 0 || map_host[i] >= c_src) S3_FAIL(ctx, S3_EINVAL, "step_handover: channel map out of range");
+      e.map[i] = map_host[i];
+    }
+    e.scale[i] = e.un && i < c_src ? scale_host[i] : 1.f;
+    e.shift[i] = e.un && i < c_src ? shift_host[i] : 0.f;
+    e.mean[i] = e.nrm && i < c_sel + n_exo ? mean_host[i] : 0.f;
+    e.sd[i] = e.nrm && i < c_sel + n_exo ? std_host[i] : 1.f;
+  }
+  hipLaunchKernelGGL(step_handover_kernel, dim3(grid_for(n_pos * (c_sel + n_exo), ctx->num_cu)), dim3(kBlock), 0,
+                     ctx->stream, y, exo, x, n_pos, e);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 extern "C" int s3_chunk_stats(s3_ctx* ctx, const float* x, int n_chunks,
                               int64_t pos_per_chunk, int c, float* partial) {
   if (!ctx) return S3_EINVAL;

@@ -652,6 +652,9 @@ class ForwardPass:
         axis is the chunks' time axis (forward_pass.py:274-337); anything
         else (``MultiStepGan``, 'output' exo) takes ``run_generator`` ->
         ``model.generate`` chunk by chunk"""
+        steps = getattr(model, 'models', None)
+        if steps is not None:
+            return cls._device_chain(model, chunk)
         if getattr(model, '_gen', None) is None or \
                 not getattr(model, 'supports_device_chunks', False):
             return False
@@ -662,6 +665,63 @@ class ForwardPass:
             if any(st['combine_type'].lower() == 'output'
                    for st in entry['steps']):
                 return False
+        return True
+
+    #: MultiStepGan chains on the device chunk path (False: chunk by chunk
+    #: through ``MultiStepGan.generate``, every hand-over through host numpy)
+    device_chains = True
+
+    @classmethod
+    def _device_chain(cls, model, chunk):
+        """a ``MultiStepGan`` whose steps all run on this package's engine
+        with the base class's normalisation, spatial (4-D) steps first, then
+        spatio-temporal (5-D) ones — the reference's production arrangements
+        (examples/sup3rwind/run_configs/wind/config_fwp_spatial.json: two
+        spatial steps; config_fwp_temporal.json: one 5-D step) — fp32
+        statistics and 'input' exo fields, at most 16 channels at a
+        hand-over, no 'output' exo: the hand-overs stay on the device
+        (s3_step_handover); anything else through ``MultiStepGan.generate``"""
+        from .gan import Sup3rGan as _BaseGan
+        steps = list(model.models)
+        if not cls.device_chains or not steps:
+            return False
+
+        def base(m, name):
+            f = getattr(type(m), name, None)
+            return getattr(f, '__func__', f) is getattr(_BaseGan, name)
+        seen_5d = False
+        for i, m in enumerate(steps):
+            if getattr(m, '_gen', None) is None or \
+                    not getattr(m, 'supports_device_chunks', False) or \
+                    hasattr(m, 'models'):
+                return False
+            if not (base(m, 'norm_input') and base(m, 'un_norm_output')):
+                return False
+            if getattr(m, 'is_5d', False):
+                seen_5d = True
+            elif seen_5d or not (getattr(m, 'is_4d', False) and
+                                 cls.device_chunks_4d):
+                return False
+            if m._gen.dev is not steps[0]._gen.dev:
+                return False
+            if len(steps) > 1:
+                if len(m.lr_features) > 16 or len(m.hr_out_features) > 16:
+                    return False
+                if m._means is not None:
+                    for feats in (m.lr_features, m.hr_out_features):
+                        mu, sd = m._stats_for(feats)
+                        if mu.dtype != np.float32 or sd.dtype != np.float32:
+                            return False
+                elif i > 0 and steps[i - 1]._means is not None:
+                    pass
+        for entry in (chunk.exo_data or {}).values():
+            for st in entry['steps']:
+                if st['combine_type'].lower() == 'output':
+                    return False
+                if st.get('model', 0) > 0 and \
+                        st['combine_type'].lower() == 'input' and \
+                        np.asarray(st['data']).dtype != np.float32:
+                    return False
         return True
 
     @classmethod
@@ -816,32 +876,44 @@ class ForwardPass:
 
         from . import _lib
         from .utilities import ExoData
-        gen = model._gen
+        # a MultiStepGan chain runs step by step on the device; a single
+        # model is a chain of one
+        chain = hasattr(model, 'models')
+        steps = list(model.models) if chain else [model]
+        first, last = steps[0], steps[-1]
+        gen = first._gen
         dev, L = gen.dev, _lib.lib()
         n = len(group)
-        is_4d = not getattr(model, 'is_5d', False)
+        is_4d = not getattr(first, 'is_5d', False)
         xs, exos = [], []
+
+        def step_exo(exo, i):
+            """the exo entries model step ``i`` consumes (exo.py:108-130)"""
+            if exo is None or not chain:
+                return exo
+            return exo.get_model_step_exo(i)
+        for chunk in group:
+            exo = chunk.exo_data
+            if exo is not None and not isinstance(exo, ExoData):
+                exo = ExoData(exo)
+            exos.append(exo)
         # 4-D models: transpose + normalisation on the device
         # (s3_chunk_time_first, numpy's arithmetic) unless the model brings
         # its own norm_input
         from .gan import Sup3rGan as _BaseGan
         dev_norm = is_4d and cls.device_norm_4d and \
-            not any(c.exo_data for c in group) and \
-            getattr(type(model).norm_input, '__func__',
-                    type(model).norm_input) is _BaseGan.norm_input
-        for chunk in group:
+            not any(step_exo(e, 0) for e in exos) and \
+            getattr(type(first).norm_input, '__func__',
+                    type(first).norm_input) is _BaseGan.norm_input
+        for chunk, exo in zip(group, exos):
             # (one flat pass; the per-feature reduction over a (…, 2 .. 8)-wide
             # last axis — 0.7 ms per 75 x 75 x 48 chunk — only when it found one)
             if np.isnan(chunk.input_data).any():
                 mask = np.isnan(chunk.input_data).any(axis=(0, 1, 2))
-                feats = np.array(model.lr_features[:len(mask)])[mask]
+                feats = np.array(first.lr_features[:len(mask)])[mask]
                 msg = f'Input data for {feats} contains NaN values!'
                 logger.error(msg)
                 raise RuntimeError(msg)
-            exo = chunk.exo_data
-            if exo is not None and not isinstance(exo, ExoData):
-                exo = ExoData(exo)
-            exos.append(exo)
             if dev_norm:
                 xs.append(np.asarray(chunk.input_data, dtype=np.float32))
                 continue
@@ -850,13 +922,14 @@ class ForwardPass:
                 # model (``_reshape_data_chunk``, forward_pass.py:274-337)
                 # (contiguous: the normalisation below walks a transposed
                 # view four times slower)
-                x = model._combine_fwp_input(np.ascontiguousarray(np.transpose(
+                x = first._combine_fwp_input(np.ascontiguousarray(np.transpose(
                     np.asarray(chunk.input_data), (2, 0, 1, 3))),
-                    cls._batch_axis(exo, time_first=True))
+                    cls._batch_axis(step_exo(exo, 0), time_first=True))
             else:
-                x = model._combine_fwp_input(
-                    np.asarray(chunk.input_data)[None], cls._batch_axis(exo))
-            xs.append(np.asarray(model.norm_input(x), dtype=np.float32))
+                x = first._combine_fwp_input(
+                    np.asarray(chunk.input_data)[None],
+                    cls._batch_axis(step_exo(exo, 0)))
+            xs.append(np.asarray(first.norm_input(x), dtype=np.float32))
         if dev_norm:
             raw = np.stack(xs, axis=0)                  # (n, s1, s2, t, f)
             x_shape = (n * raw.shape[3], raw.shape[1], raw.shape[2],
@@ -866,36 +939,123 @@ class ForwardPass:
             x = np.concatenate(xs, axis=0) if n > 1 else xs[0]
             x_shape = tuple(x.shape)
         n_t = x_shape[0] // n          # 4-D: time steps per chunk
+        lr_t = n_t if is_4d else x_shape[3]
         staged = []               # pinned upload buffers, alive until finish()
-        try:
-            ph = gen.plan(x_shape, training=False)
-            layer_exo = {}
+        pf = C.POINTER(C.c_float)
+        i64x3 = C.c_int64 * 3
+
+        def layer_exo_for(m, ph, i, rank4, nt):
+            """the 'layer' exo fields step ``i``'s generator consumes
+            mid-network, normalised, stacked over the batch, uploaded"""
+            out = {}
             for name in ph.input_names:
                 if name == 'x':
                     continue
                 sh = list(ph.in_shapes[name])
                 parts = []
                 for exo in exos:
-                    assert exo is not None and name in exo, \
+                    e = step_exo(exo, i)
+                    assert e is not None and name in e, \
                         f'the generator needs exogenous feature "{name}"'
-                    field = np.asarray(exo.get_combine_type_data(
-                        name, 'layer'))
+                    field = np.asarray(e.get_combine_type_data(name, 'layer'))
                     # (4-D: the field's time steps on the batch axis too)
-                    arr = model._reshape_norm_exo(
-                        tuple([n_t if is_4d else 1] + sh[1:]),
-                        np.transpose(field, (2, 0, 1, 3)) if is_4d
+                    arr = m._reshape_norm_exo(
+                        tuple([nt if rank4 else 1] + sh[1:]),
+                        np.transpose(field, (2, 0, 1, 3)) if rank4
                         else field[None], name)
                     parts.append(arr.astype(np.float32, copy=False))
-                layer_exo[name] = cls._upload_async(
+                out[name] = cls._upload_async(
                     dev, np.concatenate(parts, axis=0) if n > 1 else parts[0],
                     staged)
+            return out
+
+        def hand_over(i, y, rank4, nt):
+            """step i's normalised output -> step i + 1's normalised input
+            (multi_step.py:233-259) without leaving the device"""
+            m, nxt = steps[i], steps[i + 1]
+            ysh = tuple(int(v) for v in y.shape)
+            nxt4 = not getattr(nxt, 'is_5d', False)
+            if rank4 and not nxt4:
+                # (n t, H, W, C) -> n samples (H, W, t, C)
+                # (_transpose_model_input, multi_step.py:107-146)
+                yt = dev.empty((n, ysh[1], ysh[2], nt, ysh[3]))
+                rc = L.s3_chunk_time_last(
+                    dev.ctx, C.c_void_p(y.data_ptr()), n,
+                    i64x3(nt, ysh[1], ysh[2]), i64x3(0, 0, 0),
+                    i64x3(ysh[1], ysh[2], nt), ysh[3], None, None,
+                    C.c_void_p(yt.data_ptr()))
+                _lib.check(rc, dev.ctx, 's3_chunk_time_last')
+                y, ysh = yt, tuple(int(v) for v in yt.shape)
+            produced = list(m.hr_out_features)
+            if len(produced) != ysh[-1]:
+                raise RuntimeError(
+                    f'step {i} produced {ysh[-1]} channels for '
+                    f'{len(produced)} output features')
+            nxt_exo = [step_exo(e, i + 1) for e in exos]
+            wanted = [f for f in nxt.lr_features
+                      if f not in (nxt_exo[0] or {})]
+            missing = [f for f in wanted if f not in produced]
+            if missing:
+                raise ValueError(
+                    f'step {i + 1} needs {missing}, step {i} only produces '
+                    f'{produced}')
+            extra = len(nxt.lr_features) - len(wanted)
+            names = list(nxt.lr_features[-extra:]) if extra > 0 else []
+            exo_t = None
+            if names:
+                parts = []
+                for e in nxt_exo:
+                    absent = [f for f in names if f not in (e or {})]
+                    assert not absent, (f'exogenous_data lacks {absent} '
+                                        '(combine_type "input")')
+                    a = np.concatenate([np.asarray(e.get_combine_type_data(
+                        f, 'input')) for f in names], axis=-1)
+                    parts.append(np.transpose(a, (2, 0, 1, 3)) if nxt4
+                                 else a[None])
+                exo_arr = np.concatenate(parts, axis=0) if n > 1 else parts[0]
+                if tuple(exo_arr.shape[:-1]) != ysh[:-1]:
+                    raise RuntimeError(
+                        f'"input" exo of step {i + 1} has shape '
+                        f'{exo_arr.shape}, the data {ysh}')
+                exo_t = cls._upload_async(dev, exo_arr, staged)
+            sc = sh_ = mu = sd = None
+            if m._means is not None:
+                mu0, sd0 = m._stats_for(m.hr_out_features)
+                sc = np.ascontiguousarray(sd0, dtype=np.float32)
+                sh_ = np.ascontiguousarray(mu0, dtype=np.float32)
+            if nxt._means is not None:
+                mu1, sd1 = nxt._stats_for(nxt.lr_features)
+                if (sd1 == 0).any():
+                    from warnings import warn
+                    warn('a feature has zero standard deviation; dividing '
+                         'by 1')
+                    sd1 = np.where(sd1 == 0, 1, sd1)
+                mu = np.ascontiguousarray(mu1, dtype=np.float32)
+                sd = np.ascontiguousarray(sd1, dtype=np.float32)
+            cmap = (C.c_int32 * len(wanted))(
+                *[produced.index(f) for f in wanted])
+            xn = dev.empty(ysh[:-1] + (len(wanted) + len(names),))
+            n_pos = int(np.prod(ysh[:-1], dtype=np.int64))
+            rc = L.s3_step_handover(
+                dev.ctx, C.c_void_p(y.data_ptr()), n_pos, ysh[-1], cmap,
+                len(wanted),
+                sc.ctypes.data_as(pf) if sc is not None else None,
+                sh_.ctypes.data_as(pf) if sh_ is not None else None,
+                C.c_void_p(exo_t.data_ptr()) if exo_t is not None else None,
+                len(names),
+                mu.ctypes.data_as(pf) if mu is not None else None,
+                sd.ctypes.data_as(pf) if sd is not None else None,
+                C.c_void_p(xn.data_ptr()))
+            _lib.check(rc, dev.ctx, 's3_step_handover')
+            return xn, nxt4
+        try:
             if dev_norm:
                 rawd = cls._upload_async(dev, raw, staged)
                 xd = dev.empty(x_shape)
                 mu = sd = None
                 f32 = 1
-                if model._means is not None:
-                    mu, sd = model._stats_for(model.lr_features)
+                if first._means is not None:
+                    mu, sd = first._stats_for(first.lr_features)
                     if len(mu) != x_shape[-1]:
                         raise RuntimeError(
                             f'{len(mu)} normalisation statistics for '
@@ -920,27 +1080,36 @@ class ForwardPass:
                 _lib.check(rc, dev.ctx, 's3_chunk_time_first')
             else:
                 xd = cls._upload_async(dev, x, staged)
+            # every step but the last: plan forward + hand-over on the device
+            in_shape = x_shape
+            for i in range(len(steps) - 1):
+                ph_i = steps[i]._gen.plan(x_shape, training=False)
+                y_i = ph_i.forward(xd, layer_exo_for(steps[i], ph_i, i, is_4d,
+                                                     n_t))
+                xd, is_4d = hand_over(i, y_i, is_4d, n_t)
+                del y_i
+                x_shape = tuple(int(v) for v in xd.shape)
+            ph = last._gen.plan(x_shape, training=False)
+            layer_exo = layer_exo_for(last, ph, len(steps) - 1, is_4d, n_t)
             # the enhancement checks of the reference (forward_pass.py:
             # _run_generator) on the plan's output shape
             yshape = tuple(int(v) for v in ph.out_shape)
-            if model.s_enhance * x_shape[1] != yshape[1]:
+            if model.s_enhance * in_shape[1] != yshape[1]:
                 msg = ('The stated spatial enhancement of {}x did not match '
                        'the low res / high res shapes of {} -> {}'.format(
-                           model.s_enhance, x_shape, yshape))
+                           model.s_enhance, in_shape, yshape))
                 logger.error(msg)
                 raise _EnhancementMismatch(msg)
-            if (model.t_enhance != 1) if is_4d else \
-                    (model.t_enhance * x_shape[3] != yshape[3]):
+            if model.t_enhance * lr_t != (n_t if is_4d else yshape[3]):
                 msg = ('The stated temporal enhancement of {}x did not match '
                        'the low res / high res shapes of {} -> {}'.format(
-                           model.t_enhance, x_shape, yshape))
+                           model.t_enhance, in_shape, yshape))
                 logger.error(msg)
                 raise _EnhancementMismatch(msg)
             n_out = yshape[-1]
-            pf = C.POINTER(C.c_float)
             scale = shift = None
-            if model.means is not None:
-                mu, sd = model._stats_for(model.hr_out_features)
+            if last.means is not None:
+                mu, sd = last._stats_for(last.hr_out_features)
                 scale = np.ascontiguousarray(sd, dtype=np.float32)
                 shift = np.ascontiguousarray(mu, dtype=np.float32)
             # (4-D: the chunk's hi-res extents are (H, W, time steps))

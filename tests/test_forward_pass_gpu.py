@@ -3,6 +3,7 @@ equal the un-chunked generator where the receptive field allows
 (test_forward_pass.py:411-558 of the reference, re-run on this generator) and
 the device-pipelined ``run_batched`` must reproduce the chunk-by-chunk ``run``
 bit for bit — ragged edge chunks, halo padding, normalisation, rank sharding."""
+import json
 import os
 
 import numpy as np
@@ -729,6 +730,215 @@ def test_multi_step_model_with_per_step_exo_through_run_chunk():
     # the node runner takes the same route for every chunk
     done, kept = ForwardPass.run(st, 0, return_data=True)
     assert done == 8 and len(kept) == 8
+
+
+def test_step_handover_kernel_vs_numpy():
+    """``s3_step_handover``: un_norm_output of step i, the channel selection
+    of ``_match_model_input``, the trailing 'input' exo channels and
+    norm_input of step i + 1 (multi_step.py:233-259) in one pass — the bits of
+    the numpy chain in fp32"""
+    import ctypes as C
+
+    from sup3r_amd import _lib
+    from sup3r_amd.engine import Device
+    dev, L = Device.get(), _lib.lib()
+    rng = np.random.default_rng(31)
+    pf = C.POINTER(C.c_float)
+    for (n_pos, c_src, cmap, n_exo, un, nrm) in (
+            (10007, 5, [3, 0, 4], 2, True, True),
+            (4096, 2, [0, 1], 0, True, True),
+            (333, 14, list(range(14)), 1, True, False),
+            (1000, 3, [2], 0, False, True),
+            (77, 4, [1, 1, 0], 3, False, False)):
+        y = (rng.standard_normal((n_pos, c_src)) * 3).astype(np.float32)
+        exo = (300 + 150 * rng.standard_normal((n_pos, max(n_exo, 1)))).astype(
+            np.float32)
+        sc = (0.5 + rng.random(c_src)).astype(np.float32)
+        sh = rng.standard_normal(c_src).astype(np.float32)
+        c_dst = len(cmap) + n_exo
+        mu = rng.standard_normal(c_dst).astype(np.float32)
+        sd = (0.5 + rng.random(c_dst)).astype(np.float32)
+        u = y * sc + sh if un else y
+        want = u[:, cmap]
+        if n_exo:
+            want = np.concatenate([want, exo[:, :n_exo]], axis=-1)
+        if nrm:
+            want = (want - mu) / sd
+        assert want.dtype == np.float32
+        yd, ed = dev.to_device(y), dev.to_device(exo[:, :max(n_exo, 1)].copy())
+        xd = dev.empty((n_pos, c_dst))
+        rc = L.s3_step_handover(
+            dev.ctx, C.c_void_p(yd.data_ptr()), n_pos, c_src,
+            (C.c_int32 * len(cmap))(*cmap), len(cmap),
+            sc.ctypes.data_as(pf) if un else None,
+            sh.ctypes.data_as(pf) if un else None,
+            C.c_void_p(ed.data_ptr()) if n_exo else None, n_exo,
+            mu.ctypes.data_as(pf) if nrm else None,
+            sd.ctypes.data_as(pf) if nrm else None, C.c_void_p(xd.data_ptr()))
+        _lib.check(rc, dev.ctx, 's3_step_handover')
+        np.testing.assert_array_equal(xd.cpu().numpy(), want)
+    # argument checks
+    rc = L.s3_step_handover(dev.ctx, C.c_void_p(yd.data_ptr()), 10, 4,
+                            (C.c_int32 * 1)(7), 1, None, None, None, 0, None,
+                            None, C.c_void_p(xd.data_ptr()))
+    assert rc != 0 and 'map' in _lib.last_error(dev.ctx)
+
+
+def test_multi_step_chain_of_spatial_steps_on_the_device():
+    """MultiStepGan([spatial 2x, spatial 5x + topography]) through
+    ``iter_chunks``: plans, hand-over (s3_step_handover: un-normalise, pick
+    the next step's channels, append its lo-res topography, normalise), exo
+    uploads, crop and delivery on the device — bit-identical to the chain of
+    ``generate`` calls through host numpy (multi_step.py:233-259)"""
+    from sup3r_amd import ForwardPass, MultiStepGan, Sup3rGan
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    Sup3rGan.seed(19)
+    f6 = ['u_10m', 'v_10m', 'u_100m', 'v_100m', 'u_200m', 'v_200m']
+    st = {f: (0.1 * (i + 1), 1.0 + 0.25 * i) for i, f in enumerate(f6)}
+    st['topography'] = (300.0, 150.0)
+    means = {k: np.float32(v[0]) for k, v in st.items()}
+    stds = {k: np.float32(v[1]) for k, v in st.items()}
+    # step 1: 6 features 2x (no exo); step 2: the same 6 in ANOTHER order +
+    # lo-res topography at the input, hi-res topography mid-network, 5x
+    spec1 = json.load(open(os.path.join(CFG, 'sup3r/spatial/gen_2x_2f.json')))
+    for layer in (spec1['hidden_layers'] if isinstance(spec1, dict)
+                  else spec1):
+        if layer.get('filters') == 2:
+            layer['filters'] = 6
+    m1 = Sup3rGan(spec1, os.path.join(CFG, 'test_disc_s_same.json'),
+                  means=means, stdevs=stds, precision='bf16')
+    m1.set_model_params(lr_features=f6, hr_out_features=f6, s_enhance=2,
+                        t_enhance=1)
+    m1.init_weights((1, 18, 17, 6), (1, 36, 34, 6))
+    order = ['v_10m', 'u_10m', 'u_200m', 'v_200m', 'u_100m', 'v_100m']
+    means2 = {k: np.float32(v + 0.05) for k, v in means.items()}
+    m2 = Sup3rGan(os.path.join(CFG, 'sup3r/sup3rcc/gen_wind_5x_1x_6f.json'),
+                  os.path.join(CFG, 'test_disc_s_same.json'), means=means2,
+                  stdevs=stds, precision='bf16')
+    m2.set_model_params(lr_features=order + ['topography'],
+                        hr_out_features=order, hr_exo_features=['topography'],
+                        s_enhance=5, t_enhance=1)
+    m2.init_weights((1, 36, 34, 7), (1, 180, 170, 7))
+    ms = MultiStepGan([m1, m2])
+    assert ms.s_enhance == 10 and ms.t_enhance == 1 and ms.is_4d
+    register_model('MultiStepGan', {'model_dirs': ['s1', 's2']}, ms)
+    rng = np.random.default_rng(29)
+    domain = (rng.standard_normal((32, 30, 7, 6)) * 2 + 0.4).astype(np.float32)
+    topo_hr = (300 + 150 * rng.standard_normal((320, 300, 1))).astype(
+        np.float32)
+    topo_mid = topo_hr.reshape(64, 5, 60, 5, 1).mean(axis=(1, 3)).astype(
+        np.float32)
+    exo = {'topography': {'steps': [
+        {'model': 1, 'combine_type': 'input', 'data': topo_mid,
+         's_enhance': 2, 't_enhance': 1},
+        {'model': 1, 'combine_type': 'layer', 'data': topo_hr,
+         's_enhance': 10, 't_enhance': 1}]}}
+    stg = ArrayStrategy(domain, {'model_dirs': ['s1', 's2']}, (16, 15, 4),
+                        spatial_pad=1, temporal_pad=1, exo_data=exo,
+                        model_class='MultiStepGan', max_nodes=1, model=ms)
+    fwp = ForwardPass(stg, 0)
+    ids = [int(i) for i in stg.node_chunks[0]]
+    assert len(ids) == 8
+
+    def run(batch):
+        return {c.index: np.array(d) for c, failed, d in
+                ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids),
+                                        ms, batch=batch) if not failed}
+    c0 = fwp.get_input_chunk(ids[0])
+    assert ForwardPass._device_path(ms, c0)
+    try:
+        ForwardPass.device_chains = False
+        assert not ForwardPass._device_path(ms, c0)
+        ref = run(1)
+    finally:
+        ForwardPass.device_chains = True
+    assert len(ref) == len(ids)
+    for batch in (1, 3):
+        got = run(batch)
+        assert sorted(got) == sorted(ref)
+        for k in ref:
+            assert got[k].shape == ref[k].shape and got[k].shape[-1] == 6
+            assert np.isfinite(got[k]).all()
+            np.testing.assert_array_equal(got[k], ref[k])
+    # ... and the host chain is the manual chain of generate calls
+    c = fwp.get_input_chunk(ids[1])
+    y1 = m1.generate(np.transpose(c.input_data, (2, 0, 1, 3)))
+    sel = y1[..., [f6.index(f) for f in order]]
+    e = c.exo_data['topography']['steps']
+    y2 = m2.generate(sel, exogenous_data={'topography': {'steps': [
+        {'model': 0, 'combine_type': 'input',
+         'data': np.transpose(e[0]['data'], (2, 0, 1, 3))},
+        {'model': 0, 'combine_type': 'layer',
+         'data': np.transpose(e[1]['data'], (2, 0, 1, 3))}]}})
+    want = np.transpose(y2, (1, 2, 0, 3))[tuple(c.hr_crop_slice)]
+    np.testing.assert_array_equal(ref[ids[1]], want)
+    # a MultiStepGan of ONE step (config_fwp_temporal.json) is a chain too
+    one = MultiStepGan([m1])
+    register_model('MultiStepGan', {'model_dirs': ['s1']}, one)
+    st1 = ArrayStrategy(domain, {'model_dirs': ['s1']}, (16, 15, 4),
+                        spatial_pad=1, temporal_pad=1,
+                        model_class='MultiStepGan', max_nodes=1, model=one)
+    f1 = ForwardPass(st1, 0)
+    ca = f1.get_input_chunk(0)
+    assert ForwardPass._device_path(one, ca)
+    a = next(np.array(d) for _, _, d in ForwardPass.iter_chunks(
+        [ca], one, batch=1))
+    b = next(np.array(d) for _, _, d in ForwardPass.iter_chunks(
+        [f1.get_input_chunk(0)], m1, batch=1))
+    np.testing.assert_array_equal(a, b)
+
+
+def test_multi_step_chain_spatial_then_temporal_on_the_device():
+    """MultiStepGan([spatial 2x, spatio-temporal 3x / 4x + topography]): the
+    hand-over also moves the time axis from the batch to axis 3
+    (_transpose_model_input, multi_step.py:107-146); device chain == host
+    chain, batches of 1 and 3 chunks"""
+    from sup3r_amd import ForwardPass, MultiStepGan, Sup3rGan
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    feats = ['u_10m', 'v_10m']
+    Sup3rGan.seed(11)
+    m_s = Sup3rGan(os.path.join(CFG, 'test_gen_s_2x_2f.json'),
+                   os.path.join(CFG, 'test_disc_s_same.json'),
+                   means={f: np.float32(0.1) for f in feats},
+                   stdevs={f: np.float32(2.0) for f in feats})
+    m_s.set_model_params(lr_features=feats, hr_out_features=feats,
+                         s_enhance=2, t_enhance=1)
+    m_s.init_weights((4, 16, 16, 2), (4, 32, 32, 2))
+    m_st = _topo_model()
+    ms = MultiStepGan([m_s, m_st])
+    register_model('MultiStepGan', {'model_dirs': ['s', 'st-topo-b']}, ms)
+    rng = np.random.default_rng(37)
+    domain = (rng.standard_normal((28, 26, 8, 2)) * 2 + 0.3).astype(np.float32)
+    topo = (300 + 150 * rng.standard_normal((168, 156, 1))).astype(np.float32)
+    exo = {'topography': {'steps': [
+        {'model': 1, 'combine_type': 'layer', 'data': topo, 's_enhance': 6,
+         't_enhance': 4}]}}
+    stg = ArrayStrategy(domain, {'model_dirs': ['s', 'st-topo-b']},
+                        (14, 13, 4), spatial_pad=1, temporal_pad=1,
+                        exo_data=exo, model_class='MultiStepGan',
+                        max_nodes=1, model=ms)
+    fwp = ForwardPass(stg, 0)
+    ids = [int(i) for i in stg.node_chunks[0]]
+    assert len(ids) == 8
+
+    def run(batch):
+        return {c.index: np.array(d) for c, failed, d in
+                ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids),
+                                        ms, batch=batch) if not failed}
+    assert ForwardPass._device_path(ms, fwp.get_input_chunk(ids[0]))
+    try:
+        ForwardPass.device_chains = False
+        ref = run(1)
+    finally:
+        ForwardPass.device_chains = True
+    assert len(ref) == 8
+    for batch in (1, 3):
+        got = run(batch)
+        for k in ref:
+            assert got[k].shape == ref[k].shape and got[k].ndim == 4
+            np.testing.assert_array_equal(got[k], ref[k])
 
 
 def test_residency_is_explicit():
