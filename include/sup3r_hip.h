@@ -464,6 +464,14 @@ int s3_chunk_epilogue(s3_ctx* ctx, const float* y, int n_chunks, const int64_t* 
 int s3_chunk_time_first(s3_ctx* ctx, const float* x, int n_chunks, const int64_t* hwt, int c,
                         const double* mean_host, const double* std_host, int stats_fp32,
                         float* out);
+/* a time-invariant exo field laid over a chunk's time steps on the device:
+ * dst[o][a][r][b] = src[o][a][b] for r < reps (outer x a x b floats in, outer x
+ * a x reps x b out).  ForwardPass.pad_source_data (sup3r/pipeline/
+ * forward_pass.py:160-186) repeats 3-D exo fields along time on the host
+ * (np.repeat) before every chunk; here the chunk carries a zero-stride view and
+ * the executor uploads the field once. */
+int s3_broadcast_axis(s3_ctx* ctx, const float* src, int64_t outer, int64_t a, int64_t b, int64_t reps,
+                      float* dst);
 /* between two steps of a MultiStepGan chain (MultiStepGan.generate,
  * sup3r/models/multi_step.py:233-259) on the device, position by position: y =
  * (n_pos, c_src) the NORMALISED output of step i's generator; x = (n_pos, c_sel

@@ -43,7 +43,7 @@ EXPORTS = [
     's3_copy_channels', 's3_affine_channels', 's3_fill', 's3_copy_block',
     's3_coarsen', 's3_gaussian_smooth', 's3_chunk_stats',
     's3_chunk_epilogue', 's3_chunk_time_last', 's3_chunk_time_first',
-    's3_step_handover',
+    's3_step_handover', 's3_broadcast_axis',
     's3_host_register', 's3_host_unregister', 's3_d2h_window',
     's3_d2h_stream', 's3_host_alloc', 's3_host_free', 's3_d2h_async',
     's3_dma_d2h_begin', 's3_dma_wait',
@@ -189,6 +189,7 @@ def lib():
         's3_chunk_time_first': (i32, [vp, vp, i32, C.POINTER(i64), i32,
                                       C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), i32, vp]),
+        's3_broadcast_axis': (i32, [vp, vp, i64, i64, i64, i64, vp]),
         's3_step_handover': (i32, [vp, vp, i64, i32, C.POINTER(i32), i32, pf,
                                    pf, vp, i32, pf, pf, vp]),
         's3_chunk_time_last': (i32, [vp, vp, i32, C.POINTER(i64),

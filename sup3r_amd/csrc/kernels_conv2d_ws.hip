@@ -147,7 +147,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     im_ = im_ > g.N - 1 ? g.N - 1 : im_;                                                        \
     r_ = r_ < 0 ? 0 : (r_ > g.H - 1 ? g.H - 1 : r_);                                            \
     c_ = c_ < 0 ? 0 : (c_ > g.W - 1 ? g.W - 1 : c_);                                            \
-    const unsigned cell_ = ((unsigned)im_ * g.H + r_) * g.W + c_; /* < 2^25 */                  \
+    const unsigned cell_ = ((unsigned)im_ * g.H + r_) * g.W + c_; /* < 2^31 */                  \
     P = *reinterpret_cast<const uint4*>(x + (size_t)cell_ * 64 + (tid & 7) * 8);                \
   }
   // (named registers, not an array: an array that lives across the tap loop
@@ -359,8 +359,10 @@ bool conv2d_ws_geom_ok(const ConvGeom& g) {
   if (g.act == S3_ACT_LEAKY && !(g.alpha >= 0.f && g.alpha <= 1.f)) return false;
   // per sample, like the logical-axes kernel it replaces for these layers
   if ((int64_t)g.O[0] * g.O[1] < 256) return false;
-  return (int64_t)g.N * g.D[0] * g.D[1] * 64 < ((int64_t)1 << 31) &&
-         (int64_t)g.N * g.O[0] * g.O[1] * g.Cout < ((int64_t)1 << 31);
+  // (cell indices are 32-bit, element offsets 64-bit: the 750 x 750 x 96-image
+  // hi-res layers of a 10x chain of spatial steps — 3.5e9 elements — stay here)
+  return (int64_t)g.N * g.D[0] * g.D[1] < ((int64_t)1 << 31) &&
+         (int64_t)g.N * g.O[0] * g.O[1] * (g.d2s < 1 ? 1 : g.d2s) * (g.d2s < 1 ? 1 : g.d2s) < ((int64_t)1 << 31);
 }
 
 // the few-feature output conv: 64 -> C_out <= 16, no depth-to-space

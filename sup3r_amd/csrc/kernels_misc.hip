@@ -1809,6 +1809,32 @@ extern "C" int s3_chunk_time_last(s3_ctx* ctx, const float* y, int n_chunks, con
   return S3_OK;
 }
 
+// dst[o][a][r][b] = src[o][a][b], r < reps: a time-invariant exo field
+// (topography) uploaded once per chunk and laid over the chunk's time steps —
+// (n, H W c) -> (n reps, H W c) for a 2-D model (a = 1), (n, H W, c) ->
+// (n, H W, reps, c) for a 3-D one (ForwardPass.pad_source_data,
+// sup3r/pipeline/forward_pass.py:160-186, does this with np.repeat on the host)
+__global__ void broadcast_axis_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t oa,
+                                      int64_t reps, int64_t b) {
+  const int64_t total = oa * reps * b;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bi = i % b;
+    const int64_t q = i / (b * reps);
+    dst[i] = src[q * b + bi];
+  }
+}
+
+extern "C" int s3_broadcast_axis(s3_ctx* ctx, const float* src, int64_t outer, int64_t a, int64_t b, int64_t reps,
+                                 float* dst) {
+  if (!ctx || !src || !dst) return S3_EINVAL;
+  if (outer < 1 || a < 1 || b < 1 || reps < 1) S3_FAIL(ctx, S3_EINVAL, "broadcast_axis: empty extent");
+  hipLaunchKernelGGL(broadcast_axis_kernel, dim3(grid_for(outer * a * reps * b, ctx->num_cu)), dim3(kBlock), 0,
+                     ctx->stream, src, dst, outer * a, reps, b);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
 // One model step's output -> the next step's input of a MultiStepGan chain
 // (sup3r/models/multi_step.py:233-259), position by position:
 // un_norm_output of step i (y * std + mean, abstract.py:240-275),

@@ -233,6 +233,24 @@ class ForwardPass:
                     ew = tuple((en * pw[0], en * pw[1]) for en, pw in
                                zip((s_en, s_en, t_en), pad_width)) + ((0, 0),)
                     new = step['data']
+                    if new.ndim == 3 and mode in ('reflect', 'symmetric',
+                                                  'edge', 'wrap'):
+                        # a field without a time axis (topography): the
+                        # reference repeats it along time (np.repeat) and pads
+                        # the result; padding a time-constant field along
+                        # time with these modes leaves it time-constant, so
+                        # the SAME values come out of a spatial pad and a
+                        # zero-stride (read-only) view along time — and the
+                        # device executor uploads the field once per chunk
+                        # instead of once per time step (108 MB per 75 x 75 x
+                        # 48 chunk of a 10x model)
+                        n_t = t_en * input_data.shape[2] + ew[2][0] + ew[2][1]
+                        flat = np.pad(new, (ew[0], ew[1], (0, 0)), mode=mode)
+                        exo_data[feature]['steps'][i]['data'] = \
+                            np.broadcast_to(
+                                flat[:, :, None, :],
+                                flat.shape[:2] + (n_t, flat.shape[2]))
+                        continue
                     if new.ndim == 3:
                         new = np.repeat(np.expand_dims(new, 2),
                                         t_en * input_data.shape[2], axis=2)
@@ -951,22 +969,27 @@ class ForwardPass:
             for name in ph.input_names:
                 if name == 'x':
                     continue
-                sh = list(ph.in_shapes[name])
-                parts = []
+                fields = []
                 for exo in exos:
                     e = step_exo(exo, i)
                     assert e is not None and name in e, \
                         f'the generator needs exogenous feature "{name}"'
-                    field = np.asarray(e.get_combine_type_data(name, 'layer'))
-                    # (4-D: the field's time steps on the batch axis too)
-                    arr = m._reshape_norm_exo(
-                        tuple([nt if rank4 else 1] + sh[1:]),
-                        np.transpose(field, (2, 0, 1, 3)) if rank4
-                        else field[None], name)
-                    parts.append(arr.astype(np.float32, copy=False))
-                out[name] = cls._upload_async(
-                    dev, np.concatenate(parts, axis=0) if n > 1 else parts[0],
-                    staged)
+                    fields.append(np.asarray(
+                        e.get_combine_type_data(name, 'layer')))
+                out[name] = cls._exo_to_device(
+                    dev, fields, rank4, staged,
+                    lambda a, m=m, name=name: m._reshape_norm_exo(
+                        tuple(a.shape), a, name))
+                # (the plan of a 2-D model carries a time axis of one)
+                want = tuple(int(v) for v in ph.in_shapes[name])
+                if tuple(v for v in out[name].shape if v != 1) == \
+                        tuple(v for v in want if v != 1):
+                    out[name] = out[name].reshape(want)
+                if tuple(out[name].shape) != want:
+                    raise RuntimeError(
+                        f'exogenous "{name}" of shape '
+                        f'{tuple(out[name].shape)} cannot be laid over '
+                        f'hi-res {want}')
             return out
 
         def hand_over(i, y, rank4, nt):
@@ -1003,21 +1026,21 @@ class ForwardPass:
             names = list(nxt.lr_features[-extra:]) if extra > 0 else []
             exo_t = None
             if names:
-                parts = []
+                fields = []
                 for e in nxt_exo:
                     absent = [f for f in names if f not in (e or {})]
                     assert not absent, (f'exogenous_data lacks {absent} '
                                         '(combine_type "input")')
-                    a = np.concatenate([np.asarray(e.get_combine_type_data(
-                        f, 'input')) for f in names], axis=-1)
-                    parts.append(np.transpose(a, (2, 0, 1, 3)) if nxt4
-                                 else a[None])
-                exo_arr = np.concatenate(parts, axis=0) if n > 1 else parts[0]
-                if tuple(exo_arr.shape[:-1]) != ysh[:-1]:
+                    cols = [np.asarray(e.get_combine_type_data(f, 'input'))
+                            for f in names]
+                    fields.append(cols[0] if len(cols) == 1 else
+                                  np.concatenate(cols, axis=-1))
+                exo_t = cls._exo_to_device(dev, fields, nxt4, staged,
+                                           lambda a: a)
+                if tuple(exo_t.shape[:-1]) != ysh[:-1]:
                     raise RuntimeError(
                         f'"input" exo of step {i + 1} has shape '
-                        f'{exo_arr.shape}, the data {ysh}')
-                exo_t = cls._upload_async(dev, exo_arr, staged)
+                        f'{tuple(exo_t.shape)}, the data {ysh}')
             sc = sh_ = mu = sd = None
             if m._means is not None:
                 mu0, sd0 = m._stats_for(m.hr_out_features)
@@ -1293,6 +1316,45 @@ class ForwardPass:
                        host_arr[k] if host_arr is not None else None)
         finish.deliver = deliver
         return finish
+
+    @classmethod
+    def _exo_to_device(cls, dev, fields, rank4, keep, prep):
+        """the exo fields of a batch's chunks -> one device tensor in the
+        model's layout: ``fields`` = per chunk ``(s1, s2, t, c)``; a 2-D model
+        (``rank4``) takes ``(n t, s1, s2, c)`` (the time steps on the batch
+        axis, forward_pass.py:303-337), a 3-D one ``(n, s1, s2, t, c)``;
+        ``prep`` (normalisation) runs on the host in that layout.  Fields
+        that are constant in time — the zero-stride views ``pad_source_data``
+        builds from 3-D exo data — cross PCIe once and are laid over the
+        time steps on the device (s3_broadcast_axis)"""
+        import ctypes as C
+
+        from . import _lib
+        n = len(fields)
+        const = all(f.ndim == 4 and f.shape[2] > 1 and f.strides[2] == 0
+                    for f in fields)
+        lay = (lambda f: np.transpose(f, (2, 0, 1, 3))) if rank4 else \
+            (lambda f: f[None])
+        if const:
+            nt = int(fields[0].shape[2])
+            parts = [np.asarray(prep(lay(f[:, :, :1])), dtype=np.float32)
+                     for f in fields]
+            small = cls._upload_async(
+                dev, np.concatenate(parts, axis=0) if n > 1 else parts[0],
+                keep)
+            h, w, c = (int(v) for v in (fields[0].shape[0],
+                                        fields[0].shape[1],
+                                        fields[0].shape[3]))
+            out = dev.empty((n * nt, h, w, c) if rank4 else (n, h, w, nt, c))
+            rc = _lib.lib().s3_broadcast_axis(
+                dev.ctx, C.c_void_p(small.data_ptr()), n,
+                1 if rank4 else h * w, h * w * c if rank4 else c, nt,
+                C.c_void_p(out.data_ptr()))
+            _lib.check(rc, dev.ctx, 's3_broadcast_axis')
+            return out
+        parts = [np.asarray(prep(lay(f)), dtype=np.float32) for f in fields]
+        return cls._upload_async(
+            dev, np.concatenate(parts, axis=0) if n > 1 else parts[0], keep)
 
     @staticmethod
     def _upload_async(dev, arr, keep):
