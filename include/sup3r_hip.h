@@ -277,8 +277,9 @@ enum {
   S3_OPINFO_MASK_FUSED_FROM = 8, /* op whose activation adjoint this conv's
                                   dgrad store applies, or -1                  */
   S3_OPINFO_IN_REP = 9,        /* conv reads its input through a fused temporal
-                                  repeat of this factor; a repeat op: 1 = absorbed
-                                  by its consumer (no launch)                   */
+                                  repeat of this factor; a repeat op / a concat op
+                                  (Sup3rConcat): 1 = absorbed by its consumer
+                                  conv (no launch)                              */
   S3_OPINFO_RES_REP = 10,      /* ... and its residual operand                  */
   S3_OPINFO_DGRAD_FRAME16 = 11, /* the padded-frame data gradient is stored as
                                   bf16 between the conv kernel and its fold    */

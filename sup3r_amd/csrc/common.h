@@ -66,6 +66,8 @@
   X(NO_DGRAD_GEN) \
   X(NO_CONV2D_WS) \
   X(NO_TRAIN2D_BF16) \
+  X(NO_ADD16) \
+  X(NO_WS_EXO) \
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \
@@ -185,6 +187,15 @@ struct ConvGeom {
   // slice exist (0 = the tensor has exactly C_in channels).  Used by the
   // chunked data gradient of convs with C_out > 64.
   int in_cstride = 0, in_cvalid = 0;
+  // weights-stationary 2-D kernel, inference plans: the conv behind a
+  // Sup3rConcat of a 64-channel tensor and ONE exogenous channel (topography),
+  // 65 -> C_out, runs as the 64-channel conv over the bf16 tensor plus the
+  // exogenous channel's nine taps per output added from the fp32 field in the
+  // same launch — the 65-channel tensor is never written.  w_cin = the C_in
+  // axis of the canonical weights (65; 0 = C_in), exo = the field (N, s1, s2, 1)
+  // (set at launch time)
+  int w_cin = 0;
+  const float* exo = nullptr;
   // persistent trunk kernel, inference plans: the input is the temporal repeat
   // (SpatioTemporalExpansion temporal_mult, out[.., j, :] = in[.., j / rep, :]) of
   // a tensor with D[2] / in_rep time steps, read through the halo index instead
@@ -496,6 +507,7 @@ int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
 bool conv_epilogue_bwd_d16_ok(const ConvGeom& g);
 bool conv_epilogue_bwd_bsum_ok(const ConvGeom& g);
 int conv_epilogue_bwd_blocks(const s3_ctx* ctx, const ConvGeom& g, bool with_bsum);
+int launch_add16(s3_ctx* ctx, const void* a, const void* b, void* y, int64_t n);
 int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
                int c, int bcast_c);
 int launch_axpy(s3_ctx* ctx, const float* x, float* y, int64_t n);  // y += x

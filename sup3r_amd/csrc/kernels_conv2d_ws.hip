@@ -48,6 +48,10 @@ constexpr int W_HALO_BYTES = WHP * 128;             // 82,944
 constexpr int W_SLAB_OFF = W_HALO_BYTES;
 constexpr int W_BIAS_OFF = W_SLAB_OFF + 9 * 8192;   // 156,672
 constexpr int W_LDS = W_BIAS_OFF + 256;             // 156,928
+// EXO form: + the exogenous channel's halo (648 fp32) and its 9 x 64 filter taps
+constexpr int W_EXO_OFF = W_LDS;
+constexpr int W_WE_OFF = W_EXO_OFF + WHP * 4;       // 159,520
+constexpr int W_LDS_EXO = W_WE_OFF + 9 * 64 * 4;    // 161,824
 constexpr int W_NT = 512;
 constexpr int W_TRIPS = (WHP * 8 + W_NT - 1) / W_NT;   // 11 16-B chunks per lane
 
@@ -67,15 +71,27 @@ __device__ __host__ inline int ws_row_cout(int rho) {
 
 // canonical fp32 w[tap 9][ci 64][co] -> bf16 images [ct][tap][rho 64][ci 64]
 // tail (C_out <= 16, one N fragment): rows 0 .. 15 are the channels in order
+// w_cin: channels of the canonical weights' C_in axis (64, or 65 with an
+// exogenous channel behind the 64: its taps go out as fp32 values of the bf16
+// roundings, [ct][tap][64 channels in natural order], behind the images)
 __global__ void pack_ws_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cout,
-                               int n_ct, int tail) {
+                               int n_ct, int tail, int w_cin) {
   const int total = n_ct * 9 * 64 * 64;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int ci = idx & 63, rho = (idx >> 6) & 63, tap = (idx >> 12) % 9, ct = (idx >> 12) / 9;
     const int co = tail ? (rho < 16 ? rho : cout) : ct * 64 + ws_row_cout(rho);
-    const float v = co < cout ? w[((size_t)tap * 64 + ci) * cout + co] : 0.f;
+    const float v = co < cout ? w[((size_t)tap * w_cin + ci) * cout + co] : 0.f;
     const int slot = (ci >> 3) ^ ((rho >> 1) & 7);
     out[(((size_t)ct * 9 + tap) * 64 + rho) * 64 + slot * 8 + (ci & 7)] = (unsigned short)(ws_pk(v, 0.f) & 0xFFFFu);
+  }
+  if (w_cin > 64) {
+    float* we = reinterpret_cast<float*>(out + (size_t)total);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_ct * 9 * 64; idx += gridDim.x * blockDim.x) {
+      const int c = idx & 63, tap = (idx >> 6) % 9, ct = (idx >> 6) / 9;
+      const int co = ct * 64 + c;
+      const float v = co < cout ? w[((size_t)tap * w_cin + 64) * cout + co] : 0.f;
+      we[idx] = __uint_as_float(ws_pk(v, 0.f) << 16);
+    }
   }
 }
 
@@ -94,10 +110,15 @@ struct WsGeom {
 // natural order, scalar fp32 stores — read-bound (5 fragment reads per 4 MFMAs),
 // but the 150 x 150 x 48 output conv of gen_2x_2f drops from 178 us on the
 // one-barrier-per-tap tile kernel to a pass at the speed its input streams.
-template <int NF>
+// EXO: + one exogenous fp32 channel (see ConvGeom::w_cin): its 2 x 18 x 18 halo
+// rides along the cell halo (two more prefetch registers, bf16-rounded when it
+// lands in LDS — the rounding the 65-channel conv's staging applied), its nine
+// taps per output are 576 fused multiply-adds per lane and tile on the vector
+// unit between the MFMA loop and the hand-over.
+template <int NF, bool EXO = false>
 __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg, const float* __restrict__ bias,
-    const unsigned short* __restrict__ res, void* __restrict__ yv, WsGeom g) {
+    const unsigned short* __restrict__ res, void* __restrict__ yv, WsGeom g, const float* __restrict__ exo) {
   unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(yv);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -174,7 +195,39 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
   }
   static_assert(W_TRIPS == 11, "prefetch registers p0 .. p10");
   uint4 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10;
+  // exogenous channel: cell tid (+ 512 for tid < 136) of the same halo
+#define WS_EFETCH1(P, q, i0_, r0_, c0_)                                                         \
+  {                                                                                             \
+    int cl_ = tid + q * W_NT;                                                                   \
+    cl_ = cl_ > WHP - 1 ? WHP - 1 : cl_;                                                        \
+    int im_ = i0_ + cl_ / (WH_C * WH_R);                                                        \
+    int r_ = s3_reflect(r0_ + (cl_ / WH_C) % WH_R - 1, g.H);                                    \
+    int c_ = s3_reflect(c0_ + cl_ % WH_C - 1, g.W);                                             \
+    im_ = im_ > g.N - 1 ? g.N - 1 : im_;                                                        \
+    r_ = r_ < 0 ? 0 : (r_ > g.H - 1 ? g.H - 1 : r_);                                            \
+    c_ = c_ < 0 ? 0 : (c_ > g.W - 1 ? g.W - 1 : c_);                                            \
+    P = exo[((size_t)im_ * g.H + r_) * g.W + c_];                                               \
+  }
+#define WS_EFETCH(T)                                                                            \
+  if constexpr (EXO) {                                                                          \
+    int i0_, r0_, c0_;                                                                          \
+    tile_org((T), i0_, r0_, c0_);                                                               \
+    WS_EFETCH1(pe0, 0, i0_, r0_, c0_) WS_EFETCH1(pe1, 1, i0_, r0_, c0_)                         \
+  }
+#define WS_ECOMMIT()                                                                            \
+  if constexpr (EXO) {                                                                          \
+    float* E_ = reinterpret_cast<float*>(smem + W_EXO_OFF);                                     \
+    E_[tid] = __uint_as_float(ws_pk(pe0, 0.f) << 16);                                           \
+    if (tid + W_NT < WHP) E_[tid + W_NT] = __uint_as_float(ws_pk(pe1, 0.f) << 16);              \
+  }
+  float pe0 = 0.f, pe1 = 0.f;
   WS_FETCH(t_cur);
+  WS_EFETCH(t_cur);
+  if constexpr (EXO) {
+    const float* wsrc = reinterpret_cast<const float*>(wimg + (size_t)gridDim.y * 9 * 8192) + (size_t)ct * 576;
+    float* WE = reinterpret_cast<float*>(smem + W_WE_OFF);
+    for (int i = tid; i < 576; i += W_NT) WE[i] = wsrc[i];
+  }
   {
     uint4* dst = reinterpret_cast<uint4*>(smem + W_SLAB_OFF);
 #pragma unroll
@@ -185,6 +238,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     }
   }
   WS_COMMIT();
+  WS_ECOMMIT();
   __syncthreads();
 
   // ---- fragment addresses: wave w = image w >> 2, rows 4 (w & 3) .. + 3
@@ -212,7 +266,10 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
 
   while (true) {
     const bool has_next = t_cur + 1 < t_end;
-    if (has_next && !(g.dbg & 1)) WS_FETCH(t_cur + 1);
+    if (has_next && !(g.dbg & 1)) {
+      WS_FETCH(t_cur + 1);
+      WS_EFETCH(t_cur + 1);
+    }
     // this tile's skip rows (d2s == 1), fetched now: their latency hides under
     // the tap loop as well
     int i0, r0, c0;
@@ -270,6 +327,28 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
       }
     }
 
+    if constexpr (EXO) {
+      // the exogenous channel's taps: lane (column frow, channel groups kq 8 ..
+      // and 32 + kq 8 ..) x rows m, straight into the accumulators
+      const float* E = reinterpret_cast<const float*>(smem + W_EXO_OFF);
+      const float* WE = reinterpret_cast<const float*>(smem + W_WE_OFF);
+#pragma unroll 1
+      for (int tb = 0; tb < 3; ++tb) {
+#pragma unroll
+        for (int tc = 0; tc < 3; ++tc) {
+          const float* wt = WE + (tb * 3 + tc) * 64 + kq * 8;
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
+          const f32x4 w2 = *reinterpret_cast<const f32x4*>(wt + 32), w3 = *reinterpret_cast<const f32x4*>(wt + 36);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float ev = E[(w_img * WH_R + w_row + m + tb) * WH_C + frow + tc];
+            acc[m][0] += w0 * ev; acc[m][1 % NF] += w1 * ev;
+            acc[m][2 % NF] += w2 * ev; acc[m][3 % NF] += w3 * ev;
+          }
+        }
+      }
+    }
+
     // ---- halo hand-over BEFORE the epilogue, behind raw barriers.  The wait for
     // the prefetched loads is a vmcnt wait and on gfx9 stores count in vmcnt too
     // (as does the vmcnt(0) inside __syncthreads()): in this order the loads have
@@ -285,6 +364,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     if (has_next) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       WS_COMMIT();
+      WS_ECOMMIT();
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
@@ -339,6 +419,9 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
   }
 }
 
+#undef WS_EFETCH
+#undef WS_EFETCH1
+#undef WS_ECOMMIT
 #undef WS_FETCH
 #undef WS_FETCH1
 #undef WS_COMMIT
@@ -376,20 +459,24 @@ bool conv2d_ws_tail_geom_ok(const ConvGeom& g) {
 
 bool conv2d_ws_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res) {
   if (precision != S3_PREC_BF16 || s3_opt_on(S3O_NO_CONV2D_WS)) return false;
+  if (g.w_cin && (g.w_cin != 65 || conv2d_ws_tail_geom_ok(g))) return false;   // (one exogenous channel, trunk form)
   if (conv2d_ws_tail_geom_ok(g)) return io.in_bf16 && !io.out_bf16 && !has_res;
   if (!io.in_bf16 || !io.out_bf16 || (has_res && !io.res_bf16)) return false;
   if (has_res && g.d2s > 1) return false;
   return conv2d_ws_geom_ok(g);
 }
 
-size_t conv2d_ws_image_bytes(const ConvGeom& g) { return (size_t)((g.Cout + 63) / 64) * 9 * 8192; }
+size_t conv2d_ws_image_bytes(const ConvGeom& g) {
+  const size_t n_ct = (size_t)((g.Cout + 63) / 64);
+  return n_ct * 9 * 8192 + (g.w_cin > 64 ? n_ct * 9 * 64 * sizeof(float) : 0);
+}
 
 int launch_conv2d_ws_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image) {
   const int n_ct = (g.Cout + 63) / 64;
   int grid = (n_ct * 9 * 64 * 64 + 255) / 256;
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(pack_ws_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, (unsigned short*)image, g.Cout, n_ct,
-                     conv2d_ws_tail_geom_ok(g) ? 1 : 0);
+                     conv2d_ws_tail_geom_ok(g) ? 1 : 0, g.w_cin ? g.w_cin : 64);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
@@ -402,6 +489,8 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel<1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel<4, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_EXO));
     attr_set = true;
   }
   WsGeom w;
@@ -416,12 +505,17 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
   int gx = (ctx->num_cu + n_ct - 1) / n_ct;
   if (gx > T) gx = T;
   if (gx < 1) gx = 1;
+  if (g.w_cin && !g.exo) S3_FAIL(ctx, S3_ESTATE, "conv2d_ws: the exogenous channel's field is not bound");
   if (tail)
     hipLaunchKernelGGL(conv2d_ws_kernel<1>, dim3(gx, 1), dim3(W_NT), W_LDS, ctx->stream, (const unsigned short*)x,
-                       (const char*)image, bias, (const unsigned short*)nullptr, y, w);
+                       (const char*)image, bias, (const unsigned short*)nullptr, y, w, (const float*)nullptr);
+  else if (g.w_cin)
+    hipLaunchKernelGGL((conv2d_ws_kernel<4, true>), dim3(gx, n_ct), dim3(W_NT), W_LDS_EXO, ctx->stream,
+                       (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res, y, w, g.exo);
   else
     hipLaunchKernelGGL(conv2d_ws_kernel<4>, dim3(gx, n_ct), dim3(W_NT), W_LDS, ctx->stream,
-                       (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res, y, w);
+                       (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res, y, w,
+                       (const float*)nullptr);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

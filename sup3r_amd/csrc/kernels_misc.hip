@@ -589,6 +589,26 @@ __global__ void add_kernel(const float* __restrict__ a,
     y[i] = a[i] + (bcast_c ? b[i / c] : b[i]);
 }
 
+// bf16 cells: y = bf16(a + b), eight channels per lane (inference plans: a
+// SkipConnection add that no conv epilogue absorbed — the second of two adds
+// behind one conv in sup3rcc/gen_*_5x_1x_* at hi-res — stays in bf16 so that
+// the convs on either side keep their bf16 kernels)
+__global__ void add16_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ y,
+                             int64_t n8) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  auto add2 = [](unsigned u, unsigned v) {
+    const f2 s = {__uint_as_float(u << 16) + __uint_as_float(v << 16),
+                  __uint_as_float(u & 0xFFFF0000u) + __uint_as_float(v & 0xFFFF0000u)};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(s, bf2));
+  };
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const uint4 p = a[i], q = b[i];
+    y[i] = make_uint4(add2(p.x, q.x), add2(p.y, q.y), add2(p.z, q.z), add2(p.w, q.w));
+  }
+}
+
 __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y,
                             int64_t n) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1444,6 +1464,14 @@ int launch_conv_epilogue_bwd(s3_ctx* ctx, const ConvGeom& g, const float* y,
 int launch_add(s3_ctx* ctx, const float* a, const float* b, float* y, int64_t n,
                int c, int bcast_c) {
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, ctx->num_cu)), dim3(kBlock), 0, ctx->stream, a, b, y, n, c, bcast_c);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_add16(s3_ctx* ctx, const void* a, const void* b, void* y, int64_t n) {
+  if (n & 7) S3_FAIL(ctx, S3_EINVAL, "add16: element count must be a multiple of 8");
+  hipLaunchKernelGGL(add16_kernel, dim3(grid_for(n / 8, ctx->num_cu)), dim3(kBlock), 0, ctx->stream,
+                     (const uint4*)a, (const uint4*)b, (uint4*)y, n / 8);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

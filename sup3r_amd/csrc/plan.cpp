@@ -74,6 +74,7 @@ struct OpRec {
   ConvGeom dg;                 // geometry of the dgrad-as-conv launch
   int rep_src = -1;            // conv: tensor read through a fused temporal repeat (cg.in_rep)
   int res_src = -1;            // ... and the residual (cg.res_rep)
+  int exo_src = -1;            // conv behind a fused-away Sup3rConcat: the exogenous field (cg.w_cin)
   void* sign_bytes = nullptr;  // training: activation sign bytes next to the output (conv_dgrad_s2's mask)
   bool fused_away = false;     // repeat op absorbed by its consumer conv: no launch
   float* dg_w32 = nullptr;     // flipped / transposed fp32 filter
@@ -887,6 +888,47 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         return bad("plan: unknown op kind");
     }
   }
+  // ---- inference plans: Sup3rConcat of a 64-channel tensor and ONE exogenous
+  // channel in front of a 3 x 3 Conv2D (sup3rcc/gen_wind_5x_1x_6f at hi-res: a
+  // 65-channel fp32 tensor written, read back by a two-pass fp32 conv: 28 of
+  // 126 ms at 96 x 750 x 750).  The conv is linear in its input channels: it
+  // runs as the 64 -> C_out conv over the bf16 tensor on the weights-stationary
+  // kernel, which adds the exogenous channel's nine taps per output from the
+  // fp32 field itself (ConvGeom::w_cin / exo); the concat never runs.  Checked
+  // again once the dtypes are known; if the kernel cannot take the conv after
+  // all the plan is built again without the split.
+  static thread_local int tl_no_ws_exo = 0;
+  if (!training && precision == S3_PREC_BF16 && !s3_opt_has(S3O_NO_WS_EXO) && !s3_opt_has(S3O_FP32_ACT) &&
+      !tl_no_ws_exo) {
+    for (int i = 0; i < n_ops; ++i) {
+      OpRec& c = pl->ops[i];
+      if (c.d.kind != S3_OP_CONCAT) continue;
+      const TensorRec& xt = pl->t[c.d.in0];
+      const TensorRec& et = pl->t[c.d.in1];
+      if (xt.dims[4] != 64 || et.dims[4] != 1 || !pl->t[root_of(pl, c.d.in1)].is_input) continue;
+      const int ct_ = root_of(pl, c.d.out);
+      if (ct_ == root_of(pl, output)) continue;
+      int user = -1, n_use = 0;
+      for (int k = 0; k < n_ops; ++k) {
+        const s3_op_desc& u = pl->ops[k].d;
+        for (int id : {u.in0, u.in1, u.res})
+          if (id >= 0 && root_of(pl, id) == ct_) { ++n_use; user = k; }
+      }
+      if (n_use != 1 || user <= i) continue;
+      OpRec& v = pl->ops[user];
+      if (v.d.kind != S3_OP_CONV || root_of(pl, v.d.in0) != ct_ || v.cg.Cin != 65) continue;
+      ConvGeom gs = v.cg;
+      gs.Cin = 64; gs.w_cin = 65;
+      if (!conv2d_ws_geom_ok(gs) || conv2d_ws_tail_geom_ok(gs) || !conv_mfma_supported(gs, precision)) continue;
+      v.cg = gs;
+      v.d.in0 = c.d.in0;
+      v.exo_src = c.d.in1;
+      v.mfma = true;
+      v.fewpos = v.gconv = v.halo32 = v.halo_s2 = v.tail_x3 = false;
+      c.fused_away = true;
+    }
+  }
+
   // ---- activation dtypes.  Inference plans in bf16 mode keep a tensor in
   // bf16 when its producer can write it (MFMA conv, direct conv, index op) and
   // EVERY consumer can read it (MFMA conv input / residual, index op);
@@ -927,6 +969,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
       changed = false;
       for (auto& o : pl->ops) {
         const s3_op_desc& d = o.d;
+        if (d.kind == S3_OP_CONCAT && o.fused_away) continue;   // (never runs: its operands go to the conv)
         switch (d.kind) {
           case S3_OP_CONV:
             if (training && d.res >= 0 && fewch_out[root_of(pl, d.res)]) demote(d.res, changed);
@@ -981,6 +1024,14 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
             break;
           case S3_OP_VIEW:
             break;  // alias: one root, one dtype (element count is preserved)
+          case S3_OP_ADD:
+            // inference plans: a skip add stays in bf16 when both operands and
+            // the sum are bf16 tensors (add16_kernel)
+            if (training || d.bcast_c || (pl->t[d.out].numel & 7) || s3_opt_has(S3O_NO_ADD16) ||
+                !(dt[root_of(pl, d.in0)] && dt[root_of(pl, d.in1)] && dt[root_of(pl, d.out)])) {
+              demote(d.in0, changed); demote(d.in1, changed); demote(d.out, changed);
+            }
+            break;
           default:
             demote(d.in0, changed); demote(d.in1, changed);
             demote(d.res, changed); demote(d.out, changed);
@@ -1002,6 +1053,19 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
               (int)o.halo32, o.io.in_bf16, o.io.out_bf16, o.io.res_bf16, (int)o.wgrad_bf16, (int)o.wgrad_bf16_gen,
               (int)o.wgrad_bf16_2d, (int)o.wgrad_c2, (int)o.wgrad_tail, (int)o.wgrad_mfma, (int)o.dgrad_mfma,
               (int)o.dgrad_c2, (int)o.dgrad_s2, (int)o.gconv_dgrad);
+  }
+
+  for (auto& o : pl->ops) {
+    if (o.d.kind != S3_OP_CONV || o.exo_src < 0) continue;
+    if (conv2d_ws_supported(o.cg, precision, o.io, o.d.res >= 0)) continue;
+    // (a consumer of the 64-channel tensor that needs fp32 cells, ...): build
+    // the plan again with the concat as it is written
+    delete pl;
+    ++tl_no_ws_exo;
+    const int rc = s3_plan_create_opt(ctx, params, tensors, n_tensors, ops, n_ops, inputs, n_inputs, output,
+                                      precision, training, options, out);
+    --tl_no_ws_exo;
+    return rc;
   }
 
   // ---- activation-adjoint fusion (training): a conv whose data gradient runs
@@ -1085,8 +1149,8 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
   std::vector<int> last_use(n_tensors, -1);
   for (int i = 0; i < n_ops; ++i) {
     const s3_op_desc& d = pl->ops[i].d;
-    int ids[6] = {d.in0, d.in1, d.res, d.out, pl->ops[i].rep_src, pl->ops[i].res_src};
-    for (int q = 0; q < 6; ++q)
+    int ids[7] = {d.in0, d.in1, d.res, d.out, pl->ops[i].rep_src, pl->ops[i].res_src, pl->ops[i].exo_src};
+    for (int q = 0; q < 7; ++q)
       if (ids[q] >= 0) last_use[root_of(pl, ids[q])] = i;
   }
   last_use[root_of(pl, output)] = n_ops + 1;
@@ -1095,6 +1159,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
   for (int i = 0; i < n_ops; ++i) {
     const s3_op_desc& d = pl->ops[i].d;
     if (d.kind == S3_OP_VIEW) continue;
+    if (d.kind == S3_OP_CONCAT && pl->ops[i].fused_away) continue;   // (never materialised)
     TensorRec& ot = pl->t[d.out];
     size_t need = ot.bytes();
     int pick = -1;
@@ -1395,6 +1460,11 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
           o.packed_version = P->version;
         }
         const void* wp = pl->precision != S3_PREC_F32 ? (const void*)o.packed : (const void*)w;
+        if (o.exo_src >= 0) {
+          ConvGeom ge = o.cg;
+          ge.exo = (const float*)tptr(pl, o.exo_src);
+          return launch_conv_mfma_fwd(ctx, ge, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out), o.io);
+        }
         return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, o.rep_src >= 0 ? o.rep_src : d.in0), wp, b,
                                     res, tptr(pl, d.out), o.io);
       }
@@ -1447,6 +1517,7 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
       if (o.fused_away) return S3_OK;        // read through its consumer's halo index
       return launch_gather(ctx, o.gg, tptr(pl, d.in0), tptr(pl, d.out), tdtype(pl, d.out) ? 2 : 4);
     case S3_OP_CONCAT: {
+      if (o.fused_away) return S3_OK;   // its consumer conv reads both operands (OpRec::exo_src)
       // two channel-range copies: x -> out[..., :Cx], exo -> out[..., Cx:]
       const TensorRec& a = pl->t[d.in0];
       const TensorRec& b = pl->t[d.in1];
@@ -1456,6 +1527,7 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
       return s3_copy_channels(ctx, tptr(pl, d.in1), (int)b.dims[4], 0, tptr(pl, d.out), (int)ot.dims[4], (int)a.dims[4], (int)b.dims[4], npos, 0);
     }
     case S3_OP_ADD:
+      if (ot.dtype) return launch_add16(ctx, tptr(pl, d.in0), tptr(pl, d.in1), tptr(pl, d.out), ot.numel);
       return launch_add(ctx, tptr(pl, d.in0), tptr(pl, d.in1), tptr(pl, d.out), ot.numel, (int)ot.dims[4], d.bcast_c);
     case S3_OP_ACT:
       return launch_act(ctx, tptr(pl, d.in0), tptr(pl, d.out), ot.numel, d.act, d.alpha);
@@ -1757,7 +1829,7 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
       v[S3_OPINFO_MASK_FUSED_FROM] = o.mask_prod;
     }
   }
-  if (o.d.kind == S3_OP_REPEAT_T) v[S3_OPINFO_IN_REP] = o.fused_away ? 1 : 0;
+  if (o.d.kind == S3_OP_REPEAT_T || o.d.kind == S3_OP_CONCAT) v[S3_OPINFO_IN_REP] = o.fused_away ? 1 : 0;
   for (int q = 0; q < cap && q < S3_OPINFO_COUNT; ++q) out[q] = v[q];
   return S3_OPINFO_COUNT;
 }

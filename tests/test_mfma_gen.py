@@ -131,6 +131,63 @@ def test_gen_kernel_can_be_switched_off():
     assert np.abs(ya - yc).max() < 3e-2 * max(1.0, np.abs(yc).max())
 
 
+def test_concat_of_one_exo_channel_runs_inside_the_ws_conv():
+    """sup3rcc/gen_wind_5x_1x_6f: the Sup3rConcat of the 64-channel hi-res
+    tensor and the topography in front of a 65 -> 64 Conv2D.  bf16 inference
+    plans never write the 65-channel tensor: the conv runs as 64 -> 64 on the
+    weights-stationary kernel, which adds the topography's nine taps per
+    output from the fp32 field (option NO_WS_EXO: the concat + two-pass conv).
+    Same result as the unsplit plan to bf16 accumulation-order noise, oracle
+    parity per op in the tests above (they run on this plan), batch
+    invariance, and the skip add behind a residual conv stays in bf16
+    (add16, option NO_ADD16)."""
+    from sup3r_amd.engine import Network
+    rel = 'sup3rcc/gen_wind_5x_1x_6f.json'
+    spec = load_surface(rel)
+    shape = (3, 16, 17, 7)
+    rng = np.random.default_rng(71)
+    x = rng.standard_normal(shape).astype(np.float32)
+    plan = S.build_plan(S.parse_layers(spec), shape)
+    exo = _exo_for(plan, 'topography', rng, np.float32)
+    net = Network(spec, precision='bf16')
+    net.build(shape, seed=8)
+    dev = net.dev
+    xd = dev.to_device(x)
+    ed = {k: dev.to_device(v) for k, v in exo.items()}
+    a = net.plan(shape, training=False)
+    kinds = [op['kind'] for op in a.plan.ops]
+    ic = kinds.index(S.OP_CONCAT)
+    assert a.op_info(ic)['in_rep'] == 1                    # fused away
+    conv65 = next(i for i, op in enumerate(a.plan.ops)
+                  if op['kind'] == S.OP_CONV and op['cin'] == 65)
+    assert a.op_info(conv65)['fwd'] == 'conv2d_ws'
+    # the d2s conv in front of it stores bf16 cells now (-> ws as well)
+    d2s = next(i for i, op in enumerate(a.plan.ops)
+               if op['kind'] == S.OP_CONV and op.get('d2s', 1) == 5)
+    assert a.tensor_is_bf16(a.plan.ops[d2s]['out'])
+    assert a.op_info(d2s)['fwd'] == 'conv2d_ws'
+    iadd = [i for i, k in enumerate(kinds) if k == S.OP_ADD]
+    assert iadd and all(a.tensor_is_bf16(a.plan.ops[i]['out']) for i in iadd)
+    ya = a.forward(xd, ed).cpu().numpy()
+    b = net.plan(shape, training=False, options={'NO_WS_EXO': 1,
+                                                  'NO_ADD16': 1})
+    assert b.op_info(ic)['in_rep'] == 0
+    assert b.op_info(conv65)['fwd'] == 'mfma_gen'
+    assert not any(b.tensor_is_bf16(b.plan.ops[i]['out']) for i in iadd)
+    yb = b.forward(xd, ed).cpu().numpy()
+    assert np.isfinite(ya).all()
+    assert np.abs(ya - yb).max() < 3e-2 * max(1.0, np.abs(yb).max())
+    # the topography matters, and sample by sample == the batch
+    e2 = {k: dev.to_device(v[::-1].copy()) for k, v in exo.items()}
+    assert np.abs(a.forward(xd, e2).cpu().numpy() - ya).max() > 1e-3
+    a1 = net.plan((1,) + shape[1:], training=False)
+    for k in range(shape[0]):
+        yk = a1.forward(dev.to_device(x[k:k + 1]),
+                        {n_: dev.to_device(v[k:k + 1]) for n_, v in
+                         exo.items()}).cpu().numpy()
+        np.testing.assert_array_equal(yk[0], ya[k])
+
+
 def test_2d_training_plan_keeps_bf16_cells():
     """a 2-D training plan: the 64 -> 64 k layers keep bf16 cells (forward on
     the weights-stationary kernel, weight gradient staged from bf16), EVERY
