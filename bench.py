@@ -437,6 +437,98 @@ def fwp2d_executor_leg(rank=0, batch=4, reps=3):
                         '(150, 150, 38, 2) fp32 chunks delivered to the host'}
 
 
+def fwp2d_chain_leg(rank=0, batch=2, reps=2):
+    """the arrangement of examples/sup3rwind/run_configs/wind/
+    config_fwp_spatial.json: ``model_class: MultiStepGan`` of two spatial
+    steps with topography (here gen_2x_2f then the gen_wind_5x_1x_6f body with
+    lo-res topography at its input and hi-res topography through its
+    mid-network Sup3rConcat: 10x), 75 x 75 x 38 chunks + temporal_pad 5,
+    through ForwardPass.get_input_chunk -> iter_chunks.  Both steps, the
+    hand-over between them (s3_step_handover) and the exo fields stay on the
+    device; ``host_chain`` = the same chunks through MultiStepGan.generate
+    (every hand-over through host numpy, the reference's arrangement)"""
+    import json
+
+    from sup3r_amd import ForwardPass, MultiStepGan, Sup3rGan
+    from sup3r_amd.forward_pass import register_model
+    from sup3r_amd.strategy import ArrayStrategy
+    feats = ['u_10m', 'v_10m']
+    Sup3rGan.seed(5)
+    means = {f: np.float32(0.1 * (i + 1)) for i, f in enumerate(feats)}
+    stds = {f: np.float32(1.5 + i) for i, f in enumerate(feats)}
+    means['topography'], stds['topography'] = np.float32(300), np.float32(150)
+    m1 = Sup3rGan(os.path.join(CFGDIR, 'sup3r', 'spatial', 'gen_2x_2f.json'),
+                  os.path.join(CFGDIR, 'disc_s_same.json'), means=means,
+                  stdevs=stds, precision='bf16')
+    m1.set_model_params(lr_features=feats, hr_out_features=feats, s_enhance=2,
+                        t_enhance=1)
+    m1.init_weights((1, 16, 16, 2), (1, 32, 32, 2))
+    with open(os.path.join(CFGDIR, 'sup3r', 'sup3rcc',
+                           'gen_wind_5x_1x_6f.json')) as f:
+        spec2 = json.load(f)
+    for layer in spec2['hidden_layers']:
+        if layer.get('filters') == 6:
+            layer['filters'] = 2
+    m2 = Sup3rGan(spec2, os.path.join(CFGDIR, 'disc_s_same.json'), means=means,
+                  stdevs=stds, precision='bf16')
+    m2.set_model_params(lr_features=feats + ['topography'],
+                        hr_out_features=feats, hr_exo_features=['topography'],
+                        s_enhance=5, t_enhance=1)
+    m2.init_weights((1, 16, 16, 3), (1, 80, 80, 3))
+    ms = MultiStepGan([m1, m2])
+    rng = np.random.default_rng(11 + rank)
+    domain = rng.standard_normal((150, 150, 76, 2)).astype(np.float32)
+    topo_hr = (300 + 150 * rng.standard_normal((1500, 1500, 1))).astype(
+        np.float32)
+    topo_mid = topo_hr.reshape(300, 5, 300, 5, 1).mean(axis=(1, 3)).astype(
+        np.float32)
+    exo = {'topography': {'steps': [
+        {'model': 1, 'combine_type': 'input', 'data': topo_mid,
+         's_enhance': 2, 't_enhance': 1},
+        {'model': 1, 'combine_type': 'layer', 'data': topo_hr,
+         's_enhance': 10, 't_enhance': 1}]}}
+    kw = {'model_dirs': ['bench-chain-a', 'bench-chain-b']}
+    register_model('MultiStepGan', kw, ms)
+    st = ArrayStrategy(domain, kw, (75, 75, 38), spatial_pad=0,
+                       temporal_pad=5, exo_data=exo,
+                       model_class='MultiStepGan', max_nodes=1, model=ms)
+    fwp = ForwardPass(st, 0)
+    ids = [int(i) for i in st.node_chunks[0]]
+
+    def run(n_rep):
+        best = None
+        for _ in range(n_rep):
+            t0 = time.perf_counter()
+            n = 0
+            for c, failed, d in ForwardPass.iter_chunks(
+                    (fwp.get_input_chunk(i) for i in ids), ms, batch=batch):
+                assert not failed and d.shape == (750, 750, 38, 2)
+                n += 1
+            el = time.perf_counter() - t0
+            best = el if best is None or el < best else best
+        return n, best
+    assert ForwardPass._device_path(ms, fwp.get_input_chunk(ids[0]))
+    n, best = run(reps + 1)          # (first pass: plans, pinned rings)
+    try:
+        ForwardPass.device_chains = False
+        _, host = run(1)
+    finally:
+        ForwardPass.device_chains = True
+    ForwardPass.release_delivery_buffers()
+    return {'value': n / best, 'unit': 'chunks/s', 'chunks': n,
+            'chunks_per_launch_sequence': batch,
+            'px_per_sec': n / best * 750 * 750 * 38,
+            'host_chain': {'value': n / host, 'unit': 'chunks/s',
+                           'what': 'MultiStepGan.generate chunk by chunk: '
+                                   'hand-overs and exo fields through host '
+                                   'numpy'},
+            'workload': 'MultiStepGan [spatial/gen_2x_2f, sup3rcc/'
+                        'gen_wind_5x_1x_6f body (2 features) + topography]: '
+                        '75 x 75 x 38 chunks + temporal_pad 5 of a (150, 150, '
+                        '76, 2) domain -> (750, 750, 38, 2) fp32 chunks '
+                        '(171 MB each) delivered to the host'}
+
+
 def _smi_poll(stop, out):
     import re as _re
     while not stop.is_set():
@@ -870,6 +962,10 @@ def main():
             out['executor'] = fwp2d_executor_leg(rank)
         except Exception as e:          # a leg, never the line
             out['executor'] = {'error': repr(e)[:300]}
+        try:
+            out['chain'] = fwp2d_chain_leg(rank)
+        except Exception as e:
+            out['chain'] = {'error': repr(e)[:300]}
         ms_ = max_over_ranks(out['ms_per_step'])
         if rank == 0:
             B2 = args.batch or 48
@@ -1102,6 +1198,11 @@ def main():
             result['fwd2d']['executor'] = fwp2d_executor_leg()
         except Exception as e:
             result.setdefault('fwd2d', {})['error'] = repr(e)[:300]
+        torch.cuda.empty_cache()
+        try:
+            result['fwd2d']['chain'] = fwp2d_chain_leg()
+        except Exception as e:
+            result.setdefault('fwd2d', {})['chain'] = {'error': repr(e)[:300]}
         torch.cuda.empty_cache()
         # the reference's own training test shape (BASELINE.json config 1,
         # tests/training/test_train_gan.py:45-114): a launch-bound mini-batch
