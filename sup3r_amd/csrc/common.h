@@ -196,6 +196,10 @@ struct ConvGeom {
   // (set at launch time)
   int w_cin = 0;
   const float* exo = nullptr;
+  // set by the plan once the tensor dtypes are known: this conv's forward IS the
+  // weights-stationary kernel — the logical-axes tile image is not packed (a
+  // training step re-packs every filter: one 5 us launch less per conv and step)
+  int ws_only = 0;
   // persistent trunk kernel, inference plans: the input is the temporal repeat
   // (SpatioTemporalExpansion temporal_mult, out[.., j, :] = in[.., j / rep, :]) of
   // a tensor with D[2] / in_rep time steps, read through the halo index instead

@@ -262,7 +262,8 @@ int launch_conv_mfma_gen_pack(s3_ctx* ctx, const ConvGeom& g, int precision, con
   const int npass = (g.Cin + kch - 1) / kch, ltaps = m.ka * 9, n_ct = (g.Cout + CT - 1) / CT;
   // (a conv with an exogenous channel split off runs on the weights-stationary
   // kernel only: its tile image is never read)
-  if (g.w_cin) return launch_conv2d_ws_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka));
+  if (g.w_cin || (g.ws_only && precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g))))
+    return launch_conv2d_ws_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka));
   const int64_t total = (int64_t)n_ct * npass * ltaps * CT * (x3 ? 32 : CIN);
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
@@ -285,7 +286,7 @@ int launch_conv_mfma_gen_fwd(s3_ctx* ctx, const ConvGeom& g, int precision, cons
   if (io.in_bf16 && g.Cin % 8 != 0) S3_FAIL(ctx, S3_ESTATE, "gen MFMA conv: bf16 input needs C_in % 8 == 0");
   if (conv2d_ws_supported(g, precision, io, res != nullptr))
     return launch_conv2d_ws(ctx, g, x, (const char*)packed + gen_tile_image_bytes(g, precision, m.ka), bias, res, y);
-  if (g.w_cin) S3_FAIL(ctx, S3_ESTATE, "conv with a split exogenous channel off the weights-stationary kernel");
+  if (g.w_cin || g.ws_only) S3_FAIL(ctx, S3_ESTATE, "conv planned for the weights-stationary kernel launched off it");
   if (precision == S3_PREC_BF16X3) {
     if (m.ka == 1) return launch_gen_prec<S3_PREC_BF16X3, 1>(ctx, m.l, x, packed, bias, res, y, io);
     return launch_gen_prec<S3_PREC_BF16X3, 3>(ctx, m.l, x, packed, bias, res, y, io);

@@ -1055,6 +1055,10 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
               (int)o.dgrad_c2, (int)o.dgrad_s2, (int)o.gconv_dgrad);
   }
 
+  for (auto& o : pl->ops)
+    if (o.d.kind == S3_OP_CONV && o.mfma && conv_mfma_is_gen(o.cg, precision) && o.cg.in_rep <= 1 &&
+        conv2d_ws_supported(o.cg, precision, o.io, o.d.res >= 0))
+      o.cg.ws_only = 1;
   for (auto& o : pl->ops) {
     if (o.d.kind != S3_OP_CONV || o.exo_src < 0) continue;
     if (conv2d_ws_supported(o.cg, precision, o.io, o.d.res >= 0)) continue;
