@@ -564,7 +564,16 @@ extern "C" int s3_capture_begin(s3_ctx* ctx) {
   if (!ctx->cap_stream) S3_HIP(ctx, hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
   // what was enqueued so far runs before anything the capture stream does later
   S3_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  S3_HIP(ctx, hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed));
+  hipError_t be = hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed);
+  if (be != hipSuccess) {
+    // a capture stream left in a broken state by an earlier, failed recording
+    // must not poison every later one: drop it and try once on a fresh stream
+    (void)hipGetLastError();
+    (void)hipStreamDestroy(ctx->cap_stream);
+    ctx->cap_stream = nullptr;
+    S3_HIP(ctx, hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+    S3_HIP(ctx, hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed));
+  }
   ctx->saved_stream = ctx->stream;
   ctx->stream = ctx->cap_stream;
   ctx->capturing = true;
@@ -578,6 +587,9 @@ static int capture_stop(s3_ctx* ctx, hipGraph_t* g) {
   if (e != hipSuccess) {
     (void)hipGetLastError();
     ctx->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e);
+    // (the next recording starts on a fresh stream)
+    if (ctx->cap_stream) { (void)hipStreamDestroy(ctx->cap_stream); ctx->cap_stream = nullptr; }
+    (void)hipGetLastError();
     return S3_EHIP;
   }
   return S3_OK;
