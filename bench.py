@@ -834,6 +834,9 @@ def main():
     ap.add_argument('--no-traffic', action='store_true',
                     help='skip the rocprofv3 --pmc passes (roofline.traffic '
                          'is then null)')
+    ap.add_argument('--no-executor', action='store_true',
+                    help='fwd2d: skip the ForwardPass executor / chain legs '
+                         '(profiling runs: every dispatch is the timed forward)')
     ap.add_argument('--c3-entry', default='strategy',
                     choices=['strategy', 'domain'],
                     help="c3: 'strategy' = ForwardPassChunk structures through "
@@ -958,14 +961,15 @@ def main():
         out = fwd2d_leg(dev, args.steps, max(args.warmup, 3),
                         args.batch or 48, seed=42 + rank)
         barrier()
-        try:
-            out['executor'] = fwp2d_executor_leg(rank)
-        except Exception as e:          # a leg, never the line
-            out['executor'] = {'error': repr(e)[:300]}
-        try:
-            out['chain'] = fwp2d_chain_leg(rank)
-        except Exception as e:
-            out['chain'] = {'error': repr(e)[:300]}
+        if not args.no_executor:
+            try:
+                out['executor'] = fwp2d_executor_leg(rank)
+            except Exception as e:          # a leg, never the line
+                out['executor'] = {'error': repr(e)[:300]}
+            try:
+                out['chain'] = fwp2d_chain_leg(rank)
+            except Exception as e:
+                out['chain'] = {'error': repr(e)[:300]}
         ms_ = max_over_ranks(out['ms_per_step'])
         if rank == 0:
             B2 = args.batch or 48
