@@ -1572,7 +1572,14 @@ static int forward_ops(s3_plan* pl, hipEvent_t* ev) {
   if (ev) S3_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
   for (int i = 0; i < n_ops; ++i) {
     int rc = run_op_forward(pl, pl->ops[i]);
-    if (rc) return rc;
+    if (rc) {
+      // (which launch: a failure inside a stream capture is otherwise anonymous)
+      char where[96];
+      snprintf(where, sizeof(where), " [forward op %d of %d, kind %d%s]", i, n_ops, pl->ops[i].d.kind,
+               ctx->capturing ? ", capturing" : "");
+      ctx->err += where;
+      return rc;
+    }
     if (ev) S3_HIP(ctx, hipEventRecord(ev[i + 1], ctx->stream));
   }
   return S3_OK;
@@ -1650,7 +1657,10 @@ extern "C" int s3_plan_forward(s3_plan* pl, const void* const* inputs, void* out
     float* dst = output ? (float*)output : tptr(pl, pl->output);
     rc = fused2d_run(ctx, pl->fused2d, pl->params->buf[S3_BUF_W], pl->params->version,
                      (const float*)inputs[0], dst);
-    if (rc) return rc;
+    if (rc) {
+      ctx->err += ctx->capturing ? " [fused2d forward, capturing]" : " [fused2d forward]";
+      return rc;
+    }
     pl->forward_done = true;
     return S3_OK;
   }
