@@ -68,6 +68,7 @@
   X(NO_TRAIN2D_BF16) \
   X(NO_ADD16) \
   X(NO_WS_EXO) \
+  X(NO_WS_RES2) \
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \
@@ -196,6 +197,12 @@ struct ConvGeom {
   // (set at launch time)
   int w_cin = 0;
   const float* exo = nullptr;
+  // ... and a SECOND skip operand (bf16 cells, the conv's output shape): the
+  // SkipConnection add right behind a conv that already carries one
+  // (sup3rcc/gen_*_5x_1x_*: the last residual block's sum + the big skip) is
+  // absorbed into the conv's store instead of running as a pass of its own
+  // (set at launch time)
+  const void* res2 = nullptr;
   // set by the plan once the tensor dtypes are known: this conv's forward IS the
   // weights-stationary kernel — the logical-axes tile image is not packed (a
   // training step re-packs every filter: one 5 us launch less per conv and step)

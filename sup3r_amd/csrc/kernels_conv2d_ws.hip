@@ -118,7 +118,8 @@ struct WsGeom {
 template <int NF, bool EXO = false>
 __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg, const float* __restrict__ bias,
-    const unsigned short* __restrict__ res, void* __restrict__ yv, WsGeom g, const float* __restrict__ exo) {
+    const unsigned short* __restrict__ res, void* __restrict__ yv, WsGeom g, const float* __restrict__ exo,
+    const unsigned short* __restrict__ res2) {
   unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(yv);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -408,6 +409,17 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
             v[0] += ws_lo(q4.x); v[1] += ws_hi(q4.x); v[2] += ws_lo(q4.y); v[3] += ws_hi(q4.y);
             v[4] += ws_lo(q4.z); v[5] += ws_hi(q4.z); v[6] += ws_lo(q4.w); v[7] += ws_hi(q4.w);
           }
+          if (res2) {
+            // (d2s == 1; the sum of the first skip is rounded to bf16 first, as
+            // the separate add of two bf16 tensors saw it)
+            uint4 o1;
+            o1.x = ws_pk(v[0], v[1]); o1.y = ws_pk(v[2], v[3]); o1.z = ws_pk(v[4], v[5]); o1.w = ws_pk(v[6], v[7]);
+            const uint4 q4 = *reinterpret_cast<const uint4*>(res2 + dst);
+            v[0] = ws_lo(o1.x) + ws_lo(q4.x); v[1] = ws_hi(o1.x) + ws_hi(q4.x);
+            v[2] = ws_lo(o1.y) + ws_lo(q4.y); v[3] = ws_hi(o1.y) + ws_hi(q4.y);
+            v[4] = ws_lo(o1.z) + ws_lo(q4.z); v[5] = ws_hi(o1.z) + ws_hi(q4.z);
+            v[6] = ws_lo(o1.w) + ws_lo(q4.w); v[7] = ws_hi(o1.w) + ws_hi(q4.w);
+          }
           uint4 o;
           o.x = ws_pk(v[0], v[1]); o.y = ws_pk(v[2], v[3]); o.z = ws_pk(v[4], v[5]); o.w = ws_pk(v[6], v[7]);
           *reinterpret_cast<uint4*>(y + dst) = o;
@@ -506,16 +518,19 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
   if (gx > T) gx = T;
   if (gx < 1) gx = 1;
   if (g.w_cin && !g.exo) S3_FAIL(ctx, S3_ESTATE, "conv2d_ws: the exogenous channel's field is not bound");
+  if (g.res2 && (tail || w.b != 1)) S3_FAIL(ctx, S3_ESTATE, "conv2d_ws: a second skip operand needs the trunk form without depth-to-space");
   if (tail)
     hipLaunchKernelGGL(conv2d_ws_kernel<1>, dim3(gx, 1), dim3(W_NT), W_LDS, ctx->stream, (const unsigned short*)x,
-                       (const char*)image, bias, (const unsigned short*)nullptr, y, w, (const float*)nullptr);
+                       (const char*)image, bias, (const unsigned short*)nullptr, y, w, (const float*)nullptr,
+                       (const unsigned short*)nullptr);
   else if (g.w_cin)
     hipLaunchKernelGGL((conv2d_ws_kernel<4, true>), dim3(gx, n_ct), dim3(W_NT), W_LDS_EXO, ctx->stream,
-                       (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res, y, w, g.exo);
+                       (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res, y, w, g.exo,
+                       (const unsigned short*)g.res2);
   else
     hipLaunchKernelGGL(conv2d_ws_kernel<4>, dim3(gx, n_ct), dim3(W_NT), W_LDS, ctx->stream,
                        (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res, y, w,
-                       (const float*)nullptr);
+                       (const float*)nullptr, (const unsigned short*)g.res2);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

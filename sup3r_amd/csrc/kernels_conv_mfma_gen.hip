@@ -286,7 +286,7 @@ int launch_conv_mfma_gen_fwd(s3_ctx* ctx, const ConvGeom& g, int precision, cons
   if (io.in_bf16 && g.Cin % 8 != 0) S3_FAIL(ctx, S3_ESTATE, "gen MFMA conv: bf16 input needs C_in % 8 == 0");
   if (conv2d_ws_supported(g, precision, io, res != nullptr))
     return launch_conv2d_ws(ctx, g, x, (const char*)packed + gen_tile_image_bytes(g, precision, m.ka), bias, res, y);
-  if (g.w_cin || g.ws_only) S3_FAIL(ctx, S3_ESTATE, "conv planned for the weights-stationary kernel launched off it");
+  if (g.w_cin || g.ws_only || g.res2) S3_FAIL(ctx, S3_ESTATE, "conv planned for the weights-stationary kernel launched off it");
   if (precision == S3_PREC_BF16X3) {
     if (m.ka == 1) return launch_gen_prec<S3_PREC_BF16X3, 1>(ctx, m.l, x, packed, bias, res, y, io);
     return launch_gen_prec<S3_PREC_BF16X3, 3>(ctx, m.l, x, packed, bias, res, y, io);

@@ -75,6 +75,7 @@ struct OpRec {
   int rep_src = -1;            // conv: tensor read through a fused temporal repeat (cg.in_rep)
   int res_src = -1;            // ... and the residual (cg.res_rep)
   int exo_src = -1;            // conv behind a fused-away Sup3rConcat: the exogenous field (cg.w_cin)
+  int res2_src = -1;           // conv that absorbed the skip add behind it: the add's other operand (cg.res2)
   void* sign_bytes = nullptr;  // training: activation sign bytes next to the output (conv_dgrad_s2's mask)
   bool fused_away = false;     // repeat op absorbed by its consumer conv: no launch
   float* dg_w32 = nullptr;     // flipped / transposed fp32 filter
@@ -941,6 +942,45 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
     }
   }
 
+  // ---- inference plans: a skip add right behind a 2-D 64 -> 64 k conv that
+  // already carries a residual (the last block's sum + the big skip of
+  // sup3rcc/gen_*_5x_1x_* at hi-res) is absorbed into that conv's store on the
+  // weights-stationary kernel (ConvGeom::res2): conv.out := add.out, the add
+  // never runs.  Verified with the dtypes below, like the concat split.
+  if (!training && precision == S3_PREC_BF16 && !s3_opt_has(S3O_NO_WS_RES2) && !s3_opt_has(S3O_FP32_ACT) &&
+      !s3_opt_has(S3O_NO_ADD16) && !tl_no_ws_exo) {
+    for (int i = 0; i < n_ops; ++i) {
+      OpRec& a = pl->ops[i];
+      if (a.d.kind != S3_OP_ADD || a.d.bcast_c || a.fused_away) continue;
+      for (int side = 0; side < 2; ++side) {
+        const int t_conv = side ? a.d.in1 : a.d.in0, t_other = side ? a.d.in0 : a.d.in1;
+        const int rt = root_of(pl, t_conv);
+        if (rt == root_of(pl, output) || rt == root_of(pl, t_other)) continue;
+        int prod = -1, n_use = 0;
+        for (int k = 0; k < n_ops; ++k) {
+          const s3_op_desc& u = pl->ops[k].d;
+          if (u.kind != S3_OP_VIEW && root_of(pl, u.out) == rt) prod = k;
+          for (int id : {u.in0, u.in1, u.res})
+            if (id >= 0 && root_of(pl, id) == rt) ++n_use;
+        }
+        if (prod < 0 || prod >= i || n_use != 1) continue;
+        OpRec& c = pl->ops[prod];
+        if (c.d.kind != S3_OP_CONV || c.res2_src >= 0 || c.d.res < 0 || c.cg.act != S3_ACT_NONE || c.cg.d2s != 1 ||
+            c.cg.w_cin || !c.mfma || !conv2d_ws_geom_ok(c.cg) || conv2d_ws_tail_geom_ok(c.cg))
+          continue;
+        // (the other operand must exist before the conv runs)
+        int prod_other = -1;
+        for (int k = 0; k < n_ops; ++k)
+          if (pl->ops[k].d.kind != S3_OP_VIEW && root_of(pl, pl->ops[k].d.out) == root_of(pl, t_other)) prod_other = k;
+        if (prod_other >= prod) continue;
+        c.res2_src = t_other;
+        c.d.out = a.d.out;
+        a.fused_away = true;
+        break;
+      }
+    }
+  }
+
   // ---- activation dtypes.  Inference plans in bf16 mode keep a tensor in
   // bf16 when its producer can write it (MFMA conv, direct conv, index op) and
   // EVERY consumer can read it (MFMA conv input / residual, index op);
@@ -981,7 +1021,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
       changed = false;
       for (auto& o : pl->ops) {
         const s3_op_desc& d = o.d;
-        if (d.kind == S3_OP_CONCAT && o.fused_away) continue;   // (never runs: its operands go to the conv)
+        if ((d.kind == S3_OP_CONCAT || d.kind == S3_OP_ADD) && o.fused_away) continue;   // (never runs: its operands go to the conv)
         switch (d.kind) {
           case S3_OP_CONV:
             if (training && d.res >= 0 && fewch_out[root_of(pl, d.res)]) demote(d.res, changed);
@@ -1072,8 +1112,10 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         conv2d_ws_supported(o.cg, precision, o.io, o.d.res >= 0))
       o.cg.ws_only = 1;
   for (auto& o : pl->ops) {
-    if (o.d.kind != S3_OP_CONV || o.exo_src < 0) continue;
-    if (conv2d_ws_supported(o.cg, precision, o.io, o.d.res >= 0)) continue;
+    if (o.d.kind != S3_OP_CONV || (o.exo_src < 0 && o.res2_src < 0)) continue;
+    if (conv2d_ws_supported(o.cg, precision, o.io, o.d.res >= 0) &&
+        (o.res2_src < 0 || pl->t[root_of(pl, o.res2_src)].dtype == 1))
+      continue;
     // (a consumer of the 64-channel tensor that needs fp32 cells, ...): build
     // the plan again with the concat as it is written
     delete pl;
@@ -1165,8 +1207,9 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
   std::vector<int> last_use(n_tensors, -1);
   for (int i = 0; i < n_ops; ++i) {
     const s3_op_desc& d = pl->ops[i].d;
-    int ids[7] = {d.in0, d.in1, d.res, d.out, pl->ops[i].rep_src, pl->ops[i].res_src, pl->ops[i].exo_src};
-    for (int q = 0; q < 7; ++q)
+    int ids[8] = {d.in0, d.in1, d.res, d.out, pl->ops[i].rep_src, pl->ops[i].res_src, pl->ops[i].exo_src,
+                  pl->ops[i].res2_src};
+    for (int q = 0; q < 8; ++q)
       if (ids[q] >= 0) last_use[root_of(pl, ids[q])] = i;
   }
   last_use[root_of(pl, output)] = n_ops + 1;
@@ -1175,7 +1218,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
   for (int i = 0; i < n_ops; ++i) {
     const s3_op_desc& d = pl->ops[i].d;
     if (d.kind == S3_OP_VIEW) continue;
-    if (d.kind == S3_OP_CONCAT && pl->ops[i].fused_away) continue;   // (never materialised)
+    if ((d.kind == S3_OP_CONCAT || d.kind == S3_OP_ADD) && pl->ops[i].fused_away) continue;   // (never materialised / written by the conv)
     TensorRec& ot = pl->t[d.out];
     size_t need = ot.bytes();
     int pick = -1;
@@ -1476,9 +1519,10 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
           o.packed_version = P->version;
         }
         const void* wp = pl->precision != S3_PREC_F32 ? (const void*)o.packed : (const void*)w;
-        if (o.exo_src >= 0) {
+        if (o.exo_src >= 0 || o.res2_src >= 0) {
           ConvGeom ge = o.cg;
-          ge.exo = (const float*)tptr(pl, o.exo_src);
+          if (o.exo_src >= 0) ge.exo = (const float*)tptr(pl, o.exo_src);
+          if (o.res2_src >= 0) ge.res2 = tptr(pl, o.res2_src);
           return launch_conv_mfma_fwd(ctx, ge, pl->precision, tptr(pl, d.in0), wp, b, res, tptr(pl, d.out), o.io);
         }
         return launch_conv_mfma_fwd(ctx, o.cg, pl->precision, tptr(pl, o.rep_src >= 0 ? o.rep_src : d.in0), wp, b,
@@ -1543,6 +1587,7 @@ static int run_op_forward(s3_plan* pl, OpRec& o) {
       return s3_copy_channels(ctx, tptr(pl, d.in1), (int)b.dims[4], 0, tptr(pl, d.out), (int)ot.dims[4], (int)a.dims[4], (int)b.dims[4], npos, 0);
     }
     case S3_OP_ADD:
+      if (o.fused_away) return S3_OK;   // absorbed by the conv in front of it (OpRec::res2_src)
       if (ot.dtype) return launch_add16(ctx, tptr(pl, d.in0), tptr(pl, d.in1), tptr(pl, d.out), ot.numel);
       return launch_add(ctx, tptr(pl, d.in0), tptr(pl, d.in1), tptr(pl, d.out), ot.numel, (int)ot.dims[4], d.bcast_c);
     case S3_OP_ACT:
@@ -1855,7 +1900,8 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
       v[S3_OPINFO_MASK_FUSED_FROM] = o.mask_prod;
     }
   }
-  if (o.d.kind == S3_OP_REPEAT_T || o.d.kind == S3_OP_CONCAT) v[S3_OPINFO_IN_REP] = o.fused_away ? 1 : 0;
+  if (o.d.kind == S3_OP_REPEAT_T || o.d.kind == S3_OP_CONCAT || o.d.kind == S3_OP_ADD)
+    v[S3_OPINFO_IN_REP] = o.fused_away ? 1 : 0;
   for (int q = 0; q < cap && q < S3_OPINFO_COUNT; ++q) out[q] = v[q];
   return S3_OPINFO_COUNT;
 }

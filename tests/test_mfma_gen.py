@@ -169,6 +169,13 @@ def test_concat_of_one_exo_channel_runs_inside_the_ws_conv():
     iadd = [i for i, k in enumerate(kinds) if k == S.OP_ADD]
     assert iadd and all(a.tensor_is_bf16(a.plan.ops[i]['out']) for i in iadd)
     ya = a.forward(xd, ed).cpu().numpy()
+    # ... and the LAST of them (the big skip right behind a conv that already
+    # adds the block's skip) is absorbed into that conv's store: the same
+    # bits as the plan that runs it as a pass of its own
+    assert [a.op_info(i)['in_rep'] for i in iadd] == [0] * (len(iadd) - 1) + [1]
+    c = net.plan(shape, training=False, options={'NO_WS_RES2': 1})
+    assert [c.op_info(i)['in_rep'] for i in iadd] == [0] * len(iadd)
+    np.testing.assert_array_equal(c.forward(xd, ed).cpu().numpy(), ya)
     b = net.plan(shape, training=False, options={'NO_WS_EXO': 1,
                                                   'NO_ADD16': 1})
     assert b.op_info(ic)['in_rep'] == 0
