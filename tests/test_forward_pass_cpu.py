@@ -337,3 +337,91 @@ def test_reshape_data_chunk_lays_exo_out_per_model_step():
                                      'data': e1}]}}
     with pytest.raises(AssertionError):
         ForwardPass._reshape_data_chunk(Chain(), x, bad)
+
+
+@pytest.mark.parametrize('mode', ['reflect', 'symmetric', 'edge', 'wrap',
+                                  'constant'])
+def test_pad_source_data_time_invariant_exo_is_the_repeated_field(mode):
+    """``pad_source_data`` (forward_pass.py:122-186) repeats a 3-D exo field
+    along time and pads the result.  For the padding modes that keep a
+    time-constant field time-constant the build hands out a zero-stride view
+    of the spatially padded field instead — the same VALUES and shape as
+    ``np.pad(np.repeat(...))``, which the device executor uploads once per
+    chunk; 'constant' (zero) padding along time keeps the materialised form"""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((6, 5, 4, 2)).astype(np.float32)
+    topo = rng.standard_normal((18, 15, 1)).astype(np.float32)
+    tvar = rng.standard_normal((18, 15, 8, 1)).astype(np.float32)
+    pad = ((1, 2), (2, 1), (1, 1))
+    exo = {'topography': {'steps': [
+        {'model': 0, 'combine_type': 'layer', 'data': topo},
+        {'model': 0, 'combine_type': 'input', 'data': tvar}]}}
+    enh = {'topography': [(3, 2), (3, 2)]}
+    out, got = ForwardPass.pad_source_data(x, pad, exo, mode=mode,
+                                           enhancements=enh)
+    np.testing.assert_array_equal(out, np.pad(x, (*pad, (0, 0)), mode=mode))
+    ew = ((3, 6), (6, 3), (2, 2), (0, 0))
+    want0 = np.pad(np.repeat(topo[:, :, None, :], 2 * 4, axis=2), ew,
+                   mode=mode)
+    g0 = got['topography']['steps'][0]['data']
+    assert g0.shape == want0.shape
+    np.testing.assert_array_equal(g0, want0)
+    assert (g0.strides[2] == 0) == (mode != 'constant')
+    # a field WITH a time axis is padded as it is
+    g1 = got['topography']['steps'][1]['data']
+    np.testing.assert_array_equal(g1, np.pad(tvar, ew, mode=mode))
+    assert g1.strides[2] != 0
+
+
+def test_device_chain_predicate_on_duck_typed_steps():
+    """which ``MultiStepGan`` chains the executor keeps on the device
+    (``ForwardPass._device_chain``): spatial steps before spatio-temporal
+    ones, every step on this engine with the base class's normalisation, fp32
+    statistics, no 'output' exo, fp32 'input' exo for the later steps"""
+    import types
+
+    from sup3r_amd.gan import Sup3rGan
+
+    dev = object()
+
+    def step(rank4, dtype=np.float32, own_norm=False, on_device=True):
+        cls = type('Step', (), {
+            'norm_input': (lambda self, x: x) if own_norm
+            else Sup3rGan.norm_input,
+            'un_norm_output': Sup3rGan.un_norm_output,
+            'supports_device_chunks': True})
+        m = cls()
+        m._gen = types.SimpleNamespace(dev=dev) if on_device else None
+        m.is_4d, m.is_5d = rank4, not rank4
+        m.lr_features, m.hr_out_features = ['u', 'v'], ['u', 'v']
+        m._means = {'u': dtype(0), 'v': dtype(1)}
+        m._stats_for = lambda feats: (np.array([m._means[f] for f in feats]),
+                                      np.array([dtype(1)] * len(feats)))
+        return m
+
+    def chain(*steps):
+        return types.SimpleNamespace(models=list(steps))
+    chunk = types.SimpleNamespace(exo_data=None)
+    ok = ForwardPass._device_chain
+    assert ok(chain(step(True), step(True)), chunk)
+    assert ok(chain(step(True), step(False)), chunk)
+    assert ok(chain(step(False)), chunk)
+    assert not ok(chain(step(False), step(True)), chunk)        # 5-D then 4-D
+    assert not ok(chain(step(True), step(True, np.float64)), chunk)
+    assert not ok(chain(step(True, own_norm=True), step(True)), chunk)
+    assert not ok(chain(step(True), step(True, on_device=False)), chunk)
+    try:
+        ForwardPass.device_chains = False
+        assert not ok(chain(step(True), step(True)), chunk)
+    finally:
+        ForwardPass.device_chains = True
+    e32 = np.zeros((4, 4, 2, 1), np.float32)
+    for ctype, data, want in (('layer', e32, True), ('input', e32, True),
+                              ('input', e32.astype(np.float64), False),
+                              ('output', e32, False)):
+        chunk = types.SimpleNamespace(exo_data={'topography': {'steps': [
+            {'model': 1, 'combine_type': ctype, 'data': data}]}})
+        assert ok(chain(step(True), step(True)), chunk) == want, ctype
+    # the public predicate routes chains there
+    assert ForwardPass._device_path(chain(step(True), step(True)),
+                                    types.SimpleNamespace(exo_data=None))
