@@ -321,6 +321,7 @@ int launch_conv_mfma_gen_fwd(s3_ctx* ctx, const ConvGeom& g, int precision, cons
 // weights-stationary persistent 2-D conv for the all-bf16 64 -> 64 k trunks of
 // the spatial generators (kernels_conv2d_ws.hip); physical 2-D geometry
 bool conv2d_ws_geom_ok(const ConvGeom& g);
+bool conv2d_ws_frame_geom_ok(const ConvGeom& g);  // its data gradient over the zero-padded frame (bf16 in / out)
 bool conv2d_ws_tail_geom_ok(const ConvGeom& g);   // 64 -> C_out <= 16 output conv, fp32 out
 bool conv2d_ws_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);
 size_t conv2d_ws_image_bytes(const ConvGeom& g);
@@ -426,7 +427,8 @@ int launch_conv_dgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const 
 bool conv_wgrad_bf16_2d_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_bf16_2d_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);
 int launch_conv_wgrad_bf16_2d(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                              float* dw, float* partial, size_t partial_bytes, int accumulate, int x_bf16 = 0);
+                              float* dw, float* partial, size_t partial_bytes, int accumulate, int x_bf16 = 0,
+                              int dy_bf16 = 0);
 // wgrad of the 2-channel hi-res conv, LDS-free bf16 MFMA (kernels_conv_wgrad_fewch.hip)
 bool conv_wgrad_c2_supported(const ConvGeom& g, int precision);
 size_t conv_wgrad_c2_partial_bytes(const s3_ctx* ctx, const ConvGeom& g);

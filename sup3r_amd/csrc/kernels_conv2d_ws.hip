@@ -102,6 +102,10 @@ struct WsGeom {
   float alpha;
   int tiles_i, tiles_r, tiles_c;
   int dbg;             // option MFMA_DBG (ablations): 1 no halo prefetch, 2 no tap loop, 4 no epilogue
+  // 1: the data gradient of such a conv — the full correlation of dPre (N, H, W)
+  // with the flipped / transposed filter over the frame padded by one cell,
+  // zero boundary: out (N, H + 2, W + 2), out[r] = sum_t w[t] in[r - 2 + t]
+  int frame;
 };
 
 // NF = 4: 64 output channels per workgroup, bf16 cells out (the trunk form).
@@ -164,13 +168,16 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     int cl_ = (tid + q * W_NT) >> 3;                                                            \
     cl_ = cl_ > WHP - 1 ? WHP - 1 : cl_;                                                        \
     int im_ = i0_ + cl_ / (WH_C * WH_R);                                                        \
-    int r_ = s3_reflect(r0_ + (cl_ / WH_C) % WH_R - 1, g.H);                                    \
-    int c_ = s3_reflect(c0_ + cl_ % WH_C - 1, g.W);                                             \
+    const int rv_ = r0_ + (cl_ / WH_C) % WH_R - 1 - g.frame, cv_ = c0_ + cl_ % WH_C - 1 - g.frame;  \
+    int r_ = g.frame ? rv_ : s3_reflect(rv_, g.H);                                              \
+    int c_ = g.frame ? cv_ : s3_reflect(cv_, g.W);                                              \
+    const bool z_ = g.frame && (rv_ < 0 || rv_ >= g.H || cv_ < 0 || cv_ >= g.W);               \
     im_ = im_ > g.N - 1 ? g.N - 1 : im_;                                                        \
     r_ = r_ < 0 ? 0 : (r_ > g.H - 1 ? g.H - 1 : r_);                                            \
     c_ = c_ < 0 ? 0 : (c_ > g.W - 1 ? g.W - 1 : c_);                                            \
     const unsigned cell_ = ((unsigned)im_ * g.H + r_) * g.W + c_; /* < 2^31 */                  \
     P = *reinterpret_cast<const uint4*>(x + (size_t)cell_ * 64 + (tid & 7) * 8);                \
+    if (z_) P = make_uint4(0, 0, 0, 0);   /* (zero boundary of the frame) */                    \
   }
   // (named registers, not an array: an array that lives across the tap loop
   // was demoted to scratch, and each scratch store waited for its load)
@@ -276,7 +283,8 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     int i0, r0, c0;
     tile_org(t_cur, i0, r0, c0);
     const int im = i0 + w_img, c = c0 + frow;
-    const bool pos_ok = im < g.N && c < g.W;
+    const int Ho = g.H + 2 * g.frame, Wo = g.W + 2 * g.frame;   // output extents
+    const bool pos_ok = im < g.N && c < Wo;
     uint4 rr[4][2];
     if (NF == 4 && res) {
 #pragma unroll
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int r = r0 + w_row + m;
-        if (!pos_ok || r >= g.H || (g.dbg & 4)) continue;
+        if (!pos_ok || r >= Ho || (g.dbg & 4)) continue;
         if constexpr (NF == 1) {
           // lane (column frow, kq): channels 4 kq .. 4 kq + 3 of C_out <= 16, fp32
           float* yo = reinterpret_cast<float*>(yv) + (((size_t)im * g.H + r) * g.W + c) * g.Cout;
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
           for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
           size_t dst;
           if (g.b == 1) {
-            dst = (((size_t)im * g.H + r) * g.W + c) * g.Cout + co;
+            dst = (((size_t)im * Ho + r) * Wo + c) * g.Cout + co;
           } else {
             const int blk = co / g.cpo, cc = co % g.cpo;
             dst = (((size_t)im * (g.H * g.b) + r * g.b + blk / g.b) * (g.W * g.b) + c * g.b + blk % g.b) *
@@ -460,6 +468,20 @@ bool conv2d_ws_geom_ok(const ConvGeom& g) {
          (int64_t)g.N * g.O[0] * g.O[1] * (g.d2s < 1 ? 1 : g.d2s) * (g.d2s < 1 ? 1 : g.d2s) < ((int64_t)1 << 31);
 }
 
+// the data gradient of a 2-D reflect-'same' 64 -> 64 k conv as a conv over the
+// zero-padded frame (conv_dgrad_gen_geom): bf16 dPre in, bf16 frame out
+bool conv2d_ws_frame_geom_ok(const ConvGeom& g) {
+  if (g.Cin != 64 || g.Cout != 64 || g.w_cin) return false;
+  if (g.k[0] != 3 || g.k[1] != 3 || g.k[2] != 1 || g.D[2] != 1 || g.O[2] != 1) return false;
+  if (g.pad_mode != S3_PAD_ZERO || g.in_cstride || g.in_rep > 1 || g.res_rep > 1 || g.d2s > 1) return false;
+  if (g.act != S3_ACT_NONE) return false;
+  for (int d = 0; d < 2; ++d)
+    if (g.s[d] != 1 || g.lo[d] != 2 || g.O[d] != g.D[d] + 2 || g.D[d] < 2) return false;
+  if (g.s[2] != 1 || g.lo[2] != 0) return false;
+  if ((int64_t)g.D[0] * g.D[1] < 256) return false;
+  return (int64_t)g.N * g.O[0] * g.O[1] < ((int64_t)1 << 31);
+}
+
 // the few-feature output conv: 64 -> C_out <= 16, no depth-to-space
 bool conv2d_ws_tail_geom_ok(const ConvGeom& g) {
   if (g.Cout < 1 || g.Cout > 16 || (g.d2s > 1)) return false;
@@ -471,6 +493,7 @@ bool conv2d_ws_tail_geom_ok(const ConvGeom& g) {
 
 bool conv2d_ws_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res) {
   if (precision != S3_PREC_BF16 || s3_opt_on(S3O_NO_CONV2D_WS)) return false;
+  if (conv2d_ws_frame_geom_ok(g)) return io.in_bf16 && io.out_bf16 && !has_res;
   if (g.w_cin && (g.w_cin != 65 || conv2d_ws_tail_geom_ok(g))) return false;   // (one exogenous channel, trunk form)
   if (conv2d_ws_tail_geom_ok(g)) return io.in_bf16 && !io.out_bf16 && !has_res;
   if (!io.in_bf16 || !io.out_bf16 || (has_res && !io.res_bf16)) return false;
@@ -510,7 +533,10 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
   w.Cout = g.Cout; w.b = g.d2s < 1 ? 1 : g.d2s; w.cpo = g.Cout / (w.b * w.b);
   w.act = g.act; w.alpha = g.alpha;
   w.dbg = (int)s3_opt_int(S3O_MFMA_DBG, 0);
-  w.tiles_i = (g.N + WT_I - 1) / WT_I; w.tiles_r = (w.H + WT_R - 1) / WT_R; w.tiles_c = (w.W + WT_C - 1) / WT_C;
+  w.frame = conv2d_ws_frame_geom_ok(g) ? 1 : 0;
+  if (w.frame && (res || g.res2 || g.w_cin)) S3_FAIL(ctx, S3_ESTATE, "conv2d_ws: the frame form takes no skip / exo operand");
+  w.tiles_i = (g.N + WT_I - 1) / WT_I;
+  w.tiles_r = (w.H + 2 * w.frame + WT_R - 1) / WT_R; w.tiles_c = (w.W + 2 * w.frame + WT_C - 1) / WT_C;
   const bool tail = conv2d_ws_tail_geom_ok(g);
   const int T = w.tiles_i * w.tiles_r * w.tiles_c, n_ct = (g.Cout + 63) / 64;
   // ~one workgroup per CU over all output-channel tiles (each keeps ITS image)

@@ -245,7 +245,7 @@ size_t conv_mfma_gen_packed_bytes(const ConvGeom& g, int precision) {
   const int npass = (g.Cin + kch - 1) / kch;
   size_t b = (size_t)((g.Cout + CT - 1) / CT) * npass * m.ka * 9 * CT * CIN * 2;
   // the weights-stationary 2-D kernel's image rides behind the tile image
-  if (precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g))) b += conv2d_ws_image_bytes(g);
+  if (precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g) || conv2d_ws_frame_geom_ok(g))) b += conv2d_ws_image_bytes(g);
   return b;
 }
 
@@ -262,7 +262,7 @@ int launch_conv_mfma_gen_pack(s3_ctx* ctx, const ConvGeom& g, int precision, con
   const int npass = (g.Cin + kch - 1) / kch, ltaps = m.ka * 9, n_ct = (g.Cout + CT - 1) / CT;
   // (a conv with an exogenous channel split off runs on the weights-stationary
   // kernel only: its tile image is never read)
-  if (g.w_cin || (g.ws_only && precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g))))
+  if (g.w_cin || (g.ws_only && precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g) || conv2d_ws_frame_geom_ok(g))))
     return launch_conv2d_ws_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka));
   const int64_t total = (int64_t)n_ct * npass * ltaps * CT * (x3 ? 32 : CIN);
   int grid = (int)((total + 255) / 256);
@@ -274,7 +274,7 @@ int launch_conv_mfma_gen_pack(s3_ctx* ctx, const ConvGeom& g, int precision, con
     hipLaunchKernelGGL(pack_gen_bf16_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, (unsigned short*)packed, ltaps,
                        g.Cin, g.Cout, n_ct, npass, m.tp[0], m.tp[1], m.tp[2]);
   S3_HIP(ctx, hipGetLastError());
-  if (precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g)))
+  if (precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g) || conv2d_ws_frame_geom_ok(g)))
     return launch_conv2d_ws_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka));
   return S3_OK;
 }

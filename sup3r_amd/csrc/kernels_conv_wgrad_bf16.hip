@@ -1024,7 +1024,9 @@ struct Bf2D {
 
 // IN16: x is bf16 cells (C_in % 8 == 0; the activations a 2-D training plan
 // saves behind the weights-stationary / logical-axes forward kernels)
-template <int CIB, int STR, bool IN16 = false>
+// DY16: dPre is bf16 cells as well (C_out % 4 == 0; the masked fold of the
+// consumer's data gradient stored it as bf16 only)
+template <int CIB, int STR, bool IN16 = false, bool DY16 = false>
 __global__ __launch_bounds__(BNT) void conv2_wgrad_bf16_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     float* __restrict__ partial, ConvGeom g, int tiles1, int tiles2, int n_tiles) {
@@ -1124,6 +1126,14 @@ __global__ __launch_bounds__(BNT) void conv2_wgrad_bf16_kernel(
       const int pl = item >> 3, ch = item & 7;
       const int o0 = org1 + pl / T2, o1 = org2 + pl % T2;
       const int co = ct * BCT + ch * 4;
+      if constexpr (DY16) {
+        uint2 v16 = make_uint2(0, 0);
+        if (o0 < g.O[0] && o1 < g.O[1] && co < Cout)
+          v16 = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(dy) +
+                                                (((size_t)n * g.O[0] + o0) * g.O[1] + o1) * Cout + co);
+        *reinterpret_cast<uint2*>(ds + pl * 64 + (((ch >> 2) ^ ((pl >> 3) & 1)) << 5) + ((ch & 3) << 3)) = v16;
+        continue;
+      }
       float4 v = make_float4(0, 0, 0, 0);
       if (o0 < g.O[0] && o1 < g.O[1] && co < Cout) {
         const float* dp = dy + (((size_t)n * g.O[0] + o0) * g.O[1] + o1) * Cout + co;
@@ -1193,7 +1203,7 @@ int bf_2d_grid(const s3_ctx* ctx, const ConvGeom& g, int* n_tiles, int* t1, int*
   return grid;
 }
 
-template <int CIB, int STR, bool IN16 = false>
+template <int CIB, int STR, bool IN16 = false, bool DY16 = false>
 int bf_2d_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy, float* dw,
                  float* partial, size_t partial_bytes, int accumulate) {
   using W = Bf2D<CIB, STR>;
@@ -1201,7 +1211,7 @@ int bf_2d_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy
   const int grid = bf_2d_grid<CIB, STR>(ctx, g, &n_tiles, &t1, &t2);
   const size_t need = (size_t)grid * 9 * g.Cin * g.Cout * sizeof(float);
   if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_2d: partial buffer too small");
-  auto kern = conv2_wgrad_bf16_kernel<CIB, STR, IN16>;
+  auto kern = conv2_wgrad_bf16_kernel<CIB, STR, IN16, DY16>;
   static bool attr_set = false;
   if (!attr_set) {
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1354,8 +1364,15 @@ size_t conv_wgrad_bf16_2d_partial_bytes(const s3_ctx* ctx, const ConvGeom& g) {
 }
 
 int launch_conv_wgrad_bf16_2d(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy,
-                              float* dw, float* partial, size_t partial_bytes, int accumulate, int x_bf16) {
+                              float* dw, float* partial, size_t partial_bytes, int accumulate, int x_bf16,
+                              int dy_bf16) {
   const bool s2 = g.s[0] == 2;
+  if (dy_bf16) {
+    if (!x_bf16 || g.Cin % 8 != 0 || g.Cout % 4 != 0 || s2)
+      S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_2d: bf16 dPre needs bf16 x cells, stride 1, C_in % 8 == 0, C_out % 4 == 0");
+    if (g.Cin <= 32) return bf_2d_launch<2, 1, true, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
+    return bf_2d_launch<4, 1, true, true>(ctx, g, x, dy, dw, partial, partial_bytes, accumulate);
+  }
   if (x_bf16) {
     if (g.Cin % 8 != 0) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_2d: bf16 cells need C_in % 8 == 0");
     if (g.Cin <= 32)

@@ -1274,6 +1274,11 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         o.dgrad_frame16 = training && o.dgrad_mfma && !o.dgrad_valid && !o.dgrad_chunked && !o.dgrad_fewch &&
                           o.dg.Cout == 64 && (o.cg.Cin & 3) == 0 && o.cg.pad_mode == S3_PAD_REFLECT &&
                           conv_mfma_persist_dgrad_supported(ctx, o.dg) && !s3_opt_has(S3O_NO_FRAME16);
+        // ... and so is the frame of a 2-D 64 -> 64 k conv's data gradient on the
+        // weights-stationary kernel (round 5)
+        if (training && o.dgrad_gen && !o.dgrad_valid && conv2d_ws_frame_geom_ok(o.dg) &&
+            !s3_opt_has(S3O_NO_FRAME16) && !s3_opt_on(S3O_NO_CONV2D_WS))
+          o.dgrad_frame16 = true;
       }
       // ... and for the stride-2 data gradient that stores dPre of the
       // few-channel conv below it as bf16 only (see the dgrad_s2 branch)
@@ -2153,7 +2158,8 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
         if (only16) {
           dpre16 = pl->dpre16;
           pl->dpre16_for = -1;
-          const bool trunk16 = o.use16 && o.wgrad_bf16;
+          const bool trunk16 = o.use16 && (o.wgrad_bf16 || (o.wgrad_bf16_2d && !o.fewpos && o.io.in_bf16 &&
+                                                            g.s[0] == 1 && (g.Cout & 3) == 0));
           const bool fewch16 = o.wgrad_c2 && (o.dgrad_c2 || !wants_grad(d.in0));
           if ((!trunk16 && !fewch16) || d.res >= 0)
             S3_FAIL(ctx, S3_ESTATE, "backward: bf16-only dPre reached a conv that needs fp32");
@@ -2264,7 +2270,12 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
                                       pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, only16 ? 1 : 0,
                                       pl->precision == S3_PREC_BF16X3);
           else if (o.wgrad_bf16_2d)
-            rc = launch_conv_wgrad_bf16_2d(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16);
+          {
+            // (bf16-only dPre out of the consumer's masked fold, or a bf16 copy next to the fp32 one)
+            const bool dy16 = only16 || (dpre16 && o.io.in_bf16 && g.s[0] == 1 && (g.Cout & 3) == 0 && (g.Cin & 7) == 0);
+            rc = launch_conv_wgrad_bf16_2d(ctx, g, tptr(pl, d.in0), dy16 ? (const float*)dpre16 : dpre, G + P->p[d.w].offset,
+                                           pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16, dy16 ? 1 : 0);
+          }
           else if (o.wgrad_bf16_gen)
             rc = launch_conv_wgrad_bf16_gen(ctx, g, tptr(pl, d.in0), dpre, G + P->p[d.w].offset, pl->wg_partial, pl->wg_partial_bytes, accumulate_wgrad, o.io.in_bf16,
                                             pl->precision == S3_PREC_BF16X3);
@@ -2350,7 +2361,9 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
             // along — it is stored as bf16 ONLY: the fold writes 75 instead of
             // 151 MB and the readers stage half the bytes; they would round to
             // bf16 (the same round-to-nearest-even) anyway.
-            const bool to16 = out == pl->t[rin].gptr && back_to_back(o.mask_prod, i) && po.use16 && po.wgrad_bf16 &&
+            const bool to16 = out == pl->t[rin].gptr && back_to_back(o.mask_prod, i) && po.use16 &&
+                              (po.wgrad_bf16 || (po.wgrad_bf16_2d && !po.fewpos && !po.wgrad_tail && !po.wgrad_c2 &&
+                                                 po.cg.s[0] == 1 && !s3_opt_has(S3O_NO_TRAIN2D_BF16))) &&
                               po.io.in_bf16 && po.d.res < 0 &&
                               (po.cg.Cout & 3) == 0 && pl->dpre16 && pl->dpre16_for < 0 &&
                               (!need_wgrad || po.d.b < 0 || bs != nullptr) && pl->precision == S3_PREC_BF16;
@@ -2426,6 +2439,13 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
             } else {
               ConvIO dio;
               dio.in_bf16 = (o.use16 && dpre16) ? 1 : 0;
+              // 2-D 64 -> 64 k convs: the frame form of the weights-stationary
+              // kernel, bf16 dPre in, bf16 frame out (folded from bf16)
+              if (dio.in_bf16 && o.dgrad_gen && o.dgrad_frame16 && !o.dgrad_valid && pl->precision == S3_PREC_BF16) {
+                ConvIO wio = dio;
+                wio.out_bf16 = 1;
+                if (conv2d_ws_supported(o.dg, pl->precision, wio, false)) { dio = wio; frame16 = 1; }
+              }
               rc = launch_conv_mfma_fwd(ctx, o.dg, pl->precision, dio.in_bf16 ? dpre16 : (const void*)dpre, wp, nullptr,
                                         nullptr, o.dgrad_valid ? dst : pl->dxp, dio);
             }
