@@ -53,7 +53,6 @@ constexpr int W_EXO_OFF = W_LDS;
 constexpr int W_WE_OFF = W_EXO_OFF + WHP * 4;       // 159,520
 constexpr int W_LDS_EXO = W_WE_OFF + 9 * 64 * 4;    // 161,824
 constexpr int W_NT = 512;
-constexpr int W_TRIPS = (WHP * 8 + W_NT - 1) / W_NT;   // 11 16-B chunks per lane
 
 __device__ inline unsigned ws_pk(float a, float b) {
   hf32x2 v = {a, b};
@@ -119,7 +118,10 @@ struct WsGeom {
 // lands in LDS — the rounding the 65-channel conv's staging applied), its nine
 // taps per output are 576 fused multiply-adds per lane and tile on the vector
 // unit between the MFMA loop and the hand-over.
-template <int NF, bool EXO = false>
+// RES: a skip operand (res) is added in the epilogue — a template parameter so
+// that the loads of its rows and their use are unconditional code (see
+// conv2d_ws_tile.inc on why that matters).
+template <int NF, bool EXO = false, bool RES = false>
 __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     const unsigned short* __restrict__ x, const char* __restrict__ wimg, const float* __restrict__ bias,
     const unsigned short* __restrict__ res, void* __restrict__ yv, WsGeom g, const float* __restrict__ exo,
@@ -134,9 +136,24 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
 
   // ---- this workgroup's contiguous run of tiles (neighbours share halo
   // columns: the second read of a column hits this XCD's L2)
+  // Ranks are XCD-major: workgroups are dealt to the 8 XCDs round-robin by their
+  // linear id, so the workgroups of one XCD take CONSECUTIVE runs — the halo
+  // columns two neighbouring runs share are fetched into that XCD's L2 once
+  // (with rank = blockIdx.x the neighbour sat on another XCD and fetched its
+  // own copy: FETCH_SIZE 1.69 x the input at the config_fwp_spatial chunk).
   const int T = g.tiles_i * g.tiles_r * g.tiles_c;
-  int t_cur = (int)(((long long)blockIdx.x * T) / gridDim.x);
-  const int t_end = (int)(((long long)(blockIdx.x + 1) * T) / gridDim.x);
+  int rank;
+  {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int o = (int)((blockIdx.y * gridDim.x) & 7);   // XCD of this row's first workgroup
+    const int xcd = (b + o) & 7;
+    rank = 0;
+    // workgroups of this row on the XCDs dealt before this one (in the order o, o + 1, ..)
+    for (int k = 0; k < ((xcd - o) & 7); ++k) rank += (nb - k + 7) / 8;
+    rank += (b - ((xcd - o) & 7)) / 8;
+  }
+  int t_cur = (int)(((long long)rank * T) / gridDim.x);
+  const int t_end = (int)(((long long)(rank + 1) * T) / gridDim.x);
   if (t_cur >= t_end) return;
 
   // ---- the filter image of this output-channel tile: 72 KB, once.  Its nine
@@ -149,10 +166,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
     for (int q = 0; q < 9; ++q) wimg_r[q] = src[tid + q * W_NT];
   }
 
-  // ---- per-lane halo chunks: chunk id tid + 512 q -> (image, row, column,
-  // 16-B chunk) of the halo and its swizzled LDS byte offset.  Recomputed per
-  // trip (a handful of integer ops per 16-B load) rather than kept in 22
-  // registers next to the 44 of the prefetch and the 64 accumulators.
+  // ---- origin of tile t (t is uniform: scalar divisions)
   auto tile_org = [&](int t, int& i0, int& r0, int& c0) __attribute__((always_inline)) {
     c0 = (t % g.tiles_c) * WT_C; t /= g.tiles_c;
     r0 = (t % g.tiles_r) * WT_R; t /= g.tiles_r;
@@ -161,23 +175,34 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
   // (macros, not lambdas: the prefetch buffer is a loop-local array that must
   // stay in registers — captured by a lambda it was demoted to scratch, and the
   // scratch store waited for every load on the spot)
-#define WS_FETCH1(P, q, i0_, r0_, c0_)                                                          \
+  //
+  // Lane -> halo chunk.  A trip covers THREE consecutive halo rows: lane = (sub-row
+  // j, column, 16-B chunk) = 3 x 18 x 8 = 432 lanes (the other 80 shadow sub-row 2:
+  // same address, same data, same LDS slot), trip q = rows 3 q .. 3 q + 2 of the 36
+  // (2 images x 18) — so a lane's COLUMN is the same in all twelve trips: reflect /
+  // clamp / zero flag / LDS swizzle of the column are evaluated once per tile, the
+  // image of a trip is a compile-time constant (18 = 6 x 3), and a trip costs the
+  // row's reflect and one multiply-add.  (Before: chunk id tid + 512 q decoded by
+  // two divisions per trip, ~50 instructions per 16-B load — with the epilogue's
+  // index arithmetic 3 us of vector-ALU work per 10 us tile, serial with the MFMAs.)
+  const int lt = tid < 3 * WH_C * 8 ? tid : tid - WH_C * 8;
+  const int h_j = lt / (WH_C * 8), h_col = (lt - h_j * (WH_C * 8)) >> 3;
+  const unsigned lds_lane = (unsigned)((h_j * WH_C + h_col) * 128 + (((tid & 7) ^ (h_col & 7)) << 4));
+#define WS_FETCH1(P, q)                                                                         \
   {                                                                                             \
-    /* every lane loads in every trip (lanes past the last chunk re-read a legal cell and do */ \
-    /* not commit it); ragged tiles: the address stays legal (masked at the store) */          \
-    int cl_ = (tid + q * W_NT) >> 3;                                                            \
-    cl_ = cl_ > WHP - 1 ? WHP - 1 : cl_;                                                        \
-    int im_ = i0_ + cl_ / (WH_C * WH_R);                                                        \
-    const int rv_ = r0_ + (cl_ / WH_C) % WH_R - 1 - g.frame, cv_ = c0_ + cl_ % WH_C - 1 - g.frame;  \
+    constexpr int up_ = (3 * q >= WH_R) ? 1 : 0;            /* second image of the tile */      \
+    const int rv_ = r0_ + 3 * q - up_ * WH_R + h_j - 1 - g.frame;                               \
     int r_ = g.frame ? rv_ : s3_reflect(rv_, g.H);                                              \
-    int c_ = g.frame ? cv_ : s3_reflect(cv_, g.W);                                              \
-    const bool z_ = g.frame && (rv_ < 0 || rv_ >= g.H || cv_ < 0 || cv_ >= g.W);               \
+    const bool z_ = zc_ || (g.frame && (rv_ < 0 || rv_ >= g.H));                               \
+    /* ragged tiles: the address stays legal (masked at the store) */                          \
+    int im_ = i0_ + up_;                                                                        \
     im_ = im_ > g.N - 1 ? g.N - 1 : im_;                                                        \
     r_ = r_ < 0 ? 0 : (r_ > g.H - 1 ? g.H - 1 : r_);                                            \
-    c_ = c_ < 0 ? 0 : (c_ > g.W - 1 ? g.W - 1 : c_);                                            \
-    const unsigned cell_ = ((unsigned)im_ * g.H + r_) * g.W + c_; /* < 2^31 */                  \
-    P = *reinterpret_cast<const uint4*>(x + (size_t)cell_ * 64 + (tid & 7) * 8);                \
-    if (z_) P = make_uint4(0, 0, 0, 0);   /* (zero boundary of the frame) */                    \
+    const unsigned rowcell_ = ((unsigned)im_ * g.H + r_) * g.W;   /* < 2^31 */                  \
+    P = *reinterpret_cast<const uint4*>(x + (size_t)rowcell_ * 64 + colel_);                    \
+    /* (zero boundary of the frame: only FLAGGED here and zeroed by WS_COMMIT1 — a select on */ \
+    /* the loaded value at this point is a wait for the load in front of the tap loop) */       \
+    zmask |= z_ ? (1u << q) : 0u;                                                               \
   }
   // (named registers, not an array: an array that lives across the tap loop
   // was demoted to scratch, and each scratch store waited for its load)
@@ -185,24 +210,29 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
   {                                                                                             \
     int i0_, r0_, c0_;                                                                          \
     tile_org((T), i0_, r0_, c0_);                                                               \
-    WS_FETCH1(p0, 0, i0_, r0_, c0_) WS_FETCH1(p1, 1, i0_, r0_, c0_) WS_FETCH1(p2, 2, i0_, r0_, c0_)   \
-    WS_FETCH1(p3, 3, i0_, r0_, c0_) WS_FETCH1(p4, 4, i0_, r0_, c0_) WS_FETCH1(p5, 5, i0_, r0_, c0_)   \
-    WS_FETCH1(p6, 6, i0_, r0_, c0_) WS_FETCH1(p7, 7, i0_, r0_, c0_) WS_FETCH1(p8, 8, i0_, r0_, c0_)   \
-    WS_FETCH1(p9, 9, i0_, r0_, c0_) WS_FETCH1(p10, 10, i0_, r0_, c0_)                           \
+    const int cv_ = c0_ + h_col - 1 - g.frame;                                                  \
+    int c_ = g.frame ? cv_ : s3_reflect(cv_, g.W);                                              \
+    const bool zc_ = g.frame && (cv_ < 0 || cv_ >= g.W);                                       \
+    c_ = c_ < 0 ? 0 : (c_ > g.W - 1 ? g.W - 1 : c_);                                            \
+    const unsigned colel_ = (unsigned)c_ * 64 + (tid & 7) * 8;                                  \
+    zmask = 0u;                                                                                 \
+    WS_FETCH1(p0, 0) WS_FETCH1(p1, 1) WS_FETCH1(p2, 2) WS_FETCH1(p3, 3) WS_FETCH1(p4, 4)        \
+    WS_FETCH1(p5, 5) WS_FETCH1(p6, 6) WS_FETCH1(p7, 7) WS_FETCH1(p8, 8) WS_FETCH1(p9, 9)        \
+    WS_FETCH1(p10, 10) WS_FETCH1(p11, 11)                                                       \
   }
 #define WS_COMMIT1(P, q)                                                                        \
-  if (q * W_NT + tid < WHP * 8) {                                                               \
-    const int cl_ = (tid + q * W_NT) >> 3;                                                      \
-    *reinterpret_cast<uint4*>(smem + cl_ * 128 + (((tid & 7) ^ ((cl_ % WH_C) & 7)) << 4)) = P;  \
-  }
+  *reinterpret_cast<uint4*>(smem + lds_lane + q * (3 * WH_C * 128)) =                           \
+      ((zmask >> q) & 1u) ? make_uint4(0, 0, 0, 0) : P;
 #define WS_COMMIT()                                                                             \
   {                                                                                             \
     WS_COMMIT1(p0, 0) WS_COMMIT1(p1, 1) WS_COMMIT1(p2, 2) WS_COMMIT1(p3, 3) WS_COMMIT1(p4, 4)   \
     WS_COMMIT1(p5, 5) WS_COMMIT1(p6, 6) WS_COMMIT1(p7, 7) WS_COMMIT1(p8, 8) WS_COMMIT1(p9, 9)   \
-    WS_COMMIT1(p10, 10)                                                                         \
+    WS_COMMIT1(p10, 10) WS_COMMIT1(p11, 11)                                                     \
   }
-  static_assert(W_TRIPS == 11, "prefetch registers p0 .. p10");
-  uint4 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10;
+  static_assert(WT_I == 2 && WH_R % 3 == 0 && W_NT >= 3 * WH_C * 8 && W_NT - 3 * WH_C * 8 <= WH_C * 8,
+                "twelve trips of three halo rows: prefetch registers p0 .. p11");
+  uint4 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11;
+  unsigned zmask = 0u;   // bit q: chunk q of the prefetched halo lies on the frame's zero boundary
   // exogenous channel: cell tid (+ 512 for tid < 136) of the same halo
 #define WS_EFETCH1(P, q, i0_, r0_, c0_)                                                         \
   {                                                                                             \
@@ -226,7 +256,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
   if constexpr (EXO) {                                                                          \
     float* E_ = reinterpret_cast<float*>(smem + W_EXO_OFF);                                     \
     E_[tid] = __uint_as_float(ws_pk(pe0, 0.f) << 16);                                           \
-    if (tid + W_NT < WHP) E_[tid + W_NT] = __uint_as_float(ws_pk(pe1, 0.f) << 16);              \
+    E_[tid + W_NT < WHP ? tid + W_NT : WHP - 1] = __uint_as_float(ws_pk(pe1, 0.f) << 16);       \
   }
   float pe0 = 0.f, pe1 = 0.f;
   WS_FETCH(t_cur);
@@ -254,7 +284,9 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
   //   cell (img, 4 (w & 3) + m + tb, frow + tc), chunk (ks 4 + kq) ^ ((frow + tc) & 7)
   // filter fragment (A operand) nf of tap: row nf 16 + frow, chunk (ks 4 + kq) ^ ((row >> 1) & 7)
   const int w_img = wave >> 2, w_row = (wave & 3) * 4;
-  unsigned p_addr[3][2], f_addr[4][2];
+  // (the slab swizzle (row >> 1) & 7 does not depend on nf — rows nf 16 + frow — so fragment nf
+  // sits 2048 B behind fragment 0: two address registers instead of eight)
+  unsigned p_addr[3][2], f_addr[2];
 #pragma unroll
   for (int tc = 0; tc < 3; ++tc)
 #pragma unroll
@@ -262,181 +294,39 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
       p_addr[tc][ks] = (unsigned)(((w_img * WH_R + w_row) * WH_C + frow + tc) * 128 +
                                   (((ks * 4 + kq) ^ ((frow + tc) & 7)) << 4));
 #pragma unroll
-  for (int nf = 0; nf < 4; ++nf) {
-    const int row = nf * 16 + frow;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      f_addr[nf][ks] = (unsigned)(W_SLAB_OFF + row * 128 + (((ks * 4 + kq) ^ ((row >> 1) & 7)) << 4));
-  }
+  for (int ks = 0; ks < 2; ++ks)
+    f_addr[ks] = (unsigned)(W_SLAB_OFF + frow * 128 + (((ks * 4 + kq) ^ ((frow >> 1) & 7)) << 4));
   // this lane's output channels: h 32 + kq 8 .. + 7 for h = 0, 1 (inside the tile)
   const float* bl = reinterpret_cast<const float*>(smem + W_BIAS_OFF);
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
-
-  while (true) {
-    const bool has_next = t_cur + 1 < t_end;
-    if (has_next && !(g.dbg & 1)) {
-      WS_FETCH(t_cur + 1);
-      WS_EFETCH(t_cur + 1);
-    }
-    // this tile's skip rows (d2s == 1), fetched now: their latency hides under
-    // the tap loop as well
-    int i0, r0, c0;
-    tile_org(t_cur, i0, r0, c0);
-    const int im = i0 + w_img, c = c0 + frow;
-    const int Ho = g.H + 2 * g.frame, Wo = g.W + 2 * g.frame;   // output extents
-    const bool pos_ok = im < g.N && c < Wo;
-    uint4 rr[4][2];
-    if (NF == 4 && res) {
+  // output addressing (trunk form), set up once: element index of (image im, row r, column c,
+  // this lane's chunk h) = im IS + r RS + c CS + off_h[h] — with a depth-to-space store
+  // (block b, cpo = C_out / b^2 channels per hi-res cell) chunk h is block (bi, bj), channel cq
+  // of the hi-res cell (r b + bi, c b + bj).  Per tile one 64-bit base, per row one multiply-add,
+  // per chunk one add (the index arithmetic of the epilogue was ~100 instructions per store).
+  const int Ho = g.H + 2 * g.frame, Wo = g.W + 2 * g.frame;   // output extents
+  const unsigned rsd = (unsigned)(Wo * g.b * g.cpo);           // elements per output row
+  const unsigned long long IS = (unsigned long long)(Ho * g.b) * rsd;
+  const unsigned RS = (unsigned)g.b * rsd, CS = (unsigned)(g.b * g.cpo);
+  unsigned off_h[2];
+  bool ch_ok[2];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        int r = r0 + w_row + m;
-        r = r > g.H - 1 ? g.H - 1 : r;
-        const int imc = im > g.N - 1 ? g.N - 1 : im, cc = c > g.W - 1 ? g.W - 1 : c;
-        const size_t cellr = ((size_t)imc * g.H + r) * g.W + cc;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          int co = ct * 64 + h * 32 + kq * 8;
-          co = co > g.Cout - 8 ? g.Cout - 8 : co;
-          rr[m][h] = *reinterpret_cast<const uint4*>(res + cellr * g.Cout + co);
-        }
-      }
-    }
-
-    f32x4 acc[4][NF];
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const int cb = NF == 1 ? kq * 4 : (nf >> 1) * 32 + kq * 8 + (nf & 1) * 4;
-      const f32x4 b4 = {bl[cb], bl[cb + 1], bl[cb + 2], bl[cb + 3]};
-#pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m][nf] = b4;
-    }
-    // (tried: (tc, k-step) outermost with the six halo rows m + tb read once
-    // and shared by the three taps — 18 instead of 24 fragment reads per 48
-    // MFMAs, but 32 spilled registers: 519 instead of 899 TFLOP/s at 512 x 64 x 64)
-#pragma unroll 1
-    for (int tb = 0; tb < ((g.dbg & 2) ? 0 : 3); ++tb) {
-#pragma unroll
-      for (int tc = 0; tc < 3; ++tc) {
-        const int tap = tb * 3 + tc;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 wf[NF], pf[4];
-#pragma unroll
-          for (int nf = 0; nf < NF; ++nf)
-            wf[nf] = *reinterpret_cast<const bf16x8*>(smem + f_addr[nf][ks] + tap * 8192);
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            pf[m] = *reinterpret_cast<const bf16x8*>(smem + p_addr[tc][ks] + (m + tb) * WH_C * 128);
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
-              acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], pf[m], acc[m][nf], 0, 0, 0);
-        }
-      }
-    }
-
-    if constexpr (EXO) {
-      // the exogenous channel's taps: lane (column frow, channel groups kq 8 ..
-      // and 32 + kq 8 ..) x rows m, straight into the accumulators
-      const float* E = reinterpret_cast<const float*>(smem + W_EXO_OFF);
-      const float* WE = reinterpret_cast<const float*>(smem + W_WE_OFF);
-#pragma unroll 1
-      for (int tb = 0; tb < 3; ++tb) {
-#pragma unroll
-        for (int tc = 0; tc < 3; ++tc) {
-          const float* wt = WE + (tb * 3 + tc) * 64 + kq * 8;
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
-          const f32x4 w2 = *reinterpret_cast<const f32x4*>(wt + 32), w3 = *reinterpret_cast<const f32x4*>(wt + 36);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const float ev = E[(w_img * WH_R + w_row + m + tb) * WH_C + frow + tc];
-            acc[m][0] += w0 * ev; acc[m][1 % NF] += w1 * ev;
-            acc[m][2 % NF] += w2 * ev; acc[m][3 % NF] += w3 * ev;
-          }
-        }
-      }
-    }
-
-    // ---- halo hand-over BEFORE the epilogue, behind raw barriers.  The wait for
-    // the prefetched loads is a vmcnt wait and on gfx9 stores count in vmcnt too
-    // (as does the vmcnt(0) inside __syncthreads()): in this order the loads have
-    // had the whole tap loop to arrive and the output stores are issued after the
-    // hand-over, free to drain under the next tile's taps.  Only LDS is handed
-    // over: every wave's fragment reads are back (lgkmcnt) before the first
-    // barrier, the ds_writes of the new halo before the second.
-    // Measured (tools/dbg/ws_scaling.py, option MFMA_DBG ablations, 16 tiles per
-    // CU): read-only 3.8 us per tile (5.5 TB/s), write-only 3.3 us (5.0 TB/s), tap
-    // loop 3.0 us, everything 10.4 - 10.7 us with either barrier order — the loop
-    // moves 145 KB per tile and CU, 3.5 TB/s of mixed read + write traffic in
-    // aggregate: the steady state is the HBM side of the ridge, not the MFMAs.
-    if (has_next) {
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      WS_COMMIT();
-      WS_ECOMMIT();
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-
-    // ---- epilogue from registers: lane (position column frow, channel
-    // group kq): rows m, halves h -> 8 consecutive channels, one 16-B store
-    {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int r = r0 + w_row + m;
-        if (!pos_ok || r >= Ho || (g.dbg & 4)) continue;
-        if constexpr (NF == 1) {
-          // lane (column frow, kq): channels 4 kq .. 4 kq + 3 of C_out <= 16, fp32
-          float* yo = reinterpret_cast<float*>(yv) + (((size_t)im * g.H + r) * g.W + c) * g.Cout;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int co = kq * 4 + e;
-            const float v = acc[m][0][e];
-            if (co < g.Cout) yo[co] = v > 0.f ? v : slope * v;
-          }
-          continue;
-        }
-#pragma unroll
-        for (int h = 0; h < (NF == 4 ? 2 : 0); ++h) {
-          const int co = ct * 64 + h * 32 + kq * 8;
-          if (co >= g.Cout) continue;
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = acc[m][(2 * h) % NF][e]; v[4 + e] = acc[m][(2 * h + 1) % NF][e]; }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
-          size_t dst;
-          if (g.b == 1) {
-            dst = (((size_t)im * Ho + r) * Wo + c) * g.Cout + co;
-          } else {
-            const int blk = co / g.cpo, cc = co % g.cpo;
-            dst = (((size_t)im * (g.H * g.b) + r * g.b + blk / g.b) * (g.W * g.b) + c * g.b + blk % g.b) *
-                      g.cpo + cc;
-          }
-          if (res) {
-            const uint4 q4 = rr[m][h];
-            v[0] += ws_lo(q4.x); v[1] += ws_hi(q4.x); v[2] += ws_lo(q4.y); v[3] += ws_hi(q4.y);
-            v[4] += ws_lo(q4.z); v[5] += ws_hi(q4.z); v[6] += ws_lo(q4.w); v[7] += ws_hi(q4.w);
-          }
-          if (res2) {
-            // (d2s == 1; the sum of the first skip is rounded to bf16 first, as
-            // the separate add of two bf16 tensors saw it)
-            uint4 o1;
-            o1.x = ws_pk(v[0], v[1]); o1.y = ws_pk(v[2], v[3]); o1.z = ws_pk(v[4], v[5]); o1.w = ws_pk(v[6], v[7]);
-            const uint4 q4 = *reinterpret_cast<const uint4*>(res2 + dst);
-            v[0] = ws_lo(o1.x) + ws_lo(q4.x); v[1] = ws_hi(o1.x) + ws_hi(q4.x);
-            v[2] = ws_lo(o1.y) + ws_lo(q4.y); v[3] = ws_hi(o1.y) + ws_hi(q4.y);
-            v[4] = ws_lo(o1.z) + ws_lo(q4.z); v[5] = ws_hi(o1.z) + ws_hi(q4.z);
-            v[6] = ws_lo(o1.w) + ws_lo(q4.w); v[7] = ws_hi(o1.w) + ws_hi(q4.w);
-          }
-          uint4 o;
-          o.x = ws_pk(v[0], v[1]); o.y = ws_pk(v[2], v[3]); o.z = ws_pk(v[4], v[5]); o.w = ws_pk(v[6], v[7]);
-          *reinterpret_cast<uint4*>(y + dst) = o;
-        }
-      }
-    }
-    if (!has_next) break;
-    ++t_cur;
+  for (int h = 0; h < 2; ++h) {
+    const int co_raw = ct * 64 + h * 32 + kq * 8;
+    ch_ok[h] = co_raw < g.Cout;
+    const int co = co_raw > g.Cout - 8 ? (g.Cout >= 8 ? g.Cout - 8 : 0) : co_raw;
+    const int blk = co / g.cpo, cq = co % g.cpo;
+    off_h[h] = (unsigned)(blk / g.b) * rsd + (unsigned)((blk % g.b) * g.cpo + cq);
   }
+
+  for (; t_cur + 1 < t_end; ++t_cur) {
+#define WS_HAS_NEXT 1
+#include "conv2d_ws_tile.inc"
+#undef WS_HAS_NEXT
+  }
+#define WS_HAS_NEXT 0
+#include "conv2d_ws_tile.inc"
+#undef WS_HAS_NEXT
 }
 
 #undef WS_EFETCH
@@ -526,6 +416,10 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel<4, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_EXO));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel<4, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel<4, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_EXO));
     attr_set = true;
   }
   WsGeom w;
@@ -549,14 +443,13 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
     hipLaunchKernelGGL(conv2d_ws_kernel<1>, dim3(gx, 1), dim3(W_NT), W_LDS, ctx->stream, (const unsigned short*)x,
                        (const char*)image, bias, (const unsigned short*)nullptr, y, w, (const float*)nullptr,
                        (const unsigned short*)nullptr);
-  else if (g.w_cin)
-    hipLaunchKernelGGL((conv2d_ws_kernel<4, true>), dim3(gx, n_ct), dim3(W_NT), W_LDS_EXO, ctx->stream,
-                       (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res, y, w, g.exo,
-                       (const unsigned short*)g.res2);
-  else
-    hipLaunchKernelGGL(conv2d_ws_kernel<4>, dim3(gx, n_ct), dim3(W_NT), W_LDS, ctx->stream,
+  else {
+    auto kern = g.w_cin ? (res ? conv2d_ws_kernel<4, true, true> : conv2d_ws_kernel<4, true, false>)
+                        : (res ? conv2d_ws_kernel<4, false, true> : conv2d_ws_kernel<4, false, false>);
+    hipLaunchKernelGGL(kern, dim3(gx, n_ct), dim3(W_NT), g.w_cin ? W_LDS_EXO : W_LDS, ctx->stream,
                        (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res, y, w,
-                       (const float*)nullptr, (const unsigned short*)g.res2);
+                       g.w_cin ? g.exo : (const float*)nullptr, (const unsigned short*)g.res2);
+  }
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
