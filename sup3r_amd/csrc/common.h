@@ -69,6 +69,7 @@
   X(NO_ADD16) \
   X(NO_WS_EXO) \
   X(NO_WS_RES2) \
+  X(NO_WS_PP) \
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \

@@ -337,6 +337,343 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_kernel(
 #undef WS_COMMIT
 #undef WS_COMMIT1
 
+// ---------------------------------------------------------------------------
+// Ping-pong form of the trunk conv (64 output channels per workgroup, bf16
+// cells out, no exogenous channel).
+//
+// Why.  In conv2d_ws_kernel all eight waves walk the same phases together:
+// prefetch issue, taps, hand-over, epilogue.  Ablations of that kernel at 16
+// tiles per CU (tools/dbg/ws_scaling.py, MFMA_DBG): the tap loop alone is 4.6 us
+// per 2-image tile (the MFMA pipes' time: 288 MFMAs x 2 waves per SIMD), the
+// prefetch adds 1.4 - 1.8 us, the output stores 1.1 us, hand-over + index
+// arithmetic 2.7 us, and the whole tile is the SUM, 11.3 us: a wave issues in
+// order, so the 96 + 64 vector-memory instructions of a tile (~16 clocks each
+// through the CU's one address unit), the 96 ds_write_b128 of the hand-over and
+// the vector-ALU work all sit between two tap loops, with the matrix cores idle
+// (41 % busy).  Removing waits or instructions from those phases moves little
+// (see conv2d_ws_tile.inc); what helps is other waves running MFMAs meanwhile.
+//
+// How.  The two images of a tile were already independent (waves 0-3 / 4-7,
+// separate halves of the LDS halo).  Here each half-workgroup ("group") owns
+// its own list of single-image tiles and the groups run half a period apart:
+//
+//   group 0:  T0 | M0 | T1 | M1 | ...          T = the 9-tap MFMA loop of a tile
+//   group 1:     | T0 | M0 | T1 | M1 | ...     M = hand-over of the next halo, epilogue +
+//                                                  stores of this tile, prefetch issue
+//
+// with ONE workgroup barrier per phase (a group's halo is read in its T and
+// rewritten in its M, always a barrier apart; the filter image is read-only).
+// While one group's wave holds a SIMD's matrix core, the other group's wave on
+// that SIMD issues memory / LDS / vector-ALU instructions.
+//
+// All global loads are hand-ordered (asm volatile, invisible to the compiler's
+// waitcnt pass, as in kernels_conv_mfma_persist.hip): prefetch registers are
+// written in one M phase and read two phases later behind ONE explicit
+// s_waitcnt vmcnt(0) at the top of that M — where everything outstanding (that
+// prefetch, the skip rows fetched at the top of T, the previous M's stores) is
+// at least a phase old.  tests/test_abi.py checks the compiled kernel for
+// scratch use and for any touch of an in-flight register.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline u32x4 pp_ld16(const void* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+constexpr int PH_BYTES = WH_R * WH_C * 128;     // 41,472: one image's halo
+
+#define PP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <bool RES>
+__global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
+    const unsigned short* __restrict__ x, const char* __restrict__ wimg, const float* __restrict__ bias,
+    const unsigned short* __restrict__ res, unsigned short* __restrict__ y, WsGeom g,
+    const unsigned short* __restrict__ res2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                 // half-workgroup: waves 0-3 / 4-7
+  const int gt = tid & 255;                  // thread within the group
+  const int ct = blockIdx.y;
+  const int frow = lane & 15, kq = lane >> 4;
+
+  // ---- this workgroup's run of SINGLE-image tiles, XCD-major (conv2d_ws_kernel);
+  // group g takes tiles t0 + g, t0 + g + 2, ..: the groups work on neighbours
+  const int T = g.N * g.tiles_r * g.tiles_c;
+  int rank;
+  {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int o = (int)((blockIdx.y * gridDim.x) & 7);
+    const int xcd = (b + o) & 7;
+    rank = 0;
+    for (int k = 0; k < ((xcd - o) & 7); ++k) rank += (nb - k + 7) / 8;
+    rank += (b - ((xcd - o) & 7)) / 8;
+  }
+  const int t0 = (int)(((long long)rank * T) / gridDim.x);
+  const int t1 = (int)(((long long)(rank + 1) * T) / gridDim.x);
+  if (t0 >= t1) return;
+  const int n_g = (t1 - t0 - grp + 1) / 2;   // this group's tiles
+  const int n_max = (t1 - t0 + 1) / 2;       // group 0's (>= group 1's)
+  auto tile_org = [&](int t, int& im, int& r0, int& c0) __attribute__((always_inline)) {
+    c0 = (t % g.tiles_c) * WT_C; t /= g.tiles_c;
+    r0 = (t % g.tiles_r) * WT_R;
+    im = t / g.tiles_r;
+  };
+
+  uint4 wimg_r[9];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(wimg + (size_t)ct * 9 * 8192);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wimg_r[q] = src[tid + q * W_NT];
+  }
+
+  // ---- lane -> halo chunk of the group's 18 x 18 cells x 8 chunks = 2592 = 10.1 x 256:
+  //   trips 0 .. 8: rows 2 q + (gt >> 7), columns 0 .. 15   (column (gt >> 3) & 15)
+  //   trip 9:       rows 0 .. 15 (gt >> 4), columns 16, 17   (column 16 + ((gt >> 3) & 1))
+  //   trip 10:      rows 16, 17, columns 16, 17 — 32 lanes; the others shadow lane gt & 31
+  // so that a lane has two columns per tile (reflect / clamp / zero flag once each)
+  const int hcA = (gt >> 3) & 15, hcB = 16 + ((gt >> 3) & 1);
+  const unsigned gb = (unsigned)(grp * PH_BYTES);
+  const unsigned ldsA = gb + (unsigned)(((gt >> 7) * WH_C + hcA) * 128 + (((gt & 7) ^ (hcA & 7)) << 4));
+  const unsigned ldsB = gb + (unsigned)(((gt >> 4) * WH_C + hcB) * 128 + (((gt & 7) ^ (hcB & 7)) << 4));
+  const unsigned ldsC = gb + (unsigned)(((16 + ((gt & 31) >> 4)) * WH_C + hcB) * 128 + (((gt & 7) ^ (hcB & 7)) << 4));
+  u32x4 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10;
+  unsigned zmask = 0u;   // bit q: chunk q lies on the frame's zero boundary
+#define PP_COL(HC, COLEL, ZC)                                                                   \
+    unsigned COLEL;                                                                             \
+    bool ZC;                                                                                    \
+    {                                                                                           \
+      const int cv_ = c0_ + (HC) - 1 - g.frame;                                                 \
+      int c_ = g.frame ? cv_ : s3_reflect(cv_, g.W);                                            \
+      ZC = g.frame && (cv_ < 0 || cv_ >= g.W);                                                  \
+      c_ = c_ < 0 ? 0 : (c_ > g.W - 1 ? g.W - 1 : c_);                                          \
+      COLEL = (unsigned)c_ * 64 + (gt & 7) * 8;                                                 \
+    }
+#define PP_FETCH1(P, q, HR, COLEL, ZC)                                                          \
+  {                                                                                             \
+    const int rv_ = r0_ + (HR) - 1 - g.frame;                                                   \
+    int r_ = g.frame ? rv_ : s3_reflect(rv_, g.H);                                              \
+    const bool z_ = (ZC) || (g.frame && (rv_ < 0 || rv_ >= g.H));                               \
+    r_ = r_ < 0 ? 0 : (r_ > g.H - 1 ? g.H - 1 : r_);                                            \
+    const unsigned rowcell_ = ((unsigned)im_ * g.H + r_) * g.W;   /* < 2^31 */                  \
+    P = pp_ld16(x + (size_t)rowcell_ * 64 + COLEL);                                             \
+    zmask |= z_ ? (1u << q) : 0u;                                                               \
+  }
+#define PP_FETCH(T_)                                                                            \
+  {                                                                                             \
+    int im_, r0_, c0_;                                                                          \
+    tile_org((T_), im_, r0_, c0_);                                                              \
+    PP_COL(hcA, colA_, zcA_)                                                                    \
+    PP_COL(hcB, colB_, zcB_)                                                                    \
+    const int jr_ = gt >> 7;                                                                    \
+    zmask = 0u;                                                                                 \
+    PP_FETCH1(p0, 0, 0 + jr_, colA_, zcA_) PP_FETCH1(p1, 1, 2 + jr_, colA_, zcA_)               \
+    PP_FETCH1(p2, 2, 4 + jr_, colA_, zcA_) PP_FETCH1(p3, 3, 6 + jr_, colA_, zcA_)               \
+    PP_FETCH1(p4, 4, 8 + jr_, colA_, zcA_) PP_FETCH1(p5, 5, 10 + jr_, colA_, zcA_)              \
+    PP_FETCH1(p6, 6, 12 + jr_, colA_, zcA_) PP_FETCH1(p7, 7, 14 + jr_, colA_, zcA_)             \
+    PP_FETCH1(p8, 8, 16 + jr_, colA_, zcA_)                                                     \
+    PP_FETCH1(p9, 9, gt >> 4, colB_, zcB_)                                                      \
+    PP_FETCH1(p10, 10, 16 + ((gt & 31) >> 4), colB_, zcB_)                                      \
+  }
+#define PP_SEL(P, q) (((zmask >> q) & 1u) ? (u32x4){0u, 0u, 0u, 0u} : P)
+#define PP_COMMIT()                                                                             \
+  {                                                                                             \
+    *reinterpret_cast<u32x4*>(smem + ldsA + 0 * 2 * WH_C * 128) = PP_SEL(p0, 0);                \
+    *reinterpret_cast<u32x4*>(smem + ldsA + 1 * 2 * WH_C * 128) = PP_SEL(p1, 1);                \
+    *reinterpret_cast<u32x4*>(smem + ldsA + 2 * 2 * WH_C * 128) = PP_SEL(p2, 2);                \
+    *reinterpret_cast<u32x4*>(smem + ldsA + 3 * 2 * WH_C * 128) = PP_SEL(p3, 3);                \
+    *reinterpret_cast<u32x4*>(smem + ldsA + 4 * 2 * WH_C * 128) = PP_SEL(p4, 4);                \
+    *reinterpret_cast<u32x4*>(smem + ldsA + 5 * 2 * WH_C * 128) = PP_SEL(p5, 5);                \
+    *reinterpret_cast<u32x4*>(smem + ldsA + 6 * 2 * WH_C * 128) = PP_SEL(p6, 6);                \
+    *reinterpret_cast<u32x4*>(smem + ldsA + 7 * 2 * WH_C * 128) = PP_SEL(p7, 7);                \
+    *reinterpret_cast<u32x4*>(smem + ldsA + 8 * 2 * WH_C * 128) = PP_SEL(p8, 8);                \
+    *reinterpret_cast<u32x4*>(smem + ldsB) = PP_SEL(p9, 9);                                     \
+    *reinterpret_cast<u32x4*>(smem + ldsC) = PP_SEL(p10, 10);                                   \
+  }
+  // everything outstanding has landed; the "+v" operands pin every later use of
+  // the prefetch / skip registers behind this statement (volatile asm keeps
+  // program order with the loads above and with the barriers)
+#define PP_WAIT_P()                                                                             \
+  asm volatile("s_waitcnt vmcnt(0)"                                                             \
+               : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6),          \
+                 "+v"(p7), "+v"(p8), "+v"(p9), "+v"(p10)                                        \
+               :: "memory")
+#define PP_WAIT_ALL()                                                                           \
+  {                                                                                             \
+    PP_WAIT_P();                                                                                \
+    if constexpr (RES)                                                                          \
+      asm volatile("" : "+v"(rr[0][0]), "+v"(rr[0][1]), "+v"(rr[1][0]), "+v"(rr[1][1]),         \
+                        "+v"(rr[2][0]), "+v"(rr[2][1]), "+v"(rr[3][0]), "+v"(rr[3][1])          \
+                   :: "memory");                                                                \
+  }
+
+  u32x4 rr[4][2];
+
+  // ---- prologue: filter image + biases (all waves), each group's first halo,
+  // the prefetch of its second
+  // (a group without a tile — group 1 of a one-tile run — fetches group 0's: no
+  // conditional definition of the prefetch registers)
+  PP_FETCH(t0 + (n_g > 0 ? grp : 0));
+  {
+    uint4* dst = reinterpret_cast<uint4*>(smem + W_SLAB_OFF);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dst[tid + q * W_NT] = wimg_r[q];
+    if (tid < 64) {
+      const int co = ct * 64 + tid;
+      reinterpret_cast<float*>(smem + W_BIAS_OFF)[tid] = (bias && co < g.Cout) ? bias[co] : 0.f;
+    }
+  }
+  PP_WAIT_P();
+  PP_COMMIT();
+  if (n_g > 1) PP_FETCH(t0 + grp + 2);
+  PP_BARRIER();
+
+  // ---- fragment addresses (conv2d_ws_kernel): wave w of the group = rows 4 (w & 3) .. + 3
+  const int w_row = (wave & 3) * 4;
+  unsigned p_addr[3][2], f_addr[2];
+#pragma unroll
+  for (int tc = 0; tc < 3; ++tc)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      p_addr[tc][ks] = gb + (unsigned)((w_row * WH_C + frow + tc) * 128 + (((ks * 4 + kq) ^ ((frow + tc) & 7)) << 4));
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    f_addr[ks] = (unsigned)(W_SLAB_OFF + frow * 128 + (((ks * 4 + kq) ^ ((frow >> 1) & 7)) << 4));
+  const float* bl = reinterpret_cast<const float*>(smem + W_BIAS_OFF);
+  const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
+  // output addressing as in conv2d_ws_kernel: im IS + r RS + c CS + off_h[h]
+  const int Ho = g.H + 2 * g.frame, Wo = g.W + 2 * g.frame;
+  const unsigned rsd = (unsigned)(Wo * g.b * g.cpo);
+  const unsigned long long IS = (unsigned long long)(Ho * g.b) * rsd;
+  const unsigned RS = (unsigned)g.b * rsd, CS = (unsigned)(g.b * g.cpo);
+  unsigned off_h[2];
+  bool ch_ok[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int co_raw = ct * 64 + h * 32 + kq * 8;
+    ch_ok[h] = co_raw < g.Cout;
+    const int co = co_raw > g.Cout - 8 ? (g.Cout >= 8 ? g.Cout - 8 : 0) : co_raw;
+    const int blk = co / g.cpo, cq = co % g.cpo;
+    off_h[h] = (unsigned)(blk / g.b) * rsd + (unsigned)((blk % g.b) * g.cpo + cq);
+  }
+
+  f32x4 acc[4][4];
+  if (grp == 1) PP_BARRIER();      // half a period behind group 0
+#pragma unroll 1
+  for (int k = 0; k < n_max; ++k) {
+    if (k >= n_g) {     // (group 1 of an odd run: keeps the barrier count)
+      PP_BARRIER();
+      PP_BARRIER();
+      continue;
+    }
+    int im, r0, c0;
+    tile_org(t0 + grp + 2 * k, im, r0, c0);
+    const int c = c0 + frow;
+    const bool col_ok = c < Wo;
+    const int cc = c > Wo - 1 ? Wo - 1 : c;
+    const unsigned long long tbase = (unsigned long long)im * IS + (unsigned long long)((unsigned)cc * CS);
+
+    // =========================================================== T phase
+    {
+      if constexpr (RES) {
+        // this tile's skip rows (d2s == 1, no frame: the output's layout), under the taps
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          int r = r0 + w_row + m;
+          r = r > Ho - 1 ? Ho - 1 : r;
+          const unsigned long long ridx = tbase + (unsigned long long)(unsigned)r * RS;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) rr[m][h] = pp_ld16(res + ridx + off_h[h]);
+        }
+      }
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const int cb = (nf >> 1) * 32 + kq * 8 + (nf & 1) * 4;
+        const f32x4 b4 = {bl[cb], bl[cb + 1], bl[cb + 2], bl[cb + 3]};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][nf] = b4;
+      }
+#pragma unroll 1
+      for (int tb = 0; tb < 3; ++tb) {
+#pragma unroll
+        for (int tc = 0; tc < 3; ++tc) {
+          const int tap = tb * 3 + tc;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 wf[4], pf[4];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+              wf[nf] = *reinterpret_cast<const bf16x8*>(smem + f_addr[ks] + nf * 2048 + tap * 8192);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              pf[m] = *reinterpret_cast<const bf16x8*>(smem + p_addr[tc][ks] + (m + tb) * WH_C * 128);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+              for (int nf = 0; nf < 4; ++nf)
+                acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], pf[m], acc[m][nf], 0, 0, 0);
+          }
+        }
+      }
+    }
+    PP_BARRIER();
+
+    // =========================================================== M phase
+    {
+      PP_WAIT_ALL();
+      if (k + 1 < n_g) PP_COMMIT();
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int r = r0 + w_row + m;
+        const bool row_ok = col_ok && r < Ho;
+        const int rc = r > Ho - 1 ? Ho - 1 : r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = acc[m][2 * h][e]; v[4 + e] = acc[m][2 * h + 1][e]; }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float sa = slope * v[e];
+            asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(sa));
+          }
+          const unsigned long long dst = tbase + (unsigned long long)(unsigned)rc * RS + off_h[h];
+          if constexpr (RES) {
+            const u32x4 q4 = rr[m][h];
+            v[0] += ws_lo(q4[0]); v[1] += ws_hi(q4[0]); v[2] += ws_lo(q4[1]); v[3] += ws_hi(q4[1]);
+            v[4] += ws_lo(q4[2]); v[5] += ws_hi(q4[2]); v[6] += ws_lo(q4[3]); v[7] += ws_hi(q4[3]);
+          }
+          if (res2) {
+            // (d2s == 1; the sum of the first skip is rounded to bf16 first, as
+            // the separate add of two bf16 tensors saw it)
+            uint4 o1;
+            o1.x = ws_pk(v[0], v[1]); o1.y = ws_pk(v[2], v[3]); o1.z = ws_pk(v[4], v[5]); o1.w = ws_pk(v[6], v[7]);
+            const uint4 q4 = *reinterpret_cast<const uint4*>(res2 + dst);
+            v[0] = ws_lo(o1.x) + ws_lo(q4.x); v[1] = ws_hi(o1.x) + ws_hi(q4.x);
+            v[2] = ws_lo(o1.y) + ws_lo(q4.y); v[3] = ws_hi(o1.y) + ws_hi(q4.y);
+            v[4] = ws_lo(o1.z) + ws_lo(q4.z); v[5] = ws_hi(o1.z) + ws_hi(q4.z);
+            v[6] = ws_lo(o1.w) + ws_lo(q4.w); v[7] = ws_hi(o1.w) + ws_hi(q4.w);
+          }
+          uint4 o;
+          o.x = ws_pk(v[0], v[1]); o.y = ws_pk(v[2], v[3]); o.z = ws_pk(v[4], v[5]); o.w = ws_pk(v[6], v[7]);
+          if (row_ok && ch_ok[h]) *reinterpret_cast<uint4*>(y + dst) = o;
+        }
+      }
+      if (k + 2 < n_g) PP_FETCH(t0 + grp + 2 * (k + 2));
+    }
+    PP_BARRIER();
+  }
+  if (grp == 0) PP_BARRIER();
+}
+#undef PP_WAIT_ALL
+#undef PP_WAIT_P
+#undef PP_COMMIT
+#undef PP_SEL
+#undef PP_FETCH
+#undef PP_FETCH1
+#undef PP_COL
+#undef PP_BARRIER
+
 }  // namespace
 
 // physical geometry of a 2-D conv: (N, s1, s2, 1, C), k = (3, 3, 1)
@@ -420,6 +757,10 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel<4, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_EXO));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_pp_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+    S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_pp_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
     attr_set = true;
   }
   WsGeom w;
@@ -443,7 +784,17 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
     hipLaunchKernelGGL(conv2d_ws_kernel<1>, dim3(gx, 1), dim3(W_NT), W_LDS, ctx->stream, (const unsigned short*)x,
                        (const char*)image, bias, (const unsigned short*)nullptr, y, w, (const float*)nullptr,
                        (const unsigned short*)nullptr);
-  else {
+  else if (!g.w_cin && !s3_opt_on(S3O_NO_WS_PP)) {
+    // the ping-pong form: single-image tiles, two half-workgroups half a period apart
+    const int T1 = g.N * w.tiles_r * w.tiles_c;
+    int gp = (ctx->num_cu + n_ct - 1) / n_ct;
+    if (gp > (T1 + 1) / 2) gp = (T1 + 1) / 2;
+    if (gp < 1) gp = 1;
+    auto kern = res ? conv2d_ws_pp_kernel<true> : conv2d_ws_pp_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(gp, n_ct), dim3(W_NT), W_LDS, ctx->stream, (const unsigned short*)x,
+                       (const char*)image, bias, (const unsigned short*)res, (unsigned short*)y, w,
+                       (const unsigned short*)g.res2);
+  } else {
     auto kern = g.w_cin ? (res ? conv2d_ws_kernel<4, true, true> : conv2d_ws_kernel<4, true, false>)
                         : (res ? conv2d_ws_kernel<4, false, true> : conv2d_ws_kernel<4, false, false>);
     hipLaunchKernelGGL(kern, dim3(gx, n_ct), dim3(W_NT), g.w_cin ? W_LDS_EXO : W_LDS, ctx->stream,

@@ -1,10 +1,9 @@
 #!/bin/bash
-# one gpurun call: ws kernel parity tests + scaling probe (+ ablations) + fwd2d bench
+# one gpurun call: ws kernel parity tests + same-box A/B + fwd2d bench
 mkdir -p gpurun_out/r5b
-timeout 900 python -m pytest tests/test_mfma_gen.py tests/test_forward_pass_gpu.py tests/test_ref_surface.py -m gpu -x -q > gpurun_out/r5b/tests_ws.log 2>&1
+timeout 600 python -m pytest tests/test_mfma_gen.py tests/test_forward_pass_gpu.py tests/test_ref_surface.py -m gpu -x -q > gpurun_out/r5b/tests_ws.log 2>&1
 tail -5 gpurun_out/r5b/tests_ws.log
-timeout 300 python tools/dbg/ws_scaling.py MFMA_DBG=7 MFMA_DBG=5 MFMA_DBG=6 MFMA_DBG=3 2>&1 | grep -v amdgpu.ids > gpurun_out/r5b/ws_ablate.log
-cat gpurun_out/r5b/ws_ablate.log
+timeout 300 bash tools/dbg/ws_ab.sh tools/ab/ws_head.so sup3r_amd/lib/libsup3r_hip.so 2>&1 | tee gpurun_out/r5b/ws_ab.log
 timeout 300 python tools/dbg/ws_scaling.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r5b/ws_scaling.log
 cat gpurun_out/r5b/ws_scaling.log
 timeout 600 python bench.py --mode fwd2d > gpurun_out/r5b/fwd2d.json 2> gpurun_out/r5b/fwd2d.err
