@@ -449,31 +449,34 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
       c_ = c_ < 0 ? 0 : (c_ > g.W - 1 ? g.W - 1 : c_);                                          \
       COLEL = (unsigned)c_ * 64 + (gt & 7) * 8;                                                 \
     }
-#define PP_FETCH1(P, q, HR, COLEL, ZC)                                                          \
-  {                                                                                             \
-    const int rv_ = r0_ + (HR) - 1 - g.frame;                                                   \
-    int r_ = g.frame ? rv_ : s3_reflect(rv_, g.H);                                              \
-    const bool z_ = (ZC) || (g.frame && (rv_ < 0 || rv_ >= g.H));                               \
-    r_ = r_ < 0 ? 0 : (r_ > g.H - 1 ? g.H - 1 : r_);                                            \
-    const unsigned rowcell_ = ((unsigned)im_ * g.H + r_) * g.W;   /* < 2^31 */                  \
-    P = pp_ld16(x + (size_t)rowcell_ * 64 + COLEL);                                             \
-    zmask |= z_ ? (1u << q) : 0u;                                                               \
-  }
-#define PP_FETCH(T_)                                                                            \
-  {                                                                                             \
+// address of trip q's chunk (and its zero flag into zmask); the load itself is PP_LOADQ
+#define PP_ADDRQ(q)                                                                             \
+    const unsigned short* a##q##_;                                                              \
+    {                                                                                           \
+      const int hr_ = (q) <= 8 ? 2 * (q) + jr_ : ((q) == 9 ? (gt >> 4) : 16 + ((gt & 31) >> 4)); \
+      const int rv_ = r0_ + hr_ - 1 - g.frame;                                                  \
+      int r_ = g.frame ? rv_ : s3_reflect(rv_, g.H);                                            \
+      const bool z_ = ((q) <= 8 ? zcA_ : zcB_) || (g.frame && (rv_ < 0 || rv_ >= g.H));        \
+      r_ = r_ < 0 ? 0 : (r_ > g.H - 1 ? g.H - 1 : r_);                                          \
+      const unsigned rowcell_ = ((unsigned)im_ * g.H + r_) * g.W;   /* < 2^31 */                \
+      a##q##_ = x + (size_t)rowcell_ * 64 + ((q) <= 8 ? colA_ : colB_);                         \
+      zmask |= z_ ? (1u << (q)) : 0u;                                                           \
+    }
+#define PP_LOADQ(q) p##q = pp_ld16(a##q##_);
+#define PP_TRIP(q) { PP_ADDRQ(q) PP_LOADQ(q) }
+// per-tile part of a prefetch: origin, the lane's two columns (declares im_, r0_, colA_, ..)
+#define PP_FETCH_PREP(T_)                                                                       \
     int im_, r0_, c0_;                                                                          \
     tile_org((T_), im_, r0_, c0_);                                                              \
     PP_COL(hcA, colA_, zcA_)                                                                    \
     PP_COL(hcB, colB_, zcB_)                                                                    \
     const int jr_ = gt >> 7;                                                                    \
-    zmask = 0u;                                                                                 \
-    PP_FETCH1(p0, 0, 0 + jr_, colA_, zcA_) PP_FETCH1(p1, 1, 2 + jr_, colA_, zcA_)               \
-    PP_FETCH1(p2, 2, 4 + jr_, colA_, zcA_) PP_FETCH1(p3, 3, 6 + jr_, colA_, zcA_)               \
-    PP_FETCH1(p4, 4, 8 + jr_, colA_, zcA_) PP_FETCH1(p5, 5, 10 + jr_, colA_, zcA_)              \
-    PP_FETCH1(p6, 6, 12 + jr_, colA_, zcA_) PP_FETCH1(p7, 7, 14 + jr_, colA_, zcA_)             \
-    PP_FETCH1(p8, 8, 16 + jr_, colA_, zcA_)                                                     \
-    PP_FETCH1(p9, 9, gt >> 4, colB_, zcB_)                                                      \
-    PP_FETCH1(p10, 10, 16 + ((gt & 31) >> 4), colB_, zcB_)                                      \
+    zmask = 0u;
+#define PP_FETCH(T_)                                                                            \
+  {                                                                                             \
+    PP_FETCH_PREP(T_)                                                                           \
+    PP_TRIP(0) PP_TRIP(1) PP_TRIP(2) PP_TRIP(3) PP_TRIP(4) PP_TRIP(5) PP_TRIP(6) PP_TRIP(7)     \
+    PP_TRIP(8) PP_TRIP(9) PP_TRIP(10)                                                           \
   }
 #define PP_SEL(P, q) (((zmask >> q) & 1u) ? (u32x4){0u, 0u, 0u, 0u} : P)
 #define PP_COMMIT()                                                                             \
@@ -539,6 +542,9 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
     f_addr[ks] = (unsigned)(W_SLAB_OFF + frow * 128 + (((ks * 4 + kq) ^ ((frow >> 1) & 7)) << 4));
+  // (opaque to the compiler: with the constant W_SLAB_OFF visible it splits it off and re-adds
+  // it per fragment — four v_add per step — instead of using the ds_read offset field)
+  asm volatile("" : "+v"(f_addr[0]), "+v"(f_addr[1]));
   const float* bl = reinterpret_cast<const float*>(smem + W_BIAS_OFF);
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
   // output addressing as in conv2d_ws_kernel: im IS + r RS + c CS + off_h[h]
@@ -593,27 +599,54 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m][nf] = b4;
       }
-#pragma unroll 1
-      for (int tb = 0; tb < 3; ++tb) {
-#pragma unroll
-        for (int tc = 0; tc < 3; ++tc) {
-          const int tap = tb * 3 + tc;
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[4], pf[4];
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-              wf[nf] = *reinterpret_cast<const bf16x8*>(smem + f_addr[ks] + nf * 2048 + tap * 8192);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-              pf[m] = *reinterpret_cast<const bf16x8*>(smem + p_addr[tc][ks] + (m + tb) * WH_C * 128);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-              for (int nf = 0; nf < 4; ++nf)
-                acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], pf[m], acc[m][nf], 0, 0, 0);
-          }
+      // 18 steps (9 taps x 2 k-halves) of 8 fragment reads + 16 MFMAs, unrolled and scheduled
+      // BY HAND (sched_group_barrier): the fragments of step s + 1 are read during step s, one
+      // ds_read behind each of its first eight MFMAs.  (Left to itself the compiler reads a
+      // step's fragments right in front of its MFMAs, and issues them in one burst: with two
+      // waves per SIMD in the tap loop the other wave filled those gaps, here a SIMD's matrix
+      // core belongs to ONE wave during a T phase — 24 instead of 16 clocks per MFMA.)
+      // (Tried: the prefetch of the group's next tile inside this loop — the index arithmetic of
+      // one trip behind the last eight MFMAs of a step, its load behind the step: the T phase
+      // grows by 0.8 us, more than the M phase loses; the prefetch stays in M.)
+      if (!(g.dbg & 2)) {
+        bf16x8 wf[2][4], pf[2][4];
+#define PP_FRAGS(B, S)                                                                          \
+        {                                                                                       \
+          constexpr int tb_ = (S) / 6, tc_ = ((S) % 6) >> 1, ks_ = (S) & 1;                     \
+          _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                      \
+            wf[B][nf] = *reinterpret_cast<const bf16x8*>(smem + f_addr[ks_] + nf * 2048 + (tb_ * 3 + tc_) * 8192); \
+          _Pragma("unroll") for (int m = 0; m < 4; ++m)                                         \
+            pf[B][m] = *reinterpret_cast<const bf16x8*>(smem + p_addr[tc_][ks_] + (m + tb_) * WH_C * 128); \
         }
+#define PP_MFMAS(B)                                                                             \
+          _Pragma("unroll") for (int m = 0; m < 4; ++m)                                         \
+            _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                    \
+              acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[B][nf], pf[B][m], acc[m][nf], 0, 0, 0);
+#define PP_SCHED(NV)                                                                            \
+          _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                  \
+          }                                                                                     \
+          _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
+            if (NV) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                         \
+          }                                                                                     \
+          __builtin_amdgcn_sched_barrier(0);
+#define PP_STEP(S)                                                                              \
+        {                                                                                       \
+          if constexpr ((S) + 1 < 18) PP_FRAGS(((S) + 1) & 1, ((S) + 1 < 18 ? (S) + 1 : 0))     \
+          PP_MFMAS((S) & 1)                                                                     \
+          PP_SCHED(0)                                                                           \
+        }
+        __builtin_amdgcn_s_setprio(2);   // over the other group's wave on this SIMD (VALU issue: priority, then age)
+        PP_FRAGS(0, 0)
+        PP_STEP(0) PP_STEP(1) PP_STEP(2) PP_STEP(3) PP_STEP(4) PP_STEP(5) PP_STEP(6) PP_STEP(7) PP_STEP(8)
+        PP_STEP(9) PP_STEP(10) PP_STEP(11) PP_STEP(12) PP_STEP(13) PP_STEP(14) PP_STEP(15) PP_STEP(16) PP_STEP(17)
+        __builtin_amdgcn_s_setprio(0);
+#undef PP_STEP
+#undef PP_SCHED
+#undef PP_MFMAS
+#undef PP_FRAGS
       }
     }
     PP_BARRIER();
@@ -621,11 +654,12 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
     // =========================================================== M phase
     {
       PP_WAIT_ALL();
-      if (k + 1 < n_g) PP_COMMIT();
+      if (k + 1 < n_g && !(g.dbg & 8)) PP_COMMIT();
+      if (!(g.dbg & 16))
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int r = r0 + w_row + m;
-        const bool row_ok = col_ok && r < Ho;
+        const bool row_ok = col_ok && r < Ho && !(g.dbg & 4);
         const int rc = r > Ho - 1 ? Ho - 1 : r;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -659,7 +693,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
           if (row_ok && ch_ok[h]) *reinterpret_cast<uint4*>(y + dst) = o;
         }
       }
-      if (k + 2 < n_g) PP_FETCH(t0 + grp + 2 * (k + 2));
+      if (k + 2 < n_g && !(g.dbg & 1)) PP_FETCH(t0 + grp + 2 * (k + 2));
     }
     PP_BARRIER();
   }
@@ -670,7 +704,10 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
 #undef PP_COMMIT
 #undef PP_SEL
 #undef PP_FETCH
-#undef PP_FETCH1
+#undef PP_FETCH_PREP
+#undef PP_TRIP
+#undef PP_LOADQ
+#undef PP_ADDRQ
 #undef PP_COL
 #undef PP_BARRIER
 
