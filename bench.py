@@ -367,12 +367,14 @@ def fwd2d_leg(dev, steps=20, warmup=3, batch=48, seed=42):
         'whole_path_tflops': 2.0 * macs * steps / el / 1e12,
         'kernels': {k: sel.count(k) for k in sorted(set(k for k in sel if k))},
         'roofline': {
-            'kernel': 'conv2d_ws_kernel (Conv2D / Conv2DTranspose 64->64 3x3, '
-                      'reflect pad fused, weights-stationary persistent)',
+            'kernel': 'conv2d_ws_pp_kernel (Conv2D / Conv2DTranspose 64->64 3x3, '
+                      'reflect pad fused, weights-stationary persistent, two '
+                      'half-workgroups half a period apart)',
             # 288 FLOP per algorithmic byte: the ridge of the bf16 MFMA / HBM
-            # rooflines.  Ablations put the steady state on the
-            # HBM side: 3.5 TB/s of mixed read + write traffic, tap loop 3.0 of
-            # 10.5 us per tile
+            # rooflines.  Ablations: in steady state the phase
+            # that holds all the memory instructions (M) runs at 6.1 TB/s when
+            # alone — the copy rate of the chip — and the kernel at 4.5 TB/s of
+            # read + write traffic
             'bound': 'hbm', 'unit': 'GB/s',
             'achieved': bytes_conv / (t_ms * 1e-3) / 1e9,
             'peak': PEAK_HBM_GBS,
@@ -382,11 +384,11 @@ def fwd2d_leg(dev, steps=20, warmup=3, batch=48, seed=42):
             'algorithmic_bytes_per_launch': bytes_conv,
             'mfma_tflops': flop_conv / (t_ms * 1e-3) / 1e12,
             'mfma_frac': flop_conv / (t_ms * 1e-3) / 1e12 / PEAK_TFLOPS['bf16'],
-            'note': '600 tiles of 2 x 16 x 16 positions on 256 CUs (2.3 per '
-                    'CU: three rounds) at this shape; counter traffic per '
-                    'launch: profiles/r05/pmc_fwd2d.txt (95 MB vs 69 MB '
-                    'algorithmic: 18^2 / 16^2 halo overlap + 80^2 / 75^2 tile '
-                    'overhang)'}}
+            'note': '1200 single-image tiles of 16 x 16 positions on 256 CUs '
+                    '(4.7 per workgroup: three T/M periods + the prologue with '
+                    'the 72 KB filter image) at this shape, 0.44 of 8 TB/s at '
+                    '480 x 75 x 75; counter traffic per launch: '
+                    'profiles/r05/pmc_fwd2d.txt'}}
     del ph, net
     return res
 

@@ -811,8 +811,10 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
   w.tiles_r = (w.H + 2 * w.frame + WT_R - 1) / WT_R; w.tiles_c = (w.W + 2 * w.frame + WT_C - 1) / WT_C;
   const bool tail = conv2d_ws_tail_geom_ok(g);
   const int T = w.tiles_i * w.tiles_r * w.tiles_c, n_ct = (g.Cout + 63) / 64;
-  // ~one workgroup per CU over all output-channel tiles (each keeps ITS image)
-  int gx = (ctx->num_cu + n_ct - 1) / n_ct;
+  // at most one workgroup per CU over all output-channel tiles (each keeps ITS image; a
+  // workgroup fills a CU's LDS, so one more than there are CUs would run after the others:
+  // 25 channel tiles of the 64 -> 1600 conv x 11 = 275 workgroups was two rounds)
+  int gx = ctx->num_cu / n_ct;
   if (gx > T) gx = T;
   if (gx < 1) gx = 1;
   if (g.w_cin && !g.exo) S3_FAIL(ctx, S3_ESTATE, "conv2d_ws: the exogenous channel's field is not bound");
@@ -824,7 +826,7 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
   else if (!g.w_cin && !s3_opt_on(S3O_NO_WS_PP)) {
     // the ping-pong form: single-image tiles, two half-workgroups half a period apart
     const int T1 = g.N * w.tiles_r * w.tiles_c;
-    int gp = (ctx->num_cu + n_ct - 1) / n_ct;
+    int gp = ctx->num_cu / n_ct;
     if (gp > (T1 + 1) / 2) gp = (T1 + 1) / 2;
     if (gp < 1) gp = 1;
     auto kern = res ? conv2d_ws_pp_kernel<true> : conv2d_ws_pp_kernel<false>;

@@ -110,6 +110,28 @@ def test_persistent_kernel_has_no_scratch(tmp_path):
         assert scratch == 0 and spills == 0, (scratch, spills)
 
 
+def test_pingpong_conv2d_touches_no_inflight_register():
+    """conv2d_ws_pp_kernel issues every global load from ``asm volatile`` (the
+    compiler's waitcnt pass does not see them) and waits with one explicit
+    ``s_waitcnt vmcnt(0)`` per M phase.  ``tools/check_inflight.py`` walks the
+    control-flow graph of the compiled kernel: between a hand-ordered load and
+    the wait no instruction may mention its destination registers (a
+    register-allocator copy or a spill there would move a value that has not
+    arrived), and the kernel uses no scratch."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    root = os.path.join(os.path.dirname(__file__), '..')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_inflight.py')],
+                         capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HIPCC=hipcc))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert '2 kernels' in out.stdout and ' 0 problems' in out.stdout, out.stdout
+
+
 @pytest.mark.parametrize('rnd', ['r03', 'r04'])
 def test_profiles_table_regenerates(rnd):
     """``tools/pmc_table.py`` (the counter-bytes vs algorithmic-bytes table of
