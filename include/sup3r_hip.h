@@ -297,8 +297,10 @@ enum {
   S3_FWD_HALO_S2 = 10, /* C_in = 32 stride-2 valid conv on an LDS halo         */
   S3_FWD_MFMA_GEN = 11, /* halo-tile MFMA over logical axes: 2-D nets, few time steps,
                            any C_in <= 256 / C_out (kernels_conv_mfma_gen.hip)     */
-  S3_FWD_CONV2D_WS = 12 /* weights-stationary persistent Conv2D, all-bf16 64 -> 64 k
+  S3_FWD_CONV2D_WS = 12, /* weights-stationary persistent Conv2D, all-bf16 64 -> 64 k
                            trunks of the 2-D generators (kernels_conv2d_ws.hip)    */
+  S3_FWD_CONV2D_HEAD = 13 /* the few-feature head conv of those generators: C_in 1 / 2
+                           -> 64, fp32 field in, bf16 cells out, filter in registers */
 };
 enum {
   S3_WGRAD_DIRECT = 0, S3_WGRAD_F32_TRUNK = 1, S3_WGRAD_BF16_TRUNK = 2, S3_WGRAD_F32_GEN = 3,

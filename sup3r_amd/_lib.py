@@ -263,7 +263,7 @@ OPINFO_FIELDS = ('kind', 'fwd', 'in16', 'out16', 'res16', 'fwd_bf16_ops',
                  'dgrad_frame16', 'fewpos_mfma')
 FWD_KERNELS = ('direct', 'mfma_tile', 'mfma_persist', 'gconv', 'gconv_fewch',
                'halo32', 'fewpos', 'tail_mfma', 'small', 'fused2d', 'halo_s2',
-               'mfma_gen', 'conv2d_ws')
+               'mfma_gen', 'conv2d_ws', 'conv2d_head')
 WGRAD_KERNELS = ('direct', 'f32_trunk', 'bf16_trunk', 'f32_gen', 'bf16_gen',
                  'bf16_2d', 'c2', 'tail', 'fewpos')
 DGRAD_KERNELS = ('direct', 'mfma_frame', 'mfma_valid', 'mfma_chunked',

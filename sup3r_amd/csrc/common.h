@@ -70,6 +70,7 @@
   X(NO_WS_EXO) \
   X(NO_WS_RES2) \
   X(NO_WS_PP) \
+  X(NO_CONV2D_HEAD) \
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \
@@ -327,6 +328,12 @@ bool conv2d_ws_tail_geom_ok(const ConvGeom& g);   // 64 -> C_out <= 16 output co
 bool conv2d_ws_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);
 size_t conv2d_ws_image_bytes(const ConvGeom& g);
 int launch_conv2d_ws_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
+// ... and the few-feature head conv of those generators (C_in 1 / 2 -> 64, fp32 field in, bf16 out)
+bool conv2d_head_geom_ok(const ConvGeom& g);
+bool conv2d_head_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);
+size_t conv2d_head_image_bytes(const ConvGeom& g);
+int launch_conv2d_head_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
+int launch_conv2d_head(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias, void* y);
 int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias,
                      const void* res, void* y);
 // persistent wave-specialised variant for the all-bf16 64 -> 64 trunk; its

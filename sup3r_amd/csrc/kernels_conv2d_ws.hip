@@ -711,6 +711,103 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
 #undef PP_COL
 #undef PP_BARRIER
 
+// ---------------------------------------------------------------------------
+// The few-feature HEAD conv of a 2-D generator (C_in = 1 or 2 -> 64 channels,
+// fp32 field in, bf16 cells out: sup3r/configs/spatial/gen_*_{1,2}f.json,
+// sup3rcc/gen_solar_*).  On the logical-axes MFMA kernel it took 60 us at the
+// config_fwp_spatial.json chunk — K = 18 padded to a 64-wide k-step, a halo
+// staged through LDS for 0.3 GFLOP — as long as two trunk convs.  It is a
+// streaming problem (2 MB in, 35 MB out): here a lane keeps the 9 x C_in x 8
+// filter taps of ITS eight output channels in registers (bf16-rounded values, as
+// the matrix path multiplies them) and slides a 3 x 3 window along a row
+// segment: three new cells per position, 72 C_in FMAs, one 16-B store; eight
+// lanes = one position's 128-B cell.  Products of two bf16 values are exact in
+// fp32 and the accumulation is fp32 as on the matrix cores; only the order of
+// the 9 C_in terms differs.
+constexpr int HD_SEG = 25;   // positions of a row walked by one lane group
+template <int CIN>
+__global__ __launch_bounds__(256) void conv2d_head_kernel(
+    const float* __restrict__ x, const float* __restrict__ wimg, const float* __restrict__ bias,
+    unsigned short* __restrict__ y, int N, int H, int W, int act, float alpha) {
+  const int tid = threadIdx.x;
+  const int cg = tid & 7;                       // output channels cg 8 .. cg 8 + 7
+  const int nseg = (W + HD_SEG - 1) / HD_SEG;
+  const long long slots = (long long)N * H * nseg;
+  float wr[9][CIN][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const float4 a = *reinterpret_cast<const float4*>(wimg + (t * CIN + ci) * 64 + cg * 8);
+      const float4 b = *reinterpret_cast<const float4*>(wimg + (t * CIN + ci) * 64 + cg * 8 + 4);
+      wr[t][ci][0] = a.x; wr[t][ci][1] = a.y; wr[t][ci][2] = a.z; wr[t][ci][3] = a.w;
+      wr[t][ci][4] = b.x; wr[t][ci][5] = b.y; wr[t][ci][6] = b.z; wr[t][ci][7] = b.w;
+    }
+  float bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[cg * 8 + j] : 0.f;
+  const float slope = act == S3_ACT_LEAKY ? alpha : (act == S3_ACT_RELU ? 0.f : 1.f);
+  auto rnd = [](float v) __attribute__((always_inline)) { return __uint_as_float(ws_pk(v, 0.f) << 16); };
+
+  for (long long slot = (long long)blockIdx.x * 32 + (tid >> 3); slot < slots; slot += (long long)gridDim.x * 32) {
+    const int seg = (int)(slot % nseg);
+    const long long row = slot / nseg;           // n H + r
+    const int r = (int)(row % H);
+    const long long n = row / H;
+    const int c_lo = seg * HD_SEG, c_hi = c_lo + HD_SEG < W ? c_lo + HD_SEG : W;
+    const float* xr[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) xr[a] = x + ((size_t)n * H + s3_reflect(r + a - 1, H)) * W * CIN;
+    // window columns c - 1, c, c + 1 of the three rows (bf16-rounded)
+    float win[3][3][CIN];
+    auto load_col = [&](int slotc, int c) __attribute__((always_inline)) {
+      const int cr = s3_reflect(c, W);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) win[a][slotc][ci] = rnd(xr[a][(size_t)cr * CIN + ci]);
+    };
+    load_col(0, c_lo - 1);
+    load_col(1, c_lo);
+    unsigned short* yo = y + (((size_t)n * H + r) * W + c_lo) * 64 + cg * 8;
+    for (int c = c_lo; c < c_hi; ++c) {
+      load_col(2, c + 1);
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = bv[j];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) {
+            const float xv = win[a][b][ci];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(wr[a * 3 + b][ci][j], xv, acc[j]);
+          }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float sa = slope * acc[j];
+        asm("v_max_f32 %0, %1, %2" : "=v"(acc[j]) : "v"(acc[j]), "v"(sa));
+      }
+      uint4 o;
+      o.x = ws_pk(acc[0], acc[1]); o.y = ws_pk(acc[2], acc[3]); o.z = ws_pk(acc[4], acc[5]); o.w = ws_pk(acc[6], acc[7]);
+      *reinterpret_cast<uint4*>(yo) = o;
+      yo += 64;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) { win[a][0][ci] = win[a][1][ci]; win[a][1][ci] = win[a][2][ci]; }
+    }
+  }
+}
+
+// canonical fp32 w[tap 9][ci][co 64] -> the same layout with bf16-rounded values
+__global__ void pack_head_kernel(const float* __restrict__ w, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = __uint_as_float(ws_pk(w[i], 0.f) << 16);
+}
+
 }  // namespace
 
 // physical geometry of a 2-D conv: (N, s1, s2, 1, C), k = (3, 3, 1)
@@ -840,6 +937,49 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
                        (const unsigned short*)x, (const char*)image, bias, (const unsigned short*)res, y, w,
                        g.w_cin ? g.exo : (const float*)nullptr, (const unsigned short*)g.res2);
   }
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+// ---- the few-feature head conv (conv2d_head_kernel): C_in 1 / 2 -> 64, fp32 in, bf16 out
+bool conv2d_head_geom_ok(const ConvGeom& g) {
+  if ((g.Cin != 1 && g.Cin != 2) || g.Cout != 64 || g.w_cin || g.d2s > 1) return false;
+  if (g.k[0] != 3 || g.k[1] != 3 || g.k[2] != 1 || g.D[2] != 1 || g.O[2] != 1) return false;
+  if (g.pad_mode != S3_PAD_REFLECT || g.in_cstride || g.in_rep > 1 || g.res_rep > 1) return false;
+  for (int d = 0; d < 2; ++d)
+    if (g.s[d] != 1 || g.lo[d] != 1 || g.O[d] != g.D[d] || g.D[d] < 2) return false;
+  if (g.s[2] != 1 || g.lo[2] != 0) return false;
+  if (g.act == S3_ACT_LEAKY && !(g.alpha >= 0.f && g.alpha <= 1.f)) return false;
+  // per image, like conv2d_ws_geom_ok: the choice must not depend on the batch size
+  // (chunk by chunk == batched, bit for bit)
+  return (int64_t)g.O[0] * g.O[1] >= 256;
+}
+
+bool conv2d_head_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res) {
+  if (precision != S3_PREC_BF16 || s3_opt_on(S3O_NO_CONV2D_WS) || s3_opt_on(S3O_NO_CONV2D_HEAD)) return false;
+  return conv2d_head_geom_ok(g) && !io.in_bf16 && io.out_bf16 && !has_res && !g.res2;
+}
+
+size_t conv2d_head_image_bytes(const ConvGeom& g) { return (size_t)9 * g.Cin * 64 * sizeof(float); }
+
+int launch_conv2d_head_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image) {
+  const int n = 9 * g.Cin * 64;
+  hipLaunchKernelGGL(pack_head_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, w, (float*)image, n);
+  S3_HIP(ctx, hipGetLastError());
+  return S3_OK;
+}
+
+int launch_conv2d_head(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias, void* y) {
+  const int nseg = (g.D[1] + HD_SEG - 1) / HD_SEG;
+  const int64_t slots = (int64_t)g.N * g.D[0] * nseg;
+  int64_t grid = (slots + 31) / 32;
+  if (grid > (int64_t)ctx->num_cu * 8) grid = (int64_t)ctx->num_cu * 8;
+  if (g.Cin == 1)
+    hipLaunchKernelGGL(conv2d_head_kernel<1>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const float*)x,
+                       (const float*)image, bias, (unsigned short*)y, g.N, g.D[0], g.D[1], g.act, g.alpha);
+  else
+    hipLaunchKernelGGL(conv2d_head_kernel<2>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const float*)x,
+                       (const float*)image, bias, (unsigned short*)y, g.N, g.D[0], g.D[1], g.act, g.alpha);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

@@ -1839,7 +1839,9 @@ static int conv_fwd_kind(const s3_plan* pl, const OpRec& o) {
   // mirrors run_op_forward / launch_conv_generic_fwd
   if (o.mfma) {
     fwd = conv_mfma_is_gen(o.cg, pl->precision)
-              ? (conv2d_ws_supported(o.cg, pl->precision, o.io, res) ? S3_FWD_CONV2D_WS : S3_FWD_MFMA_GEN)
+              ? (conv2d_ws_supported(o.cg, pl->precision, o.io, res)     ? S3_FWD_CONV2D_WS
+                 : conv2d_head_supported(o.cg, pl->precision, o.io, res) ? S3_FWD_CONV2D_HEAD
+                                                                         : S3_FWD_MFMA_GEN)
           : bfp && conv_mfma_persist_supported(pl->ctx, o.cg, o.io, res) ? S3_FWD_MFMA_PERSIST : S3_FWD_MFMA_TILE;
   } else if (o.halo32 && !res) {
     fwd = S3_FWD_HALO32;
@@ -1877,7 +1879,7 @@ extern "C" int s3_plan_op_info(const s3_plan* pl, int i, int32_t* out, int cap) 
     v[S3_OPINFO_RES_REP] = o.cg.res_rep;
     // operands rounded to bf16 by the forward kernel
     v[S3_OPINFO_FWD_BF16_OPS] = (pl->precision == S3_PREC_BF16 &&
-                                 (fwd == S3_FWD_FUSED2D || fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_GEN || fwd == S3_FWD_CONV2D_WS || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 || fwd == S3_FWD_HALO_S2 ||
+                                 (fwd == S3_FWD_FUSED2D || fwd == S3_FWD_MFMA_TILE || fwd == S3_FWD_MFMA_GEN || fwd == S3_FWD_CONV2D_WS || fwd == S3_FWD_CONV2D_HEAD || fwd == S3_FWD_MFMA_PERSIST || fwd == S3_FWD_HALO32 || fwd == S3_FWD_HALO_S2 ||
                                   fwd == S3_FWD_GCONV || fwd == S3_FWD_GCONV_FEWCH || fwd == S3_FWD_TAIL_MFMA)) ? 1 : 0;
     v[S3_OPINFO_FEWPOS_MFMA] = (o.fp_mfma || o.fp_wg_mfma) ? 1 : 0;
     if (pl->training) {

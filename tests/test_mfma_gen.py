@@ -54,7 +54,7 @@ def _selection(ph):
 def _n_gen(sel):
     """convs on the logical-axes tile kernel or (bf16 inference plans, 2-D
     64 -> 64 k trunks) on the weights-stationary Conv2D kernel"""
-    return sel.count('mfma_gen') + sel.count('conv2d_ws')
+    return sel.count('mfma_gen') + sel.count('conv2d_ws') + sel.count('conv2d_head')
 
 
 @pytest.mark.parametrize('rel', sorted(CASES))
@@ -331,3 +331,58 @@ def test_one_hot_filters_are_exact(kind, nd, shape, prec):
         assert sel.count('conv2d_ws') == 4, sel     # 64 -> 64 x 2, 64 -> 256 d2s, 64 -> 2 output
     y = ph.forward(net.dev.to_device(x)).cpu().numpy()
     np.testing.assert_array_equal(y, y_ref)
+
+
+@pytest.mark.parametrize('rel,shape', [('spatial/gen_2x_2f.json', (3, 33, 37, 2)),
+                                        ('spatial/gen_2x_1f.json', (2, 75, 75, 1))])
+def test_head_conv_kernel_vs_the_matrix_path_and_the_oracle(rel, shape):
+    """conv2d_head_kernel (C_in 1 / 2 -> 64, fp32 field in, bf16 cells out, the
+    filter taps of a lane's eight channels in registers): same bf16 operand
+    rounding and fp32 accumulation as the logical-axes MFMA kernel it replaces
+    (option NO_CONV2D_HEAD) — the two differ by the order of 9 C_in terms, i.e. by
+    bf16 output roundings that flip — and both sit inside the bf16 bound of the
+    oracle."""
+    from sup3r_amd.engine import Network
+    from tests.helpers import rel_linf
+    from tests.test_parity_r02 import _oracle
+    spec = load_surface(rel)
+    rng = np.random.default_rng(7)
+    x = (3.0 * rng.standard_normal(shape)).astype(np.float32)
+    ref = _oracle(spec, x[:1], None, seed=11)
+    net = Network(spec, precision='bf16')
+    net.set_weights(ref.weights)
+    dev = net.dev
+    a = net.plan(shape, training=False)
+    b = net.plan(shape, training=False, options={'NO_CONV2D_HEAD': 1})
+    sa, sb = _selection(a), _selection(b)
+    assert sa[0] == 'conv2d_head' and sb[0] == 'mfma_gen', (sa[0], sb[0])
+    assert sa[1:] == sb[1:]
+    ya = a.forward(dev.to_device(x)).cpu().numpy()
+    yb = b.forward(dev.to_device(x)).cpu().numpy()
+    y_ref = ref.forward(x[:1])
+    assert rel_linf(ya[:1], y_ref) < 3e-2 and rel_linf(yb[:1], y_ref) < 3e-2
+    # (a flipped bf16 rounding of the first layer reaches the output amplified by
+    # 35 more: the two valid bf16 evaluations agree like each does with the oracle)
+    assert rel_linf(ya, yb) < 3e-2
+    # the head layers alone (+ one conv that reads their bf16 cells): at most one
+    # bf16 spacing apart, on a small fraction of the elements
+    hl = spec['hidden_layers']
+    head = {'hidden_layers': hl[:3] + [
+        {'class': 'FlexiblePadding', 'paddings': [[0, 0], [3, 3], [3, 3], [0, 0]], 'mode': 'REFLECT'},
+        {'class': 'Conv2DTranspose', 'filters': 64, 'kernel_size': 3, 'strides': 1},
+        {'class': 'Cropping2D', 'cropping': 4}]}
+    hnet = Network(head, precision='bf16')
+    hnet.build(shape, seed=5)
+    ha = hnet.plan(shape, training=False)
+    hb = hnet.plan(shape, training=False, options={'NO_CONV2D_HEAD': 1})
+    assert _selection(ha)[0] == 'conv2d_head' and _selection(hb)[0] == 'mfma_gen'
+    za = ha.forward(hnet.dev.to_device(x)).cpu().numpy()
+    zb = hb.forward(hnet.dev.to_device(x)).cpu().numpy()
+    d = np.abs(za - zb)
+    assert d.max() <= 2.0 ** -6 * np.abs(zb).max() and (d > 0).mean() < 1e-2, (d.max(), (d > 0).mean())
+    # one sample == the batch
+    a1 = net.plan((1,) + tuple(shape[1:]), training=False)
+    assert _selection(a1)[0] == 'conv2d_head'
+    for k in range(shape[0]):
+        yk = a1.forward(dev.to_device(x[k:k + 1])).cpu().numpy()
+        np.testing.assert_array_equal(yk[0], ya[k])

@@ -1,25 +1,44 @@
-"""debug: per-op times of the C2 generator forward at the C3 chunk shape"""
-import json, os, sys
+"""conv2d_head_kernel vs the logical-axes MFMA kernel on the head layers alone: where do they differ?"""
+import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from sup3r_amd.engine import Device, Network
-import torch
-spec = json.load(open('sup3r_amd/configs/gen_5x_12x_2f.json'))
-dev = Device.get()
-for shape, opts in (((8, 22, 22, 52, 4), {}), ((8, 22, 22, 52, 4), {'NO_FEWCH_HALO': 1}),
-                    ((32, 16, 16, 24, 4), {}), ((8, 24, 24, 64, 4), {})):
-    net = Network(spec, precision='bf16')
-    net.build(shape, seed=0)
-    ph = net.plan(shape, training=False, options=opts)
-    x = dev.to_device(np.random.default_rng(0).standard_normal(shape).astype(np.float32))
-    for _ in range(2):
-        ph.forward(x)
-    torch.cuda.synchronize()
-    ph.profile_begin(4)
-    for _ in range(4):
-        ph.forward(x)
-    torch.cuda.synchronize()
-    n, ms = ph.profile_end()
-    print(shape, opts, 'op0', ph.op_info(0)['fwd'], '%.3f ms' % ms[0], 'total %.2f' % sum(ms))
-    del ph
-    net.clear_plans()
+from sup3r_amd.engine import Network
+from sup3r_amd import spec as S
+from tests.test_ref_surface import load_surface
+
+spec = load_surface('spatial/gen_2x_2f.json')
+hl = spec['hidden_layers']
+head = hl[:3] + [{'class': 'FlexiblePadding', 'paddings': [[0, 0], [3, 3], [3, 3], [0, 0]], 'mode': 'REFLECT'},
+                   {'class': 'Conv2DTranspose', 'filters': 64, 'kernel_size': 3, 'strides': 1},
+                   {'class': 'Cropping2D', 'cropping': 4}]
+shape = (3, 33, 37, 2)
+x = (3.0 * np.random.default_rng(7).standard_normal(shape)).astype(np.float32)
+net = Network({'hidden_layers': head}, precision='bf16')
+net.build(shape, seed=3)
+a = net.plan(shape, training=False)
+b = net.plan(shape, training=False, options={'NO_CONV2D_HEAD': 1})
+print([a.op_info(i)['fwd'] for i, op in enumerate(a.plan.ops) if op['kind'] == S.OP_CONV],
+      [b.op_info(i)['fwd'] for i, op in enumerate(b.plan.ops) if op['kind'] == S.OP_CONV])
+ya = a.forward(net.dev.to_device(x)).cpu().numpy()
+yb = b.forward(net.dev.to_device(x)).cpu().numpy()
+d = np.abs(ya - yb)
+print('max', d.max(), 'scale', np.abs(yb).max(), 'n differing', (d > 0).sum(), 'of', d.size)
+idx = np.argwhere(d.max(axis=-1) > 0)
+print('rows', np.unique(idx[:, 1])[:40], 'cols', np.unique(idx[:, 2])[:40])
+
+# the whole network: run-to-run determinism, head kernel vs matrix path, ping-pong vs lockstep trunk
+net = Network(spec, precision='bf16')
+net.build(shape, seed=3)
+xd = net.dev.to_device(x)
+plans = {'a': net.plan(shape, training=False), 'nohead': net.plan(shape, training=False, options={'NO_CONV2D_HEAD': 1}),
+         'nopp': net.plan(shape, training=False, options={'NO_WS_PP': 1}),
+         'nopp_nohead': net.plan(shape, training=False, options={'NO_WS_PP': 1, 'NO_CONV2D_HEAD': 1})}
+out = {}
+for k, ph in plans.items():
+    y1 = ph.forward(xd).cpu().numpy()
+    y2 = ph.forward(xd).cpu().numpy()
+    out[k] = y1
+    print(k, 'run-to-run max diff', np.abs(y1 - y2).max())
+for k in ('nohead', 'nopp', 'nopp_nohead'):
+    d = np.abs(out['a'] - out[k])
+    print('a vs', k, d.max(), 'differing', (d > 0).sum(), 'of', d.size, 'scale', np.abs(out[k]).max())
