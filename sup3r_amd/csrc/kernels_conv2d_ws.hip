@@ -724,7 +724,10 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
 // lanes = one position's 128-B cell.  Products of two bf16 values are exact in
 // fp32 and the accumulation is fp32 as on the matrix cores; only the order of
 // the 9 C_in terms differs.
-constexpr int HD_SEG = 25;   // positions of a row walked by one lane group
+// positions of a row walked by one lane group per work item.  Short segments on purpose: at
+// 197 registers a CU holds two workgroups, and 25-position segments at the production chunk
+// were 338 workgroups — a third of the CUs ran two of them back to back (27 us for 13 us of work)
+constexpr int HD_SEG = 5;
 template <int CIN>
 __global__ __launch_bounds__(256) void conv2d_head_kernel(
     const float* __restrict__ x, const float* __restrict__ wimg, const float* __restrict__ bias,
@@ -769,9 +772,19 @@ __global__ __launch_bounds__(256) void conv2d_head_kernel(
     };
     load_col(0, c_lo - 1);
     load_col(1, c_lo);
+    load_col(2, c_lo + 1);
     unsigned short* yo = y + (((size_t)n * H + r) * W + c_lo) * 64 + cg * 8;
     for (int c = c_lo; c < c_hi; ++c) {
-      load_col(2, c + 1);
+      // column c + 2 is fetched one position ahead of its use (two waves per SIMD at 197
+      // registers do not cover an L1 round trip per position)
+      float nxt[3][CIN];
+      {
+        const int cr = s3_reflect(c + 2 < W + 1 ? c + 2 : W, W);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) nxt[a][ci] = xr[a][(size_t)cr * CIN + ci];
+      }
       float acc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = bv[j];
@@ -797,7 +810,9 @@ __global__ __launch_bounds__(256) void conv2d_head_kernel(
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) { win[a][0][ci] = win[a][1][ci]; win[a][1][ci] = win[a][2][ci]; }
+        for (int ci = 0; ci < CIN; ++ci) {
+          win[a][0][ci] = win[a][1][ci]; win[a][1][ci] = win[a][2][ci]; win[a][2][ci] = rnd(nxt[a][ci]);
+        }
     }
   }
 }
@@ -973,7 +988,8 @@ int launch_conv2d_head(s3_ctx* ctx, const ConvGeom& g, const void* x, const void
   const int nseg = (g.D[1] + HD_SEG - 1) / HD_SEG;
   const int64_t slots = (int64_t)g.N * g.D[0] * nseg;
   int64_t grid = (slots + 31) / 32;
-  if (grid > (int64_t)ctx->num_cu * 8) grid = (int64_t)ctx->num_cu * 8;
+  // (all workgroups resident — two per CU — each walking its share of the items)
+  if (grid > (int64_t)ctx->num_cu * 2) grid = (int64_t)ctx->num_cu * 2;
   if (g.Cin == 1)
     hipLaunchKernelGGL(conv2d_head_kernel<1>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const float*)x,
                        (const float*)image, bias, (unsigned short*)y, g.N, g.D[0], g.D[1], g.act, g.alpha);
