@@ -655,7 +655,67 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
     {
       PP_WAIT_ALL();
       if (k + 1 < n_g && !(g.dbg & 8)) PP_COMMIT();
-      if (!(g.dbg & 16))
+      if (res2 && !(g.dbg & 16)) {
+        // ---- a SECOND skip operand (d2s == 1): its eight chunks go into the prefetch
+        // registers the hand-over above has just emptied — all in flight together, under the
+        // first stage of the epilogue — instead of one load + wait per chunk inside it
+        // (each of those waits also drained the stores before it: 6.9 ms where the
+        // neighbouring convs take 4.9 at 96 x 750 x 750).
+#define PP_RES2_LOAD(M, H, P)                                                                   \
+        {                                                                                       \
+          const int r_ = r0 + w_row + (M);                                                      \
+          const int rc_ = r_ > Ho - 1 ? Ho - 1 : r_;                                            \
+          P = pp_ld16(res2 + tbase + (unsigned long long)(unsigned)rc_ * RS + off_h[H]);        \
+        }
+        PP_RES2_LOAD(0, 0, p0) PP_RES2_LOAD(0, 1, p1) PP_RES2_LOAD(1, 0, p2) PP_RES2_LOAD(1, 1, p3)
+        PP_RES2_LOAD(2, 0, p4) PP_RES2_LOAD(2, 1, p5) PP_RES2_LOAD(3, 0, p6) PP_RES2_LOAD(3, 1, p7)
+#undef PP_RES2_LOAD
+        // stage 1: activation + first skip, rounded to bf16 (as the separate add of two bf16
+        // tensors saw it), parked in the accumulator registers it came from
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[m][2 * h][e]; v[4 + e] = acc[m][2 * h + 1][e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float sa = slope * v[e];
+              asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(sa));
+            }
+            if constexpr (RES) {
+              const u32x4 q4 = rr[m][h];
+              v[0] += ws_lo(q4[0]); v[1] += ws_hi(q4[0]); v[2] += ws_lo(q4[1]); v[3] += ws_hi(q4[1]);
+              v[4] += ws_lo(q4[2]); v[5] += ws_hi(q4[2]); v[6] += ws_lo(q4[3]); v[7] += ws_hi(q4[3]);
+            }
+            acc[m][2 * h][0] = __uint_as_float(ws_pk(v[0], v[1]));
+            acc[m][2 * h][1] = __uint_as_float(ws_pk(v[2], v[3]));
+            acc[m][2 * h][2] = __uint_as_float(ws_pk(v[4], v[5]));
+            acc[m][2 * h][3] = __uint_as_float(ws_pk(v[6], v[7]));
+          }
+        PP_WAIT_P();
+        // stage 2: + second skip, stores
+#define PP_RES2_STORE(M, H, P)                                                                  \
+        {                                                                                       \
+          const int r_ = r0 + w_row + (M);                                                      \
+          const bool row_ok_ = col_ok && r_ < Ho && !(g.dbg & 4);                               \
+          const int rc_ = r_ > Ho - 1 ? Ho - 1 : r_;                                            \
+          const unsigned o1x = __float_as_uint(acc[M][2 * (H)][0]), o1y = __float_as_uint(acc[M][2 * (H)][1]); \
+          const unsigned o1z = __float_as_uint(acc[M][2 * (H)][2]), o1w = __float_as_uint(acc[M][2 * (H)][3]); \
+          const u32x4 q4 = P;                                                                   \
+          uint4 o;                                                                              \
+          o.x = ws_pk(ws_lo(o1x) + ws_lo(q4[0]), ws_hi(o1x) + ws_hi(q4[0]));                    \
+          o.y = ws_pk(ws_lo(o1y) + ws_lo(q4[1]), ws_hi(o1y) + ws_hi(q4[1]));                    \
+          o.z = ws_pk(ws_lo(o1z) + ws_lo(q4[2]), ws_hi(o1z) + ws_hi(q4[2]));                    \
+          o.w = ws_pk(ws_lo(o1w) + ws_lo(q4[3]), ws_hi(o1w) + ws_hi(q4[3]));                    \
+          if (row_ok_ && ch_ok[H])                                                              \
+            *reinterpret_cast<uint4*>(y + tbase + (unsigned long long)(unsigned)rc_ * RS + off_h[H]) = o; \
+        }
+        PP_RES2_STORE(0, 0, p0) PP_RES2_STORE(0, 1, p1) PP_RES2_STORE(1, 0, p2) PP_RES2_STORE(1, 1, p3)
+        PP_RES2_STORE(2, 0, p4) PP_RES2_STORE(2, 1, p5) PP_RES2_STORE(3, 0, p6) PP_RES2_STORE(3, 1, p7)
+#undef PP_RES2_STORE
+      } else if (!(g.dbg & 16))
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int r = r0 + w_row + m;
@@ -676,17 +736,6 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
             const u32x4 q4 = rr[m][h];
             v[0] += ws_lo(q4[0]); v[1] += ws_hi(q4[0]); v[2] += ws_lo(q4[1]); v[3] += ws_hi(q4[1]);
             v[4] += ws_lo(q4[2]); v[5] += ws_hi(q4[2]); v[6] += ws_lo(q4[3]); v[7] += ws_hi(q4[3]);
-          }
-          if (res2) {
-            // (d2s == 1; the sum of the first skip is rounded to bf16 first, as
-            // the separate add of two bf16 tensors saw it)
-            uint4 o1;
-            o1.x = ws_pk(v[0], v[1]); o1.y = ws_pk(v[2], v[3]); o1.z = ws_pk(v[4], v[5]); o1.w = ws_pk(v[6], v[7]);
-            const uint4 q4 = *reinterpret_cast<const uint4*>(res2 + dst);
-            v[0] = ws_lo(o1.x) + ws_lo(q4.x); v[1] = ws_hi(o1.x) + ws_hi(q4.x);
-            v[2] = ws_lo(o1.y) + ws_lo(q4.y); v[3] = ws_hi(o1.y) + ws_hi(q4.y);
-            v[4] = ws_lo(o1.z) + ws_lo(q4.z); v[5] = ws_hi(o1.z) + ws_hi(q4.z);
-            v[6] = ws_lo(o1.w) + ws_lo(q4.w); v[7] = ws_hi(o1.w) + ws_hi(q4.w);
           }
           uint4 o;
           o.x = ws_pk(v[0], v[1]); o.y = ws_pk(v[2], v[3]); o.z = ws_pk(v[4], v[5]); o.w = ws_pk(v[6], v[7]);
