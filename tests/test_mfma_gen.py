@@ -386,3 +386,32 @@ def test_head_conv_kernel_vs_the_matrix_path_and_the_oracle(rel, shape):
     for k in range(shape[0]):
         yk = a1.forward(dev.to_device(x[k:k + 1])).cpu().numpy()
         np.testing.assert_array_equal(yk[0], ya[k])
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_pingpong_conv2d_is_bit_identical_to_the_lockstep_kernel(seed):
+    """conv2d_ws_pp_kernel (two half-workgroups half a period apart, single-image
+    tiles, hand-ordered loads) against conv2d_ws_kernel (option NO_WS_PP): the
+    same MFMAs in the same order per position and the same epilogue arithmetic,
+    so every output bit agrees — on ragged extents, odd batch sizes, one-tile
+    runs, with and without skip operands, through a depth-to-space store and
+    with 25 output-channel tiles."""
+    from sup3r_amd.engine import Network
+    rng = np.random.default_rng(100 + seed)
+    rel = ['spatial/gen_2x_2f.json', 'spatial/gen_10x_2f.json', 'spatial/gen_2x_1f.json'][seed]
+    spec = load_surface(rel)
+    cin = 1 if rel.endswith('1f.json') else 2
+    for _ in range(3):
+        n = int(rng.integers(1, 6))
+        h, w = int(rng.integers(16, 41)), int(rng.integers(16, 41))
+        shape = (n, h, w, cin)
+        x = rng.standard_normal(shape).astype(np.float32)
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=int(rng.integers(1 << 20)))
+        a = net.plan(shape, training=False)
+        b = net.plan(shape, training=False, options={'NO_WS_PP': 1})
+        assert _selection(a) == _selection(b) and _selection(a).count('conv2d_ws') >= 34
+        xd = net.dev.to_device(x)
+        ya = a.forward(xd).cpu().numpy()
+        yb = b.forward(xd).cpu().numpy()
+        np.testing.assert_array_equal(ya, yb, err_msg=str(shape))
