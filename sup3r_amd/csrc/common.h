@@ -71,6 +71,7 @@
   X(NO_WS_RES2) \
   X(NO_WS_PP) \
   X(NO_CONV2D_HEAD) \
+  X(KEEP_ACTIVATIONS) \
   X(NO_MFMA_BWD) \
   X(NO_PERSIST) \
   X(NO_PERSIST_DGRAD) \

@@ -1222,7 +1222,10 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
     TensorRec& ot = pl->t[d.out];
     size_t need = ot.bytes();
     int pick = -1;
-    if (!training) {
+    // (option KEEP_ACTIVATIONS: an inference plan with a buffer per tensor, so that a
+    // test can read every op's output — s3_plan_tensor_read — of the kernels and
+    // fusions only inference plans select)
+    if (!training && !s3_opt_has(S3O_KEEP_ACTIVATIONS)) {
       for (int b = 0; b < (int)bsize.size(); ++b)
         if (bfree_at[b] < i && bsize[b] >= need &&
             (pick < 0 || bsize[b] < bsize[pick]))

@@ -233,7 +233,8 @@ def rel_rms(a, b):
                  / max(1e-30, np.sqrt((b ** 2).mean())))
 
 
-def teacher_forced_check(ref, ph, x, exo=None, sample=slice(None)):
+def teacher_forced_check(ref, ph, x, exo=None, sample=slice(None),
+                         allow_missing=False):
     """Per-op parity of a whole network, free of error propagation.
 
     A deep stack in bf16 is chaotic at the rounding level: two correct
@@ -249,7 +250,12 @@ def teacher_forced_check(ref, ph, x, exo=None, sample=slice(None)):
     compared with the tensor the DEVICE stored for that op — then REPLACED by
     it, so the next group starts from exactly the device's input.
 
-    Needs a training plan (keeps every activation) after its forward.
+    Needs a training plan (keeps every activation) after its forward — or an
+    inference plan created with the option ``KEEP_ACTIVATIONS``; with
+    ``allow_missing`` an op whose output the device never materialises (a
+    concat / skip add fused into a conv: ``s3_plan_tensor_read`` says "no
+    buffer") is stepped over — the oracle carries its own value to the next
+    op, whose output then covers both.
     Returns one dict per op: ``frac`` of elements that differ from the
     device value (after the same storage rounding; fp32-stored tensors: by
     more than the accumulation noise), ``excess`` = the largest difference
@@ -272,6 +278,7 @@ def teacher_forced_check(ref, ph, x, exo=None, sample=slice(None)):
             layer._dcache = None
             layer._fwd_roles = []
     stats = []
+    carry = None
     h = np.asarray(x, np.float32)[sample]
     for i, layer in enumerate(ref.layers):
         if isinstance(layer, (L.Sup3rConcat, L.Sup3rAdder)):
@@ -283,7 +290,23 @@ def teacher_forced_check(ref, ph, x, exo=None, sample=slice(None)):
             continue
         oi = last_to_op[i]
         op = plan.ops[oi]
-        dev = ph.tensor(op['out']).reshape((-1,) + h.shape[1:])[sample]
+        try:
+            dev = ph.tensor(op['out'])
+        except RuntimeError as e:
+            if allow_missing and 'no buffer' in str(e):
+                stats.append(dict(op=oi, kind=op['kind'], skipped=True))
+                # (a value the device rounds in registers on its way into
+                # the fused consumer: emulate_plan of the unfused variant of
+                # the plan put the layer into emu_store_round)
+                if i in ref.emu_store_round:
+                    h = L.round_bf16(h)
+                    # that rounding may flip too: one spacing of THIS value is
+                    # carried into the bound of the op that covers it
+                    carry = np.exp2(np.floor(np.log2(np.maximum(
+                        np.abs(h).astype(np.float64), 1e-30))) - 7)
+                continue
+            raise
+        dev = dev.reshape((-1,) + h.shape[1:])[sample]
         is16 = ph.tensor_is_bf16(op['out'])
         mine = L.round_bf16(h) if is16 else h
         diff = np.abs(mine.astype(np.float64) - dev)
@@ -298,6 +321,9 @@ def teacher_forced_check(ref, ph, x, exo=None, sample=slice(None)):
             mag = np.maximum(np.maximum(np.abs(dev), np.abs(mine)).astype(
                 np.float64), 1e-30)
             ulp = np.exp2(np.floor(np.log2(mag)) - 7)
+            if carry is not None:
+                ulp = ulp + (carry if carry.shape == ulp.shape
+                             else float(carry.max()))
             bad = diff > 0
             excess = float(((diff - ulp) / scale).max())
         else:
@@ -307,6 +333,7 @@ def teacher_forced_check(ref, ph, x, exo=None, sample=slice(None)):
                           frac=float(bad.mean()), excess=excess,
                           noise=noise / scale, shape=tuple(h.shape)))
         h = dev.astype(np.float32)
+        carry = None
     return stats
 
 
