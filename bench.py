@@ -124,6 +124,79 @@ def train_models(config, precision='bf16'):
     raise SystemExit(f'unknown --config {config}')
 
 
+def spec_gmacs(spec, shape):
+    """forward GMAC per SAMPLE of a layer spec at an input shape (convs: output
+    positions before depth-to-space x taps x C_in x C_out; dense: in x out)"""
+    from sup3r_amd import spec as S
+    layers = spec if isinstance(spec, list) and spec and not isinstance(
+        spec[0], dict) else S.parse_layers(spec)
+    plan = S.build_plan(layers, tuple(shape))
+    macs = 0
+    for op in plan.ops:
+        if 'cin' not in op:
+            continue
+        if 'k' in op:
+            npos = int(np.prod(plan.tensors[op['out']][:4])) \
+                // (op.get('d2s', 1) or 1) ** 2
+            macs += npos * int(np.prod(op['k'])) * op['cin'] * op['cout']
+        else:
+            macs += int(plan.tensors[op['out']][0]) * op['cin'] * op['cout']
+    return macs / shape[0] / 1e9
+
+
+def condmom_leg(batch, lr_s, hr_s, min_seconds, max_steps):
+    """BASELINE.json config 5: ``Sup3rCondMom(spatiotemporal/gen_3x_4x_2f)`` —
+    one ``run_gradient_descent`` (generator forward, masked MSE
+    (conditional.py:221-283), reverse pass, Adam step; the loss scalars read
+    back every step like the reference's ``_train_epoch``,
+    conditional.py:363-489) on a resident synthetic batch, mask of ones"""
+    import torch
+    from sup3r_amd import Sup3rCondMom
+    from sup3r_amd.engine import Device
+    dev = Device.get()
+    cfg = os.path.join(CFGDIR, 'gen_3x_4x_2f.json')
+    m = Sup3rCondMom(cfg, precision='bf16')
+    rng = np.random.default_rng(0)
+    lr = dev.to_device(rng.standard_normal((batch,) + lr_s).astype(np.float32))
+    out = dev.to_device(rng.standard_normal((batch,) + hr_s).astype(np.float32))
+    mask = dev.to_device(np.ones((batch,) + hr_s, np.float32))
+    m.init_weights(lr.shape, out.shape)
+
+    def step():
+        return m.run_gradient_descent(lr, out, None, mask=mask)
+    for _ in range(4):
+        det = step()
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        det = step()
+        n += 1
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if n >= max_steps or el >= min_seconds:
+            break
+    assert np.isfinite(float(det['loss_gen'])), det
+    with open(cfg) as f:
+        g = spec_gmacs(json.load(f), (batch,) + lr_s)
+    dt = el / n
+    res = {'workload': 'Sup3rCondMom.run_gradient_descent (forward, masked MSE, '
+                       'reverse pass, Adam), gen_3x_4x_2f, lr '
+                       f'{(batch,) + lr_s} -> hr {(batch,) + hr_s}, mask of '
+                       'ones, bf16 MFMA operands',
+           'ms_per_step': dt * 1e3, 'value': batch / dt, 'unit': 'samples/s',
+           'steps': n, 'seconds': el,
+           # forward + data gradient + weight gradient of every conv
+           'algorithmic_gflop_per_sample': 6.0 * g,
+           'tflops': 6.0 * g * batch / dt / 1e3,
+           'loss_gen': float(det['loss_gen'])}
+    rec = getattr(m, '_recorder', None)
+    if rec is not None and rec.replays:
+        res['recorded'] = {'replays': rec.replays}
+    del m
+    torch.cuda.empty_cache()
+    return res
+
+
 def train_leg(config, global_batch, world, rank, min_seconds, max_steps,
               multi_gpu, precision='bf16'):
     """ms per ``Sup3rGan._train_batch`` (generator step + discriminator step)
@@ -187,6 +260,14 @@ def train_leg(config, global_batch, world, rank, min_seconds, max_steps,
         # launch-bound step: recorded once, one hipGraphLaunch per mini-batch
         out['recorded'] = {'replays': rec.replays, 'graph_nodes': max(
             e['rec'].nodes for e in rec._entries.values() if e['rec'])}
+    if not gflop and getattr(model, '_disc', None) is not None:
+        try:
+            # 4 G + 9 D: both steps of _train_batch
+            gg = spec_gmacs(model._gen.layers, lr_shape)
+            dd = spec_gmacs(model._disc.layers, hr_shape)
+            gflop = 2.0 * (4 * gg + 9 * dd)
+        except Exception:
+            gflop = None
     if gflop:
         out['algorithmic_gflop_per_sample'] = gflop
         out['tflops'] = gflop * global_batch / dt / 1e3
@@ -389,6 +470,27 @@ def fwd2d_leg(dev, steps=20, warmup=3, batch=48, seed=42):
                     'the 72 KB filter image) at this shape, 0.44 of 8 TB/s at '
                     '480 x 75 x 75; counter traffic per launch: '
                     'profiles/r05/pmc_fwd2d.txt'}}
+    # ---- checker (after the timed regions): one image of the timed batch through
+    # the CPU oracle with the same weights — the number the headline prints as
+    # cpu_baseline.parity, here for the 2-D path in its multi-tile steady state
+    # (per op: tests/test_ws_multitile.py)
+    try:
+        from oracle.network import Network as OracleNet
+        y_dev = out.cpu().numpy()
+        x_np = x.cpu().numpy()
+        ref = OracleNet(spec)
+        ref.init_weights(x_np[:1, :8, :8], seed=0)
+        ref.set_weights(net.weights)
+        pick = [0, batch - 1]
+        y_ref = ref.forward(x_np[pick])
+        res['parity'] = {
+            'bf16_linf': float(np.abs(y_dev[pick] - y_ref).max()),
+            'scale': float(np.abs(y_ref).max()),
+            'sample': f'images 0 and {batch - 1} of the timed batch vs the fp32 '
+                      'numpy oracle (same weights); stated bound of the bf16 '
+                      'mode: 3e-2 of the scale'}
+    except Exception as e:                   # evidence, never fatal
+        res['parity'] = {'error': repr(e)[:200]}
     del ph, net
     return res
 
@@ -817,7 +919,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mode', default='infer',
                     choices=['infer', 'train', 'c3', 'c1', 'fwd2d'])
-    ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c4toy', 'c1'],
+    ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c4toy', 'c1', 'c5', 'c5small'],
                     help='--mode train: which GAN')
     ap.add_argument('--batch', type=int, default=None,
                     help='infer: lo-res chunks per GPU per step (default 32; '
@@ -901,8 +1003,17 @@ def main():
         if gb % world:
             raise SystemExit(f'global batch {gb} does not divide over {world}')
         barrier()
-        out = train_leg(args.config, gb, world, rank, 1e9, args.steps,
-                        multi_gpu=True, precision=args.precision)
+        if args.config in ('c5', 'c5small'):
+            if world > 1:
+                raise SystemExit('--config c5 is a 1-GPU leg')
+            gb = args.batch or (8 if args.config == 'c5' else 4)
+            out = condmom_leg(gb, *(((16, 16, 24, 2), (48, 48, 96, 2))
+                                    if args.config == 'c5' else
+                                    ((4, 4, 4, 2), (12, 12, 16, 2))),
+                              1e9, args.steps)
+        else:
+            out = train_leg(args.config, gb, world, rank, 1e9, args.steps,
+                            multi_gpu=True, precision=args.precision)
         barrier()
         if rank == 0:
             print(json.dumps(dict(
@@ -1217,6 +1328,28 @@ def main():
                                            multi_gpu=False)
         except Exception as e:
             result['train_c1'] = {'error': repr(e)[:300]}
+        torch.cuda.empty_cache()
+        # BASELINE.json config 4, ONE GPU's share of the batch of 32 (4 samples;
+        # the data-parallel line itself needs --gpus 8): the gen_3x_4x_2f body +
+        # discriminator at lr (4,16,16,24,2), and the reference's filters: 1 toy
+        # with topography at lr (4,4,4,4,2); `comm` shows world 1
+        try:
+            result['train_c4'] = train_leg('c4', 4, 1, 0, 2.0, 200,
+                                           multi_gpu=False)
+            result['train_c4']['toy'] = train_leg('c4toy', 4, 1, 0, 1.0, 400,
+                                                  multi_gpu=False)
+        except Exception as e:
+            result.setdefault('train_c4', {})['error'] = repr(e)[:300]
+        torch.cuda.empty_cache()
+        # BASELINE.json config 5: Sup3rCondMom over the same conv stack, at
+        # BASELINE.md's shape and at a production-like one
+        try:
+            result['train_c5'] = condmom_leg(8, (16, 16, 24, 2), (48, 48, 96, 2),
+                                             2.0, 200)
+            result['train_c5']['baseline_shape'] = condmom_leg(
+                4, (4, 4, 4, 2), (12, 12, 16, 2), 1.0, 400)
+        except Exception as e:
+            result.setdefault('train_c5', {})['error'] = repr(e)[:300]
         torch.cuda.empty_cache()
     if single and not args.no_traffic:
         traffic, note = measure_traffic(B)
