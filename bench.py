@@ -599,13 +599,14 @@ def fwp2d_chain_leg(rank=0, batch=2, reps=2):
     fwp = ForwardPass(st, 0)
     ids = [int(i) for i in st.node_chunks[0]]
 
-    def run(n_rep):
+    def run(n_rep, **options):
         best = None
         for _ in range(n_rep):
             t0 = time.perf_counter()
             n = 0
             for c, failed, d in ForwardPass.iter_chunks(
-                    (fwp.get_input_chunk(i) for i in ids), ms, batch=batch):
+                    (fwp.get_input_chunk(i) for i in ids), ms, batch=batch,
+                    options=options):
                 assert not failed and d.shape == (750, 750, 38, 2)
                 n += 1
             el = time.perf_counter() - t0
@@ -613,11 +614,7 @@ def fwp2d_chain_leg(rank=0, batch=2, reps=2):
         return n, best
     assert ForwardPass._device_path(ms, fwp.get_input_chunk(ids[0]))
     n, best = run(reps + 1)          # (first pass: plans, pinned rings)
-    try:
-        ForwardPass.device_chains = False
-        _, host = run(1)
-    finally:
-        ForwardPass.device_chains = True
+    _, host = run(1, device_chains=False)
     ForwardPass.release_delivery_buffers()
     return {'value': n / best, 'unit': 'chunks/s', 'chunks': n,
             'chunks_per_launch_sequence': batch,

@@ -15,11 +15,12 @@ from .condmom import Sup3rCondMom  # noqa: E402,F401
 from .data_centric import Sup3rGanDC  # noqa: E402,F401
 from .solar_cc import SolarCC  # noqa: E402,F401
 from .with_obs import Sup3rGanWithObs  # noqa: E402,F401
-from .forward_pass import ChunkSlicer, ForwardPass  # noqa: E402,F401
+from .forward_pass import (ChunkPathOptions, ChunkSlicer,  # noqa: E402,F401
+                           ForwardPass)
 from .multi_step import MultiStepGan  # noqa: E402,F401
 from .batch_queue import (DeviceBatchHandler, DeviceBatchQueue,  # noqa: E402,F401
                           DsetTuple)
 
-__all__ = ['Sup3rGan', 'Sup3rCondMom', 'Sup3rGanDC', 'SolarCC', 'Sup3rGanWithObs', 'MultiStepGan', 'ForwardPass',
+__all__ = ['Sup3rGan', 'Sup3rCondMom', 'Sup3rGanDC', 'SolarCC', 'Sup3rGanWithObs', 'MultiStepGan', 'ForwardPass', 'ChunkPathOptions',
            'ChunkSlicer', 'DeviceBatchQueue', 'DeviceBatchHandler', 'DsetTuple',
            '__version__']

@@ -112,6 +112,12 @@ class StepRecorder:
         ent = self._entries.pop(key, None)
         if ent and ent['rec'] is not None:
             rec, ent['rec'] = ent['rec'], None
+            # replays are asynchronous (hipGraphLaunch on the context's
+            # stream): the record being dropped may be the one launched on the
+            # previous step — wait for the device before its exec graph and
+            # the buffers it reads go away (eviction is rare)
+            if rec.graph or rec.retained:
+                self.dev.sync()
             if rec.graph:
                 _lib.lib().s3_graph_destroy(rec.graph)
                 rec.graph = None

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -158,6 +160,18 @@ struct s3_ctx {
   // waiting to ride along the next weight-gradient reduction launch
   // (launch_bias_grad_from_partial(.., defer) / s3_take_pending_bias)
   struct PendingBias { const float* partial = nullptr; int nblk = 0, c = 0; float* db = nullptr; int accumulate = 0; } pend_bias;
+};
+
+// One-time per-DEVICE setup of a launch function (hipFuncSetAttribute's dynamic-LDS
+// limit is a property of the function ON A DEVICE): `static S3DeviceOnce o; if
+// (!o.done(ctx->device)) { std::lock_guard<std::mutex> lk(o.m); ...; o.mark(ctx->device); }`
+// — lock-free once set; two threads racing on the first call both run the (idempotent)
+// setup, one after the other.
+struct S3DeviceOnce {
+  std::atomic<uint64_t> mask{0};
+  std::mutex m;
+  bool done(int dev) const { return (mask.load(std::memory_order_acquire) >> (dev & 63)) & 1u; }
+  void mark(int dev) { mask.fetch_or(1ull << (dev & 63), std::memory_order_release); }
 };
 
 #define S3_HIP(ctx, call)                                                    \

@@ -943,8 +943,9 @@ int launch_conv2d_ws_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* 
 
 int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias,
                      const void* res, void* y) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel<4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_kernel<1>),
@@ -959,7 +960,7 @@ int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_ws_pp_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   WsGeom w;
   w.N = g.N; w.H = g.D[0]; w.W = g.D[1];

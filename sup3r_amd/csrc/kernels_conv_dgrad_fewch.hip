@@ -412,13 +412,14 @@ int launch_conv_dgrad_c2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, vo
 
 int launch_conv_dgrad_c2(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img,
                          float* dx, int dy_bf16) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_c2_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, DLDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_c2_slide_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, GLDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   if (dgrad_c2_slide_ok(ctx, g, dy_bf16)) {
     const int segs0 = (g.D[0] + GSEG0 - 1) / GSEG0, t1 = (g.D[1] + GS1 - 1) / GS1,

@@ -333,11 +333,12 @@ int launch_conv_dgrad_c2_x3_pack(s3_ctx* ctx, const ConvGeom& g, const float* w,
   return S3_OK;
 }
 int launch_conv_dgrad_c2_x3(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_c2_x3_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DLDS1));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int tiles0 = (g.D[0] + DT0 - 1) / DT0, tiles1 = (g.D[1] + DT1 - 1) / DT1,
             tiles2 = (g.D[2] + DT2 - 1) / DT2;
@@ -371,13 +372,14 @@ int launch_conv_dgrad_s2_x3_pack(s3_ctx* ctx, const ConvGeom& g, const float* w,
 }
 int launch_conv_dgrad_s2_x3(s3_ctx* ctx, const ConvGeom& g, const float* dy, const void* img, float* dx,
                             const float* mask_y, float mask_slope) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_x3_kernel<2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLDS1));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dgrad_s2_x3_kernel<4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLDS1));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int U0 = (g.D[0] + 1) / 2, U1 = (g.D[1] + 1) / 2, U2 = (g.D[2] + 1) / 2;
   const int tiles0 = (U0 + ST0 - 1) / ST0, tiles1 = (U1 + ST1 - 1) / ST1, tiles2 = (U2 + ST2 - 1) / ST2;

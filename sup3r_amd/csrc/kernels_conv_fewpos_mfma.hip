@@ -600,13 +600,14 @@ int launch_conv_fewpos_bwd_mfma(s3_ctx* ctx, const ConvGeom& g, const ConvGeom& 
   const size_t lds_d = (size_t)(MAX_TAPS * 16 + NW * 16 * 16) * 4;
   const size_t lds_w = (size_t)(NW * 64 * 16 + NW * 4 * 16 + rows_w) * 4;
   const size_t lds = lds_d > lds_w ? lds_d : lds_w;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fewpos_bwd_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fewpos_bwd_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const dim3 grid((unsigned)(nd_x * nd_y + taps * nw_y * nw_z));
   if (v)

@@ -231,13 +231,14 @@ int launch_conv_halo32_fwd(s3_ctx* ctx, const ConvGeom& g, const void* xv, const
                            const float* bias, void* yv, int in_bf16, int out_bf16) {
   const float* x = (const float*)xv;
   float* y = (float*)yv;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo32_kernel<4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo32_kernel<2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int tiles0 = (g.O[0] + HT0 - 1) / HT0, tiles1 = (g.O[1] + HT1 - 1) / HT1,
             tiles2 = (g.O[2] + HT2 - 1) / HT2;

@@ -408,13 +408,14 @@ int launch_conv_halo_s2_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, voi
 
 int launch_conv_halo_s2_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* img,
                             const float* bias, void* y, int out_bf16) {
-  static bool attr_set = false;
+  static S3DeviceOnce attr_set;
   if (halo_s2_k64_geom(g)) {
-    static bool k_attr = false;
-    if (!k_attr) {
+    static S3DeviceOnce k_attr;
+    if (!k_attr.done(ctx->device)) {
+      std::lock_guard<std::mutex> lk_k_attr(k_attr.m);
       S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_s2_k64_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, K_LDS));
-      k_attr = true;
+      k_attr.mark(ctx->device);
     }
     const int t0 = (g.O[0] + KT0 - 1) / KT0, t1 = (g.O[1] + KT1 - 1) / KT1, t2 = (g.O[2] + KT2 - 1) / KT2;
     const int n_tiles = g.N * t0 * t1 * t2;
@@ -430,12 +431,13 @@ int launch_conv_halo_s2_fwd(s3_ctx* ctx, const ConvGeom& g, const void* x, const
     S3_HIP(ctx, hipGetLastError());
     return S3_OK;
   }
-  if (!attr_set) {
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_s2_kernel<2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_s2_kernel<1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int tiles0 = (g.O[0] + ST0 - 1) / ST0, tiles1 = (g.O[1] + ST1 - 1) / ST1,
             tiles2 = (g.O[2] + ST2 - 1) / ST2;

@@ -765,15 +765,16 @@ bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g) {
 
 int launch_conv_mfma_persist_dgrad(s3_ctx* ctx, const ConvGeom& g, const void* dpre16, const void* image,
                                    float* dxp, int accumulate, int frame16) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, true, 0, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   if (frame16 && (accumulate || g.Cout != 64))
     S3_FAIL(ctx, S3_ESTATE, "persistent data gradient: a bf16 frame is written once, 64 channels wide");
@@ -833,8 +834,9 @@ int launch_conv_mfma_persist_pack(s3_ctx* ctx, const ConvGeom& g, const float* w
 int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
                              const void* image, const float* bias,
                              const void* res, void* y) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<4, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, false>),
@@ -858,7 +860,7 @@ int launch_conv_mfma_persist(s3_ctx* ctx, const ConvGeom& g, const void* x,
     S3_HIP(ctx, hipFuncSetAttribute(
                     reinterpret_cast<const void*>(conv3_mfma_persist_kernel<2, false, 0, false, false, 6>),
                     hipFuncAttributeMaxDynamicSharedMemorySize, PGeo<6>::LDS_BYTES));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   // (tiles0 = half rows along s0, n_tiles = half-tiles: the kernel's work units)
   const int tiles0 = (g.O[0] + 1) / 2, tiles1 = (g.O[1] + TS1 - 1) / TS1,

@@ -370,13 +370,14 @@ bool conv_mfma_persist2_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO i
 
 int launch_conv_mfma_persist2(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image,
                               const float* bias, const void* res, void* y) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist2_kernel<4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_mfma_persist2_kernel<2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int nh0 = (g.O[0] + 1) / 2, tiles1 = (g.O[1] + TS1 - 1) / TS1, tiles2 = (g.O[2] + TS2 - 1) / TS2;
   const int n_half = g.N * nh0 * tiles1 * tiles2;

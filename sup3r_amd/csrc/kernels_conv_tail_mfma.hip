@@ -553,23 +553,25 @@ int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
   const int tiles0 = (g.O[0] + T0 - 1) / T0, tiles1 = (g.O[1] + T1 - 1) / T1,
             tiles2 = (g.O[2] + T2 - 1) / T2;
   const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail_mfma_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail_mfma_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const bool band = g.Cout == 2 && !s3_opt_has(S3O_NO_TAIL_BAND);
   // read per call: the parity tests flip it between two forwards
   const bool noslide = s3_opt_on(S3O_NO_TAIL_SLIDE);
   if (band && g.O[0] >= 4 && !noslide) {
-    static bool slide_attr = false;
-    if (!slide_attr) {
+    static S3DeviceOnce slide_attr;
+    if (!slide_attr.done(ctx->device)) {
+      std::lock_guard<std::mutex> lk_slide_attr(slide_attr.m);
       S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail_slide_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SLIDE_LDS));
-      slide_attr = true;
+      slide_attr.mark(ctx->device);
     }
     const int st1 = (g.O[1] + S1 - 1) / S1, st2 = (g.O[2] + S2 - 1) / S2;
     // rows per segment: a workgroup brings in seg + 2 planes per unit and the

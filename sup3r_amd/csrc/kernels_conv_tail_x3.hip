@@ -205,11 +205,12 @@ int launch_conv_tail_x3(s3_ctx* ctx, const ConvGeom& g, const float* x, const fl
             tiles2 = (g.O[2] + XT2 - 1) / XT2;
   const int n_tiles = g.N * tiles0 * tiles1 * tiles2;
   if (n_tiles <= 0) return S3_OK;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tail_x3_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, XLDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int per_xcd = (n_tiles + 7) / 8;
   hipLaunchKernelGGL(conv_tail_x3_kernel, dim3(8 * per_xcd), dim3(XNT), XLDS, ctx->stream, x, w, bias, y, g,

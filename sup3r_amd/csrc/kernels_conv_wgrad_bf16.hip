@@ -949,11 +949,12 @@ int bf_gen_launch_x3(s3_ctx* ctx, const ConvGeom& g, const float* x, const float
   const size_t need = (size_t)grid * 27 * g.Cin * g.Cout * sizeof(float);
   if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_gen: partial buffer too small");
   auto kern = conv_wgrad_bf16_gen_kernel<2, STR, false, false, true>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * W::LDS)));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
   const int n_cit = (g.Cin + 31) / 32;
@@ -978,14 +979,15 @@ int bf_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* d
   auto kern = conv_wgrad_bf16_gen_kernel<CIB, STR, IN16>;
   if constexpr (CAN_PF)
     if (!s3_opt_has(S3O_NO_WGRAD_GEN_PF)) kern = conv_wgrad_bf16_gen_kernel<CIB, STR, IN16, true>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_gen_kernel<CIB, STR, IN16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS));
     if constexpr (CAN_PF)
       S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_gen_kernel<CIB, STR, IN16, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
   const int n_cit = (g.Cin + CIB * 16 - 1) / (CIB * 16);
@@ -1212,11 +1214,12 @@ int bf_2d_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* dy
   const size_t need = (size_t)grid * 9 * g.Cin * g.Cout * sizeof(float);
   if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16_2d: partial buffer too small");
   auto kern = conv2_wgrad_bf16_kernel<CIB, STR, IN16, DY16>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
   const int n_cit = (g.Cin + CIB * 16 - 1) / (CIB * 16);
@@ -1257,8 +1260,9 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
     S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16: partial buffer too small");
   if (x3 && (x_bf16 || dy_bf16)) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16: the split-bf16 kernel takes fp32 operands");
   if (dy_bf16 && (!x_bf16 || (g.Cout & 3))) S3_FAIL(ctx, S3_EINVAL, "wgrad_bf16: bf16 dPre needs bf16 x and C_out % 4 == 0");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_bf16_kernel<true>),
@@ -1269,7 +1273,7 @@ int launch_conv_wgrad_bf16(s3_ctx* ctx, const ConvGeom& g, const float* x,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_x3_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int n_ct = (g.Cout + BCT - 1) / BCT;
   const int dbg = (int)s3_opt_int(S3O_WGRAD_DBG, 0);

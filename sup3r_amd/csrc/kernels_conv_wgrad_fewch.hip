@@ -723,13 +723,14 @@ int launch_conv_wgrad_tail(s3_ctx* ctx, const ConvGeom& g, const float* x, const
   const int grid = tail_grid(ctx, g, &t0, &t1, &t2, &n_tiles);
   if (partial_bytes < conv_wgrad_tail_partial_bytes(ctx, g))
     S3_FAIL(ctx, S3_EINVAL, "wgrad_tail: partial buffer too small");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tail_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS));
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tail_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   if (x_bf16)
     hipLaunchKernelGGL(conv_wgrad_tail_kernel<true>, dim3(grid), dim3(256), TW_LDS, ctx->stream, x, dy,

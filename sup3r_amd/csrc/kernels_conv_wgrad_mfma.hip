@@ -210,11 +210,12 @@ int launch_conv_wgrad_mfma(s3_ctx* ctx, const ConvGeom& g, const float* x,
   const int grid = wgrad_grid(ctx, g, &n_tiles, &tiles0, &tiles1, &tiles2);
   if (partial_bytes < conv_wgrad_mfma_partial_bytes(ctx, g))
     S3_FAIL(ctx, S3_EINVAL, "wgrad_mfma: partial buffer too small");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_mfma_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int n_ct = (g.Cout + WCT - 1) / WCT;
   hipLaunchKernelGGL(conv3_wgrad_mfma_kernel, dim3(grid, n_ct), dim3(WNT), WG_LDS,
@@ -403,11 +404,12 @@ int wgrad_gen_launch(s3_ctx* ctx, const ConvGeom& g, const float* x, const float
   const size_t need = (size_t)grid * W::PS * 27 * g.Cin * g.Cout * sizeof(float);
   if (partial_bytes < need) S3_FAIL(ctx, S3_EINVAL, "wgrad_gen: partial buffer too small");
   auto kern = conv_wgrad_gen_kernel<CIB, STR, NB>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   const int n_ct = (g.Cout + W::COT - 1) / W::COT;
   const int n_cit = (g.Cin + W::CIP - 1) / W::CIP;

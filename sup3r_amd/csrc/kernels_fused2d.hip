@@ -391,11 +391,12 @@ int fused2d_run(s3_ctx* ctx, Fused2dPlan* P, const float* W, uint64_t wversion, 
     S3_HIP(ctx, hipGetLastError());
     P->version = wversion;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static S3DeviceOnce attr_set;
+  if (!attr_set.done(ctx->device)) {
+    std::lock_guard<std::mutex> lk_attr_set(attr_set.m);
     S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fused2d_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_set.mark(ctx->device);
   }
   hipLaunchKernelGGL(fused2d_kernel, dim3(P->N), dim3(FNT), P->lds, ctx->stream, x, y,
                      (const char*)P->img, W, (const FL*)P->dev, (int)P->host.size(), P->H0, P->W0,

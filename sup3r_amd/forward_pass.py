@@ -18,6 +18,7 @@ MI355X design points:
   * every chunk is padded to the SAME padded shape (interior overlap +
     reflect at domain edges) so one plan serves the whole domain.
 """
+import collections
 import json
 import logging
 import os
@@ -122,6 +123,44 @@ class ResidentDomain:
             stats_key
 
 
+class ChunkPathOptions(collections.namedtuple(
+        'ChunkPathOptions', ['sdma_delivery', 'window_forward',
+                             'device_chunks_4d', 'device_norm_4d',
+                             'device_chains'],
+        defaults=[True, True, True, True, True])):
+    """How ``iter_chunks`` / ``run_chunk`` / ``run`` take a chunk batch to the
+    device — an argument of those calls (``options=``) and of the constructor,
+    NOT process state: two executors in one process may differ, and a thread
+    cannot flip another's path.
+
+    * ``sdma_delivery``: deliver by the SDMA engines through ROCr
+      (s3_dma_d2h_begin); False: ``hipMemcpyAsync`` on a copy stream.  (When
+      ROCr refuses a copy the process falls back for good, with one warning:
+      that is a fact about the runtime, kept in ``ForwardPass._sdma_refused``.)
+    * ``window_forward``: halo crop + un-normalisation inside the tail conv
+      (s3_plan_forward_window) where the plan supports it; False: full output
+      + s3_chunk_epilogue.
+    * ``device_chunks_4d``: spatial (4-D) models on the device chunk path;
+      False: chunk by chunk through ``model.generate``.
+    * ``device_norm_4d``: ... with the transpose to time-major + norm_input on
+      the device; False: host numpy, same bits.
+    * ``device_chains``: ``MultiStepGan`` chains on the device chunk path;
+      False: chunk by chunk through ``MultiStepGan.generate``, every
+      hand-over through host numpy."""
+    __slots__ = ()
+
+
+DEFAULT_OPTIONS = ChunkPathOptions()
+
+
+def _opts(options):
+    if options is None:
+        return DEFAULT_OPTIONS
+    if isinstance(options, ChunkPathOptions):
+        return options
+    return DEFAULT_OPTIONS._replace(**dict(options))
+
+
 class ForwardPass:
     """Per-chunk executor of the generator.
 
@@ -139,7 +178,8 @@ class ForwardPass:
     OUTPUT_HANDLER_CLASS = {'npz': NpzOutputHandler}
 
     def __init__(self, model, slicer=0, rank=0, nranks=1, shard='interleave',
-                 output_check=True, allowed_const=False, node_index=None):
+                 output_check=True, allowed_const=False, node_index=None,
+                 options=None):
         """``ForwardPass(strategy, node_index=0)`` (forward_pass.py:44-64) or
         ``ForwardPass(model, slicer, rank, nranks, ...)``.
 
@@ -149,6 +189,7 @@ class ForwardPass:
         constants are (0 for night-time clearsky ratio).  ``output_check=False``
         switches the whole check off."""
         self.strategy = None
+        self.options = _opts(options)
         if hasattr(model, 'init_chunk'):
             strategy = model
             self.strategy = strategy
@@ -663,21 +704,29 @@ class ForwardPass:
 
     # -- the reference's entry points over ForwardPassChunk structures -----
     @classmethod
-    def _device_path(cls, model, chunk):
+    def _device_path(cls, model, chunk, options=None):
         """single-step generator on this package's engine, no exo field
         combined at the output: the chunk batches go through one plan on the
         device — 5-D models, and (round 5) 4-D (spatial) models, whose batch
         axis is the chunks' time axis (forward_pass.py:274-337); anything
         else (``MultiStepGan``, 'output' exo) takes ``run_generator`` ->
         ``model.generate`` chunk by chunk"""
+        options = _opts(options)
         steps = getattr(model, 'models', None)
         if steps is not None:
-            return cls._device_chain(model, chunk)
+            return cls._device_chain(model, chunk, options)
         if getattr(model, '_gen', None) is None or \
                 not getattr(model, 'supports_device_chunks', False):
             return False
         if not getattr(model, 'is_5d', False):
-            if not (getattr(model, 'is_4d', False) and cls.device_chunks_4d):
+            if not (getattr(model, 'is_4d', False) and
+                    options.device_chunks_4d):
+                return False
+            # s3_chunk_time_first / s3_chunk_time_last carry at most 16
+            # channels: a spatial model with more features goes chunk by
+            # chunk through model.generate
+            if len(getattr(model, 'lr_features', None) or ()) > 16 or \
+                    len(getattr(model, 'hr_out_features', None) or ()) > 16:
                 return False
         for entry in (chunk.exo_data or {}).values():
             if any(st['combine_type'].lower() == 'output'
@@ -685,12 +734,8 @@ class ForwardPass:
                 return False
         return True
 
-    #: MultiStepGan chains on the device chunk path (False: chunk by chunk
-    #: through ``MultiStepGan.generate``, every hand-over through host numpy)
-    device_chains = True
-
     @classmethod
-    def _device_chain(cls, model, chunk):
+    def _device_chain(cls, model, chunk, options=None):
         """a ``MultiStepGan`` whose steps all run on this package's engine
         with the base class's normalisation, spatial (4-D) steps first, then
         spatio-temporal (5-D) ones — the reference's production arrangements
@@ -701,7 +746,8 @@ class ForwardPass:
         (s3_step_handover); anything else through ``MultiStepGan.generate``"""
         from .gan import Sup3rGan as _BaseGan
         steps = list(model.models)
-        if not cls.device_chains or not steps:
+        options = _opts(options)
+        if not options.device_chains or not steps:
             return False
 
         def base(m, name):
@@ -713,12 +759,18 @@ class ForwardPass:
                     not getattr(m, 'supports_device_chunks', False) or \
                     hasattr(m, 'models'):
                 return False
-            if not (base(m, 'norm_input') and base(m, 'un_norm_output')):
+            # (hand_over re-implements the base class's input combination on
+            # the device: a step that overrides any of it goes through
+            # MultiStepGan.generate)
+            if not all(base(m, name) for name in (
+                    'norm_input', 'un_norm_output', 'generate',
+                    '_combine_fwp_input')
+                    if hasattr(_BaseGan, name)):
                 return False
             if getattr(m, 'is_5d', False):
                 seen_5d = True
             elif seen_5d or not (getattr(m, 'is_4d', False) and
-                                 cls.device_chunks_4d):
+                                 options.device_chunks_4d):
                 return False
             if m._gen.dev is not steps[0]._gen.dev:
                 return False
@@ -755,7 +807,8 @@ class ForwardPass:
     @classmethod
     def iter_chunks(cls, chunks, model, allowed_const=False, batch=8,
                     invert_uv=False, nn_fill=True, meta=None,
-                    output_workers=None, return_data=True, write=True):
+                    output_workers=None, return_data=True, write=True,
+                    options=None):
         """Run ``ForwardPassChunk`` structures (already edge-padded:
         ``get_input_chunk``) through the generator, ``batch`` equal-shaped
         chunks per launch sequence, and yield ``(chunk, failed, output_data)``
@@ -780,9 +833,9 @@ class ForwardPass:
         ``d2h_ring - 2`` = two batches are yielded — consume it (write it,
         place it) or copy it before asking for more than that, and do not keep
         it past ``release_delivery_buffers``.  ``run`` / ``run_chunk`` hand
-        out copies."""
-        import collections
-
+        out copies.  ``options``: a ``ChunkPathOptions`` (or a dict of its
+        fields to change)."""
+        options = _opts(options)
         pending = collections.deque()
         # the delivery rings belong to THIS generator: two interleaved
         # ``iter_chunks`` runs (threads, two models with one output shape)
@@ -791,14 +844,14 @@ class ForwardPass:
         try:
             yield from cls._iter_chunks_lane(
                 chunks, model, allowed_const, batch, invert_uv, nn_fill, meta,
-                output_workers, return_data, write, pending, lane)
+                output_workers, return_data, write, pending, lane, options)
         finally:
             cls._lanes.discard(lane)
 
     @classmethod
     def _iter_chunks_lane(cls, chunks, model, allowed_const, batch, invert_uv,
                           nn_fill, meta, output_workers, return_data, write,
-                          pending, lane):
+                          pending, lane, options):
         def flush(keep):
             # the newest batch is on the device's queue: the one before it may
             # start crossing PCIe (its forward is the one running or done)
@@ -809,12 +862,12 @@ class ForwardPass:
 
         group, shape = [], None
         for chunk in chunks:
-            if not cls._device_path(model, chunk):
+            if not cls._device_path(model, chunk, options):
                 yield from flush(0)
                 if group:
                     pending.append(cls._launch_chunk_batch(
                         group, model, allowed_const, invert_uv, nn_fill, meta,
-                        output_workers, return_data, write, lane))
+                        output_workers, return_data, write, lane, options))
                     group, shape = [], None
                     yield from flush(0)
                 yield cls._run_chunk_host(chunk, model, allowed_const,
@@ -829,7 +882,7 @@ class ForwardPass:
             if group and (key != shape or len(group) >= batch):
                 pending.append(cls._launch_chunk_batch(
                     group, model, allowed_const, invert_uv, nn_fill, meta,
-                    output_workers, return_data, write, lane))
+                    output_workers, return_data, write, lane, options))
                 group = []
                 yield from flush(2)
             group.append(chunk)
@@ -837,7 +890,7 @@ class ForwardPass:
         if group:
             pending.append(cls._launch_chunk_batch(
                 group, model, allowed_const, invert_uv, nn_fill, meta,
-                output_workers, return_data, write, lane))
+                output_workers, return_data, write, lane, options))
         yield from flush(0)
 
     @classmethod
@@ -885,7 +938,7 @@ class ForwardPass:
     @classmethod
     def _launch_chunk_batch(cls, group, model, allowed_const, invert_uv,
                             nn_fill, meta, output_workers, return_data,
-                            write, lane=0):
+                            write, lane=0, options=None):
         """Enqueue one batch of equal-shaped chunks; returns the closure that
         waits for it and yields its ``(chunk, failed, output_data)``."""
         import ctypes as C
@@ -896,6 +949,7 @@ class ForwardPass:
         from .utilities import ExoData
         # a MultiStepGan chain runs step by step on the device; a single
         # model is a chain of one
+        options = _opts(options)
         chain = hasattr(model, 'models')
         steps = list(model.models) if chain else [model]
         first, last = steps[0], steps[-1]
@@ -919,7 +973,7 @@ class ForwardPass:
         # (s3_chunk_time_first, numpy's arithmetic) unless the model brings
         # its own norm_input
         from .gan import Sup3rGan as _BaseGan
-        dev_norm = is_4d and cls.device_norm_4d and \
+        dev_norm = is_4d and options.device_norm_4d and \
             not any(step_exo(e, 0) for e in exos) and \
             getattr(type(first).norm_input, '__func__',
                     type(first).norm_input) is _BaseGan.norm_input
@@ -1144,7 +1198,7 @@ class ForwardPass:
             # halo crop + un-normalisation inside the tail conv (the window
             # forward: no full-size output, halo positions of the last conv
             # never computed) where the plan ends in the MFMA tail ...
-            windowed = cls.window_forward and ph.supports_window and \
+            windowed = options.window_forward and ph.supports_window and \
                 not is_4d
             if windowed:
                 ph.forward_window(
@@ -1242,7 +1296,7 @@ class ForwardPass:
             state['host_ptr'] = host_ptr
             ticket = C.c_uint64()
             rc = -1
-            if cls.sdma_delivery:
+            if options.sdma_delivery and not cls._sdma_refused:
                 rc = L.s3_dma_d2h_begin(
                     dev.ctx, C.c_void_p(yc.data_ptr()), C.c_void_p(host_ptr),
                     host_arr.size * 4, C.byref(ticket))
@@ -1253,7 +1307,7 @@ class ForwardPass:
                         'SDMA delivery unavailable (%s): falling back to '
                         'hipMemcpyAsync for the chunk batches',
                         _lib.last_error(dev.ctx))
-                    cls.sdma_delivery = False
+                    ForwardPass._sdma_refused = True
             if rc != 0:
                 rc = L.s3_d2h_async(
                     dev.ctx, C.c_void_p(yc.data_ptr()), C.c_void_p(host_ptr),
@@ -1391,18 +1445,11 @@ class ForwardPass:
     #: (s3_host_alloc) per output shape, allocated once: pinning 368 MB per
     #: batch cost 8.9 ms of host time each (torch.empty(pin_memory=True))
     d2h_ring = 4
-    #: deliver by the SDMA engines through ROCr (s3_dma_d2h_begin); switched
-    #: off (with a warning) the first time ROCr refuses a copy
-    sdma_delivery = True
-    # halo crop + un-normalisation inside the tail conv (s3_plan_forward_window)
-    # where the plan supports it; False: full output + s3_chunk_epilogue
-    window_forward = True
-    # spatial (4-D) models on the device chunk path (False:
-    # chunk by chunk through model.generate, as before round 5)
-    device_chunks_4d = True
-    # ... with the transpose to time-major + norm_input on the device (False:
-    # host numpy, same bits)
-    device_norm_4d = True
+    #: ROCr refused an SDMA copy in this process (no SDMA queue in the
+    #: container, a foreign allocator ...): every later batch copies through
+    #: HIP.  A latch about the runtime, set once — the steering flags are
+    #: ``ChunkPathOptions``
+    _sdma_refused = False
     _aff_cache = {}
     _delivery = {}
     _lanes = set()
@@ -1431,12 +1478,14 @@ class ForwardPass:
         if scale is None:
             return None
         key = (dev.index, scale.tobytes(), shift.tobytes())
-        if key not in cls._aff_cache:
-            if len(cls._aff_cache) > 64:
-                cls._aff_cache.clear()
-            cls._aff_cache[key] = dev.to_device(
-                np.concatenate([scale, shift]).astype(np.float32))
-        return cls._aff_cache[key]
+        with cls._lane_lock:
+            t = cls._aff_cache.get(key)
+            if t is None:
+                if len(cls._aff_cache) > 64:
+                    cls._aff_cache.clear()
+                t = cls._aff_cache[key] = dev.to_device(
+                    np.concatenate([scale, shift]).astype(np.float32))
+        return t
 
     @classmethod
     def release_delivery_buffers(cls):
@@ -1478,15 +1527,16 @@ class ForwardPass:
     @classmethod
     def _copy_stream(cls, dev):
         import torch
-        if dev.index not in cls._copy_streams:
-            cls._copy_streams[dev.index] = torch.cuda.Stream(
-                device=dev.torch_device)
-        return cls._copy_streams[dev.index]
+        with cls._lane_lock:
+            if dev.index not in cls._copy_streams:
+                cls._copy_streams[dev.index] = torch.cuda.Stream(
+                    device=dev.torch_device)
+            return cls._copy_streams[dev.index]
 
     @classmethod
     def run_chunk(cls, chunk, model_kwargs, model_class, allowed_const,
                   invert_uv=False, meta=None, nn_fill=True,
-                  output_workers=None):
+                  output_workers=None, options=None):
         """Run a forward pass on a single spatiotemporal chunk
         (forward_pass.py:582-673): same arguments, same return value
         ``(failed, output_data)`` — ``output_data`` the cropped, un-normalised
@@ -1499,12 +1549,13 @@ class ForwardPass:
         (_, failed, output_data), = cls.iter_chunks(
             [chunk], model, allowed_const=allowed_const, batch=1,
             invert_uv=invert_uv, nn_fill=nn_fill, meta=meta,
-            output_workers=output_workers)
+            output_workers=output_workers, options=options)
         # (the caller owns what it gets: not a view of the delivery ring)
         return failed, np.array(output_data)
 
     @classmethod
-    def run(cls, strategy, node_index, batch=8, return_data=False):
+    def run(cls, strategy, node_index, batch=8, return_data=False,
+            options=None):
         """Forward passes on all chunks of one node (forward_pass.py:427-449,
         ``_run_serial`` :451-500) — one node = one process = one GPU; the
         node's chunks are the rank's share of the data-parallel work, there
@@ -1514,7 +1565,7 @@ class ForwardPass:
         ``return_data``, the list of ``(chunk_index, output_data)``)."""
         if strategy.node_finished(node_index):
             return (0, []) if return_data else 0
-        fwp = cls(strategy, node_index=node_index)
+        fwp = cls(strategy, node_index=node_index, options=options)
         todo = [int(i) for i in strategy.node_chunks[node_index]
                 if not strategy.chunk_finished(int(i))]
 
@@ -1528,7 +1579,7 @@ class ForwardPass:
                 batch=batch, invert_uv=getattr(strategy, 'invert_uv', False),
                 nn_fill=getattr(strategy, 'nn_fill', True), meta=meta,
                 output_workers=getattr(strategy, 'output_workers', None),
-                return_data=return_data):
+                return_data=return_data, options=fwp.options):
             if failed:
                 raise MemoryError(
                     f'Forward pass for chunk_index {chunk.index} failed '

@@ -384,11 +384,15 @@ def test_device_chain_predicate_on_duck_typed_steps():
 
     dev = object()
 
-    def step(rank4, dtype=np.float32, own_norm=False, on_device=True):
+    def step(rank4, dtype=np.float32, own_norm=False, on_device=True,
+             own_combine=False):
         cls = type('Step', (), {
             'norm_input': (lambda self, x: x) if own_norm
             else Sup3rGan.norm_input,
             'un_norm_output': Sup3rGan.un_norm_output,
+            'generate': Sup3rGan.generate,
+            '_combine_fwp_input': (lambda self, x, e=None: x) if own_combine
+            else Sup3rGan._combine_fwp_input,
             'supports_device_chunks': True})
         m = cls()
         m._gen = types.SimpleNamespace(dev=dev) if on_device else None
@@ -409,12 +413,28 @@ def test_device_chain_predicate_on_duck_typed_steps():
     assert not ok(chain(step(False), step(True)), chunk)        # 5-D then 4-D
     assert not ok(chain(step(True), step(True, np.float64)), chunk)
     assert not ok(chain(step(True, own_norm=True), step(True)), chunk)
+    # (the device hand-over re-implements the base class's input combination)
+    assert not ok(chain(step(True), step(True, own_combine=True)), chunk)
     assert not ok(chain(step(True), step(True, on_device=False)), chunk)
-    try:
-        ForwardPass.device_chains = False
-        assert not ok(chain(step(True), step(True)), chunk)
-    finally:
-        ForwardPass.device_chains = True
+    assert not ok(chain(step(True), step(True)), chunk,
+                  {'device_chains': False})
+    # a single spatial model whose feature count exceeds what the time-major
+    # transposes carry (s3_chunk_time_first / _last: 16 channels) goes chunk
+    # by chunk through model.generate; 16 is still on the device path
+    single = step(True)
+    assert ForwardPass._device_path(single, chunk)
+    assert not ForwardPass._device_path(single, chunk,
+                                        {'device_chunks_4d': False})
+    single.hr_out_features = [f'f{i}' for i in range(16)]
+    assert ForwardPass._device_path(single, chunk)
+    single.hr_out_features = [f'f{i}' for i in range(17)]
+    assert not ForwardPass._device_path(single, chunk)
+    single.hr_out_features, single.lr_features = ['u'], \
+        [f'f{i}' for i in range(17)]
+    assert not ForwardPass._device_path(single, chunk)
+    wide5 = step(False)
+    wide5.lr_features = [f'f{i}' for i in range(17)]
+    assert ForwardPass._device_path(wide5, chunk)        # 5-D: no such limit
     e32 = np.zeros((4, 4, 2, 1), np.float32)
     for ctype, data, want in (('layer', e32, True), ('input', e32, True),
                               ('input', e32.astype(np.float64), False),

@@ -208,8 +208,8 @@ def test_sdma_delivery_round_trip():
 
 
 def test_delivery_falls_back_to_hipmemcpy_and_the_ring_can_be_released():
-    """``ForwardPass.sdma_delivery = False`` (what a refused ROCr copy switches
-    to): the same chunks through hipMemcpyAsync on the copy stream; then the
+    """``options={'sdma_delivery': False}`` (what a refused ROCr copy switches
+    every later batch to): the same chunks through hipMemcpyAsync on the copy stream; then the
     pinned rings are given back"""
     from sup3r_amd import ForwardPass
     from sup3r_amd.forward_pass import register_model
@@ -223,15 +223,12 @@ def test_delivery_falls_back_to_hipmemcpy_and_the_ring_can_be_released():
     fwp = ForwardPass(st, 0)
     ids = [int(i) for i in st.node_chunks[0]]
 
-    def run():
+    def run(**options):
         return [np.array(d) for _, failed, d in ForwardPass.iter_chunks(
-            (fwp.get_input_chunk(i) for i in ids), model, batch=3)]
+            (fwp.get_input_chunk(i) for i in ids), model, batch=3,
+            options=options)]
     ref = run()
-    try:
-        ForwardPass.sdma_delivery = False
-        got = run()
-    finally:
-        ForwardPass.sdma_delivery = True
+    got = run(sdma_delivery=False)
     for a, b in zip(got, ref):
         np.testing.assert_array_equal(a, b)
     assert ForwardPass._delivery
@@ -428,26 +425,19 @@ def test_spatial_model_chunks_on_the_device_equal_the_generate_path(cfg,
     ids = [int(i) for i in st.node_chunks[0]]
     assert len(ids) >= 12
 
-    def run(batch):
+    def run(batch, **options):
         return {c.index: np.array(d) for c, failed, d in
                 ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids),
-                                        m, batch=batch) if not failed}
-    try:
-        ForwardPass.device_chunks_4d = False
-        ref = run(1)
-    finally:
-        ForwardPass.device_chunks_4d = True
+                                        m, batch=batch, options=options)
+                if not failed}
+    ref = run(1, device_chunks_4d=False)
     assert len(ref) == len(ids)
     c0 = fwp.get_input_chunk(ids[0])
     assert ForwardPass._device_path(m, c0)
     for batch, dev_norm in ((1, True), (3, True), (3, False)):
         # (dev_norm: transpose to time-major + norm_input in
         # s3_chunk_time_first, numpy's fp32 arithmetic; False: host numpy)
-        ForwardPass.device_norm_4d = dev_norm
-        try:
-            got = run(batch)
-        finally:
-            ForwardPass.device_norm_4d = True
+        got = run(batch, device_norm_4d=dev_norm)
         assert sorted(got) == sorted(ref)
         for k in ref:
             assert got[k].shape == ref[k].shape and got[k].ndim == 4
@@ -457,11 +447,7 @@ def test_spatial_model_chunks_on_the_device_equal_the_generate_path(cfg,
                         spatial_pad=2, temporal_pad=3, max_nodes=1, model=m)
     fwp = ForwardPass(st2, 0)
     ids = [int(i) for i in st2.node_chunks[0]]
-    try:
-        ForwardPass.device_chunks_4d = False
-        ref = run(1)
-    finally:
-        ForwardPass.device_chunks_4d = True
+    ref = run(1, device_chunks_4d=False)
     got = run(3)
     for k in ref:
         if precision == 'f32':
@@ -514,19 +500,16 @@ def test_spatial_model_with_exo_chunks_on_the_device():
     ids = [int(i) for i in st.node_chunks[0]]
     assert len(ids) == 8
 
-    def run(batch):
+    def run(batch, **options):
         return {c.index: np.array(d) for c, failed, d in
                 ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids),
-                                        m, batch=batch) if not failed}
+                                        m, batch=batch, options=options)
+                if not failed}
     c0 = fwp.get_input_chunk(ids[0])
     assert c0.exo_data['topography']['steps'][1]['data'].ndim == 4
     assert ForwardPass._device_path(m, c0)
-    try:
-        ForwardPass.device_chunks_4d = False
-        assert not ForwardPass._device_path(m, c0)
-        ref = run(1)
-    finally:
-        ForwardPass.device_chunks_4d = True
+    assert not ForwardPass._device_path(m, c0, {'device_chunks_4d': False})
+    ref = run(1, device_chunks_4d=False)
     assert len(ref) == len(ids)
     for batch in (1, 4):
         got = run(batch)
@@ -841,18 +824,15 @@ def test_multi_step_chain_of_spatial_steps_on_the_device():
     ids = [int(i) for i in stg.node_chunks[0]]
     assert len(ids) == 8
 
-    def run(batch):
+    def run(batch, **options):
         return {c.index: np.array(d) for c, failed, d in
                 ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids),
-                                        ms, batch=batch) if not failed}
+                                        ms, batch=batch, options=options)
+                if not failed}
     c0 = fwp.get_input_chunk(ids[0])
     assert ForwardPass._device_path(ms, c0)
-    try:
-        ForwardPass.device_chains = False
-        assert not ForwardPass._device_path(ms, c0)
-        ref = run(1)
-    finally:
-        ForwardPass.device_chains = True
+    assert not ForwardPass._device_path(ms, c0, {'device_chains': False})
+    ref = run(1, device_chains=False)
     assert len(ref) == len(ids)
     for batch in (1, 3):
         got = run(batch)
@@ -923,16 +903,13 @@ def test_multi_step_chain_spatial_then_temporal_on_the_device():
     ids = [int(i) for i in stg.node_chunks[0]]
     assert len(ids) == 8
 
-    def run(batch):
+    def run(batch, **options):
         return {c.index: np.array(d) for c, failed, d in
                 ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids),
-                                        ms, batch=batch) if not failed}
+                                        ms, batch=batch, options=options)
+                if not failed}
     assert ForwardPass._device_path(ms, fwp.get_input_chunk(ids[0]))
-    try:
-        ForwardPass.device_chains = False
-        ref = run(1)
-    finally:
-        ForwardPass.device_chains = True
+    ref = run(1, device_chains=False)
     assert len(ref) == 8
     for batch in (1, 3):
         got = run(batch)
@@ -1014,16 +991,13 @@ def test_window_forward_equals_full_forward_then_crop(temporal_pad):
     ids = [int(i) for i in st.node_chunks[0]]
 
     def run(window):
-        ForwardPass.window_forward = window
-        try:
-            out = {}
-            for c, failed, d in ForwardPass.iter_chunks(
-                    (fwp.get_input_chunk(i) for i in ids), m, batch=3):
-                assert not failed
-                out[c.index] = np.array(d)
-            return out
-        finally:
-            ForwardPass.window_forward = True
+        out = {}
+        for c, failed, d in ForwardPass.iter_chunks(
+                (fwp.get_input_chunk(i) for i in ids), m, batch=3,
+                options={'window_forward': window}):
+            assert not failed
+            out[c.index] = np.array(d)
+        return out
     ph = m._gen.plan((3, 8, 8, 4 + 2 * tp, 4), training=False)
     assert ph.supports_window
     got, ref = run(True), run(False)

@@ -288,6 +288,68 @@ def test_surface_forward_backward_bf16(rel):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(1, 5, 4, 3, 6), (1, 12, 8, 3, 6)])
+def test_no_residual_stack_bf16_backward_segment_by_segment(shape):
+    """sup3rcc/gen_wind_1x_24x_6f in bf16 (the spec whose end-to-end gradient
+    bound is ``BF16_GRAD_TOL`` = 1e-1): the backward kernels of EVERY layer
+    at the usual 2e-2, by cutting the 37-conv stack into overlapping segments
+    of 6 fused ops at the shapes the full plan gives them — each segment is a
+    network of its own with a fresh output gradient, so no rounding of dPre is
+    amplified by more than five layers.  Segments overlap by one op (the first
+    op of a segment reads an fp32 plan input instead of the previous layer's
+    bf16 cells: it may select other kernels and is the one not counted), and
+    every counted op must run on the kernels the full plan selects for it —
+    asserted through ``s3_plan_op_info`` (forward / weight gradient / data
+    gradient)."""
+    from oracle.network import expand_repeats
+    from sup3r_amd.engine import Network
+    from tests.test_parity_r02 import _fwd_bwd_vs_oracle
+    rel = 'sup3rcc/gen_wind_1x_24x_6f.json'
+    layers = expand_repeats(load_surface(rel)['hidden_layers'])
+    plan = S.build_plan(S.parse_layers(layers), shape)
+    assert len(plan.layer_out) == len(layers)
+    ends = [li for li, (_, oi) in enumerate(plan.layer_out)
+            if oi >= 0 and (li + 1 == len(layers) or
+                            plan.layer_out[li + 1][1] != oi)]
+    op_of_end = [plan.layer_out[li][1] for li in ends]
+    assert op_of_end == sorted(set(op_of_end)) and len(ends) >= 37
+    full = Network(layers, precision='bf16')
+    full.build(shape, seed=0)
+    phf = full.plan(shape, training=True)
+    kinds = {oi: tuple(phf.op_info(oi)[f] for f in ('fwd', 'wgrad', 'dgrad'))
+             for oi, op in enumerate(phf.plan.ops) if op['kind'] == S.OP_CONV}
+    del phf
+    full.clear_plans()
+    seg, counted, worst = 6, set(), 0.0
+    k = 0
+    while k < len(ends):
+        a = ends[k - 1] + 1 if k else 0            # first layer of the segment
+        b = ends[min(k + seg, len(ends)) - 1]      # its last layer
+        sub = layers[a:b + 1]
+        in_shape = tuple(shape) if k == 0 else \
+            tuple(plan.layer_out_shapes[a - 1])
+        ph = _fwd_bwd_vs_oracle(sub, in_shape, 'bf16', 400 + k, 3e-2, 2e-2)
+        sub_ops = [oi for oi, op in enumerate(ph.plan.ops)]
+        first_full = op_of_end[k]
+        for j in sub_ops:
+            if ph.plan.ops[j]['kind'] != S.OP_CONV:
+                continue
+            got = tuple(ph.op_info(j)[f] for f in ('fwd', 'wgrad', 'dgrad'))
+            want = kinds[first_full + j]
+            if j == 0 and k > 0:
+                continue                           # (fp32 input: not counted)
+            # (the first op of the NETWORK has no data gradient in the full
+            # plan's selection either way)
+            assert got == want, (k, j, got, want)
+            counted.add(first_full + j)
+        del ph
+        if b == ends[-1]:
+            break
+        k += seg - 1
+    assert counted == set(kinds), sorted(set(kinds) - counted)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('rel', sorted(c for c in CASES if 'gen_' in c))
 def test_surface_forward_bf16x3_meets_the_fp32_tolerance(rel):
     """the mode that owns north_star's L-inf < 1e-3: every shipped generator"""

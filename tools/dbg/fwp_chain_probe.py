@@ -53,11 +53,11 @@ fwp = ForwardPass(st, 0)
 ids = [int(i) for i in st.node_chunks[0]]
 print(len(ids), 'chunks of', chunk, 'batch', batch, flush=True)
 for name, on in (('device chain', True), ('host chain (MultiStepGan.generate)', False)):
-    ForwardPass.device_chains = on
     for rep in range(2):
         t0 = time.perf_counter()
         n = 0
-        for c, failed, d in ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids), ms, batch=batch):
+        for c, failed, d in ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids), ms, batch=batch,
+                                                    options={'device_chains': on}):
             assert not failed
             n += 1
             last = d
@@ -66,7 +66,6 @@ for name, on in (('device chain', True), ('host chain (MultiStepGan.generate)', 
 if os.environ.get('PROFILE'):
     import cProfile
     import pstats
-    ForwardPass.device_chains = True
     pr = cProfile.Profile()
     pr.enable()
     for c, failed, d in ForwardPass.iter_chunks((fwp.get_input_chunk(i) for i in ids), ms, batch=batch):
