@@ -72,6 +72,7 @@
   X(NO_WS_EXO) \
   X(NO_WS_RES2) \
   X(NO_WS_PP) \
+  X(NO_WS_X3) \
   X(NO_CONV2D_HEAD) \
   X(KEEP_ACTIVATIONS) \
   X(NO_MFMA_BWD) \
@@ -343,6 +344,13 @@ bool conv2d_ws_tail_geom_ok(const ConvGeom& g);   // 64 -> C_out <= 16 output co
 bool conv2d_ws_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);
 size_t conv2d_ws_image_bytes(const ConvGeom& g);
 int launch_conv2d_ws_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
+// ... and in the BF16X3 mode (kernels_conv2d_ws_x3.hip): fp32 cells in / out, the contraction split in
+// two K passes of 32 channels whose [hi | lo] operands have the bf16 kernel's LDS shapes
+bool conv2d_ws_x3_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);
+size_t conv2d_ws_x3_image_bytes(const ConvGeom& g);
+int launch_conv2d_ws_x3_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
+int launch_conv2d_ws_x3(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias,
+                        const void* res, void* y);
 // ... and the few-feature head conv of those generators (C_in 1 / 2 -> 64, fp32 field in, bf16 out)
 bool conv2d_head_geom_ok(const ConvGeom& g);
 bool conv2d_head_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);

@@ -246,6 +246,7 @@ size_t conv_mfma_gen_packed_bytes(const ConvGeom& g, int precision) {
   size_t b = (size_t)((g.Cout + CT - 1) / CT) * npass * m.ka * 9 * CT * CIN * 2;
   // the weights-stationary 2-D kernel's image rides behind the tile image
   if (precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g) || conv2d_ws_frame_geom_ok(g))) b += conv2d_ws_image_bytes(g);
+  if (precision == S3_PREC_BF16X3 && conv2d_ws_geom_ok(g) && !conv2d_ws_tail_geom_ok(g)) b += conv2d_ws_x3_image_bytes(g);
   // ... or the few-feature head kernel's (exclusive: C_in 1 / 2 there, 64 above)
   if (precision == S3_PREC_BF16 && conv2d_head_geom_ok(g)) b += conv2d_head_image_bytes(g);
   return b;
@@ -276,6 +277,8 @@ int launch_conv_mfma_gen_pack(s3_ctx* ctx, const ConvGeom& g, int precision, con
     hipLaunchKernelGGL(pack_gen_bf16_kernel, dim3(grid), dim3(256), 0, ctx->stream, w, (unsigned short*)packed, ltaps,
                        g.Cin, g.Cout, n_ct, npass, m.tp[0], m.tp[1], m.tp[2]);
   S3_HIP(ctx, hipGetLastError());
+  if (precision == S3_PREC_BF16X3 && conv2d_ws_geom_ok(g) && !conv2d_ws_tail_geom_ok(g) && !g.w_cin)
+    return launch_conv2d_ws_x3_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka));
   if (precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g) || conv2d_ws_frame_geom_ok(g)))
     return launch_conv2d_ws_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka));
   if (precision == S3_PREC_BF16 && conv2d_head_geom_ok(g))
@@ -290,6 +293,8 @@ int launch_conv_mfma_gen_fwd(s3_ctx* ctx, const ConvGeom& g, int precision, cons
   if (io.in_bf16 && g.Cin % 8 != 0) S3_FAIL(ctx, S3_ESTATE, "gen MFMA conv: bf16 input needs C_in % 8 == 0");
   if (conv2d_ws_supported(g, precision, io, res != nullptr))
     return launch_conv2d_ws(ctx, g, x, (const char*)packed + gen_tile_image_bytes(g, precision, m.ka), bias, res, y);
+  if (conv2d_ws_x3_supported(g, precision, io, res != nullptr))
+    return launch_conv2d_ws_x3(ctx, g, x, (const char*)packed + gen_tile_image_bytes(g, precision, m.ka), bias, res, y);
   if (conv2d_head_supported(g, precision, io, res != nullptr))
     return launch_conv2d_head(ctx, g, x, (const char*)packed + gen_tile_image_bytes(g, precision, m.ka), bias, y);
   if (g.w_cin || g.ws_only || g.res2) S3_FAIL(ctx, S3_ESTATE, "conv planned for the weights-stationary kernel launched off it");
