@@ -498,7 +498,7 @@ def fwd2d_leg(dev, steps=20, warmup=3, batch=48, seed=42):
 def fwp2d_executor_leg(rank=0, batch=4, reps=3):
     """the same spec through the reference's executor entry
     (ForwardPassStrategy-shaped chunks -> ForwardPass.get_input_chunk ->
-    iter_chunks): a (150, 150, 190) lo-res domain in 75 x 75 x 38 chunks with
+    iter_chunks): a (150, 150, 760) lo-res domain in 75 x 75 x 38 chunks with
     temporal_pad 5, normalisation statistics set, cropped (150, 150, 38, 2)
     hi-res chunks delivered to the host — 2-D models run their chunks' time
     steps as the batch (forward_pass.py:274-337)"""
@@ -515,8 +515,12 @@ def fwp2d_executor_leg(rank=0, batch=4, reps=3):
     m.set_model_params(lr_features=feats, hr_out_features=feats, s_enhance=2,
                        t_enhance=1)
     m.init_weights((1, 16, 16, 2), (1, 32, 32, 2))
+    # (80 chunks = 20 launch sequences per pass: with the 20-chunk domain of round
+    # 5 a pass was 5 sequences and a quarter of its time was the fill and drain of
+    # the three-deep pipeline — 3.6 ms per pass in the rocprofv3 timeline,
+    # profiles/r06/README.md — not the executor's steady state)
     domain = np.random.default_rng(7 + rank).standard_normal(
-        (150, 150, 190, 2)).astype(np.float32)
+        (150, 150, 760, 2), dtype=np.float32)
     register_model('Sup3rGan', {'model_dir': 'bench-fwp2d'}, m)
     st = ArrayStrategy(domain, {'model_dir': 'bench-fwp2d'}, (75, 75, 38),
                        spatial_pad=0, temporal_pad=5, max_nodes=1, model=m)
@@ -536,7 +540,7 @@ def fwp2d_executor_leg(rank=0, batch=4, reps=3):
             'chunks_per_launch_sequence': batch,
             'px_per_sec': n / best * 150 * 150 * 38,
             'workload': 'config_fwp_spatial.json shape: 75 x 75 x 38 chunks + '
-                        'temporal_pad 5 of a (150, 150, 190, 2) domain through '
+                        'temporal_pad 5 of a (150, 150, 760, 2) domain through '
                         'ForwardPass.get_input_chunk -> iter_chunks, cropped '
                         '(150, 150, 38, 2) fp32 chunks delivered to the host'}
 

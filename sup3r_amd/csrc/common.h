@@ -73,6 +73,7 @@
   X(NO_WS_RES2) \
   X(NO_WS_PP) \
   X(NO_WS_X3) \
+  X(NO_CONV2D_OUT) \
   X(NO_CONV2D_HEAD) \
   X(KEEP_ACTIVATIONS) \
   X(NO_MFMA_BWD) \
@@ -344,6 +345,13 @@ bool conv2d_ws_tail_geom_ok(const ConvGeom& g);   // 64 -> C_out <= 16 output co
 bool conv2d_ws_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);
 size_t conv2d_ws_image_bytes(const ConvGeom& g);
 int launch_conv2d_ws_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
+// the few-feature 2-D output conv with the taps as matrix columns (kernels_conv2d_out.hip):
+// 64 -> C_out <= 7, bf16 cells (bf16 plans) or fp32 cells (BF16X3 plans) in, fp32 out
+bool conv2d_out_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);
+size_t conv2d_out_image_bytes(const ConvGeom& g);
+int launch_conv2d_out_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
+int launch_conv2d_out(s3_ctx* ctx, const ConvGeom& g, int precision, const void* x, const void* image,
+                      const float* bias, void* y);
 // ... and in the BF16X3 mode (kernels_conv2d_ws_x3.hip): fp32 cells in / out, the contraction split in
 // two K passes of 32 channels whose [hi | lo] operands have the bf16 kernel's LDS shapes
 bool conv2d_ws_x3_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);

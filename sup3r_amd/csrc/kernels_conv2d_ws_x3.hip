@@ -22,11 +22,10 @@
 //     "k-steps" of the bf16 tap loop become the hi and lo halves, and a tap is
 //     W_hi X_hi + W_hi X_lo + W_lo X_hi: 16 fragment reads for 48 MFMAs;
 //   * the accumulators stay in registers across the two passes of a tile;
-//   * passes run in ZIG-ZAG order over a workgroup's tiles (A B | B A | A B ..):
-//     the 72 KB filter image is swapped once per tile (from L2: every workgroup
-//     reads the same two images), the halo half of the next pass is fetched
-//     into registers under the current pass's tap loop (fp32 -> hi / lo split on
-//     its way into LDS).
+//   * the 72 KB filter image is swapped between the passes (from L2: every
+//     workgroup reads the same two images), the halo half of the next pass is
+//     fetched into registers under the current pass's tap loop (fp32 -> hi / lo
+//     split on its way into LDS).
 //
 // One 8-wave workgroup per CU walks a contiguous, XCD-major run of 2 images x 16
 // rows x 16 columns tiles.  MFMA time per tile and SIMD: 2 waves x 864 MFMAs x 16
@@ -201,15 +200,12 @@ __global__ __launch_bounds__(X_NT) void conv2d_ws_x3_kernel(
     _Pragma("unroll") for (int q = 0; q < 9; ++q) dst_[tid + q * X_NT] = wr_[q];                \
   }
 
-  // The pass a tile STARTS with is a function of its place in its image pair
-  // (parity of the tile index within the pair), not of its place in this
-  // workgroup's run: a position's sum is bias + first pass + second pass in an
-  // order that does not depend on the batch size or the grid (sample by sample ==
-  // the batch, bit for bit).  Consecutive tiles of a pair alternate, so the
-  // resident image serves the next tile's first pass; where they do not (the
-  // first tile of the next pair after an odd count) the image is swapped once more.
-  const int tpp = g.tiles_r * g.tiles_c;
-  int pass = (t_cur % tpp) & 1;     // the pass whose filter image is in LDS
+  // Every tile runs pass A (channels 0 .. 31) then pass B: a position's sum is bias
+  // + A + B in that order whatever the batch size, the grid or the form of the
+  // kernel (sample by sample == the batch, lock-step == ping-pong, bit for bit).
+  // This form therefore swaps the filter image twice per tile; it is the A/B
+  // fallback (option NO_WS_PP) of the ping-pong form below.
+  int pass = 0;                     // the pass whose filter image is in LDS
   X3_FETCH(t_cur, pass);
   X3_LOAD_IMAGE(pass);
   if (tid < 64) {
@@ -296,8 +292,8 @@ __global__ __launch_bounds__(X_NT) void conv2d_ws_x3_kernel(
     X3_LOAD_IMAGE(pass);
     X3_COMMIT();
     __syncthreads();
-    // ---- second pass; the next tile usually starts with this pass's image (zig-zag)
-    const int next_first = ((t_cur + 1) % tpp) & 1;
+    // ---- second pass; the next tile starts with pass A again
+    const int next_first = 0;
     if (has_next && !(g.dbg & 1)) X3_FETCH(t_cur + 1, next_first);
     X3_TAPS()
     if (has_next) {

@@ -238,6 +238,15 @@ bool conv_dgrad_gen_supported(const ConvGeom& g, int precision) {
 
 bool conv_mfma_gen_in16_ok(const ConvGeom& g) { return g.Cin % 8 == 0; }
 
+// the few-feature output conv's fragment image rides last (kernels_conv2d_out.hip)
+static bool out_geom(const ConvGeom& g, int precision) {
+  return (precision == S3_PREC_BF16 || precision == S3_PREC_BF16X3) && g.Cout <= 7 && !g.w_cin &&
+         conv2d_ws_tail_geom_ok(g);
+}
+static size_t out_image_offset(const ConvGeom& g, int precision, size_t tile_bytes) {
+  return tile_bytes + (precision == S3_PREC_BF16 ? conv2d_ws_image_bytes(g) : 0);
+}
+
 size_t conv_mfma_gen_packed_bytes(const ConvGeom& g, int precision) {
   GenMap m;
   if (!gen_map(g, precision, &m)) return 16;
@@ -247,6 +256,7 @@ size_t conv_mfma_gen_packed_bytes(const ConvGeom& g, int precision) {
   // the weights-stationary 2-D kernel's image rides behind the tile image
   if (precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g) || conv2d_ws_frame_geom_ok(g))) b += conv2d_ws_image_bytes(g);
   if (precision == S3_PREC_BF16X3 && conv2d_ws_geom_ok(g) && !conv2d_ws_tail_geom_ok(g)) b += conv2d_ws_x3_image_bytes(g);
+  if (out_geom(g, precision)) b += conv2d_out_image_bytes(g);
   // ... or the few-feature head kernel's (exclusive: C_in 1 / 2 there, 64 above)
   if (precision == S3_PREC_BF16 && conv2d_head_geom_ok(g)) b += conv2d_head_image_bytes(g);
   return b;
@@ -263,6 +273,11 @@ int launch_conv_mfma_gen_pack(s3_ctx* ctx, const ConvGeom& g, int precision, con
   const bool x3 = precision == S3_PREC_BF16X3;
   const int kch = x3 ? 32 : 64;
   const int npass = (g.Cin + kch - 1) / kch, ltaps = m.ka * 9, n_ct = (g.Cout + CT - 1) / CT;
+  if (out_geom(g, precision)) {
+    const int rc = launch_conv2d_out_pack(
+        ctx, g, w, (char*)packed + out_image_offset(g, precision, gen_tile_image_bytes(g, precision, m.ka)));
+    if (rc) return rc;
+  }
   // (a conv with an exogenous channel split off runs on the weights-stationary
   // kernel only: its tile image is never read)
   if (g.w_cin || (g.ws_only && precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g) || conv2d_ws_frame_geom_ok(g))))
@@ -291,6 +306,10 @@ int launch_conv_mfma_gen_fwd(s3_ctx* ctx, const ConvGeom& g, int precision, cons
   GenMap m;
   if (!gen_map(g, precision, &m)) S3_FAIL(ctx, S3_ESTATE, "gen MFMA conv: launch of an unsupported geometry");
   if (io.in_bf16 && g.Cin % 8 != 0) S3_FAIL(ctx, S3_ESTATE, "gen MFMA conv: bf16 input needs C_in % 8 == 0");
+  if (out_geom(g, precision) && conv2d_out_supported(g, precision, io, res != nullptr))
+    return launch_conv2d_out(ctx, g, precision, x,
+                             (const char*)packed + out_image_offset(g, precision, gen_tile_image_bytes(g, precision, m.ka)),
+                             bias, y);
   if (conv2d_ws_supported(g, precision, io, res != nullptr))
     return launch_conv2d_ws(ctx, g, x, (const char*)packed + gen_tile_image_bytes(g, precision, m.ka), bias, res, y);
   if (conv2d_ws_x3_supported(g, precision, io, res != nullptr))

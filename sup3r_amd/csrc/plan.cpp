@@ -1843,7 +1843,8 @@ static int conv_fwd_kind(const s3_plan* pl, const OpRec& o) {
   if (o.mfma) {
     fwd = conv_mfma_is_gen(o.cg, pl->precision)
               ? (conv2d_ws_supported(o.cg, pl->precision, o.io, res) ||
-                 conv2d_ws_x3_supported(o.cg, pl->precision, o.io, res)  ? S3_FWD_CONV2D_WS
+                 conv2d_ws_x3_supported(o.cg, pl->precision, o.io, res) ||
+                 conv2d_out_supported(o.cg, pl->precision, o.io, res)    ? S3_FWD_CONV2D_WS
                  : conv2d_head_supported(o.cg, pl->precision, o.io, res) ? S3_FWD_CONV2D_HEAD
                                                                          : S3_FWD_MFMA_GEN)
           : bfp && conv_mfma_persist_supported(pl->ctx, o.cg, o.io, res) ? S3_FWD_MFMA_PERSIST : S3_FWD_MFMA_TILE;

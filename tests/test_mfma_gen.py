@@ -279,6 +279,10 @@ ONE_HOT = [
     ('2d', 2, (5, 21, 19, 3)),
     # 2-D, one image, 16 x 16 exactly one tile
     ('2d', 2, (1, 16, 16, 3)),
+    # 2-D at >= 64 x 64 hi-res cells per image: the 64 -> 2 output conv on the
+    # taps-as-columns kernel (kernels_conv2d_out.hip), ragged 14-column strips
+    # (72 = 5 x 14 + 2) and row segments
+    ('2d', 2, (3, 40, 36, 3)),
     # 3-D over T = 3 (run along s2), 64 -> 128 depth_to_time 2
     ('3d_small_t', 3, (2, 17, 18, 3, 5)),
     # 3-D, long T, C_in = 70 (two K passes), C_out = 72 d2s 2 (18-channel

@@ -122,6 +122,42 @@ def test_gen_2x_2f_at_the_bench_shape_vs_oracle(shape):
             f'{rel} bf16 inference plan {shape}')
 
 
+def test_gen_2x_2f_bf16x3_at_the_bench_shape_meets_the_fp32_tolerance():
+    """the mode that owns north_star's L-inf < 1e-3 on the production 2-D chunk:
+    BF16X3 plans run the 64 -> 64 k convs on conv2d_ws_x3_pp_kernel (two K passes of
+    [hi | lo] operands, ping-pong half-workgroups, 2 .. 3 tiles each at this shape)
+    and the 64 -> 2 output conv on conv2d_out_kernel<X3>; the oracle on the first
+    two and the last image"""
+    from tests.test_parity_r02 import _hip, _oracle
+    rel = 'spatial/gen_2x_2f.json'
+    spec = load_surface(rel)
+    shape = (48, 75, 75, 2)
+    rng = np.random.default_rng(611)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = _oracle(spec, x[:1], None, seed=64)
+    y_head, y_last = ref.forward(x[:2]), ref.forward(x[-1:])
+    net = _hip(spec, ref.weights, 'bf16x3')
+    ph = net.plan(shape, training=False)
+    sel = _selection(ph)
+    assert sel.count('conv2d_ws') >= 35, sel
+    y = ph.forward(net.dev.to_device(x)).cpu().numpy()
+    e_head = float(np.abs(y[:2] - y_head).max())
+    e_last = float(np.abs(y[-1:] - y_last).max())
+    print(f'{rel} bf16x3 {shape}: L-inf vs the fp32 oracle {e_head:.2e} / '
+          f'{e_last:.2e} (scale {np.abs(y_head).max():.2f})')
+    assert e_head < 1e-3 and e_last < 1e-3, (e_head, e_last)
+    # the logical-axes tile kernel (option NO_CONV2D_WS: what these plans ran on
+    # before round 6) agrees at the same level
+    alt = net.plan(shape, training=False, options={'NO_CONV2D_WS': 1})
+    assert _selection(alt).count('conv2d_ws') == 0
+    ya = alt.forward(net.dev.to_device(x)).cpu().numpy()
+    assert float(np.abs(ya - y).max()) < 1e-3
+    # lock-step form of the X3 kernel (option NO_WS_PP): same MFMAs per position in
+    # the same pass order -> the same bits
+    lock = net.plan(shape, training=False, options={'NO_WS_PP': 1})
+    np.testing.assert_array_equal(lock.forward(net.dev.to_device(x)).cpu().numpy(), y)
+
+
 # (b) the second step of the reference's wind chain (sup3rcc/gen_wind_5x_1x_6f +
 # topography): 16 hi-res 64 -> 64 convs with skip operands, the conv with TWO skip
 # operands (res2), the exogenous-channel form and the 64 -> 6 output conv, all at
