@@ -162,8 +162,12 @@ def condmom_leg(batch, lr_s, hr_s, min_seconds, max_steps):
     mask = dev.to_device(np.ones((batch,) + hr_s, np.float32))
     m.init_weights(lr.shape, out.shape)
 
+    import types
+    batch_ = types.SimpleNamespace(low_res=lr, output=out, mask=mask)
+
     def step():
-        return m.run_gradient_descent(lr, out, None, mask=mask)
+        # (what _train_epoch runs per mini-batch; the loss scalars read back)
+        return m._train_step(batch_).resolve()
     for _ in range(4):
         det = step()
     torch.cuda.synchronize()

@@ -44,7 +44,7 @@ logger = logging.getLogger(__name__)
 class _Recorded:
     def __init__(self):
         self.graph = None
-        self.low_res = self.high_res = None
+        self.inputs = {}          # field name -> recorded input buffer
         self.retained = []        # every buffer of the step
         self.opt_steps = []       # (net, optimizer) in launch order
         self.futures = []         # (scal, recipe, scale) per network step
@@ -72,8 +72,12 @@ class StepRecorder:
     # again (stale plan epoch / options / optimizer objects) go at once.
     MAX_RECORDS = 6
 
-    def __init__(self, compute):
+    def __init__(self, compute, fields=('low_res', 'high_res')):
+        """``fields``: the attributes of a batch the step reads (``Sup3rGan``:
+        low_res / high_res; ``Sup3rCondMom``: low_res / output / mask) — each
+        gets a static device buffer the batch is copied into before a replay"""
         self.compute = compute
+        self.fields = tuple(fields)
         self.dev = compute.dev
         self._entries = collections.OrderedDict()
         self.replays = 0
@@ -97,8 +101,9 @@ class StepRecorder:
         """drop the records no key can reach any more, then the least recently
         used ones beyond MAX_RECORDS (``live`` = (options_key, plan epochs,
         optimizer ids) of the step being run)"""
-        stale = [k for k in self._entries if (k[2], k[3]) != live[:2]
-                 or not set(i for i, _ in k[4]) <= live[2]]
+        # key = (input shapes, options_key, plan epochs, optimizers, digest, ...)
+        stale = [k for k in self._entries if (k[1], k[2]) != live[:2]
+                 or not set(i for i, _ in k[3]) <= live[2]]
         for k in stale:
             self._drop(k)
         recorded = [k for k, e in self._entries.items() if e['rec'] is not None]
@@ -130,13 +135,16 @@ class StepRecorder:
             return False
         if any(isinstance(kind, str) for _, kind, _, _ in model._loss_terms):
             return False
-        if getattr(batch, 'high_res', None) is None:
+        if any(getattr(batch, f, None) is None for f in self.fields):
             return False
         if mode == 'auto':
-            n = 1
-            for v in batch.high_res.shape:
-                n *= int(v)
-            return n <= self.MAX_ELEMS
+            worst = 0
+            for f in self.fields:
+                n = 1
+                for v in getattr(batch, f).shape:
+                    n *= int(v)
+                worst = max(worst, n)
+            return worst <= self.MAX_ELEMS
         return True
 
     def run(self, batch, key, optimizers, body, model=None):
@@ -146,7 +154,7 @@ class StepRecorder:
         nets = [n for n in (self.compute.gen, self.compute.disc)
                 if n is not None]
         epochs = tuple(getattr(n, 'plan_epoch', 0) for n in nets)
-        key = (tuple(batch.low_res.shape), tuple(batch.high_res.shape),
+        key = (tuple(tuple(getattr(batch, f).shape) for f in self.fields),
                self.dev.options_key, epochs,
                tuple((id(o), o.KIND) for o in optimizers),
                self._state_digest(model, nets) if model is not None else ()
@@ -180,17 +188,14 @@ class StepRecorder:
 
     # ------------------------------------------------------------- internals
     def _resident(self, batch):
-        dev = self.dev
-
-        class Resident:
-            low_res = dev.to_device(batch.low_res)
-            high_res = dev.to_device(batch.high_res)
-        return Resident
+        import types
+        return types.SimpleNamespace(**{
+            f: self.dev.to_device(getattr(batch, f)) for f in self.fields})
 
     def _load(self, rec, batch):
         torch = _torch()
-        for dst, src in ((rec.low_res, batch.low_res),
-                         (rec.high_res, batch.high_res)):
+        for f in self.fields:
+            dst, src = rec.inputs[f], getattr(batch, f)
             if not isinstance(src, torch.Tensor):
                 src = self.dev.to_device(src)
             dst.copy_(src.reshape(dst.shape))
@@ -199,11 +204,10 @@ class StepRecorder:
         L = _lib.lib()
         dev, compute = self.dev, self.compute
         rec = _Recorded()
-        rec.low_res = dev.empty(tuple(batch.low_res.shape))
-        rec.high_res = dev.empty(tuple(batch.high_res.shape))
-
-        class Static:
-            low_res, high_res = rec.low_res, rec.high_res
+        import types
+        for f in self.fields:
+            rec.inputs[f] = dev.empty(tuple(getattr(batch, f).shape))
+        Static = types.SimpleNamespace(**rec.inputs)
         for n in nets:            # every filter pack becomes part of the graph
             n.touch()
         _lib.check(L.s3_capture_begin(dev.ctx), dev.ctx, 's3_capture_begin')

@@ -32,6 +32,17 @@ class _Reported(LossFuture):
         return {k: full[k] for k in _REPORTED}
 
     @property
+    def _recipe(self):
+        # (a recorded step rebuilds its futures from (scal, recipe, scale):
+        # captured.py)
+        inner = self._inner._recipe
+
+        def narrowed(vals):
+            full = inner(vals)
+            return {k: full[k] for k in _REPORTED}
+        return narrowed
+
+    @property
     def _scale(self):
         return self._inner._scale
 
@@ -129,6 +140,41 @@ class Sup3rCondMom(Sup3rGan):
         return self._val_window.means()
 
     # ---- training
+    def _train_step(self, batch, multi_gpu=False):
+        """one mini-batch (conditional.py:363-489's loop body): gradients of
+        the masked loss + one optimizer step, returned as a ``LossFuture``.  A
+        launch-bound step (``capture_steps``, as ``Sup3rGan._launch_batch``) is
+        recorded once and replayed as one hipGraphLaunch (captured.py) — at
+        BASELINE.md's shape (N, 4, 4, 4, 2) the ~250 launches of a step are all
+        a few microseconds long."""
+        def body(b):
+            return [self.run_gradient_descent(
+                b.low_res, b.output, None, optimizer=self.optimizer,
+                multi_gpu=multi_gpu, mask=b.mask, defer=True)]
+        rec = self._condmom_recorder(batch, multi_gpu)
+        if rec is not None:
+            return rec.run(batch, ('condmom',), [self.optimizer], body,
+                           model=self)[0]
+        return body(batch)[0]
+
+    def _condmom_recorder(self, batch, multi_gpu):
+        mode = self.capture_steps
+        if not mode or self._replica_layout(multi_gpu)[1] != 1:
+            return None
+        from .compute import HipGanCompute
+        own = (type(self).get_single_grad is Sup3rCondMom.get_single_grad
+               and type(self).run_gradient_descent
+               is Sup3rGan.run_gradient_descent
+               and type(self._compute) is HipGanCompute)
+        if not own:
+            return None
+        rec = getattr(self, '_recorder', None)
+        if rec is None or rec.compute is not self._compute:
+            from .captured import StepRecorder
+            rec = self._recorder = StepRecorder(
+                self._compute, fields=('low_res', 'output', 'mask'))
+        return rec if rec.eligible(self, batch, mode, False) else None
+
     def _train_epoch(self, batch_handler, multi_gpu=False):
         """One pass over the handler; nothing is read back from the device
         until the last batch is enqueued."""
@@ -137,9 +183,7 @@ class Sup3rCondMom(Sup3rGan):
         for batch in batch_handler:
             self.init_weights(batch.low_res.shape, batch.output.shape)
             self._sync_replicas()
-            pending.append(self.run_gradient_descent(
-                batch.low_res, batch.output, None, optimizer=self.optimizer,
-                multi_gpu=multi_gpu, mask=batch.mask, defer=True))
+            pending.append(self._train_step(batch, multi_gpu))
         for step in pending:
             details = step.resolve() if isinstance(step, LossFuture) else step
             self.update_loss_details(self._train_window, details, n)

@@ -363,8 +363,10 @@ int launch_conv2d_ws_x3(s3_ctx* ctx, const ConvGeom& g, const void* x, const voi
 bool conv2d_head_geom_ok(const ConvGeom& g);
 bool conv2d_head_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res);
 size_t conv2d_head_image_bytes(const ConvGeom& g);
-int launch_conv2d_head_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image);
-int launch_conv2d_head(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias, void* y);
+// (exact: BF16X3 plans — unrounded fp32 operands, fp32 cells out)
+int launch_conv2d_head_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image, int exact);
+int launch_conv2d_head(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias, void* y,
+                       int exact);
 int launch_conv2d_ws(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias,
                      const void* res, void* y);
 // persistent wave-specialised variant for the all-bf16 64 -> 64 trunk; its

@@ -777,10 +777,14 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
 // 197 registers a CU holds two workgroups, and 25-position segments at the production chunk
 // were 338 workgroups — a third of the CUs ran two of them back to back (27 us for 13 us of work)
 constexpr int HD_SEG = 5;
-template <int CIN>
+// F32 (BF16X3 plans): exact fp32 operands, fp32 cells out — the 9 C_in terms of an
+// output are plain fp32 FMAs, at least as close to the oracle as the three-product
+// split of the matrix path this layer used to run on (73 us at the production chunk)
+template <int CIN, bool F32 = false>
 __global__ __launch_bounds__(256) void conv2d_head_kernel(
     const float* __restrict__ x, const float* __restrict__ wimg, const float* __restrict__ bias,
-    unsigned short* __restrict__ y, int N, int H, int W, int act, float alpha) {
+    void* __restrict__ yv, int N, int H, int W, int act, float alpha) {
+  unsigned short* __restrict__ y = reinterpret_cast<unsigned short*>(yv);
   const int tid = threadIdx.x;
   const int cg = tid & 7;                       // output channels cg 8 .. cg 8 + 7
   const int nseg = (W + HD_SEG - 1) / HD_SEG;
@@ -799,7 +803,9 @@ __global__ __launch_bounds__(256) void conv2d_head_kernel(
 #pragma unroll
   for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[cg * 8 + j] : 0.f;
   const float slope = act == S3_ACT_LEAKY ? alpha : (act == S3_ACT_RELU ? 0.f : 1.f);
-  auto rnd = [](float v) __attribute__((always_inline)) { return __uint_as_float(ws_pk(v, 0.f) << 16); };
+  auto rnd = [](float v) __attribute__((always_inline)) {
+    return F32 ? v : __uint_as_float(ws_pk(v, 0.f) << 16);
+  };
 
   for (long long slot = (long long)blockIdx.x * 32 + (tid >> 3); slot < slots; slot += (long long)gridDim.x * 32) {
     const int seg = (int)(slot % nseg);
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(256) void conv2d_head_kernel(
     load_col(0, c_lo - 1);
     load_col(1, c_lo);
     load_col(2, c_lo + 1);
-    unsigned short* yo = y + (((size_t)n * H + r) * W + c_lo) * 64 + cg * 8;
+    unsigned short* yo = y + ((((size_t)n * H + r) * W + c_lo) * 64 + cg * 8) * (F32 ? 2 : 1);
     for (int c = c_lo; c < c_hi; ++c) {
       // column c + 2 is fetched one position ahead of its use (two waves per SIMD at 197
       // registers do not cover an L1 round trip per position)
@@ -852,10 +858,17 @@ __global__ __launch_bounds__(256) void conv2d_head_kernel(
         const float sa = slope * acc[j];
         asm("v_max_f32 %0, %1, %2" : "=v"(acc[j]) : "v"(acc[j]), "v"(sa));
       }
-      uint4 o;
-      o.x = ws_pk(acc[0], acc[1]); o.y = ws_pk(acc[2], acc[3]); o.z = ws_pk(acc[4], acc[5]); o.w = ws_pk(acc[6], acc[7]);
-      *reinterpret_cast<uint4*>(yo) = o;
-      yo += 64;
+      if constexpr (F32) {
+        float4* yf = reinterpret_cast<float4*>(yo);
+        yf[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        yf[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        yo += 128;
+      } else {
+        uint4 o;
+        o.x = ws_pk(acc[0], acc[1]); o.y = ws_pk(acc[2], acc[3]); o.z = ws_pk(acc[4], acc[5]); o.w = ws_pk(acc[6], acc[7]);
+        *reinterpret_cast<uint4*>(yo) = o;
+        yo += 64;
+      }
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -867,9 +880,9 @@ __global__ __launch_bounds__(256) void conv2d_head_kernel(
 }
 
 // canonical fp32 w[tap 9][ci][co 64] -> the same layout with bf16-rounded values
-__global__ void pack_head_kernel(const float* __restrict__ w, float* __restrict__ out, int n) {
+__global__ void pack_head_kernel(const float* __restrict__ w, float* __restrict__ out, int n, int exact) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = __uint_as_float(ws_pk(w[i], 0.f) << 16);
+  if (i < n) out[i] = exact ? w[i] : __uint_as_float(ws_pk(w[i], 0.f) << 16);
 }
 
 }  // namespace
@@ -1021,31 +1034,33 @@ bool conv2d_head_geom_ok(const ConvGeom& g) {
 }
 
 bool conv2d_head_supported(const ConvGeom& g, int precision, ConvIO io, bool has_res) {
-  if (precision != S3_PREC_BF16 || s3_opt_on(S3O_NO_CONV2D_WS) || s3_opt_on(S3O_NO_CONV2D_HEAD)) return false;
-  return conv2d_head_geom_ok(g) && !io.in_bf16 && io.out_bf16 && !has_res && !g.res2;
+  if (s3_opt_on(S3O_NO_CONV2D_WS) || s3_opt_on(S3O_NO_CONV2D_HEAD)) return false;
+  if (!conv2d_head_geom_ok(g) || io.in_bf16 || has_res || g.res2) return false;
+  if (precision == S3_PREC_BF16) return io.out_bf16 != 0;
+  if (precision == S3_PREC_BF16X3) return io.out_bf16 == 0;     // (exact fp32 form)
+  return false;
 }
 
 size_t conv2d_head_image_bytes(const ConvGeom& g) { return (size_t)9 * g.Cin * 64 * sizeof(float); }
 
-int launch_conv2d_head_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image) {
+int launch_conv2d_head_pack(s3_ctx* ctx, const ConvGeom& g, const float* w, void* image, int exact) {
   const int n = 9 * g.Cin * 64;
-  hipLaunchKernelGGL(pack_head_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, w, (float*)image, n);
+  hipLaunchKernelGGL(pack_head_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, w, (float*)image, n, exact);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }
 
-int launch_conv2d_head(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias, void* y) {
+int launch_conv2d_head(s3_ctx* ctx, const ConvGeom& g, const void* x, const void* image, const float* bias, void* y,
+                       int exact) {
   const int nseg = (g.D[1] + HD_SEG - 1) / HD_SEG;
   const int64_t slots = (int64_t)g.N * g.D[0] * nseg;
   int64_t grid = (slots + 31) / 32;
   // (all workgroups resident — two per CU — each walking its share of the items)
   if (grid > (int64_t)ctx->num_cu * 2) grid = (int64_t)ctx->num_cu * 2;
-  if (g.Cin == 1)
-    hipLaunchKernelGGL(conv2d_head_kernel<1>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const float*)x,
-                       (const float*)image, bias, (unsigned short*)y, g.N, g.D[0], g.D[1], g.act, g.alpha);
-  else
-    hipLaunchKernelGGL(conv2d_head_kernel<2>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const float*)x,
-                       (const float*)image, bias, (unsigned short*)y, g.N, g.D[0], g.D[1], g.act, g.alpha);
+  auto kern = g.Cin == 1 ? (exact ? conv2d_head_kernel<1, true> : conv2d_head_kernel<1, false>)
+                         : (exact ? conv2d_head_kernel<2, true> : conv2d_head_kernel<2, false>);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const float*)x, (const float*)image, bias,
+                     y, g.N, g.D[0], g.D[1], g.act, g.alpha);
   S3_HIP(ctx, hipGetLastError());
   return S3_OK;
 }

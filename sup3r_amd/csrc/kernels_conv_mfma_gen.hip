@@ -258,7 +258,7 @@ size_t conv_mfma_gen_packed_bytes(const ConvGeom& g, int precision) {
   if (precision == S3_PREC_BF16X3 && conv2d_ws_geom_ok(g) && !conv2d_ws_tail_geom_ok(g)) b += conv2d_ws_x3_image_bytes(g);
   if (out_geom(g, precision)) b += conv2d_out_image_bytes(g);
   // ... or the few-feature head kernel's (exclusive: C_in 1 / 2 there, 64 above)
-  if (precision == S3_PREC_BF16 && conv2d_head_geom_ok(g)) b += conv2d_head_image_bytes(g);
+  if (conv2d_head_geom_ok(g)) b += conv2d_head_image_bytes(g);
   return b;
 }
 
@@ -296,8 +296,9 @@ int launch_conv_mfma_gen_pack(s3_ctx* ctx, const ConvGeom& g, int precision, con
     return launch_conv2d_ws_x3_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka));
   if (precision == S3_PREC_BF16 && (conv2d_ws_geom_ok(g) || conv2d_ws_tail_geom_ok(g) || conv2d_ws_frame_geom_ok(g)))
     return launch_conv2d_ws_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka));
-  if (precision == S3_PREC_BF16 && conv2d_head_geom_ok(g))
-    return launch_conv2d_head_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka));
+  if (conv2d_head_geom_ok(g))
+    return launch_conv2d_head_pack(ctx, g, w, (char*)packed + gen_tile_image_bytes(g, precision, m.ka),
+                                   precision == S3_PREC_BF16X3);
   return S3_OK;
 }
 
@@ -315,7 +316,8 @@ int launch_conv_mfma_gen_fwd(s3_ctx* ctx, const ConvGeom& g, int precision, cons
   if (conv2d_ws_x3_supported(g, precision, io, res != nullptr))
     return launch_conv2d_ws_x3(ctx, g, x, (const char*)packed + gen_tile_image_bytes(g, precision, m.ka), bias, res, y);
   if (conv2d_head_supported(g, precision, io, res != nullptr))
-    return launch_conv2d_head(ctx, g, x, (const char*)packed + gen_tile_image_bytes(g, precision, m.ka), bias, y);
+    return launch_conv2d_head(ctx, g, x, (const char*)packed + gen_tile_image_bytes(g, precision, m.ka), bias, y,
+                              precision == S3_PREC_BF16X3);
   if (g.w_cin || g.ws_only || g.res2) S3_FAIL(ctx, S3_ESTATE, "conv planned for the weights-stationary kernel launched off it");
   if (precision == S3_PREC_BF16X3) {
     if (m.ka == 1) return launch_gen_prec<S3_PREC_BF16X3, 1>(ctx, m.l, x, packed, bias, res, y, io);

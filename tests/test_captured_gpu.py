@@ -122,9 +122,11 @@ def test_large_batches_and_structured_losses_stay_eager():
     rec = StepRecorder(m._compute)
 
     class Small:
+        low_res = np.zeros(LR, np.float32)
         high_res = np.zeros(HR, np.float32)
 
     class Large:
+        low_res = np.zeros((8, 16, 16, 24, 4), np.float32)
         high_res = np.zeros((8, 80, 80, 288, 2), np.float32)
     assert rec.eligible(m, Small, 'auto', False)
     assert not rec.eligible(m, Large, 'auto', False)
@@ -136,3 +138,48 @@ def test_large_batches_and_structured_losses_stay_eager():
                   os.path.join(CFG, 'disc_s_same.json'),
                   loss={'SpatialExtremesLoss': {}}, precision='bf16')
     assert not StepRecorder(m2._compute).eligible(m2, Small, True, False)
+
+
+def test_condmom_recorded_steps_are_the_eager_steps_bit_for_bit():
+    """``Sup3rCondMom._train_step`` (the loop body of
+    /root/reference/sup3r/models/conditional.py:363-489) at BASELINE.md's C5
+    shape — lr (4, 4, 4, 4, 2) -> (4, 12, 12, 16, 2), masked MSE: replayed
+    hipGraph steps == eager steps (weights bit for bit, loss values, optimizer
+    counter), the batch's three fields (low_res / output / mask) each through
+    its recorded input buffer"""
+    import types
+    import torch
+    from sup3r_amd import Sup3rCondMom
+    from sup3r_amd.engine import Device
+    lr_s, hr_s = (4, 4, 4, 4, 2), (4, 12, 12, 16, 2)
+
+    def run(capture):
+        Sup3rCondMom.seed(7)
+        m = Sup3rCondMom(os.path.join(CFG, 'gen_3x_4x_2f.json'),
+                         precision='bf16', learning_rate=1e-3)
+        m.capture_steps = capture
+        m.init_weights(lr_s, hr_s)
+        dev = Device.get()
+        rng = np.random.default_rng(9)
+        losses = []
+        for i in range(7):
+            b = types.SimpleNamespace(
+                low_res=dev.to_device(rng.standard_normal(lr_s).astype(np.float32)),
+                output=dev.to_device(rng.standard_normal(hr_s).astype(np.float32)),
+                mask=dev.to_device((rng.uniform(size=hr_s) > 0.3).astype(np.float32)))
+            d = m._train_step(b).resolve()
+            losses.append(float(d['loss_gen']))
+        torch.cuda.synchronize()
+        return ([np.array(a) for a in m.generator.weights], losses,
+                int(m.optimizer.iterations), getattr(m, '_recorder', None))
+    w0, l0, it0, rec0 = run(False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        w1, l1, it1, rec1 = run(True)
+    # (two eager runs of the key, then the record + replays)
+    assert rec0 is None and rec1 is not None and rec1.replays == 7 - 2, \
+        (rec1 and rec1.replays)
+    assert it0 == it1 == 7
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(w0, w1):
+        np.testing.assert_array_equal(a, b)
