@@ -553,9 +553,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
   const int q = lane & 15, kg = lane >> 4;
   const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2], Cout = g.Cout;
 
-  f32x4 acc[18];
+  // Round 6: the TAPS (a, b) are columns of the matrix product.  Until then a k-step
+  // was one output row of 32 t with dPre as the B fragment (2 of its 16 columns
+  // alive) and 18 A fragments — the 9 (a, b) halo rows x 2 t-shifts — for 18 MFMAs:
+  // 37 LDS reads per k-step, and the kernel ran at the speed of those reads (0.21 of
+  // the HBM roofline; three or four workgroups per CU changed nothing).  Now a k-step
+  // is one HALO row H: its two A fragments (t-shift 0 / 2: rows (s, ci) = taps c = s,
+  // 2 + s) are read once and multiplied with B[q][(a, b, co)] = dPre[H - (a, b)][q][co]
+  // — 9 C_out live columns (18 in two fragments for the 8 -> 2 conv), zero where H -
+  // (a, b) leaves the tile — so a tile is 60 halo rows x (4 transpose reads + 2 reads +
+  // 4 MFMAs) instead of 32 x (36 + 1 + 18), and the accumulators are 4 - 6 fragments
+  // instead of 18.
+  constexpr int NBK = (9 * TW_CO + 15) / 16;      // column fragments (3 for C_out <= 4)
+  const int ncol = 9 * Cout;
+  f32x4 acc[2][NBK];
 #pragma unroll
-  for (int b = 0; b < 18; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) acc[cp][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // this lane's B columns: jc = nb 16 + q -> (tap (a, b), co), alive while jc < 9 C_out
+  int col_a[NBK], col_b[NBK], col_co[NBK];
+  bool col_ok[NBK];
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) {
+    const int jc = nb * 16 + q, ab = jc / Cout;
+    col_ok[nb] = jc < ncol;
+    col_a[nb] = ab / 3; col_b[nb] = ab % 3; col_co[nb] = jc - ab * Cout;
+  }
 
   // Round 4: the tile loop is software-pipelined.  It ran load -> LDS ->
   // barrier -> 144 MFMAs per wave back to back: ~10 us of exposed load latency
@@ -641,54 +665,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
     commit();
     __syncthreads();
     if (tile + xt_nk < (int)xt_hi) fetch(tile + xt_nk);   // in flight under the k-steps
-    // ---- 32 k-steps (one (s1, s2) row of 32 t each), 8 per wave
-    for (int ks = wave; ks < TW0 * TW1; ks += 4) {
-      const int r0 = ks / TW1, r1 = ks % TW1;
-      bf16x8 bfr = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (q < Cout) bfr = *reinterpret_cast<const bf16x8*>(dsT + q * TWN + ks * TW2 + kg * 8);
+    // ---- 60 k-steps (one halo row of 34 t each), 15 per wave
+    for (int ks = wave; ks < TG0 * TG1; ks += 4) {
+      const int h0 = ks / TG1, h1 = ks % TG1;
+      bf16x8 afr[2];
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
+      for (int cp = 0; cp < 2; ++cp) {
+        // rows of the transpose read: cells t = 8 kg + 4 h + (q >> 2) (+ 2 cp)
+        const char* base = xs + (((h0 * TG1 + h1) * TG2) + 8 * kg + (q >> 2) + 2 * cp) * 16 + ((q & 3) << 3);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(base + 4 * 16));
+        afr[cp] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+      for (int nb = 0; nb < NBK; ++nb) {
+        if (nb * 16 >= ncol) continue;          // (uniform: no live column in this fragment)
+        // output row of this column's tap: H - (a, b), inside the tile or nothing
+        const int r0 = h0 - col_a[nb], r1 = h1 - col_b[nb];
+        bf16x8 bfr = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (col_ok[nb] && r0 >= 0 && r0 < TW0 && r1 >= 0 && r1 < TW1)
+          bfr = *reinterpret_cast<const bf16x8*>(dsT + col_co[nb] * TWN + (r0 * TW1 + r1) * TW2 + kg * 8);
 #pragma unroll
-          for (int cp = 0; cp < 2; ++cp) {
-            // rows of the transpose read: positions t = 8 kg + 4 h + (q >> 2)
-            const char* base = xs + ((((r0 + a) * TG1 + (r1 + b)) * TG2) + 8 * kg + (q >> 2) + 2 * cp) * 16 +
-                               ((q & 3) << 3);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(base));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(base + 4 * 16));
-            const bf16x8 afr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[(a * 3 + b) * 2 + cp] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[(a * 3 + b) * 2 + cp], 0, 0, 0);
-          }
+        for (int cp = 0; cp < 2; ++cp)
+          acc[cp][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[cp], bfr, acc[cp][nb], 0, 0, 0);
+      }
     }
   }
-  // ---- sum the 4 waves: red[wave][block][row 16][co 16] (only lanes co < C_out matter)
+  // ---- sum the 4 waves: red[wave][cp][nb][row m 16][column 16]
   __syncthreads();
-  // 4 waves x 9 blocks x 256 floats = 36,864 B of the (dead) LDS image per half
-  float* red = reinterpret_cast<float*>(smem);
+  float* red = reinterpret_cast<float*>(smem);        // 4 x 2 NBK x 256 floats of the (dead) LDS image
   float* out = partial + (size_t)blockIdx.x * 27 * 8 * Cout;
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();
 #pragma unroll
-    for (int b = 0; b < 9; ++b)
+  for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        red[((wave * 9 + b) * 16 + kg * 4 + r) * 16 + q] = acc[half * 9 + b][r];
-    __syncthreads();
-    for (int item = tid; item < 9 * 256; item += 256) {
-      const int co = item & 15, m16 = (item >> 4) & 15, b = item >> 8;
-      const int blk = half * 9 + b;
-      const int ab = blk >> 1, cp = blk & 1;
-      const int c = 2 * cp + (m16 >> 3), ci = m16 & 7;
-      if (c < 3 && co < Cout) {
-        float t = 0.f;
+        red[(((wave * 2 + cp) * NBK + nb) * 16 + kg * 4 + r) * 16 + q] = acc[cp][nb][r];
+  __syncthreads();
+  for (int item = tid; item < 2 * NBK * 256; item += 256) {
+    const int j = item & 15, m16 = (item >> 4) & 15, blk = item >> 8;
+    const int nb = blk % NBK, cp = blk / NBK;
+    const int jc = nb * 16 + j, ab = jc / Cout, co = jc - ab * Cout;
+    const int c = 2 * cp + (m16 >> 3), ci = m16 & 7;
+    if (c < 3 && jc < ncol) {
+      float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) t += red[((w * 9 + b) * 16 + m16) * 16 + co];
-        out[((size_t)(ab * 3 + c) * 8 + ci) * Cout + co] = t;
-      }
+      for (int w = 0; w < 4; ++w) t += red[(((w * 2 + cp) * NBK + nb) * 16 + m16) * 16 + j];
+      out[((size_t)(ab * 3 + c) * 8 + ci) * Cout + co] = t;
     }
   }
 }
@@ -706,6 +732,8 @@ bool conv_wgrad_tail_supported(const ConvGeom& g, int precision) {
 static int tail_grid(const s3_ctx* ctx, const ConvGeom& g, int* t0, int* t1, int* t2, int* n_tiles) {
   *t0 = (g.O[0] + TW0 - 1) / TW0; *t1 = (g.O[1] + TW1 - 1) / TW1; *t2 = (g.O[2] + TW2 - 1) / TW2;
   *n_tiles = g.N * *t0 * *t1 * *t2;
+  // (round 6: 3 or 4 workgroups per CU are no faster — 247 / 216 us against 211 —
+  // the kernel is bound by its LDS fragment reads, not by occupancy)
   int grid = 2 * ctx->num_cu;
   if (grid > *n_tiles) grid = *n_tiles;
   return grid;
