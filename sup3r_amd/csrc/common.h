@@ -55,6 +55,7 @@
   X(NO_FEWPOS_MFMA) \
   X(NO_FEWPOS_BWD_FUSE) \
   X(NO_FEWPOS_SMALL) \
+  X(NO_FEWPOS_TRUNK) \
   X(NO_FOLD16) \
   X(NO_FRAME16) \
   X(NO_FUSED2D) \

@@ -755,6 +755,19 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         }
         if (d.res >= 0 && pl->t[d.res].numel != ot.numel) return bad("plan: residual shape mismatch");
         o.mfma = conv_mfma_supported(g, precision);
+        // Round 6: a trunk-geometry conv (64 -> 64 k, 3 x 3 x 3) over <= 1 024 positions in
+        // a TRAINING plan — the lo-res stack of the reference's test shapes, BASELINE
+        // configs 4 / 5: lr (N, 4, 4, 4, 2) — leaves the halo-tile family: two or four
+        // of its tiles keep two or four CUs busy (17 us forward, 17 us data gradient,
+        // 40 + 5 us for the weight gradient whose every workgroup holds the whole 27 x
+        // 64 x 64 tile), where the one-launch fewpos kernels split the work over (tap,
+        // channel block) and take ~8 us for forward and ~8 us for both gradients.
+        // (Training plans only: an inference plan's kernels do not depend on the batch.)
+        const int64_t P_out = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
+        const bool small_trunk = training && o.mfma && !s3_opt_has(S3O_NO_FEWPOS) &&
+                                 !s3_opt_has(S3O_NO_FEWPOS_TRUNK) && precision != S3_PREC_BF16X3 &&
+                                 P_out <= 1024 && conv_fewpos_supported(g) && conv_fewpos_mfma_ok(g);
+        if (small_trunk) o.mfma = false;
         o.fewpos = !o.mfma && !s3_opt_has(S3O_NO_FEWPOS) && conv_fewpos_supported(g);
         // bf16 plans: the weight-streaming fp32 path only for really few
         // positions; mid-size layers go to the gather-MFMA kernels
@@ -767,7 +780,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
                               conv_fewpos_mfma_small_ok(ctx, g);
         if (o.fewpos && (int64_t)g.N * g.O[0] * g.O[1] * g.O[2] >= 256 &&
             conv_gconv_supported(g, precision) && conv_gconv_dgrad_supported(g, precision) &&
-            conv_wgrad_gen_supported(g) && !(fp_small && conv_fewpos_mfma_ok(g)))
+            conv_wgrad_gen_supported(g) && !((fp_small || small_trunk) && conv_fewpos_mfma_ok(g)))
           o.fewpos = false;
         // the few-channel head / tail convs and small filters on those kernels too
         bool fp_small_taken = false;
@@ -792,7 +805,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         max_dpre = std::max(max_dpre, ysz);
         max_partial = std::max(max_partial, conv_generic_wgrad_partial_bytes(g));
         if (training && !s3_opt_has(S3O_NO_MFMA_BWD)) {
-          o.wgrad_mfma = conv_wgrad_mfma_supported(g);
+          o.wgrad_mfma = !small_trunk && conv_wgrad_mfma_supported(g);
           o.wgrad_bf16 = o.wgrad_mfma && conv_wgrad_bf16_supported(g, precision);
           if (o.wgrad_bf16)
             max_partial = std::max(max_partial, conv_wgrad_bf16_partial_bytes(ctx, g));
@@ -827,7 +840,7 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
             o.fp_wg_mfma = conv_fewpos_wgrad_mfma_ok(g);
             max_partial = std::max(max_partial, conv_fewpos_wgrad_partial_bytes(g));
           }
-          o.dgrad_mfma = conv_dgrad_mfma_supported(g, precision);
+          o.dgrad_mfma = !small_trunk && conv_dgrad_mfma_supported(g, precision);
           // (BF16X3: the split-bf16 tile kernel takes the same geometry — the
           // discriminator's valid 32 -> 64 conv left the gather-MFMA adjoint,
           // 2.25 -> 0.5 ms at C2 batch 8)
