@@ -764,7 +764,9 @@ extern "C" int s3_plan_create_opt(s3_ctx* ctx, s3_params* params,
         // channel block) and take ~8 us for forward and ~8 us for both gradients.
         // (Training plans only: an inference plan's kernels do not depend on the batch.)
         const int64_t P_out = (int64_t)g.N * g.O[0] * g.O[1] * g.O[2];
-        const bool small_trunk = training && o.mfma && !s3_opt_has(S3O_NO_FEWPOS) &&
+        // (the 3-D trunk geometry only: the logical-axes kernel of 2-D nets / few time
+        // steps keeps its layers — its tests pin the selection at such sizes)
+        const bool small_trunk = training && o.mfma && !conv_mfma_is_gen(g, precision) && !s3_opt_has(S3O_NO_FEWPOS) &&
                                  !s3_opt_has(S3O_NO_FEWPOS_TRUNK) && precision != S3_PREC_BF16X3 &&
                                  P_out <= 1024 && conv_fewpos_supported(g) && conv_fewpos_mfma_ok(g);
         if (small_trunk) o.mfma = false;
