@@ -251,8 +251,18 @@ extern "C" int s3_ctx_create(int device_id, void* stream, int create_stream,
     ctx->own_stream = true;
   }
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess)
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
     ctx->num_cu = prop.multiProcessorCount;
+    // The library is compiled for gfx950 only and its persistent kernels are sized
+    // for that part's 160 KB of LDS per workgroup (up to 163,072 B): say so here,
+    // once, instead of failing at some kernel's first launch on anything else.
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      ctx->err = std::string("sup3r_amd is built for gfx950 (MI355X) only; device ") + std::to_string(device_id) +
+                 " is " + prop.gcnArchName;
+      *out = ctx;
+      return S3_ESTATE;
+    }
+  }
   *out = ctx;
   return S3_OK;
 }
