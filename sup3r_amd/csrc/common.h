@@ -74,6 +74,7 @@
   X(NO_WS_RES2) \
   X(NO_WS_PP) \
   X(NO_WS_X3) \
+  X(WS_X3_MIN_POS) \
   X(NO_CONV2D_OUT) \
   X(NO_CONV2D_HEAD) \
   X(KEEP_ACTIVATIONS) \

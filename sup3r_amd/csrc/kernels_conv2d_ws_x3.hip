@@ -614,6 +614,12 @@ bool conv2d_ws_x3_supported(const ConvGeom& g, int precision, ConvIO io, bool ha
   if (precision != S3_PREC_BF16X3 || s3_opt_on(S3O_NO_CONV2D_WS) || s3_opt_on(S3O_NO_WS_X3)) return false;
   if (io.in_bf16 || io.out_bf16 || (has_res && io.res_bf16)) return false;
   if (g.w_cin || g.res2 || (has_res && g.d2s > 1)) return false;
+  // per IMAGE (the choice must not depend on the batch size): a 16 x 16 image is ONE tile per
+  // image — 60 tiles of two ~12 us rounds each on 256 CUs lose to the logical-axes kernel's
+  // finer split (sup3rcc/gen_solar_5x_1x_1f at (60, 16, 16): 0.64 vs 0.97 ms per forward; spatial/gen_10x_2f at
+  // (48, 20, 20): 1.30 vs 1.56 ms; from 32 x 32 cells on the weights-stationary form wins)
+  const int64_t min_pos = s3_opt_int(S3O_WS_X3_MIN_POS, 1024);
+  if ((int64_t)g.D[0] * g.D[1] < min_pos) return false;
   return conv2d_ws_geom_ok(g) && !conv2d_ws_tail_geom_ok(g);
 }
 
