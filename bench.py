@@ -474,29 +474,38 @@ def fwd2d_leg(dev, steps=20, warmup=3, batch=48, seed=42):
                     'the 72 KB filter image) at this shape, 0.44 of 8 TB/s at '
                     '480 x 75 x 75; counter traffic per launch: '
                     'profiles/r05/pmc_fwd2d.txt'}}
-    # ---- checker (after the timed regions): one image of the timed batch through
-    # the CPU oracle with the same weights — the number the headline prints as
-    # cpu_baseline.parity, here for the 2-D path in its multi-tile steady state
-    # (per op: tests/test_ws_multitile.py)
+    # what the checker needs (fwd2d_parity, run after EVERY timed leg of the line, next
+    # to the CPU baseline: nothing under oracle/ is imported before that)
+    pick = [0, batch - 1]
+    res['_parity_inputs'] = (spec, [np.array(w) for w in net.weights],
+                             x.cpu().numpy()[pick], out.cpu().numpy()[pick], pick)
+    del ph, net
+    return res
+
+
+def fwd2d_parity(res):
+    """checker use of the oracle: images 0 and N - 1 of the fwd2d leg's timed batch
+    through the CPU restatement with the same weights — the number the headline
+    prints as cpu_baseline.parity, here for the 2-D path in its multi-tile steady
+    state (per op: tests/test_ws_multitile.py)"""
+    inputs = res.pop('_parity_inputs', None)
+    if inputs is None:
+        return
     try:
         from oracle.network import Network as OracleNet
-        y_dev = out.cpu().numpy()
-        x_np = x.cpu().numpy()
+        spec, weights, x_np, y_dev, pick = inputs
         ref = OracleNet(spec)
         ref.init_weights(x_np[:1, :8, :8], seed=0)
-        ref.set_weights(net.weights)
-        pick = [0, batch - 1]
-        y_ref = ref.forward(x_np[pick])
+        ref.set_weights(weights)
+        y_ref = ref.forward(x_np)
         res['parity'] = {
-            'bf16_linf': float(np.abs(y_dev[pick] - y_ref).max()),
+            'bf16_linf': float(np.abs(y_dev - y_ref).max()),
             'scale': float(np.abs(y_ref).max()),
-            'sample': f'images 0 and {batch - 1} of the timed batch vs the fp32 '
+            'sample': f'images {pick[0]} and {pick[1]} of the timed batch vs the fp32 '
                       'numpy oracle (same weights); stated bound of the bf16 '
                       'mode: 3e-2 of the scale'}
     except Exception as e:                   # evidence, never fatal
         res['parity'] = {'error': repr(e)[:200]}
-    del ph, net
-    return res
 
 
 def fwp2d_executor_leg(rank=0, batch=4, reps=3):
@@ -1089,6 +1098,10 @@ def main():
             except Exception as e:
                 out['chain'] = {'error': repr(e)[:300]}
         ms_ = max_over_ranks(out['ms_per_step'])
+        if rank == 0 and not args.no_cpu_baseline:
+            fwd2d_parity(out)
+        else:
+            out.pop('_parity_inputs', None)
         if rank == 0:
             B2 = args.batch or 48
             print(json.dumps(dict(
@@ -1370,6 +1383,11 @@ def main():
             if tail and 'tail_mfma' in o['what']:
                 o['traffic_pmc_bytes'] = tail
                 o['traffic_over_algorithmic'] = tail / o['algorithmic_bytes']
+    if isinstance(result.get('fwd2d'), dict):
+        if args.no_cpu_baseline:
+            result['fwd2d'].pop('_parity_inputs', None)
+        else:
+            fwd2d_parity(result['fwd2d'])
     if not args.no_cpu_baseline:
         cpu, parity = cpu_legs(spec, dev)
         cpu['parity'] = parity

@@ -445,3 +445,46 @@ def test_device_chain_predicate_on_duck_typed_steps():
     # the public predicate routes chains there
     assert ForwardPass._device_path(chain(step(True), step(True)),
                                     types.SimpleNamespace(exo_data=None))
+
+
+def test_chunk_read_ahead_keeps_order_propagates_errors_and_stops():
+    """``forward_pass._read_ahead`` (the helper thread behind
+    ``ChunkPathOptions.input_prefetch``): items in order, an exception of the
+    source surfaces at the consumer where it happened, and a consumer that goes
+    away stops the helper instead of leaving it parked on a full queue"""
+    import threading
+    import time
+
+    from sup3r_amd.forward_pass import _read_ahead
+    assert list(_read_ahead(iter(range(50)), 4)) == list(range(50))
+    assert list(_read_ahead(iter(()), 3)) == []
+
+    def boom():
+        yield 1
+        yield 2
+        raise KeyError('source failed')
+    got = []
+    try:
+        for v in _read_ahead(boom(), 2):
+            got.append(v)
+    except KeyError as e:
+        assert 'source failed' in str(e)
+    else:
+        raise AssertionError('the source error was swallowed')
+    assert got == [1, 2]
+    # early exit: the generator is closed after two of a long stream
+    pulled = []
+
+    def slow():
+        for i in range(10 ** 6):
+            pulled.append(i)
+            yield i
+    n0 = threading.active_count()
+    gen = _read_ahead(slow(), 3)
+    assert next(gen) == 0 and next(gen) == 1
+    gen.close()
+    time.sleep(0.3)
+    n_pulled = len(pulled)
+    time.sleep(0.2)
+    assert len(pulled) == n_pulled and n_pulled <= 8       # (depth 3 + in flight)
+    assert threading.active_count() <= n0
