@@ -93,6 +93,7 @@
   X(NO_TAIL_BAND) \
   X(NO_TAIL_MFMA) \
   X(NO_TAIL_SLIDE) \
+  X(NO_TAIL_SWEEP) \
   X(NO_TAIL_WINDOW) \
   X(NO_TAIL_X3) \
   X(NO_TILE66) \
@@ -104,6 +105,7 @@
   X(NO_WGRAD_WS) \
   X(PERSIST_DGRAD_MIN_TILES) \
   X(POISON_ALLOC) \
+  X(TAIL_SWEEP_SHAPE) \
   X(TRACE) \
   X(WGRAD_DBG) \
   X(WGRAD_SIDE_STREAM)
@@ -310,6 +312,9 @@ bool conv_tail_x3_supported(const ConvGeom& g, int precision);
 int launch_conv_tail_x3(s3_ctx* ctx, const ConvGeom& g, const float* x, const float* w,
                         const float* bias, float* y);
 // aff (device, scale[C_out] then shift[C_out], or null): y * scale + shift on the way out
+bool conv_tail_sweep_supported(const ConvGeom& g);
+int launch_conv_tail_sweep(s3_ctx* ctx, const ConvGeom& g, const void* x, const float* w,
+                           const float* bias, float* y, const float* aff);
 int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
                           const float* w, const float* bias, float* y, const float* aff = nullptr);
 int launch_conv_generic_dgrad(s3_ctx* ctx, const ConvGeom& g, const float* dy,

@@ -565,6 +565,9 @@ int launch_conv_tail_mfma(s3_ctx* ctx, const ConvGeom& g, const void* x,
   const bool band = g.Cout == 2 && !s3_opt_has(S3O_NO_TAIL_BAND);
   // read per call: the parity tests flip it between two forwards
   const bool noslide = s3_opt_on(S3O_NO_TAIL_SLIDE);
+  // (plane-sweep form: kernels_conv_tail_sweep.hip — same bits, 0.8 of the bytes through the CU)
+  if (band && !noslide && !s3_opt_on(S3O_NO_TAIL_SWEEP) && conv_tail_sweep_supported(g))
+    return launch_conv_tail_sweep(ctx, g, x, w, bias, y, aff);
   if (band && g.O[0] >= 4 && !noslide) {
     static S3DeviceOnce slide_attr;
     if (!slide_attr.done(ctx->device)) {

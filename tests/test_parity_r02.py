@@ -556,7 +556,7 @@ def test_sliding_window_tail_conv_is_bit_identical(monkeypatch):
     spec = pcc(3, 64) + pcc(3, 200, act=False) + \
         [{'class': 'SpatioTemporalExpansion', 'spatial_mult': 5},
          {'alpha': 0.2, 'class': 'LeakyReLU'}] + pcc(3, 2, act=False)
-    for shape in ((2, 5, 7, 40, 4), (3, 9, 4, 70, 4)):
+    for shape in ((2, 5, 7, 40, 4), (3, 9, 4, 70, 4), (9, 6, 4, 20, 4)):
         x = rng.standard_normal(shape).astype(np.float32)
         ref = _oracle(spec, x)
         y_ref = ref.forward(x)
@@ -564,12 +564,26 @@ def test_sliding_window_tail_conv_is_bit_identical(monkeypatch):
         ph = net.plan(shape, training=False)
         assert _kernels(ph)[-1] == 'tail_mfma'
         xd = net.dev.to_device(x)
+        y_sweep = ph.forward(xd).cpu().numpy()
+        switch('NO_TAIL_SWEEP', 1)
         y_slide = ph.forward(xd).cpu().numpy()
+        switch('NO_TAIL_SWEEP', None)
         switch('NO_TAIL_SLIDE', 1)
         y_tile = ph.forward(xd).cpu().numpy()
         switch('NO_TAIL_SLIDE', None)
         np.testing.assert_array_equal(y_slide, y_tile)
-        assert rel_linf(y_slide, y_ref) < 3e-2
+        np.testing.assert_array_equal(y_sweep, y_tile)
+        assert rel_linf(y_sweep, y_ref) < 3e-2
+        # conv_tail_sweep_kernel with its plane shape forced (S1, S2, rows per
+        # unit): one / two / three column sets per wave, planes of 3 .. 49 DMA
+        # pieces, several units per workgroup (the plane stream crosses units),
+        # ragged planes and segments
+        for s1, s2, seg in ((4, 16, 4), (8, 64, 6), (16, 128, 10), (40, 72, 8),
+                            (8, 288, 48), (5, 24, 4), (48, 64, 128)):
+            switch('TAIL_SWEEP_SHAPE', s1 * 1000000 + s2 * 1000 + seg)
+            y_f = ph.forward(xd).cpu().numpy()
+            switch('TAIL_SWEEP_SHAPE', None)
+            np.testing.assert_array_equal(y_f, y_tile, err_msg=str((s1, s2, seg)))
 
 
 # ------------------------------------------------ whole-network 2-D kernel (C1)
