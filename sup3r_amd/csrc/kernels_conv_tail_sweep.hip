@@ -86,24 +86,6 @@ __global__ __launch_bounds__(SW_NTH) void conv_tail_sweep_kernel(
     n = tr;
   };
 
-  // banded filter fragments, as in conv_tail_mfma_kernel<true>
-  bf16x8 wf[27];
-  {
-    const int delta = p >> 1, co = p & 1;
-#pragma unroll
-    for (int f = 0; f < 27; ++f) {
-      const int ab = f / 3, s = f % 3;
-      const int c = 4 * s + kq - delta;
-      unsigned u[4] = {0u, 0u, 0u, 0u};
-      if (c >= 0 && c <= 2) {
-        const float* wp = w + (size_t)(ab * 3 + c) * 8 * 2 + co;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = sw_pk2(wp[(2 * e) * 2], wp[(2 * e + 1) * 2]);
-      }
-      uint4 uv = make_uint4(u[0], u[1], u[2], u[3]);
-      wf[f] = __builtin_bit_cast(bf16x8, uv);
-    }
-  }
   const float slope = g.act == S3_ACT_LEAKY ? g.alpha : (g.act == S3_ACT_RELU ? 0.f : 1.f);
   const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
 
@@ -176,10 +158,33 @@ __global__ __launch_bounds__(SW_NTH) void conv_tail_sweep_kernel(
   if (iu >= u_end) return;
   issue_setup();
   issue_next();
+  const bool second = issue_next();
+  // banded filter fragments, as in conv_tail_mfma_kernel<true>, built from an LDS
+  // copy of the 432 filter values (slot 2, which the first DMA reaches only after the
+  // barrier below) while planes 0 and 1 are in flight: 27 dependent trips to L2 per
+  // lane otherwise
+  bf16x8 wf[27];
   {
-    const bool second = issue_next();
-    wait_but_newest(second);
+    float* wl = reinterpret_cast<float*>(smem + 2 * sh.plane_bytes);
+    if (tid < 27 * 8 * 2) wl[tid] = w[tid];
+    __syncthreads();
+    const int delta = p >> 1, co = p & 1;
+#pragma unroll
+    for (int f = 0; f < 27; ++f) {
+      const int ab = f / 3, s = f % 3;
+      const int c = 4 * s + kq - delta;
+      unsigned u[4] = {0u, 0u, 0u, 0u};
+      if (c >= 0 && c <= 2) {
+        const float* wp = wl + (ab * 3 + c) * 8 * 2 + co;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = sw_pk2(wp[(2 * e) * 2], wp[(2 * e + 1) * 2]);
+      }
+      uint4 uv = make_uint4(u[0], u[1], u[2], u[3]);
+      wf[f] = __builtin_bit_cast(bf16x8, uv);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  wait_but_newest(second);
   SWEEP_BARRIER();
 
   // rows q - 2 / q - 1 / q of the plane being read: R0 / R1 / R2
