@@ -102,6 +102,7 @@
   X(NO_WGRAD_C2) \
   X(NO_WGRAD_GEN_PF) \
   X(NO_WGRAD_TAIL) \
+  X(NO_WGRAD_TAIL_SWEEP) \
   X(NO_WGRAD_WS) \
   X(PERSIST_DGRAD_MIN_TILES) \
   X(POISON_ALLOC) \

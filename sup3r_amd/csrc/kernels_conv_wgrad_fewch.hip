@@ -719,6 +719,365 @@ __global__ __launch_bounds__(256) void conv_wgrad_tail_kernel(
   }
 }
 
+
+// ===========================================================================
+// Plane-sweep form of the tail conv's weight gradient (round 6; C_in = 8 bf16 cells,
+// C_out = 2, reflect padding): the same matrix product per halo row as
+// conv_wgrad_tail_kernel above — A = two transpose-read fragments of an x row (taps
+// c = 0 .. 3 x 8 channels), B[t][(a, b, co)] = dPre[row - (a, b)][t][co] — with the
+// data movement of conv_tail_sweep_kernel (kernels_conv_tail_sweep.hip): a workgroup
+// owns a column of S1 x S2 positions and walks it along s0; every step ONE x plane
+// ((S1 + 2) x (S2 + 2) cells, LDS-DMA pieces in linear plane order into a 3-slot ring,
+// two planes in flight) meets the three dPre rows it belongs to (taps a = 0 / 1 / 2 of
+// rows q / q - 1 / q - 2), which sit transposed and bf16-rounded in a 4-slot ring
+// (the raw fp32 row travels with the x plane of its step — more DMA pieces behind the
+// plane's — and the lane that requested a piece converts it when it has landed).  The 4 x 8 x 32 tiles of the kernel above fetch every x cell twice (2 040 halo
+// cells per 1 024 positions) one tile deep; here 1.1 - 1.2 times, two steps deep.
+constexpr int WS_WAVES = 8, WS_NTH = WS_WAVES * 64, WS_NSLOT = 3, WS_NDS = 4;
+constexpr int WS_MAXP = 7;                     // DMA pieces per wave and plane
+constexpr int WS_DPT = 3;                      // dPre position pairs per thread and row
+constexpr int WS_LDS = 160 * 1024;
+constexpr int WS_RED = WS_WAVES * 4 * 256 * 4; // the final cross-wave sum: 32 KB
+
+struct WSweepShape {
+  int S1, S2, NCH, P2;         // positions per plane row set, 32-step chunks per row, cells per plane row
+  int plane_cells, npieces, plane_bytes, ds_bytes;
+  int ndpieces, slot_bytes;    // raw dPre pieces behind a plane's, bytes of a stream slot
+  int seg, segs0, tiles1, tiles2, n_units;
+};
+
+// LDS reads the compiler does not see: in a wave that also issues LDS-DMA it puts an
+// s_waitcnt vmcnt(0) in front of every LDS read it knows of (the DMA writes LDS) — which
+// would wait for the plane requested a moment ago.  Ordered by hand (lgkmcnt below).
+template <int OFF>
+__device__ inline s16x4 ws_lds_tr(unsigned addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ inline bf16x8 ws_lds_b128(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+__global__ __launch_bounds__(WS_NTH) void conv_wgrad_tail_sweep_kernel(
+    const unsigned short* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+    ConvGeom g, WSweepShape sh) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane & 15, kg = lane >> 4;
+  const int D0 = g.D[0], D1 = g.D[1], D2 = g.D[2];
+  const int O0 = g.O[0], O1 = g.O[1], O2 = g.O[2];
+  auto clampi = [](int i, int d) { return i < 0 ? 0 : (i > d - 1 ? d - 1 : i); };
+  char* dsT0 = smem + WS_NSLOT * sh.slot_bytes;
+  const int pos_plane = sh.S1 * sh.S2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  // 16 B of zeros behind the dPre^T ring: the B fragment of a tap that leaves the unit
+  const unsigned zero_addr = lds0 + (unsigned)(WS_NSLOT * sh.slot_bytes + WS_NDS * sh.ds_bytes);
+  if (tid < 4) reinterpret_cast<unsigned*>(dsT0 + WS_NDS * sh.ds_bytes)[tid] = 0u;
+
+  // XCD-contiguous unit ranges (conv_tail_sweep_kernel)
+  int u_first, u_step, u_end;
+  {
+    const int G = gridDim.x, b = blockIdx.x, xcd = b % 8;
+    int before = 0;
+    for (int k = 0; k < xcd; ++k) before += (G - k + 7) / 8;
+    const int mine = (G - xcd + 7) / 8;
+    u_first = (int)((long long)sh.n_units * before / G) + b / 8;
+    u_step = mine;
+    u_end = (int)((long long)sh.n_units * (before + mine) / G);
+  }
+  auto unit_org = [&](int u, int& n, int& r0, int& o1, int& o2) __attribute__((always_inline)) {
+    int tr = u;
+    o2 = (tr % sh.tiles2) * sh.S2; tr /= sh.tiles2;
+    o1 = (tr % sh.tiles1) * sh.S1; tr /= sh.tiles1;
+    r0 = (tr % sh.segs0) * sh.seg; tr /= sh.segs0;
+    n = tr;
+  };
+  auto unit_rows = [&](int r0) __attribute__((always_inline)) { return r0 + sh.seg <= O0 ? sh.seg : O0 - r0; };
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) acc[cp][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float* out = partial + (size_t)blockIdx.x * 27 * 8 * 2;
+
+  if (u_first < u_end) {
+    // this lane's B columns: jc = nb 16 + q -> tap (a, b), co; 18 live columns
+    int col_a[2], col_b[2], col_off[2];
+    bool col_ok[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int jc = nb * 16 + q, ab = jc >> 1;
+      col_ok[nb] = jc < 18;
+      col_a[nb] = ab / 3; col_b[nb] = ab % 3;
+      col_off[nb] = (jc & 1) * pos_plane;
+    }
+    // lane parts of the fragment addresses: A = transpose reads of cells 8 kg + (q >> 2) (+ 2 cp,
+    // + 4) of an x row, B = eight t of dPre^T row (h1 - b) of channel co
+    const unsigned a_lane = (unsigned)((8 * kg + (q >> 2)) * 16 + ((q & 3) << 3));
+    unsigned b_lane[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) b_lane[nb] = (unsigned)((col_off[nb] - col_b[nb] * sh.S2 + kg * 8) * 2);
+    const int nks = (sh.S1 + 2) * sh.NCH;
+    const int h1_first = wave / sh.NCH, tc_first = wave % sh.NCH;
+    const int h1_step = WS_WAVES / sh.NCH, tc_step = WS_WAVES % sh.NCH;
+    // this lane's dPre position pairs (two consecutive t of one row: 16 B of fp32): lane l of
+    // raw piece wave + 8 k holds pair (wave + 8 k) 64 + l — it converts what it requested
+    int drow[WS_DPT], dt[WS_DPT];
+    bool dact[WS_DPT];
+#pragma unroll
+    for (int k = 0; k < WS_DPT; ++k) {
+      const int pos = 2 * (((wave + WS_WAVES * k) << 6) + lane);
+      dact[k] = pos < pos_plane;
+      drow[k] = dact[k] ? pos / sh.S2 : 0;
+      dt[k] = dact[k] ? pos - drow[k] * sh.S2 : 0;
+    }
+    const int my_nd = (sh.ndpieces - wave + WS_WAVES - 1) / WS_WAVES;
+    // raw fp32 row in stream slot `rslot` (landed: this wave's own pieces) -> dPre^T slot
+    // `slot`: [co][row][t] bf16, zero outside the output (o1, o2: the unit's column)
+    auto dpre_convert = [&](int rslot, int slot, int o1, int o2) __attribute__((always_inline)) {
+      unsigned short* base = reinterpret_cast<unsigned short*>(dsT0 + slot * sh.ds_bytes);
+      const unsigned raw = lds0 + (unsigned)(rslot * sh.slot_bytes + sh.plane_bytes + wave * 1024 + lane * 16);
+#pragma unroll
+      for (int k = 0; k < WS_DPT; ++k) {
+        if (k >= my_nd || !dact[k]) continue;
+        bf16x8 rv = ws_lds_b128(raw + k * (WS_WAVES * 1024));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv) :: "memory");
+        float4 v = __builtin_bit_cast(float4, rv);
+        if (!(o1 + drow[k] < O1 && o2 + dt[k] < O2)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // (O2 is even)
+        const int idx = drow[k] * sh.S2 + dt[k];
+        *reinterpret_cast<unsigned*>(base + idx) = pk2(v.x, v.z);
+        *reinterpret_cast<unsigned*>(base + pos_plane + idx) = pk2(v.y, v.w);
+      }
+    };
+
+    // ---- the stream (issue side), as in conv_tail_sweep_kernel: item q of a unit = x plane
+    // q + the raw dPre row q (rows past the unit's last: that row again — the piece count
+    // per item stays fixed for the counted wait)
+    const int my_np = (sh.npieces - wave + WS_WAVES - 1) / WS_WAVES;
+    int iu = u_first, iq = 0, irows = 0, in_ = 0, ir0 = 0, islot = 0;
+    unsigned poff[WS_MAXP], doff[WS_DPT];
+    auto issue_setup = [&]() __attribute__((always_inline)) {
+      int o1, o2;
+      unit_org(iu, in_, ir0, o1, o2);
+      irows = unit_rows(ir0);
+#pragma unroll
+      for (int i = 0; i < WS_MAXP; ++i) {
+        int c = ((wave + WS_WAVES * i) << 6) + lane;
+        c = c < sh.plane_cells ? c : sh.plane_cells - 1;
+        const int row = c / sh.P2, col = c - row * sh.P2;
+        const int i1 = clampi(s3_reflect(o1 + row - g.lo[1], D1), D1);
+        const int i2 = clampi(s3_reflect(o2 + col - g.lo[2], D2), D2);
+        poff[i] = (unsigned)((i1 * D2 + i2) * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < WS_DPT; ++k) {
+        const int oo1 = o1 + drow[k] < O1 ? o1 + drow[k] : O1 - 1;
+        const int oo2 = o2 + dt[k] < O2 ? o2 + dt[k] : O2 - 2;
+        doff[k] = (unsigned)((oo1 * O2 + oo2) * 2);
+      }
+    };
+    auto issue_next = [&]() __attribute__((always_inline)) -> bool {
+      if (iu >= u_end) return false;
+      const int i0 = clampi(s3_reflect(ir0 + iq - g.lo[0], D0), D0);
+      const unsigned short* pl = x + ((size_t)in_ * D0 + i0) * D1 * D2 * 8;
+      char* dst = smem + islot * sh.slot_bytes + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < WS_MAXP; ++i)
+        if (i < my_np)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(pl + poff[i]),
+              (__attribute__((address_space(3))) void*)(dst + i * (WS_WAVES * 1024)), 16, 0, 0);
+      const int orow = ir0 + (iq < irows ? iq : irows - 1);
+      const float* dr = dy + ((size_t)in_ * O0 + orow) * O1 * O2 * 2;
+#pragma unroll
+      for (int k = 0; k < WS_DPT; ++k)
+        if (k < my_nd)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(dr + doff[k]),
+              (__attribute__((address_space(3))) void*)(dst + sh.plane_bytes + k * (WS_WAVES * 1024)), 16, 0, 0);
+      islot = islot == WS_NSLOT - 1 ? 0 : islot + 1;
+      if (++iq == irows + 2) {
+        iq = 0;
+        iu += u_step;
+        if (iu < u_end) issue_setup();
+      }
+      return true;
+    };
+    // everything but the newest item's pieces of this wave has landed
+    auto wait_but_newest = [&](bool newest_in_flight) __attribute__((always_inline)) {
+      switch (newest_in_flight ? my_np + my_nd : 0) {
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    };
+#define WSW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    // ---- prologue: items 0 and 1 in flight, dPre row 0 of the first unit -> slot 0
+    issue_setup();
+    issue_next();
+    {
+      const bool second = issue_next();
+      wait_but_newest(second);
+      int n, r0, o1, o2;
+      unit_org(u_first, n, r0, o1, o2);
+      dpre_convert(0, 0, o1, o2);
+    }
+    WSW_BARRIER();
+
+    int cslot = 0, dbase = 0;
+    for (int u = u_first; u < u_end; u += u_step) {
+      int n, r0, o1, o2;
+      unit_org(u, n, r0, o1, o2);
+      const int rows = unit_rows(r0);
+      // the unit after this one (its dPre row 0 is converted at the end of this unit's last step)
+      int n2 = 0, r02 = 0, o12 = 0, o22 = 0;
+      const bool more = u + u_step < u_end;
+      if (more) unit_org(u + u_step, n2, r02, o12, o22);
+      for (int qq = 0; qq < rows + 2; ++qq) {
+        const bool newest = issue_next();
+        // ---- this plane's halo rows x 32-step chunks, one in eight per wave
+        const unsigned plane_a = lds0 + (unsigned)(cslot * sh.slot_bytes) + a_lane;
+        // per plane: the ring slot of each column's dPre row qq - a, and whether it is in the unit
+        unsigned b_base[2];
+        bool b_in[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int r = qq - col_a[nb];
+          b_in[nb] = col_ok[nb] && r >= 0 && r < rows;
+          b_base[nb] = lds0 + (unsigned)(WS_NSLOT * sh.slot_bytes + ((dbase + r) & 3) * sh.ds_bytes) + b_lane[nb];
+        }
+        int h1 = h1_first, tc = tc_first;
+        for (int ks = wave; ks < nks; ks += WS_WAVES) {
+          const unsigned aa = plane_a + (unsigned)((h1 * sh.P2 + tc * 32) * 16);
+          const s16x4 lo0 = ws_lds_tr<0>(aa), hi0 = ws_lds_tr<64>(aa);
+          const s16x4 lo1 = ws_lds_tr<32>(aa), hi1 = ws_lds_tr<96>(aa);
+          bf16x8 bfr[2];
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            // row h1 - b of that dPre row set — inside the column or the zero fragment
+            const int r1 = h1 - col_b[nb];
+            const bool ok = b_in[nb] && r1 >= 0 && r1 < sh.S1;
+            const unsigned ba = ok ? b_base[nb] + (unsigned)((h1 * sh.S2 + tc * 32) * 2) : zero_addr;
+            bfr[nb] = ws_lds_b128(ba);
+          }
+          s16x4 l0 = lo0, g0 = hi0, l1 = lo1, g1 = hi1;
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(l0), "+v"(g0), "+v"(l1), "+v"(g1), "+v"(bfr[0]), "+v"(bfr[1]) :: "memory");
+          const bf16x8 afr0 = __builtin_shufflevector(l0, g0, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 afr1 = __builtin_shufflevector(l1, g1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr0, bfr[nb], acc[0][nb], 0, 0, 0);
+            acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr1, bfr[nb], acc[1][nb], 0, 0, 0);
+          }
+          // ks += 8 in (row, chunk) form
+          h1 += h1_step; tc += tc_step;
+          if (tc >= sh.NCH) { tc -= sh.NCH; ++h1; }
+        }
+        const int nslot = cslot == WS_NSLOT - 1 ? 0 : cslot + 1;
+        wait_but_newest(newest);
+        // the NEXT step's dPre row (its raw copy came with the item that has just landed)
+        if (qq + 1 < rows) dpre_convert(nslot, (dbase + qq + 1) & 3, o1, o2);
+        else if (qq == rows + 1 && more) dpre_convert(nslot, (dbase + rows) & 3, o12, o22);
+        cslot = nslot;
+        WSW_BARRIER();
+      }
+      dbase = (dbase + rows) & 3;
+    }
+#undef WSW_BARRIER
+  }
+
+  // ---- sum the 8 waves: red[wave][cp][nb][row m 16][column 16]
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[(((wave * 2 + cp) * 2 + nb) * 16 + kg * 4 + r) * 16 + q] = acc[cp][nb][r];
+  __syncthreads();
+  for (int item = tid; item < 4 * 256; item += WS_NTH) {
+    const int j = item & 15, m16 = (item >> 4) & 15, blk = item >> 8;
+    const int nb = blk & 1, cp = blk >> 1;
+    const int jc = nb * 16 + j, ab = jc >> 1, co = jc & 1;
+    const int c = 2 * cp + (m16 >> 3), ci = m16 & 7;
+    if (c < 3 && jc < 18) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WS_WAVES; ++w) t += red[(((w * 2 + cp) * 2 + nb) * 16 + m16) * 16 + j];
+      out[((size_t)(ab * 3 + c) * 8 + ci) * 2 + co] = t;
+    }
+  }
+}
+
+// column shape and rows per unit of a launch (the model of conv_tail_sweep's sweep_shape():
+// a plane costs ~1 000 clk + its bytes through the CU at 12.5 B / clk)
+bool wsweep_shape(const s3_ctx* ctx, const ConvGeom& g, WSweepShape& best) {
+  static const int s1c[] = {4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48};
+  static const int s2c[] = {32, 64, 96, 128, 160, 192};
+  static const int sgc[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128};
+  const long long forced = s3_opt_int(S3O_TAIL_SWEEP_SHAPE, 0);
+  const int f1 = (int)(forced / 1000000), f2 = (int)(forced / 1000 % 1000), fseg = (int)(forced % 1000);
+  double best_cost = -1.0;
+  for (int S1 : s1c) {
+    if (forced ? S1 != f1 : (S1 > g.O[1] && S1 != s1c[0])) continue;
+    for (int S2 : s2c) {
+      if (forced ? S2 != f2 : (S2 > g.O[2] + 31 && S2 != s2c[0])) continue;
+      if (S1 * S2 > 2 * WS_NTH * WS_DPT) continue;
+      WSweepShape s;
+      s.S1 = S1; s.S2 = S2; s.NCH = S2 / 32; s.P2 = S2 + 2;
+      s.plane_cells = (S1 + 2) * s.P2;
+      s.npieces = (s.plane_cells + 2 + 63) / 64;      // (+ 2: the transpose read of the junk tap c = 3)
+      if (s.npieces > WS_MAXP * WS_WAVES) continue;
+      s.plane_bytes = s.npieces * 1024;
+      s.ds_bytes = S1 * S2 * 2 * 2;
+      s.ndpieces = (S1 * S2 / 2 + 63) / 64;
+      s.slot_bytes = s.plane_bytes + s.ndpieces * 1024;
+      if (WS_NSLOT * s.slot_bytes + WS_NDS * s.ds_bytes + 64 > WS_LDS) continue;
+      s.tiles1 = (g.O[1] + S1 - 1) / S1;
+      s.tiles2 = (g.O[2] + S2 - 1) / S2;
+      const double plane_clk = 1000.0 + (s.plane_bytes + S1 * S2 * 8.0) / 12.5;
+      for (int seg : sgc) {
+        if (forced && seg != fseg) continue;
+        int sg = seg;
+        if (sg > g.O[0]) sg = g.O[0];
+        s.seg = sg;
+        s.segs0 = (g.O[0] + sg - 1) / sg;
+        const long long units = (long long)g.N * s.segs0 * s.tiles1 * s.tiles2;
+        if (units > 0x7fffffffLL) continue;
+        s.n_units = (int)units;
+        const long long rounds = (units + ctx->num_cu - 1) / ctx->num_cu;
+        const double cost = (double)rounds * (sg + 2) * plane_clk + 2.0 * plane_clk;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
+        if (sg == g.O[0]) break;
+      }
+    }
+  }
+  return best_cost >= 0;
+}
+
+bool wgrad_tail_sweep_ok(const ConvGeom& g, int x_bf16) {
+  if (!x_bf16 || g.Cout != 2 || g.pad_mode != S3_PAD_REFLECT || s3_opt_on(S3O_NO_WGRAD_TAIL_SWEEP)) return false;
+  if ((g.O[2] & 1) || g.O[0] < 4 || g.O[2] < 32) return false;
+  return (long long)g.D[1] * g.D[2] * 8 <= 0x7fffffffLL;
+}
+
 }  // namespace
 
 bool conv_wgrad_tail_supported(const ConvGeom& g, int precision) {
@@ -751,6 +1110,30 @@ int launch_conv_wgrad_tail(s3_ctx* ctx, const ConvGeom& g, const float* x, const
   const int grid = tail_grid(ctx, g, &t0, &t1, &t2, &n_tiles);
   if (partial_bytes < conv_wgrad_tail_partial_bytes(ctx, g))
     S3_FAIL(ctx, S3_EINVAL, "wgrad_tail: partial buffer too small");
+  WSweepShape wsh;
+  if (wgrad_tail_sweep_ok(g, x_bf16) && wsweep_shape(ctx, g, wsh)) {
+    static S3DeviceOnce sweep_attr;
+    if (!sweep_attr.done(ctx->device)) {
+      std::lock_guard<std::mutex> lk(sweep_attr.m);
+      S3_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tail_sweep_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
+      sweep_attr.mark(ctx->device);
+    }
+    // (at most num_cu partials: the buffer is sized for 2 num_cu)
+    int sgrid = ctx->num_cu;
+    if (sgrid > wsh.n_units) sgrid = wsh.n_units;
+    if (sgrid > grid) sgrid = grid;
+    int lds = WS_NSLOT * wsh.slot_bytes + WS_NDS * wsh.ds_bytes + 64;
+    if (lds < WS_RED) lds = WS_RED;
+    hipLaunchKernelGGL(conv_wgrad_tail_sweep_kernel, dim3(sgrid), dim3(WS_NTH), lds, ctx->stream,
+                       (const unsigned short*)x, dy, partial, g, wsh);
+    S3_HIP(ctx, hipGetLastError());
+    const int wsz = 27 * 8 * g.Cout;
+    hipLaunchKernelGGL(wgrad_c2_partial_reduce, dim3((wsz + 15) / 16), dim3(256), 0, ctx->stream,
+                       partial, sgrid, wsz, dw, accumulate);
+    S3_HIP(ctx, hipGetLastError());
+    return S3_OK;
+  }
   static S3DeviceOnce attr_set;
   if (!attr_set.done(ctx->device)) {
     std::lock_guard<std::mutex> lk_attr_set(attr_set.m);

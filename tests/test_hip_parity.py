@@ -860,6 +860,21 @@ def test_tail_conv_wgrad_halo_transpose_read_kernel(monkeypatch):
             return np.array(net.grads[2])
         switch('NO_WGRAD_TAIL', None)
         a = grads()
+        # round 6: the plane-sweep form (C_out = 2, bf16 cells) against the tile form: the
+        # same bf16 operands, another summation order
+        switch('NO_WGRAD_TAIL_SWEEP', 1)
+        a_tile = grads()
+        switch('NO_WGRAD_TAIL_SWEEP', None)
+        if n_out == 2:
+            assert np.abs(a - a_tile).max() > 0
+            assert np.abs(a - a_tile).max() < 2e-5 * np.abs(a_tile).max()
+            for s1, s2, seg in ((4, 32, 4), (8, 64, 6), (16, 96, 10), (12, 128, 128), (24, 32, 8)):
+                switch('TAIL_SWEEP_SHAPE', s1 * 1000000 + s2 * 1000 + seg)
+                a_f = grads()
+                switch('TAIL_SWEEP_SHAPE', None)
+                assert np.abs(a_f - a_tile).max() < 2e-5 * np.abs(a_tile).max(), (s1, s2, seg)
+        else:
+            np.testing.assert_array_equal(a, a_tile)
         switch('NO_WGRAD_TAIL', 1)
         b = grads()
         assert a.shape == (3, 3, 3, 8, n_out)
