@@ -2,8 +2,9 @@
 // stride 1, reflect padding, bf16 in, fp32 out): the same banded MFMAs per
 // output position, in the same order, as conv_tail_mfma_kernel<true> and
 // conv_tail_slide_kernel (kernels_conv_tail_mfma.hip) — identical output bits
-// — with the data movement rearranged around what bounds the op, the ~9 B per
-// clock one CU can move (loads + stores; profiles/r06/README.md):
+// — with the data movement rearranged around what bounds the op, the ~10 B per
+// clock one CU can move (loads + stores; profiles/r06/tail_sweep.md: 9.2 B / clk
+// in the sliding-window kernel, 10.7 here):
 //
 //   * the slide kernel keeps the three input planes of an output row in LDS
 //     (3 + 2 in flight = 5 slots of 19 KB), which limits its column to 16 x 64
