@@ -14,6 +14,9 @@ bash tools/pmc_bench.sh "$OUT/pmc_fwd2d" --mode fwd2d --no-executor > "$OUT/pmc_
   echo "480 images"; ORACLE=0 python tools/dbg/x3_2d_probe.py 480 | grep "^ws_x3:\|^tile" ) > "$OUT/x3_2d.log" 2>&1
 ( for a in "48 150 150 2" "192 150 150 2" "12 750 750 2" "12 750 750 6" "4 150 150 6"; do python tools/dbg/out_conv_probe.py $a | grep -v amdgpu; done ) > "$OUT/out_conv.log" 2>&1
 bash tools/pmc_cmd.sh "$OUT/pmc_out_conv" "conv2d_out_kernel" -- python tools/dbg/out_conv_probe.py 48 150 150 2 > "$OUT/pmc_out_conv.log" 2>&1
+# the plane-sweep tail conv and its weight gradient
+( python tools/dbg/tail_probe.py 32; python tools/dbg/tail_probe.py 8 ) 2>&1 | grep -v amdgpu > "$OUT/tail_probe.log"
+bash tools/pmc_cmd.sh "$OUT/pmc_tail" "conv_tail_sweep" -- python tools/dbg/tail_probe.py 32 > "$OUT/pmc_tail.log" 2>&1
 ORACLE=0 bash tools/pmc_cmd.sh "$OUT/pmc_x3" "conv2d_ws_x3" -- python tools/dbg/x3_2d_probe.py > "$OUT/pmc_x3.log" 2>&1
 # executor timeline
 ( cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$ROOTD/$OUT/tl" -- python $ROOTD/tools/dbg/fwp2d_exec_probe.py 4 2 > "$ROOTD/$OUT/tl.log" 2>&1;
@@ -27,6 +30,7 @@ bash tools/dbg/kstats.sh 30 -- python $ROOTD/bench.py --mode train --config c4 -
 bash tools/dbg/kstats.sh 24 -- python $ROOTD/bench.py --mode train --config c4toy --batch 4 --steps 100 >> "$OUT/train_c4_kernel_stats.txt" 2>&1
 bash tools/dbg/kstats.sh 30 -- python $ROOTD/bench.py --mode train --config c5 --steps 60 > "$OUT/train_c5_kernel_stats.txt" 2>&1
 bash tools/dbg/kstats.sh 24 -- python $ROOTD/bench.py --mode train --config c5small --steps 100 >> "$OUT/train_c5_kernel_stats.txt" 2>&1
+bash tools/pmc_cmd.sh "$OUT/pmc_wgrad_tail" "conv_wgrad_tail_sweep" -- python tools/train_probe.py $C2 --precision bf16 --iters 4 > "$OUT/pmc_wgrad_tail.log" 2>&1
 python tools/config_census.py --out "$OUT/config_census.md" > "$OUT/census.log" 2>&1
 python tools/dbg/c3_ops.py 16 > "$OUT/c3_ops.txt" 2>&1
 find "$OUT" -name "*.csv" -size +2M -delete
