@@ -26,12 +26,6 @@
 //     tap they drop the halo into LDS.  Their vmcnt waits are counted
 //     (never 0 inside the loop): slab t+1 has two taps to arrive.
 //
-// Round 6: the halo is a RING of six planes along s0 — halo plane L of a tile at
-// origin o0 sits in LDS plane (o0 + L) mod 6 — so the two planes a tile shares with
-// the tile four rows below it in the same column (the workgroup's next item, three
-// times in four on a 16-row column) are not fetched again: 92 instead of 138 KB of
-// halo per tile through the CU's memory path.
-//
 // One s_barrier per tap orders slab hand-over both ways (27 = 9 x 3: the ring
 // slot tap % 3 is a compile-time immediate and the tap pipeline is continuous
 // across tiles).  LDS: halo 1080 cells x 128 B | 3 slabs x 8 KB | 64 biases
@@ -222,12 +216,6 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
   // one launch per tile; wimg / bias already point at the tile's image)
   // gs1 (forward launches, !DG): first s1 column of this launch's strip
   using PG = PGeo<TW>;
-  // (A/B switch of the halo ring: a build with -DS3_NO_HALO_RING — the kernel has no scalar to spare)
-#ifdef S3_NO_HALO_RING
-  constexpr bool NO_RING = true;
-#else
-  constexpr bool NO_RING = false;
-#endif
   constexpr int TS1 = PG::TS1, H1 = PG::H1, HP = PG::HP, SLAB_OFF = PG::SLAB_OFF, BIAS_OFF = PG::BIAS_OFF;
   constexpr int MFW = PG::MFW, ROWC = PG::ROWC, JR = PG::JR, NLATE = PG::NLATE;
   (void)HP;
@@ -384,19 +372,13 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     // in-loop loads are hand-ordered (ld16_async): every tap's counted wait
     // retires all but the youngest <= 6 vector-memory ops, so a chunk issued
     // >= 2 taps before its halo_put has landed without a wait of its own
-    // next tile's plane for ring slot k: (k + (o0 - o0') mod 6) mod 6, as a scalar
-    auto ring_src = [&](unsigned ring, int k) __attribute__((always_inline)) {
-      const int v = k + (int)((__builtin_amdgcn_readfirstlane((int)ring) >> 4) & 7);
-      return v >= 6 ? v - 6 : v;
-    };
     auto halo_load = [&](int r, int j) __attribute__((always_inline)) {
       const unsigned row = (unsigned)__builtin_amdgcn_readlane(htab, r);
       // (DG: bits 30.. of the sum count the flagged axes; the rest is legal)
       const unsigned eo = DG ? ((row + in_off[j]) & 0x3FFFFFFFu) : row + in_off[j];
       return ld16_async(hx, eo * 2);
     };
-    // r: halo plane of the tile being fetched (its row of htab); pr: the LDS plane it lands in
-    auto halo_put = [&](int r, unsigned pr, int j, const u32x4& v) __attribute__((always_inline)) {
+    auto halo_put = [&](int r, int j, const u32x4& v) __attribute__((always_inline)) {
       if (pcell + 32 * j < ROWC) {
         u32x4 w = v;
         if (DG) {
@@ -417,7 +399,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
           if (cell > ROWC - 1) cell = ROWC - 1;
           lo = (unsigned)(cell * 128 + ((pch ^ ((cell % H2) & 7)) << 4));
         }
-        *reinterpret_cast<u32x4*>(smem + pr * (ROWC * 128) + lo) = w;
+        *reinterpret_cast<u32x4*>(smem + r * (ROWC * 128) + lo) = w;
       }
     };
 
@@ -435,96 +417,51 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
         for (int j = 0; j < JR; ++j) hrow[j] = halo_load(r, j);
         wait_vm<0>();
 #pragma unroll
-        for (int j = 0; j < JR; ++j) {
-          const int pr_ = 2 * ((h_cur % tiles0) % 3) + r;
-          halo_put(r, (unsigned)(pr_ >= 6 ? pr_ - 6 : pr_), j, hrow[j]);
-        }
+        for (int j = 0; j < JR; ++j) halo_put(r, j, hrow[j]);
       }
     }
     wait_vm<0>();
     WAIT_LGKM0();
     WG_BARRIER();
 
-    // Round 6: the halo is a RING of six planes along s0: halo plane L of a tile at origin o0
-    // (input row o0 + L of the padded column) sits in LDS plane (o0 + L) mod 6.  When the
-    // next item is the tile below this one in the same column (o0 + 4) its planes 0 / 1 ARE
-    // this tile's planes 4 / 5: they stay, and only four planes are fetched — its planes
-    // 2 / 3 through the early buffer into the slots of this tile's planes 0 / 1 (dead after
-    // taps 8 / 17), planes 4 / 5 through the late registers into the slots of planes 2 / 3.
-    // Otherwise (column change) all six: the two that belong into the slots of this tile's
-    // planes 0 / 1 early, the other four late.  138 -> 92 KB of halo per tile on three
-    // tiles in four of a 16-row column.
-    // ring position of an item from its half-row index: (2 hs0) mod 6
-#define RING_OF(hs) (2 * ((hs) - 3 * (int)(((unsigned)(hs) * 21846u) >> 16)))
     for (int h = h_cur; h < h_end;) {
       // (h % nh0 per item rather than a carried scalar: the producer waves
       // are at the SGPR limit)
       int nr_, hs0_ = h % tiles0;
-      const int c6_ = RING_OF(hs0_);
-      const int hs_cur_ = hs0_;
       h = item_at(h, hs0_, nr_);
       // (re-evaluated at each use instead of one more live scalar)
 #define has_next (h < h_end)
-      // the next item continues this column four rows down
-      const bool slide = !NO_RING && nr_ == 4 && hs0_ == hs_cur_ + 2 && has_next;
-      // ring state in ONE vector register (uniform; opaque to the scalar allocator):
-      // bits 0-2: ring plane of this tile's plane 0; bits 4-6: (o0 - o0') mod 6, the next
-      // tile's plane that belongs into that slot
-      unsigned ring;
-      {
-        const int nx_ = has_next ? RING_OF(hs0_) : c6_;
-        const int d_ = c6_ - nx_ + (c6_ < nx_ ? 6 : 0);
-        asm volatile("v_mov_b32 %0, %1" : "=v"(ring) : "s"(c6_ | (d_ << 4)));
-      }
       // without a next item the prefetch re-reads this rank's last tile (same
       // op count)
       HALO_TABLE(h < h_end - 1 ? h : h_end - 1);
-// LDS plane of slot k of the ring counted from this tile's plane 0 (per-lane arithmetic)
-#define PLANE_AT(k) ((((ring & 7u) + (k)) >= 6u) ? ((ring & 7u) + (k) - 6u) : ((ring & 7u) + (k)))
-// halo plane of the NEXT tile that belongs into that slot (scalar, for the htab lookup)
-#define SRC_AT(k) ring_src(ring, (k))
-// SL: compile-time mode (ring slide: source planes 2 .. 5 into slots 0 .. 3; else six planes)
-#define TAP_LOOP(SL)                                                                            \
-      {                                                                                         \
-        constexpr int NL = ((SL) ? 2 : 4) * JR;                                                 \
-        _Pragma("unroll") for (int tap = 0; tap < 27; ++tap) {                                  \
-          /* planes 0 / 1 of the current halo were last read in taps 8 / 17 */                  \
-          if ((tap == 9 || tap == 18) && has_next) {                                            \
-            const int k_ = tap == 9 ? 0 : 1;                                                    \
-            const int src_ = (SL) ? 2 + k_ : SRC_AT(k_);                                        \
-            _Pragma("unroll") for (int j = 0; j < JR; ++j) halo_put(src_, PLANE_AT(k_), j, hrow[j]); \
-          }                                                                                     \
-          /* slot (tap+2)%3 was read during tap-1: free since the last barrier */               \
-          dma_slab((tap + 2) % 27, (tap + 2) % 3);                                              \
-          if (tap < JR) hrow[tap % JR] = halo_load((SL) ? 2 : SRC_AT(0), tap % JR);             \
-          if (tap >= 9 && tap < 9 + JR) hrow[(tap - 9) % JR] = halo_load((SL) ? 3 : SRC_AT(1), (tap - 9) % JR); \
-          if (tap < NL)                                                                         \
-            hlate[tap % NLATE] = halo_load((SL) ? 4 + (tap % NLATE) / JR : SRC_AT(2 + (tap % NLATE) / JR), \
-                                           (tap % NLATE) % JR);                                 \
-          /* slab tap+1 (DMA issued one tap ago) must have landed before the consumers pass */  \
-          /* this barrier.  Younger vector-memory ops: the halo chunks of the previous tap */    \
-          /* (issued after its DMA), this tap's 2 DMA pieces and its chunks. */                 \
-          wait_vm_n(2 + PG::early_k(tap) + (tap >= 0 && tap < NL ? 1 : 0) +                     \
-                    PG::early_k(tap - 1) + (tap - 1 >= 0 && tap - 1 < NL ? 1 : 0));             \
-          WG_BARRIER();                                                                         \
-        }                                                                                       \
-        /* every consumer is past its last halo read: the late planes may land */              \
-        if (has_next) {                                                                         \
-          _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                      \
-            const int src_ = (SL) ? 4 + u / JR : SRC_AT(2 + u / JR);                            \
-            halo_put(src_, PLANE_AT(2 + u / JR), u % JR, hlate[u]);                             \
-          }                                                                                     \
-        }                                                                                       \
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        // rows 0 / 1 of the current halo were last read in taps 8 / 17
+        if ((tap == 9 || tap == 18) && has_next) {
+#pragma unroll
+          for (int j = 0; j < JR; ++j) halo_put(tap == 9 ? 0 : 1, j, hrow[j]);
+        }
+        // slot (tap+2)%3 was read during tap-1: free since the last barrier
+        dma_slab((tap + 2) % 27, (tap + 2) % 3);
+        if (tap < JR) hrow[tap % JR] = halo_load(0, tap % JR);
+        if (tap >= 9 && tap < 9 + JR) hrow[(tap - 9) % JR] = halo_load(1, (tap - 9) % JR);
+        if (tap < NLATE) hlate[tap % NLATE] = halo_load(2 + (tap % NLATE) / JR, (tap % NLATE) % JR);
+        // slab tap+1 (DMA issued one tap ago) must have landed before the
+        // consumers pass this barrier.  Younger vector-memory ops: the halo
+        // chunks of the previous tap (issued after its DMA), this tap's 2 DMA
+        // pieces and its chunks.
+        wait_vm_n(2 + PG::halo_k(tap) + PG::halo_k(tap - 1));
+        WG_BARRIER();
       }
-      if (slide) TAP_LOOP(true) else TAP_LOOP(false)
-#undef TAP_LOOP
-#undef SRC_AT
-#undef PLANE_AT
+      // every consumer is past its last halo read: rows 2..5 may land
+      if (has_next) {
+#pragma unroll
+        for (int u = 0; u < NLATE; ++u) halo_put(2 + u / JR, u % JR, hlate[u]);
+      }
       WAIT_LGKM0();
       WG_BARRIER();
 #undef has_next
     }
-#undef RING_OF
 #undef HALO_TABLE
     return;
   }
@@ -532,8 +469,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
   // ===================================================== consumer waves
   const int frow = lane & 15, kq = lane >> 4;
   const int mf0 = wave * MFW;
-  // (the s0 plane of a fragment is a slot of the halo ring: added per tile, below)
-  const int row0 = mf0 % TS1;
+  const int row0 = (mf0 / TS1) * H1 + (mf0 % TS1);
   unsigned a_addr[3][2], b_addr[4][2];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -578,18 +514,6 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
       int hs0 = org0 >> 1;
       h = item_at(h, hs0, nr);
     }
-    // halo plane L of this tile (input row org0 + L of the padded column) sits in LDS plane
-    // (org0 + L) mod 6 — the producers' ring — so fragment row my_row reads, for tap row ta,
-    // plane (org0 + my_row + ta) mod 6: recomputed from org0 where it is used (no scalar of
-    // its own: the kernel is at its SGPR limit)
-    // one scalar walks the ring with the tap rows (opaque: kept out of the fragment addresses)
-    constexpr unsigned PLANE_B = (unsigned)(H1 * H2 * 128);
-    unsigned ta_off;
-    {
-      const unsigned v = (unsigned)(org0 + my_row);
-      ta_off = (v - 6u * ((v * 10923u) >> 16)) * PLANE_B;
-      asm volatile("" : "+s"(ta_off));
-    }
     if (my_row >= nr) {
       // half-tile item: the second row pair idles, keeping the barrier count
 #pragma unroll 1
@@ -611,12 +535,10 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
     bf16x8 apre[MFW];
 #pragma unroll
     for (int m = 0; m < MFW; ++m)
-      apre[m] = *reinterpret_cast<const bf16x8*>(smem + a_addr[0][0] + ta_off + (m * H2) * 128);
+      apre[m] = *reinterpret_cast<const bf16x8*>(smem + a_addr[0][0] + (m * H2) * 128);
 #pragma unroll 1
     for (int ta = 0; ta < 3; ++ta) {
-      // the plane of the next tap row
-      unsigned nx_off = ta_off + PLANE_B;
-      nx_off = nx_off >= 6u * PLANE_B ? nx_off - 6u * PLANE_B : nx_off;
+      const unsigned ta_off = (unsigned)(ta * H1 * H2 * 128);
 #pragma unroll
       for (int tb = 0; tb < 3; ++tb) {
 #pragma unroll
@@ -648,7 +570,7 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
           {
             const int ntc = tc < 2 ? tc + 1 : 0;
             const int ntb = tc < 2 ? tb : (tb < 2 ? tb + 1 : 0);
-            const unsigned nta_off = (tc == 2 && tb == 2) ? nx_off : ta_off;
+            const unsigned nta_off = (tc == 2 && tb == 2) ? ta_off + H1 * H2 * 128 : ta_off;
             if (!(tc == 2 && tb == 2) || ta < 2) {
 #pragma unroll
               for (int m = 0; m < MFW; ++m)
@@ -659,8 +581,6 @@ __global__ __launch_bounds__(NTHR) void conv3_mfma_persist_kernel(
           WG_BARRIER();
         }
       }
-      ta_off = nx_off;
-      asm volatile("" : "+s"(ta_off));
     }
 
     if constexpr (DG) {
