@@ -105,6 +105,7 @@
   X(NO_WGRAD_TAIL_SWEEP) \
   X(NO_WGRAD_WS) \
   X(PERSIST_DGRAD_MIN_TILES) \
+  X(PERSIST_MIN_TILES) \
   X(POISON_ALLOC) \
   X(TAIL_SWEEP_SHAPE) \
   X(TRACE) \

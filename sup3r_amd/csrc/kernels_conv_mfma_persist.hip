@@ -809,7 +809,11 @@ bool conv_mfma_persist_supported(const s3_ctx* ctx, const ConvGeom& g, ConvIO io
   // (counted in whole 4-row tiles, as before the half-row work list)
   const int64_t tiles = (int64_t)g.N * ((g.O[0] + TS0 - 1) / TS0) *
                         ((g.O[1] + TS1 - 1) / TS1) * ((g.O[2] + TS2 - 1) / TS2);
-  return tiles >= ctx->num_cu;
+  // Below ~ 7/16 of a tile per CU the one-tile-per-workgroup kernel with its 64-position tiles
+  // fills the chip better (48 / 96 tiles: 20 - 27 us against 26 - 29); from there on a whole
+  // 512-position tile per workgroup wins (144 / 192 tiles: 29 - 32 us against 37 - 40: the
+  // trunk of gen_3x_4x_2f at lr (4, 16, 16, 24), profiles/r06/README.md).  Was: one per CU.
+  return tiles >= s3_opt_int(S3O_PERSIST_MIN_TILES, ctx->num_cu * 7 / 16);
 }
 
 int launch_pack_jobs(s3_ctx* ctx, const S3PackJob* jobs_dev, int n_jobs, int max_ct) {
