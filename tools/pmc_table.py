@@ -27,6 +27,9 @@ ALG = {
     'conv_wgrad_bf16_gen_kernel<2, 2, true, true, false>': ('disc 32->32 s2 weight gradient', P1 * 64 + P2 * 128, 0),
     'conv_tail_slide_kernel': ('generator 8->2 tail forward', P0 * 16, P0 * 8),
     'conv_wgrad_tail_kernel<true>': ('generator 8->2 weight gradient', P0 * 16 + P0 * 8, 0),
+    # round 6: the plane-sweep forms
+    'conv_tail_sweep_kernel<3>': ('generator 8->2 tail forward (plane sweep)', P0 * 16, P0 * 8),
+    'conv_wgrad_tail_sweep_kernel': ('generator 8->2 weight gradient (plane sweep)', P0 * 16 + P0 * 8, 0),
 }
 
 

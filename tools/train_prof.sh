@@ -15,7 +15,7 @@ def short(k):
     k = re.sub(r'\(anonymous namespace\)::', '', k)
     return k.split('(')[0].replace('void ', '')[:64]
 with open(out + '/kernel_stats.txt', 'w') as fo:
-    for r in rows[:40]:
+    for r in rows[:70]:
         fo.write('%-66s calls %6s  total %10.3f ms  avg %9.1f us  %5s %%\n' % (
             short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
             float(r['AverageNs']) / 1e3, r['Percentage']))
