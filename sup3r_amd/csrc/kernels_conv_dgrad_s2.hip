@@ -164,6 +164,9 @@ __global__ __launch_bounds__(SNT) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // (with the sign-byte mask only: the bf16-mask variant has no registers left)
   constexpr bool PAIR = O16 && MB;
   uint4 keep[PAIR ? 8 : 1];
+  // all 16 position pairs of the tile's rows exist (then i2 < D2 for every lane and the
+  // pair stores can be exchanged across the wave: see the odd class below)
+  const bool lin_t = PAIR && 2 * (u2 + 15) + 1 < g.D[2];
   // wave w owns the u rows (r0 = w, r1 = 0..7)
 #pragma unroll 1
   for (int cls = 0; cls < 8; ++cls) {
@@ -242,9 +245,35 @@ __global__ __launch_bounds__(SNT) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           // (the last even position of an odd extent has no partner)
           if (i2 + 1 < g.D[2]) keep[m] = pk;
           else *reinterpret_cast<uint4*>(dx16 + e) = pk;
-        } else {
+        } else if (!lin_t) {
           *reinterpret_cast<uint4*>(dx16 + e - 32) = keep[m];
           *reinterpret_cast<uint4*>(dx16 + e) = pk;
+        } else {
+          // Round 6: the 16 position pairs of this row are 2 KB of consecutive bytes
+          // ([even 64 B][odd 64 B] x 16).  Stored from where the values sit, an instruction
+          // wrote sixteen 64-B pieces at a 128-B pitch; exchanged across the wave first
+          // (lane L of instruction A takes 16-B piece L of the first KB: pair L >> 3, half
+          // (L >> 2) & 1, chunk L & 3, i.e. from lane (L & 3) 16 + (L >> 3); instruction B
+          // the pairs 8 .. 15), each instruction writes ONE KB in lane order: 385 -> 30x us
+          // at C2 batch 8 (an ablation with made-up linear addresses had shown 302).
+          const int srcA = (((lane & 3) << 4) + (lane >> 3)) << 2, srcB = srcA + (8 << 2);
+          const bool odd_half = (lane >> 2) & 1;
+          const unsigned ke[4] = {keep[m].x, keep[m].y, keep[m].z, keep[m].w};
+          const unsigned po[4] = {pk.x, pk.y, pk.z, pk.w};
+          unsigned oa[4], ob[4];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const unsigned ea = (unsigned)__builtin_amdgcn_ds_bpermute(srcA, (int)ke[q4]);
+            const unsigned da = (unsigned)__builtin_amdgcn_ds_bpermute(srcA, (int)po[q4]);
+            const unsigned eb = (unsigned)__builtin_amdgcn_ds_bpermute(srcB, (int)ke[q4]);
+            const unsigned db = (unsigned)__builtin_amdgcn_ds_bpermute(srcB, (int)po[q4]);
+            oa[q4] = odd_half ? da : ea;
+            ob[q4] = odd_half ? db : eb;
+          }
+          // (every lane of the wave is here: the row test above is wave-uniform in this mode)
+          const size_t e0 = ((((size_t)n * g.D[0] + i0) * g.D[1] + i1) * g.D[2] + 2 * u2) * 32 + lane * 8;
+          *reinterpret_cast<uint4*>(dx16 + e0) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+          *reinterpret_cast<uint4*>(dx16 + e0 + 512) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
         }
       }
       if (mpre) {
