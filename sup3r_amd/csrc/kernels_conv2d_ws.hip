@@ -563,6 +563,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
     off_h[h] = (unsigned)(blk / g.b) * rsd + (unsigned)((blk % g.b) * g.cpo + cq);
   }
 
+  const bool lin_cells = g.b == 1 && g.cpo == 64 && g.Cout - ct * 64 >= 64;
   f32x4 acc[4][4];
   if (grp == 1) PP_BARRIER();      // half a period behind group 0
 #pragma unroll 1
@@ -578,6 +579,15 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
     const bool col_ok = c < Wo;
     const int cc = c > Wo - 1 ? Wo - 1 : c;
     const unsigned long long tbase = (unsigned long long)im * IS + (unsigned long long)((unsigned)cc * CS);
+    // (MFMA_DBG bit 128: the row's stores exchanged across the wave, one KB of consecutive bytes per
+    // instruction — what took conv_dgrad_s2_kernel from 384 to 319 us is 4 % SLOWER here, 42 600
+    // against 44 600 samples/s at the production chunk: this kernel's stores are not what its M phase
+    // waits on.  The path stays because with it in the kernel the register allocator puts the position
+    // fragments of the tap loop (MFMA operand B) at v[4k] where the filter fragments (A) and most
+    // accumulators (C) sit at v[4k + 2]: without it 262 of the 288 MFMAs of a T phase read all three
+    // operands from registers of the same residue mod 4 and the kernel runs 31.3 instead of 29.1 us per
+    // conv — 42 350 against 44 600 samples/s in one call.  tools/dbg/mfma_banks.py prints that histogram.)
+    const bool lin_st = lin_cells && c0 + 16 <= Wo && (g.dbg & 128);
 
     // =========================================================== T phase
     {
@@ -718,6 +728,7 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
       } else if (!(g.dbg & 16))
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
+        uint4 o_lo = make_uint4(0u, 0u, 0u, 0u);
         const int r = r0 + w_row + m;
         const bool row_ok = col_ok && r < Ho && !(g.dbg & 4);
         const int rc = r > Ho - 1 ? Ho - 1 : r;
@@ -739,7 +750,31 @@ __global__ __launch_bounds__(W_NT) void conv2d_ws_pp_kernel(
           }
           uint4 o;
           o.x = ws_pk(v[0], v[1]); o.y = ws_pk(v[2], v[3]); o.z = ws_pk(v[4], v[5]); o.w = ws_pk(v[6], v[7]);
-          if (row_ok && ch_ok[h]) *reinterpret_cast<uint4*>(y + dst) = o;
+          if (!lin_st) {
+            if (row_ok && ch_ok[h]) *reinterpret_cast<uint4*>(y + dst) = o;
+          } else if (h == 0) {
+            o_lo = o;
+          } else {
+            const int srcA = (((lane & 3) << 4) + (lane >> 3)) << 2, srcB = srcA + (8 << 2);
+            const bool hi_half = (lane >> 2) & 1;
+            const unsigned lo4[4] = {o_lo.x, o_lo.y, o_lo.z, o_lo.w}, hi4[4] = {o.x, o.y, o.z, o.w};
+            unsigned oa[4], ob[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const unsigned la = (unsigned)__builtin_amdgcn_ds_bpermute(srcA, (int)lo4[q4]);
+              const unsigned ha = (unsigned)__builtin_amdgcn_ds_bpermute(srcA, (int)hi4[q4]);
+              const unsigned lb = (unsigned)__builtin_amdgcn_ds_bpermute(srcB, (int)lo4[q4]);
+              const unsigned hb = (unsigned)__builtin_amdgcn_ds_bpermute(srcB, (int)hi4[q4]);
+              oa[q4] = hi_half ? ha : la;
+              ob[q4] = hi_half ? hb : lb;
+            }
+            if (r < Ho && !(g.dbg & 4)) {
+              const unsigned long long d0 = (unsigned long long)im * IS + (unsigned long long)((unsigned)c0 * CS) +
+                                            (unsigned long long)(unsigned)rc * RS + (unsigned)(lane * 8);
+              *reinterpret_cast<uint4*>(y + d0) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+              *reinterpret_cast<uint4*>(y + d0 + 512) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+            }
+          }
         }
       }
       if (k + 2 < n_g && !(g.dbg & 1)) PP_FETCH(t0 + grp + 2 * (k + 2));
