@@ -12,8 +12,10 @@ out = tempfile.mktemp(suffix='.s')
 subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-S', '--cuda-device-only',
                 os.path.abspath(src), '-o', out], check=True, stderr=subprocess.DEVNULL, cwd=os.path.dirname(os.path.abspath(src)))
 s = open(out).read()
-f = s[s.index(key):]
-f = f[:f.index('s_endpgm')]
+# the function's text: from its label to its .Lfunc_end marker (an early exit has its own s_endpgm)
+m = re.search(r'^(' + re.escape(key) + r'[^\s:]*):', s, re.M)
+f = s[m.end():]
+f = f[:f.index('.Lfunc_end')]
 c = collections.Counter()
 n = 0
 for x in f.split('\n'):
