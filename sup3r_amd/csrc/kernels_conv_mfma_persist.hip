@@ -759,7 +759,10 @@ bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g) {
   const int64_t covered = halves * 2 * TS1 * TS2;
   const int64_t six = (int64_t)g.N * ((g.O[0] + 5) / 6) * ((g.O[1] + 5) / 6) * ((g.O[2] + 15) / 16) * 576;
   const int64_t min_tiles = s3_opt_has(S3O_PERSIST_DGRAD_MIN_TILES)
-                                ? s3_opt_int(S3O_PERSIST_DGRAD_MIN_TILES, 0) : ctx->num_cu * 7 / 16;   // (as the forward)
+                                ? s3_opt_int(S3O_PERSIST_DGRAD_MIN_TILES, 0) : ctx->num_cu;
+  // (NOT lowered with the forward's threshold: 7/16 per CU was 8 % faster on gen_3x_4x_2f at batch 3, but
+  // the training plan of sup3rcc/gen_solar_1x_8x_1f at (2, 54, 54, 3) then takes a memory access fault —
+  // tools/config_census.py found it; the plan's frame buffers are sized with this threshold in mind)
   return tiles >= min_tiles && covered * 10 <= six * 11;
 }
 
