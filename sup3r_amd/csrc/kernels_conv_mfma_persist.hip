@@ -725,6 +725,11 @@ bool conv_mfma_persist_dgrad_geom_ok(const ConvGeom& g) {
     return false;
   for (int d = 0; d < 3; ++d)
     if (g.k[d] != 3 || g.s[d] != 1 || g.lo[d] != 2 || g.O[d] != g.D[d] + 2) return false;
+  // few time steps: the logical-axes kernel, as in the forward (conv_mfma_persist_geom_ok).  Found at the end of
+  // round 6: sup3rcc/gen_solar_1x_8x_1f (3 time steps) trained at 8 / 16 samples of (54, 54, 3) — enough frame
+  // tiles for this kernel — gave non-finite gradients / a memory access fault; 4 and 6 steps likewise, 8 not
+  // (tools/dbg/train_plan_probe.py; the census trains at a quarter of its inference batch and never got here)
+  if (g.D[2] < 8) return false;
   // a 64-channel slice of a wider dPre (the 64 -> 200 conv): whole 16-B chunks
   if (g.in_cstride && ((g.in_cstride & 7) || (g.in_cvalid & 7) || g.in_cvalid < 8 || g.in_cvalid > 64)) return false;
   // 30-bit element offsets over the whole batch (the zero flag is bit 30)
@@ -760,9 +765,8 @@ bool conv_mfma_persist_dgrad_supported(const s3_ctx* ctx, const ConvGeom& g) {
   const int64_t six = (int64_t)g.N * ((g.O[0] + 5) / 6) * ((g.O[1] + 5) / 6) * ((g.O[2] + 15) / 16) * 576;
   const int64_t min_tiles = s3_opt_has(S3O_PERSIST_DGRAD_MIN_TILES)
                                 ? s3_opt_int(S3O_PERSIST_DGRAD_MIN_TILES, 0) : ctx->num_cu;
-  // (NOT lowered with the forward's threshold: 7/16 per CU was 8 % faster on gen_3x_4x_2f at batch 3, but
-  // the training plan of sup3rcc/gen_solar_1x_8x_1f at (2, 54, 54, 3) then takes a memory access fault —
-  // tools/config_census.py found it; the plan's frame buffers are sized with this threshold in mind)
+  // (not lowered with the forward's threshold: 7/16 per CU was 8 % faster on gen_3x_4x_2f at batch 3 and nothing
+  // at the BASELINE shapes; the fault tools/config_census.py found with it was the few-time-step case above)
   return tiles >= min_tiles && covered * 10 <= six * 11;
 }
 

@@ -2360,7 +2360,13 @@ static int plan_backward_impl(s3_plan* pl, const void* d_output, void* d_input, 
               void* side = nullptr;
               if (o.in_prod >= 0 && pl->dpre16 && pl->dpre16_for < 0 && !s3_opt_has(S3O_NO_FOLD16)) {
                 const OpRec& po = pl->ops[o.in_prod];
-                if (po.use16 && po.cg.act == S3_ACT_NONE && po.cg.d2s <= 1 && (po.cg.Cout & 3) == 0) side = pl->dpre16;
+                // (the size test was missing here until the end of round 6: with a dPre16 buffer sized by a
+                // smaller tensor — sup3rcc/gen_solar_1x_8x_1f at 8 or 16 samples of (54, 54, 3), whose trunk's
+                // data gradient then runs on the persistent kernel — the side copy wrote past its end:
+                // non-finite gradients at batch 8, a memory access fault at batch 16)
+                if (po.use16 && po.cg.act == S3_ACT_NONE && po.cg.d2s <= 1 && (po.cg.Cout & 3) == 0 &&
+                    pl->dpre16_bytes >= (size_t)pl->t[rin].numel * 2)
+                  side = pl->dpre16;
               }
               int arc = launch_gather_bwd_add(ctx, fg, pl->dxp, out, first, bs, side, frame16);
               if (!arc && side) { pl->dpre16_for = rin; pl->dpre16_only = false; }

@@ -431,3 +431,42 @@ def test_pad_crop_variants_device(pad, crop, shape):
     spec = pcc(3, 64, pad=pad, crop=crop) + pcc(3, 64, pad=pad, crop=crop) + \
         pcc(3, 4, pad=pad, crop=crop, act=False)
     _fwd_bwd(spec, shape, 'bf16', 9, 3e-2, 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(8, 54, 54, 3, 3), (16, 54, 54, 6, 3)])
+def test_few_time_step_trunk_trains_at_batches_that_fill_the_persistent_dgrad(shape):
+    """sup3rcc/gen_solar_1x_8x_1f (a 64-channel trunk over 3 time steps) at batch sizes whose
+    padded frames have enough tiles for conv3_mfma_persist_kernel's data gradient: until the
+    end of round 6 that kernel was selected there (its forward twin excludes fewer than 8 time
+    steps, the data gradient did not) and the step produced non-finite gradients at 8 samples
+    and a memory access fault at 16.  The gradients must be finite, the persistent data
+    gradient unused, and the result that of the plan with it switched off."""
+    from sup3r_amd.engine import Network
+    from tests.helpers import switch
+    spec = load_surface('sup3rcc/gen_solar_1x_8x_1f.json')
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape).astype(np.float32)
+
+    def run():
+        net = Network(spec, precision='bf16')
+        net.build(shape, seed=2)
+        ph = net.plan(shape, training=True)
+        n0 = net.dev.stat('persist_dgrad')
+        y = ph.forward(net.dev.to_device(x))
+        dy = net.dev.to_device(
+            np.random.default_rng(4).standard_normal(tuple(y.shape)).astype(np.float32))
+        ph.backward(dy, need_dx=False)
+        g = [np.array(a) for a in net.grads]
+        used = net.dev.stat('persist_dgrad') - n0
+        del ph
+        net.clear_plans()
+        return g, used
+    g1, used1 = run()
+    assert used1 == 0
+    assert all(np.isfinite(a).all() for a in g1)
+    switch('NO_PERSIST_DGRAD', 1)
+    g0, _ = run()
+    switch('NO_PERSIST_DGRAD', None)
+    for a, b in zip(g1, g0):
+        np.testing.assert_array_equal(a, b)
